@@ -1,0 +1,197 @@
+/*
+ * acx.h — C-ABI of the MI355X-native Aho-Corasick scan engine (libacx.so).
+ *
+ * This is the drop-in boundary for ONE hot path of WojciechMula/pyahocorasick:
+ * the per-byte goto/fail/output walk of AutomatonSearchIter / AutomatonSearchIterLong
+ * over a batch of haystacks.  The reference has no FFI of its own (everything is
+ * `static` inside one CPython translation unit), so each entry point below names the
+ * reference function(s) whose work it replaces (paths relative to the reference
+ * repository root).  INTEGRATION.md shows the binding a maintainer of the reference
+ * would add to src/Automaton.c to call these.
+ *
+ * Conventions
+ *   - plain C, plain pointers and sizes; no Python, no torch types.
+ *   - every function returns ACX_OK (0) or a negative acx_status; acx_last_error()
+ *     returns a thread-local human-readable message for the last failure.
+ *   - "host" pointers are ordinary process memory, "dev" pointers are HIP device
+ *     memory on the device that was current when the image was created.
+ *   - `stream` is a hipStream_t passed as void* (NULL = the default stream).
+ *   - integer widths follow the reference: end_index and value are C `int`
+ *     (Py_BuildValue("ii"), src/AutomatonSearchIter.c:180-184), i.e. int32.
+ */
+#ifndef ACX_H_INCLUDED
+#define ACX_H_INCLUDED
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ACX_ABI_VERSION 1
+
+typedef enum acx_status {
+    ACX_OK            =  0,
+    ACX_E_INVAL       = -1,  /* bad argument */
+    ACX_E_NOMEM       = -2,  /* host or device allocation failed (reference: MemoryError) */
+    ACX_E_STATE       = -3,  /* wrong automaton kind, e.g. scan before make_automaton
+                                (reference: AttributeError, src/Automaton.c:886-891) */
+    ACX_E_HIP         = -4,  /* a HIP runtime call failed */
+    ACX_E_UNSUPPORTED = -5,  /* automaton does not fit the device layout of this build */
+    ACX_E_FORMAT      = -6,  /* malformed flat image */
+    ACX_E_NODEVICE    = -7   /* no usable GPU: the product path never falls back to CPU */
+} acx_status;
+
+const char* acx_last_error(void);
+int         acx_abi_version(void);
+
+/* ------------------------------------------------------------------------------------
+ * 1. Host trie (CPU).  Stays on the CPU exactly as in the reference.
+ *    Replaces: trie_add_word (src/trie.c:14-63), automaton_add_word value rules
+ *    (src/Automaton.c:201-300), trie_find (src/trie.c:136-152),
+ *    automaton_make_automaton (src/Automaton.c:560-649).
+ *    Keys are byte strings (the reference's bytes build, KEY_STRING); a letter is one
+ *    byte (src/utils.c:191-205 widens each signed char to uint16 — injective on bytes).
+ * ---------------------------------------------------------------------------------- */
+typedef struct acx_trie acx_trie_t;
+
+enum { ACX_KIND_EMPTY = 0, ACX_KIND_TRIE = 1, ACX_KIND_AHOCORASICK = 2 };  /* src/Automaton.h:16-20 */
+
+int  acx_trie_new(acx_trie_t** out);
+void acx_trie_free(acx_trie_t* t);
+/* add (or overwrite the value of) a key.  *is_new = 1 if the key was not present.
+ * len == 0 is accepted and ignored (*is_new = 0), as src/Automaton.c:257 does. */
+int  acx_trie_add_word(acx_trie_t* t, const uint8_t* key, size_t len, int64_t value, int* is_new);
+/* exact lookup; *found = 1 and *value set when key is present (trie_find + eow test) */
+int  acx_trie_get(const acx_trie_t* t, const uint8_t* key, size_t len, int* found, int64_t* value);
+/* remove a key (trie_remove_word, src/trie.c:66-133); *found = 0 when absent */
+int  acx_trie_remove_word(acx_trie_t* t, const uint8_t* key, size_t len, int* found, int64_t* value);
+/* length of the longest prefix of `key` present as a path in the trie (trie_longest) */
+int  acx_trie_longest_prefix(const acx_trie_t* t, const uint8_t* key, size_t len, size_t* out_len);
+void acx_trie_clear(acx_trie_t* t);
+/* BFS failure links.  Returns ACX_OK and *changed = 1 when links were (re)built,
+ * *changed = 0 when kind != TRIE (reference returns False, src/Automaton.c:574-575). */
+int  acx_trie_make_automaton(acx_trie_t* t, int* changed);
+int      acx_trie_kind(const acx_trie_t* t);
+int64_t  acx_trie_num_keys(const acx_trie_t* t);
+int64_t  acx_trie_num_nodes(const acx_trie_t* t);
+int64_t  acx_trie_longest_word(const acx_trie_t* t);
+/* bumped by add_word(new key) / remove_word / clear / make_automaton
+ * (src/Automaton.c:284,342,364,413,640); device images are tagged with it. */
+int64_t  acx_trie_version(const acx_trie_t* t);
+
+/* ------------------------------------------------------------------------------------
+ * 2. Flat image.  One contiguous, relocatable little-endian blob (layout: acx_blob.h):
+ *    class map, dense fail-resolved transition table, fail vector, CSR output lists.
+ *    Built from a finalised trie on the CPU; it is what gets uploaded to HBM and what a
+ *    single RCCL broadcast replicates to the other GPUs of the node.
+ *    Replaces the pointer graph of src/trienode.h:19-42 as the thing the scan reads.
+ * ---------------------------------------------------------------------------------- */
+int  acx_flatten(const acx_trie_t* t, void** blob, size_t* nbytes);   /* malloc'd */
+void acx_blob_free(void* blob);
+int  acx_blob_validate(const void* blob, size_t nbytes);             /* host blob */
+
+typedef struct acx_image acx_image_t;
+/* copy a host blob to the current HIP device */
+int  acx_image_upload(const void* blob, size_t nbytes, acx_image_t** out);
+/* adopt a blob that is ALREADY in device memory (e.g. the receive buffer of the RCCL
+ * broadcast).  The image does not own `dev_blob`; the caller keeps it alive.
+ * `host_header` = the first ACX_BLOB_HEADER_BYTES of the blob in host memory. */
+int  acx_image_adopt(void* dev_blob, size_t nbytes, const void* host_header, acx_image_t** out);
+void acx_image_free(acx_image_t* img);
+int64_t acx_image_num_states(const acx_image_t* img);
+int64_t acx_image_num_classes(const acx_image_t* img);
+size_t  acx_image_nbytes(const acx_image_t* img);
+void*   acx_image_dev_ptr(const acx_image_t* img);
+
+/* ------------------------------------------------------------------------------------
+ * 3. Batch scan — THE hot path.
+ *    mode ACX_SCAN_ALL  : every match, reference order (position ascending; within a
+ *                         position the state first, then its fail chain = longest key
+ *                         first).  Replaces automaton_search_iter_next +
+ *                         automaton_build_output + ahocorasick_next
+ *                         (src/AutomatonSearchIter.c:157-197, 243-300; src/trie.c:177-194)
+ *                         and the inlined loop of automaton_find_all
+ *                         (src/Automaton.c:693-714).
+ *    mode ACX_SCAN_LONG : the exact state machine of automaton_search_iter_long_next
+ *                         (src/AutomatonSearchIterLong.c:89-153).
+ *
+ *    Input: n_hay haystacks concatenated in device buffer `dev_hay`;
+ *           haystack h = bytes [off[h], off[h+1])  (dev_off: int64[n_hay+1], device),
+ *           or, when dev_off == NULL, bytes [h*stride, (h+1)*stride) (fixed-length reads).
+ *           hay_capacity = number of readable bytes at dev_hay (>= the last offset).
+ *    Optional per-haystack device arrays (NULL = absent):
+ *           dev_init_state  int32[n_hay]  start state  (streaming continuation; the
+ *                           state that AutomatonSearchIter.set(chunk, reset=False) keeps,
+ *                           src/AutomatonSearchIter.c:344-352).  State ids are image ids.
+ *           dev_index_base  int32[n_hay]  added to every reported end_index (`shift`,
+ *                           src/AutomatonSearchIter.c:178, or the `start` of a slice).
+ *    Output (acx_result_t, device resident, optionally copied to pinned host memory):
+ *           match_off int64[n_hay+1]; matches acx_match_t[match_off[n_hay]] in haystack
+ *           order; final_state int32[n_hay] (ACX_SCAN_ALL only).
+ * ---------------------------------------------------------------------------------- */
+typedef struct acx_match {
+    int32_t end_index;   /* index of the LAST byte of the match within its haystack */
+    int32_t value;       /* low 32 bits of the stored integer / value id */
+} acx_match_t;
+
+enum { ACX_SCAN_ALL = 0, ACX_SCAN_LONG = 1 };
+
+typedef struct acx_scan_params {
+    uint32_t struct_bytes;     /* = sizeof(acx_scan_params); ABI growth guard */
+    int32_t  mode;             /* ACX_SCAN_ALL | ACX_SCAN_LONG */
+    const uint8_t* dev_hay;
+    int64_t  hay_capacity;
+    const int64_t* dev_off;    /* NULL => fixed stride */
+    int64_t  stride;
+    int64_t  n_hay;
+    const int32_t* dev_init_state;
+    const int32_t* dev_index_base;
+    int32_t  want_final_state; /* 1 => fill final_state */
+    int32_t  timing;           /* 1 => record HIP events around each kernel */
+    int32_t  variant;          /* 0 = default; >0 selects an alternative kernel (bench/tuning) */
+    int32_t  reserved;
+} acx_scan_params;
+
+typedef struct acx_result acx_result_t;
+
+/* `*result` may be NULL (a new result object is created) or a previous result whose
+ * device buffers are then reused/grown — the steady-state path allocates nothing. */
+int  acx_scan_batch(acx_image_t* img, const acx_scan_params* p, acx_result_t** result, void* stream);
+
+/* All accessors below synchronise with the scan's stream as needed. */
+int64_t            acx_result_num_matches(acx_result_t* r);
+const int64_t*     acx_result_offsets_dev(acx_result_t* r);
+const acx_match_t* acx_result_matches_dev(acx_result_t* r);
+const int32_t*     acx_result_final_state_dev(acx_result_t* r);
+/* D2H into library-owned pinned buffers, valid until the result is reused or freed */
+int  acx_result_fetch_host(acx_result_t* r, const int64_t** off, const acx_match_t** matches,
+                           const int32_t** final_state);
+/* kernel timing of the last scan (ms): walk, scan(prefix sum), expand, total GPU span.
+ * Needs params.timing = 1.  Measured with hipEvents on the scan's stream. */
+int  acx_result_timing(acx_result_t* r, float* walk_ms, float* scan_ms, float* expand_ms, float* total_ms);
+void acx_result_free(acx_result_t* r);
+
+/* ------------------------------------------------------------------------------------
+ * 4. Convenience: scan host buffers end to end (H2D, scan, D2H).  `off` is int64[n_hay+1].
+ *    This is what a CPython binding for Automaton.iter()/find_all() on a large haystack,
+ *    or a new Automaton.iter_batch(), calls.  PCIe-inclusive by construction.
+ * ---------------------------------------------------------------------------------- */
+int  acx_scan_host(acx_image_t* img, int mode, const uint8_t* hay, const int64_t* off, int64_t n_hay,
+                   const int32_t* init_state, const int32_t* index_base,
+                   acx_result_t** result);
+
+/* device helpers used by bindings that have no HIP runtime of their own */
+int  acx_device_count(int* n);
+int  acx_device_set(int dev);
+int  acx_dev_malloc(void** p, size_t nbytes);
+void acx_dev_free(void* p);
+int  acx_memcpy_h2d(void* dst_dev, const void* src_host, size_t nbytes);
+int  acx_memcpy_d2h(void* dst_host, const void* src_dev, size_t nbytes);
+int  acx_device_sync(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ACX_H_INCLUDED */

@@ -1,0 +1,73 @@
+/*
+ * acx_blob.h — layout of the flat automaton image ("blob").
+ *
+ * One contiguous little-endian buffer; every section starts on a 256-byte boundary and
+ * is addressed by a byte offset from the start of the blob, so the blob can be copied,
+ * broadcast (one RCCL call) or written to disk verbatim.  It replaces, for scanning,
+ * the pointer graph of the reference (TrieNode/Pair, src/trienode.h:19-42).
+ *
+ * States are renumbered in BFS order (root = 0, shallow states first) so the rows that
+ * random text visits most are contiguous and stay cache resident.
+ *
+ * Transition table: uint32 table[n_states][n_classes], fail links pre-resolved
+ * (table[s][c] is ahocorasick_next(s, c), src/trie.c:177-194, for every s and c), with
+ * per-TARGET facts packed into the spare bits so the scan needs ONE 4-byte gather per
+ * input byte and nothing else unless a match is reported:
+ *
+ *   bits  0..23  next state t                                   (ACX_ENTRY_STATE_MASK)
+ *   bit   24     EDGE     s has a real trie edge labelled c     (iter_long needs it:
+ *                         src/AutomatonSearchIterLong.c:117 uses trienode_get_next only)
+ *   bit   25     EOW      t->eow                                (…IterLong.c:119)
+ *   bit   26     FAILEOW  t->fail != root && t->fail->eow       (…IterLong.c:123)
+ *   bits 27..31  CNT      min(|out(t)|, 31), |out(t)| = number of eow nodes on the chain
+ *                         t, fail(t), fail(fail(t)), …  (what automaton_build_output walks,
+ *                         src/AutomatonSearchIter.c:161-168).  31 = escape: read out_off.
+ *
+ * Byte classes: bytes that occur in no key can never leave the root, so all of them
+ * share class 0; every byte that occurs in some key gets its own class.  DNA keys give
+ * 5 classes (20-byte rows) instead of 256 (1 KiB rows).
+ */
+#ifndef ACX_BLOB_H_INCLUDED
+#define ACX_BLOB_H_INCLUDED
+
+#include <stdint.h>
+
+#define ACX_BLOB_MAGIC        0x31424F4C42584341ull   /* "ACXBLOB1" */
+#define ACX_BLOB_VERSION      1u
+#define ACX_BLOB_HEADER_BYTES 256u
+#define ACX_BLOB_ALIGN        256u
+
+#define ACX_ENTRY_STATE_BITS  24
+#define ACX_ENTRY_STATE_MASK  0x00FFFFFFu
+#define ACX_ENTRY_EDGE        (1u << 24)
+#define ACX_ENTRY_EOW         (1u << 25)
+#define ACX_ENTRY_FAILEOW     (1u << 26)
+#define ACX_ENTRY_CNT_SHIFT   27
+#define ACX_ENTRY_CNT_ESCAPE  31u
+
+typedef struct acx_blob_header {
+    uint64_t magic;
+    uint32_t version;
+    uint32_t header_bytes;
+    uint64_t total_bytes;
+    uint32_t n_states;
+    uint32_t n_classes;      /* K: entries per table row */
+    uint32_t n_keys;
+    uint32_t longest_word;   /* halo size for chunked scans = longest_word - 1 */
+    uint32_t max_out_count;  /* max |out(t)| over all states */
+    uint32_t has_escape;     /* 1 if some state has |out(t)| >= ACX_ENTRY_CNT_ESCAPE */
+    uint64_t n_out;          /* total entries of out_val */
+    uint64_t trie_version;   /* acx_trie_version() at flatten time */
+    /* section offsets (bytes from blob start) */
+    uint64_t off_cls;        /* uint8  [256]            byte -> class                    */
+    uint64_t off_table;      /* uint32 [n_states * K]   packed entries (see above)       */
+    uint64_t off_fail;       /* int32  [n_states]       BFS id of fail(s); root: -1      */
+    uint64_t off_node_val;   /* int32  [n_states]       low 32 bits of s's value if eow  */
+    uint64_t off_node_flags; /* uint8  [n_states]       bit0 = eow                       */
+    uint64_t off_out_off;    /* uint32 [n_states + 1]   CSR offsets into out_val         */
+    uint64_t off_out_val;    /* int32  [n_out]          values in fail-chain order       */
+    uint64_t fnv1a64;        /* FNV-1a of bytes [header_bytes, total_bytes)              */
+    uint8_t  reserved[ACX_BLOB_HEADER_BYTES - 128];
+} acx_blob_header;
+
+#endif

@@ -1,0 +1,105 @@
+/*
+ * flat_walk.c — CPU walker over the FLAT image (include/acx_blob.h).
+ * TEST INFRASTRUCTURE ONLY, NOT PRODUCT CODE (same rules as ac_oracle.c).
+ *
+ * Purpose: separate flattener bugs from kernel bugs.  ac_oracle.c walks the pointer
+ * trie the way the reference does; this file walks the flattened arrays the way the HIP
+ * kernels do (one table entry per input byte), on the CPU.  tests/ compare
+ *      reference/_ref  ==  ac_oracle.c  ==  flat_walk.c(acx_flatten(...))  ==  HIP kernels.
+ *
+ * Semantics restated from the reference:
+ *   ALL  : src/AutomatonSearchIter.c:157-197, 243-300 (+ src/trie.c:177-194)
+ *   LONG : src/AutomatonSearchIterLong.c:89-153
+ */
+#include <stdint.h>
+#include <stddef.h>
+#include "acx_blob.h"
+
+typedef struct {
+    const acx_blob_header* h;
+    const uint8_t*  cls;
+    const uint32_t* table;
+    const uint32_t* out_off;
+    const int32_t*  out_val;
+} flat_t;
+
+static int flat_open(const void* blob, flat_t* f) {
+    const acx_blob_header* h = (const acx_blob_header*)blob;
+    if (h->magic != ACX_BLOB_MAGIC || h->version != ACX_BLOB_VERSION) return -1;
+    const uint8_t* b = (const uint8_t*)blob;
+    f->h = h;
+    f->cls = b + h->off_cls;
+    f->table = (const uint32_t*)(b + h->off_table);
+    f->out_off = (const uint32_t*)(b + h->off_out_off);
+    f->out_val = (const int32_t*)(b + h->off_out_val);
+    return 0;
+}
+
+/* returns number of matches (first `cap` stored); -1 on bad blob */
+int64_t flat_iter(const void* blob, const uint8_t* hay, int64_t len,
+                  int32_t* state_io, int64_t index_base,
+                  int32_t* out_end, int32_t* out_val, int64_t cap) {
+    flat_t f;
+    if (flat_open(blob, &f) < 0) return -1;
+    const uint32_t K = f.h->n_classes;
+    uint32_t state = state_io ? (uint32_t)*state_io : 0;
+    int64_t n = 0;
+    for (int64_t i = 0; i < len; i++) {
+        uint32_t e = f.table[(size_t)state * K + f.cls[hay[i]]];
+        state = e & ACX_ENTRY_STATE_MASK;
+        uint32_t cnt = e >> ACX_ENTRY_CNT_SHIFT;
+        if (cnt) {
+            uint32_t o0 = f.out_off[state], o1 = f.out_off[state + 1];
+            /* the packed count must agree with the CSR unless it is the escape value */
+            if (cnt != ACX_ENTRY_CNT_ESCAPE && cnt != o1 - o0) return -3;
+            if (cnt == ACX_ENTRY_CNT_ESCAPE && o1 - o0 < ACX_ENTRY_CNT_ESCAPE) return -3;
+            for (uint32_t r = o0; r < o1; r++) {
+                if (n < cap) { out_end[n] = (int32_t)(i + index_base); out_val[n] = f.out_val[r]; }
+                n++;
+            }
+        }
+    }
+    if (state_io) *state_io = (int32_t)state;
+    return n;
+}
+
+int64_t flat_iter_long(const void* blob, const uint8_t* hay, int64_t len, int64_t index_base,
+                       int32_t* out_end, int32_t* out_val, int64_t cap) {
+    flat_t f;
+    if (flat_open(blob, &f) < 0) return -1;
+    const uint32_t K = f.h->n_classes;
+    int64_t n = 0;
+    uint32_t state = 0;
+    int64_t index = 0;
+    int64_t last_index = -1;
+    uint32_t last_state = 0;          /* the state whose FIRST output is the value to report */
+    int have_last = 0;
+
+    while (1) {
+        int emit = 0;
+        while (index < len) {
+            uint32_t e = f.table[(size_t)state * K + f.cls[hay[index]]];
+            uint32_t next = e & ACX_ENTRY_STATE_MASK;
+            if (!(e & ACX_ENTRY_EDGE) && have_last) { emit = 1; break; }   /* …IterLong.c:131-132 */
+            if (next == 0) { state = 0; index++; continue; }               /* fail walk ended in NULL (:137-140) */
+            /* a real edge from `state`, or from the first fail ancestor that has one (:134-143
+             * followed by the next loop iteration at :116): the checks of :118-126 on `next` */
+            if (e & ACX_ENTRY_EOW) {
+                last_state = next; last_index = index; have_last = 1;
+            } else if (e & ACX_ENTRY_FAILEOW) {
+                last_state = next; last_index = index; have_last = 1;      /* reports fail(next): first output of next */
+                emit = 1; break;
+            }
+            state = next; index++;
+        }
+        if (!emit && !have_last) break;                                    /* StopIteration */
+        /* emit (…IterLong.c:99-111) */
+        if (n < cap) {
+            out_end[n] = (int32_t)(index_base + last_index);
+            out_val[n] = f.out_val[f.out_off[last_state]];
+        }
+        n++;
+        state = 0; index = last_index + 1; have_last = 0; last_index = -1;
+    }
+    return n;
+}

@@ -1,0 +1,444 @@
+"""`Automaton` — host-side mirror of the reference's `ahocorasick.Automaton` (bytes build)
+for the accelerated path: add_word / make_automaton / iter / iter_long / find_all, plus
+the batch entry points the reference lacks (iter_batch / scan_batch).
+
+Same names, argument meaning and error behaviour as the reference so that the parity
+tests read like the reference's own tests:
+  * constructor            src/Automaton.c:96-181
+  * add_word               src/Automaton.c:201-300   (value rules per `store`)
+  * make_automaton         src/Automaton.c:560-649   (None when built, False otherwise)
+  * iter                   src/Automaton.c:875-966 + src/AutomatonSearchIter.c
+  * iter_long              src/Automaton.c:969-1041 + src/AutomatonSearchIterLong.c
+  * find_all               src/Automaton.c:652-719
+  * [start, [end]] parsing src/utils.c:293-359 (pymod_parse_start_end)
+
+The trie and its failure links are built on the CPU inside libacx (C++).  Every search
+runs on the GPU through the C-ABI (include/acx.h); there is NO CPU search path here —
+without a GPU, iter()/iter_long()/find_all()/iter_batch() raise.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from ._lib import ACX_SCAN_ALL, ACX_SCAN_LONG, lib, check
+
+# constants of the reference module, src/pyahocorasick.c:113-134, src/Automaton.h:16-41
+EMPTY, TRIE, AHOCORASICK = 0, 1, 2
+STORE_INTS, STORE_LENGTH, STORE_ANY = 10, 20, 30
+KEY_STRING, KEY_SEQUENCE = 100, 200
+MATCH_EXACT_LENGTH, MATCH_AT_MOST_PREFIX, MATCH_AT_LEAST_PREFIX = 0, 1, 2
+unicode = 0   # this engine implements the bytes build (one letter = one byte)
+
+
+def _parse_start_end(args, lo, hi):
+    """pymod_parse_start_end, src/utils.c:293-359 (including its `len-1+end` quirk)."""
+    start, end = lo, hi
+    if len(args) >= 1:
+        start = args[0].__index__()
+        if start < 0:
+            start = hi + start
+        if start < lo or start >= hi:
+            raise IndexError("start index not in range %d..%d" % (lo, hi))
+    if len(args) >= 2:
+        end = args[1].__index__()
+        if end < 0:
+            end = hi - 1 + end
+        if end < lo or end > hi:
+            raise IndexError("end index not in range %d..%d" % (lo, hi))
+    return start, end
+
+
+class _DeviceImage:
+    """The flat automaton uploaded to HBM, tagged with the trie version it was built from."""
+
+    def __init__(self, trie, version):
+        blob = C.c_void_p()
+        nbytes = C.c_size_t()
+        check(lib().acx_flatten(trie, C.byref(blob), C.byref(nbytes)))
+        self.handle = C.c_void_p()
+        try:
+            check(lib().acx_image_upload(blob, nbytes.value, C.byref(self.handle)))
+        finally:
+            lib().acx_blob_free(blob)
+        self.version = version
+        self.nbytes = nbytes.value
+
+    def close(self):
+        if self.handle:
+            lib().acx_image_free(self.handle)
+            self.handle = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class BatchResult:
+    """CSR result of a batch scan: matches of haystack k are rows offsets[k]:offsets[k+1].
+
+    `end_index` / `value` are int32 arrays exactly as the reference emits them
+    (Py_BuildValue("ii"), src/AutomatonSearchIter.c:180-184); for STORE_ANY automata
+    `value` holds value ids — use `objects()` or `tolists()` to get the stored objects.
+    """
+
+    def __init__(self, offsets, end_index, value, final_state, values_table):
+        self.offsets = offsets
+        self.end_index = end_index
+        self.value = value
+        self.final_state = final_state
+        self._values = values_table
+
+    def __len__(self):
+        return len(self.offsets) - 1
+
+    def num_matches(self):
+        return int(self.offsets[-1])
+
+    def objects(self):
+        if self._values is None:
+            return self.value
+        return [self._values[i] for i in self.value.tolist()]
+
+    def tolists(self):
+        ends = self.end_index.tolist()
+        vals = self.objects() if self._values is not None else self.value.tolist()
+        off = self.offsets.tolist()
+        return [list(zip(ends[off[k]:off[k + 1]], vals[off[k]:off[k + 1]])) for k in range(len(off) - 1)]
+
+
+class Automaton:
+    def __init__(self, store=STORE_ANY, key_type=KEY_STRING):
+        if store not in (STORE_INTS, STORE_LENGTH, STORE_ANY):
+            raise ValueError("store value must be one of ahocorasick.STORE_LENGTH, STORE_INTS or STORE_ANY")
+        if key_type not in (KEY_STRING, KEY_SEQUENCE):
+            raise ValueError("key_type must have value KEY_STRING or KEY_SEQUENCE")
+        if key_type == KEY_SEQUENCE:
+            raise NotImplementedError("KEY_SEQUENCE automata are not byte automata; outside the GPU path (SURVEY §8f N4)")
+        self._store = store
+        self._key_type = key_type
+        self._trie = C.c_void_p()
+        check(lib().acx_trie_new(C.byref(self._trie)))
+        self._values = [] if store == STORE_ANY else None   # STORE_ANY: value id -> object
+        self._image = None
+        self._result = C.c_void_p()                          # reusable device/pinned buffers
+
+    def __del__(self):
+        try:
+            if self._image is not None:
+                self._image.close()
+            if self._result:
+                lib().acx_result_free(self._result)
+            if self._trie:
+                lib().acx_trie_free(self._trie)
+        except Exception:
+            pass
+
+    # ---- attributes (src/Automaton.c:1237-1256) ---------------------------------------
+    @property
+    def kind(self):
+        return lib().acx_trie_kind(self._trie)
+
+    @property
+    def store(self):
+        return self._store
+
+    @property
+    def _version(self):
+        return lib().acx_trie_version(self._trie)
+
+    def __len__(self):
+        return lib().acx_trie_num_keys(self._trie)
+
+    def __contains__(self, key):
+        return self.exists(key)
+
+    # ---- trie API (CPU, inside libacx) ------------------------------------------------
+    @staticmethod
+    def _key(key, what="bytes expected"):
+        if not isinstance(key, bytes):
+            raise TypeError(what)
+        return key
+
+    def add_word(self, key, *value):
+        key = self._key(key)
+        if self._store == STORE_ANY:
+            if not value:
+                raise ValueError("A value object is required as second argument.")
+            found = C.c_int(0)
+            old = C.c_int64(0)
+            check(lib().acx_trie_get(self._trie, key, len(key), C.byref(found), C.byref(old)))
+            if len(key) == 0:
+                return False
+            if found.value:
+                vid = old.value
+                self._values[vid] = value[0]
+            else:
+                vid = len(self._values)
+                self._values.append(value[0])
+            v = vid
+        elif self._store == STORE_INTS:
+            if value:
+                if not hasattr(value[0], "__index__") and not isinstance(value[0], (int, float)):
+                    raise TypeError("An integer value is required as second argument.")
+                v = int(value[0])
+            else:
+                v = len(self) + 1              # src/Automaton.c:238-242
+        else:
+            v = len(key)                       # STORE_LENGTH, src/Automaton.c:245-247
+        is_new = C.c_int(0)
+        v &= 0xFFFFFFFFFFFFFFFF
+        if v >= 1 << 63:
+            v -= 1 << 64
+        check(lib().acx_trie_add_word(self._trie, key, len(key), v, C.byref(is_new)))
+        return bool(is_new.value)
+
+    def exists(self, key):
+        key = self._key(key)
+        found = C.c_int(0)
+        check(lib().acx_trie_get(self._trie, key, len(key), C.byref(found), None))
+        return bool(found.value)
+
+    _NO_DEFAULT = object()
+
+    def get(self, key, default=_NO_DEFAULT):
+        key = self._key(key)
+        found = C.c_int(0)
+        val = C.c_int64(0)
+        check(lib().acx_trie_get(self._trie, key, len(key), C.byref(found), C.byref(val)))
+        if not found.value:
+            if default is Automaton._NO_DEFAULT:
+                raise KeyError(key)
+            return default
+        return self._values[val.value] if self._store == STORE_ANY else val.value
+
+    def longest_prefix(self, key):
+        key = self._key(key)
+        n = C.c_size_t(0)
+        check(lib().acx_trie_longest_prefix(self._trie, key, len(key), C.byref(n)))
+        return n.value
+
+    def _remove(self, key):
+        key = self._key(key)
+        found = C.c_int(0)
+        val = C.c_int64(0)
+        check(lib().acx_trie_remove_word(self._trie, key, len(key), C.byref(found), C.byref(val)))
+        if not found.value:
+            return False, None
+        if self._store == STORE_ANY:
+            obj = self._values[val.value]
+            self._values[val.value] = None
+            return True, obj
+        return True, val.value
+
+    def remove_word(self, key):
+        return self._remove(key)[0]
+
+    def pop(self, key):
+        ok, v = self._remove(key)
+        if not ok:
+            raise KeyError(key)
+        return v
+
+    def clear(self):
+        lib().acx_trie_clear(self._trie)
+        if self._values is not None:
+            self._values = []
+        self._drop_image()
+
+    def make_automaton(self):
+        changed = C.c_int(0)
+        check(lib().acx_trie_make_automaton(self._trie, C.byref(changed)))
+        return None if changed.value else False    # src/Automaton.c:574-575, 645
+
+    # ---- device image -----------------------------------------------------------------
+    def _drop_image(self):
+        if self._image is not None:
+            self._image.close()
+            self._image = None
+
+    def _ensure_image(self):
+        v = self._version
+        if self._image is None or self._image.version != v:
+            self._drop_image()                      # invalidated by version (SURVEY §7 "Invalidation")
+            self._image = _DeviceImage(self._trie, v)
+        return self._image
+
+    def flat_image_bytes(self):
+        """The flat image (include/acx_blob.h) as bytes — what a single RCCL broadcast replicates."""
+        blob = C.c_void_p()
+        nbytes = C.c_size_t()
+        check(lib().acx_flatten(self._trie, C.byref(blob), C.byref(nbytes)))
+        try:
+            return C.string_at(blob, nbytes.value)
+        finally:
+            lib().acx_blob_free(blob)
+
+    # ---- batch scan (NEW: the reference scans one haystack per iterator) ---------------
+    def scan_batch(self, data, offsets, mode=ACX_SCAN_ALL, init_state=None, index_base=None):
+        """Scan haystacks data[offsets[k]:offsets[k+1]] on the GPU; returns a BatchResult.
+
+        data: bytes-like; offsets: int64[n+1] with offsets[0] == 0.
+        """
+        if self.kind != AHOCORASICK:
+            raise AttributeError("Not an Aho-Corasick automaton yet: call add_word to add some keys and call "
+                                 "make_automaton to convert the trie to an automaton.")
+        img = self._ensure_image()
+        buf = np.frombuffer(data, dtype=np.uint8) if not isinstance(data, np.ndarray) else np.ascontiguousarray(data, dtype=np.uint8)
+        off = np.ascontiguousarray(offsets, dtype=np.int64)
+        n = len(off) - 1
+        if n < 0 or off[0] != 0 or (n and off[-1] > buf.size):
+            raise ValueError("bad offsets")
+        init = None if init_state is None else np.ascontiguousarray(init_state, dtype=np.int32)
+        base = None if index_base is None else np.ascontiguousarray(index_base, dtype=np.int32)
+        check(lib().acx_scan_host(img.handle, mode, buf.ctypes.data if buf.size else None, off.ctypes.data, n,
+                                  init.ctypes.data if init is not None else None,
+                                  base.ctypes.data if base is not None else None,
+                                  C.byref(self._result)))
+        p_off, p_m, p_f = C.c_void_p(), C.c_void_p(), C.c_void_p()
+        check(lib().acx_result_fetch_host(self._result, C.byref(p_off), C.byref(p_m), C.byref(p_f)))
+        total = lib().acx_result_num_matches(self._result)
+        r_off = np.ctypeslib.as_array(C.cast(p_off, C.POINTER(C.c_int64)), shape=(n + 1,)).copy()
+        if total:
+            m = np.ctypeslib.as_array(C.cast(p_m, C.POINTER(C.c_int32)), shape=(total, 2)).copy()
+        else:
+            m = np.zeros((0, 2), dtype=np.int32)
+        fin = None
+        if p_f and n:
+            fin = np.ctypeslib.as_array(C.cast(p_f, C.POINTER(C.c_int32)), shape=(n,)).copy()
+        return BatchResult(r_off, m[:, 0], m[:, 1], fin, self._values)
+
+    def iter_batch(self, haystacks, long=False):
+        """list of bytes -> list of lists of (end_index, value); == [list(A.iter(h)) for h in haystacks]."""
+        lens = np.fromiter((len(h) for h in haystacks), dtype=np.int64, count=len(haystacks))
+        off = np.zeros(len(haystacks) + 1, dtype=np.int64)
+        np.cumsum(lens, out=off[1:])
+        for h in haystacks:
+            if not isinstance(h, bytes):
+                raise TypeError("bytes required")
+        return self.scan_batch(b"".join(haystacks), off, ACX_SCAN_LONG if long else ACX_SCAN_ALL).tolists()
+
+    # ---- reference search API, GPU-backed ---------------------------------------------
+    def iter(self, string, start=-1, end=-1, ignore_white_space=False):
+        if self.kind != AHOCORASICK:
+            raise AttributeError("Not an Aho-Corasick automaton yet: call add_word to add some keys and call "
+                                 "make_automaton to convert the trie to an automaton.")
+        if not isinstance(string, bytes):
+            raise TypeError("bytes required")
+        # -1 means "default" for both (src/Automaton.c:893-956).  The reference does not
+        # validate the range (out-of-range is undefined behaviour there); here it is clamped.
+        s = 0 if start == -1 else start
+        e = len(string) if end == -1 else end
+        s = max(0, min(s, len(string)))
+        e = max(s, min(e, len(string)))
+        return AutomatonSearchIter(self, string, s, e, bool(ignore_white_space))
+
+    def iter_long(self, string, *args):
+        if self.kind != AHOCORASICK:
+            raise AttributeError("not an automaton yet; add some words and call make_automaton")
+        if not isinstance(string, bytes):
+            raise TypeError("bytes required")
+        s, e = _parse_start_end(args, 0, len(string))
+        return AutomatonSearchIterLong(self, string, s, e)
+
+    def find_all(self, string, callback, *args):
+        if self.kind != AHOCORASICK:
+            return None                                   # src/Automaton.c:666-667
+        if not isinstance(string, bytes):
+            raise TypeError("bytes expected")
+        if not callable(callback):
+            raise TypeError("The callback argument must be a callable such as a function.")
+        s, e = _parse_start_end(args, 0, len(string))
+        res = self.scan_batch(string[s:e], [0, max(0, e - s)], ACX_SCAN_ALL, index_base=[s])
+        for idx, val in res.tolists()[0]:
+            callback(idx, val)                            # an exception aborts, src/Automaton.c:705-708
+        return None
+
+
+_WS = np.zeros(256, dtype=bool)
+_WS[[9, 10, 11, 12, 13, 32]] = True      # iswspace() over the letters the bytes build can produce
+
+
+class AutomatonSearchIter:
+    """iterator of (end_index, value); mirrors src/AutomatonSearchIter.c.
+
+    The whole range is scanned on the GPU at construction / set(); next() hands the tuples
+    out one by one and re-checks the automaton version like the reference (:247-250)."""
+
+    def __init__(self, automaton, string, start, end, ignore_white_space=False):
+        self._a = automaton
+        self._version = automaton._version
+        self._ws = ignore_white_space
+        self._state = 0
+        self._shift = 0
+        self._load(string, start, end)
+
+    def _load(self, string, start, end):
+        chunk = string[start:end]
+        remap = None
+        if self._ws:
+            # the reference skips white-space letters without touching the state
+            # (src/AutomatonSearchIter.c:269-274): scan the compacted bytes, map indices back
+            arr = np.frombuffer(chunk, dtype=np.uint8)
+            remap = np.flatnonzero(~_WS[arr])
+            chunk = arr[remap].tobytes()
+        res = self._a.scan_batch(chunk, [0, len(chunk)], ACX_SCAN_ALL, init_state=[self._state],
+                                 index_base=[0 if remap is not None else start + self._shift])
+        if remap is not None and res.num_matches():
+            res.end_index = (remap[res.end_index] + (start + self._shift)).astype(np.int32)
+        self._pending = res.tolists()[0]
+        self._pos = 0
+        self._state = int(res.final_state[0]) if res.final_state is not None else 0
+        self._end = end
+        self._ref_index = start - 1     # the reference's iter->index (src/AutomatonSearchIter.c:123)
+
+    def __iter__(self):
+        return self
+
+    def __next__(self):
+        if self._version != self._a._version:
+            raise ValueError("underlaying automaton has changed, iterator is not valid anymore")
+        if self._pos >= len(self._pending):
+            self._ref_index = self._end
+            raise StopIteration
+        item = self._pending[self._pos]
+        self._pos += 1
+        self._ref_index = item[0] - self._shift
+        return item
+
+    def set(self, string, reset=False):
+        """src/AutomatonSearchIter.c:303-368: continue on a new chunk (keep state, accumulate
+        shift) or reset to the root."""
+        if not isinstance(string, bytes):
+            raise TypeError("bytes expected")
+        if reset:
+            self._state = 0
+            self._shift = 0
+        else:
+            self._shift += self._ref_index if self._ref_index >= 0 else 0   # :344-352
+        self._load(string, 0, len(string))
+
+
+class AutomatonSearchIterLong:
+    """mirrors src/AutomatonSearchIterLong.c (longest, non-overlapping; see the oracle for quirks)."""
+
+    def __init__(self, automaton, string, start, end):
+        self._a = automaton
+        self._version = automaton._version
+        res = automaton.scan_batch(string[start:end], [0, end - start], ACX_SCAN_LONG, index_base=[start])
+        self._pending = res.tolists()[0]
+        self._pos = 0
+
+    def __iter__(self):
+        return self
+
+    def __next__(self):
+        if self._version != self._a._version:
+            raise ValueError("underlaying automaton has changed, iterator is not valid anymore")
+        if self._pos >= len(self._pending):
+            raise StopIteration
+        item = self._pending[self._pos]
+        self._pos += 1
+        return item

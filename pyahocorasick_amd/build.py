@@ -1,0 +1,52 @@
+"""Build libacx.so (host trie + flattener + HIP kernels + C-ABI) for gfx950, in-tree.
+
+    python -m pyahocorasick_amd.build            # or: from pyahocorasick_amd.build import build_libacx
+
+hipcc cross-compiles without a GPU.  The .so lands next to this file so it travels with
+the repository snapshot to the GPU box (it is git-ignored, not gpurun-ignored).
+"""
+import os
+import shutil
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+CSRC = os.path.join(HERE, "csrc")
+SOURCES = ["acx_trie.cpp", "acx_kernels.hip", "acx_capi.hip"]
+HEADERS = [os.path.join(ROOT, "include", "acx.h"), os.path.join(ROOT, "include", "acx_blob.h"),
+           os.path.join(CSRC, "acx_internal.h"), os.path.join(CSRC, "acx_kernels.h")]
+LIB = os.path.join(HERE, "libacx.so")
+
+
+def _hipcc():
+    for cand in (os.environ.get("HIPCC"), shutil.which("hipcc"), "/opt/rocm/bin/hipcc"):
+        if cand and os.path.exists(cand):
+            return cand
+    raise RuntimeError("hipcc not found (set HIPCC or install ROCm)")
+
+
+def needs_build():
+    if not os.path.exists(LIB):
+        return True
+    t = os.path.getmtime(LIB)
+    deps = [os.path.join(CSRC, s) for s in SOURCES] + HEADERS
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def build_libacx(force=False, verbose=True):
+    if not force and not needs_build():
+        return LIB
+    cmd = [_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
+           "-Wall", "-Wno-unused-function",
+           "-I" + os.path.join(ROOT, "include"), "-I" + CSRC,
+           "-o", LIB] + [os.path.join(CSRC, s) for s in SOURCES]
+    if verbose:
+        print("[pyahocorasick_amd.build]", " ".join(cmd), flush=True)
+    subprocess.check_call(cmd)
+    return LIB
+
+
+if __name__ == "__main__":
+    build_libacx(force="--force" in sys.argv)
+    print(LIB)

@@ -1,0 +1,361 @@
+// acx_capi.hip — the C-ABI of libacx (include/acx.h): device image, batch scan driver,
+// result objects.  Host trie + flattener live in acx_trie.cpp, kernels in acx_kernels.hip.
+//
+// There is NO CPU fallback anywhere in this file: without a usable HIP device every scan
+// entry point fails with ACX_E_NODEVICE / ACX_E_HIP.
+#include "acx_internal.h"
+#include "acx_kernels.h"
+
+#include <hip/hip_runtime.h>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <new>
+
+// ------------------------------------------------------------------------------------
+// errors
+// ------------------------------------------------------------------------------------
+static thread_local char g_err[512] = "";
+
+extern "C" int acx_fail(int code, const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof g_err, fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+extern "C" const char* acx_last_error(void) { return g_err; }
+extern "C" int acx_abi_version(void) { return ACX_ABI_VERSION; }
+
+#define HIP_TRY(expr)                                                                          \
+    do {                                                                                       \
+        hipError_t _e = (expr);                                                                \
+        if (_e != hipSuccess)                                                                  \
+            return acx_fail(_e == hipErrorOutOfMemory ? ACX_E_NOMEM                            \
+                            : (_e == hipErrorNoDevice || _e == hipErrorInvalidDevice) ? ACX_E_NODEVICE \
+                                                                                      : ACX_E_HIP, \
+                            "%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, __LINE__); \
+    } while (0)
+
+// ------------------------------------------------------------------------------------
+// device helpers
+// ------------------------------------------------------------------------------------
+extern "C" int acx_device_count(int* n) {
+    if (!n) return acx_fail(ACX_E_INVAL, "acx_device_count: NULL");
+    int c = 0;
+    hipError_t e = hipGetDeviceCount(&c);
+    if (e != hipSuccess) { *n = 0; return acx_fail(ACX_E_NODEVICE, "hipGetDeviceCount: %s", hipGetErrorString(e)); }
+    *n = c;
+    return ACX_OK;
+}
+extern "C" int acx_device_set(int dev) { HIP_TRY(hipSetDevice(dev)); return ACX_OK; }
+extern "C" int acx_dev_malloc(void** p, size_t nbytes) {
+    if (!p) return acx_fail(ACX_E_INVAL, "acx_dev_malloc: NULL");
+    HIP_TRY(hipMalloc(p, nbytes ? nbytes : 1));
+    return ACX_OK;
+}
+extern "C" void acx_dev_free(void* p) { if (p) (void)hipFree(p); }
+extern "C" int acx_memcpy_h2d(void* d, const void* s, size_t n) { HIP_TRY(hipMemcpy(d, s, n, hipMemcpyHostToDevice)); return ACX_OK; }
+extern "C" int acx_memcpy_d2h(void* d, const void* s, size_t n) { HIP_TRY(hipMemcpy(d, s, n, hipMemcpyDeviceToHost)); return ACX_OK; }
+extern "C" int acx_device_sync(void) { HIP_TRY(hipDeviceSynchronize()); return ACX_OK; }
+
+// ------------------------------------------------------------------------------------
+// image
+// ------------------------------------------------------------------------------------
+struct acx_image {
+    acx_blob_header h;
+    uint8_t* dev = nullptr;     // base of the blob in device memory
+    size_t nbytes = 0;
+    bool owns = false;
+    int device = 0;
+    // resolved section pointers
+    const uint8_t* cls = nullptr;
+    const uint32_t* table = nullptr;
+    const uint32_t* out_off = nullptr;
+    const int32_t* out_val = nullptr;
+};
+
+static void image_resolve(acx_image* img) {
+    img->cls = img->dev + img->h.off_cls;
+    img->table = (const uint32_t*)(img->dev + img->h.off_table);
+    img->out_off = (const uint32_t*)(img->dev + img->h.off_out_off);
+    img->out_val = (const int32_t*)(img->dev + img->h.off_out_val);
+}
+
+extern "C" int acx_image_upload(const void* blob, size_t nbytes, acx_image_t** out) {
+    if (!blob || !out) return acx_fail(ACX_E_INVAL, "acx_image_upload: NULL argument");
+    acx_blob_header h;
+    if (nbytes < sizeof h) return acx_fail(ACX_E_FORMAT, "image: truncated");
+    memcpy(&h, blob, sizeof h);
+    int rc = acx_blob_check_header(&h, nbytes);
+    if (rc) return rc;
+    acx_image* img = new (std::nothrow) acx_image();
+    if (!img) return acx_fail(ACX_E_NOMEM, "acx_image_upload: out of memory");
+    img->h = h; img->nbytes = nbytes; img->owns = true;
+    hipError_t e = hipGetDevice(&img->device);
+    if (e == hipSuccess) e = hipMalloc((void**)&img->dev, nbytes);
+    if (e == hipSuccess) e = hipMemcpy(img->dev, blob, nbytes, hipMemcpyHostToDevice);
+    if (e != hipSuccess) {
+        if (img->dev) (void)hipFree(img->dev);
+        delete img;
+        return acx_fail(e == hipErrorOutOfMemory ? ACX_E_NOMEM : ACX_E_HIP, "acx_image_upload: %s", hipGetErrorString(e));
+    }
+    image_resolve(img);
+    *out = img;
+    return ACX_OK;
+}
+
+extern "C" int acx_image_adopt(void* dev_blob, size_t nbytes, const void* host_header, acx_image_t** out) {
+    if (!dev_blob || !host_header || !out) return acx_fail(ACX_E_INVAL, "acx_image_adopt: NULL argument");
+    acx_blob_header h;
+    memcpy(&h, host_header, sizeof h);
+    int rc = acx_blob_check_header(&h, nbytes);
+    if (rc) return rc;
+    acx_image* img = new (std::nothrow) acx_image();
+    if (!img) return acx_fail(ACX_E_NOMEM, "acx_image_adopt: out of memory");
+    img->h = h; img->nbytes = nbytes; img->owns = false; img->dev = (uint8_t*)dev_blob;
+    (void)hipGetDevice(&img->device);
+    image_resolve(img);
+    *out = img;
+    return ACX_OK;
+}
+
+extern "C" void acx_image_free(acx_image_t* img) {
+    if (!img) return;
+    if (img->owns && img->dev) (void)hipFree(img->dev);
+    delete img;
+}
+extern "C" int64_t acx_image_num_states(const acx_image_t* img) { return img ? img->h.n_states : 0; }
+extern "C" int64_t acx_image_num_classes(const acx_image_t* img) { return img ? img->h.n_classes : 0; }
+extern "C" size_t  acx_image_nbytes(const acx_image_t* img) { return img ? img->nbytes : 0; }
+extern "C" void*   acx_image_dev_ptr(const acx_image_t* img) { return img ? img->dev : nullptr; }
+
+// ------------------------------------------------------------------------------------
+// result
+// ------------------------------------------------------------------------------------
+template <typename T>
+struct DevBuf {
+    T* p = nullptr; size_t cap = 0;   // elements
+    int ensure(size_t n) {
+        if (n <= cap) return ACX_OK;
+        if (p) { (void)hipFree(p); p = nullptr; cap = 0; }
+        size_t want = n + n / 8 + 64;
+        hipError_t e = hipMalloc((void**)&p, want * sizeof(T));
+        if (e != hipSuccess) { p = nullptr; return acx_fail(ACX_E_NOMEM, "device allocation of %zu bytes failed: %s", want * sizeof(T), hipGetErrorString(e)); }
+        cap = want;
+        return ACX_OK;
+    }
+    void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
+};
+template <typename T>
+struct PinBuf {
+    T* p = nullptr; size_t cap = 0;
+    int ensure(size_t n) {
+        if (n <= cap) return ACX_OK;
+        if (p) { (void)hipHostFree(p); p = nullptr; cap = 0; }
+        size_t want = n + n / 8 + 64;
+        hipError_t e = hipHostMalloc((void**)&p, want * sizeof(T), hipHostMallocDefault);
+        if (e != hipSuccess) { p = nullptr; return acx_fail(ACX_E_NOMEM, "pinned allocation of %zu bytes failed: %s", want * sizeof(T), hipGetErrorString(e)); }
+        cap = want;
+        return ACX_OK;
+    }
+    void release() { if (p) (void)hipHostFree(p); p = nullptr; cap = 0; }
+};
+
+struct acx_result {
+    DevBuf<int32_t> counts, nev, final_state;
+    DevBuf<int64_t> match_off, partials;
+    DevBuf<uint2> events, matches;
+    PinBuf<int64_t> h_off;
+    PinBuf<acx_match_t> h_matches;
+    PinBuf<int32_t> h_final;
+    PinBuf<int64_t> h_total;
+    // staging used only by acx_scan_host
+    DevBuf<uint8_t> in_hay; DevBuf<int64_t> in_off; DevBuf<int32_t> in_init, in_base;
+    int64_t n_hay = 0;
+    int64_t total = 0;
+    bool has_final = false;
+    bool host_valid = false;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+    bool timed = false;
+    float t_walk = 0, t_scan = 0, t_expand = 0, t_total = 0;
+    ~acx_result() {
+        counts.release(); nev.release(); final_state.release(); match_off.release(); partials.release();
+        events.release(); matches.release(); h_off.release(); h_matches.release(); h_final.release(); h_total.release();
+        in_hay.release(); in_off.release(); in_init.release(); in_base.release();
+        for (auto& e : ev) if (e) (void)hipEventDestroy(e);
+    }
+};
+
+extern "C" void acx_result_free(acx_result_t* r) { delete r; }
+
+// ------------------------------------------------------------------------------------
+// scan driver
+// ------------------------------------------------------------------------------------
+static const int64_t ACX_MAX_LAUNCH_BYTES = (int64_t)4 << 30;   // event staging = 8 B per haystack byte
+
+extern "C" int acx_scan_batch(acx_image_t* img, const acx_scan_params* p, acx_result_t** result, void* stream_v) {
+    if (!img || !p || !result) return acx_fail(ACX_E_INVAL, "acx_scan_batch: NULL argument");
+    if (p->struct_bytes != sizeof(acx_scan_params))
+        return acx_fail(ACX_E_INVAL, "acx_scan_batch: params.struct_bytes = %u, library expects %zu", p->struct_bytes, sizeof(acx_scan_params));
+    if (p->mode != ACX_SCAN_ALL && p->mode != ACX_SCAN_LONG) return acx_fail(ACX_E_INVAL, "acx_scan_batch: bad mode %d", p->mode);
+    if (p->n_hay < 0 || p->hay_capacity < 0) return acx_fail(ACX_E_INVAL, "acx_scan_batch: negative size");
+    if (p->n_hay > 0 && !p->dev_hay && p->hay_capacity > 0) return acx_fail(ACX_E_INVAL, "acx_scan_batch: dev_hay is NULL");
+    if (!p->dev_off) {
+        if (p->stride < 0 || p->stride > INT32_MAX) return acx_fail(ACX_E_INVAL, "acx_scan_batch: stride out of range");
+        if (p->n_hay * p->stride > p->hay_capacity) return acx_fail(ACX_E_INVAL, "acx_scan_batch: n_hay*stride exceeds hay_capacity");
+    }
+    if (p->hay_capacity > ACX_MAX_LAUNCH_BYTES)
+        return acx_fail(ACX_E_UNSUPPORTED, "acx_scan_batch: %lld haystack bytes in one call; split the batch into calls of <= %lld bytes",
+                        (long long)p->hay_capacity, (long long)ACX_MAX_LAUNCH_BYTES);
+    if (p->mode == ACX_SCAN_LONG && p->dev_init_state)
+        return acx_fail(ACX_E_UNSUPPORTED, "acx_scan_batch: init_state is not supported for ACX_SCAN_LONG");
+
+    hipStream_t s = (hipStream_t)stream_v;
+    acx_result* r = *result;
+    if (!r) {
+        r = new (std::nothrow) acx_result();
+        if (!r) return acx_fail(ACX_E_NOMEM, "acx_scan_batch: out of memory");
+        *result = r;
+    }
+    r->stream = s; r->n_hay = p->n_hay; r->total = 0; r->host_valid = false;
+    r->has_final = p->want_final_state != 0; r->timed = p->timing != 0;
+
+    const size_t n = (size_t)p->n_hay;
+    int rc;
+    if ((rc = r->counts.ensure(n + 1))) return rc;
+    if ((rc = r->nev.ensure(n + 1))) return rc;
+    if ((rc = r->match_off.ensure(n + 1))) return rc;
+    if ((rc = r->partials.ensure((size_t)acx_scan_num_partials(p->n_hay) + 2))) return rc;
+    if ((rc = r->events.ensure((size_t)p->hay_capacity + 1))) return rc;
+    if (r->has_final && (rc = r->final_state.ensure(n + 1))) return rc;
+    if ((rc = r->h_total.ensure(1))) return rc;
+    if (r->matches.cap == 0 && (rc = r->matches.ensure((size_t)(p->hay_capacity / 8) + 1024))) return rc;
+    if (r->timed) for (auto& e : r->ev) if (!e) HIP_TRY(hipEventCreate(&e));
+
+    acx_walk_args wa;
+    wa.hay = p->dev_hay; wa.hay_cap = p->hay_capacity; wa.off = p->dev_off; wa.stride = p->stride; wa.n_hay = p->n_hay;
+    wa.init_state = p->dev_init_state; wa.index_base = p->dev_index_base;
+    wa.cls = img->cls; wa.table = img->table; wa.out_off = img->out_off; wa.row_bytes = img->h.n_classes * 4u;
+    wa.counts = r->counts.p; wa.nev = r->nev.p; wa.events = r->events.p;
+    wa.final_state = r->has_final ? r->final_state.p : nullptr;
+
+    if (r->timed) HIP_TRY(hipEventRecord(r->ev[0], s));
+    if (p->mode == ACX_SCAN_ALL) HIP_TRY(acx_launch_walk_all(wa, img->h.has_escape != 0, p->variant, s));
+    else                         HIP_TRY(acx_launch_walk_long(wa, p->variant, s));
+    if (r->timed) HIP_TRY(hipEventRecord(r->ev[1], s));
+    HIP_TRY(acx_launch_scan(r->counts.p, p->n_hay, r->match_off.p, r->partials.p, s));
+    if (r->timed) HIP_TRY(hipEventRecord(r->ev[2], s));
+
+    acx_expand_args ea;
+    ea.off = p->dev_off; ea.stride = p->stride; ea.n_hay = p->n_hay; ea.nev = r->nev.p; ea.events = r->events.p;
+    ea.match_off = r->match_off.p; ea.out_off = img->out_off; ea.out_val = img->out_val;
+    ea.long_mode = p->mode == ACX_SCAN_LONG ? 1 : 0;
+    // Speculative launch with the capacity we already have: no host round trip between
+    // scan and expand in the steady state.  The kernel is a no-op if the total does not fit.
+    ea.matches = r->matches.p; ea.capacity = (int64_t)r->matches.cap;
+    HIP_TRY(acx_launch_expand(ea, p->variant, s));
+    if (r->timed) HIP_TRY(hipEventRecord(r->ev[3], s));
+    HIP_TRY(hipMemcpyAsync(r->h_total.p, r->match_off.p + p->n_hay, sizeof(int64_t), hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    r->total = r->h_total.p[0];
+    if (r->timed) {
+        HIP_TRY(hipEventElapsedTime(&r->t_walk, r->ev[0], r->ev[1]));
+        HIP_TRY(hipEventElapsedTime(&r->t_scan, r->ev[1], r->ev[2]));
+        HIP_TRY(hipEventElapsedTime(&r->t_expand, r->ev[2], r->ev[3]));
+        HIP_TRY(hipEventElapsedTime(&r->t_total, r->ev[0], r->ev[3]));
+    }
+    if (r->total > (int64_t)r->matches.cap) {
+        // first call / larger batch than ever seen: grow and run expand again (events are intact)
+        if ((rc = r->matches.ensure((size_t)r->total))) return rc;
+        ea.matches = r->matches.p; ea.capacity = (int64_t)r->matches.cap;
+        if (r->timed) HIP_TRY(hipEventRecord(r->ev[2], s));
+        HIP_TRY(acx_launch_expand(ea, p->variant, s));
+        if (r->timed) HIP_TRY(hipEventRecord(r->ev[3], s));
+        HIP_TRY(hipStreamSynchronize(s));
+        if (r->timed) {
+            HIP_TRY(hipEventElapsedTime(&r->t_expand, r->ev[2], r->ev[3]));
+            r->t_total = r->t_walk + r->t_scan + r->t_expand;
+        }
+    }
+    return ACX_OK;
+}
+
+extern "C" int64_t acx_result_num_matches(acx_result_t* r) { return r ? r->total : 0; }
+extern "C" const int64_t* acx_result_offsets_dev(acx_result_t* r) { return r ? r->match_off.p : nullptr; }
+extern "C" const acx_match_t* acx_result_matches_dev(acx_result_t* r) { return r ? (const acx_match_t*)r->matches.p : nullptr; }
+extern "C" const int32_t* acx_result_final_state_dev(acx_result_t* r) { return (r && r->has_final) ? r->final_state.p : nullptr; }
+
+extern "C" int acx_result_fetch_host(acx_result_t* r, const int64_t** off, const acx_match_t** matches, const int32_t** final_state) {
+    if (!r) return acx_fail(ACX_E_INVAL, "acx_result_fetch_host: NULL result");
+    if (!r->host_valid) {
+        int rc;
+        const size_t n = (size_t)r->n_hay;
+        if ((rc = r->h_off.ensure(n + 1))) return rc;
+        if ((rc = r->h_matches.ensure((size_t)r->total + 1))) return rc;
+        HIP_TRY(hipMemcpyAsync(r->h_off.p, r->match_off.p, (n + 1) * sizeof(int64_t), hipMemcpyDeviceToHost, r->stream));
+        if (r->total) HIP_TRY(hipMemcpyAsync(r->h_matches.p, r->matches.p, (size_t)r->total * sizeof(acx_match_t), hipMemcpyDeviceToHost, r->stream));
+        if (r->has_final) {
+            if ((rc = r->h_final.ensure(n + 1))) return rc;
+            if (n) HIP_TRY(hipMemcpyAsync(r->h_final.p, r->final_state.p, n * sizeof(int32_t), hipMemcpyDeviceToHost, r->stream));
+        }
+        HIP_TRY(hipStreamSynchronize(r->stream));
+        r->host_valid = true;
+    }
+    if (off) *off = r->h_off.p;
+    if (matches) *matches = r->h_matches.p;
+    if (final_state) *final_state = r->has_final ? r->h_final.p : nullptr;
+    return ACX_OK;
+}
+
+extern "C" int acx_result_timing(acx_result_t* r, float* walk_ms, float* scan_ms, float* expand_ms, float* total_ms) {
+    if (!r) return acx_fail(ACX_E_INVAL, "acx_result_timing: NULL result");
+    if (!r->timed) return acx_fail(ACX_E_STATE, "acx_result_timing: the last scan was not run with params.timing = 1");
+    if (walk_ms) *walk_ms = r->t_walk;
+    if (scan_ms) *scan_ms = r->t_scan;
+    if (expand_ms) *expand_ms = r->t_expand;
+    if (total_ms) *total_ms = r->t_total;
+    return ACX_OK;
+}
+
+extern "C" int acx_scan_host(acx_image_t* img, int mode, const uint8_t* hay, const int64_t* off, int64_t n_hay,
+                             const int32_t* init_state, const int32_t* index_base, acx_result_t** result) {
+    if (!img || !off || !result || n_hay < 0) return acx_fail(ACX_E_INVAL, "acx_scan_host: bad argument");
+    if (off[0] != 0) return acx_fail(ACX_E_INVAL, "acx_scan_host: off[0] must be 0");
+    for (int64_t h = 0; h < n_hay; h++) {
+        if (off[h + 1] < off[h]) return acx_fail(ACX_E_INVAL, "acx_scan_host: offsets not monotone at %lld", (long long)h);
+        if (off[h + 1] - off[h] > INT32_MAX) return acx_fail(ACX_E_INVAL, "acx_scan_host: haystack %lld longer than INT_MAX", (long long)h);
+    }
+    const int64_t total_bytes = off[n_hay];
+    if (total_bytes > 0 && !hay) return acx_fail(ACX_E_INVAL, "acx_scan_host: hay is NULL");
+    acx_result* r = *result;
+    if (!r) {
+        r = new (std::nothrow) acx_result();
+        if (!r) return acx_fail(ACX_E_NOMEM, "acx_scan_host: out of memory");
+        *result = r;
+    }
+    int rc;
+    if ((rc = r->in_hay.ensure((size_t)total_bytes + 64))) return rc;
+    if ((rc = r->in_off.ensure((size_t)n_hay + 1))) return rc;
+    if (total_bytes) HIP_TRY(hipMemcpy(r->in_hay.p, hay, (size_t)total_bytes, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(r->in_off.p, off, ((size_t)n_hay + 1) * sizeof(int64_t), hipMemcpyHostToDevice));
+    if (init_state) {
+        if ((rc = r->in_init.ensure((size_t)n_hay + 1))) return rc;
+        if (n_hay) HIP_TRY(hipMemcpy(r->in_init.p, init_state, (size_t)n_hay * 4, hipMemcpyHostToDevice));
+    }
+    if (index_base) {
+        if ((rc = r->in_base.ensure((size_t)n_hay + 1))) return rc;
+        if (n_hay) HIP_TRY(hipMemcpy(r->in_base.p, index_base, (size_t)n_hay * 4, hipMemcpyHostToDevice));
+    }
+    acx_scan_params p;
+    memset(&p, 0, sizeof p);
+    p.struct_bytes = sizeof p; p.mode = mode;
+    p.dev_hay = r->in_hay.p; p.hay_capacity = total_bytes; p.dev_off = r->in_off.p; p.stride = 0; p.n_hay = n_hay;
+    p.dev_init_state = init_state ? r->in_init.p : nullptr;
+    p.dev_index_base = index_base ? r->in_base.p : nullptr;
+    p.want_final_state = mode == ACX_SCAN_ALL ? 1 : 0;
+    return acx_scan_batch(img, &p, result, nullptr);
+}

@@ -1,0 +1,377 @@
+// acx_kernels.hip — hand-written CDNA4 (gfx950) kernels of the batch scan.
+//
+// The hot path of the reference is a serial, dependent pointer chase per input letter
+// (automaton_search_iter_next -> ahocorasick_next -> trienode_get_next, then the
+// unconditional fail-chain walk of automaton_build_output;
+// src/AutomatonSearchIter.c:157-197,243-300, src/trie.c:177-194, src/trienode.c:42-57).
+// Here it is re-expressed as three kernels over the flat image (include/acx_blob.h):
+//
+//   walk    one LANE per haystack, 64 independent DFA walks per wavefront.  Per input
+//           byte: one LDS read (byte -> class*4), one v_mad_u32_u24 (state*row_bytes +
+//           class*4), ONE 4-byte gather from the fail-resolved table.  The entry carries
+//           the target's output count, so counting matches costs a shift+add and no
+//           memory access; positions that have outputs append an 8-byte EVENT
+//           {end_index, entry} to a per-haystack staging region (capacity = haystack
+//           length, so it cannot overflow).  No MFMA: there is no contraction here, the
+//           work is latency/transaction bound integer gathers.
+//   scan    exclusive prefix sum of the per-haystack match counts -> match_off[].
+//   expand  one lane per haystack replays its events through the CSR output lists and
+//           writes the final (end_index, value) records at match_off[h] — reference
+//           order: position ascending, then the state's fail chain (longest key first).
+//
+// Haystack bytes are read 16 B per lane per 16 steps straight into registers
+// (global_load_dwordx4 at the lane's own address; neighbouring lanes read neighbouring
+// reads, every 64-B sector is consumed completely), so the per-byte VMEM budget goes to
+// the table gathers, which are what bounds the kernel (L2 transaction rate).
+#include "acx_kernels.h"
+#include "acx_blob.h"
+
+#define ACX_WAVE 64
+#define ACX_BLOCK 256
+
+namespace {
+
+__device__ __forceinline__ uint4 load16_unaligned(const uint8_t* p) {
+    uint4 v;
+    __builtin_memcpy(&v, p, 16);
+    return v;
+}
+
+// 16 bytes starting at p, never touching bytes at or beyond `limit`
+__device__ __forceinline__ uint4 load16_guarded(const uint8_t* p, const uint8_t* limit) {
+    if (p + 16 <= limit) return load16_unaligned(p);
+    // last 15 bytes of the buffer only: keep this cold path small (no unrolling)
+    uint64_t lo = 0, hi = 0;
+#pragma nounroll
+    for (int i = 0; i < 16 && p + i < limit; i++) {
+        const uint64_t v = (uint64_t)p[i] << ((i & 7) * 8);
+        if (i < 8) lo |= v; else hi |= v;
+    }
+    return make_uint4((uint32_t)lo, (uint32_t)(lo >> 32), (uint32_t)hi, (uint32_t)(hi >> 32));
+}
+
+// ---------------------------------------------------------------------------------
+// walk, ACX_SCAN_ALL
+// ---------------------------------------------------------------------------------
+struct LaneState {
+    uint32_t state;     // current table entry (low 24 bits = state id; v_mad_u32_u24 ignores the rest)
+    uint32_t cnt;       // matches so far
+    uint2*   ev;        // next free event slot
+};
+
+template <bool ESCAPE>
+__device__ __forceinline__ void step(uint32_t c4, uint32_t idx, const uint8_t* table_bytes,
+                                     uint32_t row_bytes, const uint32_t* out_off, LaneState& L) {
+    const uint32_t o  = __umul24(L.state, row_bytes) + c4;           // v_mad_u32_u24
+    const uint32_t e  = *(const uint32_t*)(table_bytes + o);         // the one gather per byte
+    L.state = e;
+    uint32_t c = e >> ACX_ENTRY_CNT_SHIFT;
+    if (c) {
+        if (ESCAPE) {
+            if (c == ACX_ENTRY_CNT_ESCAPE) {
+                const uint32_t s = e & ACX_ENTRY_STATE_MASK;
+                c = out_off[s + 1] - out_off[s];
+            }
+        }
+        *L.ev++ = make_uint2(idx, e);
+    }
+    L.cnt += c;
+}
+
+template <bool ESCAPE, bool GUARD>
+__device__ __forceinline__ void block16(const uint4 w, uint32_t idx0, int rem, const uint32_t* s_cls4,
+                                        const uint8_t* table_bytes, uint32_t row_bytes, const uint32_t* out_off,
+                                        LaneState& L) {
+    const uint32_t words[4] = {w.x, w.y, w.z, w.w};
+    // byte -> class*4 for the whole block first: these LDS reads do not depend on the
+    // state, so they are issued back to back here instead of sitting on the per-step
+    // dependent chain (mad -> gather -> mad -> ...).
+    uint32_t c4[16];
+#pragma unroll
+    for (int i = 0; i < 16; i++) c4[i] = s_cls4[(words[i >> 2] >> ((i & 3) * 8)) & 0xffu];
+#pragma unroll
+    for (int i = 0; i < 16; i++)
+        if (!GUARD || i < rem) step<ESCAPE>(c4[i], idx0 + i, table_bytes, row_bytes, out_off, L);
+}
+
+template <bool ESCAPE>
+__global__ void __launch_bounds__(ACX_BLOCK) k_walk_all(const acx_walk_args a) {
+    __shared__ uint32_t s_cls4[256];
+    s_cls4[threadIdx.x] = (uint32_t)a.cls[threadIdx.x] * 4u;   // blockDim.x == 256
+    __syncthreads();
+
+    const int lane = threadIdx.x & (ACX_WAVE - 1);
+    const int64_t waves_per_block = ACX_BLOCK / ACX_WAVE;
+    const int64_t n_tasks = (a.n_hay + ACX_WAVE - 1) / ACX_WAVE;
+    const int64_t wave0 = (int64_t)blockIdx.x * waves_per_block + (threadIdx.x / ACX_WAVE);
+    const int64_t n_waves = (int64_t)gridDim.x * waves_per_block;
+    const uint8_t* table_bytes = (const uint8_t*)a.table;
+    const uint8_t* limit = a.hay + a.hay_cap;
+
+    for (int64_t task = wave0; task < n_tasks; task += n_waves) {
+        const int64_t h = task * ACX_WAVE + lane;
+        const bool valid = h < a.n_hay;
+        int64_t b = 0, e = 0;
+        if (valid) {
+            if (a.off) { b = a.off[h]; e = a.off[h + 1]; }
+            else       { b = h * a.stride; e = b + a.stride; }
+        }
+        const int len = (int)(e - b);
+        const uint8_t* p = a.hay + b;
+        LaneState L;
+        L.state = (valid && a.init_state) ? (uint32_t)a.init_state[h] : 0u;
+        L.cnt = 0;
+        L.ev = a.events + b;
+        uint2* const ev0 = L.ev;
+        const uint32_t base = (valid && a.index_base) ? (uint32_t)a.index_base[h] : 0u;
+
+        for (int j0 = 0;; j0 += 16) {
+            const int rem = len - j0;
+            if (!__any(rem > 0)) break;
+            if (rem > 0) {   // lanes whose haystack is exhausted sit out; __all is over the active lanes
+                const uint4 w = load16_guarded(p + j0, limit);
+                if (__all(rem >= 16)) block16<ESCAPE, false>(w, base + j0, 16, s_cls4, table_bytes, a.row_bytes, a.out_off, L);
+                else                  block16<ESCAPE, true >(w, base + j0, rem, s_cls4, table_bytes, a.row_bytes, a.out_off, L);
+            }
+        }
+        if (valid) {
+            a.counts[h] = (int32_t)L.cnt;
+            a.nev[h] = (int32_t)(L.ev - ev0);
+            if (a.final_state) a.final_state[h] = (int32_t)(L.state & ACX_ENTRY_STATE_MASK);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------
+// walk, ACX_SCAN_LONG — the state machine of automaton_search_iter_long_next
+// (src/AutomatonSearchIterLong.c:89-153) on the flat table.  EDGE tells a real trie edge
+// (trienode_get_next, :116) from a fail-resolved transition; EOW / FAILEOW are the two
+// tests of :118-126 on the target.  A transition that is not an EDGE while a match is
+// remembered ends that match (:131-132) and restarts at root one past it (:105-106);
+// not an EDGE with nothing remembered is the fail walk of :134-143 followed by the edge
+// step of the next loop iteration — which is exactly the fail-resolved transition.
+// Every event is one final match: {end_index, state whose first output is the value}.
+// ---------------------------------------------------------------------------------
+__global__ void __launch_bounds__(ACX_BLOCK) k_walk_long(const acx_walk_args a) {
+    __shared__ uint32_t s_cls4[256];
+    s_cls4[threadIdx.x] = (uint32_t)a.cls[threadIdx.x] * 4u;
+    __syncthreads();
+
+    const int64_t n_threads = (int64_t)gridDim.x * ACX_BLOCK;
+    const uint8_t* table_bytes = (const uint8_t*)a.table;
+
+    for (int64_t h = (int64_t)blockIdx.x * ACX_BLOCK + threadIdx.x; h < a.n_hay; h += n_threads) {
+        int64_t b, e;
+        if (a.off) { b = a.off[h]; e = a.off[h + 1]; }
+        else       { b = h * a.stride; e = b + a.stride; }
+        const int len = (int)(e - b);
+        const uint8_t* p = a.hay + b;
+        uint2* ev = a.events + b;
+        uint2* const ev0 = ev;
+        const uint32_t base = a.index_base ? (uint32_t)a.index_base[h] : 0u;
+
+        uint32_t state = 0;
+        int index = 0;
+        bool have_last = false;
+        int last_index = -1;
+        uint32_t last_state = 0;
+        for (;;) {
+            bool emit = false;
+            if (index < len) {
+                const uint32_t c4 = s_cls4[p[index]];
+                const uint32_t en = *(const uint32_t*)(table_bytes + (__umul24(state, a.row_bytes) + c4));
+                const uint32_t next = en & ACX_ENTRY_STATE_MASK;
+                if (!(en & ACX_ENTRY_EDGE) && have_last) {
+                    emit = true;
+                } else if (next == 0) {
+                    state = 0; index++;
+                } else {
+                    if (en & ACX_ENTRY_EOW) {
+                        last_state = next; last_index = index; have_last = true;
+                        state = next; index++;
+                    } else if (en & ACX_ENTRY_FAILEOW) {
+                        last_state = next; last_index = index; have_last = true;
+                        emit = true;
+                    } else {
+                        state = next; index++;
+                    }
+                }
+            } else {
+                if (!have_last) break;
+                emit = true;
+            }
+            if (emit) {
+                *ev++ = make_uint2(base + (uint32_t)last_index, last_state);
+                state = 0; index = last_index + 1; have_last = false;
+            }
+        }
+        const int32_t n = (int32_t)(ev - ev0);
+        a.counts[h] = n;
+        a.nev[h] = n;
+        if (a.final_state) a.final_state[h] = 0;
+    }
+}
+
+// ---------------------------------------------------------------------------------
+// scan: exclusive prefix sum int32 counts[n] -> int64 match_off[n+1]
+// three small launches (per-block sums, one-block scan of the sums, per-block rescan)
+// ---------------------------------------------------------------------------------
+constexpr int SCAN_ITEMS = 16;                       // per thread
+constexpr int SCAN_TILE = ACX_BLOCK * SCAN_ITEMS;    // 4096 per block
+
+__device__ __forceinline__ int64_t wave_incl_scan(int64_t v, int lane) {
+#pragma unroll
+    for (int d = 1; d < ACX_WAVE; d <<= 1) {
+        const int64_t t = __shfl_up(v, d, ACX_WAVE);
+        if (lane >= d) v += t;
+    }
+    return v;
+}
+
+// inclusive scan across the block of one value per thread; returns inclusive value, total via *total
+__device__ __forceinline__ int64_t block_incl_scan(int64_t v, int64_t* s_wave /*[4]*/, int64_t* total) {
+    const int lane = threadIdx.x & (ACX_WAVE - 1), wid = threadIdx.x / ACX_WAVE;
+    const int64_t inc = wave_incl_scan(v, lane);
+    if (lane == ACX_WAVE - 1) s_wave[wid] = inc;
+    __syncthreads();
+    int64_t basev = 0, tot = 0;
+#pragma unroll
+    for (int w = 0; w < ACX_BLOCK / ACX_WAVE; w++) {
+        const int64_t x = s_wave[w];
+        if (w < wid) basev += x;
+        tot += x;
+    }
+    __syncthreads();
+    *total = tot;
+    return inc + basev;
+}
+
+__global__ void __launch_bounds__(ACX_BLOCK) k_scan_partials(const int32_t* counts, int64_t n, int64_t* partials) {
+    __shared__ int64_t s_wave[ACX_BLOCK / ACX_WAVE];
+    const int64_t base = (int64_t)blockIdx.x * SCAN_TILE;
+    int64_t sum = 0;
+#pragma unroll
+    for (int k = 0; k < SCAN_ITEMS; k++) {
+        const int64_t i = base + (int64_t)k * ACX_BLOCK + threadIdx.x;   // coalesced
+        if (i < n) sum += counts[i];
+    }
+    int64_t tot;
+    block_incl_scan(sum, s_wave, &tot);
+    if (threadIdx.x == 0) partials[blockIdx.x] = tot;
+}
+
+__global__ void __launch_bounds__(ACX_BLOCK) k_scan_top(int64_t* partials, int64_t np) {
+    __shared__ int64_t s_wave[ACX_BLOCK / ACX_WAVE];
+    int64_t carry = 0;
+    for (int64_t base = 0; base < np; base += ACX_BLOCK) {
+        const int64_t i = base + threadIdx.x;
+        const int64_t v = i < np ? partials[i] : 0;
+        int64_t tot;
+        const int64_t inc = block_incl_scan(v, s_wave, &tot);
+        if (i < np) partials[i] = carry + inc - v;      // exclusive
+        carry += tot;
+    }
+    if (threadIdx.x == 0) partials[np] = carry;          // grand total
+}
+
+__global__ void __launch_bounds__(ACX_BLOCK) k_scan_final(const int32_t* counts, int64_t n, const int64_t* partials,
+                                                          int64_t np, int64_t* match_off) {
+    __shared__ int64_t s_wave[ACX_BLOCK / ACX_WAVE];
+    // thread t owns SCAN_ITEMS consecutive items so its local prefix is a register loop
+    const int64_t first = (int64_t)blockIdx.x * SCAN_TILE + (int64_t)threadIdx.x * SCAN_ITEMS;
+    int32_t c[SCAN_ITEMS];
+    int64_t sum = 0;
+#pragma unroll
+    for (int k = 0; k < SCAN_ITEMS; k++) {
+        c[k] = (first + k < n) ? counts[first + k] : 0;
+        sum += c[k];
+    }
+    int64_t tot;
+    const int64_t inc = block_incl_scan(sum, s_wave, &tot);
+    int64_t run = partials[blockIdx.x] + inc - sum;
+#pragma unroll
+    for (int k = 0; k < SCAN_ITEMS; k++) {
+        if (first + k < n) match_off[first + k] = run;
+        run += c[k];
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) match_off[n] = partials[np];
+}
+
+// ---------------------------------------------------------------------------------
+// expand: events -> final records through the CSR output lists
+// ---------------------------------------------------------------------------------
+__global__ void __launch_bounds__(ACX_BLOCK) k_expand(const acx_expand_args a) {
+    // if the staging capacity guess was too small the host grows the buffer and relaunches
+    if (a.match_off[a.n_hay] > a.capacity) return;
+    const int64_t n_threads = (int64_t)gridDim.x * ACX_BLOCK;
+    for (int64_t h = (int64_t)blockIdx.x * ACX_BLOCK + threadIdx.x; h < a.n_hay; h += n_threads) {
+        const int32_t n = a.nev[h];
+        if (n == 0) continue;
+        const uint2* ev = a.events + (a.off ? a.off[h] : h * a.stride);
+        uint2* out = a.matches + a.match_off[h];
+        if (a.long_mode) {
+            for (int32_t k = 0; k < n; k++) {
+                const uint2 v = ev[k];
+                const int32_t val = a.out_val[a.out_off[v.y & ACX_ENTRY_STATE_MASK]];
+                *out++ = make_uint2(v.x, (uint32_t)val);
+            }
+        } else {
+            for (int32_t k = 0; k < n; k++) {
+                const uint2 v = ev[k];
+                const uint32_t s = v.y & ACX_ENTRY_STATE_MASK;
+                uint32_t c = v.y >> ACX_ENTRY_CNT_SHIFT;
+                const uint32_t o = a.out_off[s];
+                if (c == ACX_ENTRY_CNT_ESCAPE) c = a.out_off[s + 1] - o;
+                for (uint32_t r = 0; r < c; r++) *out++ = make_uint2(v.x, (uint32_t)a.out_val[o + r]);
+            }
+        }
+    }
+}
+
+inline int grid_for_waves(int64_t n_tasks) {
+    // 256 CUs x 8 blocks of 4 waves = the chip's 32 waves/CU; grid-stride the rest
+    const int64_t blocks = (n_tasks + (ACX_BLOCK / ACX_WAVE) - 1) / (ACX_BLOCK / ACX_WAVE);
+    const int64_t cap = 256 * 8;
+    return (int)(blocks < 1 ? 1 : (blocks > cap ? cap : blocks));
+}
+
+}  // namespace
+
+int64_t acx_scan_num_partials(int64_t n) { return (n + SCAN_TILE - 1) / SCAN_TILE; }
+
+hipError_t acx_launch_walk_all(const acx_walk_args& a, bool has_escape, int variant, hipStream_t s) {
+    (void)variant;
+    if (a.n_hay <= 0) return hipSuccess;
+    const int grid = grid_for_waves((a.n_hay + ACX_WAVE - 1) / ACX_WAVE);
+    if (has_escape) hipLaunchKernelGGL(k_walk_all<true>, dim3(grid), dim3(ACX_BLOCK), 0, s, a);
+    else            hipLaunchKernelGGL(k_walk_all<false>, dim3(grid), dim3(ACX_BLOCK), 0, s, a);
+    return hipGetLastError();
+}
+
+hipError_t acx_launch_walk_long(const acx_walk_args& a, int variant, hipStream_t s) {
+    (void)variant;
+    if (a.n_hay <= 0) return hipSuccess;
+    const int grid = grid_for_waves((a.n_hay + ACX_WAVE - 1) / ACX_WAVE);
+    hipLaunchKernelGGL(k_walk_long, dim3(grid), dim3(ACX_BLOCK), 0, s, a);
+    return hipGetLastError();
+}
+
+hipError_t acx_launch_scan(const int32_t* counts, int64_t n, int64_t* match_off, int64_t* partials, hipStream_t s) {
+    const int64_t np = acx_scan_num_partials(n);
+    if (n <= 0) {   // match_off[0] = 0
+        return hipMemsetAsync(match_off, 0, sizeof(int64_t), s);
+    }
+    hipLaunchKernelGGL(k_scan_partials, dim3((unsigned)np), dim3(ACX_BLOCK), 0, s, counts, n, partials);
+    hipLaunchKernelGGL(k_scan_top, dim3(1), dim3(ACX_BLOCK), 0, s, partials, np);
+    hipLaunchKernelGGL(k_scan_final, dim3((unsigned)np), dim3(ACX_BLOCK), 0, s, counts, n, (const int64_t*)partials, np, match_off);
+    return hipGetLastError();
+}
+
+hipError_t acx_launch_expand(const acx_expand_args& a, int variant, hipStream_t s) {
+    (void)variant;
+    if (a.n_hay <= 0) return hipSuccess;
+    const int64_t blocks = (a.n_hay + ACX_BLOCK - 1) / ACX_BLOCK;
+    const int grid = (int)(blocks > 256 * 8 ? 256 * 8 : blocks);
+    hipLaunchKernelGGL(k_expand, dim3(grid), dim3(ACX_BLOCK), 0, s, a);
+    return hipGetLastError();
+}

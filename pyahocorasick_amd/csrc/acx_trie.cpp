@@ -1,0 +1,430 @@
+// acx_trie.cpp — host side of libacx: arena trie, BFS failure links, flattener.
+//
+// CPU only (no HIP in this file).  Mirrors what stays on the CPU in the reference:
+//   trie_add_word / trie_find / trie_remove_word / trie_longest   src/trie.c:14-175
+//   automaton_add_word value + version rules                      src/Automaton.c:201-300
+//   automaton_make_automaton (BFS fail links)                     src/Automaton.c:560-649
+// and adds the step the reference does not have: flattening the finalised trie into the
+// contiguous image of include/acx_blob.h that the HIP kernels read.
+//
+// Design differences from the reference (deliberate, this is not a port):
+//   * nodes live in one std::vector (index links, no per-node malloc): 24 B/node
+//     instead of 32 B + a separately realloc'ed Pair array;
+//   * children are a sibling list in insertion order + a 256-way direct table at the
+//     root (the only node that is routinely wide);
+//   * BFS order is recorded by make_automaton and reused as the state numbering.
+#include "acx_internal.h"
+
+#include <cstdlib>
+#include <cstring>
+#include <new>
+#include <vector>
+
+namespace {
+
+struct Node {
+    int64_t value;
+    int32_t first_child;
+    int32_t next_sibling;
+    int32_t fail;
+    uint8_t letter;
+    uint8_t eow;
+    uint16_t pad;
+};
+static_assert(sizeof(Node) == 24, "Node layout");
+
+}  // namespace
+
+struct acx_trie {
+    std::vector<Node> nodes;        // nodes[0] = root once kind != EMPTY
+    int32_t root_child[256];        // direct index for the root's children (-1 = none)
+    std::vector<int32_t> bfs;       // BFS order recorded by make_automaton (root first)
+    int kind = ACX_KIND_EMPTY;
+    int64_t count = 0;
+    int64_t longest_word = 0;
+    int64_t version = 0;
+    int64_t live_nodes = 0;
+
+    acx_trie() { for (auto& c : root_child) c = -1; }
+
+    int32_t child(int32_t node, uint8_t letter) const {
+        if (node == 0) return root_child[letter];
+        for (int32_t c = nodes[node].first_child; c >= 0; c = nodes[c].next_sibling)
+            if (nodes[c].letter == letter) return c;
+        return -1;
+    }
+
+    int32_t new_node(uint8_t letter) {
+        Node n;
+        n.value = 0; n.first_child = -1; n.next_sibling = -1; n.fail = -1;
+        n.letter = letter; n.eow = 0; n.pad = 0;
+        nodes.push_back(n);
+        live_nodes++;
+        return (int32_t)nodes.size() - 1;
+    }
+
+    // append `c` at the end of `parent`'s sibling list (insertion order, like
+    // trienode_set_next, src/trienode.c:124-147)
+    void link_child(int32_t parent, int32_t c) {
+        int32_t* slot = &nodes[parent].first_child;
+        while (*slot >= 0) slot = &nodes[*slot].next_sibling;
+        *slot = c;
+        if (parent == 0) root_child[nodes[c].letter] = c;
+    }
+
+    void unlink_child(int32_t parent, int32_t c) {
+        int32_t* slot = &nodes[parent].first_child;
+        while (*slot >= 0 && *slot != c) slot = &nodes[*slot].next_sibling;
+        if (*slot == c) *slot = nodes[c].next_sibling;
+        if (parent == 0) root_child[nodes[c].letter] = -1;
+    }
+};
+
+extern "C" {
+
+int acx_trie_new(acx_trie_t** out) {
+    if (!out) return acx_fail(ACX_E_INVAL, "acx_trie_new: out is NULL");
+    acx_trie* t = new (std::nothrow) acx_trie();
+    if (!t) return acx_fail(ACX_E_NOMEM, "acx_trie_new: out of memory");
+    *out = t;
+    return ACX_OK;
+}
+
+void acx_trie_free(acx_trie_t* t) { delete t; }
+
+void acx_trie_clear(acx_trie_t* t) {
+    if (!t) return;
+    // automaton_clear, src/Automaton.c:405-416
+    t->nodes.clear(); t->nodes.shrink_to_fit();
+    t->bfs.clear(); t->bfs.shrink_to_fit();
+    for (auto& c : t->root_child) c = -1;
+    t->kind = ACX_KIND_EMPTY;
+    t->count = 0; t->longest_word = 0; t->live_nodes = 0;
+    t->version += 1;
+}
+
+int acx_trie_add_word(acx_trie_t* t, const uint8_t* key, size_t len, int64_t value, int* is_new) {
+    if (!t || (!key && len)) return acx_fail(ACX_E_INVAL, "acx_trie_add_word: NULL argument");
+    if (is_new) *is_new = 0;
+    if (len == 0) return ACX_OK;                       // src/Automaton.c:257: empty key ignored
+    try {
+        if (t->kind == ACX_KIND_EMPTY) t->new_node(0);  // root (src/trie.c:20-25)
+        int32_t node = 0;
+        for (size_t i = 0; i < len; i++) {
+            int32_t c = t->child(node, key[i]);
+            if (c < 0) {
+                c = t->new_node(key[i]);
+                t->link_child(node, c);
+            }
+            node = c;
+        }
+        Node& n = t->nodes[node];
+        bool fresh = !n.eow;
+        if (fresh) { n.eow = 1; t->count += 1; }        // src/trie.c:52-58
+        n.value = value;                                // src/Automaton.c:268-279
+        t->kind = ACX_KIND_TRIE;                        // src/trie.c:60
+        if (fresh) {
+            t->version += 1;                            // src/Automaton.c:283-286
+            if ((int64_t)len > t->longest_word) t->longest_word = (int64_t)len;
+        }
+        if (is_new) *is_new = fresh ? 1 : 0;
+    } catch (const std::bad_alloc&) {
+        return acx_fail(ACX_E_NOMEM, "acx_trie_add_word: out of memory");
+    }
+    return ACX_OK;
+}
+
+static int32_t find_node(const acx_trie* t, const uint8_t* key, size_t len) {
+    if (t->kind == ACX_KIND_EMPTY) return -1;
+    int32_t node = 0;
+    for (size_t i = 0; i < len; i++) {
+        node = t->child(node, key[i]);
+        if (node < 0) return -1;
+    }
+    return node;
+}
+
+int acx_trie_get(const acx_trie_t* t, const uint8_t* key, size_t len, int* found, int64_t* value) {
+    if (!t || !found) return acx_fail(ACX_E_INVAL, "acx_trie_get: NULL argument");
+    int32_t node = find_node(t, key, len);
+    *found = (node >= 0 && t->nodes[node].eow) ? 1 : 0;
+    if (*found && value) *value = t->nodes[node].value;
+    return ACX_OK;
+}
+
+int acx_trie_longest_prefix(const acx_trie_t* t, const uint8_t* key, size_t len, size_t* out_len) {
+    if (!t || !out_len) return acx_fail(ACX_E_INVAL, "acx_trie_longest_prefix: NULL argument");
+    size_t n = 0;
+    if (t->kind != ACX_KIND_EMPTY) {
+        int32_t node = 0;
+        for (size_t i = 0; i < len; i++) {              // trie_longest, src/trie.c:155-173
+            node = t->child(node, key[i]);
+            if (node < 0) break;
+            n++;
+        }
+    }
+    *out_len = n;
+    return ACX_OK;
+}
+
+int acx_trie_remove_word(acx_trie_t* t, const uint8_t* key, size_t len, int* found, int64_t* value) {
+    if (!t || !found) return acx_fail(ACX_E_INVAL, "acx_trie_remove_word: NULL argument");
+    *found = 0;
+    if (len == 0 || t->kind == ACX_KIND_EMPTY) return ACX_OK;
+    // trie_remove_word, src/trie.c:66-133: remember the deepest node on the path that
+    // must survive (has other children, or is itself a key), cut the tail below it.
+    int32_t node = 0, last_multiway = 0;
+    size_t last_multiway_index = 0;
+    for (size_t i = 0; i < len; i++) {
+        node = t->child(node, key[i]);
+        if (node < 0) return ACX_OK;
+        const Node& n = t->nodes[node];
+        bool one = n.first_child >= 0 && t->nodes[n.first_child].next_sibling < 0;
+        bool many = n.first_child >= 0 && !one;
+        if (many || (one && n.eow)) { last_multiway = node; last_multiway_index = i + 1; }
+    }
+    Node& n = t->nodes[node];
+    if (!n.eow) return ACX_OK;
+    if (value) *value = n.value;
+    if (n.first_child < 0) {
+        int32_t tail = t->child(last_multiway, key[last_multiway_index]);
+        t->unlink_child(last_multiway, tail);
+        t->live_nodes -= (int64_t)(len - last_multiway_index);   // arena slots are not reused
+    } else {
+        n.eow = 0;
+    }
+    t->kind = ACX_KIND_TRIE;                            // src/trie.c:131
+    t->version += 1;                                    // src/Automaton.c:341-342
+    t->count -= 1;
+    *found = 1;
+    return ACX_OK;
+}
+
+int acx_trie_make_automaton(acx_trie_t* t, int* changed) {
+    if (!t) return acx_fail(ACX_E_INVAL, "acx_trie_make_automaton: NULL trie");
+    if (changed) *changed = 0;
+    if (t->kind != ACX_KIND_TRIE) return ACX_OK;        // src/Automaton.c:574-575
+    try {
+        std::vector<int32_t>& q = t->bfs;
+        q.clear();
+        q.reserve((size_t)t->live_nodes);
+        q.push_back(0);
+        t->nodes[0].fail = -1;                          // root->fail stays NULL (src/trienode.c:19)
+        for (int32_t c = t->nodes[0].first_child; c >= 0; c = t->nodes[c].next_sibling) {
+            t->nodes[c].fail = 0;                       // src/Automaton.c:582-596
+            q.push_back(c);
+        }
+        for (size_t head = 1; head < q.size(); head++) {   // src/Automaton.c:599-637
+            int32_t node = q[head];
+            for (int32_t c = t->nodes[node].first_child; c >= 0; c = t->nodes[c].next_sibling) {
+                q.push_back(c);
+                uint8_t letter = t->nodes[c].letter;
+                int32_t state = t->nodes[node].fail;
+                while (state != 0 && t->child(state, letter) < 0) state = t->nodes[state].fail;
+                int32_t f = t->child(state, letter);
+                t->nodes[c].fail = f < 0 ? 0 : f;
+            }
+        }
+    } catch (const std::bad_alloc&) {
+        return acx_fail(ACX_E_NOMEM, "acx_trie_make_automaton: out of memory");
+    }
+    t->kind = ACX_KIND_AHOCORASICK;
+    t->version += 1;                                    // src/Automaton.c:639-640
+    if (changed) *changed = 1;
+    return ACX_OK;
+}
+
+int     acx_trie_kind(const acx_trie_t* t)         { return t ? t->kind : ACX_KIND_EMPTY; }
+int64_t acx_trie_num_keys(const acx_trie_t* t)     { return t ? t->count : 0; }
+int64_t acx_trie_num_nodes(const acx_trie_t* t)    { return t ? t->live_nodes : 0; }
+int64_t acx_trie_longest_word(const acx_trie_t* t) { return t ? t->longest_word : 0; }
+int64_t acx_trie_version(const acx_trie_t* t)      { return t ? t->version : 0; }
+
+// ------------------------------------------------------------------------------------
+// Flattener
+// ------------------------------------------------------------------------------------
+static inline size_t align_up(size_t x) { return (x + ACX_BLOB_ALIGN - 1) & ~(size_t)(ACX_BLOB_ALIGN - 1); }
+
+uint64_t acx_fnv1a64(const uint8_t* p, size_t n) {
+    // 8 interleaved-lane FNV-1a would be faster; the image is hashed once per flatten.
+    uint64_t h = 0xcbf29ce484222325ull;
+    for (size_t i = 0; i < n; i++) { h ^= p[i]; h *= 0x100000001b3ull; }
+    return h;
+}
+
+int acx_flatten(const acx_trie_t* t, void** blob_out, size_t* nbytes_out) {
+    if (!t || !blob_out || !nbytes_out) return acx_fail(ACX_E_INVAL, "acx_flatten: NULL argument");
+    if (t->kind != ACX_KIND_AHOCORASICK)
+        return acx_fail(ACX_E_STATE, "acx_flatten: not an Aho-Corasick automaton yet: call make_automaton first");
+    const size_t n = t->bfs.size();
+    if (n >= ((size_t)1 << ACX_ENTRY_STATE_BITS))
+        return acx_fail(ACX_E_UNSUPPORTED, "acx_flatten: %zu states exceed the %d-bit state field of this image layout",
+                        n, ACX_ENTRY_STATE_BITS);
+
+    // 1. byte classes: class 0 = bytes used by no key (they all lead to the root)
+    bool used[256] = {false};
+    for (size_t i = 1; i < n; i++) used[t->nodes[t->bfs[i]].letter] = true;
+    uint8_t cls[256];
+    unsigned n_used = 0;
+    for (int b = 0; b < 256; b++) n_used += used[b];
+    uint32_t K;
+    if (n_used == 256) { K = 256; for (int b = 0; b < 256; b++) cls[b] = (uint8_t)b; }
+    else { K = n_used + 1; unsigned k = 1; for (int b = 0; b < 256; b++) cls[b] = used[b] ? (uint8_t)k++ : 0; }
+
+    const size_t table_entries = n * (size_t)K;
+    if (table_entries * 4 >= ((size_t)1 << 32))
+        return acx_fail(ACX_E_UNSUPPORTED, "acx_flatten: transition table of %zu bytes exceeds the 4 GiB "
+                        "32-bit-offset layout of this build", table_entries * 4);
+
+    std::vector<int32_t> id;          // arena index -> BFS id
+    std::vector<uint32_t> out_cnt;    // per BFS id
+    uint64_t n_out = 0;
+    uint32_t max_cnt = 0;
+    try {
+        id.assign(t->nodes.size(), -1);
+        for (size_t i = 0; i < n; i++) id[t->bfs[i]] = (int32_t)i;
+        out_cnt.assign(n, 0);
+        for (size_t i = 1; i < n; i++) {  // BFS order: fail(s) is shallower, hence already done
+            const Node& nd = t->nodes[t->bfs[i]];
+            uint32_t c = (nd.eow ? 1u : 0u) + out_cnt[id[nd.fail]];
+            out_cnt[i] = c;
+            n_out += c;
+            if (c > max_cnt) max_cnt = c;
+        }
+    } catch (const std::bad_alloc&) {
+        return acx_fail(ACX_E_NOMEM, "acx_flatten: out of memory");
+    }
+    if (n_out >= ((uint64_t)1 << 32))
+        return acx_fail(ACX_E_UNSUPPORTED, "acx_flatten: %llu output entries exceed uint32 CSR offsets",
+                        (unsigned long long)n_out);
+
+    // 2. layout
+    acx_blob_header h;
+    memset(&h, 0, sizeof h);
+    size_t off = ACX_BLOB_HEADER_BYTES;
+    h.off_cls = off;        off = align_up(off + 256);
+    h.off_table = off;      off = align_up(off + table_entries * 4);
+    h.off_fail = off;       off = align_up(off + n * 4);
+    h.off_node_val = off;   off = align_up(off + n * 4);
+    h.off_node_flags = off; off = align_up(off + n);
+    h.off_out_off = off;    off = align_up(off + (n + 1) * 4);
+    h.off_out_val = off;    off = align_up(off + (size_t)n_out * 4 + 4);
+    const size_t total = off;
+
+    uint8_t* blob = (uint8_t*)calloc(1, total);
+    if (!blob) return acx_fail(ACX_E_NOMEM, "acx_flatten: cannot allocate %zu bytes for the image", total);
+
+    memcpy(blob + h.off_cls, cls, 256);
+    uint32_t* table   = (uint32_t*)(blob + h.off_table);
+    int32_t*  fail    = (int32_t*)(blob + h.off_fail);
+    int32_t*  nval    = (int32_t*)(blob + h.off_node_val);
+    uint8_t*  nflags  = (uint8_t*)(blob + h.off_node_flags);
+    uint32_t* out_off = (uint32_t*)(blob + h.off_out_off);
+    int32_t*  out_val = (int32_t*)(blob + h.off_out_val);
+
+    // 3. per-target facts + CSR outputs (chain order: s first, then fail(s)'s list)
+    std::vector<uint32_t> tflags;
+    try { tflags.assign(n, 0); } catch (const std::bad_alloc&) { free(blob); return acx_fail(ACX_E_NOMEM, "acx_flatten: out of memory"); }
+    {
+        uint32_t o = 0;
+        fail[0] = -1;
+        for (size_t i = 0; i < n; i++) {
+            const Node& nd = t->nodes[t->bfs[i]];
+            out_off[i] = o;
+            if (i == 0) continue;
+            const int32_t f = id[nd.fail];
+            fail[i] = f;
+            nval[i] = nd.eow ? (int32_t)(uint32_t)(uint64_t)nd.value : 0;   // "ii" truncation, src/AutomatonSearchIter.c:180-184
+            nflags[i] = nd.eow ? 1 : 0;
+            if (nd.eow) out_val[o++] = nval[i];
+            const uint32_t fc = out_cnt[f];
+            if (fc) { memcpy(out_val + o, out_val + out_off[f], (size_t)fc * 4); o += fc; }
+            uint32_t fl = 0;
+            if (nd.eow) fl |= ACX_ENTRY_EOW;
+            if (f != 0 && t->nodes[nd.fail].eow) fl |= ACX_ENTRY_FAILEOW;   // src/AutomatonSearchIterLong.c:123
+            const uint32_t c = out_cnt[i];
+            fl |= (c >= ACX_ENTRY_CNT_ESCAPE ? ACX_ENTRY_CNT_ESCAPE : c) << ACX_ENTRY_CNT_SHIFT;
+            tflags[i] = fl;
+        }
+        out_off[n] = o;
+    }
+
+    // 4. dense fail-resolved rows: row(s) = row(fail(s)) with EDGE cleared, then own edges.
+    //    row(root): every class loops to the root except its own edges.
+    for (size_t i = 0; i < n; i++) {
+        uint32_t* row = table + i * K;
+        if (i > 0) {
+            const uint32_t* frow = table + (size_t)fail[i] * K;
+            for (uint32_t c = 0; c < K; c++) row[c] = frow[c] & ~ACX_ENTRY_EDGE;
+        }
+        for (int32_t ch = t->nodes[t->bfs[i]].first_child; ch >= 0; ch = t->nodes[ch].next_sibling) {
+            const uint32_t tid = (uint32_t)id[ch];
+            row[cls[t->nodes[ch].letter]] = tid | tflags[tid] | ACX_ENTRY_EDGE;
+        }
+    }
+
+    h.magic = ACX_BLOB_MAGIC;
+    h.version = ACX_BLOB_VERSION;
+    h.header_bytes = ACX_BLOB_HEADER_BYTES;
+    h.total_bytes = total;
+    h.n_states = (uint32_t)n;
+    h.n_classes = K;
+    h.n_keys = (uint32_t)t->count;
+    h.longest_word = (uint32_t)t->longest_word;
+    h.max_out_count = max_cnt;
+    h.has_escape = max_cnt >= ACX_ENTRY_CNT_ESCAPE ? 1 : 0;
+    h.n_out = n_out;
+    h.trie_version = (uint64_t)t->version;
+    h.fnv1a64 = acx_fnv1a64(blob + ACX_BLOB_HEADER_BYTES, total - ACX_BLOB_HEADER_BYTES);
+    memcpy(blob, &h, sizeof h);
+
+    *blob_out = blob;
+    *nbytes_out = total;
+    return ACX_OK;
+}
+
+void acx_blob_free(void* blob) { free(blob); }
+
+int acx_blob_check_header(const acx_blob_header* h, size_t nbytes) {
+    if (nbytes < ACX_BLOB_HEADER_BYTES) return acx_fail(ACX_E_FORMAT, "image: %zu bytes is shorter than the header", nbytes);
+    if (h->magic != ACX_BLOB_MAGIC) return acx_fail(ACX_E_FORMAT, "image: bad magic");
+    if (h->version != ACX_BLOB_VERSION) return acx_fail(ACX_E_FORMAT, "image: version %u, this build reads %u", h->version, ACX_BLOB_VERSION);
+    if (h->header_bytes != ACX_BLOB_HEADER_BYTES || h->total_bytes != nbytes)
+        return acx_fail(ACX_E_FORMAT, "image: size mismatch (header says %llu, got %zu)", (unsigned long long)h->total_bytes, nbytes);
+    if (h->n_states == 0 || h->n_states >= (1u << ACX_ENTRY_STATE_BITS) || h->n_classes == 0 || h->n_classes > 256)
+        return acx_fail(ACX_E_FORMAT, "image: bad n_states/n_classes");
+    const uint64_t n = h->n_states, K = h->n_classes;
+    struct { uint64_t off, len; } sec[] = {
+        {h->off_cls, 256}, {h->off_table, n * K * 4}, {h->off_fail, n * 4}, {h->off_node_val, n * 4},
+        {h->off_node_flags, n}, {h->off_out_off, (n + 1) * 4}, {h->off_out_val, h->n_out * 4},
+    };
+    for (auto& s : sec)
+        if (s.off % ACX_BLOB_ALIGN || s.off < ACX_BLOB_HEADER_BYTES || s.off + s.len > nbytes)
+            return acx_fail(ACX_E_FORMAT, "image: section out of bounds");
+    if (n * K * 4 >= (1ull << 32)) return acx_fail(ACX_E_FORMAT, "image: table too large for 32-bit offsets");
+    return ACX_OK;
+}
+
+int acx_blob_validate(const void* blob, size_t nbytes) {
+    if (!blob) return acx_fail(ACX_E_INVAL, "acx_blob_validate: NULL blob");
+    acx_blob_header h;
+    if (nbytes < sizeof h) return acx_fail(ACX_E_FORMAT, "image: truncated");
+    memcpy(&h, blob, sizeof h);
+    int rc = acx_blob_check_header(&h, nbytes);
+    if (rc) return rc;
+    const uint8_t* b = (const uint8_t*)blob;
+    if (acx_fnv1a64(b + ACX_BLOB_HEADER_BYTES, nbytes - ACX_BLOB_HEADER_BYTES) != h.fnv1a64)
+        return acx_fail(ACX_E_FORMAT, "image: checksum mismatch");
+    // structural checks: every entry targets a valid state; CSR is monotone and ends at n_out
+    const uint32_t* table = (const uint32_t*)(b + h.off_table);
+    const uint64_t ne = (uint64_t)h.n_states * h.n_classes;
+    for (uint64_t i = 0; i < ne; i++)
+        if ((table[i] & ACX_ENTRY_STATE_MASK) >= h.n_states) return acx_fail(ACX_E_FORMAT, "image: entry %llu targets a state out of range", (unsigned long long)i);
+    const uint32_t* oo = (const uint32_t*)(b + h.off_out_off);
+    for (uint32_t s = 0; s < h.n_states; s++)
+        if (oo[s] > oo[s + 1]) return acx_fail(ACX_E_FORMAT, "image: CSR offsets not monotone at state %u", s);
+    if (oo[h.n_states] != h.n_out) return acx_fail(ACX_E_FORMAT, "image: CSR end does not match n_out");
+    return ACX_OK;
+}
+
+}  // extern "C"

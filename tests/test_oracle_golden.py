@@ -1,0 +1,167 @@
+"""CPU suite, part 1: PIN THE ORACLE.
+
+oracle/ac_oracle.c (the restatement of the reference algorithm) is checked against
+ (a) the known-answer vectors of the reference's own tests (golden/ref_vectors.json),
+ (b) fixtures produced by running the reference itself (golden/ref_random.json),
+ (c) the reference module live, when oracle/_ref is present (build container).
+Then the product's CPU-side pieces (libacx host trie + flattener) are checked against the
+pinned oracle by walking the flat image with oracle/flat_walk.c — no GPU involved.
+"""
+import random
+
+import pytest
+
+from helpers import build_pair, expected_pairs, i32, load_json
+from oracle import orc
+
+
+def _oracle_from(keys, values):
+    O = orc.Oracle()
+    for k, v in zip(keys, values):
+        O.add_word(k, v)
+    O.make_automaton()
+    return O
+
+
+VECTORS = load_json("ref_vectors.json")["vectors"]
+RANDOM = load_json("ref_random.json")
+
+
+@pytest.mark.parametrize("v", VECTORS, ids=[v["id"] for v in VECTORS])
+def test_oracle_matches_reference_test_vectors(v):
+    keys = [bytes.fromhex(k) for k in v["keys_hex"]]
+    hay = bytes.fromhex(v["hay_hex"])
+    O = _oracle_from(keys, range(len(keys)))
+    s = 0 if v["start"] is None else v["start"]
+    e = len(hay) if v["end"] is None else v["end"]
+    got = O.iter_long(hay, s, e) if v["mode"] == "iter_long" else O.iter(hay, s, e)
+    assert got == expected_pairs(v["expected"]), v["source"]
+
+
+def _case_values(c):
+    keys = [bytes.fromhex(k) for k in c["keys_hex"]]
+    if c["store"] == "length":
+        return keys, [len(k) for k in keys]
+    if c["store"] == "ints_default":
+        vals, seen = [], set()
+        for k in keys:
+            vals.append(len(seen) + 1)       # src/Automaton.c:238-242: count + 1 at insertion time
+            seen.add(k)
+        return keys, vals
+    return keys, c["values"]
+
+
+@pytest.mark.parametrize("c", RANDOM["cases"], ids=[c["id"] for c in RANDOM["cases"]])
+def test_oracle_matches_reference_generated_fixtures(c):
+    keys, values = _case_values(c)
+    O = _oracle_from(keys, values)
+    for h in c["hays"]:
+        hay = bytes.fromhex(h["hay_hex"])
+        assert O.iter(hay) == expected_pairs(h["iter"])
+        assert O.iter(hay) == expected_pairs(h["find_all"])          # iter == find_all (tests/test_issue_56.py)
+        assert O.iter_long(hay) == expected_pairs(h["iter_long"])
+        if "slice" in h:
+            s, e = h["slice"]["start"], h["slice"]["end"]
+            assert O.iter(hay, s, e) == expected_pairs(h["slice"]["iter"])
+            assert O.iter(hay, s, e) == expected_pairs(h["slice"]["find_all"])
+            assert O.iter_long(hay, s, e) == expected_pairs(h["slice"]["iter_long"])
+    # chunked streaming: state carried over, shift accumulated (src/AutomatonSearchIter.c:344-352)
+    state, shift = 0, 0
+    for part_hex, exp in zip(c["chunks"]["parts_hex"], c["chunks"]["iter_set"]):
+        part = bytes.fromhex(part_hex)
+        e, v, state = O.iter_arrays(part, state=state, shift=shift)
+        assert list(zip(e.tolist(), v.tolist())) == expected_pairs(exp)
+        shift += len(part)
+
+
+@pytest.mark.parametrize("c", RANDOM["special"], ids=[c["id"] for c in RANDOM["special"]])
+def test_oracle_matches_reference_special_cases(c):
+    keys = [bytes.fromhex(k) for k in c["keys_hex"]]
+    if c["store"] == "length":
+        values = [len(k) for k in keys]
+    else:
+        values = [v if v is not None else i + 1 for i, v in enumerate(c["values"])]
+    O = _oracle_from(keys, values)
+    hay = bytes.fromhex(c["hay_hex"])
+    assert O.iter(hay) == expected_pairs(c["iter"])
+    assert O.iter_long(hay) == expected_pairs(c["iter_long"])
+
+
+def test_oracle_vs_live_reference_randomised():
+    """differential test against the reference module itself (build container only)"""
+    ref = orc.load_reference()
+    if ref is None:
+        pytest.skip("oracle/_ref not present (reference sources absent on this machine)")
+    rng = random.Random(7)
+    for trial in range(60):
+        alpha = rng.choice([b"ab", b"ACGT", bytes([0x61, 0x80, 0xFF]), bytes(range(256))])
+        keys = list({bytes(rng.choice(alpha) for _ in range(rng.randint(1, 7))) for _ in range(rng.randint(1, 40))})
+        vals = [rng.randint(-2**40, 2**40) for _ in keys]
+        R = ref.Automaton(ref.STORE_INTS)
+        for k, v in zip(keys, vals):
+            R.add_word(k, v)
+        R.make_automaton()
+        O = _oracle_from(keys, vals)
+        for _ in range(10):
+            hay = bytes(rng.choice(alpha) for _ in range(rng.randint(0, 120)))
+            assert O.iter(hay) == list(R.iter(hay))
+            assert O.iter_long(hay) == list(R.iter_long(hay))
+            assert O.iter(hay, ignore_ws=True) == list(R.iter(hay, ignore_white_space=True))
+
+
+# ----------------------------------------------------------------------------------------
+# product CPU pieces (host trie, BFS fail links, flattener) vs the pinned oracle
+# ----------------------------------------------------------------------------------------
+@pytest.mark.parametrize("c", RANDOM["cases"], ids=[c["id"] for c in RANDOM["cases"]])
+def test_flat_image_walk_matches_reference_fixtures(c):
+    keys, values = _case_values(c)
+    A, O = build_pair(keys, values if c["store"] not in ("length", "ints_default") else None, c["store"])
+    blob = A.flat_image_bytes()
+    for h in c["hays"]:
+        hay = bytes.fromhex(h["hay_hex"])
+        exp = expected_pairs(h["iter"])
+        if c["store"] == "any":
+            pass  # values are ids == ordinals == the stored ints
+        got, _ = orc.flat_iter(blob, hay)
+        assert got == exp
+        assert orc.flat_iter_long(blob, hay) == expected_pairs(h["iter_long"])
+    state, shift = 0, 0
+    for part_hex, exp in zip(c["chunks"]["parts_hex"], c["chunks"]["iter_set"]):
+        part = bytes.fromhex(part_hex)
+        got, state = orc.flat_iter(blob, part, state=state, index_base=shift)
+        assert got == expected_pairs(exp)
+        shift += len(part)
+
+
+def test_flat_image_walk_randomised_vs_oracle():
+    rng = random.Random(11)
+    for trial in range(40):
+        alpha = rng.choice([b"ab", b"abc", b"ACGT", bytes([0x61, 0x80, 0xFF, 0x00]), bytes(range(256))])
+        keys = list({bytes(rng.choice(alpha) for _ in range(rng.randint(1, 9))) for _ in range(rng.randint(1, 60))})
+        vals = [rng.randint(-2**40, 2**40) for _ in keys]
+        A, O = build_pair(keys, vals)
+        blob = A.flat_image_bytes()
+        for _ in range(8):
+            hay = bytes(rng.choice(alpha) for _ in range(rng.randint(0, 200)))
+            got, fin = orc.flat_iter(blob, hay)
+            assert got == O.iter(hay)
+            assert orc.flat_iter_long(blob, hay) == O.iter_long(hay)
+
+
+def test_flat_image_escape_counts():
+    """a state with more than 30 outputs uses the escape count (include/acx_blob.h)"""
+    keys = [b"a" * n for n in range(1, 41)]
+    A, O = build_pair(keys, list(range(100, 140)))
+    blob = A.flat_image_bytes()
+    hay = b"a" * 50
+    got, _ = orc.flat_iter(blob, hay)
+    assert got == O.iter(hay)
+    assert len(got) == sum(min(i + 1, 40) for i in range(50))
+    assert orc.flat_iter_long(blob, hay) == O.iter_long(hay)
+
+
+def test_int_truncation_matches_reference_probe():
+    A, O = build_pair([b"ab", b"b"], [2**40 + 5, -3])
+    got, _ = orc.flat_iter(A.flat_image_bytes(), b"xabx")
+    assert got == [(2, 5), (2, -3)] == O.iter(b"xabx")
+    assert i32(2**40 + 5) == 5
