@@ -104,6 +104,15 @@ def lib():
             "pyahocorasick_amd: %s is missing. Build it with "
             "`python -m pyahocorasick_amd.build` (needs hipcc; cross-compiles for gfx950 without a GPU). "
             "There is no CPU fallback." % LIB_PATH)
+    # ONE HIP runtime per process.  PyTorch wheels bundle their own libamdhip64 (same SONAME
+    # as /opt/rocm's).  If torch is imported first, the dynamic loader resolves our
+    # DT_NEEDED libamdhip64.so.7 to torch's already-loaded copy and both share one runtime
+    # (device pointers and streams are then interchangeable).  Loaded the other way round the
+    # process would end up with two runtimes — so when torch is installed but not yet
+    # imported and the caller asked for it (ACX_WITH_TORCH=1), import it here first.
+    import sys
+    if os.environ.get("ACX_WITH_TORCH") == "1" and "torch" not in sys.modules:
+        import torch  # noqa: F401
     try:
         l = C.CDLL(LIB_PATH)
     except OSError as e:

@@ -39,6 +39,9 @@ def build_libacx(force=False, verbose=True):
         return LIB
     cmd = [_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
            "-Wall", "-Wno-unused-function",
+           # code object v5 loads on every ROCm >= 5.x runtime, including the HIP runtime that
+           # PyTorch wheels bundle (a process must only ever hold ONE HIP runtime: see _lib.py)
+           "-mcode-object-version=5",
            "-I" + os.path.join(ROOT, "include"), "-I" + CSRC,
            "-o", LIB] + [os.path.join(CSRC, s) for s in SOURCES]
     if verbose:

@@ -52,6 +52,10 @@ __device__ __forceinline__ uint4 load16_guarded(const uint8_t* p, const uint8_t*
 
 // ---------------------------------------------------------------------------------
 // walk, ACX_SCAN_ALL
+//   ESCAPE : some state has >= 31 outputs, the packed count may be the escape value
+//   ILP    : haystacks per lane walked as interleaved, independent dependency chains
+//            (2 doubles the table gathers in flight per wave without more waves)
+//   EVENTS : false = count only (diagnostic variant: isolates the cost of event stores)
 // ---------------------------------------------------------------------------------
 struct LaneState {
     uint32_t state;     // current table entry (low 24 bits = state id; v_mad_u32_u24 ignores the rest)
@@ -59,85 +63,145 @@ struct LaneState {
     uint2*   ev;        // next free event slot
 };
 
-template <bool ESCAPE>
+template <bool ESCAPE, bool EVENTS>
 __device__ __forceinline__ void step(uint32_t c4, uint32_t idx, const uint8_t* table_bytes,
                                      uint32_t row_bytes, const uint32_t* out_off, LaneState& L) {
     const uint32_t o  = __umul24(L.state, row_bytes) + c4;           // v_mad_u32_u24
     const uint32_t e  = *(const uint32_t*)(table_bytes + o);         // the one gather per byte
     L.state = e;
-    uint32_t c = e >> ACX_ENTRY_CNT_SHIFT;
-    if (c) {
-        if (ESCAPE) {
-            if (c == ACX_ENTRY_CNT_ESCAPE) {
-                const uint32_t s = e & ACX_ENTRY_STATE_MASK;
-                c = out_off[s + 1] - out_off[s];
+    if (EVENTS || ESCAPE) {
+        // count inside the (rarely lane-wide) branch: nothing but the gather, one compare and
+        // the branch stays on the common path, and no entry has to be kept live for later
+        if (e >> ACX_ENTRY_CNT_SHIFT) {
+            uint32_t c = e >> ACX_ENTRY_CNT_SHIFT;
+            if (ESCAPE) {
+                if (c == ACX_ENTRY_CNT_ESCAPE) {
+                    const uint32_t s = e & ACX_ENTRY_STATE_MASK;
+                    c = out_off[s + 1] - out_off[s];
+                }
             }
+            if (EVENTS) *L.ev++ = make_uint2(idx, e);
+            L.cnt += c;
         }
-        *L.ev++ = make_uint2(idx, e);
+    } else {
+        L.cnt += e >> ACX_ENTRY_CNT_SHIFT;
     }
-    L.cnt += c;
 }
 
-template <bool ESCAPE, bool GUARD>
+// byte -> class*4 for 8 haystack bytes.  These LDS reads do not depend on the state, so
+// they are issued back to back ahead of the 8 dependent steps (mad -> gather -> mad ...)
+// instead of one LDS round trip per step.
+__device__ __forceinline__ void classes8(uint32_t w0, uint32_t w1, const uint32_t* s_cls4, uint32_t (&c4)[8]) {
+#pragma unroll
+    for (int i = 0; i < 4; i++) c4[i] = s_cls4[(w0 >> (i * 8)) & 0xffu];
+#pragma unroll
+    for (int i = 0; i < 4; i++) c4[4 + i] = s_cls4[(w1 >> (i * 8)) & 0xffu];
+}
+
+template <bool ESCAPE, bool EVENTS, bool GUARD>
 __device__ __forceinline__ void block16(const uint4 w, uint32_t idx0, int rem, const uint32_t* s_cls4,
                                         const uint8_t* table_bytes, uint32_t row_bytes, const uint32_t* out_off,
                                         LaneState& L) {
-    const uint32_t words[4] = {w.x, w.y, w.z, w.w};
-    // byte -> class*4 for the whole block first: these LDS reads do not depend on the
-    // state, so they are issued back to back here instead of sitting on the per-step
-    // dependent chain (mad -> gather -> mad -> ...).
-    uint32_t c4[16];
+    uint32_t c4[8];
+    classes8(w.x, w.y, s_cls4, c4);
 #pragma unroll
-    for (int i = 0; i < 16; i++) c4[i] = s_cls4[(words[i >> 2] >> ((i & 3) * 8)) & 0xffu];
+    for (int i = 0; i < 8; i++)
+        if (!GUARD || i < rem) step<ESCAPE, EVENTS>(c4[i], idx0 + i, table_bytes, row_bytes, out_off, L);
+    classes8(w.z, w.w, s_cls4, c4);
 #pragma unroll
-    for (int i = 0; i < 16; i++)
-        if (!GUARD || i < rem) step<ESCAPE>(c4[i], idx0 + i, table_bytes, row_bytes, out_off, L);
+    for (int i = 0; i < 8; i++)
+        if (!GUARD || 8 + i < rem) step<ESCAPE, EVENTS>(c4[i], idx0 + 8 + i, table_bytes, row_bytes, out_off, L);
 }
 
-template <bool ESCAPE>
-__global__ void __launch_bounds__(ACX_BLOCK) k_walk_all(const acx_walk_args a) {
+// second __launch_bounds__ argument = waves per SIMD the register allocation must allow:
+// the kernel is bound by memory latency/transactions, so ILP=1 wants all 8 (<= 64 VGPRs).
+template <bool ESCAPE, int ILP, bool EVENTS>
+__global__ void __launch_bounds__(ACX_BLOCK, ILP == 1 ? 8 : 5) k_walk_all(const acx_walk_args a) {
     __shared__ uint32_t s_cls4[256];
     s_cls4[threadIdx.x] = (uint32_t)a.cls[threadIdx.x] * 4u;   // blockDim.x == 256
     __syncthreads();
 
     const int lane = threadIdx.x & (ACX_WAVE - 1);
     const int64_t waves_per_block = ACX_BLOCK / ACX_WAVE;
-    const int64_t n_tasks = (a.n_hay + ACX_WAVE - 1) / ACX_WAVE;
+    const int64_t per_task = (int64_t)ACX_WAVE * ILP;
+    const int64_t n_tasks = (a.n_hay + per_task - 1) / per_task;
     const int64_t wave0 = (int64_t)blockIdx.x * waves_per_block + (threadIdx.x / ACX_WAVE);
     const int64_t n_waves = (int64_t)gridDim.x * waves_per_block;
     const uint8_t* table_bytes = (const uint8_t*)a.table;
     const uint8_t* limit = a.hay + a.hay_cap;
 
     for (int64_t task = wave0; task < n_tasks; task += n_waves) {
-        const int64_t h = task * ACX_WAVE + lane;
-        const bool valid = h < a.n_hay;
-        int64_t b = 0, e = 0;
-        if (valid) {
-            if (a.off) { b = a.off[h]; e = a.off[h + 1]; }
-            else       { b = h * a.stride; e = b + a.stride; }
+        int64_t h[ILP];
+        bool valid[ILP];
+        int len[ILP];
+        const uint8_t* p[ILP];
+        LaneState L[ILP];
+        uint2* ev0[ILP];
+        uint32_t base[ILP];
+#pragma unroll
+        for (int q = 0; q < ILP; q++) {
+            h[q] = task * per_task + (int64_t)q * ACX_WAVE + lane;   // neighbouring lanes, neighbouring reads
+            valid[q] = h[q] < a.n_hay;
+            int64_t b = 0, e = 0;
+            if (valid[q]) {
+                if (a.off) { b = a.off[h[q]]; e = a.off[h[q] + 1]; }
+                else       { b = h[q] * a.stride; e = b + a.stride; }
+            }
+            len[q] = (int)(e - b);
+            p[q] = a.hay + b;
+            L[q].state = (valid[q] && a.init_state) ? (uint32_t)a.init_state[h[q]] : 0u;
+            L[q].cnt = 0;
+            L[q].ev = a.events + b;
+            ev0[q] = L[q].ev;
+            base[q] = (valid[q] && a.index_base) ? (uint32_t)a.index_base[h[q]] : 0u;
         }
-        const int len = (int)(e - b);
-        const uint8_t* p = a.hay + b;
-        LaneState L;
-        L.state = (valid && a.init_state) ? (uint32_t)a.init_state[h] : 0u;
-        L.cnt = 0;
-        L.ev = a.events + b;
-        uint2* const ev0 = L.ev;
-        const uint32_t base = (valid && a.index_base) ? (uint32_t)a.index_base[h] : 0u;
 
         for (int j0 = 0;; j0 += 16) {
-            const int rem = len - j0;
-            if (!__any(rem > 0)) break;
-            if (rem > 0) {   // lanes whose haystack is exhausted sit out; __all is over the active lanes
-                const uint4 w = load16_guarded(p + j0, limit);
-                if (__all(rem >= 16)) block16<ESCAPE, false>(w, base + j0, 16, s_cls4, table_bytes, a.row_bytes, a.out_off, L);
-                else                  block16<ESCAPE, true >(w, base + j0, rem, s_cls4, table_bytes, a.row_bytes, a.out_off, L);
+            int rem[ILP];
+            bool any_left = false, all_full = true;
+#pragma unroll
+            for (int q = 0; q < ILP; q++) {
+                rem[q] = len[q] - j0;
+                any_left = any_left || rem[q] > 0;
+                all_full = all_full && rem[q] >= 16;
+            }
+            if (!__any(any_left)) break;
+            if (ILP > 1 && __all(all_full)) {
+                // every chain of every lane has a full block: interleave the chains step by step
+                uint4 w[ILP];
+#pragma unroll
+                for (int q = 0; q < ILP; q++) w[q] = load16_guarded(p[q] + j0, limit);
+#pragma unroll
+                for (int half = 0; half < 2; half++) {
+                    uint32_t c4[ILP][8];
+#pragma unroll
+                    for (int q = 0; q < ILP; q++)
+                        classes8(half ? w[q].z : w[q].x, half ? w[q].w : w[q].y, s_cls4, c4[q]);
+#pragma unroll
+                    for (int i = 0; i < 8; i++) {
+#pragma unroll
+                        for (int q = 0; q < ILP; q++)
+                            step<ESCAPE, EVENTS>(c4[q][i], base[q] + j0 + half * 8 + i, table_bytes, a.row_bytes, a.out_off, L[q]);
+                    }
+                }
+                continue;
+            }
+#pragma unroll
+            for (int q = 0; q < ILP; q++) {
+                if (rem[q] > 0) {   // lanes whose haystack is exhausted sit out; __all is over the active lanes
+                    const uint4 w = load16_guarded(p[q] + j0, limit);
+                    if (__all(rem[q] >= 16)) block16<ESCAPE, EVENTS, false>(w, base[q] + j0, 16, s_cls4, table_bytes, a.row_bytes, a.out_off, L[q]);
+                    else                     block16<ESCAPE, EVENTS, true >(w, base[q] + j0, rem[q], s_cls4, table_bytes, a.row_bytes, a.out_off, L[q]);
+                }
             }
         }
-        if (valid) {
-            a.counts[h] = (int32_t)L.cnt;
-            a.nev[h] = (int32_t)(L.ev - ev0);
-            if (a.final_state) a.final_state[h] = (int32_t)(L.state & ACX_ENTRY_STATE_MASK);
+#pragma unroll
+        for (int q = 0; q < ILP; q++) {
+            if (valid[q]) {
+                a.counts[h[q]] = (int32_t)L[q].cnt;
+                a.nev[h[q]] = (int32_t)(L[q].ev - ev0[q]);
+                if (a.final_state) a.final_state[h[q]] = (int32_t)(L[q].state & ACX_ENTRY_STATE_MASK);
+            }
         }
     }
 }
@@ -339,12 +403,36 @@ inline int grid_for_waves(int64_t n_tasks) {
 
 int64_t acx_scan_num_partials(int64_t n) { return (n + SCAN_TILE - 1) / SCAN_TILE; }
 
+// variant encoding (bench/tuning knob; 0 = default):
+//   bits 0-3  ILP - 1            (0 -> one haystack per lane, 1 -> two)
+//   bits 4-7  blocks per CU      (0 -> 8)
+//   bit  8    count only, no events (diagnostic; the result then has no matches)
+template <bool ESCAPE, int ILP, bool EVENTS>
+static void launch_walk_all_t(const acx_walk_args& a, int blocks_per_cu, hipStream_t s) {
+    const int64_t per_task = (int64_t)ACX_WAVE * ILP;
+    const int64_t n_tasks = (a.n_hay + per_task - 1) / per_task;
+    const int64_t blocks = (n_tasks + (ACX_BLOCK / ACX_WAVE) - 1) / (ACX_BLOCK / ACX_WAVE);
+    const int64_t cap = 256 * (int64_t)blocks_per_cu;
+    const int grid = (int)(blocks < 1 ? 1 : (blocks > cap ? cap : blocks));
+    hipLaunchKernelGGL((k_walk_all<ESCAPE, ILP, EVENTS>), dim3(grid), dim3(ACX_BLOCK), 0, s, a);
+}
+
 hipError_t acx_launch_walk_all(const acx_walk_args& a, bool has_escape, int variant, hipStream_t s) {
-    (void)variant;
     if (a.n_hay <= 0) return hipSuccess;
-    const int grid = grid_for_waves((a.n_hay + ACX_WAVE - 1) / ACX_WAVE);
-    if (has_escape) hipLaunchKernelGGL(k_walk_all<true>, dim3(grid), dim3(ACX_BLOCK), 0, s, a);
-    else            hipLaunchKernelGGL(k_walk_all<false>, dim3(grid), dim3(ACX_BLOCK), 0, s, a);
+    const int ilp = (variant & 0xF) + 1;
+    int bpc = (variant >> 4) & 0xF;
+    if (bpc == 0) bpc = 8;
+    const bool events = !((variant >> 8) & 1);
+    if (ilp > 2) return hipErrorInvalidValue;
+#define ACX_DISPATCH(E, I, V) launch_walk_all_t<E, I, V>(a, bpc, s)
+    if (has_escape) {
+        if (ilp == 1) { if (events) ACX_DISPATCH(true, 1, true); else ACX_DISPATCH(true, 1, false); }
+        else          { if (events) ACX_DISPATCH(true, 2, true); else ACX_DISPATCH(true, 2, false); }
+    } else {
+        if (ilp == 1) { if (events) ACX_DISPATCH(false, 1, true); else ACX_DISPATCH(false, 1, false); }
+        else          { if (events) ACX_DISPATCH(false, 2, true); else ACX_DISPATCH(false, 2, false); }
+    }
+#undef ACX_DISPATCH
     return hipGetLastError();
 }
 

@@ -1,0 +1,171 @@
+"""Device-resident batch scanning: thin Python handles over the C-ABI for callers that keep
+their haystacks in HBM (bench.py, pipelines that receive reads straight into device
+buffers, torch users passing `tensor.data_ptr()`).
+
+Nothing here computes: it only owns handles and forwards raw pointers to libacx.
+"""
+import ctypes as C
+
+import numpy as np
+
+from ._lib import ACX_SCAN_ALL, ACX_BLOB_HEADER_BYTES, ScanParams, check, lib
+
+
+class DeviceBuffer:
+    """hipMalloc'ed bytes owned by libacx (no torch needed)."""
+
+    def __init__(self, nbytes):
+        self.ptr = C.c_void_p()
+        self.nbytes = int(nbytes)
+        check(lib().acx_dev_malloc(C.byref(self.ptr), self.nbytes))
+
+    @classmethod
+    def from_numpy(cls, arr, pad=0):
+        arr = np.ascontiguousarray(arr)
+        b = cls(arr.nbytes + pad)
+        if arr.nbytes:
+            check(lib().acx_memcpy_h2d(b.ptr, arr.ctypes.data, arr.nbytes))
+        return b
+
+    def to_numpy(self, dtype, count):
+        out = np.empty(count, dtype=dtype)
+        if out.nbytes:
+            check(lib().acx_memcpy_d2h(out.ctypes.data, self.ptr, out.nbytes))
+        return out
+
+    def free(self):
+        if self.ptr:
+            lib().acx_dev_free(self.ptr)
+            self.ptr = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+class Image:
+    """A flat automaton resident in HBM.  Build from an Automaton (`Image.from_automaton`),
+    from blob bytes, or adopt a device buffer that already holds the blob (the receive
+    side of the RCCL broadcast)."""
+
+    def __init__(self, handle, keepalive=None):
+        self.handle = handle
+        self._keepalive = keepalive
+
+    @classmethod
+    def from_blob(cls, blob_bytes):
+        h = C.c_void_p()
+        buf = (C.c_char * len(blob_bytes)).from_buffer_copy(blob_bytes)
+        check(lib().acx_image_upload(buf, len(blob_bytes), C.byref(h)))
+        return cls(h)
+
+    @classmethod
+    def from_automaton(cls, automaton):
+        return cls.from_blob(automaton.flat_image_bytes())
+
+    @classmethod
+    def adopt(cls, dev_ptr, nbytes, host_header, keepalive=None):
+        h = C.c_void_p()
+        hdr = (C.c_char * ACX_BLOB_HEADER_BYTES).from_buffer_copy(bytes(host_header[:ACX_BLOB_HEADER_BYTES]))
+        check(lib().acx_image_adopt(C.c_void_p(dev_ptr), nbytes, hdr, C.byref(h)))
+        return cls(h, keepalive)
+
+    @property
+    def num_states(self):
+        return lib().acx_image_num_states(self.handle)
+
+    @property
+    def num_classes(self):
+        return lib().acx_image_num_classes(self.handle)
+
+    @property
+    def nbytes(self):
+        return lib().acx_image_nbytes(self.handle)
+
+    def free(self):
+        if self.handle:
+            lib().acx_image_free(self.handle)
+            self.handle = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+class Scanner:
+    """Reusable scan context: owns one acx_result_t (device + pinned buffers are reused
+    across calls, so the steady state allocates nothing)."""
+
+    def __init__(self, image):
+        self.image = image
+        self._res = C.c_void_p()
+        self.n_hay = 0
+
+    def scan(self, dev_hay, hay_capacity, n_hay, dev_off=None, stride=0, mode=ACX_SCAN_ALL,
+             dev_init_state=None, dev_index_base=None, want_final_state=False, timing=False,
+             variant=0, stream=None):
+        """All pointer arguments are raw device addresses (int / c_void_p / None)."""
+        p = ScanParams()
+        p.struct_bytes = C.sizeof(ScanParams)
+        p.mode = mode
+        p.dev_hay = _addr(dev_hay)
+        p.hay_capacity = int(hay_capacity)
+        p.dev_off = _addr(dev_off)
+        p.stride = int(stride)
+        p.n_hay = int(n_hay)
+        p.dev_init_state = _addr(dev_init_state)
+        p.dev_index_base = _addr(dev_index_base)
+        p.want_final_state = 1 if want_final_state else 0
+        p.timing = 1 if timing else 0
+        p.variant = int(variant)
+        check(lib().acx_scan_batch(self.image.handle, C.byref(p), C.byref(self._res), _addr(stream)))
+        self.n_hay = int(n_hay)
+        return lib().acx_result_num_matches(self._res)
+
+    def timing_ms(self):
+        w, s, e, t = C.c_float(), C.c_float(), C.c_float(), C.c_float()
+        check(lib().acx_result_timing(self._res, C.byref(w), C.byref(s), C.byref(e), C.byref(t)))
+        return {"walk": w.value, "scan": s.value, "expand": e.value, "total": t.value}
+
+    def num_matches(self):
+        return lib().acx_result_num_matches(self._res)
+
+    def fetch(self):
+        """-> (match_off int64[n+1], end_index int32[], value int32[], final_state or None) on the host"""
+        p_off, p_m, p_f = C.c_void_p(), C.c_void_p(), C.c_void_p()
+        check(lib().acx_result_fetch_host(self._res, C.byref(p_off), C.byref(p_m), C.byref(p_f)))
+        n, total = self.n_hay, self.num_matches()
+        off = np.ctypeslib.as_array(C.cast(p_off, C.POINTER(C.c_int64)), shape=(n + 1,)).copy()
+        if total:
+            m = np.ctypeslib.as_array(C.cast(p_m, C.POINTER(C.c_int32)), shape=(total, 2)).copy()
+        else:
+            m = np.zeros((0, 2), dtype=np.int32)
+        fin = None
+        if p_f and n:
+            fin = np.ctypeslib.as_array(C.cast(p_f, C.POINTER(C.c_int32)), shape=(n,)).copy()
+        return off, m[:, 0], m[:, 1], fin
+
+    def free(self):
+        if self._res:
+            lib().acx_result_free(self._res)
+            self._res = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+def _addr(x):
+    if x is None:
+        return None
+    if isinstance(x, C.c_void_p):
+        return x
+    if isinstance(x, DeviceBuffer):
+        return x.ptr
+    return C.c_void_p(int(x))

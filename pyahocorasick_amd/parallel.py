@@ -1,0 +1,90 @@
+"""Multi-GPU plumbing: one process per GPU, `torch.distributed` with the
+"nccl" backend (= RCCL over xGMI on ROCm).
+
+The path shards embarrassingly: haystacks are independent, so each rank scans a
+contiguous slice of the batch and there is NO collective on the data path.  The only
+collective is at setup: the flat automaton image (one contiguous blob, include/acx_blob.h)
+is replicated from the rank that built it with ONE broadcast.  Results are concatenated in
+rank order, which is the order a sequential scan of the whole batch produces.
+
+torch is used for device memory and the process group only; the scan itself is libacx.
+The same functions run on CPU tensors with the "gloo" backend (tests/test_parallel_cpu.py)
+— there they move bytes and partition work, they never scan.
+"""
+import numpy as np
+
+from ._lib import ACX_BLOB_HEADER_BYTES
+
+
+def shard_range(n_items, rank, world):
+    """contiguous, balanced-by-count slice [lo, hi) of rank `rank`"""
+    lo = (n_items * rank) // world
+    hi = (n_items * (rank + 1)) // world
+    return lo, hi
+
+
+def shard_range_by_bytes(offsets, rank, world):
+    """contiguous slice balanced by BYTES (variable-length haystacks): rank r takes
+    the haystacks whose start offset falls in [r*total/world, (r+1)*total/world)."""
+    off = np.asarray(offsets, dtype=np.int64)
+    total = int(off[-1])
+    n = len(off) - 1
+    cuts = [int(np.searchsorted(off[:-1], (total * r) // world, side="left")) for r in range(world + 1)]
+    cuts[0], cuts[-1] = 0, n
+    return cuts[rank], cuts[rank + 1]
+
+
+def broadcast_blob(blob, src=0, device=None):
+    """Replicate the flat image bytes.  Returns a uint8 tensor on `device` holding the blob on
+    every rank.  ONE broadcast for the payload (preceded by an 8-byte size broadcast so the
+    receivers can allocate)."""
+    import torch
+    import torch.distributed as dist
+    distributed = dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+    device = device if device is not None else torch.device("cpu")
+    if not distributed:
+        t = torch.frombuffer(bytearray(blob), dtype=torch.uint8)
+        return t.to(device)
+    rank = dist.get_rank()
+    size = torch.tensor([len(blob) if rank == src else 0], dtype=torch.int64, device=device)
+    dist.broadcast(size, src=src)
+    nbytes = int(size.item())
+    if rank == src:
+        t = torch.frombuffer(bytearray(blob), dtype=torch.uint8).to(device)
+    else:
+        t = torch.empty(nbytes, dtype=torch.uint8, device=device)
+    dist.broadcast(t, src=src)          # the single RCCL broadcast of the automaton
+    return t
+
+
+def broadcast_image(blob, src=0, device=None):
+    """broadcast_blob + adopt the received device buffer as a libacx image (no extra copy).
+    Returns (Image, tensor); the Image keeps the tensor alive."""
+    from .device import Image
+    t = broadcast_blob(blob, src, device)
+    if t.device.type != "cuda":
+        raise RuntimeError("broadcast_image needs a GPU tensor; the scan has no CPU path")
+    header = bytes(t[:ACX_BLOB_HEADER_BYTES].cpu().numpy().tobytes())
+    img = Image.adopt(t.data_ptr(), t.numel(), header, keepalive=t)
+    return img, t
+
+
+def gather_csr(local_off, local_end, local_val, dst=0):
+    """Concatenate per-rank CSR results in rank order on `dst` (host side; results of
+    different haystacks are independent, so this IS the sequential order).  Returns
+    (match_off, end_index, value) on dst, None elsewhere."""
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return local_off, local_end, local_val
+    world, rank = dist.get_world_size(), dist.get_rank()
+    parts = [None] * world if rank == dst else None
+    dist.gather_object((np.asarray(local_off), np.asarray(local_end), np.asarray(local_val)), parts, dst=dst)
+    if rank != dst:
+        return None
+    offs, ends, vals, base = [np.zeros(1, dtype=np.int64)], [], [], 0
+    for o, e, v in parts:
+        offs.append(o[1:] + base)
+        base += int(o[-1])
+        ends.append(e)
+        vals.append(v)
+    return np.concatenate(offs), np.concatenate(ends), np.concatenate(vals)

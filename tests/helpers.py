@@ -49,22 +49,4 @@ def expected_pairs(pairs):
     return [(int(i), int(v)) for i, v in pairs]
 
 
-def dna_workload(n_keys, n_reads, read_len, seed=0, klo=8, khi=32, plant=True):
-    """SURVEY §8(d) config-2 style generator, scaled: unique ACGT keys of length U[klo,khi]
-    (sorted then shuffled), reads uniform over ACGT, every even read gets one key planted."""
-    rng = random.Random(seed)
-    keys = set()
-    while len(keys) < n_keys:
-        keys.add("".join(rng.choice("ACGT") for _ in range(rng.randint(klo, khi))).encode())
-    keys = sorted(keys)
-    rng.shuffle(keys)
-    r2 = np.random.default_rng(seed + 1)
-    reads = np.frombuffer(b"ACGT", dtype=np.uint8)[r2.integers(0, 4, size=(n_reads, read_len))]
-    reads = np.ascontiguousarray(reads)
-    if plant:
-        for i in range(0, n_reads, 2):
-            k = keys[int(r2.integers(0, len(keys)))]
-            if len(k) <= read_len:
-                o = int(r2.integers(0, read_len - len(k) + 1))
-                reads[i, o:o + len(k)] = np.frombuffer(k, dtype=np.uint8)
-    return keys, reads
+from pyahocorasick_amd.workloads import dna_workload, dna_keys, dna_reads  # noqa: E402,F401

@@ -1,0 +1,291 @@
+"""GPU suite (-m gpu): parity of the HIP path, called through the C-ABI, against
+ (1) the committed golden fixtures (reference test vectors + reference-generated),
+ (2) the pinned CPU oracle on seeded inputs the oracle finishes in seconds,
+ (3) size-independent properties at the full BASELINE.json config-2 size.
+Bit-exact: every comparison is list/array equality of int32 (end_index, value) records.
+Nothing here reads /root/reference.
+"""
+import numpy as np
+import pytest
+
+import pyahocorasick_amd as acx
+from pyahocorasick_amd.device import DeviceBuffer, Image, Scanner
+from helpers import build_pair, dna_workload, expected_pairs, load_json
+from oracle import orc
+
+pytestmark = pytest.mark.gpu
+
+VECTORS = load_json("ref_vectors.json")["vectors"]
+RANDOM = load_json("ref_random.json")
+
+
+def _case_values(c):
+    keys = [bytes.fromhex(k) for k in c["keys_hex"]]
+    if c["store"] in ("length", "ints_default"):
+        return keys, None
+    return keys, c["values"]
+
+
+# ------------------------------------------------------------------ golden fixtures
+@pytest.mark.parametrize("v", VECTORS, ids=[v["id"] for v in VECTORS])
+def test_reference_test_vectors(v):
+    keys = [bytes.fromhex(k) for k in v["keys_hex"]]
+    hay = bytes.fromhex(v["hay_hex"])
+    A, _ = build_pair(keys)
+    exp = expected_pairs(v["expected"])
+    rng = [] if v["start"] is None else ([v["start"]] if v["end"] is None else [v["start"], v["end"]])
+    if v["mode"] == "iter":
+        got = list(A.iter(hay, *rng))
+    elif v["mode"] == "iter_long":
+        got = list(A.iter_long(hay, *rng))
+    else:
+        got = []
+        A.find_all(hay, lambda i, val: got.append((i, val)), *rng)
+    assert got == exp, v["source"]
+
+
+@pytest.mark.parametrize("c", RANDOM["cases"], ids=[c["id"] for c in RANDOM["cases"]])
+def test_reference_generated_fixtures(c):
+    keys, values = _case_values(c)
+    A, _ = build_pair(keys, values, c["store"])
+    hays = [bytes.fromhex(h["hay_hex"]) for h in c["hays"]]
+    assert A.iter_batch(hays) == [expected_pairs(h["iter"]) for h in c["hays"]]
+    assert A.iter_batch(hays, long=True) == [expected_pairs(h["iter_long"]) for h in c["hays"]]
+    for h, hay in zip(c["hays"], hays):
+        if "slice" in h:
+            s, e = h["slice"]["start"], h["slice"]["end"]
+            assert list(A.iter(hay, s, e)) == expected_pairs(h["slice"]["iter"])
+            if s < len(hay):
+                assert list(A.iter_long(hay, s, e)) == expected_pairs(h["slice"]["iter_long"])
+                got = []
+                A.find_all(hay, lambda i, v: got.append((i, v)), s, e)
+                assert got == expected_pairs(h["slice"]["find_all"])
+    # streaming through set(): state and shift carried across chunks
+    it = A.iter(b"")
+    for part_hex, exp in zip(c["chunks"]["parts_hex"], c["chunks"]["iter_set"]):
+        it.set(bytes.fromhex(part_hex))
+        assert list(it) == expected_pairs(exp)
+
+
+@pytest.mark.parametrize("c", RANDOM["special"], ids=[c["id"] for c in RANDOM["special"]])
+def test_reference_special_cases(c):
+    keys = [bytes.fromhex(k) for k in c["keys_hex"]]
+    A, _ = build_pair(keys, c["values"], c["store"])
+    hay = bytes.fromhex(c["hay_hex"])
+    assert list(A.iter(hay)) == expected_pairs(c["iter"])
+    assert list(A.iter_long(hay)) == expected_pairs(c["iter_long"])
+
+
+def test_store_any_returns_objects_in_reference_order():
+    A = acx.Automaton()
+    for i, w in enumerate(b"he e hers his she hi him man he".split()):
+        A.add_word(w, (i, w))
+    A.make_automaton()
+    q = b"he rshershidamanza "
+    assert list(A.iter(q, 2, 8)) == [(6, (4, b"she")), (6, (8, b"he")), (6, (1, b"e"))]   # reference tests/test_basic.py:31-32
+
+
+def test_ignore_white_space():                     # reference tests/test_unit.py:813-849
+    A = acx.Automaton()
+    for w in "he her hers she".split():
+        A.add_word(w.encode(), w)
+    A.make_automaton()
+    s = b"_sh e rher she_"
+    exp = [(4, "she"), (4, "he"), (6, "her"), (8, "he"), (9, "her"), (11, "hers"), (13, "she"), (13, "he")]
+    assert list(A.iter(s, ignore_white_space=True)) == exp
+    assert list(A.iter(s, ignore_white_space=True, start=12)) == [(13, "he")]
+
+
+def test_iterator_invalidation_and_image_refresh():   # reference tests/test_unit.py:860-879
+    A = acx.Automaton(acx.STORE_INTS)
+    A.add_word(b"he", 1)
+    A.make_automaton()
+    it = A.iter(b"hehe")
+    assert next(it) == (1, 1)
+    A.add_word(b"she", 2)
+    with pytest.raises(ValueError):
+        next(it)
+    with pytest.raises(AttributeError):
+        A.iter(b"she")                       # kind fell back to TRIE
+    A.make_automaton()
+    assert list(A.iter(b"she")) == [(2, 2), (2, 1)]   # the device image was rebuilt for the new version
+
+
+# ------------------------------------------------------------------ edge cases
+def test_empty_and_ragged_batches():
+    keys = [b"a", b"ab", b"bab", b"\xff\x80", b"b" * 17]
+    A, O = build_pair(keys)
+    assert A.iter_batch([]) == []
+    assert A.iter_batch([b""]) == [[]]
+    rng = np.random.default_rng(5)
+    hays = [bytes(rng.choice(np.frombuffer(b"ab\xff\x80z", dtype=np.uint8), size=n).tobytes())
+            for n in [0, 1, 2, 15, 16, 17, 31, 32, 33, 63, 64, 65, 0, 255, 256, 257, 1000, 0, 3]]
+    hays += [b"", b"ab" * 700, b"b" * 40, b""]
+    assert A.iter_batch(hays) == [O.iter(h) for h in hays]
+    assert A.iter_batch(hays, long=True) == [O.iter_long(h) for h in hays]
+    # more haystacks than one wavefront / one block, lengths 0..90
+    many = [bytes(rng.choice(np.frombuffer(b"ab", dtype=np.uint8), size=int(n)).tobytes())
+            for n in rng.integers(0, 91, size=1500)]
+    assert A.iter_batch(many) == [O.iter(h) for h in many]
+    assert A.iter_batch(many, long=True) == [O.iter_long(h) for h in many]
+
+
+def test_escape_counts_on_gpu():
+    keys = [b"a" * n for n in range(1, 41)]
+    A, O = build_pair(keys, list(range(100, 140)))
+    hays = [b"a" * 50, b"", b"a" * 7 + b"b" + b"a" * 45]
+    assert A.iter_batch(hays) == [O.iter(h) for h in hays]
+    assert A.iter_batch(hays, long=True) == [O.iter_long(h) for h in hays]
+
+
+def test_full_byte_alphabet_256_classes():
+    rng = np.random.default_rng(9)
+    keys = list({bytes(rng.integers(0, 256, size=int(n), dtype=np.uint8).tobytes()) for n in rng.integers(1, 4, size=3000)})
+    assert len({k[0] for k in keys}) == 256          # every byte value used: 256 classes, no "other"
+    A, O = build_pair(keys)
+    hays = [bytes(rng.integers(0, 256, size=int(n), dtype=np.uint8).tobytes()) for n in rng.integers(0, 400, size=300)]
+    assert A.iter_batch(hays) == [O.iter(h) for h in hays]
+    assert A.iter_batch(hays, long=True) == [O.iter_long(h) for h in hays]
+
+
+def test_one_large_haystack_and_state_carry():
+    keys, reads = dna_workload(2000, 1, 300_000, seed=3, klo=4, khi=12)
+    A, O = build_pair(keys)
+    hay = reads[0].tobytes()
+    e, v, fin = O.iter_arrays(hay)
+    res = A.scan_batch(hay, [0, len(hay)])
+    assert np.array_equal(res.end_index, e) and np.array_equal(res.value, v)
+    # split anywhere, carry the state, shift the indices: identical stream (set() semantics)
+    cut = 123_457
+    r1 = A.scan_batch(hay[:cut], [0, cut])
+    r2 = A.scan_batch(hay[cut:], [0, len(hay) - cut], init_state=[int(r1.final_state[0])], index_base=[cut])
+    assert np.array_equal(np.concatenate([r1.end_index, r2.end_index]), e)
+    assert np.array_equal(np.concatenate([r1.value, r2.value]), v)
+
+
+# ------------------------------------------------------------------ seeded workloads vs oracle
+@pytest.mark.parametrize("mode", [acx.ACX_SCAN_ALL, acx.ACX_SCAN_LONG], ids=["iter", "iter_long"])
+def test_dna_workload_vs_oracle(mode):
+    """config-2/5 shape at a size the oracle finishes in seconds: 5k keys, 20k x 150 B reads"""
+    keys, reads = dna_workload(5000, 20000, 150, seed=0)
+    A, O = build_pair(keys)
+    n, L = reads.shape
+    off = np.arange(n + 1, dtype=np.int64) * L
+    res = A.scan_batch(reads.reshape(-1), off, mode)
+    mo, e, v = O.batch(reads.tobytes(), off, mode)
+    assert np.array_equal(res.offsets, mo)
+    assert np.array_equal(res.end_index, e)
+    assert np.array_equal(res.value, v)
+    assert res.num_matches() > n            # the workload does produce matches
+
+
+def test_device_resident_fixed_stride_entry_point():
+    """the entry bench.py uses: inputs already in HBM, no offsets array (stride), timing on"""
+    keys, reads = dna_workload(3000, 4096 + 37, 150, seed=2)
+    A, O = build_pair(keys)
+    n, L = reads.shape
+    img = Image.from_automaton(A)
+    d_hay = DeviceBuffer.from_numpy(reads.reshape(-1), pad=64)
+    sc = Scanner(img)
+    total = sc.scan(d_hay, n * L, n, stride=L, timing=True, want_final_state=True)
+    off, e, v, fin = sc.fetch()
+    mo, oe, ov = O.batch(reads.tobytes(), np.arange(n + 1, dtype=np.int64) * L, 0)
+    assert total == mo[-1] and np.array_equal(off, mo) and np.array_equal(e, oe) and np.array_equal(v, ov)
+    t = sc.timing_ms()
+    assert t["walk"] > 0 and t["total"] >= t["walk"]
+    # second call reuses every buffer and must give the same answer
+    assert sc.scan(d_hay, n * L, n, stride=L, timing=True) == total
+    off2, e2, v2, _ = sc.fetch()
+    assert np.array_equal(off2, mo) and np.array_equal(e2, oe) and np.array_equal(v2, ov)
+    # iter_long through the same entry
+    total_l = sc.scan(d_hay, n * L, n, stride=L, mode=acx.ACX_SCAN_LONG)
+    offl, el, vl, _ = sc.fetch()
+    mol, oel, ovl = O.batch(reads.tobytes(), np.arange(n + 1, dtype=np.int64) * L, 1)
+    assert total_l == mol[-1] and np.array_equal(offl, mol) and np.array_equal(el, oel) and np.array_equal(vl, ovl)
+
+
+# ------------------------------------------------------------------ full size (BASELINE.json config 2 / 5)
+@pytest.fixture(scope="module")
+def config2():
+    keys, reads = dna_workload(100_000, 1_000_000, 150, seed=0)
+    A = acx.Automaton(acx.STORE_INTS)
+    for i, k in enumerate(keys):
+        A.add_word(k, i)
+    A.make_automaton()
+    img = Image.from_automaton(A)
+    d_hay = DeviceBuffer.from_numpy(reads.reshape(-1), pad=64)
+    return keys, reads, A, img, d_hay
+
+
+@pytest.mark.slow
+def test_config2_full_size_properties(config2):
+    keys, reads, A, img, d_hay = config2
+    n, L = reads.shape
+    sc = Scanner(img)
+    total = sc.scan(d_hay, n * L, n, stride=L, timing=True)
+    off, e, v, _ = sc.fetch()
+    assert off[0] == 0 and off[-1] == total == len(e) == len(v) and np.all(np.diff(off) >= 0)
+    hay_of = np.repeat(np.arange(n), np.diff(off))
+    klen = np.array([len(k) for k in keys], dtype=np.int64)
+    # (1) soundness: every reported (end, value) really is key[value] ending at `end`
+    ml = klen[v]
+    start = e.astype(np.int64) - ml + 1
+    assert start.min() >= 0 and e.max() < L
+    flat = reads.reshape(-1)
+    kcat = np.frombuffer(b"".join(keys), dtype=np.uint8)
+    koff = np.concatenate([[0], np.cumsum(klen)])
+    for length in np.unique(ml):
+        sel_all = np.flatnonzero(ml == length)
+        for a in range(0, len(sel_all), 1 << 20):          # bounded temporaries
+            sel = sel_all[a:a + (1 << 20)]
+            pos = (hay_of[sel] * L + start[sel])[:, None] + np.arange(length)[None, :]
+            kpos = koff[v[sel]][:, None] + np.arange(length)[None, :]
+            assert np.array_equal(flat[pos], kcat[kpos])
+    # (2) reference order: end ascending within a haystack; at equal end, longer key first
+    same_h = hay_of[1:] == hay_of[:-1]
+    de = np.diff(e.astype(np.int64))
+    assert np.all(de[same_h] >= 0)
+    tie = same_h & (de == 0)
+    assert np.all(ml[1:][tie] < ml[:-1][tie])
+    # (3) completeness on a deterministic 1% sample against the oracle (full lists)
+    O = orc.Oracle()
+    for i, k in enumerate(keys):
+        O.add_word(k, i)
+    O.make_automaton()
+    sample = np.arange(0, n, 100)
+    for h in sample[:4000]:
+        oe, ov, _ = O.iter_arrays(reads[h].tobytes())
+        assert np.array_equal(e[off[h]:off[h + 1]], oe) and np.array_equal(v[off[h]:off[h + 1]], ov), h
+    # (4) planted keys are found: every even read had a key planted
+    # (5) batch-split invariance: scanning the two halves separately gives the same records
+    half = n // 2
+    sc2 = Scanner(img)
+    t1 = sc2.scan(d_hay, half * L, half, stride=L)
+    o1, e1, v1, _ = sc2.fetch()
+    assert t1 == off[half] and np.array_equal(e1, e[:t1]) and np.array_equal(v1, v[:t1])
+    # (6) idempotence: a second full scan returns bit-identical buffers
+    assert sc.scan(d_hay, n * L, n, stride=L) == total
+    off_b, e_b, v_b, _ = sc.fetch()
+    assert np.array_equal(off_b, off) and np.array_equal(e_b, e) and np.array_equal(v_b, v)
+
+
+@pytest.mark.slow
+def test_config5_iter_long_full_size_sample(config2):
+    keys, reads, A, img, d_hay = config2
+    n, L = reads.shape
+    sc = Scanner(img)
+    total = sc.scan(d_hay, n * L, n, stride=L, mode=acx.ACX_SCAN_LONG)
+    off, e, v, _ = sc.fetch()
+    assert off[-1] == total
+    O = orc.Oracle()
+    for i, k in enumerate(keys):
+        O.add_word(k, i)
+    O.make_automaton()
+    for h in range(0, n, 500):
+        exp = O.iter_long(reads[h].tobytes())
+        got = list(zip(e[off[h]:off[h + 1]].tolist(), v[off[h]:off[h + 1]].tolist()))
+        assert got == exp, h
+    # non-overlap property of iter_long: strictly increasing end indices inside a haystack
+    hay_of = np.repeat(np.arange(n), np.diff(off))
+    same_h = hay_of[1:] == hay_of[:-1]
+    assert np.all(np.diff(e.astype(np.int64))[same_h] > 0)
