@@ -176,7 +176,7 @@ def test_dna_workload_vs_oracle(mode):
     assert np.array_equal(res.offsets, mo)
     assert np.array_equal(res.end_index, e)
     assert np.array_equal(res.value, v)
-    assert res.num_matches() > n            # the workload does produce matches
+    assert res.num_matches() > n // 2       # the workload does produce matches
 
 
 def test_device_resident_fixed_stride_entry_point():
