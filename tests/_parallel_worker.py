@@ -1,0 +1,77 @@
+"""worker for tests/test_parallel_cpu.py — run under torch.distributed.run, backend gloo.
+Exercises the N>1 plumbing on CPU: blob broadcast, sharding, rank-order concatenation.
+The scan itself has no CPU path; each rank stands in for its GPU with the test-only flat
+image walker (oracle/flat_walk.c), which is fine here: this is test infrastructure."""
+import ctypes as C
+import hashlib
+import os
+import sys
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import pyahocorasick_amd as acx  # noqa: E402
+from pyahocorasick_amd import _lib  # noqa: E402
+from pyahocorasick_amd.parallel import broadcast_blob, gather_csr, shard_range, shard_range_by_bytes  # noqa: E402
+from pyahocorasick_amd.workloads import dna_workload  # noqa: E402
+from oracle import orc  # noqa: E402
+
+
+def main():
+    dist.init_process_group("gloo")
+    rank, world = dist.get_rank(), dist.get_world_size()
+    keys, reads = dna_workload(500, 301, 60, seed=4, klo=3, khi=9)
+    blob = None
+    if rank == 0:
+        A = acx.Automaton(acx.STORE_INTS)
+        for i, k in enumerate(keys):
+            A.add_word(k, i)
+        A.make_automaton()
+        blob = A.flat_image_bytes()
+    t = broadcast_blob(blob, src=0)
+    got = t.numpy().tobytes()
+    # every rank holds a valid, identical image
+    buf = C.create_string_buffer(got, len(got))
+    _lib.check(_lib.lib().acx_blob_validate(buf, len(got)))
+    digest = hashlib.sha256(got).hexdigest()
+    digests = [None] * world
+    dist.all_gather_object(digests, digest)
+    assert len(set(digests)) == 1
+
+    # ragged batch: drop a varying tail from each read
+    lens = np.array([60 - (i % 7) for i in range(len(reads))], dtype=np.int64)
+    off = np.concatenate([[0], np.cumsum(lens)])
+    data = b"".join(reads[i, :lens[i]].tobytes() for i in range(len(reads)))
+    for splitter in (lambda: shard_range(len(reads), rank, world), lambda: shard_range_by_bytes(off, rank, world)):
+        lo, hi = splitter()
+        spans = [None] * world
+        dist.all_gather_object(spans, (lo, hi))
+        assert spans[0][0] == 0 and spans[-1][1] == len(reads)
+        assert all(spans[i][1] == spans[i + 1][0] for i in range(world - 1))      # contiguous, disjoint, complete
+        loc_off, loc_e, loc_v = [0], [], []
+        for h in range(lo, hi):
+            pairs, _ = orc.flat_iter(got, data[off[h]:off[h + 1]])
+            loc_e += [p[0] for p in pairs]
+            loc_v += [p[1] for p in pairs]
+            loc_off.append(len(loc_e))
+        res = gather_csr(np.array(loc_off, dtype=np.int64), np.array(loc_e, dtype=np.int32), np.array(loc_v, dtype=np.int32))
+        if rank == 0:
+            O = orc.Oracle()
+            for i, k in enumerate(keys):
+                O.add_word(k, i)
+            O.make_automaton()
+            mo, e, v = O.batch(data, off, 0)
+            assert np.array_equal(res[0], mo) and np.array_equal(res[1], e) and np.array_equal(res[2], v)
+        else:
+            assert res is None
+    dist.barrier()
+    dist.destroy_process_group()
+    if rank == 0:
+        print("PARALLEL_CPU_OK")
+
+
+if __name__ == "__main__":
+    main()
