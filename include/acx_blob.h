@@ -67,7 +67,9 @@ typedef struct acx_blob_header {
     uint64_t off_out_off;    /* uint32 [n_states + 1]   CSR offsets into out_val         */
     uint64_t off_out_val;    /* int32  [n_out]          values in fail-chain order       */
     uint64_t fnv1a64;        /* FNV-1a of bytes [header_bytes, total_bytes)              */
-    uint8_t  reserved[ACX_BLOB_HEADER_BYTES - 128];
+    uint64_t off_first_val;  /* int32  [n_states]       out_val[out_off[s]] (first output of s:
+                                the value iter_long reports, and the only one when CNT == 1) */
+    uint8_t  reserved[ACX_BLOB_HEADER_BYTES - 136];
 } acx_blob_header;
 
 #endif

@@ -21,6 +21,7 @@ typedef struct {
     const uint32_t* table;
     const uint32_t* out_off;
     const int32_t*  out_val;
+    const int32_t*  first_val;
 } flat_t;
 
 static int flat_open(const void* blob, flat_t* f) {
@@ -32,6 +33,7 @@ static int flat_open(const void* blob, flat_t* f) {
     f->table = (const uint32_t*)(b + h->off_table);
     f->out_off = (const uint32_t*)(b + h->off_out_off);
     f->out_val = (const int32_t*)(b + h->off_out_val);
+    f->first_val = (const int32_t*)(b + h->off_first_val);
     return 0;
 }
 
@@ -53,6 +55,7 @@ int64_t flat_iter(const void* blob, const uint8_t* hay, int64_t len,
             /* the packed count must agree with the CSR unless it is the escape value */
             if (cnt != ACX_ENTRY_CNT_ESCAPE && cnt != o1 - o0) return -3;
             if (cnt == ACX_ENTRY_CNT_ESCAPE && o1 - o0 < ACX_ENTRY_CNT_ESCAPE) return -3;
+            if (f.first_val[state] != f.out_val[o0]) return -4;
             for (uint32_t r = o0; r < o1; r++) {
                 if (n < cap) { out_end[n] = (int32_t)(i + index_base); out_val[n] = f.out_val[r]; }
                 n++;
@@ -96,7 +99,8 @@ int64_t flat_iter_long(const void* blob, const uint8_t* hay, int64_t len, int64_
         /* emit (…IterLong.c:99-111) */
         if (n < cap) {
             out_end[n] = (int32_t)(index_base + last_index);
-            out_val[n] = f.out_val[f.out_off[last_state]];
+            out_val[n] = f.first_val[last_state];
+            if (f.first_val[last_state] != f.out_val[f.out_off[last_state]]) return -4;
         }
         n++;
         state = 0; index = last_index + 1; have_last = 0; last_index = -1;

@@ -75,6 +75,7 @@ struct acx_image {
     const uint32_t* table = nullptr;
     const uint32_t* out_off = nullptr;
     const int32_t* out_val = nullptr;
+    const int32_t* first_val = nullptr;
 };
 
 static void image_resolve(acx_image* img) {
@@ -82,6 +83,7 @@ static void image_resolve(acx_image* img) {
     img->table = (const uint32_t*)(img->dev + img->h.off_table);
     img->out_off = (const uint32_t*)(img->dev + img->h.off_out_off);
     img->out_val = (const int32_t*)(img->dev + img->h.off_out_val);
+    img->first_val = (const int32_t*)(img->dev + img->h.off_first_val);
 }
 
 extern "C" int acx_image_upload(const void* blob, size_t nbytes, acx_image_t** out) {
@@ -168,6 +170,8 @@ struct acx_result {
     DevBuf<int32_t> counts, nev, final_state;
     DevBuf<int64_t> match_off, partials;
     DevBuf<uint2> events, matches;
+    // chunked scans
+    DevBuf<int32_t> nck; DevBuf<int64_t> ck_first, ck_match_off; DevBuf<acx_chunk_desc> ck;
     PinBuf<int64_t> h_off;
     PinBuf<acx_match_t> h_matches;
     PinBuf<int32_t> h_final;
@@ -184,6 +188,7 @@ struct acx_result {
     float t_walk = 0, t_scan = 0, t_expand = 0, t_total = 0;
     ~acx_result() {
         counts.release(); nev.release(); final_state.release(); match_off.release(); partials.release();
+        nck.release(); ck_first.release(); ck_match_off.release(); ck.release();
         events.release(); matches.release(); h_off.release(); h_matches.release(); h_final.release(); h_total.release();
         in_hay.release(); in_off.release(); in_init.release(); in_base.release();
         for (auto& e : ev) if (e) (void)hipEventDestroy(e);
@@ -226,14 +231,41 @@ extern "C" int acx_scan_batch(acx_image_t* img, const acx_scan_params* p, acx_re
 
     const size_t n = (size_t)p->n_hay;
     int rc;
-    if ((rc = r->counts.ensure(n + 1))) return rc;
-    if ((rc = r->nev.ensure(n + 1))) return rc;
+
+    // ---- work decomposition -----------------------------------------------------------
+    // direct : one lane per haystack (fixed-length short reads — config 2/5)
+    // chunked: ACX_SCAN_ALL over ragged or long haystacks: fixed-size chunks with a left halo of
+    //          longest_word-1 bytes, one lane per chunk (exact for `iter`).
+    //          Offsets that live in device memory are never inspected by the host, so every
+    //          dev_off batch takes this path: no single lane can be handed a huge haystack.
+    const int64_t halo = img->h.longest_word > 0 ? (int64_t)img->h.longest_word - 1 : 0;
+    int64_t CH = 0;
+    if (p->mode == ACX_SCAN_ALL && p->n_hay > 0 && !((p->variant >> 13) & 1)) {
+        int64_t want = 256;                                   // aim for >= ~1M chunks, 256 B .. 4 KiB
+        while (want < 4096 && p->hay_capacity / want > ((int64_t)1 << 20)) want <<= 1;
+        if (want < 8 * (halo + 1)) want = 8 * (halo + 1);     // keep the halo re-walk <= 1/8 of the work
+        if (p->dev_off || p->stride > want) CH = want;
+    }
+    const bool chunked = CH > 0;
+    int64_t n_items = p->n_hay;                               // work items the walk/expand kernels see
+    if (chunked) n_items = p->dev_off ? p->n_hay + p->hay_capacity / CH + 1
+                                      : p->n_hay * ((p->stride + CH - 1) / CH < 1 ? 1 : (p->stride + CH - 1) / CH);
+    const size_t ni = (size_t)n_items;
+
+    if ((rc = r->counts.ensure(ni + 1))) return rc;
+    if ((rc = r->nev.ensure(ni + 1))) return rc;
     if ((rc = r->match_off.ensure(n + 1))) return rc;
-    if ((rc = r->partials.ensure((size_t)acx_scan_num_partials(p->n_hay) + 2))) return rc;
+    if ((rc = r->partials.ensure((size_t)acx_scan_num_partials(n_items > p->n_hay ? n_items : p->n_hay) + 2))) return rc;
     if ((rc = r->events.ensure((size_t)p->hay_capacity + 1))) return rc;
     if (r->has_final && (rc = r->final_state.ensure(n + 1))) return rc;
     if ((rc = r->h_total.ensure(1))) return rc;
     if (r->matches.cap == 0 && (rc = r->matches.ensure((size_t)(p->hay_capacity / 8) + 1024))) return rc;
+    if (chunked) {
+        if ((rc = r->nck.ensure(n + 1))) return rc;
+        if ((rc = r->ck_first.ensure(n + 1))) return rc;
+        if ((rc = r->ck.ensure(ni + 1))) return rc;
+        if ((rc = r->ck_match_off.ensure(ni + 1))) return rc;
+    }
     if (r->timed) for (auto& e : r->ev) if (!e) HIP_TRY(hipEventCreate(&e));
 
     acx_walk_args wa;
@@ -243,23 +275,42 @@ extern "C" int acx_scan_batch(acx_image_t* img, const acx_scan_params* p, acx_re
     wa.counts = r->counts.p; wa.nev = r->nev.p; wa.events = r->events.p;
     wa.final_state = r->has_final ? r->final_state.p : nullptr;
 
+    int64_t* item_match_off = chunked ? r->ck_match_off.p : r->match_off.p;
+
     if (r->timed) HIP_TRY(hipEventRecord(r->ev[0], s));
-    if (p->mode == ACX_SCAN_ALL) HIP_TRY(acx_launch_walk_all(wa, img->h.has_escape != 0, p->variant, s));
-    else                         HIP_TRY(acx_launch_walk_long(wa, p->variant, s));
+    if (chunked) {
+        acx_chunk_args ca;
+        ca.off = p->dev_off; ca.stride = p->stride; ca.n_hay = p->n_hay; ca.index_base = p->dev_index_base;
+        ca.chunk_bytes = (int32_t)CH; ca.halo = (int32_t)halo;
+        ca.nck = r->nck.p; ca.ck_first = r->ck_first.p; ca.ck = r->ck.p;
+        // items beyond the real chunk count (the host only knows a bound) must read as empty
+        HIP_TRY(hipMemsetAsync(r->counts.p, 0, (ni + 1) * sizeof(int32_t), s));
+        HIP_TRY(hipMemsetAsync(r->nev.p, 0, (ni + 1) * sizeof(int32_t), s));
+        HIP_TRY(acx_launch_chunk_count(ca, s));
+        HIP_TRY(acx_launch_scan(r->nck.p, p->n_hay, r->ck_first.p, r->partials.p, s));
+        HIP_TRY(acx_launch_chunk_fill(ca, n_items, s));
+        HIP_TRY(acx_launch_walk_chunks(wa, r->ck.p, r->ck_first.p + p->n_hay, n_items, img->h.has_escape != 0, s));
+    } else if (p->mode == ACX_SCAN_ALL) {
+        HIP_TRY(acx_launch_walk_all(wa, img->h.has_escape != 0, p->variant, s));
+    } else {
+        HIP_TRY(acx_launch_walk_long(wa, p->variant, s));
+    }
     if (r->timed) HIP_TRY(hipEventRecord(r->ev[1], s));
-    HIP_TRY(acx_launch_scan(r->counts.p, p->n_hay, r->match_off.p, r->partials.p, s));
+    HIP_TRY(acx_launch_scan(r->counts.p, n_items, item_match_off, r->partials.p, s));
     if (r->timed) HIP_TRY(hipEventRecord(r->ev[2], s));
 
     acx_expand_args ea;
-    ea.off = p->dev_off; ea.stride = p->stride; ea.n_hay = p->n_hay; ea.nev = r->nev.p; ea.events = r->events.p;
-    ea.match_off = r->match_off.p; ea.out_off = img->out_off; ea.out_val = img->out_val;
+    ea.off = p->dev_off; ea.stride = p->stride; ea.n_hay = n_items; ea.nev = r->nev.p; ea.events = r->events.p;
+    ea.match_off = item_match_off; ea.out_off = img->out_off; ea.out_val = img->out_val; ea.first_val = img->first_val;
     ea.long_mode = p->mode == ACX_SCAN_LONG ? 1 : 0;
+    ea.ck = chunked ? r->ck.p : nullptr; ea.n_items_dev = nullptr;
     // Speculative launch with the capacity we already have: no host round trip between
     // scan and expand in the steady state.  The kernel is a no-op if the total does not fit.
     ea.matches = r->matches.p; ea.capacity = (int64_t)r->matches.cap;
     HIP_TRY(acx_launch_expand(ea, p->variant, s));
+    if (chunked) HIP_TRY(acx_launch_hay_offsets(r->ck_first.p, r->ck_match_off.p, p->n_hay, r->match_off.p, s));
     if (r->timed) HIP_TRY(hipEventRecord(r->ev[3], s));
-    HIP_TRY(hipMemcpyAsync(r->h_total.p, r->match_off.p + p->n_hay, sizeof(int64_t), hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipMemcpyAsync(r->h_total.p, item_match_off + n_items, sizeof(int64_t), hipMemcpyDeviceToHost, s));
     HIP_TRY(hipStreamSynchronize(s));
     r->total = r->h_total.p[0];
     if (r->timed) {

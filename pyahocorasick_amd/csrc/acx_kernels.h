@@ -27,6 +27,31 @@ struct acx_walk_args {
     int32_t* final_state;      // nullable
 };
 
+// One unit of work of the chunked scan (long haystacks): walk bytes [start, start+len) of the
+// concatenated buffer from the root (or from init_state when the chunk begins its haystack),
+// report only matches ending at or after byte start+emit.  emit = the left halo,
+// longest_word-1 bytes: every match ending at i depends only on the longest_word bytes
+// up to i, so chunks are independent (SURVEY.md §5 "chunked streaming").
+struct acx_chunk_desc {
+    int64_t start;    // global byte offset where the walk starts
+    int32_t emit;     // first reported position, relative to start
+    int32_t len;      // bytes to walk
+    int32_t idx0;     // end_index reported for byte `start` (position in haystack + index_base)
+    int32_t hay;      // owning haystack
+    int32_t flags;    // bit0: chunk starts at the haystack start, bit1: chunk ends the haystack
+    int32_t pad;
+};
+
+struct acx_chunk_args {
+    const int64_t* off; int64_t stride; int64_t n_hay;
+    const int32_t* index_base;     // nullable
+    int32_t chunk_bytes;           // CH
+    int32_t halo;                  // longest_word - 1
+    int32_t* nck;                  // int32[n_hay]     chunks per haystack
+    int64_t* ck_first;             // int64[n_hay+1]   first chunk of each haystack (exclusive scan of nck)
+    acx_chunk_desc* ck;            // [n_chunks]
+};
+
 struct acx_expand_args {
     const int64_t* off;  int64_t stride;  int64_t n_hay;
     const int32_t* nev;
@@ -34,9 +59,14 @@ struct acx_expand_args {
     const int64_t* match_off;  // int64[n_hay+1]
     const uint32_t* out_off;
     const int32_t*  out_val;
+    const int32_t*  first_val; // int32[n_states]: out_val[out_off[s]]
     uint2*   matches;          // acx_match_t[capacity]
     int64_t  capacity;
     int32_t  long_mode;        // 1: every event is exactly one match (iter_long)
+    // chunked scans: items are chunks; event base = ck[c].start + ck[c].emit; the number of
+    // items lives in device memory (n_items_dev) and n_hay is only an upper bound for the grid
+    const acx_chunk_desc* ck;  // nullable
+    const int64_t* n_items_dev;
 };
 
 // variant: 0 = default.  See acx_kernels.hip for the list.
@@ -45,6 +75,14 @@ hipError_t acx_launch_walk_long(const acx_walk_args& a, int variant, hipStream_t
 // exclusive prefix sum: counts int32[n] -> match_off int64[n+1]; partials = int64[ceil(n/4096)+1] scratch
 hipError_t acx_launch_scan(const int32_t* counts, int64_t n, int64_t* match_off, int64_t* partials, hipStream_t s);
 hipError_t acx_launch_expand(const acx_expand_args& a, int variant, hipStream_t s);
+// chunked scan (ACX_SCAN_ALL on long haystacks)
+hipError_t acx_launch_chunk_count(const acx_chunk_args& c, hipStream_t s);          // fills nck
+hipError_t acx_launch_chunk_fill(const acx_chunk_args& c, int64_t n_chunks_bound, hipStream_t s);   // needs ck_first
+hipError_t acx_launch_walk_chunks(const acx_walk_args& a, const acx_chunk_desc* ck, const int64_t* n_chunks_dev,
+                                  int64_t n_chunks_bound, bool has_escape, hipStream_t s);
+// per-haystack match offsets from per-chunk ones: match_off[h] = ck_match_off[ck_first[h]]
+hipError_t acx_launch_hay_offsets(const int64_t* ck_first, const int64_t* ck_match_off, int64_t n_hay,
+                                  int64_t* match_off, hipStream_t s);
 int64_t acx_scan_num_partials(int64_t n);
 
 #endif

@@ -31,15 +31,31 @@
 
 namespace {
 
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef u32x4 __attribute__((aligned(1))) u32x4_unaligned;
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+
+// NT = non-temporal (`nt` bit on the instruction): the haystack is read once and the events
+// are written once, neither should displace the transition-table rows that live in L2.
+template <bool NT>
 __device__ __forceinline__ uint4 load16_unaligned(const uint8_t* p) {
-    uint4 v;
-    __builtin_memcpy(&v, p, 16);
-    return v;
+    u32x4 v;
+    if (NT) v = __builtin_nontemporal_load((const u32x4_unaligned*)p);
+    else    v = *(const u32x4_unaligned*)p;
+    return make_uint4(v.x, v.y, v.z, v.w);
+}
+
+template <bool NT>
+__device__ __forceinline__ void store_event(uint2* dst, uint32_t idx, uint32_t entry) {
+    u32x2 v; v.x = idx; v.y = entry;
+    if (NT) __builtin_nontemporal_store(v, (u32x2*)dst);
+    else    *(u32x2*)dst = v;
 }
 
 // 16 bytes starting at p, never touching bytes at or beyond `limit`
+template <bool NT>
 __device__ __forceinline__ uint4 load16_guarded(const uint8_t* p, const uint8_t* limit) {
-    if (p + 16 <= limit) return load16_unaligned(p);
+    if (p + 16 <= limit) return load16_unaligned<NT>(p);
     // last 15 bytes of the buffer only: keep this cold path small (no unrolling)
     uint64_t lo = 0, hi = 0;
 #pragma nounroll
@@ -63,7 +79,7 @@ struct LaneState {
     uint2*   ev;        // next free event slot
 };
 
-template <bool ESCAPE, bool EVENTS>
+template <bool ESCAPE, bool EVENTS, bool NT>
 __device__ __forceinline__ void step(uint32_t c4, uint32_t idx, const uint8_t* table_bytes,
                                      uint32_t row_bytes, const uint32_t* out_off, LaneState& L) {
     const uint32_t o  = __umul24(L.state, row_bytes) + c4;           // v_mad_u32_u24
@@ -80,7 +96,7 @@ __device__ __forceinline__ void step(uint32_t c4, uint32_t idx, const uint8_t* t
                     c = out_off[s + 1] - out_off[s];
                 }
             }
-            if (EVENTS) *L.ev++ = make_uint2(idx, e);
+            if (EVENTS) store_event<NT>(L.ev++, idx, e);
             L.cnt += c;
         }
     } else {
@@ -98,7 +114,7 @@ __device__ __forceinline__ void classes8(uint32_t w0, uint32_t w1, const uint32_
     for (int i = 0; i < 4; i++) c4[4 + i] = s_cls4[(w1 >> (i * 8)) & 0xffu];
 }
 
-template <bool ESCAPE, bool EVENTS, bool GUARD>
+template <bool ESCAPE, bool EVENTS, bool NT, bool GUARD>
 __device__ __forceinline__ void block16(const uint4 w, uint32_t idx0, int rem, const uint32_t* s_cls4,
                                         const uint8_t* table_bytes, uint32_t row_bytes, const uint32_t* out_off,
                                         LaneState& L) {
@@ -106,16 +122,16 @@ __device__ __forceinline__ void block16(const uint4 w, uint32_t idx0, int rem, c
     classes8(w.x, w.y, s_cls4, c4);
 #pragma unroll
     for (int i = 0; i < 8; i++)
-        if (!GUARD || i < rem) step<ESCAPE, EVENTS>(c4[i], idx0 + i, table_bytes, row_bytes, out_off, L);
+        if (!GUARD || i < rem) step<ESCAPE, EVENTS, NT>(c4[i], idx0 + i, table_bytes, row_bytes, out_off, L);
     classes8(w.z, w.w, s_cls4, c4);
 #pragma unroll
     for (int i = 0; i < 8; i++)
-        if (!GUARD || 8 + i < rem) step<ESCAPE, EVENTS>(c4[i], idx0 + 8 + i, table_bytes, row_bytes, out_off, L);
+        if (!GUARD || 8 + i < rem) step<ESCAPE, EVENTS, NT>(c4[i], idx0 + 8 + i, table_bytes, row_bytes, out_off, L);
 }
 
 // second __launch_bounds__ argument = waves per SIMD the register allocation must allow:
 // the kernel is bound by memory latency/transactions, so ILP=1 wants all 8 (<= 64 VGPRs).
-template <bool ESCAPE, int ILP, bool EVENTS>
+template <bool ESCAPE, int ILP, bool EVENTS, bool NT>
 __global__ void __launch_bounds__(ACX_BLOCK, ILP == 1 ? 8 : 5) k_walk_all(const acx_walk_args a) {
     __shared__ uint32_t s_cls4[256];
     s_cls4[threadIdx.x] = (uint32_t)a.cls[threadIdx.x] * 4u;   // blockDim.x == 256
@@ -170,7 +186,7 @@ __global__ void __launch_bounds__(ACX_BLOCK, ILP == 1 ? 8 : 5) k_walk_all(const 
                 // every chain of every lane has a full block: interleave the chains step by step
                 uint4 w[ILP];
 #pragma unroll
-                for (int q = 0; q < ILP; q++) w[q] = load16_guarded(p[q] + j0, limit);
+                for (int q = 0; q < ILP; q++) w[q] = load16_guarded<NT>(p[q] + j0, limit);
 #pragma unroll
                 for (int half = 0; half < 2; half++) {
                     uint32_t c4[ILP][8];
@@ -181,7 +197,7 @@ __global__ void __launch_bounds__(ACX_BLOCK, ILP == 1 ? 8 : 5) k_walk_all(const 
                     for (int i = 0; i < 8; i++) {
 #pragma unroll
                         for (int q = 0; q < ILP; q++)
-                            step<ESCAPE, EVENTS>(c4[q][i], base[q] + j0 + half * 8 + i, table_bytes, a.row_bytes, a.out_off, L[q]);
+                            step<ESCAPE, EVENTS, NT>(c4[q][i], base[q] + j0 + half * 8 + i, table_bytes, a.row_bytes, a.out_off, L[q]);
                     }
                 }
                 continue;
@@ -189,9 +205,9 @@ __global__ void __launch_bounds__(ACX_BLOCK, ILP == 1 ? 8 : 5) k_walk_all(const 
 #pragma unroll
             for (int q = 0; q < ILP; q++) {
                 if (rem[q] > 0) {   // lanes whose haystack is exhausted sit out; __all is over the active lanes
-                    const uint4 w = load16_guarded(p[q] + j0, limit);
-                    if (__all(rem[q] >= 16)) block16<ESCAPE, EVENTS, false>(w, base[q] + j0, 16, s_cls4, table_bytes, a.row_bytes, a.out_off, L[q]);
-                    else                     block16<ESCAPE, EVENTS, true >(w, base[q] + j0, rem[q], s_cls4, table_bytes, a.row_bytes, a.out_off, L[q]);
+                    const uint4 w = load16_guarded<NT>(p[q] + j0, limit);
+                    if (__all(rem[q] >= 16)) block16<ESCAPE, EVENTS, NT, false>(w, base[q] + j0, 16, s_cls4, table_bytes, a.row_bytes, a.out_off, L[q]);
+                    else                     block16<ESCAPE, EVENTS, NT, true >(w, base[q] + j0, rem[q], s_cls4, table_bytes, a.row_bytes, a.out_off, L[q]);
                 }
             }
         }
@@ -204,6 +220,127 @@ __global__ void __launch_bounds__(ACX_BLOCK, ILP == 1 ? 8 : 5) k_walk_all(const 
             }
         }
     }
+}
+
+// ---------------------------------------------------------------------------------
+// chunked walk (ACX_SCAN_ALL over long / ragged haystacks)
+//
+// A lane owns one CHUNK (acx_chunk_desc): it walks `len` bytes from `start`, silently for
+// the first `emit` bytes (the left halo of longest_word-1 bytes that rebuilds the state),
+// then exactly like k_walk_all.  Chunks of one haystack are consecutive work items, so the
+// per-chunk results concatenate to the haystack's result in reference order.
+// ---------------------------------------------------------------------------------
+__device__ __forceinline__ void silent_step(uint32_t c4, const uint8_t* table_bytes, uint32_t row_bytes, LaneState& L) {
+    L.state = *(const uint32_t*)(table_bytes + (__umul24(L.state, row_bytes) + c4));
+}
+
+template <bool ESCAPE>
+__global__ void __launch_bounds__(ACX_BLOCK, 8) k_walk_chunks(const acx_walk_args a, const acx_chunk_desc* ck,
+                                                             const int64_t* n_chunks_dev) {
+    __shared__ uint32_t s_cls4[256];
+    s_cls4[threadIdx.x] = (uint32_t)a.cls[threadIdx.x] * 4u;
+    __syncthreads();
+
+    const int lane = threadIdx.x & (ACX_WAVE - 1);
+    const int64_t n_chunks = *n_chunks_dev;
+    const int64_t n_tasks = (n_chunks + ACX_WAVE - 1) / ACX_WAVE;
+    const int64_t wave0 = (int64_t)blockIdx.x * (ACX_BLOCK / ACX_WAVE) + (threadIdx.x / ACX_WAVE);
+    const int64_t n_waves = (int64_t)gridDim.x * (ACX_BLOCK / ACX_WAVE);
+    const uint8_t* table_bytes = (const uint8_t*)a.table;
+    const uint8_t* limit = a.hay + a.hay_cap;
+
+    for (int64_t task = wave0; task < n_tasks; task += n_waves) {
+        const int64_t c = task * ACX_WAVE + lane;
+        const bool valid = c < n_chunks;
+        acx_chunk_desc d;
+        d.start = 0; d.emit = 0; d.len = 0; d.idx0 = 0; d.hay = 0; d.flags = 0; d.pad = 0;
+        if (valid) d = ck[c];
+        const uint8_t* p = a.hay + d.start;
+        const int len = d.len, emit = d.emit;
+        LaneState L;
+        L.state = (valid && a.init_state && (d.flags & 1)) ? (uint32_t)a.init_state[d.hay] : 0u;
+        L.cnt = 0;
+        L.ev = a.events + d.start + emit;
+        uint2* const ev0 = L.ev;
+        const uint32_t base = (uint32_t)d.idx0;
+
+        for (int j0 = 0;; j0 += 16) {
+            const int rem = len - j0;
+            if (!__any(rem > 0)) break;
+            if (rem > 0) {
+                const uint4 w = load16_guarded<false>(p + j0, limit);
+                if (__all(rem >= 16 && j0 >= emit)) {
+                    block16<ESCAPE, true, false, false>(w, base + j0, 16, s_cls4, table_bytes, a.row_bytes, a.out_off, L);
+                } else {
+                    uint32_t c4[8];
+#pragma unroll
+                    for (int half = 0; half < 2; half++) {
+                        classes8(half ? w.z : w.x, half ? w.w : w.y, s_cls4, c4);
+#pragma unroll
+                        for (int i = 0; i < 8; i++) {
+                            const int j = j0 + half * 8 + i;
+                            if (half * 8 + i < rem) {
+                                if (j >= emit) step<ESCAPE, true, false>(c4[i], base + j, table_bytes, a.row_bytes, a.out_off, L);
+                                else           silent_step(c4[i], table_bytes, a.row_bytes, L);
+                            }
+                        }
+                    }
+                }
+            }
+        }
+        if (valid) {
+            a.counts[c] = (int32_t)L.cnt;
+            a.nev[c] = (int32_t)(L.ev - ev0);
+            if (a.final_state && (d.flags & 2)) a.final_state[d.hay] = (int32_t)(L.state & ACX_ENTRY_STATE_MASK);
+        }
+    }
+}
+
+// chunks per haystack: max(1, ceil(len / CH)) — an empty haystack still gets one (empty)
+// chunk so that it owns a final_state and a match_off slot
+__global__ void __launch_bounds__(ACX_BLOCK) k_chunk_count(const acx_chunk_args c) {
+    const int64_t h = (int64_t)blockIdx.x * ACX_BLOCK + threadIdx.x;
+    if (h >= c.n_hay) return;
+    const int64_t len = c.off ? c.off[h + 1] - c.off[h] : c.stride;
+    const int64_t n = (len + c.chunk_bytes - 1) / c.chunk_bytes;
+    c.nck[h] = (int32_t)(n < 1 ? 1 : n);
+}
+
+// one thread per chunk: find the owning haystack by binary search in ck_first
+__global__ void __launch_bounds__(ACX_BLOCK) k_chunk_fill(const acx_chunk_args c) {
+    const int64_t n_chunks = c.ck_first[c.n_hay];
+    const int64_t n_threads = (int64_t)gridDim.x * ACX_BLOCK;
+    for (int64_t i = (int64_t)blockIdx.x * ACX_BLOCK + threadIdx.x; i < n_chunks; i += n_threads) {
+        int64_t lo = 0, hi = c.n_hay - 1;          // largest h with ck_first[h] <= i
+        while (lo < hi) {
+            const int64_t mid = (lo + hi + 1) >> 1;
+            if (c.ck_first[mid] <= i) lo = mid; else hi = mid - 1;
+        }
+        const int64_t h = lo;
+        const int64_t hs = c.off ? c.off[h] : h * c.stride;
+        const int64_t he = c.off ? c.off[h + 1] : hs + c.stride;
+        const int64_t k = i - c.ck_first[h];
+        const int64_t cs = hs + k * c.chunk_bytes;
+        int64_t ce = cs + c.chunk_bytes;
+        if (ce > he) ce = he;
+        int64_t s0 = cs - c.halo;
+        if (s0 < hs) s0 = hs;
+        acx_chunk_desc d;
+        d.start = s0;
+        d.emit = (int32_t)(cs - s0);
+        d.len = (int32_t)(ce - s0);
+        d.idx0 = (int32_t)(s0 - hs) + (c.index_base ? c.index_base[h] : 0);
+        d.hay = (int32_t)h;
+        d.flags = (s0 == hs ? 1 : 0) | (ce == he ? 2 : 0);
+        d.pad = 0;
+        c.ck[i] = d;
+    }
+}
+
+__global__ void __launch_bounds__(ACX_BLOCK) k_hay_offsets(const int64_t* ck_first, const int64_t* ck_match_off,
+                                                          int64_t n_hay, int64_t* match_off) {
+    const int64_t h = (int64_t)blockIdx.x * ACX_BLOCK + threadIdx.x;
+    if (h <= n_hay) match_off[h] = ck_match_off[ck_first[h]];
 }
 
 // ---------------------------------------------------------------------------------
@@ -366,12 +503,13 @@ __global__ void __launch_bounds__(ACX_BLOCK) k_scan_final(const int32_t* counts,
 // ---------------------------------------------------------------------------------
 __global__ void __launch_bounds__(ACX_BLOCK) k_expand(const acx_expand_args a) {
     // if the staging capacity guess was too small the host grows the buffer and relaunches
-    if (a.match_off[a.n_hay] > a.capacity) return;
+    const int64_t n_items = a.n_items_dev ? *a.n_items_dev : a.n_hay;
+    if (a.match_off[n_items] > a.capacity) return;
     const int64_t n_threads = (int64_t)gridDim.x * ACX_BLOCK;
-    for (int64_t h = (int64_t)blockIdx.x * ACX_BLOCK + threadIdx.x; h < a.n_hay; h += n_threads) {
+    for (int64_t h = (int64_t)blockIdx.x * ACX_BLOCK + threadIdx.x; h < n_items; h += n_threads) {
         const int32_t n = a.nev[h];
         if (n == 0) continue;
-        const uint2* ev = a.events + (a.off ? a.off[h] : h * a.stride);
+        const uint2* ev = a.events + (a.ck ? a.ck[h].start + a.ck[h].emit : (a.off ? a.off[h] : h * a.stride));
         uint2* out = a.matches + a.match_off[h];
         if (a.long_mode) {
             for (int32_t k = 0; k < n; k++) {
@@ -392,6 +530,56 @@ __global__ void __launch_bounds__(ACX_BLOCK) k_expand(const acx_expand_args a) {
     }
 }
 
+// Group version (default): GROUP consecutive lanes share one haystack.  The group reads
+// GROUP consecutive events with one coalesced load, turns the per-event output counts into
+// record offsets with a GROUP-wide shuffle scan, and writes its records to consecutive
+// slots.  Events with a single output (the overwhelmingly common case) take their value
+// from first_val[s]: one gather per match instead of out_off[s] -> out_val[o].
+template <int GROUP>
+__global__ void __launch_bounds__(ACX_BLOCK) k_expand_grp(const acx_expand_args a) {
+    const int64_t n_items = a.n_items_dev ? *a.n_items_dev : a.n_hay;
+    if (a.match_off[n_items] > a.capacity) return;
+    const int sub = threadIdx.x & (GROUP - 1);
+    const int64_t groups_per_block = ACX_BLOCK / GROUP;
+    const int64_t n_groups = (int64_t)gridDim.x * groups_per_block;
+    for (int64_t h = (int64_t)blockIdx.x * groups_per_block + threadIdx.x / GROUP; h < n_items; h += n_groups) {
+        const int32_t n = a.nev[h];            // group-uniform
+        if (n == 0) continue;
+        const uint2* ev = a.events + (a.ck ? a.ck[h].start + a.ck[h].emit : (a.off ? a.off[h] : h * a.stride));
+        int64_t out_base = a.match_off[h];
+        for (int32_t k0 = 0; k0 < n; k0 += GROUP) {
+            const int32_t k = k0 + sub;
+            const bool valid = k < n;
+            uint2 v = make_uint2(0, 0);
+            if (valid) v = ev[k];
+            const uint32_t s = v.y & ACX_ENTRY_STATE_MASK;
+            uint32_t c = 0;
+            if (valid) {
+                if (a.long_mode) c = 1;
+                else {
+                    c = v.y >> ACX_ENTRY_CNT_SHIFT;
+                    if (c == ACX_ENTRY_CNT_ESCAPE) c = a.out_off[s + 1] - a.out_off[s];
+                }
+            }
+            uint32_t incl = c;                 // inclusive scan across the group
+#pragma unroll
+            for (int d = 1; d < GROUP; d <<= 1) {
+                const uint32_t t = __shfl_up(incl, d, GROUP);
+                if (sub >= d) incl += t;
+            }
+            const uint32_t total = __shfl(incl, GROUP - 1, GROUP);
+            uint2* out = a.matches + out_base + (incl - c);
+            if (c == 1) {
+                *out = make_uint2(v.x, (uint32_t)a.first_val[s]);
+            } else if (c > 1) {
+                const uint32_t o = a.out_off[s];
+                for (uint32_t r = 0; r < c; r++) out[r] = make_uint2(v.x, (uint32_t)a.out_val[o + r]);
+            }
+            out_base += total;
+        }
+    }
+}
+
 inline int grid_for_waves(int64_t n_tasks) {
     // 256 CUs x 8 blocks of 4 waves = the chip's 32 waves/CU; grid-stride the rest
     const int64_t blocks = (n_tasks + (ACX_BLOCK / ACX_WAVE) - 1) / (ACX_BLOCK / ACX_WAVE);
@@ -407,14 +595,31 @@ int64_t acx_scan_num_partials(int64_t n) { return (n + SCAN_TILE - 1) / SCAN_TIL
 //   bits 0-3  ILP - 1            (0 -> one haystack per lane, 1 -> two)
 //   bits 4-7  blocks per CU      (0 -> 8)
 //   bit  8    count only, no events (diagnostic; the result then has no matches)
-template <bool ESCAPE, int ILP, bool EVENTS>
+//   bits 9-11 expand kernel shape (see acx_launch_expand)
+//   bit  12   non-temporal haystack loads and event stores
+template <bool ESCAPE, int ILP, bool EVENTS, bool NT>
 static void launch_walk_all_t(const acx_walk_args& a, int blocks_per_cu, hipStream_t s) {
     const int64_t per_task = (int64_t)ACX_WAVE * ILP;
     const int64_t n_tasks = (a.n_hay + per_task - 1) / per_task;
     const int64_t blocks = (n_tasks + (ACX_BLOCK / ACX_WAVE) - 1) / (ACX_BLOCK / ACX_WAVE);
     const int64_t cap = 256 * (int64_t)blocks_per_cu;
     const int grid = (int)(blocks < 1 ? 1 : (blocks > cap ? cap : blocks));
-    hipLaunchKernelGGL((k_walk_all<ESCAPE, ILP, EVENTS>), dim3(grid), dim3(ACX_BLOCK), 0, s, a);
+    hipLaunchKernelGGL((k_walk_all<ESCAPE, ILP, EVENTS, NT>), dim3(grid), dim3(ACX_BLOCK), 0, s, a);
+}
+
+template <bool ESCAPE>
+static hipError_t dispatch_walk_all(const acx_walk_args& a, int ilp, bool events, bool nt, int bpc, hipStream_t s) {
+    if (ilp == 2) {            // ILP 2 exists as a tuning variant only (no gain measured on MI355X)
+        if (events) launch_walk_all_t<ESCAPE, 2, true, false>(a, bpc, s);
+        else        launch_walk_all_t<ESCAPE, 2, false, false>(a, bpc, s);
+    } else if (events) {
+        if (nt) launch_walk_all_t<ESCAPE, 1, true, true>(a, bpc, s);
+        else    launch_walk_all_t<ESCAPE, 1, true, false>(a, bpc, s);
+    } else {
+        if (nt) launch_walk_all_t<ESCAPE, 1, false, true>(a, bpc, s);
+        else    launch_walk_all_t<ESCAPE, 1, false, false>(a, bpc, s);
+    }
+    return hipGetLastError();
 }
 
 hipError_t acx_launch_walk_all(const acx_walk_args& a, bool has_escape, int variant, hipStream_t s) {
@@ -423,17 +628,10 @@ hipError_t acx_launch_walk_all(const acx_walk_args& a, bool has_escape, int vari
     int bpc = (variant >> 4) & 0xF;
     if (bpc == 0) bpc = 8;
     const bool events = !((variant >> 8) & 1);
+    const bool nt = (variant >> 12) & 1;
     if (ilp > 2) return hipErrorInvalidValue;
-#define ACX_DISPATCH(E, I, V) launch_walk_all_t<E, I, V>(a, bpc, s)
-    if (has_escape) {
-        if (ilp == 1) { if (events) ACX_DISPATCH(true, 1, true); else ACX_DISPATCH(true, 1, false); }
-        else          { if (events) ACX_DISPATCH(true, 2, true); else ACX_DISPATCH(true, 2, false); }
-    } else {
-        if (ilp == 1) { if (events) ACX_DISPATCH(false, 1, true); else ACX_DISPATCH(false, 1, false); }
-        else          { if (events) ACX_DISPATCH(false, 2, true); else ACX_DISPATCH(false, 2, false); }
-    }
-#undef ACX_DISPATCH
-    return hipGetLastError();
+    return has_escape ? dispatch_walk_all<true>(a, ilp, events, nt, bpc, s)
+                      : dispatch_walk_all<false>(a, ilp, events, nt, bpc, s);
 }
 
 hipError_t acx_launch_walk_long(const acx_walk_args& a, int variant, hipStream_t s) {
@@ -456,10 +654,52 @@ hipError_t acx_launch_scan(const int32_t* counts, int64_t n, int64_t* match_off,
 }
 
 hipError_t acx_launch_expand(const acx_expand_args& a, int variant, hipStream_t s) {
-    (void)variant;
     if (a.n_hay <= 0) return hipSuccess;
-    const int64_t blocks = (a.n_hay + ACX_BLOCK - 1) / ACX_BLOCK;
-    const int grid = (int)(blocks > 256 * 8 ? 256 * 8 : blocks);
-    hipLaunchKernelGGL(k_expand, dim3(grid), dim3(ACX_BLOCK), 0, s, a);
+    // variant bits 9-11: 0 = 16 lanes per haystack (default), 1 = one lane per haystack
+    // (first version, kept for A/B), 2 = 8 lanes, 3 = 32 lanes, 4 = 4 lanes
+    const int ev = (variant >> 9) & 7;
+    const int group = ev == 1 ? 1 : ev == 2 ? 8 : ev == 3 ? 32 : ev == 4 ? 4 : 16;
+    const int64_t per_block = ACX_BLOCK / group;
+    const int64_t blocks = (a.n_hay + per_block - 1) / per_block;
+    const int64_t cap = 256 * 8 * 4;
+    const int grid = (int)(blocks > cap ? cap : blocks);
+    switch (group) {
+        case 1:  hipLaunchKernelGGL(k_expand, dim3(grid), dim3(ACX_BLOCK), 0, s, a); break;
+        case 4:  hipLaunchKernelGGL(k_expand_grp<4>, dim3(grid), dim3(ACX_BLOCK), 0, s, a); break;
+        case 8:  hipLaunchKernelGGL(k_expand_grp<8>, dim3(grid), dim3(ACX_BLOCK), 0, s, a); break;
+        case 32: hipLaunchKernelGGL(k_expand_grp<32>, dim3(grid), dim3(ACX_BLOCK), 0, s, a); break;
+        default: hipLaunchKernelGGL(k_expand_grp<16>, dim3(grid), dim3(ACX_BLOCK), 0, s, a); break;
+    }
+    return hipGetLastError();
+}
+
+hipError_t acx_launch_chunk_count(const acx_chunk_args& c, hipStream_t s) {
+    if (c.n_hay <= 0) return hipSuccess;
+    hipLaunchKernelGGL(k_chunk_count, dim3((unsigned)((c.n_hay + ACX_BLOCK - 1) / ACX_BLOCK)), dim3(ACX_BLOCK), 0, s, c);
+    return hipGetLastError();
+}
+
+hipError_t acx_launch_chunk_fill(const acx_chunk_args& c, int64_t n_chunks_bound, hipStream_t s) {
+    if (c.n_hay <= 0) return hipSuccess;
+    int64_t blocks = (n_chunks_bound + ACX_BLOCK - 1) / ACX_BLOCK;
+    if (blocks > 256 * 16) blocks = 256 * 16;
+    if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(k_chunk_fill, dim3((unsigned)blocks), dim3(ACX_BLOCK), 0, s, c);
+    return hipGetLastError();
+}
+
+hipError_t acx_launch_walk_chunks(const acx_walk_args& a, const acx_chunk_desc* ck, const int64_t* n_chunks_dev,
+                                  int64_t n_chunks_bound, bool has_escape, hipStream_t s) {
+    if (n_chunks_bound <= 0) return hipSuccess;
+    const int grid = grid_for_waves((n_chunks_bound + ACX_WAVE - 1) / ACX_WAVE);
+    if (has_escape) hipLaunchKernelGGL(k_walk_chunks<true>, dim3(grid), dim3(ACX_BLOCK), 0, s, a, ck, n_chunks_dev);
+    else            hipLaunchKernelGGL(k_walk_chunks<false>, dim3(grid), dim3(ACX_BLOCK), 0, s, a, ck, n_chunks_dev);
+    return hipGetLastError();
+}
+
+hipError_t acx_launch_hay_offsets(const int64_t* ck_first, const int64_t* ck_match_off, int64_t n_hay,
+                                  int64_t* match_off, hipStream_t s) {
+    hipLaunchKernelGGL(k_hay_offsets, dim3((unsigned)((n_hay + 1 + ACX_BLOCK - 1) / ACX_BLOCK)), dim3(ACX_BLOCK), 0, s,
+                       ck_first, ck_match_off, n_hay, match_off);
     return hipGetLastError();
 }

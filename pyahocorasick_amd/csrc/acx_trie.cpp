@@ -309,6 +309,7 @@ int acx_flatten(const acx_trie_t* t, void** blob_out, size_t* nbytes_out) {
     h.off_node_flags = off; off = align_up(off + n);
     h.off_out_off = off;    off = align_up(off + (n + 1) * 4);
     h.off_out_val = off;    off = align_up(off + (size_t)n_out * 4 + 4);
+    h.off_first_val = off;  off = align_up(off + n * 4);
     const size_t total = off;
 
     uint8_t* blob = (uint8_t*)calloc(1, total);
@@ -321,6 +322,7 @@ int acx_flatten(const acx_trie_t* t, void** blob_out, size_t* nbytes_out) {
     uint8_t*  nflags  = (uint8_t*)(blob + h.off_node_flags);
     uint32_t* out_off = (uint32_t*)(blob + h.off_out_off);
     int32_t*  out_val = (int32_t*)(blob + h.off_out_val);
+    int32_t*  first_val = (int32_t*)(blob + h.off_first_val);
 
     // 3. per-target facts + CSR outputs (chain order: s first, then fail(s)'s list)
     std::vector<uint32_t> tflags;
@@ -345,6 +347,7 @@ int acx_flatten(const acx_trie_t* t, void** blob_out, size_t* nbytes_out) {
             const uint32_t c = out_cnt[i];
             fl |= (c >= ACX_ENTRY_CNT_ESCAPE ? ACX_ENTRY_CNT_ESCAPE : c) << ACX_ENTRY_CNT_SHIFT;
             tflags[i] = fl;
+            first_val[i] = c ? out_val[out_off[i]] : 0;
         }
         out_off[n] = o;
     }
@@ -397,6 +400,7 @@ int acx_blob_check_header(const acx_blob_header* h, size_t nbytes) {
     struct { uint64_t off, len; } sec[] = {
         {h->off_cls, 256}, {h->off_table, n * K * 4}, {h->off_fail, n * 4}, {h->off_node_val, n * 4},
         {h->off_node_flags, n}, {h->off_out_off, (n + 1) * 4}, {h->off_out_val, h->n_out * 4},
+        {h->off_first_val, n * 4},
     };
     for (auto& s : sec)
         if (s.off % ACX_BLOB_ALIGN || s.off < ACX_BLOB_HEADER_BYTES || s.off + s.len > nbytes)

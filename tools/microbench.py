@@ -29,6 +29,9 @@ def main():
     ap.add_argument("--mode", default="iter")
     ap.add_argument("--reps", type=int, default=7)
     ap.add_argument("--alphabet", default="dna", choices=["dna", "alnum"])
+    ap.add_argument("--layout", default="stride", choices=["stride", "offsets", "one"],
+                    help="stride: fixed-length reads (direct path); offsets: same reads through a device "
+                         "offsets array (chunked path); one: the whole buffer as ONE haystack (chunk+halo)")
     args = ap.parse_args()
 
     t0 = time.time()
@@ -55,12 +58,20 @@ def main():
                       "image_mb": round(img.nbytes / 1e6, 1), "reads": n, "read_len": L}), flush=True)
     mode = acx.ACX_SCAN_ALL if args.mode == "iter" else acx.ACX_SCAN_LONG
     sc = Scanner(img)
+    d_off = None
+    n_items, stride = n, L
+    if args.layout == "offsets":
+        d_off = DeviceBuffer.from_numpy(np.arange(n + 1, dtype=np.int64) * L)
+        stride = 0
+    elif args.layout == "one":
+        d_off = DeviceBuffer.from_numpy(np.array([0, n * L], dtype=np.int64))
+        n_items, stride = 1, 0
     ref_total = None
     for v in [int(x) for x in args.variants.split(",")]:
         ts = {"walk": [], "scan": [], "expand": [], "total": []}
         total = 0
         for _ in range(args.reps):
-            total = sc.scan(d_hay, n * L, n, stride=L, mode=mode, timing=True, variant=v)
+            total = sc.scan(d_hay, n * L, n_items, dev_off=d_off, stride=stride, mode=mode, timing=True, variant=v)
             t = sc.timing_ms()
             for k in ts:
                 ts[k].append(t[k])
