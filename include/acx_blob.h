@@ -37,13 +37,18 @@
 #define ACX_BLOB_HEADER_BYTES 256u
 #define ACX_BLOB_ALIGN        256u
 
-#define ACX_ENTRY_STATE_BITS  24
-#define ACX_ENTRY_STATE_MASK  0x00FFFFFFu
-#define ACX_ENTRY_EDGE        (1u << 24)
-#define ACX_ENTRY_EOW         (1u << 25)
-#define ACX_ENTRY_FAILEOW     (1u << 26)
-#define ACX_ENTRY_CNT_SHIFT   27
-#define ACX_ENTRY_CNT_ESCAPE  31u
+/* Entry layout, parameterised by the number of state bits SB.
+ *   SB = 24 (narrow): < 2^24 states and a table < 4 GiB: v_mad_u32_u24 + 32-bit offset; CNT has 5 bits
+ *   SB = 27 (wide)  : < 2^27 states, any table size: 64-bit addressing; CNT has 2 bits
+ * (bit positions in the comment above are for SB = 24) */
+#define ACX_STATE_BITS_NARROW 24
+#define ACX_STATE_BITS_WIDE   27
+#define ACX_ENTRY_STATE_MASK(SB)  ((1u << (SB)) - 1u)
+#define ACX_ENTRY_EDGE(SB)        (1u << (SB))
+#define ACX_ENTRY_EOW(SB)         (1u << ((SB) + 1))
+#define ACX_ENTRY_FAILEOW(SB)     (1u << ((SB) + 2))
+#define ACX_ENTRY_CNT_SHIFT(SB)   ((SB) + 3)
+#define ACX_ENTRY_CNT_ESCAPE(SB)  ((1u << (32 - ((SB) + 3))) - 1u)
 
 typedef struct acx_blob_header {
     uint64_t magic;
@@ -55,7 +60,7 @@ typedef struct acx_blob_header {
     uint32_t n_keys;
     uint32_t longest_word;   /* halo size for chunked scans = longest_word - 1 */
     uint32_t max_out_count;  /* max |out(t)| over all states */
-    uint32_t has_escape;     /* 1 if some state has |out(t)| >= ACX_ENTRY_CNT_ESCAPE */
+    uint32_t has_escape;     /* 1 if some state has |out(t)| >= ACX_ENTRY_CNT_ESCAPE(SB) */
     uint64_t n_out;          /* total entries of out_val */
     uint64_t trie_version;   /* acx_trie_version() at flatten time */
     /* section offsets (bytes from blob start) */
@@ -69,7 +74,9 @@ typedef struct acx_blob_header {
     uint64_t fnv1a64;        /* FNV-1a of bytes [header_bytes, total_bytes)              */
     uint64_t off_first_val;  /* int32  [n_states]       out_val[out_off[s]] (first output of s:
                                 the value iter_long reports, and the only one when CNT == 1) */
-    uint8_t  reserved[ACX_BLOB_HEADER_BYTES - 136];
+    uint32_t state_bits;     /* SB of the entry layout: 24 or 27                         */
+    uint32_t reserved0;
+    uint8_t  reserved[ACX_BLOB_HEADER_BYTES - 144];
 } acx_blob_header;
 
 #endif

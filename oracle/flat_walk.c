@@ -44,17 +44,18 @@ int64_t flat_iter(const void* blob, const uint8_t* hay, int64_t len,
     flat_t f;
     if (flat_open(blob, &f) < 0) return -1;
     const uint32_t K = f.h->n_classes;
+    const uint32_t SB = f.h->state_bits;
     uint32_t state = state_io ? (uint32_t)*state_io : 0;
     int64_t n = 0;
     for (int64_t i = 0; i < len; i++) {
         uint32_t e = f.table[(size_t)state * K + f.cls[hay[i]]];
-        state = e & ACX_ENTRY_STATE_MASK;
-        uint32_t cnt = e >> ACX_ENTRY_CNT_SHIFT;
+        state = e & ACX_ENTRY_STATE_MASK(SB);
+        uint32_t cnt = e >> ACX_ENTRY_CNT_SHIFT(SB);
         if (cnt) {
             uint32_t o0 = f.out_off[state], o1 = f.out_off[state + 1];
             /* the packed count must agree with the CSR unless it is the escape value */
-            if (cnt != ACX_ENTRY_CNT_ESCAPE && cnt != o1 - o0) return -3;
-            if (cnt == ACX_ENTRY_CNT_ESCAPE && o1 - o0 < ACX_ENTRY_CNT_ESCAPE) return -3;
+            if (cnt != ACX_ENTRY_CNT_ESCAPE(SB) && cnt != o1 - o0) return -3;
+            if (cnt == ACX_ENTRY_CNT_ESCAPE(SB) && o1 - o0 < ACX_ENTRY_CNT_ESCAPE(SB)) return -3;
             if (f.first_val[state] != f.out_val[o0]) return -4;
             for (uint32_t r = o0; r < o1; r++) {
                 if (n < cap) { out_end[n] = (int32_t)(i + index_base); out_val[n] = f.out_val[r]; }
@@ -71,6 +72,7 @@ int64_t flat_iter_long(const void* blob, const uint8_t* hay, int64_t len, int64_
     flat_t f;
     if (flat_open(blob, &f) < 0) return -1;
     const uint32_t K = f.h->n_classes;
+    const uint32_t SB = f.h->state_bits;
     int64_t n = 0;
     uint32_t state = 0;
     int64_t index = 0;
@@ -82,14 +84,14 @@ int64_t flat_iter_long(const void* blob, const uint8_t* hay, int64_t len, int64_
         int emit = 0;
         while (index < len) {
             uint32_t e = f.table[(size_t)state * K + f.cls[hay[index]]];
-            uint32_t next = e & ACX_ENTRY_STATE_MASK;
-            if (!(e & ACX_ENTRY_EDGE) && have_last) { emit = 1; break; }   /* …IterLong.c:131-132 */
+            uint32_t next = e & ACX_ENTRY_STATE_MASK(SB);
+            if (!(e & ACX_ENTRY_EDGE(SB)) && have_last) { emit = 1; break; }   /* …IterLong.c:131-132 */
             if (next == 0) { state = 0; index++; continue; }               /* fail walk ended in NULL (:137-140) */
             /* a real edge from `state`, or from the first fail ancestor that has one (:134-143
              * followed by the next loop iteration at :116): the checks of :118-126 on `next` */
-            if (e & ACX_ENTRY_EOW) {
+            if (e & ACX_ENTRY_EOW(SB)) {
                 last_state = next; last_index = index; have_last = 1;
-            } else if (e & ACX_ENTRY_FAILEOW) {
+            } else if (e & ACX_ENTRY_FAILEOW(SB)) {
                 last_state = next; last_index = index; have_last = 1;      /* reports fail(next): first output of next */
                 emit = 1; break;
             }

@@ -271,7 +271,7 @@ extern "C" int acx_scan_batch(acx_image_t* img, const acx_scan_params* p, acx_re
     acx_walk_args wa;
     wa.hay = p->dev_hay; wa.hay_cap = p->hay_capacity; wa.off = p->dev_off; wa.stride = p->stride; wa.n_hay = p->n_hay;
     wa.init_state = p->dev_init_state; wa.index_base = p->dev_index_base;
-    wa.cls = img->cls; wa.table = img->table; wa.out_off = img->out_off; wa.row_bytes = img->h.n_classes * 4u;
+    wa.cls = img->cls; wa.table = img->table; wa.out_off = img->out_off; wa.row_bytes = img->h.n_classes * 4u; wa.state_bits = img->h.state_bits;
     wa.counts = r->counts.p; wa.nev = r->nev.p; wa.events = r->events.p;
     wa.final_state = r->has_final ? r->final_state.p : nullptr;
 
@@ -302,7 +302,7 @@ extern "C" int acx_scan_batch(acx_image_t* img, const acx_scan_params* p, acx_re
     acx_expand_args ea;
     ea.off = p->dev_off; ea.stride = p->stride; ea.n_hay = n_items; ea.nev = r->nev.p; ea.events = r->events.p;
     ea.match_off = item_match_off; ea.out_off = img->out_off; ea.out_val = img->out_val; ea.first_val = img->first_val;
-    ea.long_mode = p->mode == ACX_SCAN_LONG ? 1 : 0;
+    ea.long_mode = p->mode == ACX_SCAN_LONG ? 1 : 0; ea.state_bits = img->h.state_bits;
     ea.ck = chunked ? r->ck.p : nullptr; ea.n_items_dev = nullptr;
     // Speculative launch with the capacity we already have: no host round trip between
     // scan and expand in the steady state.  The kernel is a no-op if the total does not fit.

@@ -20,6 +20,7 @@ struct acx_walk_args {
     const uint32_t* table;     // uint32[n_states*K]
     const uint32_t* out_off;   // uint32[n_states+1]
     uint32_t        row_bytes; // K*4
+    uint32_t        state_bits; // entry layout: 24 (narrow) or 27 (wide), include/acx_blob.h
     // outputs
     int32_t* counts;           // matches per haystack
     int32_t* nev;              // events per haystack
@@ -63,6 +64,7 @@ struct acx_expand_args {
     uint2*   matches;          // acx_match_t[capacity]
     int64_t  capacity;
     int32_t  long_mode;        // 1: every event is exactly one match (iter_long)
+    uint32_t state_bits;       // entry layout of the image
     // chunked scans: items are chunks; event base = ck[c].start + ck[c].emit; the number of
     // items lives in device memory (n_items_dev) and n_hay is only an upper bound for the grid
     const acx_chunk_desc* ck;  // nullable

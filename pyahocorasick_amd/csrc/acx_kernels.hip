@@ -79,28 +79,41 @@ struct LaneState {
     uint2*   ev;        // next free event slot
 };
 
-template <bool ESCAPE, bool EVENTS, bool NT>
+// one table lookup.  SB = 24: the raw previous entry is the state operand (v_mad_u32_u24 only
+// reads its low 24 bits) and the byte offset fits 32 bits (saddr + voffset addressing);
+// SB = 27: mask, 64-bit address.
+template <int SB>
+__device__ __forceinline__ uint32_t load_entry(const uint8_t* table_bytes, uint32_t state_raw, uint32_t row_bytes, uint32_t c4) {
+    if (SB == ACX_STATE_BITS_NARROW) {
+        const uint32_t o = __umul24(state_raw, row_bytes) + c4;        // v_mad_u32_u24
+        return *(const uint32_t*)(table_bytes + o);
+    } else {
+        const uint64_t o = (uint64_t)(state_raw & ACX_ENTRY_STATE_MASK(SB)) * row_bytes + c4;
+        return *(const uint32_t*)(table_bytes + o);
+    }
+}
+
+template <int SB, bool ESCAPE, bool EVENTS, int NT>
 __device__ __forceinline__ void step(uint32_t c4, uint32_t idx, const uint8_t* table_bytes,
                                      uint32_t row_bytes, const uint32_t* out_off, LaneState& L) {
-    const uint32_t o  = __umul24(L.state, row_bytes) + c4;           // v_mad_u32_u24
-    const uint32_t e  = *(const uint32_t*)(table_bytes + o);         // the one gather per byte
+    const uint32_t e = load_entry<SB>(table_bytes, L.state, row_bytes, c4);   // the one gather per byte
     L.state = e;
     if (EVENTS || ESCAPE) {
         // count inside the (rarely lane-wide) branch: nothing but the gather, one compare and
         // the branch stays on the common path, and no entry has to be kept live for later
-        if (e >> ACX_ENTRY_CNT_SHIFT) {
-            uint32_t c = e >> ACX_ENTRY_CNT_SHIFT;
+        if (e >> ACX_ENTRY_CNT_SHIFT(SB)) {
+            uint32_t c = e >> ACX_ENTRY_CNT_SHIFT(SB);
             if (ESCAPE) {
-                if (c == ACX_ENTRY_CNT_ESCAPE) {
-                    const uint32_t s = e & ACX_ENTRY_STATE_MASK;
+                if (c == ACX_ENTRY_CNT_ESCAPE(SB)) {
+                    const uint32_t s = e & ACX_ENTRY_STATE_MASK(SB);
                     c = out_off[s + 1] - out_off[s];
                 }
             }
-            if (EVENTS) store_event<NT>(L.ev++, idx, e);
+            if (EVENTS) store_event<(NT & 2) != 0>(L.ev++, idx, e);
             L.cnt += c;
         }
     } else {
-        L.cnt += e >> ACX_ENTRY_CNT_SHIFT;
+        L.cnt += e >> ACX_ENTRY_CNT_SHIFT(SB);
     }
 }
 
@@ -114,7 +127,7 @@ __device__ __forceinline__ void classes8(uint32_t w0, uint32_t w1, const uint32_
     for (int i = 0; i < 4; i++) c4[4 + i] = s_cls4[(w1 >> (i * 8)) & 0xffu];
 }
 
-template <bool ESCAPE, bool EVENTS, bool NT, bool GUARD>
+template <int SB, bool ESCAPE, bool EVENTS, int NT, bool GUARD>
 __device__ __forceinline__ void block16(const uint4 w, uint32_t idx0, int rem, const uint32_t* s_cls4,
                                         const uint8_t* table_bytes, uint32_t row_bytes, const uint32_t* out_off,
                                         LaneState& L) {
@@ -122,16 +135,16 @@ __device__ __forceinline__ void block16(const uint4 w, uint32_t idx0, int rem, c
     classes8(w.x, w.y, s_cls4, c4);
 #pragma unroll
     for (int i = 0; i < 8; i++)
-        if (!GUARD || i < rem) step<ESCAPE, EVENTS, NT>(c4[i], idx0 + i, table_bytes, row_bytes, out_off, L);
+        if (!GUARD || i < rem) step<SB, ESCAPE, EVENTS, NT>(c4[i], idx0 + i, table_bytes, row_bytes, out_off, L);
     classes8(w.z, w.w, s_cls4, c4);
 #pragma unroll
     for (int i = 0; i < 8; i++)
-        if (!GUARD || 8 + i < rem) step<ESCAPE, EVENTS, NT>(c4[i], idx0 + 8 + i, table_bytes, row_bytes, out_off, L);
+        if (!GUARD || 8 + i < rem) step<SB, ESCAPE, EVENTS, NT>(c4[i], idx0 + 8 + i, table_bytes, row_bytes, out_off, L);
 }
 
 // second __launch_bounds__ argument = waves per SIMD the register allocation must allow:
 // the kernel is bound by memory latency/transactions, so ILP=1 wants all 8 (<= 64 VGPRs).
-template <bool ESCAPE, int ILP, bool EVENTS, bool NT>
+template <int SB, bool ESCAPE, int ILP, bool EVENTS, int NT>
 __global__ void __launch_bounds__(ACX_BLOCK, ILP == 1 ? 8 : 5) k_walk_all(const acx_walk_args a) {
     __shared__ uint32_t s_cls4[256];
     s_cls4[threadIdx.x] = (uint32_t)a.cls[threadIdx.x] * 4u;   // blockDim.x == 256
@@ -186,7 +199,7 @@ __global__ void __launch_bounds__(ACX_BLOCK, ILP == 1 ? 8 : 5) k_walk_all(const 
                 // every chain of every lane has a full block: interleave the chains step by step
                 uint4 w[ILP];
 #pragma unroll
-                for (int q = 0; q < ILP; q++) w[q] = load16_guarded<NT>(p[q] + j0, limit);
+                for (int q = 0; q < ILP; q++) w[q] = load16_guarded<(NT & 1) != 0>(p[q] + j0, limit);
 #pragma unroll
                 for (int half = 0; half < 2; half++) {
                     uint32_t c4[ILP][8];
@@ -197,7 +210,7 @@ __global__ void __launch_bounds__(ACX_BLOCK, ILP == 1 ? 8 : 5) k_walk_all(const 
                     for (int i = 0; i < 8; i++) {
 #pragma unroll
                         for (int q = 0; q < ILP; q++)
-                            step<ESCAPE, EVENTS, NT>(c4[q][i], base[q] + j0 + half * 8 + i, table_bytes, a.row_bytes, a.out_off, L[q]);
+                            step<SB, ESCAPE, EVENTS, NT>(c4[q][i], base[q] + j0 + half * 8 + i, table_bytes, a.row_bytes, a.out_off, L[q]);
                     }
                 }
                 continue;
@@ -205,9 +218,9 @@ __global__ void __launch_bounds__(ACX_BLOCK, ILP == 1 ? 8 : 5) k_walk_all(const 
 #pragma unroll
             for (int q = 0; q < ILP; q++) {
                 if (rem[q] > 0) {   // lanes whose haystack is exhausted sit out; __all is over the active lanes
-                    const uint4 w = load16_guarded<NT>(p[q] + j0, limit);
-                    if (__all(rem[q] >= 16)) block16<ESCAPE, EVENTS, NT, false>(w, base[q] + j0, 16, s_cls4, table_bytes, a.row_bytes, a.out_off, L[q]);
-                    else                     block16<ESCAPE, EVENTS, NT, true >(w, base[q] + j0, rem[q], s_cls4, table_bytes, a.row_bytes, a.out_off, L[q]);
+                    const uint4 w = load16_guarded<(NT & 1) != 0>(p[q] + j0, limit);
+                    if (__all(rem[q] >= 16)) block16<SB, ESCAPE, EVENTS, NT, false>(w, base[q] + j0, 16, s_cls4, table_bytes, a.row_bytes, a.out_off, L[q]);
+                    else                     block16<SB, ESCAPE, EVENTS, NT, true >(w, base[q] + j0, rem[q], s_cls4, table_bytes, a.row_bytes, a.out_off, L[q]);
                 }
             }
         }
@@ -216,7 +229,7 @@ __global__ void __launch_bounds__(ACX_BLOCK, ILP == 1 ? 8 : 5) k_walk_all(const 
             if (valid[q]) {
                 a.counts[h[q]] = (int32_t)L[q].cnt;
                 a.nev[h[q]] = (int32_t)(L[q].ev - ev0[q]);
-                if (a.final_state) a.final_state[h[q]] = (int32_t)(L[q].state & ACX_ENTRY_STATE_MASK);
+                if (a.final_state) a.final_state[h[q]] = (int32_t)(L[q].state & ACX_ENTRY_STATE_MASK(SB));
             }
         }
     }
@@ -230,11 +243,12 @@ __global__ void __launch_bounds__(ACX_BLOCK, ILP == 1 ? 8 : 5) k_walk_all(const 
 // then exactly like k_walk_all.  Chunks of one haystack are consecutive work items, so the
 // per-chunk results concatenate to the haystack's result in reference order.
 // ---------------------------------------------------------------------------------
+template <int SB>
 __device__ __forceinline__ void silent_step(uint32_t c4, const uint8_t* table_bytes, uint32_t row_bytes, LaneState& L) {
-    L.state = *(const uint32_t*)(table_bytes + (__umul24(L.state, row_bytes) + c4));
+    L.state = load_entry<SB>(table_bytes, L.state, row_bytes, c4);
 }
 
-template <bool ESCAPE>
+template <int SB, bool ESCAPE>
 __global__ void __launch_bounds__(ACX_BLOCK, 8) k_walk_chunks(const acx_walk_args a, const acx_chunk_desc* ck,
                                                              const int64_t* n_chunks_dev) {
     __shared__ uint32_t s_cls4[256];
@@ -270,7 +284,7 @@ __global__ void __launch_bounds__(ACX_BLOCK, 8) k_walk_chunks(const acx_walk_arg
             if (rem > 0) {
                 const uint4 w = load16_guarded<false>(p + j0, limit);
                 if (__all(rem >= 16 && j0 >= emit)) {
-                    block16<ESCAPE, true, false, false>(w, base + j0, 16, s_cls4, table_bytes, a.row_bytes, a.out_off, L);
+                    block16<SB, ESCAPE, true, 2, false>(w, base + j0, 16, s_cls4, table_bytes, a.row_bytes, a.out_off, L);
                 } else {
                     uint32_t c4[8];
 #pragma unroll
@@ -280,8 +294,8 @@ __global__ void __launch_bounds__(ACX_BLOCK, 8) k_walk_chunks(const acx_walk_arg
                         for (int i = 0; i < 8; i++) {
                             const int j = j0 + half * 8 + i;
                             if (half * 8 + i < rem) {
-                                if (j >= emit) step<ESCAPE, true, false>(c4[i], base + j, table_bytes, a.row_bytes, a.out_off, L);
-                                else           silent_step(c4[i], table_bytes, a.row_bytes, L);
+                                if (j >= emit) step<SB, ESCAPE, true, 2>(c4[i], base + j, table_bytes, a.row_bytes, a.out_off, L);
+                                else           silent_step<SB>(c4[i], table_bytes, a.row_bytes, L);
                             }
                         }
                     }
@@ -291,7 +305,7 @@ __global__ void __launch_bounds__(ACX_BLOCK, 8) k_walk_chunks(const acx_walk_arg
         if (valid) {
             a.counts[c] = (int32_t)L.cnt;
             a.nev[c] = (int32_t)(L.ev - ev0);
-            if (a.final_state && (d.flags & 2)) a.final_state[d.hay] = (int32_t)(L.state & ACX_ENTRY_STATE_MASK);
+            if (a.final_state && (d.flags & 2)) a.final_state[d.hay] = (int32_t)(L.state & ACX_ENTRY_STATE_MASK(SB));
         }
     }
 }
@@ -353,6 +367,7 @@ __global__ void __launch_bounds__(ACX_BLOCK) k_hay_offsets(const int64_t* ck_fir
 // step of the next loop iteration — which is exactly the fail-resolved transition.
 // Every event is one final match: {end_index, state whose first output is the value}.
 // ---------------------------------------------------------------------------------
+template <int SB>
 __global__ void __launch_bounds__(ACX_BLOCK) k_walk_long(const acx_walk_args a) {
     __shared__ uint32_t s_cls4[256];
     s_cls4[threadIdx.x] = (uint32_t)a.cls[threadIdx.x] * 4u;
@@ -380,17 +395,17 @@ __global__ void __launch_bounds__(ACX_BLOCK) k_walk_long(const acx_walk_args a) 
             bool emit = false;
             if (index < len) {
                 const uint32_t c4 = s_cls4[p[index]];
-                const uint32_t en = *(const uint32_t*)(table_bytes + (__umul24(state, a.row_bytes) + c4));
-                const uint32_t next = en & ACX_ENTRY_STATE_MASK;
-                if (!(en & ACX_ENTRY_EDGE) && have_last) {
+                const uint32_t en = load_entry<SB>(table_bytes, state, a.row_bytes, c4);
+                const uint32_t next = en & ACX_ENTRY_STATE_MASK(SB);
+                if (!(en & ACX_ENTRY_EDGE(SB)) && have_last) {
                     emit = true;
                 } else if (next == 0) {
                     state = 0; index++;
                 } else {
-                    if (en & ACX_ENTRY_EOW) {
+                    if (en & ACX_ENTRY_EOW(SB)) {
                         last_state = next; last_index = index; have_last = true;
                         state = next; index++;
-                    } else if (en & ACX_ENTRY_FAILEOW) {
+                    } else if (en & ACX_ENTRY_FAILEOW(SB)) {
                         last_state = next; last_index = index; have_last = true;
                         emit = true;
                     } else {
@@ -505,6 +520,8 @@ __global__ void __launch_bounds__(ACX_BLOCK) k_expand(const acx_expand_args a) {
     // if the staging capacity guess was too small the host grows the buffer and relaunches
     const int64_t n_items = a.n_items_dev ? *a.n_items_dev : a.n_hay;
     if (a.match_off[n_items] > a.capacity) return;
+    const uint32_t state_mask = ACX_ENTRY_STATE_MASK(a.state_bits), cnt_shift = ACX_ENTRY_CNT_SHIFT(a.state_bits),
+                   cnt_escape = ACX_ENTRY_CNT_ESCAPE(a.state_bits);
     const int64_t n_threads = (int64_t)gridDim.x * ACX_BLOCK;
     for (int64_t h = (int64_t)blockIdx.x * ACX_BLOCK + threadIdx.x; h < n_items; h += n_threads) {
         const int32_t n = a.nev[h];
@@ -514,16 +531,16 @@ __global__ void __launch_bounds__(ACX_BLOCK) k_expand(const acx_expand_args a) {
         if (a.long_mode) {
             for (int32_t k = 0; k < n; k++) {
                 const uint2 v = ev[k];
-                const int32_t val = a.out_val[a.out_off[v.y & ACX_ENTRY_STATE_MASK]];
+                const int32_t val = a.out_val[a.out_off[v.y & state_mask]];
                 *out++ = make_uint2(v.x, (uint32_t)val);
             }
         } else {
             for (int32_t k = 0; k < n; k++) {
                 const uint2 v = ev[k];
-                const uint32_t s = v.y & ACX_ENTRY_STATE_MASK;
-                uint32_t c = v.y >> ACX_ENTRY_CNT_SHIFT;
+                const uint32_t s = v.y & state_mask;
+                uint32_t c = v.y >> cnt_shift;
                 const uint32_t o = a.out_off[s];
-                if (c == ACX_ENTRY_CNT_ESCAPE) c = a.out_off[s + 1] - o;
+                if (c == cnt_escape) c = a.out_off[s + 1] - o;
                 for (uint32_t r = 0; r < c; r++) *out++ = make_uint2(v.x, (uint32_t)a.out_val[o + r]);
             }
         }
@@ -539,6 +556,8 @@ template <int GROUP>
 __global__ void __launch_bounds__(ACX_BLOCK) k_expand_grp(const acx_expand_args a) {
     const int64_t n_items = a.n_items_dev ? *a.n_items_dev : a.n_hay;
     if (a.match_off[n_items] > a.capacity) return;
+    const uint32_t state_mask = ACX_ENTRY_STATE_MASK(a.state_bits), cnt_shift = ACX_ENTRY_CNT_SHIFT(a.state_bits),
+                   cnt_escape = ACX_ENTRY_CNT_ESCAPE(a.state_bits);
     const int sub = threadIdx.x & (GROUP - 1);
     const int64_t groups_per_block = ACX_BLOCK / GROUP;
     const int64_t n_groups = (int64_t)gridDim.x * groups_per_block;
@@ -552,13 +571,13 @@ __global__ void __launch_bounds__(ACX_BLOCK) k_expand_grp(const acx_expand_args 
             const bool valid = k < n;
             uint2 v = make_uint2(0, 0);
             if (valid) v = ev[k];
-            const uint32_t s = v.y & ACX_ENTRY_STATE_MASK;
+            const uint32_t s = v.y & state_mask;
             uint32_t c = 0;
             if (valid) {
                 if (a.long_mode) c = 1;
                 else {
-                    c = v.y >> ACX_ENTRY_CNT_SHIFT;
-                    if (c == ACX_ENTRY_CNT_ESCAPE) c = a.out_off[s + 1] - a.out_off[s];
+                    c = v.y >> cnt_shift;
+                    if (c == cnt_escape) c = a.out_off[s + 1] - a.out_off[s];
                 }
             }
             uint32_t incl = c;                 // inclusive scan across the group
@@ -597,27 +616,36 @@ int64_t acx_scan_num_partials(int64_t n) { return (n + SCAN_TILE - 1) / SCAN_TIL
 //   bit  8    count only, no events (diagnostic; the result then has no matches)
 //   bits 9-11 expand kernel shape (see acx_launch_expand)
 //   bit  12   non-temporal haystack loads and event stores
-template <bool ESCAPE, int ILP, bool EVENTS, bool NT>
+template <int SB, bool ESCAPE, int ILP, bool EVENTS, int NT>
 static void launch_walk_all_t(const acx_walk_args& a, int blocks_per_cu, hipStream_t s) {
     const int64_t per_task = (int64_t)ACX_WAVE * ILP;
     const int64_t n_tasks = (a.n_hay + per_task - 1) / per_task;
     const int64_t blocks = (n_tasks + (ACX_BLOCK / ACX_WAVE) - 1) / (ACX_BLOCK / ACX_WAVE);
     const int64_t cap = 256 * (int64_t)blocks_per_cu;
     const int grid = (int)(blocks < 1 ? 1 : (blocks > cap ? cap : blocks));
-    hipLaunchKernelGGL((k_walk_all<ESCAPE, ILP, EVENTS, NT>), dim3(grid), dim3(ACX_BLOCK), 0, s, a);
+    hipLaunchKernelGGL((k_walk_all<SB, ESCAPE, ILP, EVENTS, NT>), dim3(grid), dim3(ACX_BLOCK), 0, s, a);
 }
 
 template <bool ESCAPE>
-static hipError_t dispatch_walk_all(const acx_walk_args& a, int ilp, bool events, bool nt, int bpc, hipStream_t s) {
+static hipError_t dispatch_walk_all(const acx_walk_args& a, int ilp, bool events, int nt, int bpc, hipStream_t s) {
+    constexpr int N = ACX_STATE_BITS_NARROW;
+    if (a.state_bits == ACX_STATE_BITS_WIDE) {      // wide images: one tuned shape only
+        launch_walk_all_t<ACX_STATE_BITS_WIDE, ESCAPE, 1, true, 2>(a, bpc, s);
+        return hipGetLastError();
+    }
     if (ilp == 2) {            // ILP 2 exists as a tuning variant only (no gain measured on MI355X)
-        if (events) launch_walk_all_t<ESCAPE, 2, true, false>(a, bpc, s);
-        else        launch_walk_all_t<ESCAPE, 2, false, false>(a, bpc, s);
+        if (events) launch_walk_all_t<N, ESCAPE, 2, true, 0>(a, bpc, s);
+        else        launch_walk_all_t<N, ESCAPE, 2, false, 0>(a, bpc, s);
     } else if (events) {
-        if (nt) launch_walk_all_t<ESCAPE, 1, true, true>(a, bpc, s);
-        else    launch_walk_all_t<ESCAPE, 1, true, false>(a, bpc, s);
+        switch (nt) {
+            case 1:  launch_walk_all_t<N, ESCAPE, 1, true, 1>(a, bpc, s); break;
+            case 2:  launch_walk_all_t<N, ESCAPE, 1, true, 2>(a, bpc, s); break;
+            case 3:  launch_walk_all_t<N, ESCAPE, 1, true, 3>(a, bpc, s); break;
+            default: launch_walk_all_t<N, ESCAPE, 1, true, 0>(a, bpc, s); break;
+        }
     } else {
-        if (nt) launch_walk_all_t<ESCAPE, 1, false, true>(a, bpc, s);
-        else    launch_walk_all_t<ESCAPE, 1, false, false>(a, bpc, s);
+        if (nt & 1) launch_walk_all_t<N, ESCAPE, 1, false, 1>(a, bpc, s);
+        else        launch_walk_all_t<N, ESCAPE, 1, false, 0>(a, bpc, s);
     }
     return hipGetLastError();
 }
@@ -628,7 +656,13 @@ hipError_t acx_launch_walk_all(const acx_walk_args& a, bool has_escape, int vari
     int bpc = (variant >> 4) & 0xF;
     if (bpc == 0) bpc = 8;
     const bool events = !((variant >> 8) & 1);
-    const bool nt = (variant >> 12) & 1;
+    // Event stores are non-temporal by default (measured -4 % walk time on config 2: the 8-byte
+    // stores, one line per lane, otherwise displace table rows from L2); haystack loads are not
+    // (nt loads measured +8 %).  bit 12: nt loads too; bit 14: nt loads only; bit 15: no nt at all.
+    int nt = 2;
+    if ((variant >> 12) & 1) nt = 3;
+    if ((variant >> 14) & 1) nt = 1;
+    if ((variant >> 15) & 1) nt = 0;
     if (ilp > 2) return hipErrorInvalidValue;
     return has_escape ? dispatch_walk_all<true>(a, ilp, events, nt, bpc, s)
                       : dispatch_walk_all<false>(a, ilp, events, nt, bpc, s);
@@ -638,7 +672,8 @@ hipError_t acx_launch_walk_long(const acx_walk_args& a, int variant, hipStream_t
     (void)variant;
     if (a.n_hay <= 0) return hipSuccess;
     const int grid = grid_for_waves((a.n_hay + ACX_WAVE - 1) / ACX_WAVE);
-    hipLaunchKernelGGL(k_walk_long, dim3(grid), dim3(ACX_BLOCK), 0, s, a);
+    if (a.state_bits == ACX_STATE_BITS_WIDE) hipLaunchKernelGGL(k_walk_long<ACX_STATE_BITS_WIDE>, dim3(grid), dim3(ACX_BLOCK), 0, s, a);
+    else                                     hipLaunchKernelGGL(k_walk_long<ACX_STATE_BITS_NARROW>, dim3(grid), dim3(ACX_BLOCK), 0, s, a);
     return hipGetLastError();
 }
 
@@ -692,8 +727,14 @@ hipError_t acx_launch_walk_chunks(const acx_walk_args& a, const acx_chunk_desc* 
                                   int64_t n_chunks_bound, bool has_escape, hipStream_t s) {
     if (n_chunks_bound <= 0) return hipSuccess;
     const int grid = grid_for_waves((n_chunks_bound + ACX_WAVE - 1) / ACX_WAVE);
-    if (has_escape) hipLaunchKernelGGL(k_walk_chunks<true>, dim3(grid), dim3(ACX_BLOCK), 0, s, a, ck, n_chunks_dev);
-    else            hipLaunchKernelGGL(k_walk_chunks<false>, dim3(grid), dim3(ACX_BLOCK), 0, s, a, ck, n_chunks_dev);
+    constexpr int N = ACX_STATE_BITS_NARROW, W = ACX_STATE_BITS_WIDE;
+    if (a.state_bits == W) {
+        if (has_escape) hipLaunchKernelGGL((k_walk_chunks<W, true>), dim3(grid), dim3(ACX_BLOCK), 0, s, a, ck, n_chunks_dev);
+        else            hipLaunchKernelGGL((k_walk_chunks<W, false>), dim3(grid), dim3(ACX_BLOCK), 0, s, a, ck, n_chunks_dev);
+    } else {
+        if (has_escape) hipLaunchKernelGGL((k_walk_chunks<N, true>), dim3(grid), dim3(ACX_BLOCK), 0, s, a, ck, n_chunks_dev);
+        else            hipLaunchKernelGGL((k_walk_chunks<N, false>), dim3(grid), dim3(ACX_BLOCK), 0, s, a, ck, n_chunks_dev);
+    }
     return hipGetLastError();
 }
 

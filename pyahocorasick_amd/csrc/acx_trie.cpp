@@ -257,9 +257,9 @@ int acx_flatten(const acx_trie_t* t, void** blob_out, size_t* nbytes_out) {
     if (t->kind != ACX_KIND_AHOCORASICK)
         return acx_fail(ACX_E_STATE, "acx_flatten: not an Aho-Corasick automaton yet: call make_automaton first");
     const size_t n = t->bfs.size();
-    if (n >= ((size_t)1 << ACX_ENTRY_STATE_BITS))
-        return acx_fail(ACX_E_UNSUPPORTED, "acx_flatten: %zu states exceed the %d-bit state field of this image layout",
-                        n, ACX_ENTRY_STATE_BITS);
+    if (n >= ((size_t)1 << ACX_STATE_BITS_WIDE))
+        return acx_fail(ACX_E_UNSUPPORTED, "acx_flatten: %zu states exceed the %d-bit state field of the wide image layout",
+                        n, ACX_STATE_BITS_WIDE);
 
     // 1. byte classes: class 0 = bytes used by no key (they all lead to the root)
     bool used[256] = {false};
@@ -272,9 +272,13 @@ int acx_flatten(const acx_trie_t* t, void** blob_out, size_t* nbytes_out) {
     else { K = n_used + 1; unsigned k = 1; for (int b = 0; b < 256; b++) cls[b] = used[b] ? (uint8_t)k++ : 0; }
 
     const size_t table_entries = n * (size_t)K;
-    if (table_entries * 4 >= ((size_t)1 << 32))
-        return acx_fail(ACX_E_UNSUPPORTED, "acx_flatten: transition table of %zu bytes exceeds the 4 GiB "
-                        "32-bit-offset layout of this build", table_entries * 4);
+    // narrow layout whenever it fits: 24-bit states and 32-bit byte offsets into the table
+    // (ACX_FORCE_WIDE_LAYOUT=1 forces the wide layout on small automata: test hook)
+    const char* force_wide = getenv("ACX_FORCE_WIDE_LAYOUT");
+    const uint32_t SB = (n < ((size_t)1 << ACX_STATE_BITS_NARROW) && table_entries * 4 < ((size_t)1 << 32) &&
+                         !(force_wide && force_wide[0] == '1'))
+                            ? ACX_STATE_BITS_NARROW : ACX_STATE_BITS_WIDE;
+    const uint32_t ESC = ACX_ENTRY_CNT_ESCAPE(SB);
 
     std::vector<int32_t> id;          // arena index -> BFS id
     std::vector<uint32_t> out_cnt;    // per BFS id
@@ -342,10 +346,10 @@ int acx_flatten(const acx_trie_t* t, void** blob_out, size_t* nbytes_out) {
             const uint32_t fc = out_cnt[f];
             if (fc) { memcpy(out_val + o, out_val + out_off[f], (size_t)fc * 4); o += fc; }
             uint32_t fl = 0;
-            if (nd.eow) fl |= ACX_ENTRY_EOW;
-            if (f != 0 && t->nodes[nd.fail].eow) fl |= ACX_ENTRY_FAILEOW;   // src/AutomatonSearchIterLong.c:123
+            if (nd.eow) fl |= ACX_ENTRY_EOW(SB);
+            if (f != 0 && t->nodes[nd.fail].eow) fl |= ACX_ENTRY_FAILEOW(SB);   // src/AutomatonSearchIterLong.c:123
             const uint32_t c = out_cnt[i];
-            fl |= (c >= ACX_ENTRY_CNT_ESCAPE ? ACX_ENTRY_CNT_ESCAPE : c) << ACX_ENTRY_CNT_SHIFT;
+            fl |= (c >= ESC ? ESC : c) << ACX_ENTRY_CNT_SHIFT(SB);
             tflags[i] = fl;
             first_val[i] = c ? out_val[out_off[i]] : 0;
         }
@@ -358,11 +362,11 @@ int acx_flatten(const acx_trie_t* t, void** blob_out, size_t* nbytes_out) {
         uint32_t* row = table + i * K;
         if (i > 0) {
             const uint32_t* frow = table + (size_t)fail[i] * K;
-            for (uint32_t c = 0; c < K; c++) row[c] = frow[c] & ~ACX_ENTRY_EDGE;
+            for (uint32_t c = 0; c < K; c++) row[c] = frow[c] & ~ACX_ENTRY_EDGE(SB);
         }
         for (int32_t ch = t->nodes[t->bfs[i]].first_child; ch >= 0; ch = t->nodes[ch].next_sibling) {
             const uint32_t tid = (uint32_t)id[ch];
-            row[cls[t->nodes[ch].letter]] = tid | tflags[tid] | ACX_ENTRY_EDGE;
+            row[cls[t->nodes[ch].letter]] = tid | tflags[tid] | ACX_ENTRY_EDGE(SB);
         }
     }
 
@@ -375,7 +379,8 @@ int acx_flatten(const acx_trie_t* t, void** blob_out, size_t* nbytes_out) {
     h.n_keys = (uint32_t)t->count;
     h.longest_word = (uint32_t)t->longest_word;
     h.max_out_count = max_cnt;
-    h.has_escape = max_cnt >= ACX_ENTRY_CNT_ESCAPE ? 1 : 0;
+    h.has_escape = max_cnt >= ESC ? 1 : 0;
+    h.state_bits = SB;
     h.n_out = n_out;
     h.trie_version = (uint64_t)t->version;
     h.fnv1a64 = acx_fnv1a64(blob + ACX_BLOB_HEADER_BYTES, total - ACX_BLOB_HEADER_BYTES);
@@ -394,7 +399,9 @@ int acx_blob_check_header(const acx_blob_header* h, size_t nbytes) {
     if (h->version != ACX_BLOB_VERSION) return acx_fail(ACX_E_FORMAT, "image: version %u, this build reads %u", h->version, ACX_BLOB_VERSION);
     if (h->header_bytes != ACX_BLOB_HEADER_BYTES || h->total_bytes != nbytes)
         return acx_fail(ACX_E_FORMAT, "image: size mismatch (header says %llu, got %zu)", (unsigned long long)h->total_bytes, nbytes);
-    if (h->n_states == 0 || h->n_states >= (1u << ACX_ENTRY_STATE_BITS) || h->n_classes == 0 || h->n_classes > 256)
+    if (h->state_bits != ACX_STATE_BITS_NARROW && h->state_bits != ACX_STATE_BITS_WIDE)
+        return acx_fail(ACX_E_FORMAT, "image: unknown entry layout (state_bits = %u)", h->state_bits);
+    if (h->n_states == 0 || h->n_states >= (1u << h->state_bits) || h->n_classes == 0 || h->n_classes > 256)
         return acx_fail(ACX_E_FORMAT, "image: bad n_states/n_classes");
     const uint64_t n = h->n_states, K = h->n_classes;
     struct { uint64_t off, len; } sec[] = {
@@ -405,7 +412,8 @@ int acx_blob_check_header(const acx_blob_header* h, size_t nbytes) {
     for (auto& s : sec)
         if (s.off % ACX_BLOB_ALIGN || s.off < ACX_BLOB_HEADER_BYTES || s.off + s.len > nbytes)
             return acx_fail(ACX_E_FORMAT, "image: section out of bounds");
-    if (n * K * 4 >= (1ull << 32)) return acx_fail(ACX_E_FORMAT, "image: table too large for 32-bit offsets");
+    if (h->state_bits == ACX_STATE_BITS_NARROW && n * K * 4 >= (1ull << 32))
+        return acx_fail(ACX_E_FORMAT, "image: table too large for the narrow layout's 32-bit offsets");
     return ACX_OK;
 }
 
@@ -423,7 +431,7 @@ int acx_blob_validate(const void* blob, size_t nbytes) {
     const uint32_t* table = (const uint32_t*)(b + h.off_table);
     const uint64_t ne = (uint64_t)h.n_states * h.n_classes;
     for (uint64_t i = 0; i < ne; i++)
-        if ((table[i] & ACX_ENTRY_STATE_MASK) >= h.n_states) return acx_fail(ACX_E_FORMAT, "image: entry %llu targets a state out of range", (unsigned long long)i);
+        if ((table[i] & ACX_ENTRY_STATE_MASK(h.state_bits)) >= h.n_states) return acx_fail(ACX_E_FORMAT, "image: entry %llu targets a state out of range", (unsigned long long)i);
     const uint32_t* oo = (const uint32_t*)(b + h.off_out_off);
     for (uint32_t s = 0; s < h.n_states; s++)
         if (oo[s] > oo[s + 1]) return acx_fail(ACX_E_FORMAT, "image: CSR offsets not monotone at state %u", s);

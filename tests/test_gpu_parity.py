@@ -335,3 +335,80 @@ def test_config5_iter_long_full_size_sample(config2):
     hay_of = np.repeat(np.arange(n), np.diff(off))
     same_h = hay_of[1:] == hay_of[:-1]
     assert np.all(np.diff(e.astype(np.int64))[same_h] > 0)
+
+
+def test_wide_layout_on_gpu(monkeypatch):
+    """27-bit states, 64-bit table addressing, 2-bit counts (escape from 3 outputs on):
+    same fixtures, layout forced on small automata"""
+    monkeypatch.setenv("ACX_FORCE_WIDE_LAYOUT", "1")
+    for c in RANDOM["cases"][::3]:
+        keys, values = _case_values(c)
+        A, _ = build_pair(keys, values, c["store"])
+        hays = [bytes.fromhex(h["hay_hex"]) for h in c["hays"]]
+        assert A.iter_batch(hays) == [expected_pairs(h["iter"]) for h in c["hays"]]
+        assert A.iter_batch(hays, long=True) == [expected_pairs(h["iter_long"]) for h in c["hays"]]
+    keys, reads = dna_workload(3000, 3000, 150, seed=5)
+    A, O = build_pair(keys)
+    n, L = reads.shape
+    off = np.arange(n + 1, dtype=np.int64) * L
+    img = Image.from_automaton(A)
+    d_hay = DeviceBuffer.from_numpy(reads.reshape(-1), pad=64)
+    sc = Scanner(img)
+    for mode in (acx.ACX_SCAN_ALL, acx.ACX_SCAN_LONG):
+        sc.scan(d_hay, n * L, n, stride=L, mode=mode)            # direct kernels
+        moff, e, v, _ = sc.fetch()
+        mo, oe, ov = O.batch(reads.tobytes(), off, mode)
+        assert np.array_equal(moff, mo) and np.array_equal(e, oe) and np.array_equal(v, ov)
+    res = A.scan_batch(reads.reshape(-1), off)                     # chunked kernel
+    mo, oe, ov = O.batch(reads.tobytes(), off, 0)
+    assert np.array_equal(res.offsets, mo) and np.array_equal(res.end_index, oe) and np.array_equal(res.value, ov)
+
+
+# ------------------------------------------------------------------ configs 3 and 4 (scaled)
+def test_config3_text_corpus_scaled():
+    """BASELINE.json config 3 shape, scaled: multi-word lowercase keys, ONE long text corpus
+    (chunk + halo path), compared with the oracle over the whole corpus"""
+    from pyahocorasick_amd.workloads import text_corpus, text_keys, text_vocab
+    vocab = text_vocab(20_000, seed=2)
+    keys = text_keys(vocab, 5_000, seed=3)
+    corpus = text_corpus(vocab, 3_000_000, seed=4)
+    for k in keys[:200]:                                   # make sure there is something to find
+        p = int.from_bytes(k[:6], 'little') % (len(corpus) - 64)
+        corpus[p:p + len(k)] = np.frombuffer(k, dtype=np.uint8)
+    A, O = build_pair(keys)
+    hay = corpus.tobytes()
+    e, v, _ = O.iter_arrays(hay)
+    res = A.scan_batch(hay, [0, len(hay)])
+    assert len(e) >= 200
+    assert np.array_equal(res.end_index, e) and np.array_equal(res.value, v)
+    # sharded the way 8 GPUs would take it (contiguous shards, results concatenated in rank order)
+    from pyahocorasick_amd.parallel import shard_range
+    cuts = [shard_range(len(hay), r, 8) for r in range(8)]
+    img = Image.from_automaton(A)
+    d = DeviceBuffer.from_numpy(corpus, pad=64)
+    halo = max(len(k) for k in keys) - 1
+    es, vs = [], []
+    for lo, hi in cuts:
+        # rank r scans [lo-halo, hi) and keeps matches ending at or after lo: same rule as a chunk
+        s0 = max(0, lo - halo)
+        r = A.scan_batch(hay[s0:hi], [0, hi - s0], index_base=[s0])
+        keep = r.end_index >= lo
+        es.append(r.end_index[keep])
+        vs.append(r.value[keep])
+    assert np.array_equal(np.concatenate(es), e) and np.array_equal(np.concatenate(vs), v)
+
+
+def test_config4_snort_signatures_scaled():
+    """config 4 shape, scaled: binary + printable signatures of 4..128 B (bytes >= 0x80, deep
+    trie, 256 classes), ragged packets with planted signatures"""
+    from pyahocorasick_amd.workloads import packet_payloads, snort_signatures
+    sigs = snort_signatures(4000, seed=5)
+    data, off = packet_payloads(sigs, 2_000_000, seed=6, plant_frac=0.2)
+    A, O = build_pair(sigs)
+    res = A.scan_batch(data, off)
+    mo, e, v = O.batch(data.tobytes(), off, 0)
+    assert mo[-1] > 100
+    assert np.array_equal(res.offsets, mo) and np.array_equal(res.end_index, e) and np.array_equal(res.value, v)
+    resl = A.scan_batch(data, off, acx.ACX_SCAN_LONG)
+    mol, el, vl = O.batch(data.tobytes(), off, 1)
+    assert np.array_equal(resl.offsets, mol) and np.array_equal(resl.end_index, el) and np.array_equal(resl.value, vl)

@@ -165,3 +165,28 @@ def test_int_truncation_matches_reference_probe():
     got, _ = orc.flat_iter(A.flat_image_bytes(), b"xabx")
     assert got == [(2, 5), (2, -3)] == O.iter(b"xabx")
     assert i32(2**40 + 5) == 5
+
+
+def test_wide_layout_flat_walk(monkeypatch):
+    """the 27-bit-state / 2-bit-count entry layout used for automata beyond 2^24 states or a
+    4 GiB table, forced here on small automata"""
+    import struct
+    monkeypatch.setenv("ACX_FORCE_WIDE_LAYOUT", "1")
+    rng = random.Random(13)
+    for trial in range(25):
+        alpha = rng.choice([b"ab", b"ACGT", bytes([0x61, 0x80, 0xFF, 0x00]), bytes(range(256))])
+        keys = list({bytes(rng.choice(alpha) for _ in range(rng.randint(1, 9))) for _ in range(rng.randint(1, 60))})
+        A, O = build_pair(keys, [rng.randint(-2**40, 2**40) for _ in keys])
+        blob = A.flat_image_bytes()
+        assert struct.unpack_from("<I", blob, 136)[0] == 27
+        for _ in range(6):
+            hay = bytes(rng.choice(alpha) for _ in range(rng.randint(0, 200)))
+            got, _ = orc.flat_iter(blob, hay)
+            assert got == O.iter(hay)
+            assert orc.flat_iter_long(blob, hay) == O.iter_long(hay)
+    # counts >= 3 take the escape path in this layout
+    keys = [b"a" * n for n in range(1, 9)]
+    A, O = build_pair(keys)
+    blob = A.flat_image_bytes()
+    got, _ = orc.flat_iter(blob, b"a" * 20)
+    assert got == O.iter(b"a" * 20)

@@ -28,15 +28,26 @@ def main():
     ap.add_argument("--read-len", type=int, default=150)
     ap.add_argument("--mode", default="iter")
     ap.add_argument("--reps", type=int, default=7)
-    ap.add_argument("--alphabet", default="dna", choices=["dna", "alnum"])
+    ap.add_argument("--alphabet", default="dna", choices=["dna", "alnum", "text", "snort"],
+                    help="dna/alnum: fixed-length reads; text: config-3 style corpus as ONE haystack; "
+                         "snort: config-4 style signatures over ragged packets")
+    ap.add_argument("--bytes", type=int, default=256 << 20, help="haystack bytes for text/snort")
     ap.add_argument("--layout", default="stride", choices=["stride", "offsets", "one"],
                     help="stride: fixed-length reads (direct path); offsets: same reads through a device "
                          "offsets array (chunked path); one: the whole buffer as ONE haystack (chunk+halo)")
     args = ap.parse_args()
 
     t0 = time.time()
+    pre_off = None
     if args.alphabet == "dna":
         keys = dna_keys(args.keys, seed=0)
+    elif args.alphabet == "text":
+        from pyahocorasick_amd.workloads import text_corpus, text_keys, text_vocab
+        vocab = text_vocab(1_000_000 if args.keys >= 100_000 else 10 * args.keys, seed=2)
+        keys = text_keys(vocab, args.keys, seed=3)
+    elif args.alphabet == "snort":
+        from pyahocorasick_amd.workloads import packet_payloads, snort_signatures
+        keys = snort_signatures(args.keys, seed=5)
     else:   # SURVEY §8(d) secondary "no-match" variant: 62-symbol keys, ACGT reads (shallow walk)
         import random
         rng = random.Random(0)
@@ -46,21 +57,43 @@ def main():
             ks.add("".join(rng.choice(al) for _ in range(rng.randint(8, 32))).encode())
         keys = sorted(ks)
         rng.shuffle(keys)
+    t_gen = time.time() - t0
+    t1 = time.time()
     A = acx.Automaton(acx.STORE_INTS)
     for i, k in enumerate(keys):
         A.add_word(k, i)
+    t_add = time.time() - t1; t1 = time.time()
     A.make_automaton()
+    t_make = time.time() - t1; t1 = time.time()
     img = Image.from_automaton(A)
-    reads = dna_reads(keys if args.alphabet == "dna" else [], args.reads, args.read_len, seed=1)
-    n, L = reads.shape
-    d_hay = DeviceBuffer.from_numpy(reads.reshape(-1), pad=64)
-    print(json.dumps({"setup_s": round(time.time() - t0, 2), "states": img.num_states, "classes": img.num_classes,
-                      "image_mb": round(img.nbytes / 1e6, 1), "reads": n, "read_len": L}), flush=True)
+    t_img = time.time() - t1
+    if args.alphabet == "text":
+        flat = text_corpus(vocab, args.bytes, seed=4)
+        n, L = 1, len(flat)
+        pre_off = np.array([0, L], dtype=np.int64)
+        args.layout = "pre"
+    elif args.alphabet == "snort":
+        flat, pre_off = packet_payloads(keys, args.bytes, seed=6)
+        n, L = len(pre_off) - 1, 0
+        args.layout = "pre"
+    else:
+        reads = dna_reads(keys if args.alphabet == "dna" else [], args.reads, args.read_len, seed=1)
+        n, L = reads.shape
+        flat = reads.reshape(-1)
+    total_bytes = int(flat.size)
+    d_hay = DeviceBuffer.from_numpy(flat, pad=64)
+    print(json.dumps({"setup_s": round(time.time() - t0, 2), "gen_s": round(t_gen, 2), "add_s": round(t_add, 2),
+                      "make_automaton_s": round(t_make, 2), "flatten_upload_s": round(t_img, 2),
+                      "states": img.num_states, "classes": img.num_classes,
+                      "image_mb": round(img.nbytes / 1e6, 1), "haystacks": n, "bytes": total_bytes}), flush=True)
     mode = acx.ACX_SCAN_ALL if args.mode == "iter" else acx.ACX_SCAN_LONG
     sc = Scanner(img)
     d_off = None
     n_items, stride = n, L
-    if args.layout == "offsets":
+    if args.layout == "pre":
+        d_off = DeviceBuffer.from_numpy(pre_off)
+        stride = 0
+    elif args.layout == "offsets":
         d_off = DeviceBuffer.from_numpy(np.arange(n + 1, dtype=np.int64) * L)
         stride = 0
     elif args.layout == "one":
@@ -71,14 +104,14 @@ def main():
         ts = {"walk": [], "scan": [], "expand": [], "total": []}
         total = 0
         for _ in range(args.reps):
-            total = sc.scan(d_hay, n * L, n_items, dev_off=d_off, stride=stride, mode=mode, timing=True, variant=v)
+            total = sc.scan(d_hay, total_bytes, n_items, dev_off=d_off, stride=stride, mode=mode, timing=True, variant=v)
             t = sc.timing_ms()
             for k in ts:
                 ts[k].append(t[k])
         if ref_total is None and not (v >> 8) & 1:
             ref_total = total
         med = {k: round(float(np.median(x)), 4) for k, x in ts.items()}
-        H = n * L
+        H = total_bytes
         print(json.dumps({"variant": v, "matches": total, "matches_ok": (total == ref_total) or bool((v >> 8) & 1),
                           "ms": med, "min_walk_ms": round(min(ts["walk"]), 4),
                           "walk_GBps_haystack": round(H / med["walk"] / 1e6, 1),
