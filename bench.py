@@ -196,7 +196,10 @@ def main():
         tpath = os.path.join(ROOT, "profiles", "traffic.json")
         if os.path.exists(tpath):
             try:
-                traffic = json.load(open(tpath)).get("%s_n%d_l%d_k%d" % (args.mode, n, L, args.keys))
+                # measured offline with rocprofv3 --pmc (tools/gpu_round.sh stage pmc); bytes per launch
+                # of the dominant kernel that crossed the L2 -> fabric boundary (FETCH_SIZE + WRITE_SIZE)
+                ent = json.load(open(tpath)).get("%s_n%d_l%d_k%d" % (args.mode, n, L, args.keys))
+                traffic = ent["hbm_bytes_dominant_kernel"] if ent else None
             except Exception:
                 traffic = None
         out = {

@@ -272,7 +272,7 @@ class Automaton:
         nbytes = C.c_size_t()
         check(lib().acx_flatten(self._trie, C.byref(blob), C.byref(nbytes)))
         try:
-            return C.string_at(blob, nbytes.value)
+            return bytes((C.c_char * nbytes.value).from_address(blob.value))   # (string_at takes a C int)
         finally:
             lib().acx_blob_free(blob)
 

@@ -63,7 +63,14 @@ class Image:
 
     @classmethod
     def from_automaton(cls, automaton):
-        return cls.from_blob(automaton.flat_image_bytes())
+        """flatten + upload without routing the (possibly tens of GB) blob through Python bytes"""
+        blob, nbytes, h = C.c_void_p(), C.c_size_t(), C.c_void_p()
+        check(lib().acx_flatten(automaton._trie, C.byref(blob), C.byref(nbytes)))
+        try:
+            check(lib().acx_image_upload(blob, nbytes.value, C.byref(h)))
+        finally:
+            lib().acx_blob_free(blob)
+        return cls(h)
 
     @classmethod
     def adopt(cls, dev_ptr, nbytes, host_header, keepalive=None):

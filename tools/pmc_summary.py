@@ -31,7 +31,11 @@ def main(out_dir, tag):
                 acc[k][c].append(float(v))
     out = {}
     for k, cs in acc.items():
-        short = k.split("(")[0].replace("void ", "").replace("(anonymous namespace)::", "")
+        short = k.replace("void ", "").replace("(anonymous namespace)::", "")
+        for stop in ("<", "("):
+            if stop in short:
+                short = short.split(stop)[0]
+        short = short.strip() or k
         d = {"dispatches": max(len(v) for v in cs.values())}
         for c, vals in cs.items():
             d[c] = sum(vals) / len(vals)
