@@ -205,6 +205,34 @@ int acx_trie_make_automaton(acx_trie_t* t, int* changed) {
     if (changed) *changed = 0;
     if (t->kind != ACX_KIND_TRIE) return ACX_OK;        // src/Automaton.c:574-575
     try {
+        // Child lookup index for the BFS.  The fail-link chase asks "does `state` have a child
+        // on `letter`?" over and over for SHALLOW states, which are exactly the wide ones (256
+        // children at the top of a binary-signature trie); walking their sibling lists made
+        // make_automaton 162 s for 1M signatures.  Wide nodes (>= 8 children) get a 256-entry
+        // direct table, the rest keep the (short) sibling walk.
+        const size_t n_arena = t->nodes.size();
+        std::vector<int32_t> wide_of(n_arena, -1);
+        std::vector<int32_t> wide_tbl;
+        {
+            std::vector<uint16_t> nchild(n_arena, 0);
+            for (size_t i = 0; i < n_arena; i++)
+                for (int32_t c = t->nodes[i].first_child; c >= 0; c = t->nodes[c].next_sibling) nchild[i]++;
+            size_t n_wide = 0;
+            for (size_t i = 0; i < n_arena; i++) if (nchild[i] >= 8) wide_of[i] = (int32_t)n_wide++;
+            wide_tbl.assign(n_wide * 256, -1);
+            for (size_t i = 0; i < n_arena; i++)
+                if (wide_of[i] >= 0)
+                    for (int32_t c = t->nodes[i].first_child; c >= 0; c = t->nodes[c].next_sibling)
+                        wide_tbl[(size_t)wide_of[i] * 256 + t->nodes[c].letter] = c;
+        }
+        auto child_fast = [&](int32_t node, uint8_t letter) -> int32_t {
+            const int32_t w = wide_of[node];
+            if (w >= 0) return wide_tbl[(size_t)w * 256 + letter];
+            for (int32_t c = t->nodes[node].first_child; c >= 0; c = t->nodes[c].next_sibling)
+                if (t->nodes[c].letter == letter) return c;
+            return -1;
+        };
+
         std::vector<int32_t>& q = t->bfs;
         q.clear();
         q.reserve((size_t)t->live_nodes);
@@ -220,8 +248,8 @@ int acx_trie_make_automaton(acx_trie_t* t, int* changed) {
                 q.push_back(c);
                 uint8_t letter = t->nodes[c].letter;
                 int32_t state = t->nodes[node].fail;
-                while (state != 0 && t->child(state, letter) < 0) state = t->nodes[state].fail;
-                int32_t f = t->child(state, letter);
+                while (state != 0 && child_fast(state, letter) < 0) state = t->nodes[state].fail;
+                int32_t f = child_fast(state, letter);
                 t->nodes[c].fail = f < 0 ? 0 : f;
             }
         }
