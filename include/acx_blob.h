@@ -32,6 +32,31 @@
 
 #include <stdint.h>
 
+/*
+ * Implicit top-of-trie ("itop").  The top D levels of the trie are dense (every k-gram over
+ * the used bytes tends to exist), so a state at depth d <= D is representable as the pair
+ * (d, code) where code = its last d symbols, b bits each (symbol = class - 1).  Whether
+ * (d, code) is a trie node is ONE BIT: E_d[code].  With these bitmaps resident in LDS the
+ * transition out of a shallow state is "largest dd <= d+1 with E_dd[last dd symbols]" — LDS
+ * probes instead of a gather through the vector-memory pipe, which is what bounds the plain
+ * walk.  H_d[code] says the node has outputs (then its packed entry, same
+ * format as a table entry, is fetched from itop_entry).  Level D is the hand-over level: its
+ * nodes are numbered in code order, id = first_id(D) + rank_D(code), rank tables in LDS.
+ * States deeper than D keep their explicit rows.  Levels 1..D are numbered in code order.
+ *
+ * All levels share ONE index space: node (d, code) is bit  x = (1 << b*d) | code  ("sentinel
+ * bit" above the code; the root is x = 1), so a probe needs no per-level table: three VALU ops
+ * from the rolling history and one LDS read.  E, H and itop_entry are all indexed by x.
+ *
+ * LDS image (uint32 words): [0]=b [1]=D [2]=first id of level D [3]=rank16 word offset
+ * [4]=rank32 word offset [5]=1 if class 0 is "other" [6]=total words [7]=mask(D) = 2^(bD)-1
+ * [8]=E word offset [9]=H word offset [10]=first word of level D inside a bitmap (2^(bD)/32);
+ * E bitmap (2^(bD+1) bits), H bitmap (same), rank16 (uint16 per level-D word: ones before it
+ * inside its 64-word superblock), rank32 (uint32 per superblock: ones before it).  b*D >= 5.
+ */
+#define ACX_ITOP_MAX_LEVELS   15
+#define ACX_ITOP_HDR_WORDS    16
+
 #define ACX_BLOB_MAGIC        0x31424F4C42584341ull   /* "ACXBLOB1" */
 #define ACX_BLOB_VERSION      1u
 #define ACX_BLOB_HEADER_BYTES 256u
@@ -75,8 +100,12 @@ typedef struct acx_blob_header {
     uint64_t off_first_val;  /* int32  [n_states]       out_val[out_off[s]] (first output of s:
                                 the value iter_long reports, and the only one when CNT == 1) */
     uint32_t state_bits;     /* SB of the entry layout: 24 or 27                         */
-    uint32_t reserved0;
-    uint8_t  reserved[ACX_BLOB_HEADER_BYTES - 144];
+    uint32_t itop_depth;     /* D of the implicit top-of-trie (0 = absent), see below    */
+    uint64_t off_itop_lds;   /* uint32 [itop_lds_bytes/4]  LDS image: levels, bitmaps, ranks */
+    uint64_t off_itop_entry; /* uint32 [sum over levels 1..D of 2^(b*d)]  entry of node (d, code) */
+    uint32_t itop_lds_bytes;
+    uint32_t itop_bits;      /* b: bits per symbol                                       */
+    uint8_t  reserved[ACX_BLOB_HEADER_BYTES - 168];
 } acx_blob_header;
 
 #endif

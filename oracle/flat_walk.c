@@ -67,6 +67,83 @@ int64_t flat_iter(const void* blob, const uint8_t* hay, int64_t len,
     return n;
 }
 
+/*
+ * The same walk, but shallow states are held IMPLICITLY as (depth, k-gram code) and their
+ * transitions are resolved from the "itop" bitmaps (include/acx_blob.h) instead of table rows —
+ * the CPU restatement of k_walk_itop.  Checked against flat_iter()/the oracle in tests; it also
+ * cross-checks every implicit step against the explicit table (returns -5 on disagreement).
+ * Returns -6 if the image has no itop.
+ */
+int64_t flat_iter_itop(const void* blob, const uint8_t* hay, int64_t len, int64_t index_base,
+                       int32_t* final_state, int32_t* out_end, int32_t* out_val, int64_t cap) {
+    flat_t f;
+    if (flat_open(blob, &f) < 0) return -1;
+    if (f.h->itop_depth == 0) return -6;
+    const uint8_t* bb = (const uint8_t*)blob;
+    const uint32_t* lds = (const uint32_t*)(bb + f.h->off_itop_lds);
+    const uint32_t* ient = (const uint32_t*)(bb + f.h->off_itop_entry);
+    const uint32_t K = f.h->n_classes, SB = f.h->state_bits;
+    const uint32_t b = lds[0], D = lds[1], LD = lds[2], has_other = lds[5], maskD = lds[7];
+    const uint32_t* E = lds + lds[8];
+    const uint32_t* H = lds + lds[9];
+    const uint32_t w0 = lds[10];
+    const uint16_t* rank16 = (const uint16_t*)(lds + lds[3]);
+    const uint32_t* rank32 = lds + lds[4];
+    const uint32_t bD = b * D;
+#define XIDX(sh) ((hist & ((1u << (sh)) - 1u)) | (1u << (sh)))       /* sentinel index of the last sh/b symbols */
+#define BIT(M, x) (((M)[(x) >> 5] >> ((x) & 31)) & 1u)
+    int64_t n = 0;
+    uint32_t hist = 0, sh = 0, s = 0, shadow = 0;   /* sh = b * depth of the implicit state; shadow: cross-check only */
+    int expl = 0;
+    for (int64_t i = 0; i < len; i++) {
+        const uint32_t cls = f.cls[hay[i]];
+        const uint32_t se = f.table[(size_t)shadow * K + cls];
+        shadow = se & ACX_ENTRY_STATE_MASK(SB);
+        uint32_t ev = 0;                                  /* entry to report, 0 = none */
+        if (has_other && cls == 0) { sh = 0; expl = 0; hist = 0; if (shadow != 0) return -5; continue; }
+        hist = ((hist << b) | (cls - has_other)) & maskD;
+        uint32_t cand;                                    /* first candidate shift for the implicit resolution */
+        int resolve = 0;
+        if (expl) {
+            const uint32_t e = f.table[(size_t)s * K + cls];
+            const uint32_t t = e & ACX_ENTRY_STATE_MASK(SB);
+            if (e >> ACX_ENTRY_CNT_SHIFT(SB)) ev = e;
+            if (t >= LD) s = t;
+            else { expl = 0; cand = bD - b; resolve = 1; }
+        } else { cand = sh + b; resolve = 2; }
+        if (resolve) {
+            /* largest candidate shift whose k-gram is a node; shift 0 is the root (bit 1, always set) */
+            uint32_t c = cand, x;
+            for (;;) { x = XIDX(c); if (BIT(E, x)) break; c -= b; }
+            sh = c;
+            if (resolve == 2 && c > 0 && BIT(H, x)) ev = ient[x];
+            if (c == bD) {                                /* hand over to the explicit rows */
+                const uint32_t w = x >> 5;
+                s = LD + rank32[(w - w0) >> 6] + rank16[w - w0] + (uint32_t)__builtin_popcount(E[w] & ((1u << (x & 31)) - 1u));
+                expl = 1;
+                if ((ient[x] & ACX_ENTRY_STATE_MASK(SB)) != s) return -5;
+            }
+        }
+        /* cross-check the position and the output decision against the explicit walk */
+        {
+            uint32_t cur = expl ? s : (sh == 0 ? 0 : (ient[XIDX(sh)] & ACX_ENTRY_STATE_MASK(SB)));
+            if (cur != shadow) return -5;
+            if ((ev != 0) != ((se >> ACX_ENTRY_CNT_SHIFT(SB)) != 0)) return -5;
+        }
+        if (ev) {
+            const uint32_t st = ev & ACX_ENTRY_STATE_MASK(SB);
+            for (uint32_t r = f.out_off[st]; r < f.out_off[st + 1]; r++) {
+                if (n < cap) { out_end[n] = (int32_t)(i + index_base); out_val[n] = f.out_val[r]; }
+                n++;
+            }
+        }
+    }
+    if (final_state) *final_state = (int32_t)(expl ? s : (sh == 0 ? 0 : (ient[XIDX(sh)] & ACX_ENTRY_STATE_MASK(SB))));
+#undef XIDX
+#undef BIT
+    return n;
+}
+
 int64_t flat_iter_long(const void* blob, const uint8_t* hay, int64_t len, int64_t index_base,
                        int32_t* out_end, int32_t* out_val, int64_t cap) {
     flat_t f;

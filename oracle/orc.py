@@ -51,6 +51,8 @@ def lib():
         l.orc_iter_batch_count.argtypes = [P, P, P, I64, C.c_int]
         l.flat_iter.restype = I64
         l.flat_iter.argtypes = [P, P, I64, I32p, I64, P, P, I64]
+        l.flat_iter_itop.restype = I64
+        l.flat_iter_itop.argtypes = [P, P, I64, I64, I32p, P, P, I64]
         l.flat_iter_long.restype = I64
         l.flat_iter_long.argtypes = [P, P, I64, I64, P, P, I64]
         _lib = l
@@ -159,6 +161,22 @@ def flat_iter(blob, hay, state=0, index_base=0):
         n = lib().flat_iter(blob, hay, len(hay), C.byref(st), index_base, e.ctypes.data, v.ctypes.data, cap)
         if n < 0:
             raise RuntimeError("flat_iter failed: %d" % n)
+        if n <= cap:
+            return list(zip(e[:n].tolist(), v[:n].tolist())), st.value
+        cap = int(n)
+
+
+def flat_iter_itop(blob, hay, index_base=0):
+    """walk the flat image with the implicit top-of-trie (flat_walk.c:flat_iter_itop);
+    -> (list of (end, value), final_state).  Raises on any disagreement with the explicit table."""
+    st = C.c_int32(0)
+    cap = max(16, 2 * len(hay))
+    while True:
+        e = np.empty(cap, dtype=np.int32)
+        v = np.empty(cap, dtype=np.int32)
+        n = lib().flat_iter_itop(blob, hay, len(hay), index_base, C.byref(st), e.ctypes.data, v.ctypes.data, cap)
+        if n < 0:
+            raise RuntimeError("flat_iter_itop failed: %d" % n)
         if n <= cap:
             return list(zip(e[:n].tolist(), v[:n].tolist())), st.value
         cap = int(n)

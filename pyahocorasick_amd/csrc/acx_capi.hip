@@ -76,6 +76,8 @@ struct acx_image {
     const uint32_t* out_off = nullptr;
     const int32_t* out_val = nullptr;
     const int32_t* first_val = nullptr;
+    const uint32_t* itop_lds = nullptr;     // nullptr when the image has no implicit top
+    const uint32_t* itop_entry = nullptr;
 };
 
 static void image_resolve(acx_image* img) {
@@ -84,6 +86,10 @@ static void image_resolve(acx_image* img) {
     img->out_off = (const uint32_t*)(img->dev + img->h.off_out_off);
     img->out_val = (const int32_t*)(img->dev + img->h.off_out_val);
     img->first_val = (const int32_t*)(img->dev + img->h.off_first_val);
+    if (img->h.itop_depth > 0 && img->h.state_bits == ACX_STATE_BITS_NARROW) {
+        img->itop_lds = (const uint32_t*)(img->dev + img->h.off_itop_lds);
+        img->itop_entry = (const uint32_t*)(img->dev + img->h.off_itop_entry);
+    }
 }
 
 extern "C" int acx_image_upload(const void* blob, size_t nbytes, acx_image_t** out) {
@@ -276,6 +282,9 @@ extern "C" int acx_scan_batch(acx_image_t* img, const acx_scan_params* p, acx_re
     wa.final_state = r->has_final ? r->final_state.p : nullptr;
 
     int64_t* item_match_off = chunked ? r->ck_match_off.p : r->match_off.p;
+    // implicit top-of-trie kernel: ACX_SCAN_ALL, narrow image that carries the structures, no carried-in
+    // state (an arbitrary shallow state id has no k-gram history).  variant bit 16 turns it off (A/B).
+    const bool use_itop = p->mode == ACX_SCAN_ALL && img->itop_lds && !p->dev_init_state && !((p->variant >> 16) & 1);
 
     if (r->timed) HIP_TRY(hipEventRecord(r->ev[0], s));
     if (chunked) {
@@ -289,9 +298,13 @@ extern "C" int acx_scan_batch(acx_image_t* img, const acx_scan_params* p, acx_re
         HIP_TRY(acx_launch_chunk_count(ca, s));
         HIP_TRY(acx_launch_scan(r->nck.p, p->n_hay, r->ck_first.p, r->partials.p, s));
         HIP_TRY(acx_launch_chunk_fill(ca, n_items, s));
-        HIP_TRY(acx_launch_walk_chunks(wa, r->ck.p, r->ck_first.p + p->n_hay, n_items, img->h.has_escape != 0, s));
+        if (use_itop) HIP_TRY(acx_launch_walk_itop(wa, r->ck.p, r->ck_first.p + p->n_hay, n_items, img->h.has_escape != 0,
+                                                   img->itop_lds, img->h.itop_lds_bytes / 4, img->itop_entry, s));
+        else          HIP_TRY(acx_launch_walk_chunks(wa, r->ck.p, r->ck_first.p + p->n_hay, n_items, img->h.has_escape != 0, s));
     } else if (p->mode == ACX_SCAN_ALL) {
-        HIP_TRY(acx_launch_walk_all(wa, img->h.has_escape != 0, p->variant, s));
+        if (use_itop) HIP_TRY(acx_launch_walk_itop(wa, nullptr, nullptr, p->n_hay, img->h.has_escape != 0,
+                                                   img->itop_lds, img->h.itop_lds_bytes / 4, img->itop_entry, s));
+        else          HIP_TRY(acx_launch_walk_all(wa, img->h.has_escape != 0, p->variant, s));
     } else {
         HIP_TRY(acx_launch_walk_long(wa, p->variant, s));
     }

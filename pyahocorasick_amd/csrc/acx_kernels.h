@@ -82,6 +82,11 @@ hipError_t acx_launch_chunk_count(const acx_chunk_args& c, hipStream_t s);      
 hipError_t acx_launch_chunk_fill(const acx_chunk_args& c, int64_t n_chunks_bound, hipStream_t s);   // needs ck_first
 hipError_t acx_launch_walk_chunks(const acx_walk_args& a, const acx_chunk_desc* ck, const int64_t* n_chunks_dev,
                                   int64_t n_chunks_bound, bool has_escape, hipStream_t s);
+// walk with the implicit top-of-trie in LDS (narrow images with itop_depth > 0, no init_state);
+// items are haystacks (ck == nullptr) or chunks
+hipError_t acx_launch_walk_itop(const acx_walk_args& a, const acx_chunk_desc* ck, const int64_t* n_chunks_dev,
+                                int64_t n_items_bound, bool has_escape, const uint32_t* itop_lds, uint32_t itop_words,
+                                const uint32_t* itop_entry, hipStream_t s);
 // per-haystack match offsets from per-chunk ones: match_off[h] = ck_match_off[ck_first[h]]
 hipError_t acx_launch_hay_offsets(const int64_t* ck_first, const int64_t* ck_match_off, int64_t n_hay,
                                   int64_t* match_off, hipStream_t s);

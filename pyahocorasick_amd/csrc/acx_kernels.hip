@@ -310,6 +310,214 @@ __global__ void __launch_bounds__(ACX_BLOCK, 8) k_walk_chunks(const acx_walk_arg
     }
 }
 
+// ---------------------------------------------------------------------------------
+// walk with the IMPLICIT TOP-OF-TRIE in LDS (include/acx_blob.h "itop"), ACX_SCAN_ALL.
+//
+// The plain walk is bound by one L2 transaction per input byte.  Here a lane
+// whose state is shallower than D holds it as (depth d, code = last d symbols): the next
+// state is "the largest dd <= d+1 whose last-dd-symbols code is a trie node", answered by the
+// per-level existence bitmaps E_dd resident in LDS (~100 KB for DNA: D = 9) — LDS probes
+// instead of a gather.  Only states at depth >= D use their explicit table row.  Level D is
+// the hand-over: its nodes are numbered in code order, so id = first_id(D) + rank_D(code)
+// (popcount rank tables, also in LDS).  A node with outputs (H_dd bit) fetches its packed
+// entry from itop_entry[] and then reports exactly like the plain walk.
+// One 1024-thread block per CU (the bitmaps take most of the 160 KiB); items are haystacks
+// (ck == nullptr) or chunks.  oracle/flat_walk.c:flat_iter_itop is the CPU restatement.
+// ---------------------------------------------------------------------------------
+#define ACX_ITOP_BLOCK 1024
+#define ACX_ITOP_EXPL 255u
+
+struct ItopCtx {
+    const uint32_t* E;          // LDS: existence bitmap, all levels, sentinel-indexed
+    const uint32_t* H;          // LDS: has-output bitmap
+    const uint16_t* rank16;     // LDS
+    const uint32_t* rank32;     // LDS
+    const uint32_t* ient;       // global: packed entry of implicit node x
+    const uint8_t*  table_bytes;
+    const uint32_t* out_off;
+    uint32_t row_bytes, b, bD, LD, has_other, maskD, w0;
+};
+
+struct ItopLane {
+    uint32_t st;     // explicit: raw entry (low 24 bits = state)
+    uint32_t sh;     // implicit: b * depth (0 .. b*(D-1)); explicit: ACX_ITOP_EXPL
+    uint32_t hist;   // last D symbols, b bits each
+    uint32_t cnt;
+    uint2*   ev;
+};
+
+// sentinel index of the k-gram made of the last sh/b symbols (sh = 0 -> 1, the root)
+__device__ __forceinline__ uint32_t itop_x(uint32_t hist, uint32_t sh) {
+    return __builtin_amdgcn_ubfe(hist, 0u, sh) | (1u << sh);
+}
+
+// largest shift <= cand (in steps of b) whose k-gram is a trie node.  The three most likely
+// candidates are probed with independent LDS reads; shift 0 (the root) always hits.
+__device__ __forceinline__ void itop_resolve(uint32_t hist, uint32_t cand, const ItopCtx& C,
+                                             uint32_t& c, uint32_t& x, uint32_t& word) {
+    const uint32_t c0 = cand;
+    const uint32_t c1 = c0 >= C.b ? c0 - C.b : 0u;
+    const uint32_t c2 = c1 >= C.b ? c1 - C.b : 0u;
+    const uint32_t x0 = itop_x(hist, c0), x1 = itop_x(hist, c1), x2 = itop_x(hist, c2);
+    const uint32_t w0 = C.E[x0 >> 5], w1 = C.E[x1 >> 5], w2 = C.E[x2 >> 5];
+    const bool h0 = (w0 >> (x0 & 31)) & 1u, h1 = (w1 >> (x1 & 31)) & 1u, h2 = (w2 >> (x2 & 31)) & 1u;
+    c = h0 ? c0 : (h1 ? c1 : c2);
+    x = h0 ? x0 : (h1 ? x1 : x2);
+    word = h0 ? w0 : (h1 ? w1 : w2);
+    if (!(h0 || h1 || h2)) {                                         // rare: fell more than two levels
+        do {
+            c = c >= C.b ? c - C.b : 0u;
+            x = itop_x(hist, c);
+            word = C.E[x >> 5];
+        } while (!((word >> (x & 31)) & 1u));
+    }
+}
+
+// One input byte.  Phases are ordered so that the table gather of the lanes that hold an
+// explicit state is in flight while the other lanes of the wave do their LDS work:
+//   A  explicit lanes issue the gather            (result not touched yet)
+//   B  implicit lanes resolve from the bitmaps    (LDS + VALU, no dependence on A)
+//   C  explicit lanes consume the entry; those that fell into the implicit zone resolve too
+template <bool ESCAPE, bool GUARDED>
+__device__ __forceinline__ void itop_step(uint32_t c4, uint32_t idx, bool active, bool emit, const ItopCtx& C, ItopLane& L) {
+    constexpr int SB = ACX_STATE_BITS_NARROW;
+    const uint32_t cls = c4 >> 2;
+    const bool other = C.has_other && cls == 0;                      // a byte no key contains: root, no output
+    const bool go = GUARDED ? (active && !other) : !other;
+    const bool expl = L.sh == ACX_ITOP_EXPL;
+    const uint32_t hist = ((L.hist << C.b) | (cls - C.has_other)) & C.maskD;
+    uint32_t e = 0;                                                  // entry to report (0 = nothing)
+    uint32_t e_tab = 0;
+    if (go && expl) e_tab = load_entry<SB>(C.table_bytes, L.st, C.row_bytes, c4);      // A
+    uint32_t new_sh = L.sh, new_st = L.st;
+    if (go && !expl) {                                                                  // B
+        uint32_t c, x, word;
+        itop_resolve(hist, L.sh + C.b, C, c, x, word);
+        if ((!GUARDED || emit) && c > 0) {
+            if ((C.H[x >> 5] >> (x & 31)) & 1u) e = C.ient[x];       // the node has outputs: fetch its entry
+        }
+        if (c == C.bD) {                                             // hand over to the explicit rows
+            const uint32_t w = (x >> 5) - C.w0;
+            new_st = C.LD + C.rank32[w >> 6] + C.rank16[w] + (uint32_t)__popc(word & ((1u << (x & 31)) - 1u));
+            new_sh = ACX_ITOP_EXPL;
+        } else {
+            new_sh = c;
+        }
+    }
+    if (go && expl) {                                                                   // C
+        e = e_tab;
+        if ((e_tab & ACX_ENTRY_STATE_MASK(SB)) >= C.LD) {
+            new_st = e_tab;
+        } else {                                                     // fell back into the implicit zone
+            uint32_t c, x, word;
+            itop_resolve(hist, C.bD - C.b, C, c, x, word);
+            new_sh = c;
+        }
+    }
+    if (GUARDED ? active : true) {
+        L.hist = other ? 0u : hist;
+        L.sh = other ? 0u : new_sh;
+        L.st = new_st;
+    }
+    if ((!GUARDED || emit) && (e >> ACX_ENTRY_CNT_SHIFT(SB))) {
+        uint32_t c = e >> ACX_ENTRY_CNT_SHIFT(SB);
+        if (ESCAPE) {
+            if (c == ACX_ENTRY_CNT_ESCAPE(SB)) {
+                const uint32_t s = e & ACX_ENTRY_STATE_MASK(SB);
+                c = C.out_off[s + 1] - C.out_off[s];
+            }
+        }
+        store_event<true>(L.ev++, idx, e);
+        L.cnt += c;
+    }
+}
+
+template <bool ESCAPE>
+__global__ void __launch_bounds__(ACX_ITOP_BLOCK) k_walk_itop(const acx_walk_args a, const acx_chunk_desc* ck,
+                                                             const int64_t* n_chunks_dev, const uint32_t* itop_lds,
+                                                             uint32_t itop_words, const uint32_t* itop_entry) {
+    extern __shared__ __attribute__((aligned(16))) uint32_t s_mem[];
+    uint32_t* s_cls4 = s_mem + ((itop_words + 3) & ~3u);
+    for (uint32_t i = threadIdx.x; i < itop_words; i += ACX_ITOP_BLOCK) s_mem[i] = itop_lds[i];
+    if (threadIdx.x < 256) s_cls4[threadIdx.x] = (uint32_t)a.cls[threadIdx.x] * 4u;
+    __syncthreads();
+
+    ItopCtx C;
+    C.ient = itop_entry; C.table_bytes = (const uint8_t*)a.table; C.out_off = a.out_off; C.row_bytes = a.row_bytes;
+    C.b = s_mem[0]; C.bD = s_mem[0] * s_mem[1]; C.LD = s_mem[2]; C.has_other = s_mem[5]; C.maskD = s_mem[7];
+    C.rank16 = (const uint16_t*)(s_mem + s_mem[3]);
+    C.rank32 = s_mem + s_mem[4];
+    C.E = s_mem + s_mem[8]; C.H = s_mem + s_mem[9]; C.w0 = s_mem[10];
+
+    const int lane = threadIdx.x & (ACX_WAVE - 1);
+    const int64_t n_items = ck ? *n_chunks_dev : a.n_hay;
+    const int64_t n_tasks = (n_items + ACX_WAVE - 1) / ACX_WAVE;
+    const int64_t wave0 = (int64_t)blockIdx.x * (ACX_ITOP_BLOCK / ACX_WAVE) + (threadIdx.x / ACX_WAVE);
+    const int64_t n_waves = (int64_t)gridDim.x * (ACX_ITOP_BLOCK / ACX_WAVE);
+    const uint8_t* limit = a.hay + a.hay_cap;
+
+    for (int64_t task = wave0; task < n_tasks; task += n_waves) {
+        const int64_t c = task * ACX_WAVE + lane;
+        const bool valid = c < n_items;
+        acx_chunk_desc d;
+        d.start = 0; d.emit = 0; d.len = 0; d.idx0 = 0; d.hay = 0; d.flags = 0; d.pad = 0;
+        if (valid) {
+            if (ck) d = ck[c];
+            else {
+                const int64_t b0 = a.off ? a.off[c] : c * a.stride;
+                const int64_t e0 = a.off ? a.off[c + 1] : b0 + a.stride;
+                d.start = b0; d.len = (int32_t)(e0 - b0); d.hay = (int32_t)c; d.flags = 3;
+                d.idx0 = a.index_base ? a.index_base[c] : 0;
+            }
+        }
+        const uint8_t* p = a.hay + d.start;
+        const int len = d.len, emit = d.emit;
+        ItopLane L;
+        L.st = 0; L.sh = 0; L.hist = 0; L.cnt = 0;
+        L.ev = a.events + d.start + emit;
+        uint2* const ev0 = L.ev;
+        const uint32_t base = (uint32_t)d.idx0;
+
+        for (int j0 = 0;; j0 += 16) {
+            const int rem = len - j0;
+            if (!__any(rem > 0)) break;
+            if (rem > 0) {
+                const uint4 w = load16_guarded<false>(p + j0, limit);
+                const bool fast = __all(rem >= 16 && j0 >= emit);   // full block, every step reports
+                // one dword (4 steps) per iteration, NOT unrolled: the step body is large and the
+                // instruction cache is shared; the class lookups of a dword go first
+#pragma unroll 1
+                for (int k = 0; k < 4; k++) {
+                    const uint32_t wk = k == 0 ? w.x : (k == 1 ? w.y : (k == 2 ? w.z : w.w));
+                    uint32_t c4[4];
+#pragma unroll
+                    for (int i = 0; i < 4; i++) c4[i] = s_cls4[(wk >> (i * 8)) & 0xffu];
+                    if (fast) {
+#pragma unroll
+                        for (int i = 0; i < 4; i++) itop_step<ESCAPE, false>(c4[i], base + j0 + k * 4 + i, true, true, C, L);
+                    } else {
+#pragma unroll
+                        for (int i = 0; i < 4; i++) {
+                            const int j = j0 + k * 4 + i;
+                            itop_step<ESCAPE, true>(c4[i], base + j, j < len, j >= emit, C, L);
+                        }
+                    }
+                }
+            }
+        }
+        if (valid) {
+            a.counts[c] = (int32_t)L.cnt;
+            a.nev[c] = (int32_t)(L.ev - ev0);
+            if (a.final_state && (d.flags & 2)) {
+                uint32_t fs = 0;
+                if (L.sh == ACX_ITOP_EXPL) fs = L.st & ACX_ENTRY_STATE_MASK(ACX_STATE_BITS_NARROW);
+                else if (L.sh > 0) fs = itop_entry[itop_x(L.hist, L.sh)] & ACX_ENTRY_STATE_MASK(ACX_STATE_BITS_NARROW);
+                a.final_state[d.hay] = (int32_t)fs;
+            }
+        }
+    }
+}
+
 // chunks per haystack: max(1, ceil(len / CH)) — an empty haystack still gets one (empty)
 // chunk so that it owns a final_state and a match_off slot
 __global__ void __launch_bounds__(ACX_BLOCK) k_chunk_count(const acx_chunk_args c) {
@@ -375,6 +583,7 @@ __global__ void __launch_bounds__(ACX_BLOCK) k_walk_long(const acx_walk_args a) 
 
     const int64_t n_threads = (int64_t)gridDim.x * ACX_BLOCK;
     const uint8_t* table_bytes = (const uint8_t*)a.table;
+    const uint8_t* limit = a.hay + a.hay_cap;
 
     for (int64_t h = (int64_t)blockIdx.x * ACX_BLOCK + threadIdx.x; h < a.n_hay; h += n_threads) {
         int64_t b, e;
@@ -391,10 +600,19 @@ __global__ void __launch_bounds__(ACX_BLOCK) k_walk_long(const acx_walk_args a) 
         bool have_last = false;
         int last_index = -1;
         uint32_t last_state = 0;
+        // the current 16 haystack bytes live in registers: a byte load per step would cost the
+        // vector-memory pipe as much as the table gather itself (one lane per clock per CU).
+        // Restarts move `index` back by less than longest_word, so the block is reloaded rarely.
+        uint4 blkw = make_uint4(0, 0, 0, 0);
+        int blk = -1;
         for (;;) {
             bool emit = false;
             if (index < len) {
-                const uint32_t c4 = s_cls4[p[index]];
+                const int nb = index >> 4;
+                if (nb != blk) { blkw = load16_guarded<false>(p + (int64_t)nb * 16, limit); blk = nb; }
+                const int dw = (index >> 2) & 3;
+                const uint32_t wsel = dw == 0 ? blkw.x : (dw == 1 ? blkw.y : (dw == 2 ? blkw.z : blkw.w));
+                const uint32_t c4 = s_cls4[(wsel >> ((index & 3) * 8)) & 0xffu];
                 const uint32_t en = load_entry<SB>(table_bytes, state, a.row_bytes, c4);
                 const uint32_t next = en & ACX_ENTRY_STATE_MASK(SB);
                 if (!(en & ACX_ENTRY_EDGE(SB)) && have_last) {
@@ -742,5 +960,32 @@ hipError_t acx_launch_hay_offsets(const int64_t* ck_first, const int64_t* ck_mat
                                   int64_t* match_off, hipStream_t s) {
     hipLaunchKernelGGL(k_hay_offsets, dim3((unsigned)((n_hay + 1 + ACX_BLOCK - 1) / ACX_BLOCK)), dim3(ACX_BLOCK), 0, s,
                        ck_first, ck_match_off, n_hay, match_off);
+    return hipGetLastError();
+}
+
+hipError_t acx_launch_walk_itop(const acx_walk_args& a, const acx_chunk_desc* ck, const int64_t* n_chunks_dev,
+                                int64_t n_items_bound, bool has_escape, const uint32_t* itop_lds, uint32_t itop_words,
+                                const uint32_t* itop_entry, hipStream_t s) {
+    if (n_items_bound <= 0) return hipSuccess;
+    const size_t lds_bytes = (size_t)((itop_words + 3) & ~3u) * 4 + 1024;
+    if (lds_bytes > 160 * 1024) return hipErrorInvalidValue;
+    const int bpc = lds_bytes * 2 <= 160 * 1024 ? 2 : 1;          // 1024-thread blocks: at most 2 per CU
+    const int64_t waves_per_block = ACX_ITOP_BLOCK / ACX_WAVE;
+    const int64_t n_tasks = (n_items_bound + ACX_WAVE - 1) / ACX_WAVE;
+    int64_t blocks = (n_tasks + waves_per_block - 1) / waves_per_block;
+    if (blocks > 256 * bpc) blocks = 256 * bpc;
+    if (blocks < 1) blocks = 1;
+    hipError_t e;
+    if (has_escape) {
+        e = hipFuncSetAttribute((const void*)k_walk_itop<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL(k_walk_itop<true>, dim3((unsigned)blocks), dim3(ACX_ITOP_BLOCK), lds_bytes, s, a, ck, n_chunks_dev,
+                           itop_lds, itop_words, itop_entry);
+    } else {
+        e = hipFuncSetAttribute((const void*)k_walk_itop<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL(k_walk_itop<false>, dim3((unsigned)blocks), dim3(ACX_ITOP_BLOCK), lds_bytes, s, a, ck, n_chunks_dev,
+                           itop_lds, itop_words, itop_entry);
+    }
     return hipGetLastError();
 }

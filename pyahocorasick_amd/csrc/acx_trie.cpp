@@ -15,6 +15,7 @@
 //   * BFS order is recorded by make_automaton and reused as the state numbering.
 #include "acx_internal.h"
 
+#include <algorithm>
 #include <cstdlib>
 #include <cstring>
 #include <new>
@@ -308,16 +309,68 @@ int acx_flatten(const acx_trie_t* t, void** blob_out, size_t* nbytes_out) {
                             ? ACX_STATE_BITS_NARROW : ACX_STATE_BITS_WIDE;
     const uint32_t ESC = ACX_ENTRY_CNT_ESCAPE(SB);
 
-    std::vector<int32_t> id;          // arena index -> BFS id
-    std::vector<uint32_t> out_cnt;    // per BFS id
+    // 1b. state numbering and the implicit top-of-trie (include/acx_blob.h "itop").
+    //     Numbering = BFS order, except that levels 1..D are re-sorted by k-gram code so that
+    //     a level-D node's id is first_id(D) + rank of its code.  Any order that keeps shallower
+    //     states at smaller ids works for everything below (fail(s) is always shallower).
+    const bool has_other = n_used != 256;
+    uint32_t itop_b = 1, itop_D = 0;
+    { const uint32_t sigma = has_other ? K - 1 : 256; while ((1u << itop_b) < sigma) itop_b++; }
+    std::vector<int32_t> order;       // position (= state id) -> arena index
+    std::vector<uint32_t> acode;      // arena index -> code (valid for depth <= D)
+    std::vector<int32_t> adepth;      // arena index -> depth
+    std::vector<uint32_t> lvl_first;  // first id of depth d, d = 0..D+1
+    // one bitmap addresses every level: node (d, code) lives at bit (1 << b*d) | code
+    auto itop_bm_words = [&](uint32_t D) -> size_t { return (size_t)((2ull << (itop_b * D)) / 32); };   // needs b*D >= 5
+    auto itop_lvlD_words = [&](uint32_t D) -> size_t { return (size_t)((1ull << (itop_b * D)) / 32); };
+    auto itop_cost = [&](uint32_t D) -> size_t {      // LDS image size in words: header, E, H, rank16, rank32
+        return ACX_ITOP_HDR_WORDS + 2 * itop_bm_words(D) + (itop_lvlD_words(D) + 1) / 2 + itop_lvlD_words(D) / 64 + 1;
+    };
+    try {
+        order = t->bfs;
+        adepth.assign(t->nodes.size(), 0);
+        int32_t max_depth = 0;
+        for (size_t i = 0; i < n; i++)
+            for (int32_t ch = t->nodes[order[i]].first_child; ch >= 0; ch = t->nodes[ch].next_sibling) {
+                adepth[ch] = adepth[order[i]] + 1;
+                if (adepth[ch] > max_depth) max_depth = adepth[ch];
+            }
+        const size_t budget_words = (size_t)150 * 1024 / 4;          // of the CU's 160 KiB of LDS
+        const char* no_itop = getenv("ACX_NO_ITOP");
+        if (SB == ACX_STATE_BITS_NARROW && !(no_itop && no_itop[0] == '1')) {
+            while (itop_D < ACX_ITOP_MAX_LEVELS && (int32_t)itop_D < max_depth && itop_b * (itop_D + 1) <= 24 &&
+                   (itop_b * (itop_D + 1) < 5 || itop_cost(itop_D + 1) <= budget_words))
+                itop_D++;
+            if (itop_b * itop_D < 5) itop_D = 0;      // a trie this small does not need it (and rank needs whole words)
+        }
+        if (itop_D > 0) {
+            acode.assign(t->nodes.size(), 0);
+            lvl_first.assign(itop_D + 2, (uint32_t)n);
+            for (size_t i = n; i-- > 0;) { const int32_t d = adepth[order[i]]; if (d <= (int32_t)itop_D + 1) lvl_first[d] = (uint32_t)i; }
+            for (uint32_t d = itop_D + 1; d-- > 0;) if (lvl_first[d] > lvl_first[d + 1]) lvl_first[d] = lvl_first[d + 1];
+            for (size_t i = 0; i < lvl_first[itop_D]; i++)               // parents at depth < D
+                for (int32_t ch = t->nodes[order[i]].first_child; ch >= 0; ch = t->nodes[ch].next_sibling)
+                    acode[ch] = (acode[order[i]] << itop_b) | (uint32_t)(cls[t->nodes[ch].letter] - (has_other ? 1 : 0));
+            for (uint32_t d = 1; d <= itop_D; d++) {
+                // parents of level d were re-sorted in the previous round: codes are final before sorting
+                std::sort(order.begin() + lvl_first[d], order.begin() + lvl_first[d + 1],
+                          [&](int32_t a, int32_t b2) { return acode[a] < acode[b2]; });
+            }
+        }
+    } catch (const std::bad_alloc&) {
+        return acx_fail(ACX_E_NOMEM, "acx_flatten: out of memory");
+    }
+
+    std::vector<int32_t> id;          // arena index -> state id
+    std::vector<uint32_t> out_cnt;    // per state id
     uint64_t n_out = 0;
     uint32_t max_cnt = 0;
     try {
         id.assign(t->nodes.size(), -1);
-        for (size_t i = 0; i < n; i++) id[t->bfs[i]] = (int32_t)i;
+        for (size_t i = 0; i < n; i++) id[order[i]] = (int32_t)i;
         out_cnt.assign(n, 0);
         for (size_t i = 1; i < n; i++) {  // BFS order: fail(s) is shallower, hence already done
-            const Node& nd = t->nodes[t->bfs[i]];
+            const Node& nd = t->nodes[order[i]];
             uint32_t c = (nd.eow ? 1u : 0u) + out_cnt[id[nd.fail]];
             out_cnt[i] = c;
             n_out += c;
@@ -342,6 +395,13 @@ int acx_flatten(const acx_trie_t* t, void** blob_out, size_t* nbytes_out) {
     h.off_out_off = off;    off = align_up(off + (n + 1) * 4);
     h.off_out_val = off;    off = align_up(off + (size_t)n_out * 4 + 4);
     h.off_first_val = off;  off = align_up(off + n * 4);
+    size_t itop_lds_words = 0, itop_entries = 0;
+    if (itop_D > 0) {
+        itop_lds_words = itop_cost(itop_D);
+        itop_entries = (size_t)2 << (itop_b * itop_D);      // indexed by the same sentinel index as the bitmaps
+        h.off_itop_lds = off;    off = align_up(off + itop_lds_words * 4);
+        h.off_itop_entry = off;  off = align_up(off + itop_entries * 4);
+    }
     const size_t total = off;
 
     uint8_t* blob = (uint8_t*)calloc(1, total);
@@ -363,7 +423,7 @@ int acx_flatten(const acx_trie_t* t, void** blob_out, size_t* nbytes_out) {
         uint32_t o = 0;
         fail[0] = -1;
         for (size_t i = 0; i < n; i++) {
-            const Node& nd = t->nodes[t->bfs[i]];
+            const Node& nd = t->nodes[order[i]];
             out_off[i] = o;
             if (i == 0) continue;
             const int32_t f = id[nd.fail];
@@ -392,10 +452,44 @@ int acx_flatten(const acx_trie_t* t, void** blob_out, size_t* nbytes_out) {
             const uint32_t* frow = table + (size_t)fail[i] * K;
             for (uint32_t c = 0; c < K; c++) row[c] = frow[c] & ~ACX_ENTRY_EDGE(SB);
         }
-        for (int32_t ch = t->nodes[t->bfs[i]].first_child; ch >= 0; ch = t->nodes[ch].next_sibling) {
+        for (int32_t ch = t->nodes[order[i]].first_child; ch >= 0; ch = t->nodes[ch].next_sibling) {
             const uint32_t tid = (uint32_t)id[ch];
             row[cls[t->nodes[ch].letter]] = tid | tflags[tid] | ACX_ENTRY_EDGE(SB);
         }
+    }
+
+    // 5. implicit top-of-trie: existence / has-output bitmaps per level, rank tables of level D,
+    //    and the packed entry of every implicit node (include/acx_blob.h)
+    if (itop_D > 0) {
+        uint32_t* lds = (uint32_t*)(blob + h.off_itop_lds);
+        uint32_t* ient = (uint32_t*)(blob + h.off_itop_entry);
+        const size_t bmw = itop_bm_words(itop_D);
+        const size_t eb = ACX_ITOP_HDR_WORDS, hb = eb + bmw;
+        lds[eb] |= 1u << 1;                                   // the root: (d = 0, code = 0) -> bit 1
+        for (uint32_t d = 1; d <= itop_D; d++) {
+            for (uint32_t i = lvl_first[d]; i < lvl_first[d + 1]; i++) {
+                const uint32_t x = (1u << (itop_b * d)) | acode[order[i]];     // sentinel index
+                lds[eb + (x >> 5)] |= 1u << (x & 31);
+                if (out_cnt[i]) lds[hb + (x >> 5)] |= 1u << (x & 31);
+                ient[x] = i | tflags[i];
+            }
+        }
+        // rank of level D: ones before each word of [2^(bD), 2^(bD+1)), 64-word superblocks
+        const size_t wD = itop_lvlD_words(itop_D), w0 = wD;    // level D starts at word 2^(bD)/32 = wD
+        const size_t r16 = hb + bmw, r32 = r16 + (wD + 1) / 2;
+        uint16_t* rank16 = (uint16_t*)(lds + r16);
+        uint32_t* rank32 = lds + r32;
+        uint32_t run = 0, in_sb = 0;
+        for (size_t k = 0; k < wD; k++) {
+            if ((k & 63) == 0) { rank32[k >> 6] = run; in_sb = 0; }
+            rank16[k] = (uint16_t)in_sb;
+            const uint32_t pc = (uint32_t)__builtin_popcount(lds[eb + w0 + k]);
+            run += pc; in_sb += pc;
+        }
+        lds[0] = itop_b; lds[1] = itop_D; lds[2] = lvl_first[itop_D]; lds[3] = (uint32_t)r16; lds[4] = (uint32_t)r32;
+        lds[5] = has_other ? 1u : 0u; lds[6] = (uint32_t)itop_lds_words; lds[7] = (uint32_t)((1ull << (itop_b * itop_D)) - 1);
+        lds[8] = (uint32_t)eb; lds[9] = (uint32_t)hb; lds[10] = (uint32_t)w0;
+        h.itop_depth = itop_D; h.itop_bits = itop_b; h.itop_lds_bytes = (uint32_t)(itop_lds_words * 4);
     }
 
     h.magic = ACX_BLOB_MAGIC;
@@ -436,6 +530,8 @@ int acx_blob_check_header(const acx_blob_header* h, size_t nbytes) {
         {h->off_cls, 256}, {h->off_table, n * K * 4}, {h->off_fail, n * 4}, {h->off_node_val, n * 4},
         {h->off_node_flags, n}, {h->off_out_off, (n + 1) * 4}, {h->off_out_val, h->n_out * 4},
         {h->off_first_val, n * 4},
+        {h->itop_depth ? h->off_itop_lds : (uint64_t)ACX_BLOB_ALIGN, h->itop_depth ? h->itop_lds_bytes : 0},
+        {h->itop_depth ? h->off_itop_entry : (uint64_t)ACX_BLOB_ALIGN, 0},
     };
     for (auto& s : sec)
         if (s.off % ACX_BLOB_ALIGN || s.off < ACX_BLOB_HEADER_BYTES || s.off + s.len > nbytes)

@@ -364,6 +364,45 @@ def test_wide_layout_on_gpu(monkeypatch):
     assert np.array_equal(res.offsets, mo) and np.array_equal(res.end_index, oe) and np.array_equal(res.value, ov)
 
 
+def test_implicit_top_kernel_equals_plain_kernel():
+    """k_walk_itop (default for narrow images) vs the plain table walk (variant bit 16) vs the
+    oracle, on alphabets that give different itop depths, with bytes outside the key alphabet,
+    direct (stride) and chunked (offsets) entry, final states included"""
+    rng = np.random.default_rng(33)
+    cases = [(b"ACGT", b"ACGTN", 9), (b"ab", b"abz", None), (bytes(range(97, 123)) + b" ", bytes(range(97, 123)) + b" .", 3),
+             (bytes(range(256)), bytes(range(256)), 2), (bytes(range(48, 110)), bytes(range(40, 120)), 3)]
+    for alpha, hay_alpha, want_depth in cases:
+        a = np.frombuffer(alpha, dtype=np.uint8)
+        keys = list({bytes(rng.choice(a, size=int(n)).tobytes()) for n in rng.integers(1, 14, size=4000)})
+        A, O = build_pair(keys)
+        import struct
+        blob = A.flat_image_bytes()
+        if want_depth is not None:
+            assert struct.unpack_from("<I", blob, 140)[0] == want_depth
+        ha = np.frombuffer(hay_alpha, dtype=np.uint8)
+        n, L = 700, 173
+        reads = np.ascontiguousarray(ha[rng.integers(0, len(ha), size=(n, L))])
+        for i in range(0, n, 3):                      # plant keys: deep states and hand-overs
+            k = np.frombuffer(keys[int(rng.integers(0, len(keys)))], dtype=np.uint8)
+            o = int(rng.integers(0, L - len(k)))
+            reads[i, o:o + len(k)] = k
+        off = np.arange(n + 1, dtype=np.int64) * L
+        mo, oe, ov = O.batch(reads.tobytes(), off, 0)
+        img = Image.from_automaton(A)
+        d_hay = DeviceBuffer.from_numpy(reads.reshape(-1), pad=64)
+        d_off = DeviceBuffer.from_numpy(off)
+        outs = []
+        for variant in (0, 1 << 16):
+            sc = Scanner(img)
+            sc.scan(d_hay, n * L, n, stride=L, want_final_state=True, variant=variant)
+            outs.append(sc.fetch())
+            sc.scan(d_hay, n * L, n, dev_off=d_off, want_final_state=True, variant=variant)
+            outs.append(sc.fetch())
+        for moff, e, v, fin in outs:
+            assert np.array_equal(moff, mo) and np.array_equal(e, oe) and np.array_equal(v, ov)
+            assert np.array_equal(fin, outs[0][3])
+
+
 # ------------------------------------------------------------------ configs 3 and 4 (scaled)
 def test_config3_text_corpus_scaled():
     """BASELINE.json config 3 shape, scaled: multi-word lowercase keys, ONE long text corpus

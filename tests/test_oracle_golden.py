@@ -190,3 +190,46 @@ def test_wide_layout_flat_walk(monkeypatch):
     blob = A.flat_image_bytes()
     got, _ = orc.flat_iter(blob, b"a" * 20)
     assert got == O.iter(b"a" * 20)
+
+
+def test_implicit_top_of_trie_structures():
+    """itop (include/acx_blob.h): bitmaps + rank tables + entries let shallow states be walked
+    without table rows.  flat_walk.c:flat_iter_itop is the CPU restatement of k_walk_itop and
+    cross-checks every step against the explicit table."""
+    import struct
+    rng = random.Random(17)
+    alphabets = [b"ab", b"ACGT", b"ACGTN", bytes([0x61, 0x80, 0xFF, 0x00]), b"abcdefghijklmnopqrstuvwxyz ", bytes(range(256)),
+                 bytes(range(40, 102))]
+    seen_depths = set()
+    for trial in range(40):
+        alpha = alphabets[trial % len(alphabets)]
+        hay_alpha = alpha + (b"#" if len(alpha) < 256 and trial % 3 == 0 else b"")   # bytes outside the key alphabet
+        keys = list({bytes(rng.choice(alpha) for _ in range(rng.randint(1, 12))) for _ in range(rng.randint(1, 400))})
+        A, O = build_pair(keys, [rng.randint(-2**40, 2**40) for _ in keys])
+        blob = A.flat_image_bytes()
+        D = struct.unpack_from("<I", blob, 140)[0]
+        assert D >= 1
+        seen_depths.add(D)
+        for _ in range(6):
+            hay = bytes(rng.choice(hay_alpha) for _ in range(rng.randint(0, 300)))
+            if rng.random() < 0.5 and keys:
+                hay += rng.choice(keys) * 2 + bytes(rng.choice(hay_alpha) for _ in range(5))
+            got, fin = orc.flat_iter_itop(blob, hay)
+            exp, fin2 = orc.flat_iter(blob, hay)
+            assert got == exp == O.iter(hay)
+            assert fin == fin2
+    assert len(seen_depths) >= 3          # different alphabets pick different depths
+
+
+def test_implicit_top_dna_depth():
+    import struct
+    from pyahocorasick_amd.workloads import dna_workload
+    keys, reads = dna_workload(3000, 200, 150, seed=8)
+    A, O = build_pair(keys)
+    blob = A.flat_image_bytes()
+    D, = struct.unpack_from("<I", blob, 140)
+    bits, = struct.unpack_from("<I", blob, 164)
+    assert bits == 2 and D == 9             # 4 symbols -> 2 bits; 4^9 bits of E_9 still fit the LDS budget
+    for r in reads[:100]:
+        got, _ = orc.flat_iter_itop(blob, r.tobytes())
+        assert got == O.iter(r.tobytes())
