@@ -50,6 +50,37 @@ def build_libacx(force=False, verbose=True):
     return LIB
 
 
+DROPIN_DIR = os.path.join(ROOT, "dropin")
+
+
+def dropin_path():
+    import sysconfig
+    return os.path.join(DROPIN_DIR, "ahocorasick" + (sysconfig.get_config_var("EXT_SUFFIX") or ".so"))
+
+
+def build_dropin(force=False, verbose=True):
+    """Build the CPython extension `ahocorasick` (dropin/ahocorasick.cpython-*.so): the drop-in
+    host side that exports PyInit_ahocorasick and calls libacx through the C-ABI.
+    Use it with  sys.path.insert(0, "<repo>/dropin"); import ahocorasick"""
+    import sysconfig
+    src = os.path.join(CSRC, "ahocorasick_module.cpp")
+    out = dropin_path()
+    build_libacx(force=False, verbose=verbose)
+    if (not force and os.path.exists(out) and os.path.getmtime(out) > os.path.getmtime(src)
+            and os.path.getmtime(out) > os.path.getmtime(os.path.join(ROOT, "include", "acx.h"))):
+        return out
+    os.makedirs(DROPIN_DIR, exist_ok=True)
+    cmd = ["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-Wall",
+           "-I" + sysconfig.get_paths()["include"], "-I" + os.path.join(ROOT, "include"),
+           src, "-o", out, "-L" + HERE, "-l:libacx.so", "-Wl,-rpath,$ORIGIN/../pyahocorasick_amd"]
+    if verbose:
+        print("[pyahocorasick_amd.build]", " ".join(cmd), flush=True)
+    subprocess.check_call(cmd)
+    return out
+
+
 if __name__ == "__main__":
     build_libacx(force="--force" in sys.argv)
+    build_dropin(force="--force" in sys.argv)
     print(LIB)
+    print(dropin_path())

@@ -1,0 +1,576 @@
+// ahocorasick_module.cpp — CPython extension `ahocorasick`: the drop-in host side.
+//
+// Exports PyInit_ahocorasick and reproduces the Python-visible surface of the reference
+// module for the accelerated path (reference src/pyahocorasick.c:67-137,
+// method table src/Automaton.c:1206-1229): Automaton(store, key_type), add_word, exists, get,
+// longest_prefix, remove_word, pop, clear, make_automaton, iter (+ .set), iter_long, find_all,
+// len(), `in`, attributes kind / store, the module constants — plus the batch entry the
+// reference lacks (iter_batch).  Same argument meaning and error behaviour as the reference
+// (bytes build: keys and haystacks are `bytes`, ahocorasick.unicode == 0).
+//
+// Everything below the Python objects goes through the C-ABI of libacx (include/acx.h): the
+// trie and its failure links live in acx_trie_t (CPU), every search is acx_scan_host (GPU).
+// There is no CPU search path: without a GPU the search methods raise RuntimeError.
+//
+// Not a port: the reference's node graph, input widening, generator state machines and
+// pickling are not here; iterators hold the finished match list of one GPU scan.
+#define PY_SSIZE_T_CLEAN
+#include <Python.h>
+
+#include <cstdint>
+#include <cstring>
+#include <vector>
+
+#include "acx.h"
+
+namespace {
+
+enum { K_EMPTY = 0, K_TRIE = 1, K_AHOCORASICK = 2 };
+enum { STORE_INTS = 10, STORE_LENGTH = 20, STORE_ANY = 30 };
+enum { KEY_STRING = 100, KEY_SEQUENCE = 200 };
+enum { MATCH_EXACT_LENGTH = 0, MATCH_AT_MOST_PREFIX = 1, MATCH_AT_LEAST_PREFIX = 2 };
+
+const char* NOT_AUTOMATON_MSG =
+    "Not an Aho-Corasick automaton yet: call add_word to add some keys and call make_automaton to "
+    "convert the trie to an automaton.";
+
+struct AutomatonObject {
+    PyObject_HEAD
+    acx_trie_t* trie;
+    int store;
+    int key_type;
+    PyObject* values;          // list: value id -> object (STORE_ANY only)
+    acx_image_t* image;        // device image, valid for image_version
+    int64_t image_version;
+    acx_result_t* result;      // reusable device / pinned buffers
+};
+
+PyObject* set_acx_error(int rc) {
+    if (rc == ACX_E_NOMEM) return PyErr_NoMemory();
+    PyErr_SetString(PyExc_RuntimeError, acx_last_error());
+    return nullptr;
+}
+
+// ---- helpers -------------------------------------------------------------------------------
+bool get_bytes(PyObject* o, const char* what, const uint8_t** p, Py_ssize_t* n) {
+    if (!PyBytes_Check(o)) { PyErr_SetString(PyExc_TypeError, what); return false; }
+    *p = (const uint8_t*)PyBytes_AS_STRING(o);
+    *n = PyBytes_GET_SIZE(o);
+    return true;
+}
+
+// [start, [end]] exactly as pymod_parse_start_end does (src/utils.c:293-359), quirks included
+bool parse_start_end(PyObject* args, Py_ssize_t i0, Py_ssize_t i1, Py_ssize_t lo, Py_ssize_t hi,
+                     Py_ssize_t* start, Py_ssize_t* end) {
+    *start = lo; *end = hi;
+    if (PyTuple_GET_SIZE(args) > i0) {
+        PyObject* o = PyNumber_Index(PyTuple_GET_ITEM(args, i0));
+        if (!o) return false;
+        Py_ssize_t v = PyNumber_AsSsize_t(o, PyExc_IndexError);
+        Py_DECREF(o);
+        if (v == -1 && PyErr_Occurred()) return false;
+        if (v < 0) v = hi + v;
+        if (v < lo || v >= hi) { PyErr_Format(PyExc_IndexError, "start index not in range %zd..%zd", lo, hi); return false; }
+        *start = v;
+    } else return true;
+    if (PyTuple_GET_SIZE(args) > i1) {
+        PyObject* o = PyNumber_Index(PyTuple_GET_ITEM(args, i1));
+        if (!o) return false;
+        Py_ssize_t v = PyNumber_AsSsize_t(o, PyExc_IndexError);
+        Py_DECREF(o);
+        if (v == -1 && PyErr_Occurred()) return false;
+        if (v < 0) v = hi - 1 + v;
+        if (v < lo || v > hi) { PyErr_Format(PyExc_IndexError, "end index not in range %zd..%zd", lo, hi); return false; }
+        *end = v;
+    }
+    return true;
+}
+
+// flatten + upload when the trie version moved (device image is tagged like iterators are,
+// src/AutomatonSearchIter.c:247-250)
+bool gpu_sync(AutomatonObject* a) {
+    const int64_t v = acx_trie_version(a->trie);
+    if (a->image && a->image_version == v) return true;
+    if (a->image) { acx_image_free(a->image); a->image = nullptr; }
+    void* blob = nullptr; size_t nbytes = 0;
+    int rc = acx_flatten(a->trie, &blob, &nbytes);
+    if (rc) { set_acx_error(rc); return false; }
+    Py_BEGIN_ALLOW_THREADS
+    rc = acx_image_upload(blob, nbytes, &a->image);
+    Py_END_ALLOW_THREADS
+    acx_blob_free(blob);
+    if (rc) { set_acx_error(rc); return false; }
+    a->image_version = v;
+    return true;
+}
+
+// one GPU scan of n haystacks given as (data, offsets); results stay in a->result
+bool run_scan(AutomatonObject* a, int mode, const uint8_t* data, const int64_t* off, int64_t n,
+              const int32_t* init_state, const int32_t* index_base,
+              const int64_t** moff, const acx_match_t** m, const int32_t** fin) {
+    if (!gpu_sync(a)) return false;
+    int rc;
+    Py_BEGIN_ALLOW_THREADS      // the reference never releases the GIL; a GPU scan can
+    rc = acx_scan_host(a->image, mode, data, off, n, init_state, index_base, &a->result);
+    if (!rc) rc = acx_result_fetch_host(a->result, moff, m, fin);
+    Py_END_ALLOW_THREADS
+    if (rc) { set_acx_error(rc); return false; }
+    return true;
+}
+
+PyObject* make_pair(AutomatonObject* a, int32_t index, int32_t value) {
+    if (a->store == STORE_ANY) {
+        PyObject* o = PyList_GetItem(a->values, value);           // borrowed; "O" increfs
+        if (!o) return nullptr;
+        return Py_BuildValue("iO", (int)index, o);                // src/AutomatonSearchIter.c:186-188
+    }
+    return Py_BuildValue("ii", (int)index, (int)value);           // src/AutomatonSearchIter.c:181-184
+}
+
+// ---- Automaton -----------------------------------------------------------------------------
+PyObject* automaton_new(PyTypeObject* type, PyObject* args, PyObject*) {
+    int store = STORE_ANY, key_type = KEY_STRING;
+    if (!PyArg_ParseTuple(args, "|ii", &store, &key_type)) return nullptr;
+    if (store != STORE_INTS && store != STORE_LENGTH && store != STORE_ANY) {
+        PyErr_SetString(PyExc_ValueError, "store value must be one of ahocorasick.STORE_LENGTH, STORE_INTS or STORE_ANY");
+        return nullptr;
+    }
+    if (key_type != KEY_STRING && key_type != KEY_SEQUENCE) {
+        PyErr_SetString(PyExc_ValueError, "key_type must have value KEY_STRING or KEY_SEQUENCE");
+        return nullptr;
+    }
+    if (key_type == KEY_SEQUENCE) {
+        PyErr_SetString(PyExc_NotImplementedError, "KEY_SEQUENCE automata are not byte automata; outside the GPU path");
+        return nullptr;
+    }
+    AutomatonObject* a = (AutomatonObject*)type->tp_alloc(type, 0);
+    if (!a) return nullptr;
+    a->trie = nullptr; a->values = nullptr; a->image = nullptr; a->result = nullptr; a->image_version = -1;
+    a->store = store; a->key_type = key_type;
+    int rc = acx_trie_new(&a->trie);
+    if (rc) { Py_DECREF(a); return set_acx_error(rc); }
+    if (store == STORE_ANY) { a->values = PyList_New(0); if (!a->values) { Py_DECREF(a); return nullptr; } }
+    return (PyObject*)a;
+}
+
+void automaton_dealloc(AutomatonObject* a) {
+    if (a->image) acx_image_free(a->image);
+    if (a->result) acx_result_free(a->result);
+    if (a->trie) acx_trie_free(a->trie);
+    Py_XDECREF(a->values);
+    Py_TYPE(a)->tp_free((PyObject*)a);
+}
+
+Py_ssize_t automaton_len(AutomatonObject* a) { return (Py_ssize_t)acx_trie_num_keys(a->trie); }
+
+PyObject* automaton_add_word(AutomatonObject* a, PyObject* args) {
+    const Py_ssize_t na = PyTuple_GET_SIZE(args);
+    if (na < 1) { PyErr_SetString(PyExc_TypeError, "add_word() takes a key"); return nullptr; }
+    const uint8_t* key; Py_ssize_t len;
+    if (!get_bytes(PyTuple_GET_ITEM(args, 0), "bytes expected", &key, &len)) return nullptr;
+    int64_t v = 0;
+    PyObject* obj = nullptr;
+    Py_ssize_t slot = -1;
+    if (a->store == STORE_ANY) {                                   // src/Automaton.c:216-223
+        if (na < 2) { PyErr_SetString(PyExc_ValueError, "A value object is required as second argument."); return nullptr; }
+        obj = PyTuple_GET_ITEM(args, 1);
+        if (len == 0) Py_RETURN_FALSE;
+        int found = 0; int64_t old = 0;
+        int rc = acx_trie_get(a->trie, key, (size_t)len, &found, &old);
+        if (rc) return set_acx_error(rc);
+        if (found) slot = (Py_ssize_t)old;
+        else {
+            slot = PyList_GET_SIZE(a->values);
+            if (PyList_Append(a->values, Py_None) < 0) return nullptr;
+        }
+        v = slot;
+    } else if (a->store == STORE_INTS) {                           // src/Automaton.c:225-243
+        if (na >= 2) {
+            PyObject* o = PyTuple_GET_ITEM(args, 1);
+            if (!PyNumber_Check(o)) { PyErr_SetString(PyExc_TypeError, "An integer value is required as second argument."); return nullptr; }
+            Py_ssize_t iv = PyNumber_AsSsize_t(o, PyExc_ValueError);
+            if (iv == -1 && PyErr_Occurred()) return nullptr;
+            v = (int64_t)iv;
+        } else v = acx_trie_num_keys(a->trie) + 1;
+    } else v = (int64_t)len;                                       // STORE_LENGTH
+    int is_new = 0;
+    int rc = acx_trie_add_word(a->trie, key, (size_t)len, v, &is_new);
+    if (rc) return set_acx_error(rc);
+    if (obj && len > 0) {
+        Py_INCREF(obj);
+        if (PyList_SetItem(a->values, slot, obj) < 0) return nullptr;   // steals; drops the old value
+    }
+    if (is_new) Py_RETURN_TRUE;
+    Py_RETURN_FALSE;
+}
+
+bool lookup(AutomatonObject* a, PyObject* keyobj, int* found, int64_t* value) {
+    const uint8_t* key; Py_ssize_t len;
+    if (!get_bytes(keyobj, "bytes expected", &key, &len)) return false;
+    int rc = acx_trie_get(a->trie, key, (size_t)len, found, value);
+    if (rc) { set_acx_error(rc); return false; }
+    return true;
+}
+
+PyObject* automaton_exists(AutomatonObject* a, PyObject* args) {
+    PyObject* k; if (!PyArg_ParseTuple(args, "O", &k)) return nullptr;
+    int found; int64_t v;
+    if (!lookup(a, k, &found, &v)) return nullptr;
+    if (found) Py_RETURN_TRUE;
+    Py_RETURN_FALSE;
+}
+
+int automaton_contains(AutomatonObject* a, PyObject* k) {
+    int found; int64_t v;
+    if (!lookup(a, k, &found, &v)) return -1;
+    return found;
+}
+
+PyObject* value_object(AutomatonObject* a, int64_t v) {
+    if (a->store == STORE_ANY) { PyObject* o = PyList_GetItem(a->values, (Py_ssize_t)v); Py_XINCREF(o); return o; }
+    return PyLong_FromLongLong((long long)v);
+}
+
+PyObject* automaton_get(AutomatonObject* a, PyObject* args) {
+    PyObject* k; PyObject* dflt = nullptr;
+    if (!PyArg_ParseTuple(args, "O|O", &k, &dflt)) return nullptr;
+    int found; int64_t v;
+    if (!lookup(a, k, &found, &v)) return nullptr;
+    if (found) return value_object(a, v);
+    if (dflt) { Py_INCREF(dflt); return dflt; }
+    PyErr_SetObject(PyExc_KeyError, k);
+    return nullptr;
+}
+
+PyObject* automaton_longest_prefix(AutomatonObject* a, PyObject* args) {
+    PyObject* k; if (!PyArg_ParseTuple(args, "O", &k)) return nullptr;
+    const uint8_t* key; Py_ssize_t len;
+    if (!get_bytes(k, "bytes expected", &key, &len)) return nullptr;
+    size_t n = 0;
+    int rc = acx_trie_longest_prefix(a->trie, key, (size_t)len, &n);
+    if (rc) return set_acx_error(rc);
+    return PyLong_FromSize_t(n);
+}
+
+// 1 removed (value in *out, new ref), 0 absent, -1 error
+int remove_common(AutomatonObject* a, PyObject* args, PyObject** out) {
+    PyObject* k; if (!PyArg_ParseTuple(args, "O", &k)) return -1;
+    const uint8_t* key; Py_ssize_t len;
+    if (!get_bytes(k, "bytes expected", &key, &len)) return -1;
+    int found = 0; int64_t v = 0;
+    int rc = acx_trie_remove_word(a->trie, key, (size_t)len, &found, &v);
+    if (rc) { set_acx_error(rc); return -1; }
+    if (!found) return 0;
+    if (a->store == STORE_ANY) {
+        PyObject* o = PyList_GetItem(a->values, (Py_ssize_t)v);
+        if (!o) return -1;
+        Py_INCREF(o);
+        Py_INCREF(Py_None);
+        PyList_SetItem(a->values, (Py_ssize_t)v, Py_None);
+        *out = o;
+    } else *out = PyLong_FromLongLong((long long)v);
+    return 1;
+}
+
+PyObject* automaton_remove_word(AutomatonObject* a, PyObject* args) {
+    PyObject* v = nullptr;
+    int r = remove_common(a, args, &v);
+    if (r < 0) return nullptr;
+    Py_XDECREF(v);
+    if (r) Py_RETURN_TRUE;
+    Py_RETURN_FALSE;
+}
+
+PyObject* automaton_pop(AutomatonObject* a, PyObject* args) {
+    PyObject* v = nullptr;
+    int r = remove_common(a, args, &v);
+    if (r < 0) return nullptr;
+    if (!r) { PyErr_SetNone(PyExc_KeyError); return nullptr; }     // src/Automaton.c:354-356
+    return v;
+}
+
+PyObject* automaton_clear(AutomatonObject* a, PyObject*) {
+    acx_trie_clear(a->trie);
+    if (a->values) { if (PyList_SetSlice(a->values, 0, PyList_GET_SIZE(a->values), nullptr) < 0) return nullptr; }
+    if (a->image) { acx_image_free(a->image); a->image = nullptr; }
+    Py_RETURN_NONE;
+}
+
+PyObject* automaton_make_automaton(AutomatonObject* a, PyObject*) {
+    int changed = 0, rc;
+    Py_BEGIN_ALLOW_THREADS
+    rc = acx_trie_make_automaton(a->trie, &changed);
+    Py_END_ALLOW_THREADS
+    if (rc) return set_acx_error(rc);
+    if (changed) Py_RETURN_NONE;
+    Py_RETURN_FALSE;                                               // src/Automaton.c:574-575
+}
+
+PyObject* automaton_get_kind(AutomatonObject* a, void*) { return PyLong_FromLong(acx_trie_kind(a->trie)); }
+PyObject* automaton_get_store(AutomatonObject* a, void*) { return PyLong_FromLong(a->store); }
+
+// ---- search iterators ----------------------------------------------------------------------
+struct SearchIterObject {
+    PyObject_HEAD
+    AutomatonObject* automaton;
+    int64_t version;
+    std::vector<acx_match_t>* pending;
+    size_t pos;
+    int32_t state;          // carried across set() (ACX_SCAN_ALL only)
+    Py_ssize_t shift;
+    Py_ssize_t ref_index;   // the reference's iter->index, for set()'s shift arithmetic
+    Py_ssize_t end;
+    bool ignore_ws;
+    bool is_long;
+};
+
+extern PyTypeObject SearchIterType;
+
+inline bool is_cspace(uint8_t b) { return b == ' ' || (b >= '\t' && b <= '\r'); }    // iswspace over bytes-build letters
+
+bool iter_load(SearchIterObject* it, const uint8_t* data, Py_ssize_t start, Py_ssize_t end) {
+    AutomatonObject* a = it->automaton;
+    const int64_t* moff; const acx_match_t* m; const int32_t* fin;
+    std::vector<uint8_t> compact;
+    std::vector<int32_t> remap;
+    const uint8_t* src = data + start;
+    int64_t off[2] = {0, (int64_t)(end - start)};
+    int32_t base = (int32_t)(start + it->shift);
+    if (it->ignore_ws) {     // the reference skips white-space letters without touching the state (:269-274)
+        for (Py_ssize_t i = start; i < end; i++)
+            if (!is_cspace(data[i])) { compact.push_back(data[i]); remap.push_back((int32_t)(i + it->shift)); }
+        src = compact.data(); off[1] = (int64_t)compact.size(); base = 0;
+    }
+    int32_t init = it->state;
+    if (!run_scan(a, it->is_long ? ACX_SCAN_LONG : ACX_SCAN_ALL, src, off, 1,
+                  it->is_long ? nullptr : &init, &base, &moff, &m, &fin)) return false;
+    it->pending->assign(m, m + moff[1]);
+    if (it->ignore_ws) for (auto& r : *it->pending) r.end_index = remap[(size_t)r.end_index];
+    it->pos = 0;
+    if (!it->is_long && fin) it->state = fin[0];
+    it->end = end;
+    it->ref_index = start - 1;                                     // src/AutomatonSearchIter.c:123
+    return true;
+}
+
+PyObject* search_iter_create(AutomatonObject* a, PyObject* bytes, Py_ssize_t start, Py_ssize_t end, bool ws, bool is_long) {
+    SearchIterObject* it = PyObject_New(SearchIterObject, &SearchIterType);
+    if (!it) return nullptr;
+    it->automaton = a; Py_INCREF(a);
+    it->version = acx_trie_version(a->trie);
+    it->pending = new std::vector<acx_match_t>();
+    it->pos = 0; it->state = 0; it->shift = 0; it->ref_index = -1; it->end = 0; it->ignore_ws = ws; it->is_long = is_long;
+    if (!iter_load(it, (const uint8_t*)PyBytes_AS_STRING(bytes), start, end)) { Py_DECREF(it); return nullptr; }
+    return (PyObject*)it;
+}
+
+void search_iter_dealloc(SearchIterObject* it) {
+    Py_XDECREF(it->automaton);
+    delete it->pending;
+    PyObject_Del(it);
+}
+
+PyObject* search_iter_iter(PyObject* self) { Py_INCREF(self); return self; }
+
+PyObject* search_iter_next(SearchIterObject* it) {
+    if (it->version != acx_trie_version(it->automaton->trie)) {    // src/AutomatonSearchIter.c:247-250
+        PyErr_SetString(PyExc_ValueError, "underlaying automaton has changed, iterator is not valid anymore");
+        return nullptr;
+    }
+    if (it->pos >= it->pending->size()) { it->ref_index = it->end; return nullptr; }   // StopIteration
+    const acx_match_t r = (*it->pending)[it->pos++];
+    it->ref_index = (Py_ssize_t)r.end_index - it->shift;
+    return make_pair(it->automaton, r.end_index, r.value);
+}
+
+PyObject* search_iter_set(SearchIterObject* it, PyObject* args) {  // src/AutomatonSearchIter.c:303-368
+    PyObject* s; int reset = 0;
+    if (!PyArg_ParseTuple(args, "O|p", &s, &reset)) return nullptr;
+    const uint8_t* data; Py_ssize_t n;
+    if (!get_bytes(s, "bytes expected", &data, &n)) return nullptr;
+    if (reset) { it->state = 0; it->shift = 0; }
+    else it->shift += it->ref_index >= 0 ? it->ref_index : 0;
+    if (!iter_load(it, data, 0, n)) return nullptr;
+    Py_RETURN_NONE;
+}
+
+PyMethodDef search_iter_methods[] = {
+    {"set", (PyCFunction)search_iter_set, METH_VARARGS, "set(string, reset=False): continue the search on a new chunk"},
+    {nullptr, nullptr, 0, nullptr}};
+
+PyTypeObject SearchIterType = {PyVarObject_HEAD_INIT(nullptr, 0) "ahocorasick.AutomatonSearchIter"};
+
+// ---- search methods ------------------------------------------------------------------------
+PyObject* automaton_iter(AutomatonObject* a, PyObject* args, PyObject* kw) {
+    static const char* kwlist[] = {"string", "start", "end", "ignore_white_space", nullptr};
+    if (acx_trie_kind(a->trie) != K_AHOCORASICK) { PyErr_SetString(PyExc_AttributeError, NOT_AUTOMATON_MSG); return nullptr; }
+    PyObject* s; int start = -1, end = -1, ws = -1;
+    if (!PyArg_ParseTupleAndKeywords(args, kw, "O|iii", (char**)kwlist, &s, &start, &end, &ws)) return nullptr;
+    if (!PyBytes_Check(s)) { PyErr_SetString(PyExc_TypeError, "bytes required"); return nullptr; }
+    const Py_ssize_t n = PyBytes_GET_SIZE(s);
+    // -1 = default for both (src/Automaton.c:893-956).  The reference does not validate the
+    // range (out of range is undefined behaviour there); here it is clamped to the haystack.
+    Py_ssize_t st = start == -1 ? 0 : start, en = end == -1 ? n : end;
+    if (st < 0) st = 0;
+    if (st > n) st = n;
+    if (en > n) en = n;
+    if (en < st) en = st;
+    return search_iter_create(a, s, st, en, ws == 1, false);
+}
+
+PyObject* automaton_iter_long(AutomatonObject* a, PyObject* args) {
+    if (acx_trie_kind(a->trie) != K_AHOCORASICK) {
+        PyErr_SetString(PyExc_AttributeError, "not an automaton yet; add some words and call make_automaton");
+        return nullptr;
+    }
+    if (PyTuple_GET_SIZE(args) < 1) { PyErr_SetString(PyExc_TypeError, "iter_long() takes a string"); return nullptr; }
+    PyObject* s = PyTuple_GET_ITEM(args, 0);
+    if (!PyBytes_Check(s)) { PyErr_SetString(PyExc_TypeError, "bytes required"); return nullptr; }
+    Py_ssize_t st, en;
+    if (!parse_start_end(args, 1, 2, 0, PyBytes_GET_SIZE(s), &st, &en)) return nullptr;
+    if (en < st) en = st;
+    return search_iter_create(a, s, st, en, false, true);
+}
+
+PyObject* automaton_find_all(AutomatonObject* a, PyObject* args) {
+    if (acx_trie_kind(a->trie) != K_AHOCORASICK) Py_RETURN_NONE;   // src/Automaton.c:666-667
+    if (PyTuple_GET_SIZE(args) < 2) { PyErr_SetString(PyExc_TypeError, "find_all() takes a string and a callback"); return nullptr; }
+    PyObject* s = PyTuple_GET_ITEM(args, 0);
+    PyObject* cb = PyTuple_GET_ITEM(args, 1);
+    const uint8_t* data; Py_ssize_t n;
+    if (!get_bytes(s, "bytes expected", &data, &n)) return nullptr;
+    if (!PyCallable_Check(cb)) {
+        PyErr_SetString(PyExc_TypeError, "The callback argument must be a callable such as a function.");
+        return nullptr;
+    }
+    Py_ssize_t st, en;
+    if (!parse_start_end(args, 2, 3, 0, n, &st, &en)) return nullptr;
+    if (en < st) en = st;
+    const int64_t off[2] = {0, (int64_t)(en - st)};
+    const int32_t base = (int32_t)st;
+    const int64_t* moff; const acx_match_t* m; const int32_t* fin;
+    if (!run_scan(a, ACX_SCAN_ALL, data + st, off, 1, nullptr, &base, &moff, &m, &fin)) return nullptr;
+    std::vector<acx_match_t> copy(m, m + moff[1]);                 // the callback may re-enter this automaton
+    for (const acx_match_t& r : copy) {
+        PyObject* pair = make_pair(a, r.end_index, r.value);
+        if (!pair) return nullptr;
+        PyObject* ret = PyObject_CallObject(cb, pair);
+        Py_DECREF(pair);
+        if (!ret) return nullptr;                                  // an exception aborts, src/Automaton.c:705-708
+        Py_DECREF(ret);
+    }
+    Py_RETURN_NONE;
+}
+
+// NEW: iter_batch(list_of_bytes, long=False) -> [list(A.iter(h)) for h in list]
+PyObject* automaton_iter_batch(AutomatonObject* a, PyObject* args, PyObject* kw) {
+    static const char* kwlist[] = {"haystacks", "long", nullptr};
+    if (acx_trie_kind(a->trie) != K_AHOCORASICK) { PyErr_SetString(PyExc_AttributeError, NOT_AUTOMATON_MSG); return nullptr; }
+    PyObject* seq; int is_long = 0;
+    if (!PyArg_ParseTupleAndKeywords(args, kw, "O|p", (char**)kwlist, &seq, &is_long)) return nullptr;
+    PyObject* fast = PySequence_Fast(seq, "iter_batch() takes a sequence of bytes");
+    if (!fast) return nullptr;
+    const Py_ssize_t n = PySequence_Fast_GET_SIZE(fast);
+    std::vector<int64_t> off((size_t)n + 1, 0);
+    for (Py_ssize_t i = 0; i < n; i++) {
+        PyObject* o = PySequence_Fast_GET_ITEM(fast, i);
+        if (!PyBytes_Check(o)) { Py_DECREF(fast); PyErr_SetString(PyExc_TypeError, "bytes required"); return nullptr; }
+        off[(size_t)i + 1] = off[(size_t)i] + PyBytes_GET_SIZE(o);
+    }
+    std::vector<uint8_t> data((size_t)off[(size_t)n]);
+    for (Py_ssize_t i = 0; i < n; i++) {
+        PyObject* o = PySequence_Fast_GET_ITEM(fast, i);
+        memcpy(data.data() + off[(size_t)i], PyBytes_AS_STRING(o), (size_t)PyBytes_GET_SIZE(o));
+    }
+    Py_DECREF(fast);
+    const int64_t* moff; const acx_match_t* m; const int32_t* fin;
+    if (!run_scan(a, is_long ? ACX_SCAN_LONG : ACX_SCAN_ALL, data.data(), off.data(), n, nullptr, nullptr, &moff, &m, &fin))
+        return nullptr;
+    PyObject* out = PyList_New(n);
+    if (!out) return nullptr;
+    for (Py_ssize_t i = 0; i < n; i++) {
+        const int64_t lo = moff[i], hi = moff[i + 1];
+        PyObject* lst = PyList_New((Py_ssize_t)(hi - lo));
+        if (!lst) { Py_DECREF(out); return nullptr; }
+        for (int64_t k = lo; k < hi; k++) {
+            PyObject* pair = make_pair(a, m[k].end_index, m[k].value);
+            if (!pair) { Py_DECREF(lst); Py_DECREF(out); return nullptr; }
+            PyList_SET_ITEM(lst, (Py_ssize_t)(k - lo), pair);
+        }
+        PyList_SET_ITEM(out, i, lst);
+    }
+    return out;
+}
+
+PyObject* automaton_get_stats(AutomatonObject* a, PyObject*) {
+    return Py_BuildValue("{s:L,s:L,s:L}", "nodes_count", (long long)acx_trie_num_nodes(a->trie),
+                         "words_count", (long long)acx_trie_num_keys(a->trie),
+                         "longest_word", (long long)acx_trie_longest_word(a->trie));
+}
+
+PyMethodDef automaton_methods[] = {
+    {"add_word", (PyCFunction)automaton_add_word, METH_VARARGS, "add_word(key, [value]) -> bool"},
+    {"exists", (PyCFunction)automaton_exists, METH_VARARGS, "exists(key) -> bool"},
+    {"get", (PyCFunction)automaton_get, METH_VARARGS, "get(key[, default])"},
+    {"longest_prefix", (PyCFunction)automaton_longest_prefix, METH_VARARGS, "longest_prefix(key) -> int"},
+    {"remove_word", (PyCFunction)automaton_remove_word, METH_VARARGS, "remove_word(key) -> bool"},
+    {"pop", (PyCFunction)automaton_pop, METH_VARARGS, "pop(key) -> value"},
+    {"clear", (PyCFunction)automaton_clear, METH_NOARGS, "clear()"},
+    {"make_automaton", (PyCFunction)automaton_make_automaton, METH_NOARGS, "make_automaton()"},
+    {"iter", (PyCFunction)automaton_iter, METH_VARARGS | METH_KEYWORDS, "iter(string, [start, [end]], ignore_white_space=False)"},
+    {"iter_long", (PyCFunction)automaton_iter_long, METH_VARARGS, "iter_long(string, [start, [end]])"},
+    {"find_all", (PyCFunction)automaton_find_all, METH_VARARGS, "find_all(string, callback, [start, [end]])"},
+    {"iter_batch", (PyCFunction)automaton_iter_batch, METH_VARARGS | METH_KEYWORDS, "iter_batch(haystacks, long=False) -> list of lists (GPU batch scan)"},
+    {"get_stats", (PyCFunction)automaton_get_stats, METH_NOARGS, "get_stats() -> dict"},
+    {nullptr, nullptr, 0, nullptr}};
+
+PyGetSetDef automaton_getset[] = {
+    {"kind", (getter)automaton_get_kind, nullptr, "EMPTY, TRIE or AHOCORASICK", nullptr},
+    {"store", (getter)automaton_get_store, nullptr, "STORE_INTS, STORE_LENGTH or STORE_ANY", nullptr},
+    {nullptr, nullptr, nullptr, nullptr, nullptr}};
+
+PySequenceMethods automaton_as_sequence = {};
+
+PyTypeObject AutomatonType = {PyVarObject_HEAD_INIT(nullptr, 0) "ahocorasick.Automaton"};
+
+PyModuleDef module_def = {PyModuleDef_HEAD_INIT, "ahocorasick",
+                          "MI355X-native Aho-Corasick scan engine behind the pyahocorasick Automaton API (bytes build)",
+                          -1, nullptr, nullptr, nullptr, nullptr, nullptr};
+
+}  // namespace
+
+PyMODINIT_FUNC PyInit_ahocorasick(void) {
+    AutomatonType.tp_basicsize = sizeof(AutomatonObject);
+    AutomatonType.tp_flags = Py_TPFLAGS_DEFAULT;
+    AutomatonType.tp_doc = "Automaton(value_type=STORE_ANY, key_type=KEY_STRING)";
+    AutomatonType.tp_new = automaton_new;
+    AutomatonType.tp_dealloc = (destructor)automaton_dealloc;
+    AutomatonType.tp_methods = automaton_methods;
+    AutomatonType.tp_getset = automaton_getset;
+    automaton_as_sequence.sq_length = (lenfunc)automaton_len;
+    automaton_as_sequence.sq_contains = (objobjproc)automaton_contains;
+    AutomatonType.tp_as_sequence = &automaton_as_sequence;
+    if (PyType_Ready(&AutomatonType) < 0) return nullptr;
+
+    SearchIterType.tp_basicsize = sizeof(SearchIterObject);
+    SearchIterType.tp_flags = Py_TPFLAGS_DEFAULT;
+    SearchIterType.tp_dealloc = (destructor)search_iter_dealloc;
+    SearchIterType.tp_iter = search_iter_iter;
+    SearchIterType.tp_iternext = (iternextfunc)search_iter_next;
+    SearchIterType.tp_methods = search_iter_methods;
+    if (PyType_Ready(&SearchIterType) < 0) return nullptr;
+
+    PyObject* m = PyModule_Create(&module_def);
+    if (!m) return nullptr;
+    Py_INCREF(&AutomatonType);
+    if (PyModule_AddObject(m, "Automaton", (PyObject*)&AutomatonType) < 0) return nullptr;
+#define ADD_INT(name, value) if (PyModule_AddIntConstant(m, name, value) < 0) return nullptr
+    ADD_INT("TRIE", K_TRIE); ADD_INT("AHOCORASICK", K_AHOCORASICK); ADD_INT("EMPTY", K_EMPTY);
+    ADD_INT("STORE_LENGTH", STORE_LENGTH); ADD_INT("STORE_INTS", STORE_INTS); ADD_INT("STORE_ANY", STORE_ANY);
+    ADD_INT("KEY_STRING", KEY_STRING); ADD_INT("KEY_SEQUENCE", KEY_SEQUENCE);
+    ADD_INT("MATCH_EXACT_LENGTH", MATCH_EXACT_LENGTH); ADD_INT("MATCH_AT_MOST_PREFIX", MATCH_AT_MOST_PREFIX);
+    ADD_INT("MATCH_AT_LEAST_PREFIX", MATCH_AT_LEAST_PREFIX);
+    ADD_INT("unicode", 0);
+#undef ADD_INT
+    return m;
+}

@@ -1,0 +1,158 @@
+"""The CPython extension `ahocorasick` (dropin/): the drop-in host side of SURVEY.md §8b.
+CPU part: module surface, trie API, error conventions (modelled on reference tests/test_unit.py).
+GPU part (-m gpu): the reference's known-answer vectors and generated fixtures through
+`import ahocorasick` exactly as a user of the reference would call it."""
+import os
+import sys
+
+import pytest
+
+from helpers import expected_pairs, load_json
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def ahocorasick():
+    from pyahocorasick_amd.build import build_dropin, DROPIN_DIR
+    build_dropin(verbose=False)
+    sys.path.insert(0, DROPIN_DIR)
+    try:
+        sys.modules.pop("ahocorasick", None)
+        import ahocorasick as mod
+        assert mod.__file__.startswith(DROPIN_DIR)
+        yield mod
+    finally:
+        sys.path.remove(DROPIN_DIR)
+        sys.modules.pop("ahocorasick", None)
+
+
+def test_module_surface(ahocorasick):
+    import ctypes
+    dll = ctypes.CDLL(ahocorasick.__file__)
+    assert hasattr(dll, "PyInit_ahocorasick")
+    for name, val in dict(EMPTY=0, TRIE=1, AHOCORASICK=2, STORE_INTS=10, STORE_LENGTH=20, STORE_ANY=30,
+                          KEY_STRING=100, KEY_SEQUENCE=200, MATCH_EXACT_LENGTH=0, MATCH_AT_MOST_PREFIX=1,
+                          MATCH_AT_LEAST_PREFIX=2, unicode=0).items():
+        assert getattr(ahocorasick, name) == val          # reference src/pyahocorasick.c:113-134
+    for m in ("add_word", "exists", "get", "longest_prefix", "remove_word", "pop", "clear", "make_automaton",
+              "iter", "iter_long", "find_all", "iter_batch"):
+        assert callable(getattr(ahocorasick.Automaton, m))
+
+
+def test_trie_api_and_errors(ahocorasick):
+    with pytest.raises(ValueError):
+        ahocorasick.Automaton(1234)
+    with pytest.raises(ValueError):
+        ahocorasick.Automaton(ahocorasick.STORE_ANY, 5)
+    A = ahocorasick.Automaton()
+    assert A.kind == ahocorasick.EMPTY and len(A) == 0 and A.store == ahocorasick.STORE_ANY
+    with pytest.raises(ValueError):
+        A.add_word(b"x")                                  # STORE_ANY needs a value
+    with pytest.raises(TypeError):
+        A.add_word("text", 1)
+    assert A.add_word(b"he", "x") is True and A.add_word(b"he", "y") is False
+    assert A.get(b"he") == "y" and b"he" in A and A.exists(b"he") and not A.exists(b"h")
+    assert A.kind == ahocorasick.TRIE and len(A) == 1
+    with pytest.raises(AttributeError):
+        A.iter(b"she")
+    with pytest.raises(AttributeError):
+        A.iter_long(b"she")
+    assert A.find_all(b"she", b"not even callable") is None      # silently None before make_automaton
+    assert A.make_automaton() is None and A.kind == ahocorasick.AHOCORASICK and A.make_automaton() is False
+    with pytest.raises(TypeError, match="bytes required"):
+        A.iter("text")
+    with pytest.raises(TypeError, match="callable"):
+        A.find_all(b"she", None)
+    with pytest.raises(TypeError):
+        A.iter(b"x", ignore_white_space2=True)
+    assert A.get(b"nope", 42) == 42
+    with pytest.raises(KeyError):
+        A.get(b"nope")
+    with pytest.raises(KeyError):
+        A.pop(b"nope")
+    assert A.longest_prefix(b"hex") == 2
+    assert A.pop(b"he") == "y" and len(A) == 0 and A.kind == ahocorasick.TRIE
+    B = ahocorasick.Automaton(ahocorasick.STORE_INTS)
+    B.add_word(b"a"); B.add_word(b"b"); B.add_word(b"c", 77)
+    assert [B.get(k) for k in (b"a", b"b", b"c")] == [1, 2, 77]
+    with pytest.raises(TypeError):
+        B.add_word(b"d", "not an int")
+    C = ahocorasick.Automaton(ahocorasick.STORE_LENGTH)
+    C.add_word(b"hello")
+    assert C.get(b"hello") == 5
+    C.clear()
+    assert C.kind == ahocorasick.EMPTY and len(C) == 0
+
+
+def _build(mod, keys):
+    A = mod.Automaton(mod.STORE_INTS)
+    for i, k in enumerate(keys):
+        A.add_word(k, i)
+    A.make_automaton()
+    return A
+
+
+VECTORS = load_json("ref_vectors.json")["vectors"]
+RANDOM = load_json("ref_random.json")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("v", VECTORS, ids=[v["id"] for v in VECTORS])
+def test_dropin_reference_vectors(ahocorasick, v):
+    keys = [bytes.fromhex(k) for k in v["keys_hex"]]
+    hay = bytes.fromhex(v["hay_hex"])
+    A = _build(ahocorasick, keys)
+    rng = [] if v["start"] is None else ([v["start"]] if v["end"] is None else [v["start"], v["end"]])
+    if v["mode"] == "iter":
+        got = list(A.iter(hay, *rng))
+    elif v["mode"] == "iter_long":
+        got = list(A.iter_long(hay, *rng))
+    else:
+        got = []
+        A.find_all(hay, lambda i, val: got.append((i, val)), *rng)
+    assert got == expected_pairs(v["expected"]), v["source"]
+
+
+@pytest.mark.gpu
+def test_dropin_generated_fixtures_and_objects(ahocorasick):
+    for c in RANDOM["cases"]:
+        if c["store"] != "ints":
+            continue
+        keys = [bytes.fromhex(k) for k in c["keys_hex"]]
+        A = ahocorasick.Automaton(ahocorasick.STORE_INTS)
+        for k, val in zip(keys, c["values"]):
+            A.add_word(k, val)
+        A.make_automaton()
+        hays = [bytes.fromhex(h["hay_hex"]) for h in c["hays"]]
+        assert A.iter_batch(hays) == [expected_pairs(h["iter"]) for h in c["hays"]]
+        assert A.iter_batch(hays, long=True) == [expected_pairs(h["iter_long"]) for h in c["hays"]]
+        it = A.iter(b"")
+        for part_hex, exp in zip(c["chunks"]["parts_hex"], c["chunks"]["iter_set"]):
+            it.set(bytes.fromhex(part_hex))
+            assert list(it) == expected_pairs(exp)
+    # STORE_ANY objects, order within a position (reference tests/test_basic.py:18-50)
+    A = ahocorasick.Automaton()
+    for i, w in enumerate(b"he e hers his she hi him man he".split()):
+        A.add_word(w, (i, w))
+    A.make_automaton()
+    q = b"he rshershidamanza "
+    assert list(A.iter(string=q, start=2, end=8)) == [(6, (4, b"she")), (6, (8, b"he")), (6, (1, b"e"))]
+    res = []
+    A.find_all(q, lambda index, item: res.append((index, item)), 2, 11)
+    assert res == [(6, (4, b"she")), (6, (8, b"he")), (6, (1, b"e")), (8, (2, b"hers")), (10, (5, b"hi"))]
+    with pytest.raises(IndexError, match="end index not in range 0..19"):
+        A.find_all(q, lambda i, v: None, 0, len(q) + 5)
+    # white space skipping (reference tests/test_unit.py:813-849) and iterator invalidation (860-879)
+    B = ahocorasick.Automaton()
+    for w in "he her hers she".split():
+        B.add_word(w.encode(), w)
+    B.make_automaton()
+    s = b"_sh e rher she_"
+    assert list(B.iter(s, ignore_white_space=True)) == [(4, "she"), (4, "he"), (6, "her"), (8, "he"), (9, "her"),
+                                                        (11, "hers"), (13, "she"), (13, "he")]
+    it = B.iter(b"hehe")
+    assert next(it) == (1, "he")
+    B.add_word(b"zzz", "zzz")
+    with pytest.raises(ValueError):
+        next(it)
