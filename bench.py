@@ -192,6 +192,12 @@ def main():
         H = n * L                                     # haystack bytes per rank per step
         A_bytes = H + 8 * matches + 12 * n            # H + 8*M + 12*N
         med = {k: float(np.median(v)) for k, v in kt.items()}
+        if args.mode != "iter":
+            walk_kernel = "k_walk_long"
+        elif image.itop_depth > 0 and not (args.variant >> 16) & 1:
+            walk_kernel = "k_walk_itop"          # implicit top-of-trie walk
+        else:
+            walk_kernel = "k_walk_all"
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "traffic.json")
         if os.path.exists(tpath):
@@ -213,13 +219,13 @@ def main():
             "matches_per_step": matches_all,
             "config": {"workload": "config2: %d ACGT keys 8-32 B, %d x %d B reads per GPU, Automaton.%s"
                                    % (args.keys, n, L, args.mode),
-                       "states": int(image.num_states), "classes": int(image.num_classes),
+                       "states": int(image.num_states), "classes": int(image.num_classes), "itop_depth": int(image.itop_depth),
                        "image_mb": round(image.nbytes / 1e6, 1), "variant": args.variant,
                        "parallelism": "replicated automaton (1 RCCL broadcast), reads sharded x%d" % world},
             # dominant kernel = the walk: it alone reads the haystack (H) and the per-haystack
             # bookkeeping (12 B x N); the 8 B x M match records are written by k_expand.
             "roofline": {
-                "bound": "hbm", "kernel": "k_walk_all" if args.mode == "iter" else "k_walk_long",
+                "bound": "hbm", "kernel": walk_kernel,
                 "achieved": (H + 12 * n) / (med["walk"] * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": (H + 12 * n) / (med["walk"] * 1e-3) / 1e9 / HBM_PEAK_GBS,
                 "algorithmic_bytes": H + 12 * n, "kernel_avg_ms": round(med["walk"], 4),

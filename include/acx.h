@@ -104,6 +104,9 @@ int64_t acx_image_num_states(const acx_image_t* img);
 int64_t acx_image_num_classes(const acx_image_t* img);
 size_t  acx_image_nbytes(const acx_image_t* img);
 void*   acx_image_dev_ptr(const acx_image_t* img);
+/* depth D of the implicit top-of-trie the image carries (0 = none): states shallower than D
+ * are walked from LDS-resident k-gram bitmaps instead of table rows (include/acx_blob.h) */
+int     acx_image_itop_depth(const acx_image_t* img);
 
 /* ------------------------------------------------------------------------------------
  * 3. Batch scan — THE hot path.

@@ -139,6 +139,7 @@ extern "C" int64_t acx_image_num_states(const acx_image_t* img) { return img ? i
 extern "C" int64_t acx_image_num_classes(const acx_image_t* img) { return img ? img->h.n_classes : 0; }
 extern "C" size_t  acx_image_nbytes(const acx_image_t* img) { return img ? img->nbytes : 0; }
 extern "C" void*   acx_image_dev_ptr(const acx_image_t* img) { return img ? img->dev : nullptr; }
+extern "C" int     acx_image_itop_depth(const acx_image_t* img) { return (img && img->itop_lds) ? (int)img->h.itop_depth : 0; }
 
 // ------------------------------------------------------------------------------------
 // result

@@ -91,6 +91,10 @@ class Image:
     def nbytes(self):
         return lib().acx_image_nbytes(self.handle)
 
+    @property
+    def itop_depth(self):
+        return lib().acx_image_itop_depth(self.handle)
+
     def free(self):
         if self.handle:
             lib().acx_image_free(self.handle)
