@@ -107,6 +107,9 @@ void*   acx_image_dev_ptr(const acx_image_t* img);
 /* depth D of the implicit top-of-trie the image carries (0 = none): states shallower than D
  * are walked from LDS-resident k-gram bitmaps instead of table rows (include/acx_blob.h) */
 int     acx_image_itop_depth(const acx_image_t* img);
+/* device address of the dense transition table the scans read: inside the blob, or the table
+ * built in HBM by acx_image_upload/adopt when the blob carries only the sparse form */
+const void* acx_image_table_dev_ptr(const acx_image_t* img);
 
 /* ------------------------------------------------------------------------------------
  * 3. Batch scan — THE hot path.

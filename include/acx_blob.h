@@ -105,7 +105,21 @@ typedef struct acx_blob_header {
     uint64_t off_itop_entry; /* uint32 [sum over levels 1..D of 2^(b*d)]  entry of node (d, code) */
     uint32_t itop_lds_bytes;
     uint32_t itop_bits;      /* b: bits per symbol                                       */
-    uint8_t  reserved[ACX_BLOB_HEADER_BYTES - 168];
+    /* Sparse form of the transitions (always present): enough to (re)build `table` on the
+     * device — row(s) = row(fail(s)) with EDGE cleared, then s's own edges — level by level.
+     * When table_in_blob == 0 the blob carries NO table section (off_table = 0): the image is
+     * ~K x smaller on the wire (one RCCL broadcast of 1 GB instead of 35 GB for config 4) and
+     * acx_image_upload/adopt build the table in HBM with k_build_rows_* (SURVEY §8f N2). */
+    uint64_t off_edge_off;   /* uint32 [n_states + 1]   CSR offsets of the trie edges of s   */
+    uint64_t off_edge_cls;   /* uint8  [n_edges]        class of the edge label              */
+    uint64_t off_edge_dst;   /* uint32 [n_edges]        child state                          */
+    uint64_t off_tflags;     /* uint32 [n_states]       per-target bits of an entry (EOW, FAILEOW, CNT) */
+    uint64_t off_lvl_first;  /* uint32 [n_levels + 1]   first state id of each depth         */
+    uint32_t n_levels;       /* max depth + 1                                                */
+    uint32_t n_edges;
+    uint32_t table_in_blob;  /* 1: `table` section present; 0: build it on the device        */
+    uint32_t reserved1;
+    uint8_t  reserved[ACX_BLOB_HEADER_BYTES - 224];
 } acx_blob_header;
 
 #endif

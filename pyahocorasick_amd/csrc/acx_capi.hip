@@ -12,6 +12,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <new>
+#include <vector>
 
 // ------------------------------------------------------------------------------------
 // errors
@@ -78,11 +79,13 @@ struct acx_image {
     const int32_t* first_val = nullptr;
     const uint32_t* itop_lds = nullptr;     // nullptr when the image has no implicit top
     const uint32_t* itop_entry = nullptr;
+    uint32_t* built_table = nullptr;        // table built in HBM (blob without a table section); owned
 };
 
-static void image_resolve(acx_image* img) {
+// resolve section pointers; when the blob carries no table, build it in HBM from the sparse
+// form (acx_build.hip).  lvl_host = host copy of the level boundaries, or nullptr to fetch it.
+static int image_resolve(acx_image* img, const uint32_t* lvl_host) {
     img->cls = img->dev + img->h.off_cls;
-    img->table = (const uint32_t*)(img->dev + img->h.off_table);
     img->out_off = (const uint32_t*)(img->dev + img->h.off_out_off);
     img->out_val = (const int32_t*)(img->dev + img->h.off_out_val);
     img->first_val = (const int32_t*)(img->dev + img->h.off_first_val);
@@ -90,6 +93,25 @@ static void image_resolve(acx_image* img) {
         img->itop_lds = (const uint32_t*)(img->dev + img->h.off_itop_lds);
         img->itop_entry = (const uint32_t*)(img->dev + img->h.off_itop_entry);
     }
+    if (img->h.table_in_blob) {
+        img->table = (const uint32_t*)(img->dev + img->h.off_table);
+        return ACX_OK;
+    }
+    const size_t tbytes = (size_t)img->h.n_states * img->h.n_classes * 4;
+    HIP_TRY(hipMalloc((void**)&img->built_table, tbytes));
+    std::vector<uint32_t> lvl;
+    if (!lvl_host) {
+        lvl.resize((size_t)img->h.n_levels + 1);
+        HIP_TRY(hipMemcpy(lvl.data(), img->dev + img->h.off_lvl_first, lvl.size() * 4, hipMemcpyDeviceToHost));
+        lvl_host = lvl.data();
+    }
+    HIP_TRY(acx_launch_build_table(img->built_table, (const int32_t*)(img->dev + img->h.off_fail),
+                                   (const uint32_t*)(img->dev + img->h.off_edge_off), img->dev + img->h.off_edge_cls,
+                                   (const uint32_t*)(img->dev + img->h.off_edge_dst), (const uint32_t*)(img->dev + img->h.off_tflags),
+                                   lvl_host, img->h.n_levels, img->h.n_classes, img->h.state_bits, nullptr));
+    HIP_TRY(hipDeviceSynchronize());
+    img->table = img->built_table;
+    return ACX_OK;
 }
 
 extern "C" int acx_image_upload(const void* blob, size_t nbytes, acx_image_t** out) {
@@ -110,7 +132,8 @@ extern "C" int acx_image_upload(const void* blob, size_t nbytes, acx_image_t** o
         delete img;
         return acx_fail(e == hipErrorOutOfMemory ? ACX_E_NOMEM : ACX_E_HIP, "acx_image_upload: %s", hipGetErrorString(e));
     }
-    image_resolve(img);
+    rc = image_resolve(img, (const uint32_t*)((const uint8_t*)blob + h.off_lvl_first));
+    if (rc) { acx_image_free(img); return rc; }
     *out = img;
     return ACX_OK;
 }
@@ -125,7 +148,8 @@ extern "C" int acx_image_adopt(void* dev_blob, size_t nbytes, const void* host_h
     if (!img) return acx_fail(ACX_E_NOMEM, "acx_image_adopt: out of memory");
     img->h = h; img->nbytes = nbytes; img->owns = false; img->dev = (uint8_t*)dev_blob;
     (void)hipGetDevice(&img->device);
-    image_resolve(img);
+    rc = image_resolve(img, nullptr);
+    if (rc) { acx_image_free(img); return rc; }
     *out = img;
     return ACX_OK;
 }
@@ -133,12 +157,14 @@ extern "C" int acx_image_adopt(void* dev_blob, size_t nbytes, const void* host_h
 extern "C" void acx_image_free(acx_image_t* img) {
     if (!img) return;
     if (img->owns && img->dev) (void)hipFree(img->dev);
+    if (img->built_table) (void)hipFree(img->built_table);
     delete img;
 }
 extern "C" int64_t acx_image_num_states(const acx_image_t* img) { return img ? img->h.n_states : 0; }
 extern "C" int64_t acx_image_num_classes(const acx_image_t* img) { return img ? img->h.n_classes : 0; }
 extern "C" size_t  acx_image_nbytes(const acx_image_t* img) { return img ? img->nbytes : 0; }
 extern "C" void*   acx_image_dev_ptr(const acx_image_t* img) { return img ? img->dev : nullptr; }
+extern "C" const void* acx_image_table_dev_ptr(const acx_image_t* img) { return img ? img->table : nullptr; }
 extern "C" int     acx_image_itop_depth(const acx_image_t* img) { return (img && img->itop_lds) ? (int)img->h.itop_depth : 0; }
 
 // ------------------------------------------------------------------------------------

@@ -91,5 +91,9 @@ hipError_t acx_launch_walk_itop(const acx_walk_args& a, const acx_chunk_desc* ck
 hipError_t acx_launch_hay_offsets(const int64_t* ck_first, const int64_t* ck_match_off, int64_t n_hay,
                                   int64_t* match_off, hipStream_t s);
 int64_t acx_scan_num_partials(int64_t n);
+// build the dense transition table in HBM from the sparse form (acx_build.hip)
+hipError_t acx_launch_build_table(uint32_t* table, const int32_t* fail, const uint32_t* edge_off, const uint8_t* edge_cls,
+                                  const uint32_t* edge_dst, const uint32_t* tflags, const uint32_t* lvl_first_host,
+                                  uint32_t n_levels, uint32_t K, uint32_t state_bits, hipStream_t s);
 
 #endif

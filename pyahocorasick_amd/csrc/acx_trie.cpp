@@ -386,9 +386,25 @@ int acx_flatten(const acx_trie_t* t, void** blob_out, size_t* nbytes_out) {
     // 2. layout
     acx_blob_header h;
     memset(&h, 0, sizeof h);
+    // Where is the dense table built?  On the host (it is then part of the blob) or on the device
+    // from the sparse edge lists (the blob is ~K x smaller; acx_image_upload/adopt run the build
+    // kernels).  ACX_FLATTEN_TABLE=host|device overrides; default: device once it exceeds 64 MiB.
+    const char* tbl_env = getenv("ACX_FLATTEN_TABLE");
+    bool table_in_blob = table_entries * 4 < ((size_t)64 << 20);
+    if (tbl_env && !strcmp(tbl_env, "host")) table_in_blob = true;
+    if (tbl_env && !strcmp(tbl_env, "device")) table_in_blob = false;
+    uint32_t n_levels = 0;
+    for (size_t i = 0; i < n; i++) if ((uint32_t)adepth[order[i]] + 1 > n_levels) n_levels = (uint32_t)adepth[order[i]] + 1;
+    const size_t n_edges = n - 1;
+
     size_t off = ACX_BLOB_HEADER_BYTES;
     h.off_cls = off;        off = align_up(off + 256);
-    h.off_table = off;      off = align_up(off + table_entries * 4);
+    if (table_in_blob) { h.off_table = off; off = align_up(off + table_entries * 4); }
+    h.off_edge_off = off;   off = align_up(off + (n + 1) * 4);
+    h.off_edge_cls = off;   off = align_up(off + n_edges + 1);
+    h.off_edge_dst = off;   off = align_up(off + n_edges * 4 + 4);
+    h.off_tflags = off;     off = align_up(off + n * 4);
+    h.off_lvl_first = off;  off = align_up(off + ((size_t)n_levels + 1) * 4);
     h.off_fail = off;       off = align_up(off + n * 4);
     h.off_node_val = off;   off = align_up(off + n * 4);
     h.off_node_flags = off; off = align_up(off + n);
@@ -446,15 +462,39 @@ int acx_flatten(const acx_trie_t* t, void** blob_out, size_t* nbytes_out) {
 
     // 4. dense fail-resolved rows: row(s) = row(fail(s)) with EDGE cleared, then own edges.
     //    row(root): every class loops to the root except its own edges.
-    for (size_t i = 0; i < n; i++) {
-        uint32_t* row = table + i * K;
-        if (i > 0) {
-            const uint32_t* frow = table + (size_t)fail[i] * K;
-            for (uint32_t c = 0; c < K; c++) row[c] = frow[c] & ~ACX_ENTRY_EDGE(SB);
+    //    The sparse form (edge CSR + per-target bits + level boundaries) is always written; the
+    //    dense rows only when the table travels inside the blob.
+    {
+        uint32_t* edge_off = (uint32_t*)(blob + h.off_edge_off);
+        uint8_t*  edge_cls = blob + h.off_edge_cls;
+        uint32_t* edge_dst = (uint32_t*)(blob + h.off_edge_dst);
+        uint32_t* tfl      = (uint32_t*)(blob + h.off_tflags);
+        uint32_t* lvl      = (uint32_t*)(blob + h.off_lvl_first);
+        uint32_t ne = 0;
+        for (size_t i = 0; i < n; i++) {
+            edge_off[i] = ne;
+            tfl[i] = tflags[i];
+            for (int32_t ch = t->nodes[order[i]].first_child; ch >= 0; ch = t->nodes[ch].next_sibling) {
+                edge_cls[ne] = cls[t->nodes[ch].letter];
+                edge_dst[ne] = (uint32_t)id[ch];
+                ne++;
+            }
         }
-        for (int32_t ch = t->nodes[order[i]].first_child; ch >= 0; ch = t->nodes[ch].next_sibling) {
-            const uint32_t tid = (uint32_t)id[ch];
-            row[cls[t->nodes[ch].letter]] = tid | tflags[tid] | ACX_ENTRY_EDGE(SB);
+        edge_off[n] = ne;
+        for (uint32_t d = 0; d <= n_levels; d++) lvl[d] = (uint32_t)n;
+        for (size_t i = n; i-- > 0;) lvl[adepth[order[i]]] = (uint32_t)i;      // depths are non-decreasing in id order
+    }
+    if (table_in_blob) {
+        for (size_t i = 0; i < n; i++) {
+            uint32_t* row = table + i * K;
+            if (i > 0) {
+                const uint32_t* frow = table + (size_t)fail[i] * K;
+                for (uint32_t c = 0; c < K; c++) row[c] = frow[c] & ~ACX_ENTRY_EDGE(SB);
+            }
+            for (int32_t ch = t->nodes[order[i]].first_child; ch >= 0; ch = t->nodes[ch].next_sibling) {
+                const uint32_t tid = (uint32_t)id[ch];
+                row[cls[t->nodes[ch].letter]] = tid | tflags[tid] | ACX_ENTRY_EDGE(SB);
+            }
         }
     }
 
@@ -503,6 +543,7 @@ int acx_flatten(const acx_trie_t* t, void** blob_out, size_t* nbytes_out) {
     h.max_out_count = max_cnt;
     h.has_escape = max_cnt >= ESC ? 1 : 0;
     h.state_bits = SB;
+    h.n_levels = n_levels; h.n_edges = (uint32_t)n_edges; h.table_in_blob = table_in_blob ? 1 : 0;
     h.n_out = n_out;
     h.trie_version = (uint64_t)t->version;
     h.fnv1a64 = acx_fnv1a64(blob + ACX_BLOB_HEADER_BYTES, total - ACX_BLOB_HEADER_BYTES);
@@ -527,7 +568,10 @@ int acx_blob_check_header(const acx_blob_header* h, size_t nbytes) {
         return acx_fail(ACX_E_FORMAT, "image: bad n_states/n_classes");
     const uint64_t n = h->n_states, K = h->n_classes;
     struct { uint64_t off, len; } sec[] = {
-        {h->off_cls, 256}, {h->off_table, n * K * 4}, {h->off_fail, n * 4}, {h->off_node_val, n * 4},
+        {h->off_cls, 256}, {h->table_in_blob ? h->off_table : (uint64_t)ACX_BLOB_ALIGN, h->table_in_blob ? n * K * 4 : 0},
+        {h->off_edge_off, (n + 1) * 4}, {h->off_edge_cls, h->n_edges}, {h->off_edge_dst, (uint64_t)h->n_edges * 4},
+        {h->off_tflags, n * 4}, {h->off_lvl_first, ((uint64_t)h->n_levels + 1) * 4},
+        {h->off_fail, n * 4}, {h->off_node_val, n * 4},
         {h->off_node_flags, n}, {h->off_out_off, (n + 1) * 4}, {h->off_out_val, h->n_out * 4},
         {h->off_first_val, n * 4},
         {h->itop_depth ? h->off_itop_lds : (uint64_t)ACX_BLOB_ALIGN, h->itop_depth ? h->itop_lds_bytes : 0},
@@ -552,10 +596,26 @@ int acx_blob_validate(const void* blob, size_t nbytes) {
     if (acx_fnv1a64(b + ACX_BLOB_HEADER_BYTES, nbytes - ACX_BLOB_HEADER_BYTES) != h.fnv1a64)
         return acx_fail(ACX_E_FORMAT, "image: checksum mismatch");
     // structural checks: every entry targets a valid state; CSR is monotone and ends at n_out
-    const uint32_t* table = (const uint32_t*)(b + h.off_table);
-    const uint64_t ne = (uint64_t)h.n_states * h.n_classes;
-    for (uint64_t i = 0; i < ne; i++)
-        if ((table[i] & ACX_ENTRY_STATE_MASK(h.state_bits)) >= h.n_states) return acx_fail(ACX_E_FORMAT, "image: entry %llu targets a state out of range", (unsigned long long)i);
+    if (h.table_in_blob) {
+        const uint32_t* table = (const uint32_t*)(b + h.off_table);
+        const uint64_t ne = (uint64_t)h.n_states * h.n_classes;
+        for (uint64_t i = 0; i < ne; i++)
+            if ((table[i] & ACX_ENTRY_STATE_MASK(h.state_bits)) >= h.n_states) return acx_fail(ACX_E_FORMAT, "image: entry %llu targets a state out of range", (unsigned long long)i);
+    }
+    {   // sparse form: edges target valid, deeper states; fail links point to shallower ones
+        const uint32_t* eo = (const uint32_t*)(b + h.off_edge_off);
+        const uint32_t* ed = (const uint32_t*)(b + h.off_edge_dst);
+        const uint8_t* ec = b + h.off_edge_cls;
+        const int32_t* fl = (const int32_t*)(b + h.off_fail);
+        if (eo[h.n_states] != h.n_edges) return acx_fail(ACX_E_FORMAT, "image: edge CSR end does not match n_edges");
+        for (uint32_t s2 = 0; s2 < h.n_states; s2++) {
+            if (eo[s2] > eo[s2 + 1]) return acx_fail(ACX_E_FORMAT, "image: edge CSR not monotone at state %u", s2);
+            for (uint32_t k = eo[s2]; k < eo[s2 + 1]; k++)
+                if (ed[k] <= s2 || ed[k] >= h.n_states || ec[k] >= h.n_classes)
+                    return acx_fail(ACX_E_FORMAT, "image: bad edge %u of state %u", k, s2);
+            if (s2 > 0 && (fl[s2] < 0 || (uint32_t)fl[s2] >= s2)) return acx_fail(ACX_E_FORMAT, "image: fail link of state %u is not shallower", s2);
+        }
+    }
     const uint32_t* oo = (const uint32_t*)(b + h.off_out_off);
     for (uint32_t s = 0; s < h.n_states; s++)
         if (oo[s] > oo[s + 1]) return acx_fail(ACX_E_FORMAT, "image: CSR offsets not monotone at state %u", s);

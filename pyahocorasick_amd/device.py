@@ -95,6 +95,13 @@ class Image:
     def itop_depth(self):
         return lib().acx_image_itop_depth(self.handle)
 
+    def download_table(self):
+        """the dense transition table the scans read, as uint32[n_states, n_classes] (tests/tools)"""
+        n, K = self.num_states, self.num_classes
+        out = np.empty((n, K), dtype=np.uint32)
+        check(lib().acx_memcpy_d2h(out.ctypes.data, C.c_void_p(lib().acx_image_table_dev_ptr(self.handle)), out.nbytes))
+        return out
+
     def free(self):
         if self.handle:
             lib().acx_image_free(self.handle)

@@ -403,6 +403,42 @@ def test_implicit_top_kernel_equals_plain_kernel():
             assert np.array_equal(fin, outs[0][3])
 
 
+def test_device_built_table_equals_host_built(monkeypatch):
+    """blobs without a table section (ACX_FLATTEN_TABLE=device): the table is built in HBM level by
+    level from the sparse form and must equal the host-built one bit for bit; scans agree too"""
+    import struct
+    rng = np.random.default_rng(44)
+    for alpha, wide in ((b"ACGT", False), (bytes(range(256)), False), (b"abcdefghij ", True)):
+        a = np.frombuffer(alpha, dtype=np.uint8)
+        keys = list({bytes(rng.choice(a, size=int(n)).tobytes()) for n in rng.integers(1, 30, size=3000)})
+        if wide:
+            monkeypatch.setenv("ACX_FORCE_WIDE_LAYOUT", "1")
+        A, O = build_pair(keys)
+        monkeypatch.setenv("ACX_FLATTEN_TABLE", "host")
+        blob_h = A.flat_image_bytes()
+        monkeypatch.setenv("ACX_FLATTEN_TABLE", "device")
+        blob_d = A.flat_image_bytes()
+        monkeypatch.delenv("ACX_FLATTEN_TABLE")
+        monkeypatch.delenv("ACX_FORCE_WIDE_LAYOUT", raising=False)
+        n, K = struct.unpack_from("<II", blob_h, 24)
+        off_table, = struct.unpack_from("<Q", blob_h, 72)
+        assert struct.unpack_from("<I", blob_d, 216)[0] == 0 and struct.unpack_from("<I", blob_h, 216)[0] == 1
+        assert len(blob_d) < len(blob_h) - n * K * 4 + 4096
+        host_table = np.frombuffer(blob_h, dtype=np.uint32, count=n * K, offset=off_table).reshape(n, K)
+        img_h, img_d = Image.from_blob(blob_h), Image.from_blob(blob_d)
+        assert np.array_equal(img_h.download_table(), host_table)
+        assert np.array_equal(img_d.download_table(), host_table)
+        reads = np.ascontiguousarray(a[rng.integers(0, len(a), size=(500, 120))])
+        off = np.arange(501, dtype=np.int64) * 120
+        mo, oe, ov = O.batch(reads.tobytes(), off, 0)
+        d_hay = DeviceBuffer.from_numpy(reads.reshape(-1), pad=64)
+        for img in (img_h, img_d):
+            sc = Scanner(img)
+            sc.scan(d_hay, reads.size, 500, stride=120)
+            moff, e, v, _ = sc.fetch()
+            assert np.array_equal(moff, mo) and np.array_equal(e, oe) and np.array_equal(v, ov)
+
+
 # ------------------------------------------------------------------ configs 3 and 4 (scaled)
 def test_config3_text_corpus_scaled():
     """BASELINE.json config 3 shape, scaled: multi-word lowercase keys, ONE long text corpus
