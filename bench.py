@@ -91,6 +91,11 @@ def cpu_baseline(keys, reads, n_sample, mode):
 
 def main():
     args = parse()
+    # stdout must carry exactly ONE JSON line: RCCL prints a version banner on fd 1 when its
+    # communicator comes up, so everything until the final print goes to stderr instead.
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
     import torch
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -102,7 +107,9 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
-    if world > 1:
+    # under torch.distributed.run (RANK/MASTER_ADDR set) the process group is created even for one
+    # rank, so the N = 1 line and the N > 1 lines go through the same code (RCCL broadcast, barriers)
+    if world > 1 or ("RANK" in os.environ and "MASTER_ADDR" in os.environ):
         import torch.distributed as dist
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         dist.init_process_group("nccl", device_id=dev)
@@ -240,7 +247,7 @@ def main():
         }
         if world == 1 and args.cpu_sample_reads > 0:
             out["cpu_baseline"] = cpu_baseline(keys, reads, min(args.cpu_sample_reads, n), args.mode)
-        print(json.dumps(out), flush=True)
+        os.write(json_fd, (json.dumps(out) + "\n").encode())
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

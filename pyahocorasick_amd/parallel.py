@@ -40,7 +40,7 @@ def broadcast_blob(blob, src=0, device=None):
     receivers can allocate)."""
     import torch
     import torch.distributed as dist
-    distributed = dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+    distributed = dist.is_available() and dist.is_initialized()
     device = device if device is not None else torch.device("cpu")
     if not distributed:
         t = torch.frombuffer(bytearray(blob), dtype=torch.uint8)
