@@ -86,7 +86,7 @@ int64_t flat_iter_itop(const void* blob, const uint8_t* hay, int64_t len, int64_
     const uint32_t b = lds[0], D = lds[1], LD = lds[2], has_other = lds[5], maskD = lds[7];
     const uint32_t* E = lds + lds[8];
     const uint32_t* H = lds + lds[9];
-    const uint32_t w0 = lds[10];
+    const uint32_t w0 = lds[10], cs = lds[11], hmin = lds[12], h_first = lds[13];
     const uint16_t* rank16 = (const uint16_t*)(lds + lds[3]);
     const uint32_t* rank32 = lds + lds[4];
     const uint32_t bD = b * D;
@@ -114,9 +114,14 @@ int64_t flat_iter_itop(const void* blob, const uint8_t* hay, int64_t len, int64_
         if (resolve) {
             /* largest candidate shift whose k-gram is a node; shift 0 is the root (bit 1, always set) */
             uint32_t c = cand, x;
-            for (;;) { x = XIDX(c); if (BIT(E, x)) break; c -= b; }
+            for (;;) {
+                x = XIDX(c);
+                if (c <= cs) { if (!BIT(E, x)) return -5; break; }        /* complete levels: known hit, no probe */
+                if (BIT(E, x)) break;
+                c -= b;
+            }
             sh = c;
-            if (resolve == 2 && c > 0 && BIT(H, x)) ev = ient[x];
+            if (resolve == 2 && c >= hmin && ((H[(x >> 5) - h_first] >> (x & 31)) & 1u)) ev = ient[x];
             if (c == bD) {                                /* hand over to the explicit rows */
                 const uint32_t w = x >> 5;
                 s = LD + rank32[(w - w0) >> 6] + rank16[w - w0] + (uint32_t)__builtin_popcount(E[w] & ((1u << (x & 31)) - 1u));

@@ -335,7 +335,7 @@ struct ItopCtx {
     const uint32_t* ient;       // global: packed entry of implicit node x
     const uint8_t*  table_bytes;
     const uint32_t* out_off;
-    uint32_t row_bytes, b, bD, LD, has_other, maskD, w0;
+    uint32_t row_bytes, b, bD, LD, has_other, maskD, w0, cs, hmin, h_first;
 };
 
 struct ItopLane {
@@ -352,14 +352,19 @@ __device__ __forceinline__ uint32_t itop_x(uint32_t hist, uint32_t sh) {
 }
 
 // largest shift <= cand (in steps of b) whose k-gram is a trie node.  The three most likely
-// candidates are probed with independent LDS reads; shift 0 (the root) always hits.
+// candidates are probed with independent LDS reads; shifts up to C.cs belong to COMPLETE levels
+// (every k-gram exists: e.g. depth <= 7 for 100k DNA keys) and hit without a read; shift 0
+// (the root) always hits.
 __device__ __forceinline__ void itop_resolve(uint32_t hist, uint32_t cand, const ItopCtx& C,
                                              uint32_t& c, uint32_t& x, uint32_t& word) {
     const uint32_t c0 = cand;
     const uint32_t c1 = c0 >= C.b ? c0 - C.b : 0u;
     const uint32_t c2 = c1 >= C.b ? c1 - C.b : 0u;
     const uint32_t x0 = itop_x(hist, c0), x1 = itop_x(hist, c1), x2 = itop_x(hist, c2);
-    const uint32_t w0 = C.E[x0 >> 5], w1 = C.E[x1 >> 5], w2 = C.E[x2 >> 5];
+    uint32_t w0 = 0xFFFFFFFFu, w1 = 0xFFFFFFFFu, w2 = 0xFFFFFFFFu;
+    if (c0 > C.cs) w0 = C.E[x0 >> 5];
+    if (c1 > C.cs) w1 = C.E[x1 >> 5];
+    if (c2 > C.cs) w2 = C.E[x2 >> 5];
     const bool h0 = (w0 >> (x0 & 31)) & 1u, h1 = (w1 >> (x1 & 31)) & 1u, h2 = (w2 >> (x2 & 31)) & 1u;
     c = h0 ? c0 : (h1 ? c1 : c2);
     x = h0 ? x0 : (h1 ? x1 : x2);
@@ -368,7 +373,7 @@ __device__ __forceinline__ void itop_resolve(uint32_t hist, uint32_t cand, const
         do {
             c = c >= C.b ? c - C.b : 0u;
             x = itop_x(hist, c);
-            word = C.E[x >> 5];
+            word = c > C.cs ? C.E[x >> 5] : 0xFFFFFFFFu;
         } while (!((word >> (x & 31)) & 1u));
     }
 }
@@ -393,8 +398,8 @@ __device__ __forceinline__ void itop_step(uint32_t c4, uint32_t idx, bool active
     if (go && !expl) {                                                                  // B
         uint32_t c, x, word;
         itop_resolve(hist, L.sh + C.b, C, c, x, word);
-        if ((!GUARDED || emit) && c > 0) {
-            if ((C.H[x >> 5] >> (x & 31)) & 1u) e = C.ient[x];       // the node has outputs: fetch its entry
+        if ((!GUARDED || emit) && c >= C.hmin) {                     // no node above level hmin has outputs
+            if ((C.H[(x >> 5) - C.h_first] >> (x & 31)) & 1u) e = C.ient[x];   // fetch its packed entry
         }
         if (c == C.bD) {                                             // hand over to the explicit rows
             const uint32_t w = (x >> 5) - C.w0;
@@ -448,6 +453,7 @@ __global__ void __launch_bounds__(ACX_ITOP_BLOCK) k_walk_itop(const acx_walk_arg
     C.rank16 = (const uint16_t*)(s_mem + s_mem[3]);
     C.rank32 = s_mem + s_mem[4];
     C.E = s_mem + s_mem[8]; C.H = s_mem + s_mem[9]; C.w0 = s_mem[10];
+    C.cs = s_mem[11]; C.hmin = s_mem[12]; C.h_first = s_mem[13];
 
     const int lane = threadIdx.x & (ACX_WAVE - 1);
     const int64_t n_items = ck ? *n_chunks_dev : a.n_hay;

@@ -323,8 +323,15 @@ int acx_flatten(const acx_trie_t* t, void** blob_out, size_t* nbytes_out) {
     // one bitmap addresses every level: node (d, code) lives at bit (1 << b*d) | code
     auto itop_bm_words = [&](uint32_t D) -> size_t { return (size_t)((2ull << (itop_b * D)) / 32); };   // needs b*D >= 5
     auto itop_lvlD_words = [&](uint32_t D) -> size_t { return (size_t)((1ull << (itop_b * D)) / 32); };
+    uint32_t hmin_level = 0xFFFFu;    // shallowest level that has a node with outputs = the shortest key
+    // H covers sentinel words from the first word of level hmin on (no outputs above it)
+    auto itop_h_words = [&](uint32_t D, uint32_t hmin) -> size_t {
+        if (hmin > D) return 0;
+        return itop_bm_words(D) - (size_t)((1ull << (itop_b * hmin)) >> 5);
+    };
     auto itop_cost = [&](uint32_t D) -> size_t {      // LDS image size in words: header, E, H, rank16, rank32
-        return ACX_ITOP_HDR_WORDS + 2 * itop_bm_words(D) + (itop_lvlD_words(D) + 1) / 2 + itop_lvlD_words(D) / 64 + 1;
+        return ACX_ITOP_HDR_WORDS + itop_bm_words(D) + itop_h_words(D, hmin_level) + (itop_lvlD_words(D) + 1) / 2 +
+               itop_lvlD_words(D) / 64 + 1;
     };
     try {
         order = t->bfs;
@@ -335,6 +342,8 @@ int acx_flatten(const acx_trie_t* t, void** blob_out, size_t* nbytes_out) {
                 adepth[ch] = adepth[order[i]] + 1;
                 if (adepth[ch] > max_depth) max_depth = adepth[ch];
             }
+        for (size_t i = 1; i < n; i++)
+            if (t->nodes[order[i]].eow && (uint32_t)adepth[order[i]] < hmin_level) hmin_level = (uint32_t)adepth[order[i]];
         const size_t budget_words = (size_t)150 * 1024 / 4;          // of the CU's 160 KiB of LDS
         const char* no_itop = getenv("ACX_NO_ITOP");
         if (SB == ACX_STATE_BITS_NARROW && !(no_itop && no_itop[0] == '1')) {
@@ -504,19 +513,30 @@ int acx_flatten(const acx_trie_t* t, void** blob_out, size_t* nbytes_out) {
         uint32_t* lds = (uint32_t*)(blob + h.off_itop_lds);
         uint32_t* ient = (uint32_t*)(blob + h.off_itop_entry);
         const size_t bmw = itop_bm_words(itop_D);
+        const size_t hw = itop_h_words(itop_D, hmin_level);
+        const size_t h_first = hw ? (size_t)((1ull << (itop_b * hmin_level)) >> 5) : 0;   // sentinel word where H starts
         const size_t eb = ACX_ITOP_HDR_WORDS, hb = eb + bmw;
         lds[eb] |= 1u << 1;                                   // the root: (d = 0, code = 0) -> bit 1
+        uint32_t complete = 0;                                // levels 1..complete hold every possible k-gram
+        {
+            const uint64_t sigma = has_other ? K - 1 : 256;
+            uint64_t full = 1;
+            for (uint32_t d = 1; d <= itop_D; d++) {
+                full *= sigma;
+                if ((uint64_t)(lvl_first[d + 1] - lvl_first[d]) == full && complete == d - 1) complete = d;
+            }
+        }
         for (uint32_t d = 1; d <= itop_D; d++) {
             for (uint32_t i = lvl_first[d]; i < lvl_first[d + 1]; i++) {
                 const uint32_t x = (1u << (itop_b * d)) | acode[order[i]];     // sentinel index
                 lds[eb + (x >> 5)] |= 1u << (x & 31);
-                if (out_cnt[i]) lds[hb + (x >> 5)] |= 1u << (x & 31);
+                if (out_cnt[i]) lds[hb + (x >> 5) - h_first] |= 1u << (x & 31);
                 ient[x] = i | tflags[i];
             }
         }
         // rank of level D: ones before each word of [2^(bD), 2^(bD+1)), 64-word superblocks
         const size_t wD = itop_lvlD_words(itop_D), w0 = wD;    // level D starts at word 2^(bD)/32 = wD
-        const size_t r16 = hb + bmw, r32 = r16 + (wD + 1) / 2;
+        const size_t r16 = hb + hw, r32 = r16 + (wD + 1) / 2;
         uint16_t* rank16 = (uint16_t*)(lds + r16);
         uint32_t* rank32 = lds + r32;
         uint32_t run = 0, in_sb = 0;
@@ -529,6 +549,9 @@ int acx_flatten(const acx_trie_t* t, void** blob_out, size_t* nbytes_out) {
         lds[0] = itop_b; lds[1] = itop_D; lds[2] = lvl_first[itop_D]; lds[3] = (uint32_t)r16; lds[4] = (uint32_t)r32;
         lds[5] = has_other ? 1u : 0u; lds[6] = (uint32_t)itop_lds_words; lds[7] = (uint32_t)((1ull << (itop_b * itop_D)) - 1);
         lds[8] = (uint32_t)eb; lds[9] = (uint32_t)hb; lds[10] = (uint32_t)w0;
+        lds[11] = itop_b * complete;                           // shifts up to this one always hit: no probe needed
+        lds[12] = hw ? itop_b * hmin_level : 0xFFFFu;          // no node shallower than this has outputs
+        lds[13] = (uint32_t)h_first;
         h.itop_depth = itop_D; h.itop_bits = itop_b; h.itop_lds_bytes = (uint32_t)(itop_lds_words * 4);
     }
 
