@@ -276,6 +276,15 @@ class Automaton:
         finally:
             lib().acx_blob_free(blob)
 
+    def save_image(self, path):
+        """write the flat image to a file; pyahocorasick_amd.device.Image.from_file(path) scans with it
+        without rebuilding a trie.  Integer values only (STORE_INTS / STORE_LENGTH): object values of a
+        STORE_ANY automaton are ids into this process's value list and do not travel."""
+        if self._store == STORE_ANY:
+            raise ValueError("save_image() needs STORE_INTS or STORE_LENGTH: object values cannot be stored in the image")
+        with open(path, "wb") as f:
+            f.write(self.flat_image_bytes())
+
     # ---- batch scan (NEW: the reference scans one haystack per iterator) ---------------
     def scan_batch(self, data, offsets, mode=ACX_SCAN_ALL, init_state=None, index_base=None):
         """Scan haystacks data[offsets[k]:offsets[k+1]] on the GPU; returns a BatchResult.

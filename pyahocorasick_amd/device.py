@@ -73,6 +73,18 @@ class Image:
         return cls(h)
 
     @classmethod
+    def from_file(cls, path):
+        """load a flat image written by Automaton.save_image() (the blob is relocatable: the file
+        IS the image, include/acx_blob.h) — SURVEY §8f N3: no pointer trie is rebuilt"""
+        with open(path, "rb") as f:
+            data = f.read()
+        buf = (C.c_char * len(data)).from_buffer_copy(data)
+        check(lib().acx_blob_validate(buf, len(data)))
+        h = C.c_void_p()
+        check(lib().acx_image_upload(buf, len(data), C.byref(h)))
+        return cls(h)
+
+    @classmethod
     def adopt(cls, dev_ptr, nbytes, host_header, keepalive=None):
         h = C.c_void_p()
         hdr = (C.c_char * ACX_BLOB_HEADER_BYTES).from_buffer_copy(bytes(host_header[:ACX_BLOB_HEADER_BYTES]))

@@ -152,3 +152,25 @@ def test_flat_image_header_and_validation():
     import struct
     n_states, n_classes = struct.unpack_from("<II", blob, 24)
     assert n_classes == 5 and n_states == 8
+
+
+def test_save_image_round_trip(tmp_path):
+    """the flat image is relocatable: written to a file and read back it validates (checksum,
+    structure) and is byte-identical; STORE_ANY is refused (object values do not travel)"""
+    import ctypes as C
+    from pyahocorasick_amd._lib import lib, check
+    A = acx.Automaton(acx.STORE_INTS)
+    for i, k in enumerate([b"he", b"her", b"hers", b"she", b"\xff\x80"]):
+        A.add_word(k, 100 + i)
+    A.make_automaton()
+    p = tmp_path / "she.acx"
+    A.save_image(str(p))
+    data = p.read_bytes()
+    assert data == A.flat_image_bytes()
+    buf = C.create_string_buffer(data, len(data))
+    check(lib().acx_blob_validate(buf, len(data)))
+    B = acx.Automaton()
+    B.add_word(b"x", object())
+    B.make_automaton()
+    with pytest.raises(ValueError):
+        B.save_image(str(tmp_path / "no.acx"))
