@@ -45,14 +45,22 @@
  * States deeper than D keep their explicit rows.  Levels 1..D are numbered in code order.
  *
  * All levels share ONE index space: node (d, code) is bit  x = (1 << b*d) | code  ("sentinel
- * bit" above the code; the root is x = 1), so a probe needs no per-level table: three VALU ops
- * from the rolling history and one LDS read.  E, H and itop_entry are all indexed by x.
+ * bit" above the code; the root is x = 1).  E, H and itop_entry are all indexed by x.
+ *
+ * The steady-state step does not even probe E: ND ("next depth") is a 2-bit table indexed by
+ * the rolling history of the last D symbols that says how deep the longest k-gram node ending
+ * here is — 0: depth D, 1: D-1, 2: D-2, 3: shallower (slow path: probe E level by level).  It
+ * is exact once D symbols have been seen since the last reset (haystack start or a byte that
+ * occurs in no key); before that the slow path runs.  A level-D node is  ND == 0, so the rank
+ * that turns a level-D code into its state id counts zero fields of ND.
  *
  * LDS image (uint32 words): [0]=b [1]=D [2]=first id of level D [3]=rank16 word offset
  * [4]=rank32 word offset [5]=1 if class 0 is "other" [6]=total words [7]=mask(D) = 2^(bD)-1
- * [8]=E word offset [9]=H word offset [10]=first word of level D inside a bitmap (2^(bD)/32);
- * E bitmap (2^(bD+1) bits), H bitmap (same), rank16 (uint16 per level-D word: ones before it
- * inside its 64-word superblock), rank32 (uint32 per superblock: ones before it).  b*D >= 5.
+ * [8]=ND word offset [9]=H word offset [11]=shift up to which levels are complete (every
+ * k-gram exists) [12]=shift of the shallowest level that has outputs [13]=first sentinel word
+ * covered by H;  ND (2^(bD) x 2 bits), H (sentinel-indexed, from word [13] on), rank16 (uint16
+ * per ND word: zero fields before it inside its 64-word superblock), rank32 (uint32 per
+ * superblock).  b*D >= 5.  E lives in global memory (off_itop_ebits), used by the slow path.
  */
 #define ACX_ITOP_MAX_LEVELS   15
 #define ACX_ITOP_HDR_WORDS    16
@@ -119,7 +127,8 @@ typedef struct acx_blob_header {
     uint32_t n_edges;
     uint32_t table_in_blob;  /* 1: `table` section present; 0: build it on the device        */
     uint32_t reserved1;
-    uint8_t  reserved[ACX_BLOB_HEADER_BYTES - 224];
+    uint64_t off_itop_ebits; /* uint32 [2^(bD+1)/32]  existence bitmap E, sentinel-indexed (global; slow path) */
+    uint8_t  reserved[ACX_BLOB_HEADER_BYTES - 232];
 } acx_blob_header;
 
 #endif

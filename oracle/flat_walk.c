@@ -82,28 +82,30 @@ int64_t flat_iter_itop(const void* blob, const uint8_t* hay, int64_t len, int64_
     const uint8_t* bb = (const uint8_t*)blob;
     const uint32_t* lds = (const uint32_t*)(bb + f.h->off_itop_lds);
     const uint32_t* ient = (const uint32_t*)(bb + f.h->off_itop_entry);
+    const uint32_t* E = (const uint32_t*)(bb + f.h->off_itop_ebits);
     const uint32_t K = f.h->n_classes, SB = f.h->state_bits;
     const uint32_t b = lds[0], D = lds[1], LD = lds[2], has_other = lds[5], maskD = lds[7];
-    const uint32_t* E = lds + lds[8];
+    const uint32_t* ND = lds + lds[8];
     const uint32_t* H = lds + lds[9];
-    const uint32_t w0 = lds[10], cs = lds[11], hmin = lds[12], h_first = lds[13];
+    const uint32_t cs = lds[11], hmin = lds[12], h_first = lds[13];
     const uint16_t* rank16 = (const uint16_t*)(lds + lds[3]);
     const uint32_t* rank32 = lds + lds[4];
     const uint32_t bD = b * D;
 #define XIDX(sh) ((hist & ((1u << (sh)) - 1u)) | (1u << (sh)))       /* sentinel index of the last sh/b symbols */
 #define BIT(M, x) (((M)[(x) >> 5] >> ((x) & 31)) & 1u)
     int64_t n = 0;
-    uint32_t hist = 0, sh = 0, s = 0, shadow = 0;   /* sh = b * depth of the implicit state; shadow: cross-check only */
+    uint32_t hist = 0, sh = 0, s = 0, valid = 0, shadow = 0;   /* sh = b * implicit depth; shadow: cross-check only */
     int expl = 0;
     for (int64_t i = 0; i < len; i++) {
         const uint32_t cls = f.cls[hay[i]];
         const uint32_t se = f.table[(size_t)shadow * K + cls];
         shadow = se & ACX_ENTRY_STATE_MASK(SB);
         uint32_t ev = 0;                                  /* entry to report, 0 = none */
-        if (has_other && cls == 0) { sh = 0; expl = 0; hist = 0; if (shadow != 0) return -5; continue; }
+        if (has_other && cls == 0) { sh = 0; expl = 0; hist = 0; valid = 0; if (shadow != 0) return -5; continue; }
         hist = ((hist << b) | (cls - has_other)) & maskD;
-        uint32_t cand;                                    /* first candidate shift for the implicit resolution */
-        int resolve = 0;
+        if (valid < D) valid++;
+        uint32_t cand = 0;
+        int resolve = 0;                                  /* 1: dropped out of the explicit zone, 2: implicit source */
         if (expl) {
             const uint32_t e = f.table[(size_t)s * K + cls];
             const uint32_t t = e & ACX_ENTRY_STATE_MASK(SB);
@@ -112,19 +114,31 @@ int64_t flat_iter_itop(const void* blob, const uint8_t* hay, int64_t len, int64_
             else { expl = 0; cand = bD - b; resolve = 1; }
         } else { cand = sh + b; resolve = 2; }
         if (resolve) {
-            /* largest candidate shift whose k-gram is a node; shift 0 is the root (bit 1, always set) */
-            uint32_t c = cand, x;
-            for (;;) {
+            uint32_t c, x;
+            const uint32_t ndw = ND[hist >> 4];
+            const uint32_t fld = (ndw >> ((hist & 15) * 2)) & 3u;
+            if (valid >= D && fld != 3u) {                /* steady state: the table says how deep */
+                c = bD - b * fld;
+                if (c > cand) return -5;                  /* cannot be deeper than source + 1 (or D-1 after a drop) */
                 x = XIDX(c);
-                if (c <= cs) { if (!BIT(E, x)) return -5; break; }        /* complete levels: known hit, no probe */
-                if (BIT(E, x)) break;
-                c -= b;
+                if (!BIT(E, x)) return -5;
+            } else {                                      /* warm-up after a reset, or a fall of more than two levels */
+                c = (valid >= D) ? (bD >= 3 * b ? bD - 3 * b : 0) : cand;
+                if (c > cand) c = cand;
+                for (;;) {
+                    x = XIDX(c);
+                    if (c <= cs) { if (!BIT(E, x)) return -5; break; }
+                    if (BIT(E, x)) break;
+                    c -= b;
+                }
             }
             sh = c;
             if (resolve == 2 && c >= hmin && ((H[(x >> 5) - h_first] >> (x & 31)) & 1u)) ev = ient[x];
-            if (c == bD) {                                /* hand over to the explicit rows */
-                const uint32_t w = x >> 5;
-                s = LD + rank32[(w - w0) >> 6] + rank16[w - w0] + (uint32_t)__builtin_popcount(E[w] & ((1u << (x & 31)) - 1u));
+            if (c == bD) {                                /* hand over to the explicit rows: id = first + #ND zeros before */
+                if (fld != 0) return -5;
+                const uint32_t wi = hist >> 4;
+                const uint32_t z = ~(ndw | (ndw >> 1)) & 0x55555555u;
+                s = LD + rank32[wi >> 6] + rank16[wi] + (uint32_t)__builtin_popcount(z & ((1u << ((hist & 15) * 2)) - 1u));
                 expl = 1;
                 if ((ient[x] & ACX_ENTRY_STATE_MASK(SB)) != s) return -5;
             }

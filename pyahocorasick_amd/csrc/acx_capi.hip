@@ -79,6 +79,7 @@ struct acx_image {
     const int32_t* first_val = nullptr;
     const uint32_t* itop_lds = nullptr;     // nullptr when the image has no implicit top
     const uint32_t* itop_entry = nullptr;
+    const uint32_t* itop_ebits = nullptr;
     uint32_t* built_table = nullptr;        // table built in HBM (blob without a table section); owned
 };
 
@@ -92,6 +93,7 @@ static int image_resolve(acx_image* img, const uint32_t* lvl_host) {
     if (img->h.itop_depth > 0 && img->h.state_bits == ACX_STATE_BITS_NARROW) {
         img->itop_lds = (const uint32_t*)(img->dev + img->h.off_itop_lds);
         img->itop_entry = (const uint32_t*)(img->dev + img->h.off_itop_entry);
+        img->itop_ebits = (const uint32_t*)(img->dev + img->h.off_itop_ebits);
     }
     if (img->h.table_in_blob) {
         img->table = (const uint32_t*)(img->dev + img->h.off_table);
@@ -311,7 +313,6 @@ extern "C" int acx_scan_batch(acx_image_t* img, const acx_scan_params* p, acx_re
     int64_t* item_match_off = chunked ? r->ck_match_off.p : r->match_off.p;
     // implicit top-of-trie kernel: ACX_SCAN_ALL, narrow image that carries the structures, no carried-in
     // state (an arbitrary shallow state id has no k-gram history).  variant bit 16 turns it off (A/B).
-    const int itop_ilp = ((p->variant >> 17) & 1) ? 2 : 1;      // bit 17: two items per lane (measured: no gain)
     const bool use_itop = p->mode == ACX_SCAN_ALL && img->itop_lds && !p->dev_init_state && !((p->variant >> 16) & 1);
 
     if (r->timed) HIP_TRY(hipEventRecord(r->ev[0], s));
@@ -327,11 +328,11 @@ extern "C" int acx_scan_batch(acx_image_t* img, const acx_scan_params* p, acx_re
         HIP_TRY(acx_launch_scan(r->nck.p, p->n_hay, r->ck_first.p, r->partials.p, s));
         HIP_TRY(acx_launch_chunk_fill(ca, n_items, s));
         if (use_itop) HIP_TRY(acx_launch_walk_itop(wa, r->ck.p, r->ck_first.p + p->n_hay, n_items, img->h.has_escape != 0,
-                                                   img->itop_lds, img->h.itop_lds_bytes / 4, img->itop_entry, itop_ilp, s));
+                                                   img->itop_lds, img->h.itop_lds_bytes / 4, img->itop_entry, img->itop_ebits, s));
         else          HIP_TRY(acx_launch_walk_chunks(wa, r->ck.p, r->ck_first.p + p->n_hay, n_items, img->h.has_escape != 0, s));
     } else if (p->mode == ACX_SCAN_ALL) {
         if (use_itop) HIP_TRY(acx_launch_walk_itop(wa, nullptr, nullptr, p->n_hay, img->h.has_escape != 0,
-                                                   img->itop_lds, img->h.itop_lds_bytes / 4, img->itop_entry, itop_ilp, s));
+                                                   img->itop_lds, img->h.itop_lds_bytes / 4, img->itop_entry, img->itop_ebits, s));
         else          HIP_TRY(acx_launch_walk_all(wa, img->h.has_escape != 0, p->variant, s));
     } else {
         HIP_TRY(acx_launch_walk_long(wa, p->variant, s));

@@ -328,20 +328,22 @@ __global__ void __launch_bounds__(ACX_BLOCK, 8) k_walk_chunks(const acx_walk_arg
 #define ACX_ITOP_EXPL 255u
 
 struct ItopCtx {
-    const uint32_t* E;          // LDS: existence bitmap, all levels, sentinel-indexed
-    const uint32_t* H;          // LDS: has-output bitmap
+    const uint32_t* ND;         // LDS: 2-bit next-depth table indexed by the last D symbols
+    const uint32_t* H;          // LDS: has-output bitmap, sentinel-indexed from word h_first on
     const uint16_t* rank16;     // LDS
     const uint32_t* rank32;     // LDS
+    const uint32_t* Eg;         // global: existence bitmap, sentinel-indexed (slow path only)
     const uint32_t* ient;       // global: packed entry of implicit node x
     const uint8_t*  table_bytes;
     const uint32_t* out_off;
-    uint32_t row_bytes, b, bD, LD, has_other, maskD, w0, cs, hmin, h_first;
+    uint32_t row_bytes, b, D, bD, LD, has_other, maskD, cs, hmin, h_first;
 };
 
 struct ItopLane {
     uint32_t st;     // explicit: raw entry (low 24 bits = state)
     uint32_t sh;     // implicit: b * depth (0 .. b*(D-1)); explicit: ACX_ITOP_EXPL
     uint32_t hist;   // last D symbols, b bits each
+    uint32_t valid;  // symbols seen since the last reset, saturating at D
     uint32_t cnt;
     uint2*   ev;
 };
@@ -351,113 +353,97 @@ __device__ __forceinline__ uint32_t itop_x(uint32_t hist, uint32_t sh) {
     return __builtin_amdgcn_ubfe(hist, 0u, sh) | (1u << sh);
 }
 
-// largest shift <= cand (in steps of b) whose k-gram is a trie node.  The three most likely
-// candidates are probed with independent LDS reads; shifts up to C.cs belong to COMPLETE levels
-// (every k-gram exists: e.g. depth <= 7 for 100k DNA keys) and hit without a read; shift 0
-// (the root) always hits.
-__device__ __forceinline__ void itop_resolve(uint32_t hist, uint32_t cand, const ItopCtx& C,
-                                             uint32_t& c, uint32_t& x, uint32_t& word) {
-    const uint32_t c0 = cand;
-    const uint32_t c1 = c0 >= C.b ? c0 - C.b : 0u;
-    const uint32_t c2 = c1 >= C.b ? c1 - C.b : 0u;
-    const uint32_t x0 = itop_x(hist, c0), x1 = itop_x(hist, c1), x2 = itop_x(hist, c2);
-    uint32_t w0 = 0xFFFFFFFFu, w1 = 0xFFFFFFFFu, w2 = 0xFFFFFFFFu;
-    if (c0 > C.cs) w0 = C.E[x0 >> 5];
-    if (c1 > C.cs) w1 = C.E[x1 >> 5];
-    if (c2 > C.cs) w2 = C.E[x2 >> 5];
-    const bool h0 = (w0 >> (x0 & 31)) & 1u, h1 = (w1 >> (x1 & 31)) & 1u, h2 = (w2 >> (x2 & 31)) & 1u;
-    c = h0 ? c0 : (h1 ? c1 : c2);
-    x = h0 ? x0 : (h1 ? x1 : x2);
-    word = h0 ? w0 : (h1 ? w1 : w2);
-    if (!(h0 || h1 || h2)) {                                         // rare: fell more than two levels
-        do {
-            c = c >= C.b ? c - C.b : 0u;
-            x = itop_x(hist, c);
-            word = c > C.cs ? C.E[x >> 5] : 0xFFFFFFFFu;
-        } while (!((word >> (x & 31)) & 1u));
+// Slow path (first D steps after a reset, or a fall of more than two levels): largest shift
+// <= cand whose k-gram is a node, probing the global E bitmap level by level.  Shifts up to
+// C.cs belong to complete levels and hit without a probe; shift 0 (the root) always hits.
+__device__ __noinline__ uint32_t itop_resolve_slow(uint32_t hist, uint32_t cand, const uint32_t* Eg, uint32_t b, uint32_t cs) {
+    uint32_t c = cand;
+    for (;;) {
+        if (c <= cs) break;
+        const uint32_t x = itop_x(hist, c);
+        if ((Eg[x >> 5] >> (x & 31)) & 1u) break;
+        c -= b;
     }
+    return c;
 }
 
-// One input byte for each of the ILP independent items a lane owns.  Phases are ordered so
-// that the table gathers of the lanes that hold an explicit state are in flight while the
-// other lanes (and the other chain) do their LDS work — PMC showed the single-chain version
-// waiting 66 % of its wave cycles with only 4 waves per SIMD (the bitmaps take the CU's LDS):
-//   A  explicit lanes issue the gather, every chain          (results not touched yet)
-//   B  implicit lanes resolve from the bitmaps, every chain   (LDS + VALU, independent of A)
-//   C  explicit lanes consume their entry; those that fell into the implicit zone resolve too
-template <bool ESCAPE, bool GUARDED, int ILP>
-__device__ __forceinline__ void itop_step(const uint32_t (&c4)[ILP], const uint32_t (&idx)[ILP], const bool (&active)[ILP],
-                                          const bool (&emit)[ILP], const ItopCtx& C, ItopLane (&L)[ILP]) {
+// depth of the new state from the ND table (steady state) or the slow path; cand = deepest
+// shift the new state can have.  Returns the shift; ndw = the ND word (for the rank).
+__device__ __forceinline__ uint32_t itop_resolve(uint32_t hist, uint32_t valid, uint32_t cand, const ItopCtx& C, uint32_t& ndw) {
+    ndw = C.ND[hist >> 4];
+    const uint32_t f = (ndw >> ((hist & 15u) << 1)) & 3u;
+    if (valid >= C.D && f != 3u) return C.bD - __umul24(C.b, f);
+    uint32_t start = cand;
+    if (valid >= C.D) { const uint32_t lim = C.bD >= 3 * C.b ? C.bD - 3 * C.b : 0u; start = lim < cand ? lim : cand; }
+    return itop_resolve_slow(hist, start, C.Eg, C.b, C.cs);
+}
+
+// One input byte.  Phases are ordered so that the table gather of the lanes that hold an
+// explicit state is in flight while the other lanes of the wave do their LDS work:
+//   A  explicit lanes issue the gather                       (result not touched yet)
+//   B  implicit lanes: new depth from ND, outputs from H, hand-over rank
+//   C  explicit lanes consume the entry; those that fell into the implicit zone read ND too
+template <bool ESCAPE, bool GUARDED>
+__device__ __forceinline__ void itop_step(uint32_t c4, uint32_t idx, bool active, bool emit, const ItopCtx& C, ItopLane& L) {
     constexpr int SB = ACX_STATE_BITS_NARROW;
-    bool other[ILP], go[ILP], expl[ILP];
-    uint32_t hist[ILP], e[ILP], e_tab[ILP], new_sh[ILP], new_st[ILP];
-#pragma unroll
-    for (int q = 0; q < ILP; q++) {
-        const uint32_t cls = c4[q] >> 2;
-        other[q] = C.has_other && cls == 0;                          // a byte no key contains: root, no output
-        go[q] = GUARDED ? (active[q] && !other[q]) : !other[q];
-        expl[q] = L[q].sh == ACX_ITOP_EXPL;
-        hist[q] = ((L[q].hist << C.b) | (cls - C.has_other)) & C.maskD;
-        e[q] = 0; e_tab[q] = 0; new_sh[q] = L[q].sh; new_st[q] = L[q].st;
-    }
-#pragma unroll
-    for (int q = 0; q < ILP; q++)                                                       // A
-        if (go[q] && expl[q]) e_tab[q] = load_entry<SB>(C.table_bytes, L[q].st, C.row_bytes, c4[q]);
-#pragma unroll
-    for (int q = 0; q < ILP; q++) {                                                     // B
-        if (go[q] && !expl[q]) {
-            uint32_t c, x, word;
-            itop_resolve(hist[q], L[q].sh + C.b, C, c, x, word);
-            if ((!GUARDED || emit[q]) && c >= C.hmin) {              // no node above level hmin has outputs
-                if ((C.H[(x >> 5) - C.h_first] >> (x & 31)) & 1u) e[q] = C.ient[x];   // fetch its packed entry
-            }
-            if (c == C.bD) {                                         // hand over to the explicit rows
-                const uint32_t w = (x >> 5) - C.w0;
-                new_st[q] = C.LD + C.rank32[w >> 6] + C.rank16[w] + (uint32_t)__popc(word & ((1u << (x & 31)) - 1u));
-                new_sh[q] = ACX_ITOP_EXPL;
-            } else {
-                new_sh[q] = c;
-            }
+    const uint32_t cls = c4 >> 2;
+    const bool other = C.has_other && cls == 0;                      // a byte no key contains: root, no output
+    const bool go = GUARDED ? (active && !other) : !other;
+    const bool expl = L.sh == ACX_ITOP_EXPL;
+    const uint32_t hist = ((L.hist << C.b) | (cls - C.has_other)) & C.maskD;
+    const uint32_t valid = L.valid < C.D ? L.valid + 1 : L.valid;
+    uint32_t e = 0, e_tab = 0;
+    if (go && expl) e_tab = load_entry<SB>(C.table_bytes, L.st, C.row_bytes, c4);      // A
+    uint32_t new_sh = L.sh, new_st = L.st;
+    if (go && !expl) {                                                                  // B
+        uint32_t ndw;
+        const uint32_t c = itop_resolve(hist, valid, L.sh + C.b, C, ndw);
+        const uint32_t x = itop_x(hist, c);
+        if ((!GUARDED || emit) && c >= C.hmin) {                     // no node above level hmin has outputs
+            if ((C.H[(x >> 5) - C.h_first] >> (x & 31)) & 1u) e = C.ient[x];   // fetch its packed entry
+        }
+        if (c == C.bD) {                                             // hand over: id = first id of level D + #zero fields before
+            const uint32_t wi = hist >> 4;
+            const uint32_t z = ~(ndw | (ndw >> 1)) & 0x55555555u;
+            new_st = C.LD + C.rank32[wi >> 6] + C.rank16[wi] + (uint32_t)__popc(z & ((1u << ((hist & 15u) << 1)) - 1u));
+            new_sh = ACX_ITOP_EXPL;
+        } else {
+            new_sh = c;
         }
     }
-#pragma unroll
-    for (int q = 0; q < ILP; q++) {                                                     // C
-        if (go[q] && expl[q]) {
-            e[q] = e_tab[q];
-            if ((e_tab[q] & ACX_ENTRY_STATE_MASK(SB)) >= C.LD) {
-                new_st[q] = e_tab[q];
-            } else {                                                 // fell back into the implicit zone
-                uint32_t c, x, word;
-                itop_resolve(hist[q], C.bD - C.b, C, c, x, word);
-                new_sh[q] = c;
-            }
+    if (go && expl) {                                                                   // C
+        e = e_tab;
+        if ((e_tab & ACX_ENTRY_STATE_MASK(SB)) >= C.LD) {
+            new_st = e_tab;
+        } else {                                                     // fell back into the implicit zone
+            uint32_t ndw;
+            new_sh = itop_resolve(hist, valid, C.bD - C.b, C, ndw);
         }
     }
-#pragma unroll
-    for (int q = 0; q < ILP; q++) {
-        if (GUARDED ? active[q] : true) {
-            L[q].hist = other[q] ? 0u : hist[q];
-            L[q].sh = other[q] ? 0u : new_sh[q];
-            L[q].st = new_st[q];
-        }
-        if ((!GUARDED || emit[q]) && (e[q] >> ACX_ENTRY_CNT_SHIFT(SB))) {
-            uint32_t c = e[q] >> ACX_ENTRY_CNT_SHIFT(SB);
-            if (ESCAPE) {
-                if (c == ACX_ENTRY_CNT_ESCAPE(SB)) {
-                    const uint32_t s = e[q] & ACX_ENTRY_STATE_MASK(SB);
-                    c = C.out_off[s + 1] - C.out_off[s];
-                }
+    if (GUARDED ? active : true) {
+        L.hist = other ? 0u : hist;
+        L.valid = other ? 0u : valid;
+        L.sh = other ? 0u : new_sh;
+        L.st = new_st;
+    }
+    if ((!GUARDED || emit) && (e >> ACX_ENTRY_CNT_SHIFT(SB))) {
+        uint32_t c = e >> ACX_ENTRY_CNT_SHIFT(SB);
+        if (ESCAPE) {
+            if (c == ACX_ENTRY_CNT_ESCAPE(SB)) {
+                const uint32_t s = e & ACX_ENTRY_STATE_MASK(SB);
+                c = C.out_off[s + 1] - C.out_off[s];
             }
-            store_event<true>(L[q].ev++, idx[q], e[q]);
-            L[q].cnt += c;
         }
+        store_event<true>(L.ev++, idx, e);
+        L.cnt += c;
     }
 }
 
-template <bool ESCAPE, int ILP>
+template <bool ESCAPE>
 __global__ void __launch_bounds__(ACX_ITOP_BLOCK) k_walk_itop(const acx_walk_args a, const acx_chunk_desc* ck,
                                                              const int64_t* n_chunks_dev, const uint32_t* itop_lds,
-                                                             uint32_t itop_words, const uint32_t* itop_entry) {
+                                                             uint32_t itop_words, const uint32_t* itop_entry,
+                                                             const uint32_t* itop_ebits) {
     extern __shared__ __attribute__((aligned(16))) uint32_t s_mem[];
     uint32_t* s_cls4 = s_mem + ((itop_words + 3) & ~3u);
     for (uint32_t i = threadIdx.x; i < itop_words; i += ACX_ITOP_BLOCK) s_mem[i] = itop_lds[i];
@@ -465,98 +451,77 @@ __global__ void __launch_bounds__(ACX_ITOP_BLOCK) k_walk_itop(const acx_walk_arg
     __syncthreads();
 
     ItopCtx C;
-    C.ient = itop_entry; C.table_bytes = (const uint8_t*)a.table; C.out_off = a.out_off; C.row_bytes = a.row_bytes;
-    C.b = s_mem[0]; C.bD = s_mem[0] * s_mem[1]; C.LD = s_mem[2]; C.has_other = s_mem[5]; C.maskD = s_mem[7];
+    C.ient = itop_entry; C.Eg = itop_ebits; C.table_bytes = (const uint8_t*)a.table; C.out_off = a.out_off; C.row_bytes = a.row_bytes;
+    C.b = s_mem[0]; C.D = s_mem[1]; C.bD = s_mem[0] * s_mem[1]; C.LD = s_mem[2]; C.has_other = s_mem[5]; C.maskD = s_mem[7];
     C.rank16 = (const uint16_t*)(s_mem + s_mem[3]);
     C.rank32 = s_mem + s_mem[4];
-    C.E = s_mem + s_mem[8]; C.H = s_mem + s_mem[9]; C.w0 = s_mem[10];
+    C.ND = s_mem + s_mem[8]; C.H = s_mem + s_mem[9];
     C.cs = s_mem[11]; C.hmin = s_mem[12]; C.h_first = s_mem[13];
 
     const int lane = threadIdx.x & (ACX_WAVE - 1);
     const int64_t n_items = ck ? *n_chunks_dev : a.n_hay;
-    const int64_t per_task = (int64_t)ACX_WAVE * ILP;
-    const int64_t n_tasks = (n_items + per_task - 1) / per_task;
+    const int64_t n_tasks = (n_items + ACX_WAVE - 1) / ACX_WAVE;
     const int64_t wave0 = (int64_t)blockIdx.x * (ACX_ITOP_BLOCK / ACX_WAVE) + (threadIdx.x / ACX_WAVE);
     const int64_t n_waves = (int64_t)gridDim.x * (ACX_ITOP_BLOCK / ACX_WAVE);
     const uint8_t* limit = a.hay + a.hay_cap;
 
     for (int64_t task = wave0; task < n_tasks; task += n_waves) {
-        int64_t item[ILP];
-        bool valid[ILP];
-        acx_chunk_desc d[ILP];
-        const uint8_t* p[ILP];
-        ItopLane L[ILP];
-        uint2* ev0[ILP];
-        int maxlen = 0;
-#pragma unroll
-        for (int q = 0; q < ILP; q++) {
-            item[q] = task * per_task + (int64_t)q * ACX_WAVE + lane;      // neighbouring lanes, neighbouring items
-            valid[q] = item[q] < n_items;
-            d[q].start = 0; d[q].emit = 0; d[q].len = 0; d[q].idx0 = 0; d[q].hay = 0; d[q].flags = 0; d[q].pad = 0;
-            if (valid[q]) {
-                if (ck) d[q] = ck[item[q]];
-                else {
-                    const int64_t b0 = a.off ? a.off[item[q]] : item[q] * a.stride;
-                    const int64_t e0 = a.off ? a.off[item[q] + 1] : b0 + a.stride;
-                    d[q].start = b0; d[q].len = (int32_t)(e0 - b0); d[q].hay = (int32_t)item[q]; d[q].flags = 3;
-                    d[q].idx0 = a.index_base ? a.index_base[item[q]] : 0;
-                }
+        const int64_t c = task * ACX_WAVE + lane;
+        const bool valid = c < n_items;
+        acx_chunk_desc d;
+        d.start = 0; d.emit = 0; d.len = 0; d.idx0 = 0; d.hay = 0; d.flags = 0; d.pad = 0;
+        if (valid) {
+            if (ck) d = ck[c];
+            else {
+                const int64_t b0 = a.off ? a.off[c] : c * a.stride;
+                const int64_t e0 = a.off ? a.off[c + 1] : b0 + a.stride;
+                d.start = b0; d.len = (int32_t)(e0 - b0); d.hay = (int32_t)c; d.flags = 3;
+                d.idx0 = a.index_base ? a.index_base[c] : 0;
             }
-            p[q] = a.hay + d[q].start;
-            L[q].st = 0; L[q].sh = 0; L[q].hist = 0; L[q].cnt = 0;
-            L[q].ev = a.events + d[q].start + d[q].emit;
-            ev0[q] = L[q].ev;
-            maxlen = d[q].len > maxlen ? d[q].len : maxlen;
         }
+        const uint8_t* p = a.hay + d.start;
+        const int len = d.len, emit = d.emit;
+        ItopLane L;
+        L.st = 0; L.sh = 0; L.hist = 0; L.valid = 0; L.cnt = 0;
+        L.ev = a.events + d.start + emit;
+        uint2* const ev0 = L.ev;
+        const uint32_t base = (uint32_t)d.idx0;
 
         for (int j0 = 0;; j0 += 16) {
-            if (!__any(maxlen - j0 > 0)) break;
-            uint4 w[ILP];
-            bool full = true;
-#pragma unroll
-            for (int q = 0; q < ILP; q++) {
-                w[q] = make_uint4(0, 0, 0, 0);
-                if (d[q].len - j0 > 0) w[q] = load16_guarded<false>(p[q] + j0, limit);
-                full = full && (d[q].len - j0 >= 16) && (j0 >= d[q].emit);
-            }
-            const bool fast = __all(full);                // every chain of every lane: full block, every step reports
-            // one dword (4 steps) per iteration, NOT unrolled: the step body is large and the
-            // instruction cache is shared; the class lookups of a dword go first
+            const int rem = len - j0;
+            if (!__any(rem > 0)) break;
+            if (rem > 0) {
+                const uint4 w = load16_guarded<false>(p + j0, limit);
+                const bool fast = __all(rem >= 16 && j0 >= emit);   // full block, every step reports
+                // one dword (4 steps) per iteration, NOT unrolled: the step body is large and the
+                // instruction cache is shared; the class lookups of a dword go first
 #pragma unroll 1
-            for (int k = 0; k < 4; k++) {
-                uint32_t c4[ILP][4];
+                for (int k = 0; k < 4; k++) {
+                    const uint32_t wk = k == 0 ? w.x : (k == 1 ? w.y : (k == 2 ? w.z : w.w));
+                    uint32_t c4[4];
 #pragma unroll
-                for (int q = 0; q < ILP; q++) {
-                    const uint32_t wk = k == 0 ? w[q].x : (k == 1 ? w[q].y : (k == 2 ? w[q].z : w[q].w));
+                    for (int i = 0; i < 4; i++) c4[i] = s_cls4[(wk >> (i * 8)) & 0xffu];
+                    if (fast) {
 #pragma unroll
-                    for (int i = 0; i < 4; i++) c4[q][i] = s_cls4[(wk >> (i * 8)) & 0xffu];
-                }
+                        for (int i = 0; i < 4; i++) itop_step<ESCAPE, false>(c4[i], base + j0 + k * 4 + i, true, true, C, L);
+                    } else {
 #pragma unroll
-                for (int i = 0; i < 4; i++) {
-                    const int j = j0 + k * 4 + i;
-                    uint32_t cc[ILP], idx[ILP];
-                    bool act[ILP], em[ILP];
-#pragma unroll
-                    for (int q = 0; q < ILP; q++) {
-                        cc[q] = c4[q][i]; idx[q] = (uint32_t)d[q].idx0 + (uint32_t)j;
-                        act[q] = j < d[q].len; em[q] = j >= d[q].emit;
+                        for (int i = 0; i < 4; i++) {
+                            const int j = j0 + k * 4 + i;
+                            itop_step<ESCAPE, true>(c4[i], base + j, j < len, j >= emit, C, L);
+                        }
                     }
-                    if (fast) itop_step<ESCAPE, false, ILP>(cc, idx, act, em, C, L);
-                    else      itop_step<ESCAPE, true, ILP>(cc, idx, act, em, C, L);
                 }
             }
         }
-#pragma unroll
-        for (int q = 0; q < ILP; q++) {
-            if (valid[q]) {
-                a.counts[item[q]] = (int32_t)L[q].cnt;
-                a.nev[item[q]] = (int32_t)(L[q].ev - ev0[q]);
-                if (a.final_state && (d[q].flags & 2)) {
-                    uint32_t fs = 0;
-                    if (L[q].sh == ACX_ITOP_EXPL) fs = L[q].st & ACX_ENTRY_STATE_MASK(ACX_STATE_BITS_NARROW);
-                    else if (L[q].sh > 0) fs = itop_entry[itop_x(L[q].hist, L[q].sh)] & ACX_ENTRY_STATE_MASK(ACX_STATE_BITS_NARROW);
-                    a.final_state[d[q].hay] = (int32_t)fs;
-                }
+        if (valid) {
+            a.counts[c] = (int32_t)L.cnt;
+            a.nev[c] = (int32_t)(L.ev - ev0);
+            if (a.final_state && (d.flags & 2)) {
+                uint32_t fs = 0;
+                if (L.sh == ACX_ITOP_EXPL) fs = L.st & ACX_ENTRY_STATE_MASK(ACX_STATE_BITS_NARROW);
+                else if (L.sh > 0) fs = itop_entry[itop_x(L.hist, L.sh)] & ACX_ENTRY_STATE_MASK(ACX_STATE_BITS_NARROW);
+                a.final_state[d.hay] = (int32_t)fs;
             }
         }
     }
@@ -1009,27 +974,27 @@ hipError_t acx_launch_hay_offsets(const int64_t* ck_first, const int64_t* ck_mat
 
 hipError_t acx_launch_walk_itop(const acx_walk_args& a, const acx_chunk_desc* ck, const int64_t* n_chunks_dev,
                                 int64_t n_items_bound, bool has_escape, const uint32_t* itop_lds, uint32_t itop_words,
-                                const uint32_t* itop_entry, int ilp, hipStream_t s) {
+                                const uint32_t* itop_entry, const uint32_t* itop_ebits, hipStream_t s) {
     if (n_items_bound <= 0) return hipSuccess;
     const size_t lds_bytes = (size_t)((itop_words + 3) & ~3u) * 4 + 1024;
     if (lds_bytes > 160 * 1024) return hipErrorInvalidValue;
     const int bpc = lds_bytes * 2 <= 160 * 1024 ? 2 : 1;          // 1024-thread blocks: at most 2 per CU
     const int64_t waves_per_block = ACX_ITOP_BLOCK / ACX_WAVE;
-    const int64_t per_task = (int64_t)ACX_WAVE * ilp;
-    const int64_t n_tasks = (n_items_bound + per_task - 1) / per_task;
+    const int64_t n_tasks = (n_items_bound + ACX_WAVE - 1) / ACX_WAVE;
     int64_t blocks = (n_tasks + waves_per_block - 1) / waves_per_block;
     if (blocks > 256 * bpc) blocks = 256 * bpc;
     if (blocks < 1) blocks = 1;
-#define ACX_ITOP_LAUNCH(E, I)                                                                                          \
-    do {                                                                                                               \
-        hipError_t e = hipFuncSetAttribute((const void*)k_walk_itop<E, I>, hipFuncAttributeMaxDynamicSharedMemorySize,  \
-                                           (int)lds_bytes);                                                            \
-        if (e != hipSuccess) return e;                                                                                 \
-        hipLaunchKernelGGL((k_walk_itop<E, I>), dim3((unsigned)blocks), dim3(ACX_ITOP_BLOCK), lds_bytes, s, a, ck,      \
-                           n_chunks_dev, itop_lds, itop_words, itop_entry);                                            \
-    } while (0)
-    if (has_escape) { if (ilp == 2) ACX_ITOP_LAUNCH(true, 2); else ACX_ITOP_LAUNCH(true, 1); }
-    else            { if (ilp == 2) ACX_ITOP_LAUNCH(false, 2); else ACX_ITOP_LAUNCH(false, 1); }
-#undef ACX_ITOP_LAUNCH
+    hipError_t e;
+    if (has_escape) {
+        e = hipFuncSetAttribute((const void*)k_walk_itop<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL(k_walk_itop<true>, dim3((unsigned)blocks), dim3(ACX_ITOP_BLOCK), lds_bytes, s, a, ck, n_chunks_dev,
+                           itop_lds, itop_words, itop_entry, itop_ebits);
+    } else {
+        e = hipFuncSetAttribute((const void*)k_walk_itop<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL(k_walk_itop<false>, dim3((unsigned)blocks), dim3(ACX_ITOP_BLOCK), lds_bytes, s, a, ck, n_chunks_dev,
+                           itop_lds, itop_words, itop_entry, itop_ebits);
+    }
     return hipGetLastError();
 }

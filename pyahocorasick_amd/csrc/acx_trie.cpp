@@ -329,9 +329,10 @@ int acx_flatten(const acx_trie_t* t, void** blob_out, size_t* nbytes_out) {
         if (hmin > D) return 0;
         return itop_bm_words(D) - (size_t)((1ull << (itop_b * hmin)) >> 5);
     };
-    auto itop_cost = [&](uint32_t D) -> size_t {      // LDS image size in words: header, E, H, rank16, rank32
-        return ACX_ITOP_HDR_WORDS + itop_bm_words(D) + itop_h_words(D, hmin_level) + (itop_lvlD_words(D) + 1) / 2 +
-               itop_lvlD_words(D) / 64 + 1;
+    auto itop_nd_words = [&](uint32_t D) -> size_t { return (size_t)((1ull << (itop_b * D)) / 16); };   // 2 bits per history
+    auto itop_cost = [&](uint32_t D) -> size_t {      // LDS image size in words: header, ND, H, rank16, rank32
+        return ACX_ITOP_HDR_WORDS + itop_nd_words(D) + itop_h_words(D, hmin_level) + (itop_nd_words(D) + 1) / 2 +
+               itop_nd_words(D) / 64 + 1;
     };
     try {
         order = t->bfs;
@@ -344,7 +345,7 @@ int acx_flatten(const acx_trie_t* t, void** blob_out, size_t* nbytes_out) {
             }
         for (size_t i = 1; i < n; i++)
             if (t->nodes[order[i]].eow && (uint32_t)adepth[order[i]] < hmin_level) hmin_level = (uint32_t)adepth[order[i]];
-        const size_t budget_words = (size_t)150 * 1024 / 4;          // of the CU's 160 KiB of LDS
+        const size_t budget_words = (size_t)156 * 1024 / 4;          // of the CU's 160 KiB of LDS (+1 KiB class map)
         const char* no_itop = getenv("ACX_NO_ITOP");
         if (SB == ACX_STATE_BITS_NARROW && !(no_itop && no_itop[0] == '1')) {
             while (itop_D < ACX_ITOP_MAX_LEVELS && (int32_t)itop_D < max_depth && itop_b * (itop_D + 1) <= 24 &&
@@ -426,6 +427,7 @@ int acx_flatten(const acx_trie_t* t, void** blob_out, size_t* nbytes_out) {
         itop_entries = (size_t)2 << (itop_b * itop_D);      // indexed by the same sentinel index as the bitmaps
         h.off_itop_lds = off;    off = align_up(off + itop_lds_words * 4);
         h.off_itop_entry = off;  off = align_up(off + itop_entries * 4);
+        h.off_itop_ebits = off;  off = align_up(off + itop_bm_words(itop_D) * 4);
     }
     const size_t total = off;
 
@@ -512,12 +514,13 @@ int acx_flatten(const acx_trie_t* t, void** blob_out, size_t* nbytes_out) {
     if (itop_D > 0) {
         uint32_t* lds = (uint32_t*)(blob + h.off_itop_lds);
         uint32_t* ient = (uint32_t*)(blob + h.off_itop_entry);
-        const size_t bmw = itop_bm_words(itop_D);
+        uint32_t* E = (uint32_t*)(blob + h.off_itop_ebits);       // global: slow path only
+        const size_t ndw = itop_nd_words(itop_D);
         const size_t hw = itop_h_words(itop_D, hmin_level);
         const size_t h_first = hw ? (size_t)((1ull << (itop_b * hmin_level)) >> 5) : 0;   // sentinel word where H starts
-        const size_t eb = ACX_ITOP_HDR_WORDS, hb = eb + bmw;
-        lds[eb] |= 1u << 1;                                   // the root: (d = 0, code = 0) -> bit 1
-        uint32_t complete = 0;                                // levels 1..complete hold every possible k-gram
+        const size_t ndb = ACX_ITOP_HDR_WORDS, hb = ndb + ndw;
+        E[0] |= 1u << 1;                                          // the root: (d = 0, code = 0) -> bit 1
+        uint32_t complete = 0;                                    // levels 1..complete hold every possible k-gram
         {
             const uint64_t sigma = has_other ? K - 1 : 256;
             uint64_t full = 1;
@@ -529,26 +532,37 @@ int acx_flatten(const acx_trie_t* t, void** blob_out, size_t* nbytes_out) {
         for (uint32_t d = 1; d <= itop_D; d++) {
             for (uint32_t i = lvl_first[d]; i < lvl_first[d + 1]; i++) {
                 const uint32_t x = (1u << (itop_b * d)) | acode[order[i]];     // sentinel index
-                lds[eb + (x >> 5)] |= 1u << (x & 31);
+                E[x >> 5] |= 1u << (x & 31);
                 if (out_cnt[i]) lds[hb + (x >> 5) - h_first] |= 1u << (x & 31);
                 ient[x] = i | tflags[i];
             }
         }
-        // rank of level D: ones before each word of [2^(bD), 2^(bD+1)), 64-word superblocks
-        const size_t wD = itop_lvlD_words(itop_D), w0 = wD;    // level D starts at word 2^(bD)/32 = wD
-        const size_t r16 = hb + hw, r32 = r16 + (wD + 1) / 2;
+        // ND: for every history of D symbols, how far below D the longest k-gram node ending here is
+        const uint32_t n_hist = 1u << (itop_b * itop_D);
+        for (uint32_t hh = 0; hh < n_hist; hh++) {
+            uint32_t dd = itop_D;
+            for (;; dd--) {
+                const uint32_t x = (1u << (itop_b * dd)) | (hh & ((1u << (itop_b * dd)) - 1u));
+                if ((E[x >> 5] >> (x & 31)) & 1u) break;          // dd = 0 (the root) always exists
+            }
+            const uint32_t f = itop_D - dd > 2 ? 3u : itop_D - dd;
+            lds[ndb + (hh >> 4)] |= f << ((hh & 15) * 2);
+        }
+        // rank of level D = number of ND fields equal to 0 before a history; 64-word superblocks
+        const size_t r16 = hb + hw, r32 = r16 + (ndw + 1) / 2;
         uint16_t* rank16 = (uint16_t*)(lds + r16);
         uint32_t* rank32 = lds + r32;
         uint32_t run = 0, in_sb = 0;
-        for (size_t k = 0; k < wD; k++) {
+        for (size_t k = 0; k < ndw; k++) {
             if ((k & 63) == 0) { rank32[k >> 6] = run; in_sb = 0; }
             rank16[k] = (uint16_t)in_sb;
-            const uint32_t pc = (uint32_t)__builtin_popcount(lds[eb + w0 + k]);
+            const uint32_t w = lds[ndb + k];
+            const uint32_t pc = (uint32_t)__builtin_popcount(~(w | (w >> 1)) & 0x55555555u);
             run += pc; in_sb += pc;
         }
         lds[0] = itop_b; lds[1] = itop_D; lds[2] = lvl_first[itop_D]; lds[3] = (uint32_t)r16; lds[4] = (uint32_t)r32;
         lds[5] = has_other ? 1u : 0u; lds[6] = (uint32_t)itop_lds_words; lds[7] = (uint32_t)((1ull << (itop_b * itop_D)) - 1);
-        lds[8] = (uint32_t)eb; lds[9] = (uint32_t)hb; lds[10] = (uint32_t)w0;
+        lds[8] = (uint32_t)ndb; lds[9] = (uint32_t)hb;
         lds[11] = itop_b * complete;                           // shifts up to this one always hit: no probe needed
         lds[12] = hw ? itop_b * hmin_level : 0xFFFFu;          // no node shallower than this has outputs
         lds[13] = (uint32_t)h_first;
@@ -599,6 +613,7 @@ int acx_blob_check_header(const acx_blob_header* h, size_t nbytes) {
         {h->off_first_val, n * 4},
         {h->itop_depth ? h->off_itop_lds : (uint64_t)ACX_BLOB_ALIGN, h->itop_depth ? h->itop_lds_bytes : 0},
         {h->itop_depth ? h->off_itop_entry : (uint64_t)ACX_BLOB_ALIGN, 0},
+        {h->itop_depth ? h->off_itop_ebits : (uint64_t)ACX_BLOB_ALIGN, 0},
     };
     for (auto& s : sec)
         if (s.off % ACX_BLOB_ALIGN || s.off < ACX_BLOB_HEADER_BYTES || s.off + s.len > nbytes)
