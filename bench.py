@@ -40,7 +40,7 @@ def parse():
     ap.add_argument("--read-len", type=int, default=150)
     ap.add_argument("--mode", choices=["iter", "iter_long"], default="iter")
     ap.add_argument("--variant", type=int, default=0)
-    ap.add_argument("--cpu-sample-reads", type=int, default=300_000,
+    ap.add_argument("--cpu-sample-reads", type=int, default=1_000_000,
                     help="reads timed on the CPU baseline leg (0 disables it)")
     ap.add_argument("--verify", action="store_true", help="check a sample of the GPU output against the oracle")
     return ap.parse_args()
