@@ -33,34 +33,40 @@
 #include <stdint.h>
 
 /*
- * Implicit top-of-trie ("itop").  The top D levels of the trie are dense (every k-gram over
- * the used bytes tends to exist), so a state at depth d <= D is representable as the pair
- * (d, code) where code = its last d symbols, b bits each (symbol = class - 1).  Whether
- * (d, code) is a trie node is ONE BIT: E_d[code].  With these bitmaps resident in LDS the
- * transition out of a shallow state is "largest dd <= d+1 with E_dd[last dd symbols]" — LDS
- * probes instead of a gather through the vector-memory pipe, which is what bounds the plain
- * walk.  H_d[code] says the node has outputs (then its packed entry, same
- * format as a table entry, is fetched from itop_entry).  Level D is the hand-over level: its
- * nodes are numbered in code order, id = first_id(D) + rank_D(code), rank tables in LDS.
- * States deeper than D keep their explicit rows.  Levels 1..D are numbered in code order.
+ * Implicit top-of-trie ("itop"), for key alphabets of at most 16 symbols.  The top D levels of
+ * the trie are dense (every k-gram over the used bytes tends to exist), so a state at depth
+ * d <= D is representable as the pair (d, code) where code = its last d symbols, b bits each
+ * (symbol = class - 1): no row, no id.  The walk keeps the rolling history `hist` of the last D
+ * symbols and reads, from a table that is resident in LDS, where that history puts it:
  *
- * All levels share ONE index space: node (d, code) is bit  x = (1 << b*d) | code  ("sentinel
- * bit" above the code; the root is x = 1).  E, H and itop_entry are all indexed by x.
+ *   ND4[hist]  4 bits:  bits 0..2  delta = D - depth of the longest k-gram node that is a
+ *                                  suffix of the history (0..6; 7 = deeper fall: slow path)
+ *                       bit  3     that node has outputs (its packed entry is itop_entry[x])
  *
- * The steady-state step does not even probe E: ND ("next depth") is a 2-bit table indexed by
- * the rolling history of the last D symbols that says how deep the longest k-gram node ending
- * here is — 0: depth D, 1: D-1, 2: D-2, 3: shallower (slow path: probe E level by level).  It
- * is exact once D symbols have been seen since the last reset (haystack start or a byte that
- * occurs in no key); before that the slow path runs.  A level-D node is  ND == 0, so the rank
- * that turns a level-D code into its state id counts zero fields of ND.
+ * ND4 is exact once D symbols have been seen since the last reset (haystack start or a byte
+ * that occurs in no key); before that the slow path probes the existence bitmap E level by
+ * level.  ND4 only speaks about nodes of depth <= D (the last D symbols of a deeper state need
+ * not be a node), so:
+ *   - a lane at depth < D steps with ND4 alone;
+ *   - a lane at depth == D first asks whether its node has a child on the new symbol: one 4- or
+ *     8-byte CELL per level-D code (itop_cells, global, code-indexed: 1 MB for DNA instead of
+ *     the 1.7 MB of level-D rows, and the only thing 2/3 of all table accesses need).  Children
+ *     of a level-D node are numbered consecutively in symbol order (levels 1..D+1 are numbered in
+ *     code order), so child id = first_child + popcount(mask below the symbol).  No child: ND4.
+ *   - a lane at depth > D holds an explicit state and gathers its table entry like the plain
+ *     walk; when the target is not deeper than D it drops back to (depth from ND4, hist).
  *
- * LDS image (uint32 words): [0]=b [1]=D [2]=first id of level D [3]=rank16 word offset
- * [4]=rank32 word offset [5]=1 if class 0 is "other" [6]=total words [7]=mask(D) = 2^(bD)-1
- * [8]=ND word offset [9]=H word offset [11]=shift up to which levels are complete (every
- * k-gram exists) [12]=shift of the shallowest level that has outputs [13]=first sentinel word
- * covered by H;  ND (2^(bD) x 2 bits), H (sentinel-indexed, from word [13] on), rank16 (uint16
- * per ND word: zero fields before it inside its 64-word superblock), rank32 (uint32 per
- * superblock).  b*D >= 5.  E lives in global memory (off_itop_ebits), used by the slow path.
+ *   cell, 4 bytes (<= 4 symbols):  first_child[0..23] | child mask[24..27] | child-has-outputs[28..31]
+ *   cell, 8 bytes (<= 16 symbols): first_child (low word); child mask[0..15] | child-has-outputs[16..31] (high word)
+ *   (a child with outputs takes its packed entry from  id | tflags[id])
+ *
+ * Levels 0..D share ONE index space: node (d, code) is  x = (1 << b*d) | code  ("sentinel bit"
+ * above the code; the root is x = 1).  E (global) and itop_entry (global) are indexed by x.
+ *
+ * LDS image (uint32 words): [0]=b [1]=D [2]=first id of level D+1 (ids from here on are "deep")
+ * [3]=cell bytes (4 or 8) [5]=1 if class 0 is "other" [6]=total words [7]=mask(D) = 2^(bD)-1
+ * [8]=ND4 word offset [11]=shift up to which levels are complete (every k-gram exists: no probe
+ * needed);  then ND4 (2^(bD) x 4 bits).  b*D >= 5.
  */
 #define ACX_ITOP_MAX_LEVELS   15
 #define ACX_ITOP_HDR_WORDS    16
@@ -108,7 +114,7 @@ typedef struct acx_blob_header {
     uint64_t off_first_val;  /* int32  [n_states]       out_val[out_off[s]] (first output of s:
                                 the value iter_long reports, and the only one when CNT == 1) */
     uint32_t state_bits;     /* SB of the entry layout: 24 or 27                         */
-    uint32_t itop_depth;     /* D of the implicit top-of-trie (0 = absent), see below    */
+    uint32_t itop_depth;     /* D of the implicit top-of-trie (0 = absent), see above    */
     uint64_t off_itop_lds;   /* uint32 [itop_lds_bytes/4]  LDS image: levels, bitmaps, ranks */
     uint64_t off_itop_entry; /* uint32 [sum over levels 1..D of 2^(b*d)]  entry of node (d, code) */
     uint32_t itop_lds_bytes;
@@ -126,9 +132,10 @@ typedef struct acx_blob_header {
     uint32_t n_levels;       /* max depth + 1                                                */
     uint32_t n_edges;
     uint32_t table_in_blob;  /* 1: `table` section present; 0: build it on the device        */
-    uint32_t reserved1;
+    uint32_t itop_cell_bytes; /* 4 or 8 (0 without itop)                                      */
     uint64_t off_itop_ebits; /* uint32 [2^(bD+1)/32]  existence bitmap E, sentinel-indexed (global; slow path) */
-    uint8_t  reserved[ACX_BLOB_HEADER_BYTES - 232];
+    uint64_t off_itop_cells; /* uint32|uint64 [2^(bD)]  child cell of the level-D node with that code   */
+    uint8_t  reserved[ACX_BLOB_HEADER_BYTES - 240];
 } acx_blob_header;
 
 #endif

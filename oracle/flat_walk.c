@@ -27,6 +27,7 @@ typedef struct {
 static int flat_open(const void* blob, flat_t* f) {
     const acx_blob_header* h = (const acx_blob_header*)blob;
     if (h->magic != ACX_BLOB_MAGIC || h->version != ACX_BLOB_VERSION) return -1;
+    if (!h->table_in_blob) return -1;      /* these walkers read the host-built table (ACX_FLATTEN_TABLE=host) */
     const uint8_t* b = (const uint8_t*)blob;
     f->h = h;
     f->cls = b + h->off_cls;
@@ -69,13 +70,15 @@ int64_t flat_iter(const void* blob, const uint8_t* hay, int64_t len,
 
 /*
  * The same walk, but shallow states are held IMPLICITLY as (depth, k-gram code) and their
- * transitions are resolved from the "itop" bitmaps (include/acx_blob.h) instead of table rows —
+ * transitions are resolved from the "itop" ND4 table (include/acx_blob.h) instead of table rows —
  * the CPU restatement of k_walk_itop.  Checked against flat_iter()/the oracle in tests; it also
- * cross-checks every implicit step against the explicit table (returns -5 on disagreement).
+ * cross-checks every implicit step against the explicit table (returns -(1000 + source line) on
+ * disagreement).
  * Returns -6 if the image has no itop.
  */
 int64_t flat_iter_itop(const void* blob, const uint8_t* hay, int64_t len, int64_t index_base,
                        int32_t* final_state, int32_t* out_end, int32_t* out_val, int64_t cap) {
+#define BAD return -(int64_t)(1000 + __LINE__)
     flat_t f;
     if (flat_open(blob, &f) < 0) return -1;
     if (f.h->itop_depth == 0) return -6;
@@ -83,73 +86,94 @@ int64_t flat_iter_itop(const void* blob, const uint8_t* hay, int64_t len, int64_
     const uint32_t* lds = (const uint32_t*)(bb + f.h->off_itop_lds);
     const uint32_t* ient = (const uint32_t*)(bb + f.h->off_itop_entry);
     const uint32_t* E = (const uint32_t*)(bb + f.h->off_itop_ebits);
+    const uint32_t* cells = (const uint32_t*)(bb + f.h->off_itop_cells);
+    const uint32_t* tflags = (const uint32_t*)(bb + f.h->off_tflags);
     const uint32_t K = f.h->n_classes, SB = f.h->state_bits;
-    const uint32_t b = lds[0], D = lds[1], LD = lds[2], has_other = lds[5], maskD = lds[7];
+    const uint32_t b = lds[0], D = lds[1], LD1 = lds[2], cell_bytes = lds[3], NS = lds[4], has_other = lds[5], maskD = lds[7];
     const uint32_t* ND = lds + lds[8];
-    const uint32_t* H = lds + lds[9];
-    const uint32_t cs = lds[11], hmin = lds[12], h_first = lds[13];
-    const uint16_t* rank16 = (const uint16_t*)(lds + lds[3]);
-    const uint32_t* rank32 = lds + lds[4];
+    const uint32_t cs = lds[11];
     const uint32_t bD = b * D;
+    if (cell_bytes != f.h->itop_cell_bytes || (cell_bytes != 4 && cell_bytes != 8) || NS != f.h->n_states) BAD;
 #define XIDX(sh) ((hist & ((1u << (sh)) - 1u)) | (1u << (sh)))       /* sentinel index of the last sh/b symbols */
 #define BIT(M, x) (((M)[(x) >> 5] >> ((x) & 31)) & 1u)
     int64_t n = 0;
-    uint32_t hist = 0, sh = 0, s = 0, valid = 0, shadow = 0;   /* sh = b * implicit depth; shadow: cross-check only */
-    int expl = 0;
+    uint32_t hist = 0, sh = 0, s = 0, valid = 0, shadow = 0;   /* sh = b * implicit depth (0..bD); shadow: cross-check only */
+    int expl = 0;                                              /* 1: depth > D, state s */
     for (int64_t i = 0; i < len; i++) {
         const uint32_t cls = f.cls[hay[i]];
         const uint32_t se = f.table[(size_t)shadow * K + cls];
         shadow = se & ACX_ENTRY_STATE_MASK(SB);
         uint32_t ev = 0;                                  /* entry to report, 0 = none */
-        if (has_other && cls == 0) { sh = 0; expl = 0; hist = 0; valid = 0; if (shadow != 0) return -5; continue; }
-        hist = ((hist << b) | (cls - has_other)) & maskD;
+        int pseudo = 0;                                   /* the kernel reports NS + x instead of the real entry */
+        if (has_other && cls == 0) { sh = 0; expl = 0; hist = 0; valid = 0; if (shadow != 0) BAD; continue; }
+        const uint32_t sym = cls - has_other;
+        const uint32_t code_before = hist;                /* code of the level-D node when sh == bD */
+        hist = ((hist << b) | sym) & maskD;
         if (valid < D) valid++;
-        uint32_t cand = 0;
-        int resolve = 0;                                  /* 1: dropped out of the explicit zone, 2: implicit source */
-        if (expl) {
+        const uint32_t q = (ND[hist >> 3] >> ((hist & 7u) * 4)) & 15u;
+        const uint32_t delta = q & 3u, oc = q >> 2;       /* oc: 0 no output, 1 exactly one, 2 more */
+        int settled = 0, own_out = 0;
+        if (oc == 3u || (delta == 3u && oc)) BAD;          /* delta 3 = shallower than D - 2: probe */
+        if (expl) {                                       /* depth > D: the table row */
             const uint32_t e = f.table[(size_t)s * K + cls];
-            const uint32_t t = e & ACX_ENTRY_STATE_MASK(SB);
+            if (valid < D) BAD;
             if (e >> ACX_ENTRY_CNT_SHIFT(SB)) ev = e;
-            if (t >= LD) s = t;
-            else { expl = 0; cand = bD - b; resolve = 1; }
-        } else { cand = sh + b; resolve = 2; }
-        if (resolve) {
-            uint32_t c, x;
-            const uint32_t ndw = ND[hist >> 4];
-            const uint32_t fld = (ndw >> ((hist & 15) * 2)) & 3u;
-            if (valid >= D && fld != 3u) {                /* steady state: the table says how deep */
-                c = bD - b * fld;
-                if (c > cand) return -5;                  /* cannot be deeper than source + 1 (or D-1 after a drop) */
-                x = XIDX(c);
-                if (!BIT(E, x)) return -5;
-            } else {                                      /* warm-up after a reset, or a fall of more than two levels */
-                c = (valid >= D) ? (bD >= 3 * b ? bD - 3 * b : 0) : cand;
-                if (c > cand) c = cand;
+            own_out = 1;
+            if ((e & ACX_ENTRY_STATE_MASK(SB)) >= LD1) { s = e & ACX_ENTRY_STATE_MASK(SB); settled = 1; }
+            else expl = 0;
+        } else if (sh == bD) {                            /* depth == D: the cell of this node */
+            uint32_t first, mask, outs;
+            if (cell_bytes == 4) { const uint32_t cw = cells[code_before]; first = cw & 0xFFFFFFu; mask = (cw >> 24) & 15u; outs = cw >> 28; }
+            else { first = cells[2 * (size_t)code_before]; mask = cells[2 * (size_t)code_before + 1] & 0xFFFFu; outs = cells[2 * (size_t)code_before + 1] >> 16; }
+            if ((mask >> sym) & 1u) {
+                const uint32_t child = first + (uint32_t)__builtin_popcount(mask & ((1u << sym) - 1u));
+                if (child < LD1) BAD;
+                s = child; expl = 1; settled = 1; own_out = 1;
+                if ((outs >> sym) & 1u) ev = child | tflags[child];
+            }
+        }
+        if (!settled) {                                   /* the new state is not deeper than D */
+            if (valid >= D && delta != 3u) {              /* steady state: ND4 says how deep */
+                sh = bD - b * delta;
+                if (!BIT(E, XIDX(sh))) BAD;
+                for (uint32_t c = sh + b; c <= bD; c += b) if (BIT(E, XIDX(c))) BAD;   /* it is the longest */
+                if (!own_out && oc) {
+                    const uint32_t real = ient[XIDX(sh)];
+                    if (oc == 1) {                        /* reported as pseudo state NS + x, count 1 */
+                        if ((real >> ACX_ENTRY_CNT_SHIFT(SB)) != 1u) BAD;
+                        if (f.first_val[NS + XIDX(sh)] != f.first_val[real & ACX_ENTRY_STATE_MASK(SB)]) BAD;
+                        pseudo = 1;
+                    } else if ((real >> ACX_ENTRY_CNT_SHIFT(SB)) < 2u) BAD;
+                    ev = real;
+                }
+            } else {                                      /* warm-up after a reset, or a deep fall */
+                uint32_t c;
+                if (valid < D) c = sh + b;
+                else { if (bD < 3u * b) BAD; c = bD - 3u * b; for (uint32_t c2 = c + b; c2 <= bD; c2 += b) if (BIT(E, XIDX(c2))) BAD; }
+                if (c > bD) BAD;
                 for (;;) {
-                    x = XIDX(c);
-                    if (c <= cs) { if (!BIT(E, x)) return -5; break; }
-                    if (BIT(E, x)) break;
+                    if (c <= cs) { if (!BIT(E, XIDX(c))) BAD; break; }
+                    if (BIT(E, XIDX(c))) break;
                     c -= b;
                 }
-            }
-            sh = c;
-            if (resolve == 2 && c >= hmin && ((H[(x >> 5) - h_first] >> (x & 31)) & 1u)) ev = ient[x];
-            if (c == bD) {                                /* hand over to the explicit rows: id = first + #ND zeros before */
-                if (fld != 0) return -5;
-                const uint32_t wi = hist >> 4;
-                const uint32_t z = ~(ndw | (ndw >> 1)) & 0x55555555u;
-                s = LD + rank32[wi >> 6] + rank16[wi] + (uint32_t)__builtin_popcount(z & ((1u << ((hist & 15) * 2)) - 1u));
-                expl = 1;
-                if ((ient[x] & ACX_ENTRY_STATE_MASK(SB)) != s) return -5;
+                sh = c;
+                if (!own_out) {
+                    ev = c ? ient[XIDX(c)] : 0;
+                    if (!(ev >> ACX_ENTRY_CNT_SHIFT(SB))) ev = 0;
+                }
             }
         }
         /* cross-check the position and the output decision against the explicit walk */
         {
             uint32_t cur = expl ? s : (sh == 0 ? 0 : (ient[XIDX(sh)] & ACX_ENTRY_STATE_MASK(SB)));
-            if (cur != shadow) return -5;
-            if ((ev != 0) != ((se >> ACX_ENTRY_CNT_SHIFT(SB)) != 0)) return -5;
+            if (cur != shadow) BAD;
+            if ((ev != 0) != ((se >> ACX_ENTRY_CNT_SHIFT(SB)) != 0)) BAD;
+            if (ev && ((ev ^ se) & ~ACX_ENTRY_EDGE(SB))) BAD;      /* same target, same flags */
         }
-        if (ev) {
+        if (ev && pseudo) {                               /* one record, value through the pseudo state */
+            if (n < cap) { out_end[n] = (int32_t)(i + index_base); out_val[n] = f.first_val[NS + XIDX(sh)]; }
+            n++;
+        } else if (ev) {
             const uint32_t st = ev & ACX_ENTRY_STATE_MASK(SB);
             for (uint32_t r = f.out_off[st]; r < f.out_off[st + 1]; r++) {
                 if (n < cap) { out_end[n] = (int32_t)(i + index_base); out_val[n] = f.out_val[r]; }
@@ -160,6 +184,7 @@ int64_t flat_iter_itop(const void* blob, const uint8_t* hay, int64_t len, int64_
     if (final_state) *final_state = (int32_t)(expl ? s : (sh == 0 ? 0 : (ient[XIDX(sh)] & ACX_ENTRY_STATE_MASK(SB))));
 #undef XIDX
 #undef BIT
+#undef BAD
     return n;
 }
 

@@ -80,6 +80,8 @@ struct acx_image {
     const uint32_t* itop_lds = nullptr;     // nullptr when the image has no implicit top
     const uint32_t* itop_entry = nullptr;
     const uint32_t* itop_ebits = nullptr;
+    const void* itop_cells = nullptr;
+    const uint32_t* tflags = nullptr;
     uint32_t* built_table = nullptr;        // table built in HBM (blob without a table section); owned
 };
 
@@ -94,13 +96,15 @@ static int image_resolve(acx_image* img, const uint32_t* lvl_host) {
         img->itop_lds = (const uint32_t*)(img->dev + img->h.off_itop_lds);
         img->itop_entry = (const uint32_t*)(img->dev + img->h.off_itop_entry);
         img->itop_ebits = (const uint32_t*)(img->dev + img->h.off_itop_ebits);
+        img->itop_cells = img->dev + img->h.off_itop_cells;
+        img->tflags = (const uint32_t*)(img->dev + img->h.off_tflags);
     }
     if (img->h.table_in_blob) {
         img->table = (const uint32_t*)(img->dev + img->h.off_table);
         return ACX_OK;
     }
     const size_t tbytes = (size_t)img->h.n_states * img->h.n_classes * 4;
-    HIP_TRY(hipMalloc((void**)&img->built_table, tbytes));
+    HIP_TRY(hipMalloc((void**)&img->built_table, tbytes + 16));      // the itop walk may read one entry past the end
     std::vector<uint32_t> lvl;
     if (!lvl_host) {
         lvl.resize((size_t)img->h.n_levels + 1);
@@ -328,11 +332,13 @@ extern "C" int acx_scan_batch(acx_image_t* img, const acx_scan_params* p, acx_re
         HIP_TRY(acx_launch_scan(r->nck.p, p->n_hay, r->ck_first.p, r->partials.p, s));
         HIP_TRY(acx_launch_chunk_fill(ca, n_items, s));
         if (use_itop) HIP_TRY(acx_launch_walk_itop(wa, r->ck.p, r->ck_first.p + p->n_hay, n_items, img->h.has_escape != 0,
-                                                   img->itop_lds, img->h.itop_lds_bytes / 4, img->itop_entry, img->itop_ebits, s));
+                                                   img->itop_lds, img->h.itop_lds_bytes / 4, img->itop_entry, img->itop_ebits,
+                                                   img->itop_cells, img->tflags, img->h.itop_cell_bytes, (int)((p->variant >> 17) & 0x3f), s));
         else          HIP_TRY(acx_launch_walk_chunks(wa, r->ck.p, r->ck_first.p + p->n_hay, n_items, img->h.has_escape != 0, s));
     } else if (p->mode == ACX_SCAN_ALL) {
         if (use_itop) HIP_TRY(acx_launch_walk_itop(wa, nullptr, nullptr, p->n_hay, img->h.has_escape != 0,
-                                                   img->itop_lds, img->h.itop_lds_bytes / 4, img->itop_entry, img->itop_ebits, s));
+                                                   img->itop_lds, img->h.itop_lds_bytes / 4, img->itop_entry, img->itop_ebits,
+                                                   img->itop_cells, img->tflags, img->h.itop_cell_bytes, (int)((p->variant >> 17) & 0x3f), s));
         else          HIP_TRY(acx_launch_walk_all(wa, img->h.has_escape != 0, p->variant, s));
     } else {
         HIP_TRY(acx_launch_walk_long(wa, p->variant, s));

@@ -24,6 +24,7 @@
 // reads, every 64-B sector is consumed completely), so the per-byte VMEM budget goes to
 // the table gathers, which are what bounds the kernel (L2 transaction rate).
 #include "acx_kernels.h"
+#include <cstdlib>
 #include "acx_blob.h"
 
 #define ACX_WAVE 64
@@ -313,35 +314,43 @@ __global__ void __launch_bounds__(ACX_BLOCK, 8) k_walk_chunks(const acx_walk_arg
 // ---------------------------------------------------------------------------------
 // walk with the IMPLICIT TOP-OF-TRIE in LDS (include/acx_blob.h "itop"), ACX_SCAN_ALL.
 //
-// The plain walk is bound by one L2 transaction per input byte.  Here a lane
-// whose state is shallower than D holds it as (depth d, code = last d symbols): the next
-// state is "the largest dd <= d+1 whose last-dd-symbols code is a trie node", answered by the
-// per-level existence bitmaps E_dd resident in LDS (~100 KB for DNA: D = 9) — LDS probes
-// instead of a gather.  Only states at depth >= D use their explicit table row.  Level D is
-// the hand-over: its nodes are numbered in code order, so id = first_id(D) + rank_D(code)
-// (popcount rank tables, also in LDS).  A node with outputs (H_dd bit) fetches its packed
-// entry from itop_entry[] and then reports exactly like the plain walk.
-// One 1024-thread block per CU (the bitmaps take most of the 160 KiB); items are haystacks
+// The plain walk is bound by one cache transaction per input byte, and most of them miss L2
+// (DESIGN.md §4).  Here every lane keeps the rolling history of its last D symbols and reads
+// ONE nibble of the LDS-resident table ND4[hist]: how deep the longest trie node (of depth <= D)
+// that is a suffix of the history is (D - 0..2: shallower levels are complete), and whether it
+// has no, exactly one, or more outputs.
+//   depth <  D : the lane holds (depth, hist); its step is that nibble and nothing else.  A node
+//                with exactly one output is reported as pseudo state n_states + x (first_val has
+//                an entry for it): no memory access; more outputs: packed entry from itop_entry[].
+//   depth == D : same, after asking the node's CELL (4 or 8 bytes, indexed by the node's code:
+//                a 1 MB array for DNA) whether it has a child on the new symbol.
+//   depth >  D : explicit state; gathers its table entry like the plain walk and drops back to
+//                (depth from the nibble, hist) when the target is not deeper than D.
+// The steady-state step (itop_fast_step: every lane has seen D symbols since its last reset, no
+// byte outside the key alphabet in this dword, every step reports) is written for instruction
+// count; everything else takes itop_step.  ILP items per lane: their memory operations are
+// issued together, before either result is used.
+// One 1024-thread block per CU (ND4 is 128 KiB for DNA: b = 2, D = 9); items are haystacks
 // (ck == nullptr) or chunks.  oracle/flat_walk.c:flat_iter_itop is the CPU restatement.
 // ---------------------------------------------------------------------------------
 #define ACX_ITOP_BLOCK 1024
 #define ACX_ITOP_EXPL 255u
+#define ACX_ITOP_SYM_OTHER 0x80u
 
 struct ItopCtx {
-    const uint32_t* ND;         // LDS: 2-bit next-depth table indexed by the last D symbols
-    const uint32_t* H;          // LDS: has-output bitmap, sentinel-indexed from word h_first on
-    const uint16_t* rank16;     // LDS
-    const uint32_t* rank32;     // LDS
-    const uint32_t* Eg;         // global: existence bitmap, sentinel-indexed (slow path only)
+    const uint32_t* ND;         // LDS: 4 bits per history of D symbols
+    const uint32_t* Eg;         // global: existence bitmap, sentinel-indexed (warm-up only)
     const uint32_t* ient;       // global: packed entry of implicit node x
+    const uint32_t* cells;      // global: child cell of the level-D node with a given code
+    const uint32_t* tflags;     // global: per-state entry bits
     const uint8_t*  table_bytes;
     const uint32_t* out_off;
-    uint32_t row_bytes, b, D, bD, LD, has_other, maskD, cs, hmin, h_first;
+    uint32_t row_bytes, b, D, bD, LD1, has_other, maskD, cs, pseudo1;
 };
 
 struct ItopLane {
-    uint32_t st;     // explicit: raw entry (low 24 bits = state)
-    uint32_t sh;     // implicit: b * depth (0 .. b*(D-1)); explicit: ACX_ITOP_EXPL
+    uint32_t st;     // explicit (depth > D): raw entry (low 24 bits = state)
+    uint32_t sh;     // implicit: b * depth (0 .. b*D); explicit: ACX_ITOP_EXPL
     uint32_t hist;   // last D symbols, b bits each
     uint32_t valid;  // symbols seen since the last reset, saturating at D
     uint32_t cnt;
@@ -353,9 +362,9 @@ __device__ __forceinline__ uint32_t itop_x(uint32_t hist, uint32_t sh) {
     return __builtin_amdgcn_ubfe(hist, 0u, sh) | (1u << sh);
 }
 
-// Slow path (first D steps after a reset, or a fall of more than two levels): largest shift
-// <= cand whose k-gram is a node, probing the global E bitmap level by level.  Shifts up to
-// C.cs belong to complete levels and hit without a probe; shift 0 (the root) always hits.
+// Warm-up (first D steps after a reset): largest shift <= cand whose k-gram is a node, probing
+// the global E bitmap level by level.  Shifts up to cs belong to complete levels and hit
+// without a probe; shift 0 (the root) always hits.
 __device__ __noinline__ uint32_t itop_resolve_slow(uint32_t hist, uint32_t cand, const uint32_t* Eg, uint32_t b, uint32_t cs) {
     uint32_t c = cand;
     for (;;) {
@@ -367,161 +376,262 @@ __device__ __noinline__ uint32_t itop_resolve_slow(uint32_t hist, uint32_t cand,
     return c;
 }
 
-// depth of the new state from the ND table (steady state) or the slow path; cand = deepest
-// shift the new state can have.  Returns the shift; ndw = the ND word (for the rank).
-__device__ __forceinline__ uint32_t itop_resolve(uint32_t hist, uint32_t valid, uint32_t cand, const ItopCtx& C, uint32_t& ndw) {
-    ndw = C.ND[hist >> 4];
-    const uint32_t f = (ndw >> ((hist & 15u) << 1)) & 3u;
-    if (valid >= C.D && f != 3u) return C.bD - __umul24(C.b, f);
-    uint32_t start = cand;
-    if (valid >= C.D) { const uint32_t lim = C.bD >= 3 * C.b ? C.bD - 3 * C.b : 0u; start = lim < cand ? lim : cand; }
-    return itop_resolve_slow(hist, start, C.Eg, C.b, C.cs);
+// raw cell of the level-D node `code`; decoded by itop_cell_first/bits AFTER the other loads of
+// the step have been issued (decoding inside the branch would make the wave wait right there)
+template <bool CELL8>
+__device__ __forceinline__ uint2 itop_load_cell(const uint32_t* cells, uint32_t code) {
+    if (CELL8) return ((const uint2*)cells)[code];
+    return make_uint2(cells[code], 0u);
+}
+template <bool CELL8>
+__device__ __forceinline__ uint32_t itop_cell_first(uint2 cw) { return CELL8 ? cw.x : (cw.x & 0xFFFFFFu); }
+// child mask in bits 0..15, child-has-outputs in bits 16..31
+template <bool CELL8>
+__device__ __forceinline__ uint32_t itop_cell_bits(uint2 cw) { return CELL8 ? cw.y : (((cw.x >> 24) & 15u) | ((cw.x >> 28) << 16)); }
+
+template <bool ESCAPE>
+__device__ __forceinline__ void itop_report(uint32_t e, uint32_t c, uint32_t idx, const ItopCtx& C, ItopLane& L) {
+    if (ESCAPE) {
+        if (c == ACX_ENTRY_CNT_ESCAPE(ACX_STATE_BITS_NARROW)) {
+            const uint32_t s = e & ACX_ENTRY_STATE_MASK(ACX_STATE_BITS_NARROW);
+            c = C.out_off[s + 1] - C.out_off[s];
+        }
+    }
+    store_event<true>(L.ev++, idx, e);
+    L.cnt += c;
 }
 
-// One input byte.  Phases are ordered so that the table gather of the lanes that hold an
-// explicit state is in flight while the other lanes of the wave do their LDS work:
-//   A  explicit lanes issue the gather                       (result not touched yet)
-//   B  implicit lanes: new depth from ND, outputs from H, hand-over rank
-//   C  explicit lanes consume the entry; those that fell into the implicit zone read ND too
-template <bool ESCAPE, bool GUARDED>
-__device__ __forceinline__ void itop_step(uint32_t c4, uint32_t idx, bool active, bool emit, const ItopCtx& C, ItopLane& L) {
+// One input byte, any situation (warm-up, bytes outside the key alphabet, ragged ends, halo).
+// sy = symbol of the byte, or ACX_ITOP_SYM_OTHER.
+template <bool ESCAPE, bool CELL8>
+__device__ __forceinline__ void itop_step(uint32_t sy, uint32_t idx, bool active, bool emit, const ItopCtx& C, ItopLane& L) {
     constexpr int SB = ACX_STATE_BITS_NARROW;
-    const uint32_t cls = c4 >> 2;
-    const bool other = C.has_other && cls == 0;                      // a byte no key contains: root, no output
-    const bool go = GUARDED ? (active && !other) : !other;
-    const bool expl = L.sh == ACX_ITOP_EXPL;
-    const uint32_t hist = ((L.hist << C.b) | (cls - C.has_other)) & C.maskD;
+    const bool other = (sy & ACX_ITOP_SYM_OTHER) != 0;              // a byte no key contains: root, no output
+    const bool go = active && !other;
+    const uint32_t sym = sy & (ACX_ITOP_SYM_OTHER - 1u);
+    const uint32_t hist = ((L.hist << C.b) | sym) & C.maskD;
+    const bool deep = L.sh == ACX_ITOP_EXPL, atD = L.sh == C.bD;
+    uint32_t e_tab = 0;
+    uint2 cw = make_uint2(0u, 0u);
+    if (go && deep) e_tab = load_entry<SB>(C.table_bytes, L.st, C.row_bytes, (sym + C.has_other) << 2);
+    if (go && atD) cw = itop_load_cell<CELL8>(C.cells, L.hist);
+    const uint32_t q = (C.ND[hist >> 3] >> ((hist & 7u) << 2)) & 15u;
+    const uint32_t cell_first = itop_cell_first<CELL8>(cw), cell_bits = itop_cell_bits<CELL8>(cw);
     const uint32_t valid = L.valid < C.D ? L.valid + 1 : L.valid;
-    uint32_t e = 0, e_tab = 0;
-    if (go && expl) e_tab = load_entry<SB>(C.table_bytes, L.st, C.row_bytes, c4);      // A
-    uint32_t new_sh = L.sh, new_st = L.st;
-    if (go && !expl) {                                                                  // B
-        uint32_t ndw;
-        const uint32_t c = itop_resolve(hist, valid, L.sh + C.b, C, ndw);
-        const uint32_t x = itop_x(hist, c);
-        if ((!GUARDED || emit) && c >= C.hmin) {                     // no node above level hmin has outputs
-            if ((C.H[(x >> 5) - C.h_first] >> (x & 31)) & 1u) e = C.ient[x];   // fetch its packed entry
+    uint32_t e = 0, new_sh = L.sh, new_st = L.st;
+    if (go) {
+        bool settled = false, own_out = false;                       // own_out: e already holds the target's outputs
+        if (deep) {
+            e = e_tab; own_out = true;
+            if ((e_tab & ACX_ENTRY_STATE_MASK(SB)) >= C.LD1) { new_st = e_tab; settled = true; }
+        } else if (atD && ((cell_bits >> sym) & 1u)) {               // a child on this symbol: depth D + 1
+            const uint32_t child = cell_first + (uint32_t)__popc(cell_bits & ((1u << sym) - 1u) & 0xFFFFu);
+            new_st = child; new_sh = ACX_ITOP_EXPL; settled = true; own_out = true;
+            if (emit && ((cell_bits >> (16 + sym)) & 1u)) e = child | C.tflags[child];
         }
-        if (c == C.bD) {                                             // hand over: id = first id of level D + #zero fields before
-            const uint32_t wi = hist >> 4;
-            const uint32_t z = ~(ndw | (ndw >> 1)) & 0x55555555u;
-            new_st = C.LD + C.rank32[wi >> 6] + C.rank16[wi] + (uint32_t)__popc(z & ((1u << ((hist & 15u) << 1)) - 1u));
-            new_sh = ACX_ITOP_EXPL;
-        } else {
-            new_sh = c;
-        }
-    }
-    if (go && expl) {                                                                   // C
-        e = e_tab;
-        if ((e_tab & ACX_ENTRY_STATE_MASK(SB)) >= C.LD) {
-            new_st = e_tab;
-        } else {                                                     // fell back into the implicit zone
-            uint32_t ndw;
-            new_sh = itop_resolve(hist, valid, C.bD - C.b, C, ndw);
+        if (!settled) {                                              // the new state is not deeper than D
+            const bool exact = valid >= C.D && (q & 3u) != 3u;       // steady state and not a deep fall: ND4 says it all
+            if (exact) new_sh = C.bD - __umul24(C.b, q & 3u);
+            else new_sh = itop_resolve_slow(hist, valid >= C.D ? C.bD - 3u * C.b : L.sh + C.b, C.Eg, C.b, C.cs);
+            if (!own_out && emit && new_sh && (!exact || (q >> 2))) e = C.ient[itop_x(hist, new_sh)];
         }
     }
-    if (GUARDED ? active : true) {
+    if (active) {
         L.hist = other ? 0u : hist;
         L.valid = other ? 0u : valid;
         L.sh = other ? 0u : new_sh;
         L.st = new_st;
     }
-    if ((!GUARDED || emit) && (e >> ACX_ENTRY_CNT_SHIFT(SB))) {
-        uint32_t c = e >> ACX_ENTRY_CNT_SHIFT(SB);
-        if (ESCAPE) {
-            if (c == ACX_ENTRY_CNT_ESCAPE(SB)) {
-                const uint32_t s = e & ACX_ENTRY_STATE_MASK(SB);
-                c = C.out_off[s + 1] - C.out_off[s];
-            }
+    if (emit && (e >> ACX_ENTRY_CNT_SHIFT(SB))) itop_report<ESCAPE>(e, e >> ACX_ENTRY_CNT_SHIFT(SB), idx, C, L);
+}
+
+// One input byte for each of the lane's ILP items in the steady state: every lane active and
+// reporting, D symbols seen since the last reset, no byte outside the key alphabet.
+template <bool ESCAPE, bool CELL8, int ILP>
+__device__ __forceinline__ void itop_fast_step(const uint32_t (&sym)[ILP], const uint32_t (&idx)[ILP], const ItopCtx& C, ItopLane (&L)[ILP]) {
+    constexpr int SB = ACX_STATE_BITS_NARROW;
+    uint32_t hist[ILP], ndw[ILP];
+    uint2 raw[ILP];
+    bool deep[ILP];
+#pragma unroll
+    for (int q = 0; q < ILP; q++) {                                  // issue: ONE load (table entry | cell) and the ND4 word
+        deep[q] = L[q].sh == ACX_ITOP_EXPL;
+        const bool atD = L[q].sh == C.bD;
+        // the vector-memory pipe charges per instruction, not per active lane:
+        // the two kinds of lanes share one load with per-lane addresses
+        const uint8_t* addr = deep[q] ? C.table_bytes + (__umul24(L[q].st, C.row_bytes) + ((sym[q] + C.has_other) << 2))
+                                      : (const uint8_t*)C.cells + (size_t)L[q].hist * (CELL8 ? 8u : 4u);
+        raw[q] = make_uint2(0u, 0u);
+        if (deep[q] || atD) {
+            if (CELL8) raw[q] = *(const uint2*)addr;
+            else raw[q].x = *(const uint32_t*)addr;
         }
-        store_event<true>(L.ev++, idx, e);
-        L.cnt += c;
+        hist[q] = ((L[q].hist << C.b) | sym[q]) & C.maskD;
+        ndw[q] = C.ND[hist[q] >> 3];
+    }
+#pragma unroll
+    for (int q = 0; q < ILP; q++) {
+        const uint32_t nib = ndw[q] >> ((hist[q] & 7u) << 2);       // low 4 bits: depth field, output class
+        const uint32_t e_tab_q = deep[q] ? raw[q].x : 0u;
+        const uint2 cw_q = deep[q] ? make_uint2(0u, 0u) : raw[q];
+        uint32_t sh_nd = C.bD - __umul24(C.b, nib & 3u);
+        const uint32_t oc = (nib >> 2) & 3u;                         // (0 when the depth field escapes)
+        const bool stay = deep[q] && (e_tab_q & ACX_ENTRY_STATE_MASK(SB)) >= C.LD1;
+        const uint32_t cell_bits = itop_cell_bits<CELL8>(cw_q);    // 0 unless the lane is at depth D
+        const bool kid = (cell_bits >> sym[q]) & 1u;
+        const uint32_t child = itop_cell_first<CELL8>(cw_q) + (uint32_t)__popc(cell_bits & ((1u << sym[q]) - 1u) & 0xFFFFu);
+        const bool esc = (nib & 3u) == 3u && !stay && !kid;          // fell below D - 2: probe (rare by the choice of D)
+        if (esc) sh_nd = itop_resolve_slow(hist[q], C.bD - 3u * C.b, C.Eg, C.b, C.cs);
+        L[q].hist = hist[q];
+        L[q].sh = (stay || kid) ? ACX_ITOP_EXPL : sh_nd;
+        L[q].st = stay ? e_tab_q : child;                           // read only while sh == EXPL
+        // outputs: deep lanes carry them in the entry; a shallow node with exactly one output is
+        // reported as its pseudo state; the rest (child with outputs, several outputs) fetches
+        uint32_t ev_e = deep[q] ? e_tab_q : itop_x(hist[q], sh_nd) + C.pseudo1;
+        uint32_t ev_c = deep[q] ? e_tab_q >> ACX_ENTRY_CNT_SHIFT(SB) : ((!kid && oc == 1u) ? 1u : 0u);
+        const bool fetch = !deep[q] && (kid ? ((cell_bits >> (16 + sym[q])) & 1u) != 0 : (oc == 2u || (esc && sh_nd)));
+        if (fetch) {
+            ev_e = kid ? (child | C.tflags[child]) : C.ient[itop_x(hist[q], sh_nd)];
+            ev_c = ev_e >> ACX_ENTRY_CNT_SHIFT(SB);
+        }
+        if (ev_c) itop_report<ESCAPE>(ev_e, ev_c, idx[q], C, L[q]);
     }
 }
 
-template <bool ESCAPE>
+template <bool ESCAPE, bool CELL8, int ILP, int HB, bool HNT>
 __global__ void __launch_bounds__(ACX_ITOP_BLOCK) k_walk_itop(const acx_walk_args a, const acx_chunk_desc* ck,
                                                              const int64_t* n_chunks_dev, const uint32_t* itop_lds,
                                                              uint32_t itop_words, const uint32_t* itop_entry,
-                                                             const uint32_t* itop_ebits) {
+                                                             const uint32_t* itop_ebits, const uint32_t* itop_cells,
+                                                             const uint32_t* tflags) {
     extern __shared__ __attribute__((aligned(16))) uint32_t s_mem[];
-    uint32_t* s_cls4 = s_mem + ((itop_words + 3) & ~3u);
-    for (uint32_t i = threadIdx.x; i < itop_words; i += ACX_ITOP_BLOCK) s_mem[i] = itop_lds[i];
-    if (threadIdx.x < 256) s_cls4[threadIdx.x] = (uint32_t)a.cls[threadIdx.x] * 4u;
+    uint32_t* s_sym = s_mem + ((itop_words + 3) & ~3u);              // byte -> symbol, or ACX_ITOP_SYM_OTHER
+    for (uint32_t i = threadIdx.x; i < itop_words; i += blockDim.x) s_mem[i] = itop_lds[i];
+    __syncthreads();
+    if (threadIdx.x < 256) {
+        const uint32_t cl = a.cls[threadIdx.x], ho = s_mem[5];
+        s_sym[threadIdx.x] = (ho && cl == 0) ? ACX_ITOP_SYM_OTHER : cl - ho;
+    }
     __syncthreads();
 
     ItopCtx C;
-    C.ient = itop_entry; C.Eg = itop_ebits; C.table_bytes = (const uint8_t*)a.table; C.out_off = a.out_off; C.row_bytes = a.row_bytes;
-    C.b = s_mem[0]; C.D = s_mem[1]; C.bD = s_mem[0] * s_mem[1]; C.LD = s_mem[2]; C.has_other = s_mem[5]; C.maskD = s_mem[7];
-    C.rank16 = (const uint16_t*)(s_mem + s_mem[3]);
-    C.rank32 = s_mem + s_mem[4];
-    C.ND = s_mem + s_mem[8]; C.H = s_mem + s_mem[9];
-    C.cs = s_mem[11]; C.hmin = s_mem[12]; C.h_first = s_mem[13];
+    C.ient = itop_entry; C.Eg = itop_ebits; C.cells = itop_cells; C.tflags = tflags; C.table_bytes = (const uint8_t*)a.table; C.out_off = a.out_off; C.row_bytes = a.row_bytes;
+    C.b = s_mem[0]; C.D = s_mem[1]; C.bD = s_mem[0] * s_mem[1]; C.LD1 = s_mem[2]; C.has_other = s_mem[5]; C.maskD = s_mem[7];
+    C.pseudo1 = s_mem[4] | (1u << ACX_ENTRY_CNT_SHIFT(ACX_STATE_BITS_NARROW));
+    C.ND = s_mem + s_mem[8];
+    C.cs = s_mem[11];
 
     const int lane = threadIdx.x & (ACX_WAVE - 1);
     const int64_t n_items = ck ? *n_chunks_dev : a.n_hay;
-    const int64_t n_tasks = (n_items + ACX_WAVE - 1) / ACX_WAVE;
-    const int64_t wave0 = (int64_t)blockIdx.x * (ACX_ITOP_BLOCK / ACX_WAVE) + (threadIdx.x / ACX_WAVE);
-    const int64_t n_waves = (int64_t)gridDim.x * (ACX_ITOP_BLOCK / ACX_WAVE);
+    const int64_t per_task = (int64_t)ACX_WAVE * ILP;
+    const int64_t n_tasks = (n_items + per_task - 1) / per_task;
+    const int64_t wave0 = (int64_t)blockIdx.x * (blockDim.x / ACX_WAVE) + (threadIdx.x / ACX_WAVE);
+    const int64_t n_waves = (int64_t)gridDim.x * (blockDim.x / ACX_WAVE);
     const uint8_t* limit = a.hay + a.hay_cap;
 
     for (int64_t task = wave0; task < n_tasks; task += n_waves) {
-        const int64_t c = task * ACX_WAVE + lane;
-        const bool valid = c < n_items;
-        acx_chunk_desc d;
-        d.start = 0; d.emit = 0; d.len = 0; d.idx0 = 0; d.hay = 0; d.flags = 0; d.pad = 0;
-        if (valid) {
-            if (ck) d = ck[c];
-            else {
-                const int64_t b0 = a.off ? a.off[c] : c * a.stride;
-                const int64_t e0 = a.off ? a.off[c + 1] : b0 + a.stride;
-                d.start = b0; d.len = (int32_t)(e0 - b0); d.hay = (int32_t)c; d.flags = 3;
-                d.idx0 = a.index_base ? a.index_base[c] : 0;
+        int64_t item[ILP];
+        bool ok[ILP];
+        acx_chunk_desc d[ILP];
+        const uint8_t* p[ILP];
+        ItopLane L[ILP];
+        uint2* ev0[ILP];
+#pragma unroll
+        for (int q = 0; q < ILP; q++) {
+            item[q] = task * per_task + q * ACX_WAVE + lane;
+            ok[q] = item[q] < n_items;
+            d[q].start = 0; d[q].emit = 0; d[q].len = 0; d[q].idx0 = 0; d[q].hay = 0; d[q].flags = 0; d[q].pad = 0;
+            if (ok[q]) {
+                if (ck) d[q] = ck[item[q]];
+                else {
+                    const int64_t b0 = a.off ? a.off[item[q]] : item[q] * a.stride;
+                    const int64_t e0 = a.off ? a.off[item[q] + 1] : b0 + a.stride;
+                    d[q].start = b0; d[q].len = (int32_t)(e0 - b0); d[q].hay = (int32_t)item[q]; d[q].flags = 3;
+                    d[q].idx0 = a.index_base ? a.index_base[item[q]] : 0;
+                }
             }
+            p[q] = a.hay + d[q].start;
+            L[q].st = 0; L[q].sh = 0; L[q].hist = 0; L[q].valid = 0; L[q].cnt = 0;
+            L[q].ev = a.events + d[q].start + d[q].emit;
+            ev0[q] = L[q].ev;
         }
-        const uint8_t* p = a.hay + d.start;
-        const int len = d.len, emit = d.emit;
-        ItopLane L;
-        L.st = 0; L.sh = 0; L.hist = 0; L.valid = 0; L.cnt = 0;
-        L.ev = a.events + d.start + emit;
-        uint2* const ev0 = L.ev;
-        const uint32_t base = (uint32_t)d.idx0;
 
-        for (int j0 = 0;; j0 += 16) {
-            const int rem = len - j0;
-            if (!__any(rem > 0)) break;
-            if (rem > 0) {
-                const uint4 w = load16_guarded<false>(p + j0, limit);
-                const bool fast = __all(rem >= 16 && j0 >= emit);   // full block, every step reports
-                // one dword (4 steps) per iteration, NOT unrolled: the step body is large and the
-                // instruction cache is shared; the class lookups of a dword go first
+        // The haystack is fetched HB x 16 bytes per lane at a time: lane-per-haystack means every
+        // lane streams its own cache line, a line is re-read 16 bytes at a time ~20 us apart and is
+        // usually evicted in between; 64 bytes per visit cut those re-fetches.
+        // (Non-temporal loads were measured slower: HNT stays a diagnostic switch.)
+        for (int j0 = 0;; j0 += 16 * HB) {
+            bool more = false;
+#pragma unroll
+            for (int q = 0; q < ILP; q++) more = more || d[q].len - j0 > 0;
+            if (!__any(more)) break;
+            uint4 wq[ILP][HB];
+#pragma unroll
+            for (int q = 0; q < ILP; q++)
+#pragma unroll
+                for (int t = 0; t < HB; t++) {
+                    wq[q][t] = make_uint4(0, 0, 0, 0);
+                    if (d[q].len - (j0 + 16 * t) > 0) wq[q][t] = load16_guarded<HNT>(p[q] + j0 + 16 * t, limit);
+                }
+#pragma unroll 1
+            for (int t = 0; t < HB; t++) {                           // 16-byte blocks; the buffer rotates, indices stay constant
+                const int jb = j0 + 16 * t;
+                bool blk_more = false, full = true;
+                uint4 w[ILP];
+#pragma unroll
+                for (int q = 0; q < ILP; q++) {
+                    blk_more = blk_more || d[q].len - jb > 0;
+                    full = full && d[q].len - jb >= 16 && jb >= d[q].emit;
+                    w[q] = wq[q][0];
+#pragma unroll
+                    for (int u = 0; u + 1 < HB; u++) wq[q][u] = wq[q][u + 1];
+                }
+                if (!__any(blk_more)) break;
+                const bool blk_full = __all(full);                   // full block for every item, every step reports
+                // one dword (4 steps) per iteration, NOT unrolled: the instruction cache is shared
 #pragma unroll 1
                 for (int k = 0; k < 4; k++) {
-                    const uint32_t wk = k == 0 ? w.x : (k == 1 ? w.y : (k == 2 ? w.z : w.w));
-                    uint32_t c4[4];
+                    uint32_t sy[ILP][4];
+                    bool steady = true;
 #pragma unroll
-                    for (int i = 0; i < 4; i++) c4[i] = s_cls4[(wk >> (i * 8)) & 0xffu];
-                    if (fast) {
+                    for (int q = 0; q < ILP; q++) {
+                        const uint32_t wk = k == 0 ? w[q].x : (k == 1 ? w[q].y : (k == 2 ? w[q].z : w[q].w));
 #pragma unroll
-                        for (int i = 0; i < 4; i++) itop_step<ESCAPE, false>(c4[i], base + j0 + k * 4 + i, true, true, C, L);
-                    } else {
+                        for (int i = 0; i < 4; i++) sy[q][i] = s_sym[(wk >> (i * 8)) & 0xffu];
+                        steady = steady && L[q].valid >= C.D && !((sy[q][0] | sy[q][1] | sy[q][2] | sy[q][3]) & ACX_ITOP_SYM_OTHER);
+                    }
+                    if (blk_full && __all(steady)) {
 #pragma unroll
                         for (int i = 0; i < 4; i++) {
-                            const int j = j0 + k * 4 + i;
-                            itop_step<ESCAPE, true>(c4[i], base + j, j < len, j >= emit, C, L);
+                            uint32_t s1[ILP], ix[ILP];
+#pragma unroll
+                            for (int q = 0; q < ILP; q++) { s1[q] = sy[q][i]; ix[q] = (uint32_t)d[q].idx0 + jb + k * 4 + i; }
+                            itop_fast_step<ESCAPE, CELL8, ILP>(s1, ix, C, L);
+                        }
+                    } else {
+#pragma unroll
+                        for (int q = 0; q < ILP; q++) {
+#pragma unroll 1
+                            for (int i = 0; i < 4; i++) {
+                                const int j = jb + k * 4 + i;
+                                itop_step<ESCAPE, CELL8>(sy[q][i], (uint32_t)d[q].idx0 + j, j < d[q].len, j < d[q].len && j >= d[q].emit, C, L[q]);
+                            }
                         }
                     }
                 }
             }
         }
-        if (valid) {
-            a.counts[c] = (int32_t)L.cnt;
-            a.nev[c] = (int32_t)(L.ev - ev0);
-            if (a.final_state && (d.flags & 2)) {
-                uint32_t fs = 0;
-                if (L.sh == ACX_ITOP_EXPL) fs = L.st & ACX_ENTRY_STATE_MASK(ACX_STATE_BITS_NARROW);
-                else if (L.sh > 0) fs = itop_entry[itop_x(L.hist, L.sh)] & ACX_ENTRY_STATE_MASK(ACX_STATE_BITS_NARROW);
-                a.final_state[d.hay] = (int32_t)fs;
+#pragma unroll
+        for (int q = 0; q < ILP; q++) {
+            if (ok[q]) {
+                a.counts[item[q]] = (int32_t)L[q].cnt;
+                a.nev[item[q]] = (int32_t)(L[q].ev - ev0[q]);
+                if (a.final_state && (d[q].flags & 2)) {
+                    uint32_t fs = 0;
+                    if (L[q].sh == ACX_ITOP_EXPL) fs = L[q].st & ACX_ENTRY_STATE_MASK(ACX_STATE_BITS_NARROW);
+                    else if (L[q].sh > 0) fs = itop_entry[itop_x(L[q].hist, L[q].sh)] & ACX_ENTRY_STATE_MASK(ACX_STATE_BITS_NARROW);
+                    a.final_state[d[q].hay] = (int32_t)fs;
+                }
             }
         }
     }
@@ -766,6 +876,7 @@ __global__ void __launch_bounds__(ACX_BLOCK) k_expand(const acx_expand_args a) {
                 const uint2 v = ev[k];
                 const uint32_t s = v.y & state_mask;
                 uint32_t c = v.y >> cnt_shift;
+                if (c == 1) { *out++ = make_uint2(v.x, (uint32_t)a.first_val[s]); continue; }   // s may be a pseudo state (itop)
                 const uint32_t o = a.out_off[s];
                 if (c == cnt_escape) c = a.out_off[s + 1] - o;
                 for (uint32_t r = 0; r < c; r++) *out++ = make_uint2(v.x, (uint32_t)a.out_val[o + r]);
@@ -972,29 +1083,47 @@ hipError_t acx_launch_hay_offsets(const int64_t* ck_first, const int64_t* ck_mat
     return hipGetLastError();
 }
 
+// tune: bits 0-1 = items per lane - 1 (0 or 1); bit 2 = non-temporal instead of cached haystack loads (slower: measured);
+// bits 4-5 = haystack bytes fetched per lane at a time (0: 64 (32 with 2 items per lane), 1: 16, 2: 32, 3: 64)
 hipError_t acx_launch_walk_itop(const acx_walk_args& a, const acx_chunk_desc* ck, const int64_t* n_chunks_dev,
                                 int64_t n_items_bound, bool has_escape, const uint32_t* itop_lds, uint32_t itop_words,
-                                const uint32_t* itop_entry, const uint32_t* itop_ebits, hipStream_t s) {
+                                const uint32_t* itop_entry, const uint32_t* itop_ebits, const void* itop_cells,
+                                const uint32_t* tflags, uint32_t cell_bytes, int tune, hipStream_t s) {
     if (n_items_bound <= 0) return hipSuccess;
     const size_t lds_bytes = (size_t)((itop_words + 3) & ~3u) * 4 + 1024;
-    if (lds_bytes > 160 * 1024) return hipErrorInvalidValue;
+    if (lds_bytes > 160 * 1024 || (cell_bytes != 4 && cell_bytes != 8)) return hipErrorInvalidValue;
+    const int ilp = (tune & 3) == 1 ? 2 : 1;
+    const bool cached = !((tune >> 2) & 1);
+    int hb = (tune >> 4) & 3;
+    hb = hb == 0 ? (ilp == 2 ? 2 : 4) : (hb == 1 ? 1 : (hb == 2 ? 2 : 4));
+    if (ilp == 2 && hb == 4) hb = 2;                              // register budget: 1024 threads -> 128 VGPRs
     const int bpc = lds_bytes * 2 <= 160 * 1024 ? 2 : 1;          // 1024-thread blocks: at most 2 per CU
-    const int64_t waves_per_block = ACX_ITOP_BLOCK / ACX_WAVE;
-    const int64_t n_tasks = (n_items_bound + ACX_WAVE - 1) / ACX_WAVE;
+    int threads = ACX_ITOP_BLOCK;
+    if (const char* tv = getenv("ACX_ITOP_THREADS")) { const int v = atoi(tv); if (v == 256 || v == 512 || v == 768) threads = v; }   // occupancy experiments
+    const int64_t waves_per_block = threads / ACX_WAVE;
+    const int64_t n_tasks = (n_items_bound + ACX_WAVE * ilp - 1) / (ACX_WAVE * ilp);
     int64_t blocks = (n_tasks + waves_per_block - 1) / waves_per_block;
     if (blocks > 256 * bpc) blocks = 256 * bpc;
     if (blocks < 1) blocks = 1;
-    hipError_t e;
-    if (has_escape) {
-        e = hipFuncSetAttribute((const void*)k_walk_itop<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+    auto launch = [&](auto kernel) -> hipError_t {
+        hipError_t e = hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
         if (e != hipSuccess) return e;
-        hipLaunchKernelGGL(k_walk_itop<true>, dim3((unsigned)blocks), dim3(ACX_ITOP_BLOCK), lds_bytes, s, a, ck, n_chunks_dev,
-                           itop_lds, itop_words, itop_entry, itop_ebits);
-    } else {
-        e = hipFuncSetAttribute((const void*)k_walk_itop<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
-        if (e != hipSuccess) return e;
-        hipLaunchKernelGGL(k_walk_itop<false>, dim3((unsigned)blocks), dim3(ACX_ITOP_BLOCK), lds_bytes, s, a, ck, n_chunks_dev,
-                           itop_lds, itop_words, itop_entry, itop_ebits);
-    }
-    return hipGetLastError();
+        hipLaunchKernelGGL(kernel, dim3((unsigned)blocks), dim3(threads), lds_bytes, s, a, ck, n_chunks_dev,
+                           itop_lds, itop_words, itop_entry, itop_ebits, (const uint32_t*)itop_cells, tflags);
+        return hipGetLastError();
+    };
+#define ACX_ITOP_CASE(E, C8) \
+    do { \
+        if (ilp == 2) { \
+            if (hb == 1) return cached ? launch(k_walk_itop<E, C8, 2, 1, false>) : launch(k_walk_itop<E, C8, 2, 1, true>); \
+            return cached ? launch(k_walk_itop<E, C8, 2, 2, false>) : launch(k_walk_itop<E, C8, 2, 2, true>); \
+        } \
+        if (hb == 1) return cached ? launch(k_walk_itop<E, C8, 1, 1, false>) : launch(k_walk_itop<E, C8, 1, 1, true>); \
+        if (hb == 2) return cached ? launch(k_walk_itop<E, C8, 1, 2, false>) : launch(k_walk_itop<E, C8, 1, 2, true>); \
+        return cached ? launch(k_walk_itop<E, C8, 1, 4, false>) : launch(k_walk_itop<E, C8, 1, 4, true>); \
+    } while (0)
+    if (has_escape) { if (cell_bytes == 8) ACX_ITOP_CASE(true, true); else ACX_ITOP_CASE(true, false); }
+    else            { if (cell_bytes == 8) ACX_ITOP_CASE(false, true); else ACX_ITOP_CASE(false, false); }
+#undef ACX_ITOP_CASE
+    return hipErrorInvalidValue;
 }

@@ -300,39 +300,32 @@ int acx_flatten(const acx_trie_t* t, void** blob_out, size_t* nbytes_out) {
     if (n_used == 256) { K = 256; for (int b = 0; b < 256; b++) cls[b] = (uint8_t)b; }
     else { K = n_used + 1; unsigned k = 1; for (int b = 0; b < 256; b++) cls[b] = used[b] ? (uint8_t)k++ : 0; }
 
-    const size_t table_entries = n * (size_t)K;
     // narrow layout whenever it fits: 24-bit states and 32-bit byte offsets into the table
     // (ACX_FORCE_WIDE_LAYOUT=1 forces the wide layout on small automata: test hook)
     const char* force_wide = getenv("ACX_FORCE_WIDE_LAYOUT");
-    const uint32_t SB = (n < ((size_t)1 << ACX_STATE_BITS_NARROW) && table_entries * 4 < ((size_t)1 << 32) &&
-                         !(force_wide && force_wide[0] == '1'))
-                            ? ACX_STATE_BITS_NARROW : ACX_STATE_BITS_WIDE;
+    auto narrow_fits = [&](size_t rows) -> bool {
+        return rows < ((size_t)1 << ACX_STATE_BITS_NARROW) && rows * (size_t)K * 4 < ((size_t)1 << 32);
+    };
+    const uint32_t SB = (narrow_fits(n) && !(force_wide && force_wide[0] == '1')) ? ACX_STATE_BITS_NARROW : ACX_STATE_BITS_WIDE;
     const uint32_t ESC = ACX_ENTRY_CNT_ESCAPE(SB);
 
     // 1b. state numbering and the implicit top-of-trie (include/acx_blob.h "itop").
-    //     Numbering = BFS order, except that levels 1..D are re-sorted by k-gram code so that
-    //     a level-D node's id is first_id(D) + rank of its code.  Any order that keeps shallower
-    //     states at smaller ids works for everything below (fail(s) is always shallower).
+    //     Numbering = BFS order, except that levels 1..D+1 are re-sorted by k-gram code (any order
+    //     that keeps shallower states at smaller ids works for everything below: fail(s) is
+    //     always shallower), so the children of a level-D node are consecutive, in symbol order.
     const bool has_other = n_used != 256;
-    uint32_t itop_b = 1, itop_D = 0;
-    { const uint32_t sigma = has_other ? K - 1 : 256; while ((1u << itop_b) < sigma) itop_b++; }
+    const uint32_t sigma = has_other ? K - 1 : 256;
+    uint32_t itop_b = 1, itop_D = 0, itop_complete = 0;
+    while ((1u << itop_b) < sigma) itop_b++;
     std::vector<int32_t> order;       // position (= state id) -> arena index
-    std::vector<uint32_t> acode;      // arena index -> code (valid for depth <= D)
+    std::vector<uint32_t> acode;      // arena index -> code (valid for depth <= D + 1)
     std::vector<int32_t> adepth;      // arena index -> depth
-    std::vector<uint32_t> lvl_first;  // first id of depth d, d = 0..D+1
-    // one bitmap addresses every level: node (d, code) lives at bit (1 << b*d) | code
+    std::vector<uint32_t> lvl_first;  // first id of depth d, d = 0..D+2
+    // one bitmap addresses levels 0..D: node (d, code) lives at bit (1 << b*d) | code
     auto itop_bm_words = [&](uint32_t D) -> size_t { return (size_t)((2ull << (itop_b * D)) / 32); };   // needs b*D >= 5
-    auto itop_lvlD_words = [&](uint32_t D) -> size_t { return (size_t)((1ull << (itop_b * D)) / 32); };
-    uint32_t hmin_level = 0xFFFFu;    // shallowest level that has a node with outputs = the shortest key
-    // H covers sentinel words from the first word of level hmin on (no outputs above it)
-    auto itop_h_words = [&](uint32_t D, uint32_t hmin) -> size_t {
-        if (hmin > D) return 0;
-        return itop_bm_words(D) - (size_t)((1ull << (itop_b * hmin)) >> 5);
-    };
-    auto itop_nd_words = [&](uint32_t D) -> size_t { return (size_t)((1ull << (itop_b * D)) / 16); };   // 2 bits per history
-    auto itop_cost = [&](uint32_t D) -> size_t {      // LDS image size in words: header, ND, H, rank16, rank32
-        return ACX_ITOP_HDR_WORDS + itop_nd_words(D) + itop_h_words(D, hmin_level) + (itop_nd_words(D) + 1) / 2 +
-               itop_nd_words(D) / 64 + 1;
+    auto itop_nd_words = [&](uint32_t D) -> size_t { return (size_t)((1ull << (itop_b * D)) / 8); };    // 4 bits per history
+    auto itop_cost = [&](uint32_t D) -> size_t {      // LDS image size in words: header, ND4
+        return ACX_ITOP_HDR_WORDS + itop_nd_words(D);
     };
     try {
         order = t->bfs;
@@ -343,26 +336,38 @@ int acx_flatten(const acx_trie_t* t, void** blob_out, size_t* nbytes_out) {
                 adepth[ch] = adepth[order[i]] + 1;
                 if (adepth[ch] > max_depth) max_depth = adepth[ch];
             }
-        for (size_t i = 1; i < n; i++)
-            if (t->nodes[order[i]].eow && (uint32_t)adepth[order[i]] < hmin_level) hmin_level = (uint32_t)adepth[order[i]];
         const size_t budget_words = (size_t)156 * 1024 / 4;          // of the CU's 160 KiB of LDS (+1 KiB class map)
         const char* no_itop = getenv("ACX_NO_ITOP");
-        if (SB == ACX_STATE_BITS_NARROW && !(no_itop && no_itop[0] == '1')) {
-            while (itop_D < ACX_ITOP_MAX_LEVELS && (int32_t)itop_D < max_depth && itop_b * (itop_D + 1) <= 24 &&
+        if (SB == ACX_STATE_BITS_NARROW && sigma <= 16 && !(no_itop && no_itop[0] == '1')) {
+            // complete levels: every k-gram over the key alphabet is a node (the warm-up path needs
+            // no probe there).  dense levels: at least 95 % of them are.  In the steady state the
+            // automaton is hardly ever shallower than the last dense level, so with D <= dense + 2
+            // the 2-bit depth field of ND4 (D - depth: 0, 1, 2; 3 = shallower, resolved by probing)
+            // almost never escapes.
+            std::vector<uint64_t> per_level((size_t)max_depth + 1, 0);
+            for (size_t i = 0; i < n; i++) per_level[adepth[order[i]]]++;
+            uint64_t full = 1;
+            while ((int32_t)itop_complete < max_depth && full * sigma == per_level[itop_complete + 1]) { full *= sigma; itop_complete++; }
+            uint32_t dense = itop_complete;
+            while ((int32_t)dense < max_depth && full <= ((uint64_t)1 << 40) && per_level[dense + 1] * 100 >= full * sigma * 95) { full *= sigma; dense++; }
+            // deepest such D whose ND4 fits LDS, whose codes of level D+1 fit 24 bits and whose
+            // pseudo states (n + sentinel index, see first_val) fit the state field
+            while (itop_D < ACX_ITOP_MAX_LEVELS && (int32_t)itop_D < max_depth && itop_D < dense + 2 &&
+                   itop_b * (itop_D + 2) <= 24 && n + ((size_t)2 << (itop_b * (itop_D + 1))) < ((size_t)1 << ACX_STATE_BITS_NARROW) &&
                    (itop_b * (itop_D + 1) < 5 || itop_cost(itop_D + 1) <= budget_words))
                 itop_D++;
-            if (itop_b * itop_D < 5) itop_D = 0;      // a trie this small does not need it (and rank needs whole words)
+            if (itop_b * itop_D < 5) itop_D = 0;      // a trie this small does not need it (ND4 needs whole words)
         }
         if (itop_D > 0) {
             acode.assign(t->nodes.size(), 0);
-            lvl_first.assign(itop_D + 2, (uint32_t)n);
-            for (size_t i = n; i-- > 0;) { const int32_t d = adepth[order[i]]; if (d <= (int32_t)itop_D + 1) lvl_first[d] = (uint32_t)i; }
-            for (uint32_t d = itop_D + 1; d-- > 0;) if (lvl_first[d] > lvl_first[d + 1]) lvl_first[d] = lvl_first[d + 1];
-            for (size_t i = 0; i < lvl_first[itop_D]; i++)               // parents at depth < D
-                for (int32_t ch = t->nodes[order[i]].first_child; ch >= 0; ch = t->nodes[ch].next_sibling)
-                    acode[ch] = (acode[order[i]] << itop_b) | (uint32_t)(cls[t->nodes[ch].letter] - (has_other ? 1 : 0));
-            for (uint32_t d = 1; d <= itop_D; d++) {
-                // parents of level d were re-sorted in the previous round: codes are final before sorting
+            lvl_first.assign(itop_D + 3, (uint32_t)n);
+            for (size_t i = n; i-- > 0;) { const int32_t d = adepth[order[i]]; if (d <= (int32_t)itop_D + 2) lvl_first[d] = (uint32_t)i; }
+            for (uint32_t d = itop_D + 2; d-- > 0;) if (lvl_first[d] > lvl_first[d + 1]) lvl_first[d] = lvl_first[d + 1];
+            for (uint32_t d = 1; d <= itop_D + 1; d++) {
+                // parents (level d-1) already have their final code and position
+                for (size_t i = lvl_first[d - 1]; i < lvl_first[d]; i++)
+                    for (int32_t ch = t->nodes[order[i]].first_child; ch >= 0; ch = t->nodes[ch].next_sibling)
+                        acode[ch] = (acode[order[i]] << itop_b) | (uint32_t)(cls[t->nodes[ch].letter] - (has_other ? 1 : 0));
                 std::sort(order.begin() + lvl_first[d], order.begin() + lvl_first[d + 1],
                           [&](int32_t a, int32_t b2) { return acode[a] < acode[b2]; });
             }
@@ -399,6 +404,8 @@ int acx_flatten(const acx_trie_t* t, void** blob_out, size_t* nbytes_out) {
     // Where is the dense table built?  On the host (it is then part of the blob) or on the device
     // from the sparse edge lists (the blob is ~K x smaller; acx_image_upload/adopt run the build
     // kernels).  ACX_FLATTEN_TABLE=host|device overrides; default: device once it exceeds 64 MiB.
+    const size_t table_entries = n * (size_t)K;
+    const uint32_t itop_cell_bytes = itop_D ? (sigma <= 4 ? 4u : 8u) : 0u;
     const char* tbl_env = getenv("ACX_FLATTEN_TABLE");
     bool table_in_blob = table_entries * 4 < ((size_t)64 << 20);
     if (tbl_env && !strcmp(tbl_env, "host")) table_in_blob = true;
@@ -420,7 +427,11 @@ int acx_flatten(const acx_trie_t* t, void** blob_out, size_t* nbytes_out) {
     h.off_node_flags = off; off = align_up(off + n);
     h.off_out_off = off;    off = align_up(off + (n + 1) * 4);
     h.off_out_val = off;    off = align_up(off + (size_t)n_out * 4 + 4);
-    h.off_first_val = off;  off = align_up(off + n * 4);
+    // first_val has an entry per state and, with an itop, one per implicit node after them
+    // ("pseudo state" n + x for sentinel index x): the walk reports an implicit node that has
+    // exactly one output as that pseudo state with count 1 and never fetches its real entry
+    const size_t itop_nx = itop_D ? (size_t)2 << (itop_b * itop_D) : 0;
+    h.off_first_val = off;  off = align_up(off + (n + itop_nx) * 4);
     size_t itop_lds_words = 0, itop_entries = 0;
     if (itop_D > 0) {
         itop_lds_words = itop_cost(itop_D);
@@ -428,6 +439,7 @@ int acx_flatten(const acx_trie_t* t, void** blob_out, size_t* nbytes_out) {
         h.off_itop_lds = off;    off = align_up(off + itop_lds_words * 4);
         h.off_itop_entry = off;  off = align_up(off + itop_entries * 4);
         h.off_itop_ebits = off;  off = align_up(off + itop_bm_words(itop_D) * 4);
+        h.off_itop_cells = off;  off = align_up(off + ((size_t)itop_cell_bytes << (itop_b * itop_D)));
     }
     const size_t total = off;
 
@@ -509,64 +521,62 @@ int acx_flatten(const acx_trie_t* t, void** blob_out, size_t* nbytes_out) {
         }
     }
 
-    // 5. implicit top-of-trie: existence / has-output bitmaps per level, rank tables of level D,
-    //    and the packed entry of every implicit node (include/acx_blob.h)
+    // 5. implicit top-of-trie: ND4 (LDS), the existence bitmap and the packed entry of every
+    //    implicit node (global)  (include/acx_blob.h)
     if (itop_D > 0) {
         uint32_t* lds = (uint32_t*)(blob + h.off_itop_lds);
         uint32_t* ient = (uint32_t*)(blob + h.off_itop_entry);
         uint32_t* E = (uint32_t*)(blob + h.off_itop_ebits);       // global: slow path only
-        const size_t ndw = itop_nd_words(itop_D);
-        const size_t hw = itop_h_words(itop_D, hmin_level);
-        const size_t h_first = hw ? (size_t)((1ull << (itop_b * hmin_level)) >> 5) : 0;   // sentinel word where H starts
-        const size_t ndb = ACX_ITOP_HDR_WORDS, hb = ndb + ndw;
+        const size_t ndb = ACX_ITOP_HDR_WORDS;
         E[0] |= 1u << 1;                                          // the root: (d = 0, code = 0) -> bit 1
-        uint32_t complete = 0;                                    // levels 1..complete hold every possible k-gram
-        {
-            const uint64_t sigma = has_other ? K - 1 : 256;
-            uint64_t full = 1;
-            for (uint32_t d = 1; d <= itop_D; d++) {
-                full *= sigma;
-                if ((uint64_t)(lvl_first[d + 1] - lvl_first[d]) == full && complete == d - 1) complete = d;
-            }
-        }
+        const uint32_t complete = itop_complete < itop_D ? itop_complete : itop_D;   // levels 1..complete hold every k-gram
         for (uint32_t d = 1; d <= itop_D; d++) {
             for (uint32_t i = lvl_first[d]; i < lvl_first[d + 1]; i++) {
                 const uint32_t x = (1u << (itop_b * d)) | acode[order[i]];     // sentinel index
                 E[x >> 5] |= 1u << (x & 31);
-                if (out_cnt[i]) lds[hb + (x >> 5) - h_first] |= 1u << (x & 31);
                 ient[x] = i | tflags[i];
             }
         }
-        // ND: for every history of D symbols, how far below D the longest k-gram node ending here is
+        // ND4: for every history of D symbols, how far below D the longest k-gram node ending
+        // here is (0..2; 3 = more: resolved by probing E) and its outputs (0 none, 1 exactly one, 2 more)
         const uint32_t n_hist = 1u << (itop_b * itop_D);
         for (uint32_t hh = 0; hh < n_hist; hh++) {
-            uint32_t dd = itop_D;
+            uint32_t dd = itop_D, x = 1;
             for (;; dd--) {
-                const uint32_t x = (1u << (itop_b * dd)) | (hh & ((1u << (itop_b * dd)) - 1u));
+                x = (1u << (itop_b * dd)) | (hh & ((1u << (itop_b * dd)) - 1u));
                 if ((E[x >> 5] >> (x & 31)) & 1u) break;          // dd = 0 (the root) always exists
             }
-            const uint32_t f = itop_D - dd > 2 ? 3u : itop_D - dd;
-            lds[ndb + (hh >> 4)] |= f << ((hh & 15) * 2);
+            const uint32_t oc = dd == 0 ? 0 : out_cnt[ient[x] & ACX_ENTRY_STATE_MASK(SB)];
+            const uint32_t q = itop_D - dd > 2 ? 3u : ((itop_D - dd) | ((oc > 2 ? 2u : oc) << 2));   // 3: shallower than D - 2
+            lds[ndb + (hh >> 3)] |= q << ((hh & 7) * 4);
         }
-        // rank of level D = number of ND fields equal to 0 before a history; 64-word superblocks
-        const size_t r16 = hb + hw, r32 = r16 + (ndw + 1) / 2;
-        uint16_t* rank16 = (uint16_t*)(lds + r16);
-        uint32_t* rank32 = lds + r32;
-        uint32_t run = 0, in_sb = 0;
-        for (size_t k = 0; k < ndw; k++) {
-            if ((k & 63) == 0) { rank32[k >> 6] = run; in_sb = 0; }
-            rank16[k] = (uint16_t)in_sb;
-            const uint32_t w = lds[ndb + k];
-            const uint32_t pc = (uint32_t)__builtin_popcount(~(w | (w >> 1)) & 0x55555555u);
-            run += pc; in_sb += pc;
+        // pseudo states: first_val[n + x] = the first output of implicit node x
+        for (uint32_t d = 1; d <= itop_D; d++)
+            for (uint32_t i = lvl_first[d]; i < lvl_first[d + 1]; i++)
+                first_val[n + ((1u << (itop_b * d)) | acode[order[i]])] = first_val[i];
+        // cells: children of the level-D node with a given code (consecutive ids, symbol order)
+        {
+            uint8_t* cells = blob + h.off_itop_cells;
+            for (uint32_t i = lvl_first[itop_D]; i < lvl_first[itop_D + 1]; i++) {
+                uint32_t first = 0, mask = 0, outs = 0;
+                for (int32_t ch = t->nodes[order[i]].first_child; ch >= 0; ch = t->nodes[ch].next_sibling) {
+                    const uint32_t sym = (uint32_t)(cls[t->nodes[ch].letter] - (has_other ? 1 : 0));
+                    const uint32_t cid = (uint32_t)id[ch];
+                    mask |= 1u << sym;
+                    if (out_cnt[cid]) outs |= 1u << sym;
+                    if (first == 0 || cid < first) first = cid;
+                }
+                const uint32_t code = acode[order[i]];
+                if (itop_cell_bytes == 4) ((uint32_t*)cells)[code] = first | (mask << 24) | (outs << 28);
+                else { ((uint32_t*)cells)[2 * (size_t)code] = first; ((uint32_t*)cells)[2 * (size_t)code + 1] = mask | (outs << 16); }
+            }
         }
-        lds[0] = itop_b; lds[1] = itop_D; lds[2] = lvl_first[itop_D]; lds[3] = (uint32_t)r16; lds[4] = (uint32_t)r32;
+        lds[0] = itop_b; lds[1] = itop_D; lds[2] = lvl_first[itop_D + 1]; lds[3] = itop_cell_bytes; lds[4] = (uint32_t)n;
         lds[5] = has_other ? 1u : 0u; lds[6] = (uint32_t)itop_lds_words; lds[7] = (uint32_t)((1ull << (itop_b * itop_D)) - 1);
-        lds[8] = (uint32_t)ndb; lds[9] = (uint32_t)hb;
+        lds[8] = (uint32_t)ndb;
         lds[11] = itop_b * complete;                           // shifts up to this one always hit: no probe needed
-        lds[12] = hw ? itop_b * hmin_level : 0xFFFFu;          // no node shallower than this has outputs
-        lds[13] = (uint32_t)h_first;
         h.itop_depth = itop_D; h.itop_bits = itop_b; h.itop_lds_bytes = (uint32_t)(itop_lds_words * 4);
+        h.itop_cell_bytes = itop_cell_bytes;
     }
 
     h.magic = ACX_BLOB_MAGIC;
@@ -604,16 +614,22 @@ int acx_blob_check_header(const acx_blob_header* h, size_t nbytes) {
     if (h->n_states == 0 || h->n_states >= (1u << h->state_bits) || h->n_classes == 0 || h->n_classes > 256)
         return acx_fail(ACX_E_FORMAT, "image: bad n_states/n_classes");
     const uint64_t n = h->n_states, K = h->n_classes;
+    const uint64_t n_codes = h->itop_depth ? 1ull << (h->itop_bits * h->itop_depth) : 0;
+    if (h->itop_depth && (h->itop_bits == 0 || h->itop_bits > 4 || h->itop_bits * h->itop_depth > 22 ||
+                          (h->itop_cell_bytes != 4 && h->itop_cell_bytes != 8) ||
+                          h->itop_lds_bytes != (ACX_ITOP_HDR_WORDS + n_codes / 8) * 4))
+        return acx_fail(ACX_E_FORMAT, "image: inconsistent implicit-top fields");
     struct { uint64_t off, len; } sec[] = {
         {h->off_cls, 256}, {h->table_in_blob ? h->off_table : (uint64_t)ACX_BLOB_ALIGN, h->table_in_blob ? n * K * 4 : 0},
         {h->off_edge_off, (n + 1) * 4}, {h->off_edge_cls, h->n_edges}, {h->off_edge_dst, (uint64_t)h->n_edges * 4},
         {h->off_tflags, n * 4}, {h->off_lvl_first, ((uint64_t)h->n_levels + 1) * 4},
         {h->off_fail, n * 4}, {h->off_node_val, n * 4},
         {h->off_node_flags, n}, {h->off_out_off, (n + 1) * 4}, {h->off_out_val, h->n_out * 4},
-        {h->off_first_val, n * 4},
+        {h->off_first_val, (n + 2 * n_codes) * 4},
         {h->itop_depth ? h->off_itop_lds : (uint64_t)ACX_BLOB_ALIGN, h->itop_depth ? h->itop_lds_bytes : 0},
-        {h->itop_depth ? h->off_itop_entry : (uint64_t)ACX_BLOB_ALIGN, 0},
-        {h->itop_depth ? h->off_itop_ebits : (uint64_t)ACX_BLOB_ALIGN, 0},
+        {h->itop_depth ? h->off_itop_entry : (uint64_t)ACX_BLOB_ALIGN, n_codes * 8},
+        {h->itop_depth ? h->off_itop_ebits : (uint64_t)ACX_BLOB_ALIGN, n_codes / 4},
+        {h->itop_depth ? h->off_itop_cells : (uint64_t)ACX_BLOB_ALIGN, n_codes * h->itop_cell_bytes},
     };
     for (auto& s : sec)
         if (s.off % ACX_BLOB_ALIGN || s.off < ACX_BLOB_HEADER_BYTES || s.off + s.len > nbytes)
