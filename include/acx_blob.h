@@ -66,7 +66,7 @@
  * LDS image (uint32 words): [0]=b [1]=D [2]=first id of level D+1 (ids from here on are "deep")
  * [3]=cell bytes (4 or 8) [5]=1 if class 0 is "other" [6]=total words [7]=mask(D) = 2^(bD)-1
  * [8]=ND4 word offset [11]=shift up to which levels are complete (every k-gram exists: no probe
- * needed);  then ND4 (2^(bD) x 4 bits).  b*D >= 5.
+ * needed) [12]=shift of the shallowest level that has outputs;  then ND4 (2^(bD) x 4 bits).  b*D >= 5.
  */
 #define ACX_ITOP_MAX_LEVELS   15
 #define ACX_ITOP_HDR_WORDS    16

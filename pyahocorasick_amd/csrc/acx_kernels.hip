@@ -345,7 +345,7 @@ struct ItopCtx {
     const uint32_t* tflags;     // global: per-state entry bits
     const uint8_t*  table_bytes;
     const uint32_t* out_off;
-    uint32_t row_bytes, b, D, bD, LD1, has_other, maskD, cs, pseudo1;
+    uint32_t row_bytes, b, D, bD, LD1, has_other, maskD, cs, hmin, pseudo1;
 };
 
 struct ItopLane {
@@ -403,6 +403,10 @@ __device__ __forceinline__ void itop_report(uint32_t e, uint32_t c, uint32_t idx
 
 // One input byte, any situation (warm-up, bytes outside the key alphabet, ragged ends, halo).
 // sy = symbol of the byte, or ACX_ITOP_SYM_OTHER.
+// Warm-up: for the first D - 1 symbols after a reset (item start, or a byte no key contains) the
+// history is not full and ND4 does not apply; the lane is at most `valid` deep, and the depth is
+// found by probing E downwards from its old depth + 1 (no memory access while that is inside the
+// complete levels).  Nodes shallower than the shortest key (C.hmin) have no outputs.
 template <bool ESCAPE, bool CELL8>
 __device__ __forceinline__ void itop_step(uint32_t sy, uint32_t idx, bool active, bool emit, const ItopCtx& C, ItopLane& L) {
     constexpr int SB = ACX_STATE_BITS_NARROW;
@@ -430,10 +434,10 @@ __device__ __forceinline__ void itop_step(uint32_t sy, uint32_t idx, bool active
             if (emit && ((cell_bits >> (16 + sym)) & 1u)) e = child | C.tflags[child];
         }
         if (!settled) {                                              // the new state is not deeper than D
-            const bool exact = valid >= C.D && (q & 3u) != 3u;       // steady state and not a deep fall: ND4 says it all
+            const bool exact = valid >= C.D && (q & 3u) != 3u;       // full history and not a deep fall: ND4 says it all
             if (exact) new_sh = C.bD - __umul24(C.b, q & 3u);
             else new_sh = itop_resolve_slow(hist, valid >= C.D ? C.bD - 3u * C.b : L.sh + C.b, C.Eg, C.b, C.cs);
-            if (!own_out && emit && new_sh && (!exact || (q >> 2))) e = C.ient[itop_x(hist, new_sh)];
+            if (!own_out && emit && new_sh >= C.hmin && (!exact || (q >> 2))) e = C.ient[itop_x(hist, new_sh)];
         }
     }
     if (active) {
@@ -519,7 +523,7 @@ __global__ void __launch_bounds__(ACX_ITOP_BLOCK) k_walk_itop(const acx_walk_arg
     C.b = s_mem[0]; C.D = s_mem[1]; C.bD = s_mem[0] * s_mem[1]; C.LD1 = s_mem[2]; C.has_other = s_mem[5]; C.maskD = s_mem[7];
     C.pseudo1 = s_mem[4] | (1u << ACX_ENTRY_CNT_SHIFT(ACX_STATE_BITS_NARROW));
     C.ND = s_mem + s_mem[8];
-    C.cs = s_mem[11];
+    C.cs = s_mem[11]; C.hmin = s_mem[12];
 
     const int lane = threadIdx.x & (ACX_WAVE - 1);
     const int64_t n_items = ck ? *n_chunks_dev : a.n_hay;

@@ -575,6 +575,11 @@ int acx_flatten(const acx_trie_t* t, void** blob_out, size_t* nbytes_out) {
         lds[5] = has_other ? 1u : 0u; lds[6] = (uint32_t)itop_lds_words; lds[7] = (uint32_t)((1ull << (itop_b * itop_D)) - 1);
         lds[8] = (uint32_t)ndb;
         lds[11] = itop_b * complete;                           // shifts up to this one always hit: no probe needed
+        {   // shift of the shallowest level that has a node with outputs = the shortest key (>= 1 symbol)
+            uint32_t hmin = 0xFFFFu;
+            for (size_t i = 1; i < n && hmin == 0xFFFFu; i++) if (out_cnt[i]) hmin = (uint32_t)adepth[order[i]];
+            lds[12] = hmin == 0xFFFFu ? 0xFFFFu : itop_b * hmin;
+        }
         h.itop_depth = itop_D; h.itop_bits = itop_b; h.itop_lds_bytes = (uint32_t)(itop_lds_words * 4);
         h.itop_cell_bytes = itop_cell_bytes;
     }
