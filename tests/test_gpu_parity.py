@@ -490,3 +490,83 @@ def test_config4_snort_signatures_scaled():
     resl = A.scan_batch(data, off, acx.ACX_SCAN_LONG)
     mol, el, vl = O.batch(data.tobytes(), off, 1)
     assert np.array_equal(resl.offsets, mol) and np.array_equal(resl.end_index, el) and np.array_equal(resl.value, vl)
+
+
+def _itop_fields(blob):
+    import struct
+    return struct.unpack_from("<I", blob, 140)[0], struct.unpack_from("<I", blob, 164)[0], struct.unpack_from("<I", blob, 220)[0]
+
+
+def _scan_all_ways(A, O, reads, n, L):
+    """itop (1 and 2 items per lane) and the plain walk, stride and offsets entry: all equal the oracle"""
+    off = np.arange(n + 1, dtype=np.int64) * L
+    mo, oe, ov = O.batch(reads.tobytes(), off, 0)
+    img = Image.from_automaton(A)
+    d_hay = DeviceBuffer.from_numpy(reads.reshape(-1), pad=64)
+    d_off = DeviceBuffer.from_numpy(off)
+    fins = []
+    for variant in (0, 1 << 17, 1 << 16):
+        sc = Scanner(img)
+        for kw in (dict(stride=L), dict(dev_off=d_off)):
+            sc.scan(d_hay, n * L, n, want_final_state=True, variant=variant, **kw)
+            moff, e, v, fin = sc.fetch()
+            assert np.array_equal(moff, mo) and np.array_equal(e, oe) and np.array_equal(v, ov)
+            fins.append(fin)
+    for fin in fins[1:]:
+        assert np.array_equal(fin, fins[0])
+    return len(oe)
+
+
+def test_implicit_top_deep_fall_escape():
+    """ND4's 2-bit depth field escapes (value 3) when the automaton falls below D - 2: keys =
+    every 5-gram over ACGT except those starting with AAA (level 5 is 98 % full: D = 7), plus a
+    few long keys; reads full of A-runs force the escape, which probes E"""
+    import itertools
+    rng = np.random.default_rng(5)
+    grams = [bytes(g) for g in itertools.product(b"ACGT", repeat=5) if bytes(g[:3]) != b"AAA"]
+    longk = [bytes(rng.choice(np.frombuffer(b"ACGT", dtype=np.uint8), size=int(k)).tobytes()) for k in rng.integers(8, 20, size=300)]
+    keys = list(dict.fromkeys(grams + longk))
+    A, O = build_pair(keys)
+    D, b, cell = _itop_fields(A.flat_image_bytes())
+    assert b == 2 and cell == 4 and D >= 6
+    n, L = 512, 200
+    base = np.frombuffer(b"ACGT", dtype=np.uint8)
+    reads = np.ascontiguousarray(base[rng.integers(0, 4, size=(n, L))])
+    for i in range(n):                                   # A-runs of 4..12 at random places
+        for _ in range(6):
+            o = int(rng.integers(0, L - 12)); r = int(rng.integers(4, 13))
+            reads[i, o:o + r] = ord("A")
+    assert _scan_all_ways(A, O, reads, n, L) > 0
+
+
+def test_implicit_top_many_outputs_and_escape_counts():
+    """shallow nodes with several outputs (ND4 output class 2: entry fetched), children with
+    outputs (cell bit -> tflags), and states with >= 31 outputs (count escape) under the itop walk"""
+    rng = np.random.default_rng(6)
+    keys = [b"A" * k for k in range(1, 41)] + [b"C" * k for k in range(1, 12)]
+    a = np.frombuffer(b"ACGT", dtype=np.uint8)
+    keys += list({bytes(rng.choice(a, size=int(k)).tobytes()) for k in rng.integers(1, 14, size=6000)})
+    keys = list(dict.fromkeys(keys))
+    A, O = build_pair(keys)
+    D, b, cell = _itop_fields(A.flat_image_bytes())
+    assert b == 2 and D >= 5
+    n, L = 300, 240
+    reads = np.ascontiguousarray(a[rng.integers(0, 4, size=(n, L))])
+    for i in range(0, n, 2):
+        o = int(rng.integers(0, L - 60)); r = int(rng.integers(20, 60))
+        reads[i, o:o + r] = ord("A")
+    assert _scan_all_ways(A, O, reads, n, L) > 10 * n
+
+
+def test_implicit_top_eight_byte_cells_with_foreign_bytes():
+    """<= 16 symbols (8-byte cells), resets by bytes outside the key alphabet in every read"""
+    rng = np.random.default_rng(7)
+    alpha = np.frombuffer(b"0123456789abcdef", dtype=np.uint8)
+    keys = list({bytes(rng.choice(alpha, size=int(k)).tobytes()) for k in rng.integers(1, 10, size=30000)})
+    A, O = build_pair(keys)
+    D, b, cell = _itop_fields(A.flat_image_bytes())
+    assert b == 4 and cell == 8 and D >= 2
+    n, L = 400, 191
+    hay_alpha = np.frombuffer(b"0123456789abcdef \n-", dtype=np.uint8)
+    reads = np.ascontiguousarray(hay_alpha[rng.integers(0, len(hay_alpha), size=(n, L))])
+    assert _scan_all_ways(A, O, reads, n, L) > 0
