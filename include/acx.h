@@ -82,6 +82,38 @@ int64_t  acx_trie_longest_word(const acx_trie_t* t);
 int64_t  acx_trie_version(const acx_trie_t* t);
 
 /* ------------------------------------------------------------------------------------
+ * 1b. The reference's persistence formats <-> the trie (acx_persist.cpp).
+ *     Bytes build, LP64.  Loading rebuilds the trie node for node (same child order);
+ *     fail links are not taken from the dump: call acx_trie_make_automaton afterwards when
+ *     the dump was an automaton.  Out-arrays are malloc'd: release with acx_blob_free.
+ *     values_by_position (STORE_ANY): the values travel outside the dump, one per key in
+ *     dump (pre-order) order; a loaded trie then stores that position as the key's value.
+ * ---------------------------------------------------------------------------------- */
+enum { ACX_STORE_LENGTH = 20, ACX_STORE_INTS = 10, ACX_STORE_ANY = 30 };    /* src/Automaton.h:22-27 */
+enum { ACX_KEY_STRING = 100, ACX_KEY_SEQUENCE = 200 };                      /* src/Automaton.h:29-32 */
+typedef struct acx_ref_meta {       /* header of a save file, src/custompickle/custompickle.h:5-17 */
+    int32_t kind, store, key_type, reserved;
+    int64_t count, longest_word, n_nodes, n_eow;
+} acx_ref_meta_t;
+/* Automaton.__reduce__ payload: the list of byte chunks (src/Automaton_pickle.c:128-285 writes it,
+ * automaton_unpickle :326-488 reads it) */
+int acx_trie_from_ref_pickle(const void* const* chunks, const size_t* chunk_bytes, size_t n_chunks,
+                             int values_by_position, int64_t longest_word /* of the tuple; never lowered by remove_word */,
+                             acx_trie_t** out, int64_t* n_eow);
+int acx_trie_to_ref_pickle(const acx_trie_t* t, int values_by_position, size_t chunk_limit,
+                           void** buf, size_t** chunk_bytes, size_t* n_chunks);   /* chunks back to back in buf */
+/* values of the keys in dump order (what the `values` list of a STORE_ANY pickle is ordered by) */
+int acx_trie_eow_values(const acx_trie_t* t, int64_t** values, int64_t* n);
+/* Automaton.save file (src/custompickle/save/automaton_save.c:36-138; loader
+ * src/custompickle/load/module_automaton_load.c).  payload_off/len: byte range of the
+ * serialized value of each key, in dump order (STORE_ANY only, else NULL); *out is NULL
+ * for the file of an empty automaton. */
+int acx_trie_from_ref_savefile(const void* data, size_t nbytes, acx_trie_t** out, acx_ref_meta_t* meta,
+                               int64_t** payload_off, int64_t** payload_len);
+int acx_trie_to_ref_savefile(const acx_trie_t* t, int store, int key_type, const void* const* payloads,
+                             const size_t* payload_bytes, void** buf, size_t* nbytes);
+
+/* ------------------------------------------------------------------------------------
  * 2. Flat image.  One contiguous, relocatable little-endian blob (layout: acx_blob.h):
  *    class map, dense fail-resolved transition table, fail vector, CSR output lists.
  *    Built from a finalised trie on the CPU; it is what gets uploaded to HBM and what a

@@ -13,7 +13,7 @@ from .automaton import (  # noqa: F401
     Automaton, AutomatonSearchIter, AutomatonSearchIterLong, BatchResult,
     EMPTY, TRIE, AHOCORASICK, STORE_INTS, STORE_LENGTH, STORE_ANY,
     KEY_STRING, KEY_SEQUENCE, MATCH_EXACT_LENGTH, MATCH_AT_MOST_PREFIX, MATCH_AT_LEAST_PREFIX,
-    unicode,
+    unicode, load,
 )
 from ._lib import AcxError, AcxNoDevice, ACX_SCAN_ALL, ACX_SCAN_LONG, device_count  # noqa: F401
 

@@ -63,6 +63,15 @@ SIGNATURES = {
     "acx_trie_num_nodes": (C.c_int64, [_P]),
     "acx_trie_longest_word": (C.c_int64, [_P]),
     "acx_trie_version": (C.c_int64, [_P]),
+    "acx_trie_from_ref_pickle": (C.c_int, [C.POINTER(C.c_void_p), C.POINTER(C.c_size_t), C.c_size_t, C.c_int, C.c_int64, _PP,
+                                           C.POINTER(C.c_int64)]),
+    "acx_trie_to_ref_pickle": (C.c_int, [_P, C.c_int, C.c_size_t, _PP, C.POINTER(C.POINTER(C.c_size_t)),
+                                         C.POINTER(C.c_size_t)]),
+    "acx_trie_eow_values": (C.c_int, [_P, C.POINTER(C.POINTER(C.c_int64)), C.POINTER(C.c_int64)]),
+    "acx_trie_from_ref_savefile": (C.c_int, [_P, C.c_size_t, _PP, _P, C.POINTER(C.POINTER(C.c_int64)),
+                                             C.POINTER(C.POINTER(C.c_int64))]),
+    "acx_trie_to_ref_savefile": (C.c_int, [_P, C.c_int, C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t), _PP,
+                                           C.POINTER(C.c_size_t)]),
     "acx_flatten": (C.c_int, [_P, _PP, C.POINTER(C.c_size_t)]),
     "acx_blob_free": (None, [_P]),
     "acx_blob_validate": (C.c_int, [_P, C.c_size_t]),

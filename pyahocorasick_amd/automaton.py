@@ -21,7 +21,7 @@ import ctypes as C
 import numpy as np
 
 from . import _lib
-from ._lib import ACX_SCAN_ALL, ACX_SCAN_LONG, lib, check
+from ._lib import ACX_SCAN_ALL, ACX_SCAN_LONG, AcxError, lib, check
 
 # constants of the reference module, src/pyahocorasick.c:113-134, src/Automaton.h:16-41
 EMPTY, TRIE, AHOCORASICK = 0, 1, 2
@@ -110,7 +110,27 @@ class BatchResult:
 
 
 class Automaton:
-    def __init__(self, store=STORE_ANY, key_type=KEY_STRING):
+    def __init__(self, *args):
+        """Automaton([store, [key_type]]) — or the 7-tuple of `__reduce__`
+        (bytes_list, kind, store, key_type, count, longest_word, values), which is how pickles of
+        this class AND of the reference's bytes build are loaded (src/Automaton.c:97-181)."""
+        self._trie = C.c_void_p()
+        self._image = None
+        self._result = C.c_void_p()                          # reusable device/pinned buffers
+        pickled = None
+        if len(args) == 7:
+            pickled = args
+            store, key_type = args[2], args[3]
+            if not all(isinstance(a, int) for a in args[1:6]):
+                raise ValueError("Unable to load from pickle.")
+            if args[1] not in (EMPTY, TRIE, AHOCORASICK):
+                raise ValueError("kind value must be one of ahocorasick.EMPTY, TRIE or AHOCORASICK")
+        else:
+            store, key_type = STORE_ANY, KEY_STRING
+            if len(args) >= 1 and isinstance(args[0], int):
+                store = args[0]
+                if len(args) >= 2 and isinstance(args[1], int):
+                    key_type = args[1]
         if store not in (STORE_INTS, STORE_LENGTH, STORE_ANY):
             raise ValueError("store value must be one of ahocorasick.STORE_LENGTH, STORE_INTS or STORE_ANY")
         if key_type not in (KEY_STRING, KEY_SEQUENCE):
@@ -119,11 +139,91 @@ class Automaton:
             raise NotImplementedError("KEY_SEQUENCE automata are not byte automata; outside the GPU path (SURVEY §8f N4)")
         self._store = store
         self._key_type = key_type
-        self._trie = C.c_void_p()
-        check(lib().acx_trie_new(C.byref(self._trie)))
         self._values = [] if store == STORE_ANY else None   # STORE_ANY: value id -> object
-        self._image = None
-        self._result = C.c_void_p()                          # reusable device/pinned buffers
+        if pickled is not None and pickled[1] != EMPTY:
+            self._load_pickle(*pickled)
+        else:
+            check(lib().acx_trie_new(C.byref(self._trie)))
+
+    # ---- persistence in the reference's formats (csrc/acx_persist.cpp) ----------
+    def _load_pickle(self, bytes_list, kind, store, key_type, count, longest_word, values):
+        if type(bytes_list) is not list:
+            raise TypeError("Expected list")
+        for k, b in enumerate(bytes_list):
+            if type(b) is not bytes:
+                raise ValueError("Item #%d on the bytes list is not a bytes object" % k)
+        any_ = store == STORE_ANY
+        if any_ and not isinstance(values, list):
+            raise ValueError("Unable to load from pickle.")
+        n = len(bytes_list)
+        ptrs = (C.c_void_p * n)(*[C.cast(C.c_char_p(b), C.c_void_p) for b in bytes_list])
+        sizes = (C.c_size_t * n)(*[len(b) for b in bytes_list])
+        n_eow = C.c_int64(0)
+        try:
+            check(lib().acx_trie_from_ref_pickle(ptrs, sizes, n, 1 if any_ else 0, longest_word, C.byref(self._trie), C.byref(n_eow)))
+        except AcxError as e:
+            raise ValueError(str(e)) from None
+        if any_:
+            if len(values) < n_eow.value:
+                raise IndexError("list index out of range")          # PyList_GetItem in automaton_unpickle
+            self._values = list(values[:n_eow.value])
+        if kind == AHOCORASICK:
+            self.make_automaton()
+
+    def __reduce__(self):
+        """same tuple as the reference (src/Automaton_pickle.c:192-285): loadable by either side"""
+        if len(self) == 0:
+            return (type(self), ())
+        any_ = self._store == STORE_ANY
+        buf, sizes, n = C.c_void_p(), C.POINTER(C.c_size_t)(), C.c_size_t()
+        check(lib().acx_trie_to_ref_pickle(self._trie, 1 if any_ else 0, 0, C.byref(buf), C.byref(sizes), C.byref(n)))
+        try:
+            chunks, at = [], 0
+            for k in range(n.value):
+                chunks.append(C.string_at(buf.value + at, sizes[k]))
+                at += sizes[k]
+        finally:
+            lib().acx_blob_free(buf)
+            lib().acx_blob_free(C.cast(sizes, C.c_void_p))
+        values = [self._values[i] for i in self._eow_values()] if any_ else None
+        return (type(self), (chunks, self.kind, self._store, self._key_type, len(self),
+                             lib().acx_trie_longest_word(self._trie), values))
+
+    def _eow_values(self):
+        vals, n = C.POINTER(C.c_int64)(), C.c_int64()
+        check(lib().acx_trie_eow_values(self._trie, C.byref(vals), C.byref(n)))
+        try:
+            return [vals[i] for i in range(n.value)]
+        finally:
+            lib().acx_blob_free(C.cast(vals, C.c_void_p))
+
+    def save(self, *args):
+        """save(path[, serializer]) in the reference's file format (src/custompickle/save/automaton_save.c)"""
+        any_ = self._store == STORE_ANY
+        if len(args) != (2 if any_ else 1):                            # src/custompickle/pyhelpers.c:8-18
+            raise ValueError("expected exactly two arguments" if any_ else "expected exactly one argument")
+        if not isinstance(args[0], str):
+            raise TypeError("the first argument must be a string")
+        if any_ and not callable(args[1]):
+            raise TypeError("the second argument must be a callable object")
+        payloads = None
+        if any_:
+            payloads = []
+            for i in self._eow_values():
+                b = args[1](self._values[i])
+                if type(b) is not bytes:
+                    raise TypeError("serializer must return bytes object")
+                payloads.append(b)
+        n = len(payloads) if payloads else 0
+        ptrs = (C.c_void_p * max(n, 1))(*[C.cast(C.c_char_p(b), C.c_void_p) for b in (payloads or [])])
+        sizes = (C.c_size_t * max(n, 1))(*[len(b) for b in (payloads or [])])
+        buf, nbytes = C.c_void_p(), C.c_size_t()
+        check(lib().acx_trie_to_ref_savefile(self._trie, self._store, self._key_type, ptrs, sizes, C.byref(buf), C.byref(nbytes)))
+        try:
+            with open(args[0], "wb") as f:
+                f.write(C.string_at(buf, nbytes.value))
+        finally:
+            lib().acx_blob_free(buf)
 
     def __del__(self):
         try:
@@ -451,3 +551,49 @@ class AutomatonSearchIterLong:
         item = self._pending[self._pos]
         self._pos += 1
         return item
+
+
+class _RefMeta(C.Structure):
+    _fields_ = [("kind", C.c_int32), ("store", C.c_int32), ("key_type", C.c_int32), ("reserved", C.c_int32),
+                ("count", C.c_int64), ("longest_word", C.c_int64), ("n_nodes", C.c_int64), ("n_eow", C.c_int64)]
+
+
+def load(*args):
+    """ahocorasick.load(path, deserializer): read a file written by Automaton.save — the
+    reference's (bytes build) or this package's (src/custompickle/load/module_automaton_load.c).
+    Both arguments are always required, as in the reference."""
+    if len(args) != 2:
+        raise ValueError("expected exactly two arguments")
+    path, deserializer = args
+    if not isinstance(path, str):
+        raise TypeError("the first argument must be a string")
+    if not callable(deserializer):
+        raise TypeError("the second argument must be a callable object")
+    with open(path, "rb") as f:                                   # IOError as in loadbuffer_open
+        data = f.read()
+    meta = _RefMeta()
+    trie, poff, plen = C.c_void_p(), C.POINTER(C.c_int64)(), C.POINTER(C.c_int64)()
+    try:
+        check(lib().acx_trie_from_ref_savefile(data, len(data), C.byref(trie), C.byref(meta), C.byref(poff), C.byref(plen)))
+    except AcxError as e:
+        raise ValueError(str(e)) from None
+    try:
+        if meta.store not in (STORE_INTS, STORE_LENGTH, STORE_ANY) or meta.key_type not in (KEY_STRING, KEY_SEQUENCE) \
+                or meta.kind not in (EMPTY, TRIE, AHOCORASICK):
+            raise ValueError("invalid header")
+        A = Automaton(meta.store, meta.key_type)
+        if trie:
+            lib().acx_trie_free(A._trie)
+            A._trie, trie = trie, C.c_void_p()
+            if meta.store == STORE_ANY:
+                A._values = [deserializer(data[poff[k]:poff[k] + plen[k]]) for k in range(meta.n_eow)]
+            if meta.kind == AHOCORASICK:
+                A.make_automaton()
+        return A
+    finally:
+        if trie:
+            lib().acx_trie_free(trie)
+        if poff:
+            lib().acx_blob_free(C.cast(poff, C.c_void_p))
+        if plen:
+            lib().acx_blob_free(C.cast(plen, C.c_void_p))

@@ -1,0 +1,364 @@
+// acx_persist.cpp — the reference's two persistence formats <-> the arena trie.
+//
+// CPU only.  Both formats are dumps of the reference's pointer trie in trie_traverse order
+// (pre-order, children in array order: src/trie.c:197-225), one record per node:
+//
+//   record  = 24 bytes  { u64 output; u64 fail; u32 n; u8 eow; 3 bytes of padding (garbage) }
+//             = PICKLE_TRIENODE_SIZE, src/pickle/pickle.h:7 (TrieNode without its `next` pointer,
+//               src/trienode.h:27-41; LP64; the bytes build stores letters as uint16:
+//               src/common.h:63-67, hence the 32-bit n)
+//           + n x 10 bytes { u16 letter; u64 child }      (packed Pair, src/trienode.h:19-24; a key byte
+//             >= 0x80 is stored sign-extended: `char` widened to uint16)
+//
+//   pickle  (Automaton.__reduce__, src/Automaton_pickle.c:128-285): a list of byte chunks, each
+//           { i64 nodes in this chunk; records }.  Links are 1-based node numbers in dump order
+//           (0 = NULL, the root is node 1); `output` is the integer value, or 0 when the values
+//           travel as a separate Python list (STORE_ANY: one item per eow node, in dump order).
+//   save    (Automaton.save, src/custompickle/save/automaton_save.c:36-138): one file
+//           { magic "pyahocorasick002"; i32 kind, store, key_type; u64 words; i32 longest }   48 bytes
+//           then per node { u64 address of the node; record; [STORE_ANY and eow: `output` bytes of
+//           serialized value] } with links = raw addresses, then { u64 nodes; magic }.
+//
+// Loading rebuilds the arena trie node for node (same child order, so keys() order and every
+// search result are the reference's); fail links are NOT taken from the file — the host calls
+// make_automaton again when the dump was an automaton.  Dumps written here carry the fail links
+// the reference's loader expects.
+#include "acx_trie_impl.h"
+
+#include <cstdlib>
+#include <cstring>
+#include <new>
+#include <unordered_map>
+#include <vector>
+
+namespace {
+
+constexpr size_t REC = 24, PAIR = 10, SAVE_HEADER = 48, SAVE_FOOTER = 24;
+const char MAGIC[16] = {'p', 'y', 'a', 'h', 'o', 'c', 'o', 'r', 'a', 's', 'i', 'c', 'k', '0', '0', '2'};
+
+inline uint64_t rd64(const uint8_t* p) { uint64_t v; memcpy(&v, p, 8); return v; }
+inline uint32_t rd32(const uint8_t* p) { uint32_t v; memcpy(&v, p, 4); return v; }
+inline uint16_t rd16(const uint8_t* p) { uint16_t v; memcpy(&v, p, 2); return v; }
+inline void wr64(uint8_t* p, uint64_t v) { memcpy(p, &v, 8); }
+inline void wr32(uint8_t* p, uint32_t v) { memcpy(p, &v, 4); }
+inline void wr16(uint8_t* p, uint16_t v) { memcpy(p, &v, 2); }
+
+struct RawNode {            // one parsed record; links still in the file's own naming
+    uint64_t output;
+    uint32_t n;
+    uint8_t eow;
+    const uint8_t* pairs;   // n x PAIR bytes
+};
+
+// Build the arena trie from parsed records.  child_index(k, j) = index (0-based, dump order) of
+// the j-th child of node k, or -1 if the link is invalid.  Node 0 is the root.
+template <class ChildIndex>
+int build_trie(const std::vector<RawNode>& raw, bool values_by_position, int64_t longest_word, ChildIndex child_index,
+               acx_trie** out, int64_t* n_eow_out) {
+    const size_t n = raw.size();
+    if (n == 0 || n >= ((size_t)1 << 31)) return acx_fail(ACX_E_FORMAT, "reference dump: %zu nodes", n);
+    acx_trie* t = new (std::nothrow) acx_trie();
+    if (!t) return acx_fail(ACX_E_NOMEM, "reference dump: out of memory");
+    int rc = ACX_OK;
+    try {
+        t->nodes.resize(n);
+        std::vector<int32_t> depth(n, -1);
+        std::vector<uint8_t> linked(n, 0);
+        for (size_t k = 0; k < n; k++) {
+            Node& nd = t->nodes[k];
+            nd.value = 0; nd.first_child = -1; nd.next_sibling = -1; nd.fail = -1; nd.letter = 0; nd.eow = raw[k].eow ? 1 : 0; nd.pad = 0;
+        }
+        depth[0] = 0;
+        int64_t eow_seen = 0, longest = 0;
+        // dump order is pre-order, so a parent always precedes its children: one forward pass
+        for (size_t k = 0; k < n && rc == ACX_OK; k++) {
+            if (depth[k] < 0) { rc = acx_fail(ACX_E_FORMAT, "reference dump: node #%zu is not reachable from the root", k); break; }
+            Node& nd = t->nodes[k];
+            if (nd.eow) {
+                nd.value = values_by_position ? eow_seen : (int64_t)raw[k].output;
+                eow_seen++;
+                if (depth[k] > longest) longest = depth[k];
+                if (k == 0) { rc = acx_fail(ACX_E_FORMAT, "reference dump: the root is marked as a key"); break; }
+            }
+            int32_t last = -1;
+            for (uint32_t j = 0; j < raw[k].n; j++) {
+                const int64_t c = child_index(k, j);
+                if (c <= (int64_t)k || c >= (int64_t)n || linked[c]) {
+                    rc = acx_fail(ACX_E_FORMAT, "reference dump: node #%zu has a malformed link #%u", k, j);
+                    break;
+                }
+                // the bytes build widens `char` key bytes to uint16 letters, so bytes >= 0x80 arrive
+                // sign-extended (0xFF80..0xFFFF)
+                const uint16_t letter = rd16(raw[k].pairs + (size_t)j * PAIR);
+                if (letter > 0x7F && letter < 0xFF80) { rc = acx_fail(ACX_E_FORMAT, "reference dump: node #%zu has letter %u: not a bytes-build dump", k, letter); break; }
+                linked[c] = 1;
+                depth[c] = depth[k] + 1;
+                t->nodes[c].letter = (uint8_t)letter;
+                if (last < 0) nd.first_child = (int32_t)c; else t->nodes[last].next_sibling = (int32_t)c;
+                last = (int32_t)c;
+                if (k == 0) {
+                    if (t->root_child[t->nodes[c].letter] >= 0) { rc = acx_fail(ACX_E_FORMAT, "reference dump: duplicate root edge"); break; }
+                    t->root_child[t->nodes[c].letter] = (int32_t)c;
+                }
+            }
+        }
+        if (rc == ACX_OK) {
+            t->kind = ACX_KIND_TRIE;
+            t->count = eow_seen;
+            // the reference never lowers longest_word (remove_word leaves it): keep the dump's value,
+            // but never below the truth (the chunk halo of the scan is longest_word - 1)
+            t->longest_word = longest_word > longest ? longest_word : longest;
+            t->live_nodes = (int64_t)n;
+            t->version = 1;
+            if (n_eow_out) *n_eow_out = eow_seen;
+        }
+    } catch (const std::bad_alloc&) {
+        rc = acx_fail(ACX_E_NOMEM, "reference dump: out of memory");
+    }
+    if (rc != ACX_OK) { delete t; return rc; }
+    *out = t;
+    return ACX_OK;
+}
+
+// pre-order list of the live nodes (arena indices), children in sibling order
+int preorder(const acx_trie* t, std::vector<int32_t>& order) {
+    order.clear();
+    if (t->kind == ACX_KIND_EMPTY || t->nodes.empty()) return ACX_OK;
+    try {
+        order.reserve((size_t)t->live_nodes);
+        std::vector<int32_t> stack, kids;
+        stack.push_back(0);
+        while (!stack.empty()) {
+            const int32_t k = stack.back();
+            stack.pop_back();
+            order.push_back(k);
+            kids.clear();
+            for (int32_t c = t->nodes[k].first_child; c >= 0; c = t->nodes[c].next_sibling) kids.push_back(c);
+            for (size_t i = kids.size(); i-- > 0;) stack.push_back(kids[i]);
+        }
+    } catch (const std::bad_alloc&) {
+        return acx_fail(ACX_E_NOMEM, "reference dump: out of memory");
+    }
+    return ACX_OK;
+}
+
+uint32_t n_children(const acx_trie* t, int32_t k) {
+    uint32_t n = 0;
+    for (int32_t c = t->nodes[k].first_child; c >= 0; c = t->nodes[c].next_sibling) n++;
+    return n;
+}
+
+}  // namespace
+
+extern "C" {
+
+int acx_trie_from_ref_pickle(const void* const* chunks, const size_t* chunk_bytes, size_t n_chunks, int values_by_position,
+                             int64_t longest_word, acx_trie_t** out, int64_t* n_eow) {
+    if (!chunks || !chunk_bytes || !out || n_chunks == 0) return acx_fail(ACX_E_INVAL, "acx_trie_from_ref_pickle: bad argument");
+    std::vector<RawNode> raw;
+    try {
+        for (size_t c = 0; c < n_chunks; c++) {
+            const uint8_t* p = (const uint8_t*)chunks[c];
+            const uint8_t* end = p + chunk_bytes[c];
+            if (!p || chunk_bytes[c] < 8) return acx_fail(ACX_E_FORMAT, "pickle chunk #%zu: too short", c);
+            const int64_t cnt = (int64_t)rd64(p);
+            if (cnt <= 0) return acx_fail(ACX_E_FORMAT, "pickle chunk #%zu: nodes count is not positive", c);   // src/Automaton_pickle.c:306-311
+            p += 8;
+            for (int64_t i = 0; i < cnt; i++) {
+                if ((size_t)(end - p) < REC) return acx_fail(ACX_E_FORMAT, "pickle chunk #%zu: data truncated in the header of node #%lld", c, (long long)i);
+                RawNode r;
+                r.output = rd64(p); r.n = rd32(p + 16); r.eow = p[20]; r.pairs = p + REC;
+                p += REC;
+                if ((size_t)(end - p) < (size_t)r.n * PAIR) return acx_fail(ACX_E_FORMAT, "pickle chunk #%zu: data truncated in the children of node #%lld", c, (long long)i);
+                p += (size_t)r.n * PAIR;
+                raw.push_back(r);
+            }
+        }
+    } catch (const std::bad_alloc&) {
+        return acx_fail(ACX_E_NOMEM, "acx_trie_from_ref_pickle: out of memory");
+    }
+    const std::vector<RawNode>& rr = raw;
+    return build_trie(raw, values_by_position != 0, longest_word,
+                      [&rr](size_t k, uint32_t j) -> int64_t { return (int64_t)rd64(rr[k].pairs + (size_t)j * PAIR + 2) - 1; },   // 1-based ids
+                      out, n_eow);
+}
+
+int acx_trie_eow_values(const acx_trie_t* t, int64_t** values, int64_t* n) {
+    if (!t || !values || !n) return acx_fail(ACX_E_INVAL, "acx_trie_eow_values: NULL argument");
+    std::vector<int32_t> order;
+    int rc = preorder(t, order);
+    if (rc) return rc;
+    int64_t* v = (int64_t*)malloc(((size_t)t->count + 1) * sizeof(int64_t));
+    if (!v) return acx_fail(ACX_E_NOMEM, "acx_trie_eow_values: out of memory");
+    int64_t k = 0;
+    for (int32_t i : order) if (t->nodes[i].eow && k < t->count) v[k++] = t->nodes[i].value;
+    *values = v; *n = k;
+    return ACX_OK;
+}
+
+int acx_trie_to_ref_pickle(const acx_trie_t* t, int values_by_position, size_t chunk_limit, void** buf, size_t** chunk_bytes,
+                           size_t* n_chunks) {
+    if (!t || !buf || !chunk_bytes || !n_chunks) return acx_fail(ACX_E_INVAL, "acx_trie_to_ref_pickle: NULL argument");
+    if (chunk_limit < 8 + REC + 256 * PAIR) chunk_limit = (size_t)16 << 20;                // the reference's array size, src/Automaton_pickle.c:197
+    std::vector<int32_t> order;
+    int rc = preorder(t, order);
+    if (rc) return rc;
+    if (order.empty()) return acx_fail(ACX_E_STATE, "acx_trie_to_ref_pickle: empty automaton (the reference pickles it as Automaton())");
+    try {
+        std::vector<int64_t> id(t->nodes.size(), 0);                                      // arena index -> 1-based dump number
+        for (size_t k = 0; k < order.size(); k++) id[order[k]] = (int64_t)k + 1;
+        std::vector<uint8_t> data;
+        std::vector<size_t> sizes;
+        size_t chunk_start = 0;
+        int64_t in_chunk = 0;
+        auto open_chunk = [&]() { chunk_start = data.size(); data.resize(data.size() + 8, 0); in_chunk = 0; };
+        auto close_chunk = [&]() { wr64(data.data() + chunk_start, (uint64_t)in_chunk); sizes.push_back(data.size() - chunk_start); };
+        open_chunk();
+        const bool has_fail = t->kind == ACX_KIND_AHOCORASICK;
+        for (int32_t k : order) {
+            const Node& nd = t->nodes[k];
+            const uint32_t nc = n_children(t, k);
+            const size_t need = REC + (size_t)nc * PAIR;
+            if (in_chunk > 0 && data.size() - chunk_start + need > chunk_limit) { close_chunk(); open_chunk(); }
+            const size_t at = data.size();
+            data.resize(at + need, 0);
+            uint8_t* p = data.data() + at;
+            wr64(p, (nd.eow && !values_by_position) ? (uint64_t)nd.value : 0);
+            wr64(p + 8, (has_fail && nd.fail >= 0) ? (uint64_t)id[nd.fail] : 0);
+            wr32(p + 16, nc);
+            p[20] = nd.eow;
+            p += REC;
+            for (int32_t c = nd.first_child; c >= 0; c = t->nodes[c].next_sibling, p += PAIR) { wr16(p, (uint16_t)(int16_t)(int8_t)t->nodes[c].letter); wr64(p + 2, (uint64_t)id[c]); }
+            in_chunk++;
+        }
+        close_chunk();
+        uint8_t* ob = (uint8_t*)malloc(data.size() ? data.size() : 1);
+        size_t* os = (size_t*)malloc(sizes.size() * sizeof(size_t));
+        if (!ob || !os) { free(ob); free(os); return acx_fail(ACX_E_NOMEM, "acx_trie_to_ref_pickle: out of memory"); }
+        memcpy(ob, data.data(), data.size());
+        memcpy(os, sizes.data(), sizes.size() * sizeof(size_t));
+        *buf = ob; *chunk_bytes = os; *n_chunks = sizes.size();
+    } catch (const std::bad_alloc&) {
+        return acx_fail(ACX_E_NOMEM, "acx_trie_to_ref_pickle: out of memory");
+    }
+    return ACX_OK;
+}
+
+int acx_trie_from_ref_savefile(const void* data, size_t nbytes, acx_trie_t** out, acx_ref_meta_t* meta, int64_t** payload_off,
+                               int64_t** payload_len) {
+    if (!data || !out || !meta) return acx_fail(ACX_E_INVAL, "acx_trie_from_ref_savefile: NULL argument");
+    const uint8_t* b = (const uint8_t*)data;
+    if (nbytes < SAVE_HEADER + SAVE_FOOTER || memcmp(b, MAGIC, 16) != 0 || memcmp(b + nbytes - 16, MAGIC, 16) != 0)
+        return acx_fail(ACX_E_FORMAT, "save file: bad magic (not a pyahocorasick002 file, or truncated)");   // src/custompickle/custompickle.c:35-52
+    memset(meta, 0, sizeof *meta);
+    meta->kind = (int32_t)rd32(b + 16); meta->store = (int32_t)rd32(b + 20); meta->key_type = (int32_t)rd32(b + 24);
+    meta->count = (int64_t)rd64(b + 32); meta->longest_word = (int32_t)rd32(b + 40);
+    const uint64_t n_nodes = rd64(b + nbytes - SAVE_FOOTER);
+    meta->n_nodes = (int64_t)n_nodes;
+    const bool any = meta->store == ACX_STORE_ANY;
+    *out = nullptr;
+    if (payload_off) *payload_off = nullptr;
+    if (payload_len) *payload_len = nullptr;
+    if (n_nodes == 0) return ACX_OK;                                                       // an empty automaton: header + footer only
+    if (n_nodes > (nbytes - SAVE_HEADER - SAVE_FOOTER) / (8 + REC)) return acx_fail(ACX_E_FORMAT, "save file: nodes count does not fit the file");
+    std::vector<RawNode> raw;
+    std::unordered_map<uint64_t, int64_t> index;
+    std::vector<int64_t> poff, plen;
+    try {
+        raw.reserve(n_nodes);
+        index.reserve(n_nodes * 2);
+        const uint8_t* p = b + SAVE_HEADER;
+        const uint8_t* end = b + nbytes - SAVE_FOOTER;
+        for (uint64_t i = 0; i < n_nodes; i++) {
+            if ((size_t)(end - p) < 8 + REC) return acx_fail(ACX_E_FORMAT, "save file: truncated at node #%llu", (unsigned long long)i);
+            const uint64_t addr = rd64(p);
+            p += 8;
+            RawNode r;
+            r.output = rd64(p); r.n = rd32(p + 16); r.eow = p[20]; r.pairs = p + REC;
+            p += REC;
+            if ((size_t)(end - p) < (size_t)r.n * PAIR) return acx_fail(ACX_E_FORMAT, "save file: truncated in the children of node #%llu", (unsigned long long)i);
+            p += (size_t)r.n * PAIR;
+            if (any && r.eow) {                                                            // serialized value follows, `output` bytes long
+                if ((uint64_t)(end - p) < r.output) return acx_fail(ACX_E_FORMAT, "save file: truncated in the value of node #%llu", (unsigned long long)i);
+                poff.push_back((int64_t)(p - b)); plen.push_back((int64_t)r.output);
+                p += r.output;
+            }
+            if (!index.emplace(addr, (int64_t)i).second) return acx_fail(ACX_E_FORMAT, "save file: node #%llu repeats an address", (unsigned long long)i);
+            raw.push_back(r);
+        }
+        if (p != end) return acx_fail(ACX_E_FORMAT, "save file: %zu stray bytes before the footer", (size_t)(end - p));
+    } catch (const std::bad_alloc&) {
+        return acx_fail(ACX_E_NOMEM, "acx_trie_from_ref_savefile: out of memory");
+    }
+    const std::vector<RawNode>& rr = raw;
+    const std::unordered_map<uint64_t, int64_t>& ix = index;
+    int64_t n_eow = 0;
+    int rc = build_trie(raw, any, meta->longest_word,
+                        [&rr, &ix](size_t k, uint32_t j) -> int64_t {
+                            auto it = ix.find(rd64(rr[k].pairs + (size_t)j * PAIR + 2));
+                            return it == ix.end() ? -1 : it->second;
+                        },
+                        out, &n_eow);
+    if (rc) return rc;
+    meta->n_eow = n_eow;
+    if (any && payload_off && payload_len) {
+        int64_t* o = (int64_t*)malloc((poff.size() + 1) * sizeof(int64_t));
+        int64_t* l = (int64_t*)malloc((plen.size() + 1) * sizeof(int64_t));
+        if (!o || !l) { free(o); free(l); acx_trie_free(*out); *out = nullptr; return acx_fail(ACX_E_NOMEM, "acx_trie_from_ref_savefile: out of memory"); }
+        memcpy(o, poff.data(), poff.size() * sizeof(int64_t));
+        memcpy(l, plen.data(), plen.size() * sizeof(int64_t));
+        *payload_off = o; *payload_len = l;
+    }
+    return ACX_OK;
+}
+
+int acx_trie_to_ref_savefile(const acx_trie_t* t, int store, int key_type, const void* const* payloads, const size_t* payload_bytes,
+                             void** buf, size_t* nbytes) {
+    if (!t || !buf || !nbytes) return acx_fail(ACX_E_INVAL, "acx_trie_to_ref_savefile: NULL argument");
+    const bool any = store == ACX_STORE_ANY;
+    if (any && t->count > 0 && (!payloads || !payload_bytes)) return acx_fail(ACX_E_INVAL, "acx_trie_to_ref_savefile: STORE_ANY needs the serialized values");
+    std::vector<int32_t> order;
+    int rc = preorder(t, order);
+    if (rc) return rc;
+    try {
+        std::vector<uint8_t> data(SAVE_HEADER, 0);
+        memcpy(data.data(), MAGIC, 16);
+        wr32(data.data() + 16, (uint32_t)t->kind); wr32(data.data() + 20, (uint32_t)store); wr32(data.data() + 24, (uint32_t)key_type);
+        wr64(data.data() + 32, (uint64_t)t->count); wr32(data.data() + 40, (uint32_t)t->longest_word);
+        // node "addresses": any distinct non-zero numbers do (the loader only uses them as keys)
+        auto addr = [](int32_t k) -> uint64_t { return 0x100000000ull + (uint64_t)k * 32u; };
+        const bool has_fail = t->kind == ACX_KIND_AHOCORASICK;
+        int64_t eow_seen = 0;
+        for (int32_t k : order) {
+            const Node& nd = t->nodes[k];
+            const uint32_t nc = n_children(t, k);
+            const size_t pl = (any && nd.eow) ? payload_bytes[eow_seen] : 0;
+            const size_t at = data.size();
+            data.resize(at + 8 + REC + (size_t)nc * PAIR + pl, 0);
+            uint8_t* p = data.data() + at;
+            wr64(p, addr(k));
+            p += 8;
+            wr64(p, nd.eow ? (any ? (uint64_t)pl : (uint64_t)nd.value) : 0);
+            wr64(p + 8, (has_fail && nd.fail >= 0) ? addr(nd.fail) : 0);
+            wr32(p + 16, nc);
+            p[20] = nd.eow;
+            p += REC;
+            for (int32_t c = nd.first_child; c >= 0; c = t->nodes[c].next_sibling, p += PAIR) { wr16(p, (uint16_t)(int16_t)(int8_t)t->nodes[c].letter); wr64(p + 2, addr(c)); }
+            if (pl) memcpy(p, payloads[eow_seen], pl);
+            if (nd.eow) eow_seen++;
+        }
+        const size_t at = data.size();
+        data.resize(at + SAVE_FOOTER);
+        wr64(data.data() + at, (uint64_t)order.size());
+        memcpy(data.data() + at + 8, MAGIC, 16);
+        uint8_t* ob = (uint8_t*)malloc(data.size());
+        if (!ob) return acx_fail(ACX_E_NOMEM, "acx_trie_to_ref_savefile: out of memory");
+        memcpy(ob, data.data(), data.size());
+        *buf = ob; *nbytes = data.size();
+    } catch (const std::bad_alloc&) {
+        return acx_fail(ACX_E_NOMEM, "acx_trie_to_ref_savefile: out of memory");
+    }
+    return ACX_OK;
+}
+
+}  // extern "C"

@@ -13,73 +13,13 @@
 //   * children are a sibling list in insertion order + a 256-way direct table at the
 //     root (the only node that is routinely wide);
 //   * BFS order is recorded by make_automaton and reused as the state numbering.
-#include "acx_internal.h"
+#include "acx_trie_impl.h"
 
 #include <algorithm>
 #include <cstdlib>
 #include <cstring>
 #include <new>
 #include <vector>
-
-namespace {
-
-struct Node {
-    int64_t value;
-    int32_t first_child;
-    int32_t next_sibling;
-    int32_t fail;
-    uint8_t letter;
-    uint8_t eow;
-    uint16_t pad;
-};
-static_assert(sizeof(Node) == 24, "Node layout");
-
-}  // namespace
-
-struct acx_trie {
-    std::vector<Node> nodes;        // nodes[0] = root once kind != EMPTY
-    int32_t root_child[256];        // direct index for the root's children (-1 = none)
-    std::vector<int32_t> bfs;       // BFS order recorded by make_automaton (root first)
-    int kind = ACX_KIND_EMPTY;
-    int64_t count = 0;
-    int64_t longest_word = 0;
-    int64_t version = 0;
-    int64_t live_nodes = 0;
-
-    acx_trie() { for (auto& c : root_child) c = -1; }
-
-    int32_t child(int32_t node, uint8_t letter) const {
-        if (node == 0) return root_child[letter];
-        for (int32_t c = nodes[node].first_child; c >= 0; c = nodes[c].next_sibling)
-            if (nodes[c].letter == letter) return c;
-        return -1;
-    }
-
-    int32_t new_node(uint8_t letter) {
-        Node n;
-        n.value = 0; n.first_child = -1; n.next_sibling = -1; n.fail = -1;
-        n.letter = letter; n.eow = 0; n.pad = 0;
-        nodes.push_back(n);
-        live_nodes++;
-        return (int32_t)nodes.size() - 1;
-    }
-
-    // append `c` at the end of `parent`'s sibling list (insertion order, like
-    // trienode_set_next, src/trienode.c:124-147)
-    void link_child(int32_t parent, int32_t c) {
-        int32_t* slot = &nodes[parent].first_child;
-        while (*slot >= 0) slot = &nodes[*slot].next_sibling;
-        *slot = c;
-        if (parent == 0) root_child[nodes[c].letter] = c;
-    }
-
-    void unlink_child(int32_t parent, int32_t c) {
-        int32_t* slot = &nodes[parent].first_child;
-        while (*slot >= 0 && *slot != c) slot = &nodes[*slot].next_sibling;
-        if (*slot == c) *slot = nodes[c].next_sibling;
-        if (parent == 0) root_child[nodes[c].letter] = -1;
-    }
-};
 
 extern "C" {
 

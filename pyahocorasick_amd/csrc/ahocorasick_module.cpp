@@ -18,6 +18,7 @@
 #include <Python.h>
 
 #include <cstdint>
+#include <cstdio>
 #include <cstring>
 #include <vector>
 
@@ -128,25 +129,97 @@ PyObject* make_pair(AutomatonObject* a, int32_t index, int32_t value) {
 }
 
 // ---- Automaton -----------------------------------------------------------------------------
-PyObject* automaton_new(PyTypeObject* type, PyObject* args, PyObject*) {
-    int store = STORE_ANY, key_type = KEY_STRING;
-    if (!PyArg_ParseTuple(args, "|ii", &store, &key_type)) return nullptr;
+bool check_store_key(int store, int key_type) {
     if (store != STORE_INTS && store != STORE_LENGTH && store != STORE_ANY) {
         PyErr_SetString(PyExc_ValueError, "store value must be one of ahocorasick.STORE_LENGTH, STORE_INTS or STORE_ANY");
-        return nullptr;
+        return false;
     }
     if (key_type != KEY_STRING && key_type != KEY_SEQUENCE) {
         PyErr_SetString(PyExc_ValueError, "key_type must have value KEY_STRING or KEY_SEQUENCE");
-        return nullptr;
+        return false;
     }
     if (key_type == KEY_SEQUENCE) {
         PyErr_SetString(PyExc_NotImplementedError, "KEY_SEQUENCE automata are not byte automata; outside the GPU path");
-        return nullptr;
+        return false;
     }
+    return true;
+}
+
+AutomatonObject* automaton_alloc(PyTypeObject* type, int store, int key_type) {
     AutomatonObject* a = (AutomatonObject*)type->tp_alloc(type, 0);
     if (!a) return nullptr;
     a->trie = nullptr; a->values = nullptr; a->image = nullptr; a->result = nullptr; a->image_version = -1;
     a->store = store; a->key_type = key_type;
+    return a;
+}
+
+// the 7-tuple of __reduce__ (ours or the reference's bytes build): src/Automaton.c:107-149,
+// automaton_unpickle src/Automaton_pickle.c:326-488; parsing in libacx (acx_persist.cpp)
+PyObject* automaton_from_pickle(PyTypeObject* type, PyObject* args) {
+    PyObject *bytes_list = nullptr, *values = nullptr;
+    int kind, store, key_type, count, longest;
+    if (!PyArg_ParseTuple(args, "OiiiiiO", &bytes_list, &kind, &store, &key_type, &count, &longest, &values)) {
+        PyErr_SetString(PyExc_ValueError, "Unable to load from pickle.");
+        return nullptr;
+    }
+    if (!check_store_key(store, key_type)) return nullptr;
+    if (kind != K_EMPTY && kind != K_TRIE && kind != K_AHOCORASICK) {
+        PyErr_SetString(PyExc_ValueError, "kind value must be one of ahocorasick.EMPTY, TRIE or AHOCORASICK");
+        return nullptr;
+    }
+    if (!PyList_CheckExact(bytes_list)) { PyErr_SetString(PyExc_TypeError, "Expected list"); return nullptr; }
+    AutomatonObject* a = automaton_alloc(type, store, key_type);
+    if (!a) return nullptr;
+    int rc;
+    if (kind == K_EMPTY) {
+        rc = acx_trie_new(&a->trie);
+        if (rc) { Py_DECREF(a); return set_acx_error(rc); }
+        if (store == STORE_ANY && !(a->values = PyList_New(0))) { Py_DECREF(a); return nullptr; }
+        return (PyObject*)a;
+    }
+    const Py_ssize_t n = PyList_GET_SIZE(bytes_list);
+    std::vector<const void*> ptrs((size_t)n);
+    std::vector<size_t> sizes((size_t)n);
+    for (Py_ssize_t k = 0; k < n; k++) {
+        PyObject* b = PyList_GET_ITEM(bytes_list, k);
+        if (!PyBytes_CheckExact(b)) {
+            PyErr_Format(PyExc_ValueError, "Item #%zd on the bytes list is not a bytes object", k);
+            Py_DECREF(a);
+            return nullptr;
+        }
+        ptrs[(size_t)k] = PyBytes_AS_STRING(b);
+        sizes[(size_t)k] = (size_t)PyBytes_GET_SIZE(b);
+    }
+    int64_t n_eow = 0;
+    rc = acx_trie_from_ref_pickle(ptrs.data(), sizes.data(), (size_t)n, store == STORE_ANY, longest, &a->trie, &n_eow);
+    if (rc) {
+        Py_DECREF(a);
+        if (rc == ACX_E_NOMEM) return PyErr_NoMemory();
+        PyErr_SetString(PyExc_ValueError, acx_last_error());
+        return nullptr;
+    }
+    if (store == STORE_ANY) {
+        if (!PyList_Check(values) || PyList_GET_SIZE(values) < (Py_ssize_t)n_eow) {
+            PyErr_SetString(PyExc_IndexError, "list index out of range");
+            Py_DECREF(a);
+            return nullptr;
+        }
+        if (!(a->values = PyList_GetSlice(values, 0, (Py_ssize_t)n_eow))) { Py_DECREF(a); return nullptr; }
+    }
+    if (kind == K_AHOCORASICK) {
+        rc = acx_trie_make_automaton(a->trie, nullptr);
+        if (rc) { Py_DECREF(a); return set_acx_error(rc); }
+    }
+    return (PyObject*)a;
+}
+
+PyObject* automaton_new(PyTypeObject* type, PyObject* args, PyObject*) {
+    if (PyTuple_GET_SIZE(args) == 7) return automaton_from_pickle(type, args);
+    int store = STORE_ANY, key_type = KEY_STRING;
+    if (!PyArg_ParseTuple(args, "|ii", &store, &key_type)) return nullptr;
+    if (!check_store_key(store, key_type)) return nullptr;
+    AutomatonObject* a = automaton_alloc(type, store, key_type);
+    if (!a) return nullptr;
     int rc = acx_trie_new(&a->trie);
     if (rc) { Py_DECREF(a); return set_acx_error(rc); }
     if (store == STORE_ANY) { a->values = PyList_New(0); if (!a->values) { Py_DECREF(a); return nullptr; } }
@@ -502,6 +575,93 @@ PyObject* automaton_iter_batch(AutomatonObject* a, PyObject* args, PyObject* kw)
     return out;
 }
 
+// ---- persistence in the reference's formats (parsing/writing in acx_persist.cpp) ----
+// objects of the keys in dump (pre-order) order: the `values` list of a STORE_ANY pickle
+PyObject* eow_objects(AutomatonObject* a) {
+    int64_t* ids = nullptr; int64_t n = 0;
+    int rc = acx_trie_eow_values(a->trie, &ids, &n);
+    if (rc) return set_acx_error(rc);
+    PyObject* list = PyList_New((Py_ssize_t)n);
+    for (int64_t k = 0; list && k < n; k++) {
+        PyObject* o = PyList_GetItem(a->values, (Py_ssize_t)ids[k]);  // borrowed
+        if (!o) { Py_CLEAR(list); break; }
+        Py_INCREF(o);
+        PyList_SET_ITEM(list, (Py_ssize_t)k, o);
+    }
+    acx_blob_free(ids);
+    return list;
+}
+
+// same tuple as the reference (src/Automaton_pickle.c:192-285): loadable by either side
+PyObject* automaton_reduce(AutomatonObject* a, PyObject*) {
+    if (acx_trie_num_keys(a->trie) == 0) return Py_BuildValue("O()", Py_TYPE(a));
+    void* buf = nullptr; size_t* sizes = nullptr; size_t n = 0;
+    int rc = acx_trie_to_ref_pickle(a->trie, a->store == STORE_ANY, 0, &buf, &sizes, &n);
+    if (rc) return set_acx_error(rc);
+    PyObject* chunks = PyList_New((Py_ssize_t)n);
+    size_t at = 0;
+    for (size_t k = 0; chunks && k < n; k++) {
+        PyObject* b = PyBytes_FromStringAndSize((const char*)buf + at, (Py_ssize_t)sizes[k]);
+        if (!b) { Py_CLEAR(chunks); break; }
+        PyList_SET_ITEM(chunks, (Py_ssize_t)k, b);
+        at += sizes[k];
+    }
+    acx_blob_free(buf); acx_blob_free(sizes);
+    if (!chunks) return nullptr;
+    PyObject* values;
+    if (a->store == STORE_ANY) { values = eow_objects(a); if (!values) { Py_DECREF(chunks); return nullptr; } }
+    else { values = Py_None; Py_INCREF(values); }
+    return Py_BuildValue("O(NiiiiiN)", Py_TYPE(a), chunks, acx_trie_kind(a->trie), a->store, a->key_type,
+                         (int)acx_trie_num_keys(a->trie), (int)acx_trie_longest_word(a->trie), values);
+}
+
+// argument rules of save()/load(): src/custompickle/pyhelpers.c:4-59
+bool parse_path_callback(int store, PyObject* args, const char** path, PyObject** callback) {
+    if (store == STORE_ANY) {
+        if (PyTuple_GET_SIZE(args) != 2) { PyErr_SetString(PyExc_ValueError, "expected exactly two arguments"); return false; }
+    } else if (PyTuple_GET_SIZE(args) != 1) { PyErr_SetString(PyExc_ValueError, "expected exactly one argument"); return false; }
+    PyObject* s = PyTuple_GET_ITEM(args, 0);
+    if (!PyUnicode_Check(s)) { PyErr_SetString(PyExc_TypeError, "the first argument must be a string"); return false; }
+    *callback = nullptr;
+    if (store == STORE_ANY) {
+        *callback = PyTuple_GET_ITEM(args, 1);
+        if (!PyCallable_Check(*callback)) { PyErr_SetString(PyExc_TypeError, "the second argument must be a callable object"); return false; }
+    }
+    *path = PyUnicode_AsUTF8(s);
+    return *path != nullptr;
+}
+
+// Automaton.save(path[, serializer]): src/custompickle/save/automaton_save.c:13-138
+PyObject* automaton_save(AutomatonObject* a, PyObject* args) {
+    const char* path; PyObject* serializer;
+    if (!parse_path_callback(a->store, args, &path, &serializer)) return nullptr;
+    std::vector<PyObject*> keep;                 // serialized values, kept alive until written
+    std::vector<const void*> ptrs;
+    std::vector<size_t> sizes;
+    auto release = [&]() { for (PyObject* o : keep) Py_DECREF(o); };
+    if (a->store == STORE_ANY) {
+        PyObject* objs = eow_objects(a);
+        if (!objs) return nullptr;
+        for (Py_ssize_t k = 0; k < PyList_GET_SIZE(objs); k++) {
+            PyObject* b = PyObject_CallFunctionObjArgs(serializer, PyList_GET_ITEM(objs, k), nullptr);
+            if (b && !PyBytes_CheckExact(b)) { Py_DECREF(b); b = nullptr; PyErr_SetString(PyExc_TypeError, "serializer must return bytes object"); }
+            if (!b) { Py_DECREF(objs); release(); return nullptr; }
+            keep.push_back(b); ptrs.push_back(PyBytes_AS_STRING(b)); sizes.push_back((size_t)PyBytes_GET_SIZE(b));
+        }
+        Py_DECREF(objs);
+    }
+    void* buf = nullptr; size_t nbytes = 0;
+    int rc = acx_trie_to_ref_savefile(a->trie, a->store, a->key_type, ptrs.data(), sizes.data(), &buf, &nbytes);
+    release();
+    if (rc) return set_acx_error(rc);
+    FILE* f = fopen(path, "wb");
+    const bool ok = f && fwrite(buf, 1, nbytes, f) == nbytes;
+    if (f) fclose(f);
+    acx_blob_free(buf);
+    if (!ok) return PyErr_SetFromErrnoWithFilename(PyExc_IOError, path);
+    Py_RETURN_NONE;
+}
+
 PyObject* automaton_get_stats(AutomatonObject* a, PyObject*) {
     return Py_BuildValue("{s:L,s:L,s:L}", "nodes_count", (long long)acx_trie_num_nodes(a->trie),
                          "words_count", (long long)acx_trie_num_keys(a->trie),
@@ -522,6 +682,8 @@ PyMethodDef automaton_methods[] = {
     {"find_all", (PyCFunction)automaton_find_all, METH_VARARGS, "find_all(string, callback, [start, [end]])"},
     {"iter_batch", (PyCFunction)automaton_iter_batch, METH_VARARGS | METH_KEYWORDS, "iter_batch(haystacks, long=False) -> list of lists (GPU batch scan)"},
     {"get_stats", (PyCFunction)automaton_get_stats, METH_NOARGS, "get_stats() -> dict"},
+    {"__reduce__", (PyCFunction)automaton_reduce, METH_NOARGS, "pickle support: the reference's (bytes build) payload"},
+    {"save", (PyCFunction)automaton_save, METH_VARARGS, "save(path[, serializer]): the reference's file format"},
     {nullptr, nullptr, 0, nullptr}};
 
 PyGetSetDef automaton_getset[] = {
@@ -533,9 +695,64 @@ PySequenceMethods automaton_as_sequence = {};
 
 PyTypeObject AutomatonType = {PyVarObject_HEAD_INIT(nullptr, 0) "ahocorasick.Automaton"};
 
+// ahocorasick.load(path, deserializer): src/custompickle/load/module_automaton_load.c:12-36
+PyObject* module_load(PyObject*, PyObject* args) {
+    const char* path; PyObject* deserializer;
+    if (!parse_path_callback(STORE_ANY, args, &path, &deserializer)) return nullptr;   // both arguments, always
+    FILE* f = fopen(path, "rb");
+    if (!f) return PyErr_SetFromErrnoWithFilename(PyExc_IOError, path);
+    std::vector<uint8_t> data;
+    uint8_t chunk[1 << 16];
+    for (size_t got; (got = fread(chunk, 1, sizeof chunk, f)) > 0;) data.insert(data.end(), chunk, chunk + got);
+    fclose(f);
+    acx_trie_t* trie = nullptr; acx_ref_meta_t meta; int64_t *poff = nullptr, *plen = nullptr;
+    int rc = acx_trie_from_ref_savefile(data.data(), data.size(), &trie, &meta, &poff, &plen);
+    if (rc) {
+        if (rc == ACX_E_NOMEM) return PyErr_NoMemory();
+        PyErr_SetString(PyExc_ValueError, acx_last_error());
+        return nullptr;
+    }
+    AutomatonObject* a = nullptr;
+    if ((meta.kind == K_EMPTY || meta.kind == K_TRIE || meta.kind == K_AHOCORASICK) && check_store_key(meta.store, meta.key_type))
+        a = automaton_alloc(&AutomatonType, meta.store, meta.key_type);
+    else if (!PyErr_Occurred()) PyErr_SetString(PyExc_ValueError, "invalid header");
+    bool ok = a != nullptr;
+    if (ok) {
+        a->trie = trie; trie = nullptr;
+        if (!a->trie) ok = acx_trie_new(&a->trie) == ACX_OK;
+        if (ok && meta.store == STORE_ANY) {
+            a->values = PyList_New((Py_ssize_t)meta.n_eow);
+            ok = a->values != nullptr;
+            for (int64_t k = 0; ok && k < meta.n_eow; k++) {
+                PyObject* b = PyBytes_FromStringAndSize((const char*)data.data() + poff[k], (Py_ssize_t)plen[k]);
+                PyObject* v = b ? PyObject_CallFunctionObjArgs(deserializer, b, nullptr) : nullptr;
+                Py_XDECREF(b);
+                if (!v) { ok = false; break; }
+                PyList_SET_ITEM(a->values, (Py_ssize_t)k, v);
+            }
+            if (!ok && a->values) {                       // fill the holes so that dealloc is safe
+                for (Py_ssize_t k = 0; k < PyList_GET_SIZE(a->values); k++)
+                    if (!PyList_GET_ITEM(a->values, k)) { Py_INCREF(Py_None); PyList_SET_ITEM(a->values, k, Py_None); }
+            }
+        }
+        if (ok && meta.kind == K_AHOCORASICK && acx_trie_num_keys(a->trie) > 0) {
+            rc = acx_trie_make_automaton(a->trie, nullptr);
+            if (rc) { set_acx_error(rc); ok = false; }
+        }
+    }
+    if (trie) acx_trie_free(trie);
+    acx_blob_free(poff); acx_blob_free(plen);
+    if (!ok) { Py_XDECREF(a); if (!PyErr_Occurred()) PyErr_SetString(PyExc_RuntimeError, acx_last_error()); return nullptr; }
+    return (PyObject*)a;
+}
+
+PyMethodDef module_methods[] = {
+    {"load", (PyCFunction)module_load, METH_VARARGS, "load(path, deserializer) -> Automaton: read a file written by Automaton.save"},
+    {nullptr, nullptr, 0, nullptr}};
+
 PyModuleDef module_def = {PyModuleDef_HEAD_INIT, "ahocorasick",
                           "MI355X-native Aho-Corasick scan engine behind the pyahocorasick Automaton API (bytes build)",
-                          -1, nullptr, nullptr, nullptr, nullptr, nullptr};
+                          -1, module_methods, nullptr, nullptr, nullptr, nullptr};
 
 }  // namespace
 
