@@ -1,0 +1,36 @@
+"""PCIe-inclusive rate of the host entry point (acx_scan_host: H2D + scan + D2H), config 2.
+Reported in DESIGN.md §4; never the bench `value`."""
+import json
+import sys
+import time
+
+import numpy as np
+
+sys.path.insert(0, __file__.rsplit("/", 2)[0])
+from pyahocorasick_amd import Automaton, STORE_INTS            # noqa: E402
+from pyahocorasick_amd.workloads import dna_keys, dna_reads    # noqa: E402
+
+
+def main():
+    n_reads = int(sys.argv[1]) if len(sys.argv) > 1 else 1_000_000
+    keys = dna_keys(100_000, seed=1)
+    reads = dna_reads(keys, n_reads, 150, seed=2)
+    A = Automaton(STORE_INTS)
+    for i, k in enumerate(keys):
+        A.add_word(bytes(k), i)
+    A.make_automaton()
+    data = np.ascontiguousarray(reads).reshape(-1)
+    off = np.arange(n_reads + 1, dtype=np.int64) * 150
+    A.scan_batch(data, off)                                    # warm-up: image upload, buffers
+    ts = []
+    for _ in range(5):
+        t0 = time.perf_counter()
+        res = A.scan_batch(data, off)
+        ts.append(time.perf_counter() - t0)
+    t = min(ts)
+    print(json.dumps({"reads": n_reads, "bytes": int(data.size), "matches": int(res.num_matches()),
+                      "best_s": t, "all_s": ts, "GBps_haystack_pcie_inclusive": data.size / t / 1e9}))
+
+
+if __name__ == "__main__":
+    main()
