@@ -38,7 +38,7 @@ def build_libacx(force=False, verbose=True):
     if not force and not needs_build():
         return LIB
     cmd = [_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
-           "-Wall", "-Wno-unused-function",
+           "-Wall", "-Wno-unused-function", *os.environ.get("ACX_EXTRA_CFLAGS", "").split(),
            # code object v5 loads on every ROCm >= 5.x runtime, including the HIP runtime that
            # PyTorch wheels bundle (a process must only ever hold ONE HIP runtime: see _lib.py)
            "-mcode-object-version=5",
