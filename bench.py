@@ -40,6 +40,15 @@ def parse():
     ap.add_argument("--read-len", type=int, default=150)
     ap.add_argument("--mode", choices=["iter", "iter_long"], default="iter")
     ap.add_argument("--variant", type=int, default=0)
+    ap.add_argument("--pipeline", type=int, default=1,
+                    help="result objects kept in flight per GPU (ACX_SCAN_ASYNC): the host queues step i+1 while "
+                         "step i runs.  1 (default) = synchronous call per step (on one stream the GPU does not "
+                         "idle between steps either way: measured)")
+    ap.add_argument("--streams", type=int, default=1,
+                    help="streams the in-flight steps are spread over.  1 (default): every kernel still runs alone, "
+                         "one after the other, so kernel times are standalone durations.  2 lets consecutive steps "
+                         "overlap on the GPU (needs --pipeline >= 2; +5-13 %% measured: 180-194 GB/s) but concurrent "
+                         "kernels stretch each other and the per-kernel roofline is then not a standalone figure")
     ap.add_argument("--cpu-sample-reads", type=int, default=1_000_000,
                     help="reads timed on the CPU baseline leg (0 disables it)")
     ap.add_argument("--verify", action="store_true", help="check a sample of the GPU output against the oracle")
@@ -144,21 +153,35 @@ def main():
     d_hay[: n * L].copy_(torch.from_numpy(reads.reshape(-1)))
     torch.cuda.synchronize()
     mode = acx.ACX_SCAN_ALL if args.mode == "iter" else acx.ACX_SCAN_LONG
-    sc = Scanner(image)
+    # every step is one complete batch scan (walk + prefix sum + expand -> match records in HBM) of
+    # the same resident batch; with --pipeline P, P result objects on P streams are kept in flight
+    P = max(1, args.pipeline)
+    scs = [Scanner(image) for _ in range(P)]
+    sc = scs[0]
     stream = torch.cuda.current_stream().cuda_stream
+    S = max(1, min(args.streams, P))
+    tstreams = [torch.cuda.Stream(device=dev) for _ in range(S)] if S > 1 else []
+    streams = [t.cuda_stream for t in tstreams] if S > 1 else [stream]
 
-    def step(timing=False):
-        return sc.scan(d_hay.data_ptr(), n * L, n, stride=L, mode=mode, timing=timing, variant=args.variant, stream=stream)
+    def step(timing=False, k=0):
+        return scs[k % P].scan(d_hay.data_ptr(), n * L, n, stride=L, mode=mode, timing=timing, variant=args.variant,
+                               stream=streams[k % P % S], asynchronous=P > 1)
 
-    for _ in range(args.warmup):
-        step()
-    # per-kernel times from HIP events on the scan's stream (separate, untimed passes)
+    for k in range(max(args.warmup, P)):
+        step(k=k)
+    for x in scs:
+        x.wait()
+    # per-kernel times from HIP events on each scan's stream (separate passes, same pipelining as the
+    # timed loop: with P > 1 a walk shares the GPU with the previous step's expand, as it does there)
     kt = {"walk": [], "scan": [], "expand": [], "total": []}
     for _ in range(3):
-        step(timing=True)
-        t = sc.timing_ms()
-        for k in kt:
-            kt[k].append(t[k])
+        for k in range(P):
+            step(timing=True, k=k)
+        for x in scs:
+            x.wait()
+            t = x.timing_ms()
+            for k in kt:
+                kt[k].append(t[k])
     matches = sc.num_matches()
 
     def barrier():
@@ -168,8 +191,10 @@ def main():
 
     barrier()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
+    for k in range(args.steps):
+        step(k=k)
+    for x in scs:
+        x.wait()                                   # every step complete: totals read, records in HBM
     barrier()
     dt = time.perf_counter() - t0
     if dist is not None:
@@ -227,7 +252,7 @@ def main():
             "config": {"workload": "config2: %d ACGT keys 8-32 B, %d x %d B reads per GPU, Automaton.%s"
                                    % (args.keys, n, L, args.mode),
                        "states": int(image.num_states), "classes": int(image.num_classes), "itop_depth": int(image.itop_depth),
-                       "image_mb": round(image.nbytes / 1e6, 1), "variant": args.variant,
+                       "image_mb": round(image.nbytes / 1e6, 1), "variant": args.variant, "pipeline_depth": P, "streams": S,
                        "parallelism": "replicated automaton (1 RCCL broadcast), reads sharded x%d" % world},
             # dominant kernel = the walk: it alone reads the haystack (H) and the per-haystack
             # bookkeeping (12 B x N); the 8 B x M match records are written by k_expand.

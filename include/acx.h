@@ -189,16 +189,23 @@ typedef struct acx_scan_params {
     int32_t  want_final_state; /* 1 => fill final_state */
     int32_t  timing;           /* 1 => record HIP events around each kernel */
     int32_t  variant;          /* 0 = default; >0 selects an alternative kernel (bench/tuning) */
-    int32_t  reserved;
+    int32_t  flags;            /* ACX_SCAN_ASYNC or 0 */
 } acx_scan_params;
+/* Return as soon as the kernels are queued on `stream`.  The result completes (stream sync,
+ * total read, expand re-run if the match buffer was too small) in acx_result_wait or in the
+ * first accessor.  Lets one host thread keep several batches in flight on several streams:
+ * the expand of batch i then overlaps the walk of batch i+1 (bench.py --pipeline). */
+enum { ACX_SCAN_ASYNC = 1 };
 
 typedef struct acx_result acx_result_t;
 
 /* `*result` may be NULL (a new result object is created) or a previous result whose
- * device buffers are then reused/grown — the steady-state path allocates nothing. */
+ * device buffers are then reused/grown — the steady-state path allocates nothing.
+ * Reusing a result that is still in flight waits for it first. */
 int  acx_scan_batch(acx_image_t* img, const acx_scan_params* p, acx_result_t** result, void* stream);
+int  acx_result_wait(acx_result_t* r);
 
-/* All accessors below synchronise with the scan's stream as needed. */
+/* All accessors below complete the scan (acx_result_wait) as needed. */
 int64_t            acx_result_num_matches(acx_result_t* r);
 const int64_t*     acx_result_offsets_dev(acx_result_t* r);
 const acx_match_t* acx_result_matches_dev(acx_result_t* r);

@@ -14,6 +14,7 @@ ACX_OK = 0
 ACX_E_INVAL, ACX_E_NOMEM, ACX_E_STATE, ACX_E_HIP = -1, -2, -3, -4
 ACX_E_UNSUPPORTED, ACX_E_FORMAT, ACX_E_NODEVICE = -5, -6, -7
 ACX_SCAN_ALL, ACX_SCAN_LONG = 0, 1
+ACX_SCAN_ASYNC = 1
 ACX_BLOB_HEADER_BYTES = 256
 
 
@@ -38,7 +39,7 @@ class ScanParams(C.Structure):
         ("dev_off", C.c_void_p), ("stride", C.c_int64), ("n_hay", C.c_int64),
         ("dev_init_state", C.c_void_p), ("dev_index_base", C.c_void_p),
         ("want_final_state", C.c_int32), ("timing", C.c_int32),
-        ("variant", C.c_int32), ("reserved", C.c_int32),
+        ("variant", C.c_int32), ("flags", C.c_int32),
     ]
 
 
@@ -85,6 +86,7 @@ SIGNATURES = {
     "acx_image_itop_depth": (C.c_int, [_P]),
     "acx_image_table_dev_ptr": (C.c_void_p, [_P]),
     "acx_scan_batch": (C.c_int, [_P, C.POINTER(ScanParams), _PP, _P]),
+    "acx_result_wait": (C.c_int, [_P]),
     "acx_result_num_matches": (C.c_int64, [_P]),
     "acx_result_offsets_dev": (C.c_void_p, [_P]),
     "acx_result_matches_dev": (C.c_void_p, [_P]),

@@ -225,7 +225,13 @@ struct acx_result {
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
     bool timed = false;
     float t_walk = 0, t_scan = 0, t_expand = 0, t_total = 0;
+    // ACX_SCAN_ASYNC: kernels queued, not yet completed (see result_complete)
+    bool pending = false;
+    acx_expand_args pend_ea;
+    int pend_variant = 0;
+    int device = 0;
     ~acx_result() {
+        if (pending) (void)hipStreamSynchronize(stream);
         counts.release(); nev.release(); final_state.release(); match_off.release(); partials.release();
         nck.release(); ck_first.release(); ck_match_off.release(); ck.release();
         events.release(); matches.release(); h_off.release(); h_matches.release(); h_final.release(); h_total.release();
@@ -233,6 +239,43 @@ struct acx_result {
         for (auto& e : ev) if (e) (void)hipEventDestroy(e);
     }
 };
+
+// Finish a scan whose kernels are queued: wait, read the total, and if the speculative expand did
+// not fit the match buffer grow it and run expand again (the events are intact).
+static int result_complete(acx_result* r) {
+    if (!r || !r->pending) return ACX_OK;
+    r->pending = false;
+    hipStream_t s = r->stream;
+    HIP_TRY(hipStreamSynchronize(s));
+    r->total = r->h_total.p[0];
+    if (r->timed) {
+        HIP_TRY(hipEventElapsedTime(&r->t_walk, r->ev[0], r->ev[1]));
+        HIP_TRY(hipEventElapsedTime(&r->t_scan, r->ev[1], r->ev[2]));
+        HIP_TRY(hipEventElapsedTime(&r->t_expand, r->ev[2], r->ev[3]));
+        HIP_TRY(hipEventElapsedTime(&r->t_total, r->ev[0], r->ev[3]));
+    }
+    if (r->total > (int64_t)r->matches.cap) {
+        // first call / larger batch than ever seen: grow and run expand again
+        int rc;
+        if ((rc = r->matches.ensure((size_t)r->total))) return rc;
+        acx_expand_args ea = r->pend_ea;
+        ea.matches = r->matches.p; ea.capacity = (int64_t)r->matches.cap;
+        if (r->timed) HIP_TRY(hipEventRecord(r->ev[2], s));
+        HIP_TRY(acx_launch_expand(ea, r->pend_variant, s));
+        if (r->timed) HIP_TRY(hipEventRecord(r->ev[3], s));
+        HIP_TRY(hipStreamSynchronize(s));
+        if (r->timed) {
+            HIP_TRY(hipEventElapsedTime(&r->t_expand, r->ev[2], r->ev[3]));
+            r->t_total = r->t_walk + r->t_scan + r->t_expand;
+        }
+    }
+    return ACX_OK;
+}
+
+extern "C" int acx_result_wait(acx_result_t* r) {
+    if (!r) return acx_fail(ACX_E_INVAL, "acx_result_wait: NULL result");
+    return result_complete(r);
+}
 
 extern "C" void acx_result_free(acx_result_t* r) { delete r; }
 
@@ -265,6 +308,7 @@ extern "C" int acx_scan_batch(acx_image_t* img, const acx_scan_params* p, acx_re
         if (!r) return acx_fail(ACX_E_NOMEM, "acx_scan_batch: out of memory");
         *result = r;
     }
+    if (r->pending) { int rcw = result_complete(r); if (rcw) return rcw; }     // still in flight on its old stream
     r->stream = s; r->n_hay = p->n_hay; r->total = 0; r->host_valid = false;
     r->has_final = p->want_final_state != 0; r->timed = p->timing != 0;
 
@@ -319,6 +363,7 @@ extern "C" int acx_scan_batch(acx_image_t* img, const acx_scan_params* p, acx_re
     // state (an arbitrary shallow state id has no k-gram history).  variant bit 16 turns it off (A/B).
     const bool use_itop = p->mode == ACX_SCAN_ALL && img->itop_lds && !p->dev_init_state && !((p->variant >> 16) & 1);
 
+    const bool async = (p->flags & ACX_SCAN_ASYNC) != 0;
     if (r->timed) HIP_TRY(hipEventRecord(r->ev[0], s));
     if (chunked) {
         acx_chunk_args ca;
@@ -359,37 +404,23 @@ extern "C" int acx_scan_batch(acx_image_t* img, const acx_scan_params* p, acx_re
     if (chunked) HIP_TRY(acx_launch_hay_offsets(r->ck_first.p, r->ck_match_off.p, p->n_hay, r->match_off.p, s));
     if (r->timed) HIP_TRY(hipEventRecord(r->ev[3], s));
     HIP_TRY(hipMemcpyAsync(r->h_total.p, item_match_off + n_items, sizeof(int64_t), hipMemcpyDeviceToHost, s));
-    HIP_TRY(hipStreamSynchronize(s));
-    r->total = r->h_total.p[0];
-    if (r->timed) {
-        HIP_TRY(hipEventElapsedTime(&r->t_walk, r->ev[0], r->ev[1]));
-        HIP_TRY(hipEventElapsedTime(&r->t_scan, r->ev[1], r->ev[2]));
-        HIP_TRY(hipEventElapsedTime(&r->t_expand, r->ev[2], r->ev[3]));
-        HIP_TRY(hipEventElapsedTime(&r->t_total, r->ev[0], r->ev[3]));
-    }
-    if (r->total > (int64_t)r->matches.cap) {
-        // first call / larger batch than ever seen: grow and run expand again (events are intact)
-        if ((rc = r->matches.ensure((size_t)r->total))) return rc;
-        ea.matches = r->matches.p; ea.capacity = (int64_t)r->matches.cap;
-        if (r->timed) HIP_TRY(hipEventRecord(r->ev[2], s));
-        HIP_TRY(acx_launch_expand(ea, p->variant, s));
-        if (r->timed) HIP_TRY(hipEventRecord(r->ev[3], s));
-        HIP_TRY(hipStreamSynchronize(s));
-        if (r->timed) {
-            HIP_TRY(hipEventElapsedTime(&r->t_expand, r->ev[2], r->ev[3]));
-            r->t_total = r->t_walk + r->t_scan + r->t_expand;
-        }
-    }
-    return ACX_OK;
+    r->pending = true; r->pend_ea = ea; r->pend_variant = p->variant;
+    if (async) return ACX_OK;
+    return result_complete(r);
 }
 
-extern "C" int64_t acx_result_num_matches(acx_result_t* r) { return r ? r->total : 0; }
-extern "C" const int64_t* acx_result_offsets_dev(acx_result_t* r) { return r ? r->match_off.p : nullptr; }
-extern "C" const acx_match_t* acx_result_matches_dev(acx_result_t* r) { return r ? (const acx_match_t*)r->matches.p : nullptr; }
-extern "C" const int32_t* acx_result_final_state_dev(acx_result_t* r) { return (r && r->has_final) ? r->final_state.p : nullptr; }
+extern "C" int64_t acx_result_num_matches(acx_result_t* r) { return (r && result_complete(r) == ACX_OK) ? r->total : 0; }
+extern "C" const int64_t* acx_result_offsets_dev(acx_result_t* r) { return (r && result_complete(r) == ACX_OK) ? r->match_off.p : nullptr; }
+extern "C" const acx_match_t* acx_result_matches_dev(acx_result_t* r) {
+    return (r && result_complete(r) == ACX_OK) ? (const acx_match_t*)r->matches.p : nullptr;
+}
+extern "C" const int32_t* acx_result_final_state_dev(acx_result_t* r) {
+    return (r && r->has_final && result_complete(r) == ACX_OK) ? r->final_state.p : nullptr;
+}
 
 extern "C" int acx_result_fetch_host(acx_result_t* r, const int64_t** off, const acx_match_t** matches, const int32_t** final_state) {
     if (!r) return acx_fail(ACX_E_INVAL, "acx_result_fetch_host: NULL result");
+    { int rcw = result_complete(r); if (rcw) return rcw; }
     if (!r->host_valid) {
         int rc;
         const size_t n = (size_t)r->n_hay;
@@ -412,6 +443,7 @@ extern "C" int acx_result_fetch_host(acx_result_t* r, const int64_t** off, const
 
 extern "C" int acx_result_timing(acx_result_t* r, float* walk_ms, float* scan_ms, float* expand_ms, float* total_ms) {
     if (!r) return acx_fail(ACX_E_INVAL, "acx_result_timing: NULL result");
+    { int rcw = result_complete(r); if (rcw) return rcw; }
     if (!r->timed) return acx_fail(ACX_E_STATE, "acx_result_timing: the last scan was not run with params.timing = 1");
     if (walk_ms) *walk_ms = r->t_walk;
     if (scan_ms) *scan_ms = r->t_scan;

@@ -529,7 +529,9 @@ __global__ void __launch_bounds__(ACX_ITOP_BLOCK) k_walk_itop(const acx_walk_arg
     const int64_t n_items = ck ? *n_chunks_dev : a.n_hay;
     const int64_t per_task = (int64_t)ACX_WAVE * ILP;
     const int64_t n_tasks = (n_items + per_task - 1) / per_task;
-    const int64_t wave0 = (int64_t)blockIdx.x * (blockDim.x / ACX_WAVE) + (threadIdx.x / ACX_WAVE);
+    // wave numbering is block-minor: the last, partial round of tasks then spreads over ALL CUs
+    // (each runs a few waves less) instead of leaving the highest-numbered CUs idle
+    const int64_t wave0 = (int64_t)(threadIdx.x / ACX_WAVE) * gridDim.x + blockIdx.x;
     const int64_t n_waves = (int64_t)gridDim.x * (blockDim.x / ACX_WAVE);
     const uint8_t* limit = a.hay + a.hay_cap;
 

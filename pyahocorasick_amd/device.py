@@ -8,7 +8,7 @@ import ctypes as C
 
 import numpy as np
 
-from ._lib import ACX_SCAN_ALL, ACX_BLOB_HEADER_BYTES, ScanParams, check, lib
+from ._lib import ACX_SCAN_ALL, ACX_SCAN_ASYNC, ACX_BLOB_HEADER_BYTES, ScanParams, check, lib
 
 
 class DeviceBuffer:
@@ -137,8 +137,10 @@ class Scanner:
 
     def scan(self, dev_hay, hay_capacity, n_hay, dev_off=None, stride=0, mode=ACX_SCAN_ALL,
              dev_init_state=None, dev_index_base=None, want_final_state=False, timing=False,
-             variant=0, stream=None):
-        """All pointer arguments are raw device addresses (int / c_void_p / None)."""
+             variant=0, stream=None, asynchronous=False):
+        """All pointer arguments are raw device addresses (int / c_void_p / None).
+        asynchronous=True: return as soon as the kernels are queued on `stream` (returns None);
+        `wait()`, `num_matches()`, `fetch()` complete the scan."""
         p = ScanParams()
         p.struct_bytes = C.sizeof(ScanParams)
         p.mode = mode
@@ -152,9 +154,14 @@ class Scanner:
         p.want_final_state = 1 if want_final_state else 0
         p.timing = 1 if timing else 0
         p.variant = int(variant)
+        p.flags = ACX_SCAN_ASYNC if asynchronous else 0
         check(lib().acx_scan_batch(self.image.handle, C.byref(p), C.byref(self._res), _addr(stream)))
         self.n_hay = int(n_hay)
-        return lib().acx_result_num_matches(self._res)
+        return None if asynchronous else lib().acx_result_num_matches(self._res)
+
+    def wait(self):
+        if self._res:
+            check(lib().acx_result_wait(self._res))
 
     def timing_ms(self):
         w, s, e, t = C.c_float(), C.c_float(), C.c_float(), C.c_float()
