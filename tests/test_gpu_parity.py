@@ -570,3 +570,34 @@ def test_implicit_top_eight_byte_cells_with_foreign_bytes():
     hay_alpha = np.frombuffer(b"0123456789abcdef \n-", dtype=np.uint8)
     reads = np.ascontiguousarray(hay_alpha[rng.integers(0, len(hay_alpha), size=(n, L))])
     assert _scan_all_ways(A, O, reads, n, L) > 0
+
+
+def test_asynchronous_scans_complete_lazily():
+    """ACX_SCAN_ASYNC: the call returns with the kernels queued; wait()/num_matches()/fetch() complete
+    the scan (including the expand re-run when the first guess of the match capacity was too
+    small), and reusing a result that is still in flight waits for it first"""
+    keys, reads = dna_workload(3000, 4000, 150, seed=21)
+    A, O = build_pair(keys)
+    n, L = reads.shape
+    off = np.arange(n + 1, dtype=np.int64) * L
+    mo, oe, ov = O.batch(reads.tobytes(), off, 0)
+    img = Image.from_automaton(A)
+    d_hay = DeviceBuffer.from_numpy(reads.reshape(-1), pad=64)
+    small = DeviceBuffer.from_numpy(np.ascontiguousarray(reads[:8]).reshape(-1), pad=64)
+    a, b = Scanner(img), Scanner(img)
+    assert a.scan(d_hay, n * L, n, stride=L, asynchronous=True) is None      # fresh result: capacity guess, re-run
+    assert b.scan(d_hay, n * L, n, stride=L, asynchronous=True) is None
+    a.wait()
+    for sc in (a, b):
+        assert sc.num_matches() == len(oe)
+        moff, e, v, _ = sc.fetch()
+        assert np.array_equal(moff, mo) and np.array_equal(e, oe) and np.array_equal(v, ov)
+    # reuse while in flight: the small scan must not disturb ... and the big one again afterwards
+    a.scan(small, 8 * L, 8, stride=L, asynchronous=True)
+    a.scan(d_hay, n * L, n, stride=L, asynchronous=True)
+    moff, e, v, _ = a.fetch()
+    assert np.array_equal(moff, mo) and np.array_equal(e, oe) and np.array_equal(v, ov)
+    a.scan(small, 8 * L, 8, stride=L, asynchronous=True)
+    m8, e8, v8 = O.batch(reads[:8].tobytes(), off[:9], 0)
+    moff, e, v, _ = a.fetch()
+    assert np.array_equal(moff, m8) and np.array_equal(e, e8) and np.array_equal(v, v8)
