@@ -216,6 +216,18 @@ __global__ void __launch_bounds__(ACX_BLOCK, ILP == 1 ? 8 : 5) k_walk_all(const 
                 }
                 continue;
             }
+            if (ILP == 1 && __all(rem[0] >= 64)) {
+                // 64 bytes per visit: a lane streams its own cache line, and one fetched 16 bytes at a
+                // time is usually evicted from L2 between visits (profiles/r02_experiments.md)
+                uint4 w4[4];
+#pragma unroll
+                for (int t = 0; t < 4; t++) w4[t] = load16_guarded<(NT & 1) != 0>(p[0] + j0 + 16 * t, limit);
+#pragma unroll
+                for (int t = 0; t < 4; t++)
+                    block16<SB, ESCAPE, EVENTS, NT, false>(w4[t], base[0] + j0 + 16 * t, 16, s_cls4, table_bytes, a.row_bytes, a.out_off, L[0]);
+                j0 += 48;
+                continue;
+            }
 #pragma unroll
             for (int q = 0; q < ILP; q++) {
                 if (rem[q] > 0) {   // lanes whose haystack is exhausted sit out; __all is over the active lanes
@@ -282,6 +294,16 @@ __global__ void __launch_bounds__(ACX_BLOCK, 8) k_walk_chunks(const acx_walk_arg
         for (int j0 = 0;; j0 += 16) {
             const int rem = len - j0;
             if (!__any(rem > 0)) break;
+            if (__all(rem >= 64 && j0 >= emit)) {                  // 64 bytes per visit (see k_walk_all)
+                uint4 w4[4];
+#pragma unroll
+                for (int t = 0; t < 4; t++) w4[t] = load16_guarded<false>(p + j0 + 16 * t, limit);
+#pragma unroll
+                for (int t = 0; t < 4; t++)
+                    block16<SB, ESCAPE, true, 2, false>(w4[t], base + j0 + 16 * t, 16, s_cls4, table_bytes, a.row_bytes, a.out_off, L);
+                j0 += 48;
+                continue;
+            }
             if (rem > 0) {
                 const uint4 w = load16_guarded<false>(p + j0, limit);
                 if (__all(rem >= 16 && j0 >= emit)) {
