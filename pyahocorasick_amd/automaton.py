@@ -429,6 +429,45 @@ class Automaton:
                 raise TypeError("bytes required")
         return self.scan_batch(b"".join(haystacks), off, ACX_SCAN_LONG if long else ACX_SCAN_ALL).tolists()
 
+    # ---- dict-like enumeration (src/Automaton.c:722-873, src/AutomatonItemsIter.c) ---------------
+    def _items_iter(self, args, what):
+        if len(args) > 3:
+            raise TypeError("at most 3 arguments: [prefix, [wildcard, [how]]]")
+        pattern = b""
+        if len(args) >= 1:
+            pattern = self._key(args[0])
+        use_wildcard, wildcard = False, 0
+        if len(args) >= 2:
+            w = self._key(args[1])
+            if len(w) != 1:
+                raise ValueError("Wildcard must be a single character.")
+            use_wildcard, wildcard = True, w[0]
+        how = MATCH_EXACT_LENGTH if use_wildcard else MATCH_AT_LEAST_PREFIX
+        if len(args) >= 3:
+            how = args[2].__index__()
+            if how not in (MATCH_EXACT_LENGTH, MATCH_AT_MOST_PREFIX, MATCH_AT_LEAST_PREFIX):
+                raise ValueError("The optional how third argument must be one of: "
+                                 "MATCH_EXACT_LENGTH, MATCH_AT_LEAST_PREFIX or MATCH_AT_LEAST_PREFIX")
+        return AutomatonItemsIter(self, pattern, use_wildcard, wildcard, how, what)
+
+    def keys(self, *args):
+        return self._items_iter(args, "keys")
+
+    def values(self, *args):
+        return self._items_iter(args, "values")
+
+    def items(self, *args):
+        return self._items_iter(args, "items")
+
+    def __iter__(self):
+        return self._items_iter((), "keys")
+
+    def get_stats(self):
+        v = [C.c_int64() for _ in range(6)]
+        check(lib().acx_trie_stats(self._trie, *[C.byref(x) for x in v]))
+        names = ("nodes_count", "words_count", "longest_word", "links_count", "sizeof_node", "total_size")
+        return {k: x.value for k, x in zip(names, v)}
+
     # ---- reference search API, GPU-backed ---------------------------------------------
     def iter(self, string, start=-1, end=-1, ignore_white_space=False):
         if self.kind != AHOCORASICK:
@@ -597,3 +636,46 @@ def load(*args):
             lib().acx_blob_free(C.cast(poff, C.c_void_p))
         if plen:
             lib().acx_blob_free(C.cast(plen, C.c_void_p))
+
+
+class AutomatonItemsIter:
+    """keys() / values() / items() iterator (src/AutomatonItemsIter.c): the enumeration is done in
+    libacx in the reference's order; like the reference's, the iterator dies when the automaton changes"""
+
+    def __init__(self, automaton, pattern, use_wildcard, wildcard, how, what):
+        self._a = automaton
+        self._version = automaton._version
+        self._what = what
+        keys, koff, vals, n = C.c_void_p(), C.POINTER(C.c_int64)(), C.POINTER(C.c_int64)(), C.c_int64()
+        check(lib().acx_trie_items(automaton._trie, pattern, len(pattern), 1 if use_wildcard else 0, wildcard, how,
+                                   C.byref(keys), C.byref(koff), C.byref(vals), C.byref(n)))
+        try:
+            self._n = n.value
+            off = [koff[i] for i in range(self._n + 1)]
+            blob = C.string_at(keys, off[-1]) if self._n else b""
+            self._keys = [blob[off[i]:off[i + 1]] for i in range(self._n)]
+            self._vals = [vals[i] for i in range(self._n)]
+        finally:
+            lib().acx_blob_free(keys)
+            lib().acx_blob_free(C.cast(koff, C.c_void_p))
+            lib().acx_blob_free(C.cast(vals, C.c_void_p))
+        self._pos = 0
+
+    def __iter__(self):
+        return self
+
+    def __next__(self):
+        if self._version != self._a._version:
+            raise ValueError("The underlying automaton has changed: this iterator is no longer valid.")
+        if self._pos >= self._n:
+            raise StopIteration
+        i = self._pos
+        self._pos += 1
+        if self._what == "keys":
+            return self._keys[i]
+        v = self._vals[i]
+        if self._a._values is not None:
+            v = self._a._values[v]
+        else:
+            v = int(C.c_int32(v).value)                      # Py_BuildValue("i"): the low 32 bits
+        return v if self._what == "values" else (self._keys[i], v)

@@ -662,11 +662,102 @@ PyObject* automaton_save(AutomatonObject* a, PyObject* args) {
     Py_RETURN_NONE;
 }
 
-PyObject* automaton_get_stats(AutomatonObject* a, PyObject*) {
-    return Py_BuildValue("{s:L,s:L,s:L}", "nodes_count", (long long)acx_trie_num_nodes(a->trie),
-                         "words_count", (long long)acx_trie_num_keys(a->trie),
-                         "longest_word", (long long)acx_trie_longest_word(a->trie));
+PyObject* automaton_get_stats(AutomatonObject* a, PyObject*) {       // src/Automaton.c:1077-1096
+    int64_t v[6] = {0, 0, 0, 0, 0, 0};
+    int rc = acx_trie_stats(a->trie, &v[0], &v[1], &v[2], &v[3], &v[4], &v[5]);
+    if (rc) return set_acx_error(rc);
+    return Py_BuildValue("{s:L,s:L,s:L,s:L,s:i,s:L}", "nodes_count", (long long)v[0], "words_count", (long long)v[1],
+                         "longest_word", (long long)v[2], "links_count", (long long)v[3], "sizeof_node", (int)v[4],
+                         "total_size", (long long)v[5]);
 }
+
+// ---- keys() / values() / items() / __iter__ (src/Automaton.c:722-873, src/AutomatonItemsIter.c) -------
+// The enumeration is done in libacx (acx_items.cpp) in the reference's order; the iterator hands the
+// items out one by one and, like the reference's, dies when the automaton changes.
+enum { ITER_KEYS = 0, ITER_VALUES = 1, ITER_ITEMS = 2 };
+
+struct ItemsIterObject {
+    PyObject_HEAD
+    AutomatonObject* automaton;
+    int64_t version;
+    int what;
+    uint8_t* keys; int64_t* key_off; int64_t* values;
+    int64_t n, pos;
+};
+
+void items_iter_dealloc(ItemsIterObject* it) {
+    acx_blob_free(it->keys); acx_blob_free(it->key_off); acx_blob_free(it->values);
+    Py_XDECREF(it->automaton);
+    Py_TYPE(it)->tp_free((PyObject*)it);
+}
+
+PyObject* items_iter_iter(PyObject* self) { Py_INCREF(self); return self; }
+
+PyObject* items_iter_next(ItemsIterObject* it) {
+    if (it->version != acx_trie_version(it->automaton->trie)) {
+        PyErr_SetString(PyExc_ValueError, "The underlying automaton has changed: this iterator is no longer valid.");
+        return nullptr;
+    }
+    if (it->pos >= it->n) return nullptr;                             // StopIteration
+    const int64_t i = it->pos++;
+    PyObject* key = nullptr;
+    if (it->what != ITER_VALUES) {
+        key = PyBytes_FromStringAndSize((const char*)it->keys + it->key_off[i], (Py_ssize_t)(it->key_off[i + 1] - it->key_off[i]));
+        if (!key || it->what == ITER_KEYS) return key;
+    }
+    PyObject* val;
+    if (it->automaton->store == STORE_ANY) {
+        val = PyList_GetItem(it->automaton->values, (Py_ssize_t)it->values[i]);      // borrowed
+        Py_XINCREF(val);
+    } else {
+        val = Py_BuildValue("i", (int)it->values[i]);               // as the reference: the low 32 bits
+    }
+    if (!val) { Py_XDECREF(key); return nullptr; }
+    if (it->what == ITER_VALUES) return val;
+    return Py_BuildValue("(NN)", key, val);
+}
+
+PyTypeObject ItemsIterType = {PyVarObject_HEAD_INIT(nullptr, 0) "ahocorasick.AutomatonItemsIter"};
+
+// argument rules of automaton_items_create, src/Automaton.c:722-850
+PyObject* automaton_items_create(AutomatonObject* a, PyObject* args, int what) {
+    const Py_ssize_t na = args ? PyTuple_GET_SIZE(args) : 0;
+    const uint8_t* pat = nullptr; Py_ssize_t plen = 0;
+    if (na >= 1 && !get_bytes(PyTuple_GET_ITEM(args, 0), "bytes expected", &pat, &plen)) return nullptr;
+    int use_wildcard = 0; uint8_t wildcard = 0;
+    if (na >= 2) {
+        const uint8_t* w; Py_ssize_t wl;
+        if (!get_bytes(PyTuple_GET_ITEM(args, 1), "bytes expected", &w, &wl)) return nullptr;
+        if (wl != 1) { PyErr_SetString(PyExc_ValueError, "Wildcard must be a single character."); return nullptr; }
+        use_wildcard = 1; wildcard = w[0];
+    }
+    int how = use_wildcard ? MATCH_EXACT_LENGTH : MATCH_AT_LEAST_PREFIX;
+    if (na >= 3) {
+        const Py_ssize_t v = PyNumber_AsSsize_t(PyTuple_GET_ITEM(args, 2), PyExc_OverflowError);
+        if (v == -1 && PyErr_Occurred()) return nullptr;
+        if (v != MATCH_EXACT_LENGTH && v != MATCH_AT_MOST_PREFIX && v != MATCH_AT_LEAST_PREFIX) {
+            PyErr_SetString(PyExc_ValueError, "The optional how third argument must be one of: "
+                                              "MATCH_EXACT_LENGTH, MATCH_AT_LEAST_PREFIX or MATCH_AT_LEAST_PREFIX");
+            return nullptr;
+        }
+        how = (int)v;
+    }
+    ItemsIterObject* it = (ItemsIterObject*)ItemsIterType.tp_alloc(&ItemsIterType, 0);
+    if (!it) return nullptr;
+    it->automaton = nullptr; it->keys = nullptr; it->key_off = nullptr; it->values = nullptr; it->n = 0; it->pos = 0;
+    it->what = what;
+    int rc = acx_trie_items(a->trie, pat, (size_t)plen, use_wildcard, wildcard, how, &it->keys, &it->key_off, &it->values, &it->n);
+    if (rc) { Py_DECREF(it); return set_acx_error(rc); }
+    Py_INCREF(a);
+    it->automaton = a;
+    it->version = acx_trie_version(a->trie);
+    return (PyObject*)it;
+}
+
+PyObject* automaton_keys(AutomatonObject* a, PyObject* args) { return automaton_items_create(a, args, ITER_KEYS); }
+PyObject* automaton_values(AutomatonObject* a, PyObject* args) { return automaton_items_create(a, args, ITER_VALUES); }
+PyObject* automaton_items(AutomatonObject* a, PyObject* args) { return automaton_items_create(a, args, ITER_ITEMS); }
+PyObject* automaton_tp_iter(PyObject* a) { return automaton_items_create((AutomatonObject*)a, nullptr, ITER_KEYS); }
 
 PyMethodDef automaton_methods[] = {
     {"add_word", (PyCFunction)automaton_add_word, METH_VARARGS, "add_word(key, [value]) -> bool"},
@@ -682,6 +773,9 @@ PyMethodDef automaton_methods[] = {
     {"find_all", (PyCFunction)automaton_find_all, METH_VARARGS, "find_all(string, callback, [start, [end]])"},
     {"iter_batch", (PyCFunction)automaton_iter_batch, METH_VARARGS | METH_KEYWORDS, "iter_batch(haystacks, long=False) -> list of lists (GPU batch scan)"},
     {"get_stats", (PyCFunction)automaton_get_stats, METH_NOARGS, "get_stats() -> dict"},
+    {"keys", (PyCFunction)automaton_keys, METH_VARARGS, "keys([prefix, [wildcard, [how]]]) -> iterator"},
+    {"values", (PyCFunction)automaton_values, METH_VARARGS, "values([prefix, [wildcard, [how]]]) -> iterator"},
+    {"items", (PyCFunction)automaton_items, METH_VARARGS, "items([prefix, [wildcard, [how]]]) -> iterator"},
     {"__reduce__", (PyCFunction)automaton_reduce, METH_NOARGS, "pickle support: the reference's (bytes build) payload"},
     {"save", (PyCFunction)automaton_save, METH_VARARGS, "save(path[, serializer]): the reference's file format"},
     {nullptr, nullptr, 0, nullptr}};
@@ -767,7 +861,15 @@ PyMODINIT_FUNC PyInit_ahocorasick(void) {
     automaton_as_sequence.sq_length = (lenfunc)automaton_len;
     automaton_as_sequence.sq_contains = (objobjproc)automaton_contains;
     AutomatonType.tp_as_sequence = &automaton_as_sequence;
+    AutomatonType.tp_iter = automaton_tp_iter;
     if (PyType_Ready(&AutomatonType) < 0) return nullptr;
+
+    ItemsIterType.tp_basicsize = sizeof(ItemsIterObject);
+    ItemsIterType.tp_flags = Py_TPFLAGS_DEFAULT;
+    ItemsIterType.tp_dealloc = (destructor)items_iter_dealloc;
+    ItemsIterType.tp_iter = items_iter_iter;
+    ItemsIterType.tp_iternext = (iternextfunc)items_iter_next;
+    if (PyType_Ready(&ItemsIterType) < 0) return nullptr;
 
     SearchIterType.tp_basicsize = sizeof(SearchIterObject);
     SearchIterType.tp_flags = Py_TPFLAGS_DEFAULT;
