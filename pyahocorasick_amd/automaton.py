@@ -462,6 +462,52 @@ class Automaton:
     def __iter__(self):
         return self._items_iter((), "keys")
 
+    def match(self, key):
+        """True iff `key` is a prefix of some key (src/Automaton.c:460-479)"""
+        key = self._key(key)
+        return self.longest_prefix(key) == len(key)
+
+    def dump(self):
+        """(nodes, edges, fail) like the reference (src/Automaton.c:1098-1180): nodes = [(id, eow)],
+        edges = [(id, letter, child id)], fail = [(id, fail id)], in pre-order; ids are 1-based dump
+        numbers here (the reference prints node addresses)"""
+        if self.kind == EMPTY:
+            return None
+        import struct
+        chunks = self.__reduce__()[1][0] if len(self) else self._trie_chunks()
+        nodes, edges, fail, nid = [], [], [], 0
+        for chunk in chunks:
+            n_nodes, = struct.unpack_from("<q", chunk, 0)
+            at = 8
+            for _ in range(n_nodes):
+                nid += 1
+                _out, f, n, eow = struct.unpack_from("<QQIB", chunk, at)
+                at += 24
+                nodes.append((nid, int(eow)))
+                for j in range(n):
+                    letter, child = struct.unpack_from("<HQ", chunk, at)
+                    at += 10
+                    edges.append((nid, bytes([letter & 0xFF]), child))
+                if f:
+                    fail.append((nid, f))
+        return nodes, edges, fail
+
+    def _trie_chunks(self):
+        buf, sizes, n = C.c_void_p(), C.POINTER(C.c_size_t)(), C.c_size_t()
+        check(lib().acx_trie_to_ref_pickle(self._trie, 0, 0, C.byref(buf), C.byref(sizes), C.byref(n)))
+        try:
+            out, at = [], 0
+            for k in range(n.value):
+                out.append(C.string_at(buf.value + at, sizes[k]))
+                at += sizes[k]
+            return out
+        finally:
+            lib().acx_blob_free(buf)
+            lib().acx_blob_free(C.cast(sizes, C.c_void_p))
+
+    def __sizeof__(self):
+        return object.__sizeof__(self) + (self.get_stats()["total_size"] if self.kind != EMPTY else 0)
+
     def get_stats(self):
         v = [C.c_int64() for _ in range(6)]
         check(lib().acx_trie_stats(self._trie, *[C.byref(x) for x in v]))

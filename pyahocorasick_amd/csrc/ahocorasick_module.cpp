@@ -671,6 +671,59 @@ PyObject* automaton_get_stats(AutomatonObject* a, PyObject*) {       // src/Auto
                          "total_size", (long long)v[5]);
 }
 
+// match(key): True iff key is a prefix of some key (src/Automaton.c:460-479)
+PyObject* automaton_match(AutomatonObject* a, PyObject* args) {
+    if (PyTuple_GET_SIZE(args) < 1) { PyErr_SetString(PyExc_TypeError, "match() takes a key"); return nullptr; }
+    const uint8_t* key; Py_ssize_t len;
+    if (!get_bytes(PyTuple_GET_ITEM(args, 0), "bytes expected", &key, &len)) return nullptr;
+    size_t n = 0;
+    int rc = acx_trie_longest_prefix(a->trie, key, (size_t)len, &n);
+    if (rc) return set_acx_error(rc);
+    if (n == (size_t)len) Py_RETURN_TRUE;
+    Py_RETURN_FALSE;
+}
+
+// dump() -> (nodes, edges, fail) like src/Automaton.c:1098-1180, in pre-order; ids are 1-based dump
+// numbers (the reference prints node addresses).  Read off the pickle records libacx writes.
+PyObject* automaton_dump(AutomatonObject* a, PyObject*) {
+    if (acx_trie_kind(a->trie) == K_EMPTY) Py_RETURN_NONE;
+    void* buf = nullptr; size_t* sizes = nullptr; size_t n_chunks = 0;
+    int rc = acx_trie_to_ref_pickle(a->trie, 0, 0, &buf, &sizes, &n_chunks);
+    if (rc) return set_acx_error(rc);
+    PyObject *nodes = PyList_New(0), *edges = PyList_New(0), *fail = PyList_New(0);
+    bool ok = nodes && edges && fail;
+    const uint8_t* p = (const uint8_t*)buf;
+    long long id = 0;
+    auto append = [&](PyObject* list, PyObject* tuple) { if (!tuple || PyList_Append(list, tuple) < 0) ok = false; Py_XDECREF(tuple); };
+    for (size_t c = 0; ok && c < n_chunks; c++) {
+        const uint8_t* q = p;
+        int64_t cnt; memcpy(&cnt, q, 8); q += 8;
+        for (int64_t i = 0; ok && i < cnt; i++) {
+            id++;
+            uint64_t f; uint32_t nch; memcpy(&f, q + 8, 8); memcpy(&nch, q + 16, 4);
+            const int eow = q[20];
+            q += 24;
+            append(nodes, Py_BuildValue("Li", id, eow));
+            for (uint32_t j = 0; ok && j < nch; j++, q += 10) {
+                uint16_t letter; uint64_t child; memcpy(&letter, q, 2); memcpy(&child, q + 2, 8);
+                const char ch = (char)(letter & 0xFF);
+                append(edges, Py_BuildValue("Ly#L", id, &ch, (Py_ssize_t)1, (long long)child));
+            }
+            if (f) append(fail, Py_BuildValue("LL", id, (long long)f));
+        }
+        p += sizes[c];
+    }
+    acx_blob_free(buf); acx_blob_free(sizes);
+    if (!ok) { Py_XDECREF(nodes); Py_XDECREF(edges); Py_XDECREF(fail); return nullptr; }
+    return Py_BuildValue("NNN", nodes, edges, fail);
+}
+
+PyObject* automaton_sizeof(AutomatonObject* a, PyObject*) {          // src/Automaton.c:1183-1198
+    int64_t total = 0;
+    if (acx_trie_kind(a->trie) != K_EMPTY) (void)acx_trie_stats(a->trie, nullptr, nullptr, nullptr, nullptr, nullptr, &total);
+    return PyLong_FromLongLong((long long)sizeof(AutomatonObject) + total);
+}
+
 // ---- keys() / values() / items() / __iter__ (src/Automaton.c:722-873, src/AutomatonItemsIter.c) -------
 // The enumeration is done in libacx (acx_items.cpp) in the reference's order; the iterator hands the
 // items out one by one and, like the reference's, dies when the automaton changes.
@@ -773,6 +826,9 @@ PyMethodDef automaton_methods[] = {
     {"find_all", (PyCFunction)automaton_find_all, METH_VARARGS, "find_all(string, callback, [start, [end]])"},
     {"iter_batch", (PyCFunction)automaton_iter_batch, METH_VARARGS | METH_KEYWORDS, "iter_batch(haystacks, long=False) -> list of lists (GPU batch scan)"},
     {"get_stats", (PyCFunction)automaton_get_stats, METH_NOARGS, "get_stats() -> dict"},
+    {"match", (PyCFunction)automaton_match, METH_VARARGS, "match(key) -> bool: key is a prefix of some key"},
+    {"dump", (PyCFunction)automaton_dump, METH_NOARGS, "dump() -> (nodes, edges, fail)"},
+    {"__sizeof__", (PyCFunction)automaton_sizeof, METH_NOARGS, "size in bytes (as the reference's pointer trie would take)"},
     {"keys", (PyCFunction)automaton_keys, METH_VARARGS, "keys([prefix, [wildcard, [how]]]) -> iterator"},
     {"values", (PyCFunction)automaton_values, METH_VARARGS, "values([prefix, [wildcard, [how]]]) -> iterator"},
     {"items", (PyCFunction)automaton_items, METH_VARARGS, "items([prefix, [wildcard, [how]]]) -> iterator"},

@@ -84,3 +84,57 @@ def test_items_iterator_rules(host):
         next(it)
     E = mod.Automaton()
     assert list(E.keys()) == [] and list(E) == [] and E.get_stats()["nodes_count"] == 0
+
+
+def _canon(dump):
+    """rename node ids to their position in `nodes` (the reference prints truncated addresses)"""
+    nodes, edges, fail = dump
+    name = {nid: i for i, (nid, _) in enumerate(nodes)}
+    return ([e for _, e in nodes], sorted((name[a], l, name[b]) for a, l, b in edges), sorted((name[a], name[b]) for a, b in fail))
+
+
+@pytest.mark.parametrize("host", list(HOSTS))
+def test_match_dump_sizeof(host):
+    mod = HOSTS[host]()
+    A = mod.Automaton(mod.STORE_INTS)
+    assert A.dump() is None                                            # src/Automaton.c:1153-1154
+    for i, k in enumerate([b"he", b"her", b"hers", b"she"]):
+        A.add_word(k, i)
+    assert A.match(b"h") and A.match(b"sh") and A.match(b"hers") and not A.match(b"hex") and A.match(b"")
+    nodes, edges, fail = A.dump()
+    assert len(nodes) == 8 and len(edges) == 7 and fail == []         # a plain trie has no fail links
+    assert sum(e for _, e in nodes) == 4 and sorted(l for _, l, _ in edges) == [b"e", b"e", b"h", b"h", b"r", b"s", b"s"]
+    A.make_automaton()
+    nodes, edges, fail = A.dump()
+    assert len(fail) == 7                                              # every node but the root
+    # she -> he, sh -> h (the classic)
+    canon = _canon((nodes, edges, fail))
+    child = {(a, l): b for a, l, b in canon[1]}
+    h, s = child[(0, b"h")], child[(0, b"s")]
+    he, sh = child[(h, b"e")], child[(s, b"h")]
+    she = child[(sh, b"e")]
+    assert (sh, h) in canon[2] and (she, he) in canon[2] and (h, 0) in canon[2]
+    assert A.__sizeof__() >= A.get_stats()["total_size"] > 0
+
+
+def test_dump_equals_the_live_reference():
+    from oracle import orc
+    ref = orc.load_reference()
+    if ref is None:
+        pytest.skip("oracle/_ref (the reference itself) is not built")
+    import random
+    rng = random.Random(9)
+    keys = list({bytes(rng.choice(b"abc") for _ in range(rng.randint(1, 7))) for _ in range(60)})
+    R = ref.Automaton(ref.STORE_INTS)
+    for i, k in enumerate(keys):
+        R.add_word(k, i)
+    R.make_automaton()
+    want = _canon(R.dump())
+    for name in HOSTS:
+        mod = HOSTS[name]()
+        A = mod.Automaton(mod.STORE_INTS)
+        for i, k in enumerate(keys):
+            A.add_word(k, i)
+        A.make_automaton()
+        assert _canon(A.dump()) == want
+        assert all(A.match(k[:j]) for k in keys for j in range(len(k) + 1))
