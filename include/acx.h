@@ -85,9 +85,12 @@ int64_t  acx_trie_version(const acx_trie_t* t);
  * that Automaton.keys/values/items([prefix, [wildcard, [how]]]) iterate over, in the reference's
  * order (automaton_items_iter_next, src/AutomatonItemsIter.c:124-209).  how: 0 exact length,
  * 1 at most, 2 at least the pattern's length (src/Automaton.h:43-47).  keys are returned back to
- * back, key i = keys[key_off[i] .. key_off[i+1]); the three arrays are malloc'd (acx_blob_free). */
-int acx_trie_items(const acx_trie_t* t, const uint8_t* pattern, size_t plen, int use_wildcard, uint8_t wildcard,
-                   int how, uint8_t** keys, int64_t** key_off, int64_t** values, int64_t* n);
+ * back, key i = keys[key_off[i] .. key_off[i+1]); the three arrays are malloc'd (acx_blob_free).
+ * wildcard: the bytes of the one wildcard letter, wlen = 0 for none.  letters_utf8 = 1 (str build):
+ * the trie holds UTF-8 and a letter is one whole sequence — depth, pattern and wildcard count
+ * characters, children are visited in the order their letters were first added. */
+int acx_trie_items(const acx_trie_t* t, const uint8_t* pattern, size_t plen, const uint8_t* wildcard, size_t wlen,
+                   int how, int letters_utf8, uint8_t** keys, int64_t** key_off, int64_t** values, int64_t* n);
 /* Automaton.get_stats (src/Automaton.c:1044-1096); sizes are those of the reference's pointer trie */
 int acx_trie_stats(const acx_trie_t* t, int64_t* nodes, int64_t* words, int64_t* longest, int64_t* links,
                    int64_t* sizeof_node, int64_t* total_size);

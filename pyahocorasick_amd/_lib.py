@@ -64,8 +64,8 @@ SIGNATURES = {
     "acx_trie_num_nodes": (C.c_int64, [_P]),
     "acx_trie_longest_word": (C.c_int64, [_P]),
     "acx_trie_version": (C.c_int64, [_P]),
-    "acx_trie_items": (C.c_int, [_P, _u8p, C.c_size_t, C.c_int, C.c_uint8, C.c_int, _PP, C.POINTER(C.POINTER(C.c_int64)),
-                                 C.POINTER(C.POINTER(C.c_int64)), C.POINTER(C.c_int64)]),
+    "acx_trie_items": (C.c_int, [_P, _u8p, C.c_size_t, _u8p, C.c_size_t, C.c_int, C.c_int, _PP,
+                                 C.POINTER(C.POINTER(C.c_int64)), C.POINTER(C.POINTER(C.c_int64)), C.POINTER(C.c_int64)]),
     "acx_trie_stats": (C.c_int, [_P] + [C.POINTER(C.c_int64)] * 6),
     "acx_trie_from_ref_pickle": (C.c_int, [C.POINTER(C.c_void_p), C.POINTER(C.c_size_t), C.c_size_t, C.c_int, C.c_int64, _PP,
                                            C.POINTER(C.c_int64)]),

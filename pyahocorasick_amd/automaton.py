@@ -693,7 +693,8 @@ class AutomatonItemsIter:
         self._version = automaton._version
         self._what = what
         keys, koff, vals, n = C.c_void_p(), C.POINTER(C.c_int64)(), C.POINTER(C.c_int64)(), C.c_int64()
-        check(lib().acx_trie_items(automaton._trie, pattern, len(pattern), 1 if use_wildcard else 0, wildcard, how,
+        wc = bytes([wildcard]) if use_wildcard else b""
+        check(lib().acx_trie_items(automaton._trie, pattern, len(pattern), wc, len(wc), how, 0,
                                    C.byref(keys), C.byref(koff), C.byref(vals), C.byref(n)))
         try:
             self._n = n.value

@@ -53,26 +53,30 @@ def build_libacx(force=False, verbose=True):
 DROPIN_DIR = os.path.join(ROOT, "dropin")
 
 
-def dropin_path():
+def dropin_path(unicode=False):
     import sysconfig
-    return os.path.join(DROPIN_DIR, "ahocorasick" + (sysconfig.get_config_var("EXT_SUFFIX") or ".so"))
+    d = os.path.join(DROPIN_DIR, "unicode") if unicode else DROPIN_DIR
+    return os.path.join(d, "ahocorasick" + (sysconfig.get_config_var("EXT_SUFFIX") or ".so"))
 
 
-def build_dropin(force=False, verbose=True):
-    """Build the CPython extension `ahocorasick` (dropin/ahocorasick.cpython-*.so): the drop-in
-    host side that exports PyInit_ahocorasick and calls libacx through the C-ABI.
-    Use it with  sys.path.insert(0, "<repo>/dropin"); import ahocorasick"""
+def build_dropin(force=False, verbose=True, unicode=False):
+    """Build the CPython extension `ahocorasick`: the drop-in host side that exports
+    PyInit_ahocorasick and calls libacx through the C-ABI.
+      dropin/ahocorasick.cpython-*.so           bytes build  (keys and haystacks are bytes)
+      dropin/unicode/ahocorasick.cpython-*.so   unicode build (str; -DACX_UNICODE_BUILD=1)
+    Use it with  sys.path.insert(0, "<repo>/dropin")  (or ".../dropin/unicode"); import ahocorasick"""
     import sysconfig
     src = os.path.join(CSRC, "ahocorasick_module.cpp")
-    out = dropin_path()
+    out = dropin_path(unicode)
     build_libacx(force=False, verbose=verbose)
     if (not force and os.path.exists(out) and os.path.getmtime(out) > os.path.getmtime(src)
             and os.path.getmtime(out) > os.path.getmtime(os.path.join(ROOT, "include", "acx.h"))):
         return out
-    os.makedirs(DROPIN_DIR, exist_ok=True)
-    cmd = ["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-Wall",
+    os.makedirs(os.path.dirname(out), exist_ok=True)
+    rpath = "$ORIGIN/../../pyahocorasick_amd" if unicode else "$ORIGIN/../pyahocorasick_amd"
+    cmd = ["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-Wall", "-DACX_UNICODE_BUILD=%d" % (1 if unicode else 0),
            "-I" + sysconfig.get_paths()["include"], "-I" + os.path.join(ROOT, "include"),
-           src, "-o", out, "-L" + HERE, "-l:libacx.so", "-Wl,-rpath,$ORIGIN/../pyahocorasick_amd"]
+           src, "-o", out, "-L" + HERE, "-l:libacx.so", "-Wl,-rpath," + rpath]
     if verbose:
         print("[pyahocorasick_amd.build]", " ".join(cmd), flush=True)
     subprocess.check_call(cmd)
@@ -82,5 +86,7 @@ def build_dropin(force=False, verbose=True):
 if __name__ == "__main__":
     build_libacx(force="--force" in sys.argv)
     build_dropin(force="--force" in sys.argv)
+    build_dropin(force="--force" in sys.argv, unicode=True)
     print(LIB)
     print(dropin_path())
+    print(dropin_path(True))

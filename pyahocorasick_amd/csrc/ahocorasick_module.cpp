@@ -53,11 +53,73 @@ PyObject* set_acx_error(int rc) {
 }
 
 // ---- helpers -------------------------------------------------------------------------------
-bool get_bytes(PyObject* o, const char* what, const uint8_t** p, Py_ssize_t* n) {
-    if (!PyBytes_Check(o)) { PyErr_SetString(PyExc_TypeError, what); return false; }
-    *p = (const uint8_t*)PyBytes_AS_STRING(o);
-    *n = PyBytes_GET_SIZE(o);
+// ---- letters --------------------------------------------------------------------------------
+// Two flavours of this module are built from this file, like the reference (src/common.h:50-67):
+//   bytes build   (default)              keys and haystacks are `bytes`, one letter = one byte;
+//   unicode build (-DACX_UNICODE_BUILD)   keys and haystacks are `str`, one letter = one code point.
+// The engine underneath is the byte automaton in both: the unicode build feeds it UTF-8.  UTF-8 is
+// prefix-free and self-synchronising, so a key's bytes can only match on code-point boundaries
+// and the byte trie's failure links mirror the code-point trie's: same matches, and an index in
+// bytes converts to an index in letters by counting the bytes that start a character.
+#ifndef ACX_UNICODE_BUILD
+#define ACX_UNICODE_BUILD 0
+#endif
+
+struct Text {
+    const uint8_t* data;     // the bytes the engine sees
+    Py_ssize_t nbytes;
+    Py_ssize_t nchars;       // letters as the reference counts them
+    bool ascii() const { return nbytes == nchars; }
+};
+
+inline bool is_char_start(uint8_t b) { return (b & 0xC0) != 0x80; }
+
+// haystack = true: the wording iter()/iter_long() use for a wrong argument type
+bool get_text(PyObject* o, Text* t, bool haystack = false) {
+#if ACX_UNICODE_BUILD
+    if (!PyUnicode_Check(o)) { PyErr_SetString(PyExc_TypeError, haystack ? "string required" : "string expected"); return false; }
+    Py_ssize_t n = 0;
+    const char* u = PyUnicode_AsUTF8AndSize(o, &n);              // cached in the str object: lives as long as `o`
+    if (!u) return false;
+    t->data = (const uint8_t*)u; t->nbytes = n; t->nchars = PyUnicode_GET_LENGTH(o);
+#else
+    if (!PyBytes_Check(o)) { PyErr_SetString(PyExc_TypeError, haystack ? "bytes required" : "bytes expected"); return false; }
+    t->data = (const uint8_t*)PyBytes_AS_STRING(o); t->nbytes = PyBytes_GET_SIZE(o); t->nchars = t->nbytes;
+#endif
     return true;
+}
+
+bool get_bytes(PyObject* o, const char*, const uint8_t** p, Py_ssize_t* n) {      // keys: bytes the engine sees
+    Text t;
+    if (!get_text(o, &t)) return false;
+    *p = t.data; *n = t.nbytes;
+    return true;
+}
+
+// byte offset of letter `ci` (0 <= ci <= nchars)
+Py_ssize_t char_to_byte(const Text& t, Py_ssize_t ci) {
+    if (t.ascii()) return ci;
+    if (ci >= t.nchars) return t.nbytes;
+    Py_ssize_t seen = -1;
+    for (Py_ssize_t i = 0; i < t.nbytes; i++) {
+        if (is_char_start(t.data[i]) && ++seen == ci) return i;
+    }
+    return t.nbytes;
+}
+
+// number of letters in the first `nb` bytes
+Py_ssize_t chars_in(const uint8_t* p, Py_ssize_t nb) {
+    Py_ssize_t c = 0;
+    for (Py_ssize_t i = 0; i < nb; i++) c += is_char_start(p[i]);
+    return c;
+}
+
+PyObject* make_key_object(const uint8_t* p, Py_ssize_t n) {
+#if ACX_UNICODE_BUILD
+    return PyUnicode_DecodeUTF8((const char*)p, n, "strict");
+#else
+    return PyBytes_FromStringAndSize((const char*)p, n);
+#endif
 }
 
 // [start, [end]] exactly as pymod_parse_start_end does (src/utils.c:293-359), quirks included
@@ -214,7 +276,29 @@ PyObject* automaton_from_pickle(PyTypeObject* type, PyObject* args) {
 }
 
 PyObject* automaton_new(PyTypeObject* type, PyObject* args, PyObject*) {
+#if ACX_UNICODE_BUILD
+    // this build pickles its UTF-8 byte trie: an 8th element marks the payload so that neither the
+    // reference's unicode build (4-byte letters) nor a bytes build mistakes it for its own
+    if (PyTuple_GET_SIZE(args) == 8) {
+        PyObject* tag = PyTuple_GET_ITEM(args, 7);
+        if (!PyUnicode_Check(tag) || PyUnicode_CompareWithASCIIString(tag, "utf8") != 0) {
+            PyErr_SetString(PyExc_ValueError, "Unable to load from pickle.");
+            return nullptr;
+        }
+        PyObject* seven = PyTuple_GetSlice(args, 0, 7);
+        if (!seven) return nullptr;
+        PyObject* r = automaton_from_pickle(type, seven);
+        Py_DECREF(seven);
+        return r;
+    }
+    if (PyTuple_GET_SIZE(args) == 7) {
+        PyErr_SetString(PyExc_ValueError, "this is a pickle of the reference's unicode build (4-byte letters) or of a bytes build; "
+                                          "this str build reads only its own UTF-8 payload");
+        return nullptr;
+    }
+#else
     if (PyTuple_GET_SIZE(args) == 7) return automaton_from_pickle(type, args);
+#endif
     int store = STORE_ANY, key_type = KEY_STRING;
     if (!PyArg_ParseTuple(args, "|ii", &store, &key_type)) return nullptr;
     if (!check_store_key(store, key_type)) return nullptr;
@@ -239,8 +323,9 @@ Py_ssize_t automaton_len(AutomatonObject* a) { return (Py_ssize_t)acx_trie_num_k
 PyObject* automaton_add_word(AutomatonObject* a, PyObject* args) {
     const Py_ssize_t na = PyTuple_GET_SIZE(args);
     if (na < 1) { PyErr_SetString(PyExc_TypeError, "add_word() takes a key"); return nullptr; }
-    const uint8_t* key; Py_ssize_t len;
-    if (!get_bytes(PyTuple_GET_ITEM(args, 0), "bytes expected", &key, &len)) return nullptr;
+    Text kt;
+    if (!get_text(PyTuple_GET_ITEM(args, 0), &kt)) return nullptr;
+    const uint8_t* key = kt.data; const Py_ssize_t len = kt.nbytes;
     int64_t v = 0;
     PyObject* obj = nullptr;
     Py_ssize_t slot = -1;
@@ -265,7 +350,7 @@ PyObject* automaton_add_word(AutomatonObject* a, PyObject* args) {
             if (iv == -1 && PyErr_Occurred()) return nullptr;
             v = (int64_t)iv;
         } else v = acx_trie_num_keys(a->trie) + 1;
-    } else v = (int64_t)len;                                       // STORE_LENGTH
+    } else v = (int64_t)kt.nchars;                                 // STORE_LENGTH: letters
     int is_new = 0;
     int rc = acx_trie_add_word(a->trie, key, (size_t)len, v, &is_new);
     if (rc) return set_acx_error(rc);
@@ -322,7 +407,9 @@ PyObject* automaton_longest_prefix(AutomatonObject* a, PyObject* args) {
     size_t n = 0;
     int rc = acx_trie_longest_prefix(a->trie, key, (size_t)len, &n);
     if (rc) return set_acx_error(rc);
-    return PyLong_FromSize_t(n);
+    // (unicode build: a prefix that ends inside a character still counts only whole letters)
+    while (ACX_UNICODE_BUILD && n > 0 && n < (size_t)len && !is_char_start(key[n])) n--;
+    return PyLong_FromSize_t((size_t)chars_in(key, (Py_ssize_t)n));
 }
 
 // 1 removed (value in *out, new ref), 0 absent, -1 error
@@ -401,39 +488,59 @@ extern PyTypeObject SearchIterType;
 
 inline bool is_cspace(uint8_t b) { return b == ' ' || (b >= '\t' && b <= '\r'); }    // iswspace over bytes-build letters
 
-bool iter_load(SearchIterObject* it, const uint8_t* data, Py_ssize_t start, Py_ssize_t end) {
-    AutomatonObject* a = it->automaton;
-    const int64_t* moff; const acx_match_t* m; const int32_t* fin;
+// Scan letters [start, end) of `t`; matches come back with end_index in LETTERS of the whole
+// string plus `index_shift`.  ignore_ws: white-space letters are skipped without touching the state
+// (src/AutomatonSearchIter.c:269-274).  state_io: automaton state carried in and out (iter.set()).
+bool scan_text(AutomatonObject* a, int mode, const Text& t, Py_ssize_t start, Py_ssize_t end, bool ignore_ws,
+               int32_t* state_io, Py_ssize_t index_shift, std::vector<acx_match_t>* out) {
+    const Py_ssize_t bs = char_to_byte(t, start), be = char_to_byte(t, end);
+    const uint8_t* src = t.data + bs;
+    const Py_ssize_t nb = be - bs;
     std::vector<uint8_t> compact;
-    std::vector<int32_t> remap;
-    const uint8_t* src = data + start;
-    int64_t off[2] = {0, (int64_t)(end - start)};
-    int32_t base = (int32_t)(start + it->shift);
-    if (it->ignore_ws) {     // the reference skips white-space letters without touching the state (:269-274)
-        for (Py_ssize_t i = start; i < end; i++)
-            if (!is_cspace(data[i])) { compact.push_back(data[i]); remap.push_back((int32_t)(i + it->shift)); }
-        src = compact.data(); off[1] = (int64_t)compact.size(); base = 0;
+    std::vector<int32_t> remap;                                   // compacted byte -> byte of the slice
+    int64_t off[2] = {0, (int64_t)nb};
+    const uint8_t* scan_src = src;
+    if (ignore_ws) {
+        for (Py_ssize_t i = 0; i < nb; i++)
+            if (!is_cspace(src[i])) { compact.push_back(src[i]); remap.push_back((int32_t)i); }
+        scan_src = compact.data(); off[1] = (int64_t)compact.size();
     }
-    int32_t init = it->state;
-    if (!run_scan(a, it->is_long ? ACX_SCAN_LONG : ACX_SCAN_ALL, src, off, 1,
-                  it->is_long ? nullptr : &init, &base, &moff, &m, &fin)) return false;
-    it->pending->assign(m, m + moff[1]);
-    if (it->ignore_ws) for (auto& r : *it->pending) r.end_index = remap[(size_t)r.end_index];
+    std::vector<int32_t> cob;                                     // letter (relative to `start`) of each byte of the slice
+    if (!t.ascii()) {
+        cob.resize((size_t)nb);
+        int32_t c = -1;
+        for (Py_ssize_t i = 0; i < nb; i++) { c += is_char_start(src[i]); cob[(size_t)i] = c; }
+    }
+    const int64_t* moff; const acx_match_t* m; const int32_t* fin;
+    int32_t init = state_io ? *state_io : 0;
+    if (!run_scan(a, mode, scan_src, off, 1, state_io ? &init : nullptr, nullptr, &moff, &m, &fin)) return false;
+    out->assign(m, m + moff[1]);
+    for (auto& r : *out) {
+        int32_t byte_off = ignore_ws ? remap[(size_t)r.end_index] : r.end_index;
+        const int32_t letter = t.ascii() ? byte_off : cob[(size_t)byte_off];
+        r.end_index = (int32_t)(start + letter + index_shift);
+    }
+    if (state_io && fin) *state_io = fin[0];
+    return true;
+}
+
+bool iter_load(SearchIterObject* it, const Text& t, Py_ssize_t start, Py_ssize_t end) {
+    if (!scan_text(it->automaton, it->is_long ? ACX_SCAN_LONG : ACX_SCAN_ALL, t, start, end, it->ignore_ws,
+                   it->is_long ? nullptr : &it->state, it->shift, it->pending)) return false;
     it->pos = 0;
-    if (!it->is_long && fin) it->state = fin[0];
     it->end = end;
     it->ref_index = start - 1;                                     // src/AutomatonSearchIter.c:123
     return true;
 }
 
-PyObject* search_iter_create(AutomatonObject* a, PyObject* bytes, Py_ssize_t start, Py_ssize_t end, bool ws, bool is_long) {
+PyObject* search_iter_create(AutomatonObject* a, const Text& t, Py_ssize_t start, Py_ssize_t end, bool ws, bool is_long) {
     SearchIterObject* it = PyObject_New(SearchIterObject, &SearchIterType);
     if (!it) return nullptr;
     it->automaton = a; Py_INCREF(a);
     it->version = acx_trie_version(a->trie);
     it->pending = new std::vector<acx_match_t>();
     it->pos = 0; it->state = 0; it->shift = 0; it->ref_index = -1; it->end = 0; it->ignore_ws = ws; it->is_long = is_long;
-    if (!iter_load(it, (const uint8_t*)PyBytes_AS_STRING(bytes), start, end)) { Py_DECREF(it); return nullptr; }
+    if (!iter_load(it, t, start, end)) { Py_DECREF(it); return nullptr; }
     return (PyObject*)it;
 }
 
@@ -459,11 +566,11 @@ PyObject* search_iter_next(SearchIterObject* it) {
 PyObject* search_iter_set(SearchIterObject* it, PyObject* args) {  // src/AutomatonSearchIter.c:303-368
     PyObject* s; int reset = 0;
     if (!PyArg_ParseTuple(args, "O|p", &s, &reset)) return nullptr;
-    const uint8_t* data; Py_ssize_t n;
-    if (!get_bytes(s, "bytes expected", &data, &n)) return nullptr;
+    Text t;
+    if (!get_text(s, &t)) return nullptr;
     if (reset) { it->state = 0; it->shift = 0; }
     else it->shift += it->ref_index >= 0 ? it->ref_index : 0;
-    if (!iter_load(it, data, 0, n)) return nullptr;
+    if (!iter_load(it, t, 0, t.nchars)) return nullptr;
     Py_RETURN_NONE;
 }
 
@@ -479,8 +586,9 @@ PyObject* automaton_iter(AutomatonObject* a, PyObject* args, PyObject* kw) {
     if (acx_trie_kind(a->trie) != K_AHOCORASICK) { PyErr_SetString(PyExc_AttributeError, NOT_AUTOMATON_MSG); return nullptr; }
     PyObject* s; int start = -1, end = -1, ws = -1;
     if (!PyArg_ParseTupleAndKeywords(args, kw, "O|iii", (char**)kwlist, &s, &start, &end, &ws)) return nullptr;
-    if (!PyBytes_Check(s)) { PyErr_SetString(PyExc_TypeError, "bytes required"); return nullptr; }
-    const Py_ssize_t n = PyBytes_GET_SIZE(s);
+    Text t;
+    if (!get_text(s, &t, true)) return nullptr;
+    const Py_ssize_t n = t.nchars;
     // -1 = default for both (src/Automaton.c:893-956).  The reference does not validate the
     // range (out of range is undefined behaviour there); here it is clamped to the haystack.
     Py_ssize_t st = start == -1 ? 0 : start, en = end == -1 ? n : end;
@@ -488,7 +596,7 @@ PyObject* automaton_iter(AutomatonObject* a, PyObject* args, PyObject* kw) {
     if (st > n) st = n;
     if (en > n) en = n;
     if (en < st) en = st;
-    return search_iter_create(a, s, st, en, ws == 1, false);
+    return search_iter_create(a, t, st, en, ws == 1, false);
 }
 
 PyObject* automaton_iter_long(AutomatonObject* a, PyObject* args) {
@@ -497,12 +605,12 @@ PyObject* automaton_iter_long(AutomatonObject* a, PyObject* args) {
         return nullptr;
     }
     if (PyTuple_GET_SIZE(args) < 1) { PyErr_SetString(PyExc_TypeError, "iter_long() takes a string"); return nullptr; }
-    PyObject* s = PyTuple_GET_ITEM(args, 0);
-    if (!PyBytes_Check(s)) { PyErr_SetString(PyExc_TypeError, "bytes required"); return nullptr; }
+    Text t;
+    if (!get_text(PyTuple_GET_ITEM(args, 0), &t, true)) return nullptr;
     Py_ssize_t st, en;
-    if (!parse_start_end(args, 1, 2, 0, PyBytes_GET_SIZE(s), &st, &en)) return nullptr;
+    if (!parse_start_end(args, 1, 2, 0, t.nchars, &st, &en)) return nullptr;
     if (en < st) en = st;
-    return search_iter_create(a, s, st, en, false, true);
+    return search_iter_create(a, t, st, en, false, true);
 }
 
 PyObject* automaton_find_all(AutomatonObject* a, PyObject* args) {
@@ -510,20 +618,17 @@ PyObject* automaton_find_all(AutomatonObject* a, PyObject* args) {
     if (PyTuple_GET_SIZE(args) < 2) { PyErr_SetString(PyExc_TypeError, "find_all() takes a string and a callback"); return nullptr; }
     PyObject* s = PyTuple_GET_ITEM(args, 0);
     PyObject* cb = PyTuple_GET_ITEM(args, 1);
-    const uint8_t* data; Py_ssize_t n;
-    if (!get_bytes(s, "bytes expected", &data, &n)) return nullptr;
+    Text t;
+    if (!get_text(s, &t)) return nullptr;
     if (!PyCallable_Check(cb)) {
         PyErr_SetString(PyExc_TypeError, "The callback argument must be a callable such as a function.");
         return nullptr;
     }
     Py_ssize_t st, en;
-    if (!parse_start_end(args, 2, 3, 0, n, &st, &en)) return nullptr;
+    if (!parse_start_end(args, 2, 3, 0, t.nchars, &st, &en)) return nullptr;
     if (en < st) en = st;
-    const int64_t off[2] = {0, (int64_t)(en - st)};
-    const int32_t base = (int32_t)st;
-    const int64_t* moff; const acx_match_t* m; const int32_t* fin;
-    if (!run_scan(a, ACX_SCAN_ALL, data + st, off, 1, nullptr, &base, &moff, &m, &fin)) return nullptr;
-    std::vector<acx_match_t> copy(m, m + moff[1]);                 // the callback may re-enter this automaton
+    std::vector<acx_match_t> copy;                                 // the callback may re-enter this automaton
+    if (!scan_text(a, ACX_SCAN_ALL, t, st, en, false, nullptr, 0, &copy)) return nullptr;
     for (const acx_match_t& r : copy) {
         PyObject* pair = make_pair(a, r.end_index, r.value);
         if (!pair) return nullptr;
@@ -545,20 +650,35 @@ PyObject* automaton_iter_batch(AutomatonObject* a, PyObject* args, PyObject* kw)
     if (!fast) return nullptr;
     const Py_ssize_t n = PySequence_Fast_GET_SIZE(fast);
     std::vector<int64_t> off((size_t)n + 1, 0);
+    std::vector<Text> texts((size_t)n);
+    bool all_ascii = true;
     for (Py_ssize_t i = 0; i < n; i++) {
-        PyObject* o = PySequence_Fast_GET_ITEM(fast, i);
-        if (!PyBytes_Check(o)) { Py_DECREF(fast); PyErr_SetString(PyExc_TypeError, "bytes required"); return nullptr; }
-        off[(size_t)i + 1] = off[(size_t)i] + PyBytes_GET_SIZE(o);
+        if (!get_text(PySequence_Fast_GET_ITEM(fast, i), &texts[(size_t)i], true)) { Py_DECREF(fast); return nullptr; }
+        off[(size_t)i + 1] = off[(size_t)i] + texts[(size_t)i].nbytes;
+        all_ascii = all_ascii && texts[(size_t)i].ascii();
     }
     std::vector<uint8_t> data((size_t)off[(size_t)n]);
-    for (Py_ssize_t i = 0; i < n; i++) {
-        PyObject* o = PySequence_Fast_GET_ITEM(fast, i);
-        memcpy(data.data() + off[(size_t)i], PyBytes_AS_STRING(o), (size_t)PyBytes_GET_SIZE(o));
-    }
+    for (Py_ssize_t i = 0; i < n; i++) memcpy(data.data() + off[(size_t)i], texts[(size_t)i].data, (size_t)texts[(size_t)i].nbytes);
     Py_DECREF(fast);
-    const int64_t* moff; const acx_match_t* m; const int32_t* fin;
-    if (!run_scan(a, is_long ? ACX_SCAN_LONG : ACX_SCAN_ALL, data.data(), off.data(), n, nullptr, nullptr, &moff, &m, &fin))
+    const int64_t* moff; const acx_match_t* m0; const int32_t* fin;
+    if (!run_scan(a, is_long ? ACX_SCAN_LONG : ACX_SCAN_ALL, data.data(), off.data(), n, nullptr, nullptr, &moff, &m0, &fin))
         return nullptr;
+    std::vector<acx_match_t> conv;                                // unicode build: byte indices -> letters
+    const acx_match_t* m = m0;
+    if (!all_ascii) {
+        conv.assign(m0, m0 + moff[n]);
+        for (Py_ssize_t i = 0; i < n; i++) {
+            if (texts[(size_t)i].ascii()) continue;
+            const uint8_t* p = data.data() + off[(size_t)i];
+            int64_t k = moff[i];
+            int32_t c = -1;
+            for (Py_ssize_t bi = 0; bi < texts[(size_t)i].nbytes && k < moff[i + 1]; bi++) {   // matches are sorted by end index
+                c += is_char_start(p[bi]);
+                while (k < moff[i + 1] && conv[(size_t)k].end_index == (int32_t)bi) conv[(size_t)k++].end_index = c;
+            }
+        }
+        m = conv.data();
+    }
     PyObject* out = PyList_New(n);
     if (!out) return nullptr;
     for (Py_ssize_t i = 0; i < n; i++) {
@@ -611,8 +731,13 @@ PyObject* automaton_reduce(AutomatonObject* a, PyObject*) {
     PyObject* values;
     if (a->store == STORE_ANY) { values = eow_objects(a); if (!values) { Py_DECREF(chunks); return nullptr; } }
     else { values = Py_None; Py_INCREF(values); }
+#if ACX_UNICODE_BUILD
+    return Py_BuildValue("O(NiiiiiNs)", Py_TYPE(a), chunks, acx_trie_kind(a->trie), a->store, a->key_type,
+                         (int)acx_trie_num_keys(a->trie), (int)acx_trie_longest_word(a->trie), values, "utf8");
+#else
     return Py_BuildValue("O(NiiiiiN)", Py_TYPE(a), chunks, acx_trie_kind(a->trie), a->store, a->key_type,
                          (int)acx_trie_num_keys(a->trie), (int)acx_trie_longest_word(a->trie), values);
+#endif
 }
 
 // argument rules of save()/load(): src/custompickle/pyhelpers.c:4-59
@@ -755,7 +880,7 @@ PyObject* items_iter_next(ItemsIterObject* it) {
     const int64_t i = it->pos++;
     PyObject* key = nullptr;
     if (it->what != ITER_VALUES) {
-        key = PyBytes_FromStringAndSize((const char*)it->keys + it->key_off[i], (Py_ssize_t)(it->key_off[i + 1] - it->key_off[i]));
+        key = make_key_object(it->keys + it->key_off[i], (Py_ssize_t)(it->key_off[i + 1] - it->key_off[i]));
         if (!key || it->what == ITER_KEYS) return key;
     }
     PyObject* val;
@@ -777,12 +902,13 @@ PyObject* automaton_items_create(AutomatonObject* a, PyObject* args, int what) {
     const Py_ssize_t na = args ? PyTuple_GET_SIZE(args) : 0;
     const uint8_t* pat = nullptr; Py_ssize_t plen = 0;
     if (na >= 1 && !get_bytes(PyTuple_GET_ITEM(args, 0), "bytes expected", &pat, &plen)) return nullptr;
-    int use_wildcard = 0; uint8_t wildcard = 0;
+    int use_wildcard = 0;
+    const uint8_t* wild = nullptr; Py_ssize_t wild_len = 0;
     if (na >= 2) {
-        const uint8_t* w; Py_ssize_t wl;
-        if (!get_bytes(PyTuple_GET_ITEM(args, 1), "bytes expected", &w, &wl)) return nullptr;
-        if (wl != 1) { PyErr_SetString(PyExc_ValueError, "Wildcard must be a single character."); return nullptr; }
-        use_wildcard = 1; wildcard = w[0];
+        Text wt;
+        if (!get_text(PyTuple_GET_ITEM(args, 1), &wt)) return nullptr;
+        if (wt.nchars != 1) { PyErr_SetString(PyExc_ValueError, "Wildcard must be a single character."); return nullptr; }
+        use_wildcard = 1; wild = wt.data; wild_len = wt.nbytes;
     }
     int how = use_wildcard ? MATCH_EXACT_LENGTH : MATCH_AT_LEAST_PREFIX;
     if (na >= 3) {
@@ -799,7 +925,9 @@ PyObject* automaton_items_create(AutomatonObject* a, PyObject* args, int what) {
     if (!it) return nullptr;
     it->automaton = nullptr; it->keys = nullptr; it->key_off = nullptr; it->values = nullptr; it->n = 0; it->pos = 0;
     it->what = what;
-    int rc = acx_trie_items(a->trie, pat, (size_t)plen, use_wildcard, wildcard, how, &it->keys, &it->key_off, &it->values, &it->n);
+    // (str build: the trie holds UTF-8; libacx then enumerates letter by letter)
+    int rc = acx_trie_items(a->trie, pat, (size_t)plen, wild, (size_t)wild_len, how, ACX_UNICODE_BUILD,
+                            &it->keys, &it->key_off, &it->values, &it->n);
     if (rc) { Py_DECREF(it); return set_acx_error(rc); }
     Py_INCREF(a);
     it->automaton = a;
@@ -945,7 +1073,7 @@ PyMODINIT_FUNC PyInit_ahocorasick(void) {
     ADD_INT("KEY_STRING", KEY_STRING); ADD_INT("KEY_SEQUENCE", KEY_SEQUENCE);
     ADD_INT("MATCH_EXACT_LENGTH", MATCH_EXACT_LENGTH); ADD_INT("MATCH_AT_MOST_PREFIX", MATCH_AT_MOST_PREFIX);
     ADD_INT("MATCH_AT_LEAST_PREFIX", MATCH_AT_LEAST_PREFIX);
-    ADD_INT("unicode", 0);
+    ADD_INT("unicode", ACX_UNICODE_BUILD);
 #undef ADD_INT
     return m;
 }

@@ -23,7 +23,8 @@ def main():
     for trial in range(24):
         alpha = [b"ab", b"abc", b"abcd?"][trial % 3]
         store = [ref.STORE_INTS, ref.STORE_LENGTH, ref.STORE_ANY][(trial // 3) % 3]
-        keys = list({bytes(rng.choice(alpha) for _ in range(rng.randint(1, 6))) for _ in range(rng.randint(0, 30))})
+        keys = sorted({bytes(rng.choice(alpha) for _ in range(rng.randint(1, 6))) for _ in range(rng.randint(0, 30))})
+        rng.shuffle(keys)                      # insertion order matters; keep it reproducible
         A = ref.Automaton(store)
         vals = []
         for i, k in enumerate(keys):
