@@ -97,7 +97,9 @@ int acx_trie_stats(const acx_trie_t* t, int64_t* nodes, int64_t* words, int64_t*
 
 /* ------------------------------------------------------------------------------------
  * 1b. The reference's persistence formats <-> the trie (acx_persist.cpp).
- *     Bytes build, LP64.  Loading rebuilds the trie node for node (same child order);
+ *     LP64.  Dumps of the bytes build (letters stored as uint16) are read and written; dumps of the
+ *     unicode build (uint32 code points) are read: their keys are re-inserted as UTF-8.
+ *     Loading a bytes-build dump rebuilds the trie node for node (same child order);
  *     fail links are not taken from the dump: call acx_trie_make_automaton afterwards when
  *     the dump was an automaton.  Out-arrays are malloc'd: release with acx_blob_free.
  *     values_by_position (STORE_ANY): the values travel outside the dump, one per key in
@@ -113,6 +115,7 @@ typedef struct acx_ref_meta {       /* header of a save file, src/custompickle/c
  * automaton_unpickle :326-488 reads it) */
 int acx_trie_from_ref_pickle(const void* const* chunks, const size_t* chunk_bytes, size_t n_chunks,
                              int values_by_position, int64_t longest_word /* of the tuple; never lowered by remove_word */,
+                             int letter_bytes /* 2: bytes build; 4: unicode build (code points -> UTF-8 keys) */,
                              acx_trie_t** out, int64_t* n_eow);
 int acx_trie_to_ref_pickle(const acx_trie_t* t, int values_by_position, size_t chunk_limit,
                            void** buf, size_t** chunk_bytes, size_t* n_chunks);   /* chunks back to back in buf */
@@ -122,7 +125,7 @@ int acx_trie_eow_values(const acx_trie_t* t, int64_t** values, int64_t* n);
  * src/custompickle/load/module_automaton_load.c).  payload_off/len: byte range of the
  * serialized value of each key, in dump order (STORE_ANY only, else NULL); *out is NULL
  * for the file of an empty automaton. */
-int acx_trie_from_ref_savefile(const void* data, size_t nbytes, acx_trie_t** out, acx_ref_meta_t* meta,
+int acx_trie_from_ref_savefile(const void* data, size_t nbytes, int letter_bytes, acx_trie_t** out, acx_ref_meta_t* meta,
                                int64_t** payload_off, int64_t** payload_len);
 int acx_trie_to_ref_savefile(const acx_trie_t* t, int store, int key_type, const void* const* payloads,
                              const size_t* payload_bytes, void** buf, size_t* nbytes);

@@ -160,7 +160,7 @@ class Automaton:
         sizes = (C.c_size_t * n)(*[len(b) for b in bytes_list])
         n_eow = C.c_int64(0)
         try:
-            check(lib().acx_trie_from_ref_pickle(ptrs, sizes, n, 1 if any_ else 0, longest_word, C.byref(self._trie), C.byref(n_eow)))
+            check(lib().acx_trie_from_ref_pickle(ptrs, sizes, n, 1 if any_ else 0, longest_word, 2, C.byref(self._trie), C.byref(n_eow)))
         except AcxError as e:
             raise ValueError(str(e)) from None
         if any_:
@@ -659,7 +659,7 @@ def load(*args):
     meta = _RefMeta()
     trie, poff, plen = C.c_void_p(), C.POINTER(C.c_int64)(), C.POINTER(C.c_int64)()
     try:
-        check(lib().acx_trie_from_ref_savefile(data, len(data), C.byref(trie), C.byref(meta), C.byref(poff), C.byref(plen)))
+        check(lib().acx_trie_from_ref_savefile(data, len(data), 2, C.byref(trie), C.byref(meta), C.byref(poff), C.byref(plen)))
     except AcxError as e:
         raise ValueError(str(e)) from None
     try:

@@ -33,7 +33,7 @@
 
 namespace {
 
-constexpr size_t REC = 24, PAIR = 10, SAVE_HEADER = 48, SAVE_FOOTER = 24;
+constexpr size_t REC = 24, PAIR = 10, PAIR_UCS4 = 12, SAVE_HEADER = 48, SAVE_FOOTER = 24;
 const char MAGIC[16] = {'p', 'y', 'a', 'h', 'o', 'c', 'o', 'r', 'a', 's', 'i', 'c', 'k', '0', '0', '2'};
 
 inline uint64_t rd64(const uint8_t* p) { uint64_t v; memcpy(&v, p, 8); return v; }
@@ -120,6 +120,79 @@ int build_trie(const std::vector<RawNode>& raw, bool values_by_position, int64_t
     return ACX_OK;
 }
 
+// The unicode build's dumps: same records, but a pair is { u32 letter (code point); u64 child } = 12
+// bytes (src/common.h:50-56: TRIE_LETTER_TYPE uint32_t).  The byte trie here holds UTF-8, so the
+// code-point trie is not copied node for node: its keys are re-inserted, in dump (pre-order) order,
+// which also recreates the reference's child order letter by letter (a letter's node is created
+// when the first key through it is added).
+inline size_t utf8_encode(uint32_t cp, uint8_t* o) {
+    if (cp < 0x80) { o[0] = (uint8_t)cp; return 1; }
+    if (cp < 0x800) { o[0] = (uint8_t)(0xC0 | (cp >> 6)); o[1] = (uint8_t)(0x80 | (cp & 0x3F)); return 2; }
+    if (cp < 0x10000) { o[0] = (uint8_t)(0xE0 | (cp >> 12)); o[1] = (uint8_t)(0x80 | ((cp >> 6) & 0x3F)); o[2] = (uint8_t)(0x80 | (cp & 0x3F)); return 3; }
+    o[0] = (uint8_t)(0xF0 | (cp >> 18)); o[1] = (uint8_t)(0x80 | ((cp >> 12) & 0x3F)); o[2] = (uint8_t)(0x80 | ((cp >> 6) & 0x3F)); o[3] = (uint8_t)(0x80 | (cp & 0x3F));
+    return 4;
+}
+
+template <class ChildIndex>
+int build_trie_ucs4(const std::vector<RawNode>& raw, bool values_by_position, ChildIndex child_index, acx_trie** out,
+                    int64_t* n_eow_out) {
+    const size_t n = raw.size();
+    if (n == 0 || n >= ((size_t)1 << 31)) return acx_fail(ACX_E_FORMAT, "reference dump: %zu nodes", n);
+    acx_trie* t = nullptr;
+    int rc = acx_trie_new(&t);
+    if (rc) return rc;
+    try {
+        std::vector<uint8_t> linked(n, 0);
+        struct Frame { size_t node; uint32_t next; size_t key_len; };
+        std::vector<Frame> stack;
+        std::vector<uint8_t> key;
+        int64_t eow_seen = 0;
+        size_t visited = 0;
+        stack.push_back({0, 0, 0});
+        // pre-order = dump order, so the i-th node entered is node i and eow ordinals follow the dump
+        bool entering = true;
+        while (!stack.empty() && rc == ACX_OK) {
+            Frame& f = stack.back();
+            if (entering) {
+                if (f.node != visited) { rc = acx_fail(ACX_E_FORMAT, "reference dump: node #%zu is not in pre-order", f.node); break; }
+                visited++;
+                if (raw[f.node].eow) {
+                    if (f.node == 0) { rc = acx_fail(ACX_E_FORMAT, "reference dump: the root is marked as a key"); break; }
+                    const int64_t v = values_by_position ? eow_seen : (int64_t)raw[f.node].output;
+                    eow_seen++;
+                    rc = acx_trie_add_word(t, key.data(), key.size(), v, nullptr);
+                    if (rc) break;
+                }
+                entering = false;
+            }
+            if (f.next < raw[f.node].n) {
+                const uint32_t j = f.next++;
+                const int64_t c = child_index(f.node, j);
+                if (c <= (int64_t)f.node || c >= (int64_t)n || linked[c]) { rc = acx_fail(ACX_E_FORMAT, "reference dump: node #%zu has a malformed link #%u", f.node, j); break; }
+                linked[c] = 1;
+                const uint32_t cp = rd32(raw[f.node].pairs + (size_t)j * PAIR_UCS4);
+                if (cp > 0x10FFFF) { rc = acx_fail(ACX_E_FORMAT, "reference dump: node #%zu has letter %u: not a code point", f.node, cp); break; }
+                uint8_t enc[4];
+                const size_t el = utf8_encode(cp, enc);
+                const size_t kl = key.size();
+                key.insert(key.end(), enc, enc + el);
+                stack.push_back({(size_t)c, 0, kl});
+                entering = true;
+            } else {
+                key.resize(f.key_len);
+                stack.pop_back();
+            }
+        }
+        if (rc == ACX_OK && visited != n) rc = acx_fail(ACX_E_FORMAT, "reference dump: %zu of %zu nodes are not reachable from the root", n - visited, n);
+        if (rc == ACX_OK && n_eow_out) *n_eow_out = eow_seen;
+    } catch (const std::bad_alloc&) {
+        rc = acx_fail(ACX_E_NOMEM, "reference dump: out of memory");
+    }
+    if (rc != ACX_OK) { acx_trie_free(t); return rc; }
+    *out = t;
+    return ACX_OK;
+}
+
 // pre-order list of the live nodes (arena indices), children in sibling order
 int preorder(const acx_trie* t, std::vector<int32_t>& order) {
     order.clear();
@@ -153,8 +226,10 @@ uint32_t n_children(const acx_trie* t, int32_t k) {
 extern "C" {
 
 int acx_trie_from_ref_pickle(const void* const* chunks, const size_t* chunk_bytes, size_t n_chunks, int values_by_position,
-                             int64_t longest_word, acx_trie_t** out, int64_t* n_eow) {
+                             int64_t longest_word, int letter_bytes, acx_trie_t** out, int64_t* n_eow) {
     if (!chunks || !chunk_bytes || !out || n_chunks == 0) return acx_fail(ACX_E_INVAL, "acx_trie_from_ref_pickle: bad argument");
+    if (letter_bytes != 2 && letter_bytes != 4) return acx_fail(ACX_E_INVAL, "acx_trie_from_ref_pickle: letter_bytes must be 2 (bytes build) or 4 (unicode build)");
+    const size_t PAIR = letter_bytes == 4 ? PAIR_UCS4 : ::PAIR;
     std::vector<RawNode> raw;
     try {
         for (size_t c = 0; c < n_chunks; c++) {
@@ -178,8 +253,12 @@ int acx_trie_from_ref_pickle(const void* const* chunks, const size_t* chunk_byte
         return acx_fail(ACX_E_NOMEM, "acx_trie_from_ref_pickle: out of memory");
     }
     const std::vector<RawNode>& rr = raw;
+    if (letter_bytes == 4)
+        return build_trie_ucs4(raw, values_by_position != 0,
+                               [&rr](size_t k, uint32_t j) -> int64_t { return (int64_t)rd64(rr[k].pairs + (size_t)j * PAIR_UCS4 + 4) - 1; },
+                               out, n_eow);
     return build_trie(raw, values_by_position != 0, longest_word,
-                      [&rr](size_t k, uint32_t j) -> int64_t { return (int64_t)rd64(rr[k].pairs + (size_t)j * PAIR + 2) - 1; },   // 1-based ids
+                      [&rr](size_t k, uint32_t j) -> int64_t { return (int64_t)rd64(rr[k].pairs + (size_t)j * ::PAIR + 2) - 1; },   // 1-based ids
                       out, n_eow);
 }
 
@@ -244,9 +323,11 @@ int acx_trie_to_ref_pickle(const acx_trie_t* t, int values_by_position, size_t c
     return ACX_OK;
 }
 
-int acx_trie_from_ref_savefile(const void* data, size_t nbytes, acx_trie_t** out, acx_ref_meta_t* meta, int64_t** payload_off,
-                               int64_t** payload_len) {
+int acx_trie_from_ref_savefile(const void* data, size_t nbytes, int letter_bytes, acx_trie_t** out, acx_ref_meta_t* meta,
+                               int64_t** payload_off, int64_t** payload_len) {
     if (!data || !out || !meta) return acx_fail(ACX_E_INVAL, "acx_trie_from_ref_savefile: NULL argument");
+    if (letter_bytes != 2 && letter_bytes != 4) return acx_fail(ACX_E_INVAL, "acx_trie_from_ref_savefile: letter_bytes must be 2 (bytes build) or 4 (unicode build)");
+    const size_t PAIR = letter_bytes == 4 ? PAIR_UCS4 : ::PAIR;
     const uint8_t* b = (const uint8_t*)data;
     if (nbytes < SAVE_HEADER + SAVE_FOOTER || memcmp(b, MAGIC, 16) != 0 || memcmp(b + nbytes - 16, MAGIC, 16) != 0)
         return acx_fail(ACX_E_FORMAT, "save file: bad magic (not a pyahocorasick002 file, or truncated)");   // src/custompickle/custompickle.c:35-52
@@ -293,9 +374,18 @@ int acx_trie_from_ref_savefile(const void* data, size_t nbytes, acx_trie_t** out
     const std::vector<RawNode>& rr = raw;
     const std::unordered_map<uint64_t, int64_t>& ix = index;
     int64_t n_eow = 0;
-    int rc = build_trie(raw, any, meta->longest_word,
+    int rc;
+    if (letter_bytes == 4)
+        rc = build_trie_ucs4(raw, any,
+                             [&rr, &ix](size_t k, uint32_t j) -> int64_t {
+                                 auto it = ix.find(rd64(rr[k].pairs + (size_t)j * PAIR_UCS4 + 4));
+                                 return it == ix.end() ? -1 : it->second;
+                             },
+                             out, &n_eow);
+    else
+        rc = build_trie(raw, any, meta->longest_word,
                         [&rr, &ix](size_t k, uint32_t j) -> int64_t {
-                            auto it = ix.find(rd64(rr[k].pairs + (size_t)j * PAIR + 2));
+                            auto it = ix.find(rd64(rr[k].pairs + (size_t)j * ::PAIR + 2));
                             return it == ix.end() ? -1 : it->second;
                         },
                         out, &n_eow);

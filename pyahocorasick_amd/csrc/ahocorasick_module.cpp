@@ -217,7 +217,7 @@ AutomatonObject* automaton_alloc(PyTypeObject* type, int store, int key_type) {
 
 // the 7-tuple of __reduce__ (ours or the reference's bytes build): src/Automaton.c:107-149,
 // automaton_unpickle src/Automaton_pickle.c:326-488; parsing in libacx (acx_persist.cpp)
-PyObject* automaton_from_pickle(PyTypeObject* type, PyObject* args) {
+PyObject* automaton_from_pickle(PyTypeObject* type, PyObject* args, int letter_bytes = 2) {
     PyObject *bytes_list = nullptr, *values = nullptr;
     int kind, store, key_type, count, longest;
     if (!PyArg_ParseTuple(args, "OiiiiiO", &bytes_list, &kind, &store, &key_type, &count, &longest, &values)) {
@@ -253,7 +253,7 @@ PyObject* automaton_from_pickle(PyTypeObject* type, PyObject* args) {
         sizes[(size_t)k] = (size_t)PyBytes_GET_SIZE(b);
     }
     int64_t n_eow = 0;
-    rc = acx_trie_from_ref_pickle(ptrs.data(), sizes.data(), (size_t)n, store == STORE_ANY, longest, &a->trie, &n_eow);
+    rc = acx_trie_from_ref_pickle(ptrs.data(), sizes.data(), (size_t)n, store == STORE_ANY, longest, letter_bytes, &a->trie, &n_eow);
     if (rc) {
         Py_DECREF(a);
         if (rc == ACX_E_NOMEM) return PyErr_NoMemory();
@@ -291,11 +291,9 @@ PyObject* automaton_new(PyTypeObject* type, PyObject* args, PyObject*) {
         Py_DECREF(seven);
         return r;
     }
-    if (PyTuple_GET_SIZE(args) == 7) {
-        PyErr_SetString(PyExc_ValueError, "this is a pickle of the reference's unicode build (4-byte letters) or of a bytes build; "
-                                          "this str build reads only its own UTF-8 payload");
-        return nullptr;
-    }
+    // 7 elements: a pickle written by the reference's unicode build (4-byte letters): its keys are
+    // re-inserted as UTF-8 (acx_persist.cpp)
+    if (PyTuple_GET_SIZE(args) == 7) return automaton_from_pickle(type, args, 4);
 #else
     if (PyTuple_GET_SIZE(args) == 7) return automaton_from_pickle(type, args);
 #endif
@@ -984,7 +982,7 @@ PyObject* module_load(PyObject*, PyObject* args) {
     for (size_t got; (got = fread(chunk, 1, sizeof chunk, f)) > 0;) data.insert(data.end(), chunk, chunk + got);
     fclose(f);
     acx_trie_t* trie = nullptr; acx_ref_meta_t meta; int64_t *poff = nullptr, *plen = nullptr;
-    int rc = acx_trie_from_ref_savefile(data.data(), data.size(), &trie, &meta, &poff, &plen);
+    int rc = acx_trie_from_ref_savefile(data.data(), data.size(), ACX_UNICODE_BUILD ? 4 : 2, &trie, &meta, &poff, &plen);
     if (rc) {
         if (rc == ACX_E_NOMEM) return PyErr_NoMemory();
         PyErr_SetString(PyExc_ValueError, acx_last_error());

@@ -23,7 +23,7 @@ ALPHA = "abcżółć日本語ß€ "
 def main():
     rng = random.Random(11)
     cases = []
-    for trial in range(30):
+    for trial in range(18):
         alpha = ALPHA if trial % 3 else "ab ć"
         keys = sorted({"".join(rng.choice(alpha.replace(" ", "")) for _ in range(rng.randint(1, 5))) for _ in range(rng.randint(1, 30))})
         rng.shuffle(keys)                      # insertion order matters (child order); keep it reproducible
@@ -53,6 +53,19 @@ def main():
                 "enum": [[list(A.keys(*q)), list(A.values(*q))] for q in pats], "iter_keys": list(A),
                 "probe_results": [[A.exists(p), A.match(p), A.longest_prefix(p), A.get(p, None)] for p in probes]}
         A.make_automaton()
+        # persistence of the unicode build: __reduce__ payload and save file (4-byte letters)
+        import pickle
+        import tempfile
+        cls, args = A.__reduce__()
+        case["reduce"] = {"chunks": [c.hex() for c in args[0]], "rest": list(args[1:6]),
+                          "values_pickle": None if args[6] is None else pickle.dumps(args[6], protocol=2).hex()}
+        with tempfile.TemporaryDirectory() as d:
+            path = os.path.join(d, "a.sav")
+            if store == ref.STORE_ANY:
+                A.save(path, lambda v: pickle.dumps(v, protocol=2))
+            else:
+                A.save(path)
+            case["savefile"] = open(path, "rb").read().hex()
         hays = []
         for _ in range(5):
             h = "".join(rng.choice(alpha) for _ in range(rng.randint(0, 120)))

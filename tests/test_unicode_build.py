@@ -61,6 +61,22 @@ def test_trie_api_and_enumeration_match_the_unicode_reference(U):
         assert sorted(map(repr, B.items())) == sorted(map(repr, zip(case["iter_keys"], case["enum"][0][1])))
 
 
+def test_pickles_and_save_files_of_the_unicode_reference_load(U, tmp_path):
+    """4-byte letters (src/common.h:50-56): the keys are re-inserted as UTF-8 (acx_persist.cpp)"""
+    for case in CASES:
+        r = case["reduce"]
+        values = None if r["values_pickle"] is None else pickle.loads(bytes.fromhex(r["values_pickle"]))
+        A = U.Automaton([bytes.fromhex(c) for c in r["chunks"]], *r["rest"], values)
+        path = str(tmp_path / "u.sav")
+        open(path, "wb").write(bytes.fromhex(case["savefile"]))
+        B = U.load(path, pickle.loads)
+        for X in (A, B):
+            assert X.kind == U.AHOCORASICK and len(X) == len(case["keys"])
+            assert list(X.keys()) == case["iter_keys"] and list(X.values()) == case["enum"][0][1]
+            for q, (keys, values_q) in zip(case["pats"], case["enum"]):
+                assert list(X.keys(*q)) == keys
+
+
 def test_str_build_rules(U):
     A = U.Automaton()
     with pytest.raises(TypeError, match="string expected"):
@@ -72,9 +88,8 @@ def test_str_build_rules(U):
     assert L.get("日本語") == 3                                         # letters, not bytes
     with pytest.raises(ValueError, match="single character"):
         A.keys("ż", "??")
-    # a bytes-build / reference-unicode-build pickle payload is refused, not misread
-    with pytest.raises(ValueError):
-        U.Automaton([b"\x01" + b"\x00" * 31], 1, 10, 100, 0, 0, None)
+    with pytest.raises(ValueError):                                     # truncated 7-tuple payload
+        U.Automaton([b"\x02" + b"\x00" * 31], 1, 10, 100, 0, 0, None)
     A.make_automaton()
     with pytest.raises(TypeError, match="string required"):
         A.iter(b"bytes")
