@@ -27,14 +27,15 @@
 namespace {
 
 inline bool char_start(uint8_t b) { return (b & 0xC0) != 0x80; }
-inline int utf8_len(uint8_t lead) { return lead < 0x80 ? 1 : (lead >= 0xF0 ? 4 : (lead >= 0xE0 ? 3 : 2)); }
+// (5- and 6-byte forms: the str build's hosts also store KEY_SEQUENCE letters up to 31 bits this way)
+inline int utf8_len(uint8_t lead) { return lead < 0x80 ? 1 : lead >= 0xFC ? 6 : lead >= 0xF8 ? 5 : lead >= 0xF0 ? 4 : lead >= 0xE0 ? 3 : 2; }
 
 struct Item {            // a node one whole letter below its parent item
     int32_t node;
     int32_t depth;       // letters
     int32_t nbytes;      // key bytes up to and including this letter
     uint8_t len;         // bytes of this letter (0 for the root)
-    uint8_t b[4];
+    uint8_t b[6];
 };
 
 // the nodes one letter below `parent` (for UTF-8: 1-4 byte levels down), in creation order
@@ -44,7 +45,7 @@ void letter_children(const acx_trie* t, const Item& parent, bool utf8, std::vect
     std::vector<Walk> todo;
     for (int32_t c = t->nodes[parent.node].first_child; c >= 0; c = t->nodes[c].next_sibling) {
         Item k;
-        k.node = c; k.depth = parent.depth + 1; k.len = 1; k.b[0] = t->nodes[c].letter; k.b[1] = k.b[2] = k.b[3] = 0;
+        k.node = c; k.depth = parent.depth + 1; k.len = 1; memset(k.b, 0, sizeof k.b); k.b[0] = t->nodes[c].letter;
         const int len = utf8 ? utf8_len(t->nodes[c].letter) : 1;
         k.nbytes = parent.nbytes + len;
         if (len == 1) out.push_back(k);
@@ -67,7 +68,7 @@ void letter_children(const acx_trie* t, const Item& parent, bool utf8, std::vect
 
 extern "C" int acx_trie_items(const acx_trie_t* t, const uint8_t* pattern, size_t plen, const uint8_t* wildcard, size_t wlen,
                               int how, int letters_utf8, uint8_t** keys, int64_t** key_off, int64_t** values, int64_t* n) {
-    if (!t || !keys || !key_off || !values || !n || (plen && !pattern) || (wlen && !wildcard) || wlen > 4)
+    if (!t || !keys || !key_off || !values || !n || (plen && !pattern) || (wlen && !wildcard) || wlen > 6)
         return acx_fail(ACX_E_INVAL, "acx_trie_items: bad argument");
     if (how < 0 || how > 2) return acx_fail(ACX_E_INVAL, "acx_trie_items: bad match type %d", how);
     const bool utf8 = letters_utf8 != 0;
@@ -83,7 +84,7 @@ extern "C" int acx_trie_items(const acx_trie_t* t, const uint8_t* pattern, size_
             std::vector<Item> stack, kids;
             std::vector<uint8_t> path((size_t)t->longest_word + 8, 0);    // key bytes of the current branch
             Item root;
-            root.node = 0; root.depth = 0; root.nbytes = 0; root.len = 0; root.b[0] = root.b[1] = root.b[2] = root.b[3] = 0;
+            root.node = 0; root.depth = 0; root.nbytes = 0; root.len = 0; memset(root.b, 0, sizeof root.b);
             stack.push_back(root);
             while (!stack.empty()) {
                 const Item it = stack.back();
@@ -103,10 +104,10 @@ extern "C" int acx_trie_items(const acx_trie_t* t, const uint8_t* pattern, size_
                     const size_t l0 = poff[depth], l1 = poff[depth + 1];
                     int32_t c = it.node;
                     for (size_t i = l0; i < l1 && c >= 0; i++) c = t->child(c, pattern[i]);
-                    if (c >= 0 && l1 - l0 <= 4) {
+                    if (c >= 0 && l1 - l0 <= 6) {
                         Item k;
                         k.node = c; k.depth = it.depth + 1; k.nbytes = it.nbytes + (int32_t)(l1 - l0); k.len = (uint8_t)(l1 - l0);
-                        k.b[0] = k.b[1] = k.b[2] = k.b[3] = 0;
+                        memset(k.b, 0, sizeof k.b);
                         memcpy(k.b, pattern + l0, l1 - l0);
                         stack.push_back(k);
                     }

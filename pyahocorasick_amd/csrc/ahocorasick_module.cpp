@@ -69,13 +69,59 @@ struct Text {
     const uint8_t* data;     // the bytes the engine sees
     Py_ssize_t nbytes;
     Py_ssize_t nchars;       // letters as the reference counts them
+    std::vector<uint8_t> own;   // storage when the bytes had to be made (KEY_SEQUENCE); never copy a filled Text
     bool ascii() const { return nbytes == nchars; }
 };
 
 inline bool is_char_start(uint8_t b) { return (b & 0xC0) != 0x80; }
 
+// one letter as a self-synchronising byte sequence: UTF-8, continued to 31 bits the way UTF-8 was
+// first specified (5- and 6-byte forms) so that KEY_SEQUENCE letters fit as well
+inline void encode_letter(uint32_t v, std::vector<uint8_t>& out) {
+    if (v < 0x80) { out.push_back((uint8_t)v); return; }
+    int n = v < 0x800 ? 2 : v < 0x10000 ? 3 : v < 0x200000 ? 4 : v < 0x4000000 ? 5 : 6;
+    static const uint8_t lead[7] = {0, 0, 0xC0, 0xE0, 0xF0, 0xF8, 0xFC};
+    out.push_back((uint8_t)(lead[n] | (v >> (6 * (n - 1)))));
+    for (int k = n - 2; k >= 0; k--) out.push_back((uint8_t)(0x80 | ((v >> (6 * k)) & 0x3F)));
+}
+
+inline const uint8_t* decode_letter(const uint8_t* p, const uint8_t* e, uint32_t* v) {
+    const uint8_t b = *p++;
+    if (b < 0x80) { *v = b; return p; }
+    int n = b >= 0xFC ? 6 : b >= 0xF8 ? 5 : b >= 0xF0 ? 4 : b >= 0xE0 ? 3 : 2;
+    uint32_t x = b & (0xFF >> (n + 1));
+    for (int k = 1; k < n && p < e; k++) x = (x << 6) | (*p++ & 0x3F);
+    *v = x;
+    return p;
+}
+
+// KEY_SEQUENCE (src/utils.c:238-289): a tuple of integers, one letter each
+bool get_sequence(PyObject* o, Text* t, bool haystack) {
+    if (!PyTuple_Check(o)) {
+        PyErr_SetString(PyExc_TypeError, haystack ? "tuple required" : "argument is not a supported sequence type");
+        return false;
+    }
+    const Py_ssize_t n = PyTuple_GET_SIZE(o);
+    t->own.clear();
+    t->own.reserve((size_t)n + 8);
+    for (Py_ssize_t i = 0; i < n; i++) {
+        const Py_ssize_t v = PyNumber_AsSsize_t(PyTuple_GET_ITEM(o, i), PyExc_ValueError);
+        if (v == -1 && PyErr_Occurred()) { PyErr_Format(PyExc_ValueError, "item #%zd is not a number", i); return false; }
+        const unsigned long max_val = ACX_UNICODE_BUILD ? 2147483647ul : 65535ul;     // (the unicode build allows 2^32-1)
+        if (v < 0 || (unsigned long)v > max_val) {
+            PyErr_Format(PyExc_ValueError, "item #%zd: value %zd outside range [%d..%lu]", i, v, 0, max_val);
+            return false;
+        }
+        encode_letter((uint32_t)v, t->own);
+    }
+    t->own.push_back(0);                                             // never an empty vector: data() stays valid
+    t->data = t->own.data(); t->nbytes = (Py_ssize_t)t->own.size() - 1; t->nchars = n;
+    return true;
+}
+
 // haystack = true: the wording iter()/iter_long() use for a wrong argument type
-bool get_text(PyObject* o, Text* t, bool haystack = false) {
+bool get_text(PyObject* o, Text* t, bool haystack = false, int key_type = KEY_STRING) {
+    if (key_type == KEY_SEQUENCE) return get_sequence(o, t, haystack);
 #if ACX_UNICODE_BUILD
     if (!PyUnicode_Check(o)) { PyErr_SetString(PyExc_TypeError, haystack ? "string required" : "string expected"); return false; }
     Py_ssize_t n = 0;
@@ -89,10 +135,28 @@ bool get_text(PyObject* o, Text* t, bool haystack = false) {
     return true;
 }
 
-bool get_bytes(PyObject* o, const char*, const uint8_t** p, Py_ssize_t* n) {      // keys: bytes the engine sees
-    Text t;
-    if (!get_text(o, &t)) return false;
-    *p = t.data; *n = t.nbytes;
+// the prefix pattern / wildcard of keys() & co: always bytes (str in the unicode build), also for
+// KEY_SEQUENCE automata (pymod_get_string, src/Automaton.c:746, 765) — whose letters are then the
+// reference's widening of each byte (bytes build: sign-extended to uint16)
+bool get_pattern(PyObject* o, Text* t, int key_type) {
+    if (!get_text(o, t)) return false;
+    if (key_type != KEY_SEQUENCE) return true;
+    std::vector<uint8_t> enc;
+    const uint8_t *p = t->data, *e = t->data + t->nbytes;
+    Py_ssize_t n = 0;
+    while (p < e) {
+        uint32_t v;
+#if ACX_UNICODE_BUILD
+        p = decode_letter(p, e, &v);
+#else
+        v = (uint16_t)(int16_t)(int8_t)*p++;
+#endif
+        encode_letter(v, enc);
+        n++;
+    }
+    enc.push_back(0);
+    t->own.swap(enc);
+    t->data = t->own.data(); t->nbytes = (Py_ssize_t)t->own.size() - 1; t->nchars = n;
     return true;
 }
 
@@ -114,7 +178,21 @@ Py_ssize_t chars_in(const uint8_t* p, Py_ssize_t nb) {
     return c;
 }
 
-PyObject* make_key_object(const uint8_t* p, Py_ssize_t n) {
+PyObject* make_key_object(const uint8_t* p, Py_ssize_t n, int key_type = KEY_STRING) {
+    if (key_type == KEY_SEQUENCE) {
+        // what the reference's keys() gives for a sequence automaton: its letter buffer as a string —
+        // bytes build: the low byte of each letter (char_buffer, src/AutomatonItemsIter.c:211-216);
+        // unicode build: a str of the letters taken as code points
+        std::vector<uint32_t> letters;
+        for (const uint8_t *q = p, *e = p + n; q < e;) { uint32_t v; q = decode_letter(q, e, &v); letters.push_back(v); }
+#if ACX_UNICODE_BUILD
+        return PyUnicode_FromKindAndData(PyUnicode_4BYTE_KIND, letters.data(), (Py_ssize_t)letters.size());
+#else
+        std::vector<char> low(letters.size() + 1);
+        for (size_t i = 0; i < letters.size(); i++) low[i] = (char)(letters[i] & 0xFF);
+        return PyBytes_FromStringAndSize(low.data(), (Py_ssize_t)letters.size());
+#endif
+    }
 #if ACX_UNICODE_BUILD
     return PyUnicode_DecodeUTF8((const char*)p, n, "strict");
 #else
@@ -200,10 +278,6 @@ bool check_store_key(int store, int key_type) {
         PyErr_SetString(PyExc_ValueError, "key_type must have value KEY_STRING or KEY_SEQUENCE");
         return false;
     }
-    if (key_type == KEY_SEQUENCE) {
-        PyErr_SetString(PyExc_NotImplementedError, "KEY_SEQUENCE automata are not byte automata; outside the GPU path");
-        return false;
-    }
     return true;
 }
 
@@ -276,9 +350,8 @@ PyObject* automaton_from_pickle(PyTypeObject* type, PyObject* args, int letter_b
 }
 
 PyObject* automaton_new(PyTypeObject* type, PyObject* args, PyObject*) {
-#if ACX_UNICODE_BUILD
-    // this build pickles its UTF-8 byte trie: an 8th element marks the payload so that neither the
-    // reference's unicode build (4-byte letters) nor a bytes build mistakes it for its own
+    // an 8th element "utf8" marks a payload whose letters are multi-byte sequences in the byte trie
+    // (the str build; KEY_SEQUENCE automata): neither reference build mistakes it for its own
     if (PyTuple_GET_SIZE(args) == 8) {
         PyObject* tag = PyTuple_GET_ITEM(args, 7);
         if (!PyUnicode_Check(tag) || PyUnicode_CompareWithASCIIString(tag, "utf8") != 0) {
@@ -291,6 +364,7 @@ PyObject* automaton_new(PyTypeObject* type, PyObject* args, PyObject*) {
         Py_DECREF(seven);
         return r;
     }
+#if ACX_UNICODE_BUILD
     // 7 elements: a pickle written by the reference's unicode build (4-byte letters): its keys are
     // re-inserted as UTF-8 (acx_persist.cpp)
     if (PyTuple_GET_SIZE(args) == 7) return automaton_from_pickle(type, args, 4);
@@ -322,7 +396,7 @@ PyObject* automaton_add_word(AutomatonObject* a, PyObject* args) {
     const Py_ssize_t na = PyTuple_GET_SIZE(args);
     if (na < 1) { PyErr_SetString(PyExc_TypeError, "add_word() takes a key"); return nullptr; }
     Text kt;
-    if (!get_text(PyTuple_GET_ITEM(args, 0), &kt)) return nullptr;
+    if (!get_text(PyTuple_GET_ITEM(args, 0), &kt, false, a->key_type)) return nullptr;
     const uint8_t* key = kt.data; const Py_ssize_t len = kt.nbytes;
     int64_t v = 0;
     PyObject* obj = nullptr;
@@ -361,9 +435,9 @@ PyObject* automaton_add_word(AutomatonObject* a, PyObject* args) {
 }
 
 bool lookup(AutomatonObject* a, PyObject* keyobj, int* found, int64_t* value) {
-    const uint8_t* key; Py_ssize_t len;
-    if (!get_bytes(keyobj, "bytes expected", &key, &len)) return false;
-    int rc = acx_trie_get(a->trie, key, (size_t)len, found, value);
+    Text kt;
+    if (!get_text(keyobj, &kt, false, a->key_type)) return false;
+    int rc = acx_trie_get(a->trie, kt.data, (size_t)kt.nbytes, found, value);
     if (rc) { set_acx_error(rc); return false; }
     return true;
 }
@@ -400,23 +474,24 @@ PyObject* automaton_get(AutomatonObject* a, PyObject* args) {
 
 PyObject* automaton_longest_prefix(AutomatonObject* a, PyObject* args) {
     PyObject* k; if (!PyArg_ParseTuple(args, "O", &k)) return nullptr;
-    const uint8_t* key; Py_ssize_t len;
-    if (!get_bytes(k, "bytes expected", &key, &len)) return nullptr;
+    Text kt;
+    if (!get_text(k, &kt, false, a->key_type)) return nullptr;
+    const uint8_t* key = kt.data; const Py_ssize_t len = kt.nbytes;
     size_t n = 0;
     int rc = acx_trie_longest_prefix(a->trie, key, (size_t)len, &n);
     if (rc) return set_acx_error(rc);
-    // (unicode build: a prefix that ends inside a character still counts only whole letters)
-    while (ACX_UNICODE_BUILD && n > 0 && n < (size_t)len && !is_char_start(key[n])) n--;
+    // (multi-byte letters: a prefix that ends inside a letter still counts only whole letters)
+    while (n > 0 && n < (size_t)len && !is_char_start(key[n])) n--;
     return PyLong_FromSize_t((size_t)chars_in(key, (Py_ssize_t)n));
 }
 
 // 1 removed (value in *out, new ref), 0 absent, -1 error
 int remove_common(AutomatonObject* a, PyObject* args, PyObject** out) {
     PyObject* k; if (!PyArg_ParseTuple(args, "O", &k)) return -1;
-    const uint8_t* key; Py_ssize_t len;
-    if (!get_bytes(k, "bytes expected", &key, &len)) return -1;
+    Text kt;
+    if (!get_text(k, &kt, false, a->key_type)) return -1;
     int found = 0; int64_t v = 0;
-    int rc = acx_trie_remove_word(a->trie, key, (size_t)len, &found, &v);
+    int rc = acx_trie_remove_word(a->trie, kt.data, (size_t)kt.nbytes, &found, &v);
     if (rc) { set_acx_error(rc); return -1; }
     if (!found) return 0;
     if (a->store == STORE_ANY) {
@@ -565,7 +640,7 @@ PyObject* search_iter_set(SearchIterObject* it, PyObject* args) {  // src/Automa
     PyObject* s; int reset = 0;
     if (!PyArg_ParseTuple(args, "O|p", &s, &reset)) return nullptr;
     Text t;
-    if (!get_text(s, &t)) return nullptr;
+    if (!get_text(s, &t, true, it->automaton->key_type)) return nullptr;
     if (reset) { it->state = 0; it->shift = 0; }
     else it->shift += it->ref_index >= 0 ? it->ref_index : 0;
     if (!iter_load(it, t, 0, t.nchars)) return nullptr;
@@ -585,7 +660,7 @@ PyObject* automaton_iter(AutomatonObject* a, PyObject* args, PyObject* kw) {
     PyObject* s; int start = -1, end = -1, ws = -1;
     if (!PyArg_ParseTupleAndKeywords(args, kw, "O|iii", (char**)kwlist, &s, &start, &end, &ws)) return nullptr;
     Text t;
-    if (!get_text(s, &t, true)) return nullptr;
+    if (!get_text(s, &t, true, a->key_type)) return nullptr;
     const Py_ssize_t n = t.nchars;
     // -1 = default for both (src/Automaton.c:893-956).  The reference does not validate the
     // range (out of range is undefined behaviour there); here it is clamped to the haystack.
@@ -604,7 +679,7 @@ PyObject* automaton_iter_long(AutomatonObject* a, PyObject* args) {
     }
     if (PyTuple_GET_SIZE(args) < 1) { PyErr_SetString(PyExc_TypeError, "iter_long() takes a string"); return nullptr; }
     Text t;
-    if (!get_text(PyTuple_GET_ITEM(args, 0), &t, true)) return nullptr;
+    if (!get_text(PyTuple_GET_ITEM(args, 0), &t, true, a->key_type)) return nullptr;
     Py_ssize_t st, en;
     if (!parse_start_end(args, 1, 2, 0, t.nchars, &st, &en)) return nullptr;
     if (en < st) en = st;
@@ -617,7 +692,7 @@ PyObject* automaton_find_all(AutomatonObject* a, PyObject* args) {
     PyObject* s = PyTuple_GET_ITEM(args, 0);
     PyObject* cb = PyTuple_GET_ITEM(args, 1);
     Text t;
-    if (!get_text(s, &t)) return nullptr;
+    if (!get_text(s, &t, false, a->key_type)) return nullptr;
     if (!PyCallable_Check(cb)) {
         PyErr_SetString(PyExc_TypeError, "The callback argument must be a callable such as a function.");
         return nullptr;
@@ -651,7 +726,7 @@ PyObject* automaton_iter_batch(AutomatonObject* a, PyObject* args, PyObject* kw)
     std::vector<Text> texts((size_t)n);
     bool all_ascii = true;
     for (Py_ssize_t i = 0; i < n; i++) {
-        if (!get_text(PySequence_Fast_GET_ITEM(fast, i), &texts[(size_t)i], true)) { Py_DECREF(fast); return nullptr; }
+        if (!get_text(PySequence_Fast_GET_ITEM(fast, i), &texts[(size_t)i], true, a->key_type)) { Py_DECREF(fast); return nullptr; }
         off[(size_t)i + 1] = off[(size_t)i] + texts[(size_t)i].nbytes;
         all_ascii = all_ascii && texts[(size_t)i].ascii();
     }
@@ -729,6 +804,9 @@ PyObject* automaton_reduce(AutomatonObject* a, PyObject*) {
     PyObject* values;
     if (a->store == STORE_ANY) { values = eow_objects(a); if (!values) { Py_DECREF(chunks); return nullptr; } }
     else { values = Py_None; Py_INCREF(values); }
+    if (!ACX_UNICODE_BUILD && a->key_type == KEY_SEQUENCE)          // multi-byte letters: tag it so the reference refuses it
+        return Py_BuildValue("O(NiiiiiNs)", Py_TYPE(a), chunks, acx_trie_kind(a->trie), a->store, a->key_type,
+                             (int)acx_trie_num_keys(a->trie), (int)acx_trie_longest_word(a->trie), values, "utf8");
 #if ACX_UNICODE_BUILD
     return Py_BuildValue("O(NiiiiiNs)", Py_TYPE(a), chunks, acx_trie_kind(a->trie), a->store, a->key_type,
                          (int)acx_trie_num_keys(a->trie), (int)acx_trie_longest_word(a->trie), values, "utf8");
@@ -797,12 +875,12 @@ PyObject* automaton_get_stats(AutomatonObject* a, PyObject*) {       // src/Auto
 // match(key): True iff key is a prefix of some key (src/Automaton.c:460-479)
 PyObject* automaton_match(AutomatonObject* a, PyObject* args) {
     if (PyTuple_GET_SIZE(args) < 1) { PyErr_SetString(PyExc_TypeError, "match() takes a key"); return nullptr; }
-    const uint8_t* key; Py_ssize_t len;
-    if (!get_bytes(PyTuple_GET_ITEM(args, 0), "bytes expected", &key, &len)) return nullptr;
+    Text kt;
+    if (!get_text(PyTuple_GET_ITEM(args, 0), &kt, false, a->key_type)) return nullptr;
     size_t n = 0;
-    int rc = acx_trie_longest_prefix(a->trie, key, (size_t)len, &n);
+    int rc = acx_trie_longest_prefix(a->trie, kt.data, (size_t)kt.nbytes, &n);
     if (rc) return set_acx_error(rc);
-    if (n == (size_t)len) Py_RETURN_TRUE;
+    if (n == (size_t)kt.nbytes) Py_RETURN_TRUE;
     Py_RETURN_FALSE;
 }
 
@@ -878,7 +956,7 @@ PyObject* items_iter_next(ItemsIterObject* it) {
     const int64_t i = it->pos++;
     PyObject* key = nullptr;
     if (it->what != ITER_VALUES) {
-        key = make_key_object(it->keys + it->key_off[i], (Py_ssize_t)(it->key_off[i + 1] - it->key_off[i]));
+        key = make_key_object(it->keys + it->key_off[i], (Py_ssize_t)(it->key_off[i + 1] - it->key_off[i]), it->automaton->key_type);
         if (!key || it->what == ITER_KEYS) return key;
     }
     PyObject* val;
@@ -898,13 +976,16 @@ PyTypeObject ItemsIterType = {PyVarObject_HEAD_INIT(nullptr, 0) "ahocorasick.Aut
 // argument rules of automaton_items_create, src/Automaton.c:722-850
 PyObject* automaton_items_create(AutomatonObject* a, PyObject* args, int what) {
     const Py_ssize_t na = args ? PyTuple_GET_SIZE(args) : 0;
+    Text pt, wt;
     const uint8_t* pat = nullptr; Py_ssize_t plen = 0;
-    if (na >= 1 && !get_bytes(PyTuple_GET_ITEM(args, 0), "bytes expected", &pat, &plen)) return nullptr;
+    if (na >= 1) {
+        if (!get_pattern(PyTuple_GET_ITEM(args, 0), &pt, a->key_type)) return nullptr;
+        pat = pt.data; plen = pt.nbytes;
+    }
     int use_wildcard = 0;
     const uint8_t* wild = nullptr; Py_ssize_t wild_len = 0;
     if (na >= 2) {
-        Text wt;
-        if (!get_text(PyTuple_GET_ITEM(args, 1), &wt)) return nullptr;
+        if (!get_pattern(PyTuple_GET_ITEM(args, 1), &wt, a->key_type)) return nullptr;
         if (wt.nchars != 1) { PyErr_SetString(PyExc_ValueError, "Wildcard must be a single character."); return nullptr; }
         use_wildcard = 1; wild = wt.data; wild_len = wt.nbytes;
     }
@@ -924,7 +1005,7 @@ PyObject* automaton_items_create(AutomatonObject* a, PyObject* args, int what) {
     it->automaton = nullptr; it->keys = nullptr; it->key_off = nullptr; it->values = nullptr; it->n = 0; it->pos = 0;
     it->what = what;
     // (str build: the trie holds UTF-8; libacx then enumerates letter by letter)
-    int rc = acx_trie_items(a->trie, pat, (size_t)plen, wild, (size_t)wild_len, how, ACX_UNICODE_BUILD,
+    int rc = acx_trie_items(a->trie, pat, (size_t)plen, wild, (size_t)wild_len, how, ACX_UNICODE_BUILD || a->key_type == KEY_SEQUENCE,
                             &it->keys, &it->key_off, &it->values, &it->n);
     if (rc) { Py_DECREF(it); return set_acx_error(rc); }
     Py_INCREF(a);
