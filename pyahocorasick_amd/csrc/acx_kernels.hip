@@ -368,7 +368,13 @@ struct ItopCtx {
     const uint8_t*  table_bytes;
     const uint32_t* out_off;
     uint32_t row_bytes, b, D, bD, LD1, has_other, maskD, cs, hmin, pseudo1;
+    uint2* evq;                 // LDS: event queue, slot k of this thread at evq[k * ACX_ITOP_BLOCK + tid]; nullptr = store directly
 };
+
+// Events are queued per lane in LDS and written out ACX_ITOP_EVQ at a time: a store instruction
+// occupies the vector-memory pipe like a gather does, whether 3 or 60 of its lanes have something
+// to write, and almost every step has SOME lane with a match.
+#define ACX_ITOP_EVQ 3
 
 struct ItopLane {
     uint32_t st;     // explicit (depth > D): raw entry (low 24 bits = state)
@@ -376,6 +382,7 @@ struct ItopLane {
     uint32_t hist;   // last D symbols, b bits each
     uint32_t valid;  // symbols seen since the last reset, saturating at D
     uint32_t cnt;
+    uint32_t pend;   // events waiting in this lane's LDS queue (ILP == 1 only)
     uint2*   ev;
 };
 
@@ -419,8 +426,22 @@ __device__ __forceinline__ void itop_report(uint32_t e, uint32_t c, uint32_t idx
             c = C.out_off[s + 1] - C.out_off[s];
         }
     }
-    store_event<true>(L.ev++, idx, e);
+    if (C.evq) { C.evq[L.pend * ACX_ITOP_BLOCK + threadIdx.x] = make_uint2(idx, e); L.pend++; }
+    else store_event<true>(L.ev++, idx, e);
     L.cnt += c;
+}
+
+// write the queued events of every lane of the wave (wave-uniform call)
+__device__ __forceinline__ void itop_flush(const ItopCtx& C, ItopLane& L) {
+#pragma unroll
+    for (uint32_t k = 0; k < ACX_ITOP_EVQ; k++) {
+        if (k < L.pend) {
+            const uint2 v = C.evq[k * ACX_ITOP_BLOCK + threadIdx.x];
+            store_event<true>(L.ev + k, v.x, v.y);
+        }
+    }
+    L.ev += L.pend;
+    L.pend = 0;
 }
 
 // One input byte, any situation (warm-up, bytes outside the key alphabet, ragged ends, halo).
@@ -546,6 +567,7 @@ __global__ void __launch_bounds__(ACX_ITOP_BLOCK) k_walk_itop(const acx_walk_arg
     C.pseudo1 = s_mem[4] | (1u << ACX_ENTRY_CNT_SHIFT(ACX_STATE_BITS_NARROW));
     C.ND = s_mem + s_mem[8];
     C.cs = s_mem[11]; C.hmin = s_mem[12];
+    C.evq = ILP == 1 ? (uint2*)(s_sym + 256) : nullptr;          // one lane, one item: a private queue fits the rest of LDS
 
     const int lane = threadIdx.x & (ACX_WAVE - 1);
     const int64_t n_items = ck ? *n_chunks_dev : a.n_hay;
@@ -579,7 +601,7 @@ __global__ void __launch_bounds__(ACX_ITOP_BLOCK) k_walk_itop(const acx_walk_arg
                 }
             }
             p[q] = a.hay + d[q].start;
-            L[q].st = 0; L[q].sh = 0; L[q].hist = 0; L[q].valid = 0; L[q].cnt = 0;
+            L[q].st = 0; L[q].sh = 0; L[q].hist = 0; L[q].valid = 0; L[q].cnt = 0; L[q].pend = 0;
             L[q].ev = a.events + d[q].start + d[q].emit;
             ev0[q] = L[q].ev;
         }
@@ -635,6 +657,7 @@ __global__ void __launch_bounds__(ACX_ITOP_BLOCK) k_walk_itop(const acx_walk_arg
 #pragma unroll
                             for (int q = 0; q < ILP; q++) { s1[q] = sy[q][i]; ix[q] = (uint32_t)d[q].idx0 + jb + k * 4 + i; }
                             itop_fast_step<ESCAPE, CELL8, ILP>(s1, ix, C, L);
+                            if (ILP == 1 && __any(L[0].pend == ACX_ITOP_EVQ)) itop_flush(C, L[0]);
                         }
                     } else {
 #pragma unroll
@@ -643,12 +666,14 @@ __global__ void __launch_bounds__(ACX_ITOP_BLOCK) k_walk_itop(const acx_walk_arg
                             for (int i = 0; i < 4; i++) {
                                 const int j = jb + k * 4 + i;
                                 itop_step<ESCAPE, CELL8>(sy[q][i], (uint32_t)d[q].idx0 + j, j < d[q].len, j < d[q].len && j >= d[q].emit, C, L[q]);
+                                if (ILP == 1 && __any(L[q].pend == ACX_ITOP_EVQ)) itop_flush(C, L[q]);
                             }
                         }
                     }
                 }
             }
         }
+        if (ILP == 1) itop_flush(C, L[0]);
 #pragma unroll
         for (int q = 0; q < ILP; q++) {
             if (ok[q]) {
@@ -1118,9 +1143,9 @@ hipError_t acx_launch_walk_itop(const acx_walk_args& a, const acx_chunk_desc* ck
                                 const uint32_t* itop_entry, const uint32_t* itop_ebits, const void* itop_cells,
                                 const uint32_t* tflags, uint32_t cell_bytes, int tune, hipStream_t s) {
     if (n_items_bound <= 0) return hipSuccess;
-    const size_t lds_bytes = (size_t)((itop_words + 3) & ~3u) * 4 + 1024;
-    if (lds_bytes > 160 * 1024 || (cell_bytes != 4 && cell_bytes != 8)) return hipErrorInvalidValue;
     const int ilp = (tune & 3) == 1 ? 2 : 1;
+    const size_t lds_bytes = (size_t)((itop_words + 3) & ~3u) * 4 + 1024 + (ilp == 1 ? (size_t)ACX_ITOP_EVQ * ACX_ITOP_BLOCK * 8 : 0);
+    if (lds_bytes > 160 * 1024 || (cell_bytes != 4 && cell_bytes != 8)) return hipErrorInvalidValue;
     const bool cached = !((tune >> 2) & 1);
     int hb = (tune >> 4) & 3;
     hb = hb == 0 ? (ilp == 2 ? 2 : 4) : (hb == 1 ? 1 : (hb == 2 ? 2 : 4));
