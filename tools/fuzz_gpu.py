@@ -51,6 +51,13 @@ def one_case(rng, trial):
                 raise SystemExit("MISMATCH trial %d variant %d %s sigma %d keys %d kmax %d n %d L %d itop_depth %d"
                                  % (trial, variant, list(kw), sigma, len(keys), kmax, n, L, img.itop_depth))
             fins.append(fin)
+    from pyahocorasick_amd import ACX_SCAN_LONG
+    lo, le, lv = O.batch(reads.tobytes(), off, 1)                   # iter_long
+    sc = Scanner(img)
+    sc.scan(d_hay, n * L, n, stride=L, mode=ACX_SCAN_LONG)
+    moff, e, v, _ = sc.fetch()
+    if not (np.array_equal(moff, lo) and np.array_equal(e, le) and np.array_equal(v, lv)):
+        raise SystemExit("ITER_LONG MISMATCH trial %d sigma %d keys %d" % (trial, sigma, len(keys)))
     for fin in fins[1:]:
         if not np.array_equal(fin, fins[0]):
             raise SystemExit("FINAL STATE MISMATCH trial %d" % trial)
