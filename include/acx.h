@@ -239,6 +239,9 @@ void acx_result_free(acx_result_t* r);
  * 4. Convenience: scan host buffers end to end (H2D, scan, D2H).  `off` is int64[n_hay+1].
  *    This is what a CPython binding for Automaton.iter()/find_all() on a large haystack,
  *    or a new Automaton.iter_batch(), calls.  PCIe-inclusive by construction.
+ *    A batch larger than one launch can stage (4 GiB of haystack) is scanned in groups of whole
+ *    haystacks; acx_result_fetch_host returns the assembled result (the *_dev accessors then only
+ *    see the last group).
  * ---------------------------------------------------------------------------------- */
 int  acx_scan_host(acx_image_t* img, int mode, const uint8_t* hay, const int64_t* off, int64_t n_hay,
                    const int32_t* init_state, const int32_t* index_base,

@@ -452,22 +452,11 @@ extern "C" int acx_result_timing(acx_result_t* r, float* walk_ms, float* scan_ms
     return ACX_OK;
 }
 
-extern "C" int acx_scan_host(acx_image_t* img, int mode, const uint8_t* hay, const int64_t* off, int64_t n_hay,
-                             const int32_t* init_state, const int32_t* index_base, acx_result_t** result) {
-    if (!img || !off || !result || n_hay < 0) return acx_fail(ACX_E_INVAL, "acx_scan_host: bad argument");
-    if (off[0] != 0) return acx_fail(ACX_E_INVAL, "acx_scan_host: off[0] must be 0");
-    for (int64_t h = 0; h < n_hay; h++) {
-        if (off[h + 1] < off[h]) return acx_fail(ACX_E_INVAL, "acx_scan_host: offsets not monotone at %lld", (long long)h);
-        if (off[h + 1] - off[h] > INT32_MAX) return acx_fail(ACX_E_INVAL, "acx_scan_host: haystack %lld longer than INT_MAX", (long long)h);
-    }
-    const int64_t total_bytes = off[n_hay];
-    if (total_bytes > 0 && !hay) return acx_fail(ACX_E_INVAL, "acx_scan_host: hay is NULL");
+// one group of haystacks that fits a launch: H2D, scan; `off` starts at 0
+static int scan_host_once(acx_image_t* img, int mode, const uint8_t* hay, const int64_t* off, int64_t n_hay,
+                          const int32_t* init_state, const int32_t* index_base, acx_result_t** result) {
     acx_result* r = *result;
-    if (!r) {
-        r = new (std::nothrow) acx_result();
-        if (!r) return acx_fail(ACX_E_NOMEM, "acx_scan_host: out of memory");
-        *result = r;
-    }
+    const int64_t total_bytes = off[n_hay];
     int rc;
     if ((rc = r->in_hay.ensure((size_t)total_bytes + 64))) return rc;
     if ((rc = r->in_off.ensure((size_t)n_hay + 1))) return rc;
@@ -489,4 +478,74 @@ extern "C" int acx_scan_host(acx_image_t* img, int mode, const uint8_t* hay, con
     p.dev_index_base = index_base ? r->in_base.p : nullptr;
     p.want_final_state = mode == ACX_SCAN_ALL ? 1 : 0;
     return acx_scan_batch(img, &p, result, nullptr);
+}
+
+static int64_t max_launch_bytes() {
+    if (const char* v = getenv("ACX_MAX_LAUNCH_BYTES")) { const long long x = atoll(v); if (x > 0) return (int64_t)x; }   // test hook
+    return ACX_MAX_LAUNCH_BYTES;
+}
+
+extern "C" int acx_scan_host(acx_image_t* img, int mode, const uint8_t* hay, const int64_t* off, int64_t n_hay,
+                             const int32_t* init_state, const int32_t* index_base, acx_result_t** result) {
+    if (!img || !off || !result || n_hay < 0) return acx_fail(ACX_E_INVAL, "acx_scan_host: bad argument");
+    if (off[0] != 0) return acx_fail(ACX_E_INVAL, "acx_scan_host: off[0] must be 0");
+    for (int64_t h = 0; h < n_hay; h++) {
+        if (off[h + 1] < off[h]) return acx_fail(ACX_E_INVAL, "acx_scan_host: offsets not monotone at %lld", (long long)h);
+        if (off[h + 1] - off[h] > INT32_MAX) return acx_fail(ACX_E_INVAL, "acx_scan_host: haystack %lld longer than INT_MAX", (long long)h);
+    }
+    const int64_t total_bytes = off[n_hay];
+    if (total_bytes > 0 && !hay) return acx_fail(ACX_E_INVAL, "acx_scan_host: hay is NULL");
+    acx_result* r = *result;
+    if (!r) {
+        r = new (std::nothrow) acx_result();
+        if (!r) return acx_fail(ACX_E_NOMEM, "acx_scan_host: out of memory");
+        *result = r;
+    }
+    const int64_t limit = max_launch_bytes();
+    if (total_bytes <= limit) return scan_host_once(img, mode, hay, off, n_hay, init_state, index_base, result);
+
+    // More than one launch can stage (8 B of event scratch per haystack byte): scan groups of whole
+    // haystacks one after the other and assemble the host-side result; the device-side accessors then
+    // only see the last group, acx_result_fetch_host sees everything.
+    int rc;
+    std::vector<int64_t> all_off;
+    std::vector<acx_match_t> all_m;
+    std::vector<int32_t> all_fin;
+    std::vector<int64_t> goff;
+    try {
+        all_off.reserve((size_t)n_hay + 1);
+        all_off.push_back(0);
+        for (int64_t g0 = 0; g0 < n_hay;) {
+            int64_t g1 = g0 + 1;                                      // at least one haystack per group (each is < 2 GiB)
+            while (g1 < n_hay && off[g1 + 1] - off[g0] <= limit) g1++;
+            const int64_t gn = g1 - g0;
+            goff.resize((size_t)gn + 1);
+            for (int64_t k = 0; k <= gn; k++) goff[(size_t)k] = off[g0 + k] - off[g0];
+            if (goff[(size_t)gn] > ACX_MAX_LAUNCH_BYTES)
+                return acx_fail(ACX_E_UNSUPPORTED, "acx_scan_host: haystack %lld alone exceeds one launch", (long long)g0);
+            rc = scan_host_once(img, mode, hay + off[g0], goff.data(), gn, init_state ? init_state + g0 : nullptr,
+                                index_base ? index_base + g0 : nullptr, result);
+            if (rc) return rc;
+            const int64_t* moff; const acx_match_t* m; const int32_t* fin;
+            if ((rc = acx_result_fetch_host(r, &moff, &m, &fin))) return rc;
+            const int64_t base = all_off.back();
+            for (int64_t k = 1; k <= gn; k++) all_off.push_back(base + moff[k]);
+            all_m.insert(all_m.end(), m, m + moff[gn]);
+            if (fin) all_fin.insert(all_fin.end(), fin, fin + gn);
+            g0 = g1;
+        }
+    } catch (const std::bad_alloc&) {
+        return acx_fail(ACX_E_NOMEM, "acx_scan_host: out of memory");
+    }
+    if ((rc = r->h_off.ensure((size_t)n_hay + 1))) return rc;
+    if ((rc = r->h_matches.ensure(all_m.size() + 1))) return rc;
+    memcpy(r->h_off.p, all_off.data(), all_off.size() * sizeof(int64_t));
+    if (!all_m.empty()) memcpy(r->h_matches.p, all_m.data(), all_m.size() * sizeof(acx_match_t));
+    r->has_final = (int64_t)all_fin.size() == n_hay && n_hay > 0;
+    if (r->has_final) {
+        if ((rc = r->h_final.ensure((size_t)n_hay + 1))) return rc;
+        memcpy(r->h_final.p, all_fin.data(), all_fin.size() * sizeof(int32_t));
+    }
+    r->n_hay = n_hay; r->total = (int64_t)all_m.size(); r->host_valid = true;
+    return ACX_OK;
 }

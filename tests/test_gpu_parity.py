@@ -601,3 +601,18 @@ def test_asynchronous_scans_complete_lazily():
     m8, e8, v8 = O.batch(reads[:8].tobytes(), off[:9], 0)
     moff, e, v, _ = a.fetch()
     assert np.array_equal(moff, m8) and np.array_equal(e, e8) and np.array_equal(v, v8)
+
+
+def test_host_scan_splits_batches_that_exceed_one_launch(monkeypatch):
+    """acx_scan_host scans groups of whole haystacks when the batch is larger than one launch can
+    stage (4 GiB; the limit is lowered here through the test hook) and assembles one result"""
+    keys, reads = dna_workload(2000, 3000, 150, seed=31)
+    A, O = build_pair(keys)
+    hays = [r.tobytes() for r in reads] + [b"", reads[0].tobytes() * 40]
+    want = [O.iter(h) for h in hays]
+    assert A.iter_batch(hays) == want                                   # one launch
+    monkeypatch.setenv("ACX_MAX_LAUNCH_BYTES", "20000")                 # ~130 haystacks per group, one group of 1
+    assert A.iter_batch(hays) == want
+    assert A.iter_batch(hays, long=True) == [O.iter_long(h) for h in hays]
+    monkeypatch.setenv("ACX_MAX_LAUNCH_BYTES", "1")                     # every haystack its own launch
+    assert A.iter_batch(hays[:50]) == want[:50]
