@@ -116,6 +116,7 @@ typedef struct acx_ref_meta {       /* header of a save file, src/custompickle/c
 int acx_trie_from_ref_pickle(const void* const* chunks, const size_t* chunk_bytes, size_t n_chunks,
                              int values_by_position, int64_t longest_word /* of the tuple; never lowered by remove_word */,
                              int letter_bytes /* 2: bytes build; 4: unicode build (code points -> UTF-8 keys) */,
+                             int sequence /* 1: a KEY_SEQUENCE dump: letters are integers, re-encoded like the hosts do */,
                              acx_trie_t** out, int64_t* n_eow);
 int acx_trie_to_ref_pickle(const acx_trie_t* t, int values_by_position, size_t chunk_limit,
                            void** buf, size_t** chunk_bytes, size_t* n_chunks);   /* chunks back to back in buf */
@@ -127,7 +128,9 @@ int acx_trie_eow_values(const acx_trie_t* t, int64_t** values, int64_t* n);
  * for the file of an empty automaton. */
 int acx_trie_from_ref_savefile(const void* data, size_t nbytes, int letter_bytes, acx_trie_t** out, acx_ref_meta_t* meta,
                                int64_t** payload_off, int64_t** payload_len);
-int acx_trie_to_ref_savefile(const acx_trie_t* t, int store, int key_type, const void* const* payloads,
+/* letters_utf8 = 1: the trie's letters are multi-byte sequences (str flavour, KEY_SEQUENCE): the file
+ * is marked ("UTF8" in the header's first padding word) so that it is read back node for node */
+int acx_trie_to_ref_savefile(const acx_trie_t* t, int store, int key_type, int letters_utf8, const void* const* payloads,
                              const size_t* payload_bytes, void** buf, size_t* nbytes);
 
 /* ------------------------------------------------------------------------------------

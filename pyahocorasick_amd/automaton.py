@@ -160,7 +160,7 @@ class Automaton:
         sizes = (C.c_size_t * n)(*[len(b) for b in bytes_list])
         n_eow = C.c_int64(0)
         try:
-            check(lib().acx_trie_from_ref_pickle(ptrs, sizes, n, 1 if any_ else 0, longest_word, 2, C.byref(self._trie), C.byref(n_eow)))
+            check(lib().acx_trie_from_ref_pickle(ptrs, sizes, n, 1 if any_ else 0, longest_word, 2, 0, C.byref(self._trie), C.byref(n_eow)))
         except AcxError as e:
             raise ValueError(str(e)) from None
         if any_:
@@ -218,7 +218,7 @@ class Automaton:
         ptrs = (C.c_void_p * max(n, 1))(*[C.cast(C.c_char_p(b), C.c_void_p) for b in (payloads or [])])
         sizes = (C.c_size_t * max(n, 1))(*[len(b) for b in (payloads or [])])
         buf, nbytes = C.c_void_p(), C.c_size_t()
-        check(lib().acx_trie_to_ref_savefile(self._trie, self._store, self._key_type, ptrs, sizes, C.byref(buf), C.byref(nbytes)))
+        check(lib().acx_trie_to_ref_savefile(self._trie, self._store, self._key_type, 0, ptrs, sizes, C.byref(buf), C.byref(nbytes)))
         try:
             with open(args[0], "wb") as f:
                 f.write(C.string_at(buf, nbytes.value))

@@ -34,6 +34,7 @@
 namespace {
 
 constexpr size_t REC = 24, PAIR = 10, PAIR_UCS4 = 12, SAVE_HEADER = 48, SAVE_FOOTER = 24;
+constexpr uint32_t SAVE_UTF8_MARK = 0x38465455u;      // "UTF8"
 const char MAGIC[16] = {'p', 'y', 'a', 'h', 'o', 'c', 'o', 'r', 'a', 's', 'i', 'c', 'k', '0', '0', '2'};
 
 inline uint64_t rd64(const uint8_t* p) { uint64_t v; memcpy(&v, p, 8); return v; }
@@ -133,9 +134,19 @@ inline size_t utf8_encode(uint32_t cp, uint8_t* o) {
     return 4;
 }
 
+// any letter up to 31 bits as one self-synchronising sequence: UTF-8 continued with its original
+// 5- and 6-byte forms (KEY_SEQUENCE letters; the hosts encode the same way)
+inline size_t letter_encode(uint32_t v, uint8_t* o) {
+    if (v < 0x200000) return utf8_encode(v, o);
+    const int n = v < 0x4000000 ? 5 : 6;
+    o[0] = (uint8_t)((n == 5 ? 0xF8 : 0xFC) | (v >> (6 * (n - 1))));
+    for (int k = n - 2, i = 1; k >= 0; k--, i++) o[i] = (uint8_t)(0x80 | ((v >> (6 * k)) & 0x3F));
+    return (size_t)n;
+}
+
 template <class ChildIndex>
-int build_trie_ucs4(const std::vector<RawNode>& raw, bool values_by_position, ChildIndex child_index, acx_trie** out,
-                    int64_t* n_eow_out) {
+int build_trie_reinsert(const std::vector<RawNode>& raw, bool values_by_position, size_t pair_size, int letter_bytes, bool sequence,
+                        ChildIndex child_index, acx_trie** out, int64_t* n_eow_out) {
     const size_t n = raw.size();
     if (n == 0 || n >= ((size_t)1 << 31)) return acx_fail(ACX_E_FORMAT, "reference dump: %zu nodes", n);
     acx_trie* t = nullptr;
@@ -170,10 +181,11 @@ int build_trie_ucs4(const std::vector<RawNode>& raw, bool values_by_position, Ch
                 const int64_t c = child_index(f.node, j);
                 if (c <= (int64_t)f.node || c >= (int64_t)n || linked[c]) { rc = acx_fail(ACX_E_FORMAT, "reference dump: node #%zu has a malformed link #%u", f.node, j); break; }
                 linked[c] = 1;
-                const uint32_t cp = rd32(raw[f.node].pairs + (size_t)j * PAIR_UCS4);
-                if (cp > 0x10FFFF) { rc = acx_fail(ACX_E_FORMAT, "reference dump: node #%zu has letter %u: not a code point", f.node, cp); break; }
-                uint8_t enc[4];
-                const size_t el = utf8_encode(cp, enc);
+                const uint8_t* lp = raw[f.node].pairs + (size_t)j * pair_size;
+                const uint32_t cp = letter_bytes == 4 ? rd32(lp) : rd16(lp);
+                if (sequence ? cp > 0x7FFFFFFFu : cp > 0x10FFFF) { rc = acx_fail(ACX_E_FORMAT, "reference dump: node #%zu has letter %u: out of range", f.node, cp); break; }
+                uint8_t enc[6];
+                const size_t el = letter_encode(cp, enc);
                 const size_t kl = key.size();
                 key.insert(key.end(), enc, enc + el);
                 stack.push_back({(size_t)c, 0, kl});
@@ -226,7 +238,7 @@ uint32_t n_children(const acx_trie* t, int32_t k) {
 extern "C" {
 
 int acx_trie_from_ref_pickle(const void* const* chunks, const size_t* chunk_bytes, size_t n_chunks, int values_by_position,
-                             int64_t longest_word, int letter_bytes, acx_trie_t** out, int64_t* n_eow) {
+                             int64_t longest_word, int letter_bytes, int sequence, acx_trie_t** out, int64_t* n_eow) {
     if (!chunks || !chunk_bytes || !out || n_chunks == 0) return acx_fail(ACX_E_INVAL, "acx_trie_from_ref_pickle: bad argument");
     if (letter_bytes != 2 && letter_bytes != 4) return acx_fail(ACX_E_INVAL, "acx_trie_from_ref_pickle: letter_bytes must be 2 (bytes build) or 4 (unicode build)");
     const size_t PAIR = letter_bytes == 4 ? PAIR_UCS4 : ::PAIR;
@@ -253,10 +265,12 @@ int acx_trie_from_ref_pickle(const void* const* chunks, const size_t* chunk_byte
         return acx_fail(ACX_E_NOMEM, "acx_trie_from_ref_pickle: out of memory");
     }
     const std::vector<RawNode>& rr = raw;
-    if (letter_bytes == 4)
-        return build_trie_ucs4(raw, values_by_position != 0,
-                               [&rr](size_t k, uint32_t j) -> int64_t { return (int64_t)rd64(rr[k].pairs + (size_t)j * PAIR_UCS4 + 4) - 1; },
-                               out, n_eow);
+    if (letter_bytes == 4 || sequence) {
+        const size_t lb = (size_t)letter_bytes;
+        return build_trie_reinsert(raw, values_by_position != 0, PAIR, letter_bytes, sequence != 0,
+                                   [&rr, PAIR, lb](size_t k, uint32_t j) -> int64_t { return (int64_t)rd64(rr[k].pairs + (size_t)j * PAIR + lb) - 1; },
+                                   out, n_eow);
+    }
     return build_trie(raw, values_by_position != 0, longest_word,
                       [&rr](size_t k, uint32_t j) -> int64_t { return (int64_t)rd64(rr[k].pairs + (size_t)j * ::PAIR + 2) - 1; },   // 1-based ids
                       out, n_eow);
@@ -327,7 +341,6 @@ int acx_trie_from_ref_savefile(const void* data, size_t nbytes, int letter_bytes
                                int64_t** payload_off, int64_t** payload_len) {
     if (!data || !out || !meta) return acx_fail(ACX_E_INVAL, "acx_trie_from_ref_savefile: NULL argument");
     if (letter_bytes != 2 && letter_bytes != 4) return acx_fail(ACX_E_INVAL, "acx_trie_from_ref_savefile: letter_bytes must be 2 (bytes build) or 4 (unicode build)");
-    const size_t PAIR = letter_bytes == 4 ? PAIR_UCS4 : ::PAIR;
     const uint8_t* b = (const uint8_t*)data;
     if (nbytes < SAVE_HEADER + SAVE_FOOTER || memcmp(b, MAGIC, 16) != 0 || memcmp(b + nbytes - 16, MAGIC, 16) != 0)
         return acx_fail(ACX_E_FORMAT, "save file: bad magic (not a pyahocorasick002 file, or truncated)");   // src/custompickle/custompickle.c:35-52
@@ -337,6 +350,12 @@ int acx_trie_from_ref_savefile(const void* data, size_t nbytes, int letter_bytes
     const uint64_t n_nodes = rd64(b + nbytes - SAVE_FOOTER);
     meta->n_nodes = (int64_t)n_nodes;
     const bool any = meta->store == ACX_STORE_ANY;
+    // files written HERE with multi-byte letters (the str flavour, KEY_SEQUENCE) carry "UTF8" in the
+    // header's first padding word: bytes-build records whose letters are the bytes of the encoding
+    const bool own_utf8 = rd32(b + 28) == SAVE_UTF8_MARK;
+    if (own_utf8) letter_bytes = 2;
+    const bool reinsert = !own_utf8 && (letter_bytes == 4 || meta->key_type == ACX_KEY_SEQUENCE);
+    const size_t PAIR = letter_bytes == 4 ? PAIR_UCS4 : ::PAIR;
     *out = nullptr;
     if (payload_off) *payload_off = nullptr;
     if (payload_len) *payload_len = nullptr;
@@ -375,13 +394,15 @@ int acx_trie_from_ref_savefile(const void* data, size_t nbytes, int letter_bytes
     const std::unordered_map<uint64_t, int64_t>& ix = index;
     int64_t n_eow = 0;
     int rc;
-    if (letter_bytes == 4)
-        rc = build_trie_ucs4(raw, any,
-                             [&rr, &ix](size_t k, uint32_t j) -> int64_t {
-                                 auto it = ix.find(rd64(rr[k].pairs + (size_t)j * PAIR_UCS4 + 4));
-                                 return it == ix.end() ? -1 : it->second;
-                             },
-                             out, &n_eow);
+    if (reinsert) {
+        const size_t lb = (size_t)letter_bytes;
+        rc = build_trie_reinsert(raw, any, PAIR, letter_bytes, meta->key_type == ACX_KEY_SEQUENCE,
+                                 [&rr, &ix, PAIR, lb](size_t k, uint32_t j) -> int64_t {
+                                     auto it = ix.find(rd64(rr[k].pairs + (size_t)j * PAIR + lb));
+                                     return it == ix.end() ? -1 : it->second;
+                                 },
+                                 out, &n_eow);
+    }
     else
         rc = build_trie(raw, any, meta->longest_word,
                         [&rr, &ix](size_t k, uint32_t j) -> int64_t {
@@ -402,8 +423,8 @@ int acx_trie_from_ref_savefile(const void* data, size_t nbytes, int letter_bytes
     return ACX_OK;
 }
 
-int acx_trie_to_ref_savefile(const acx_trie_t* t, int store, int key_type, const void* const* payloads, const size_t* payload_bytes,
-                             void** buf, size_t* nbytes) {
+int acx_trie_to_ref_savefile(const acx_trie_t* t, int store, int key_type, int letters_utf8, const void* const* payloads,
+                             const size_t* payload_bytes, void** buf, size_t* nbytes) {
     if (!t || !buf || !nbytes) return acx_fail(ACX_E_INVAL, "acx_trie_to_ref_savefile: NULL argument");
     const bool any = store == ACX_STORE_ANY;
     if (any && t->count > 0 && (!payloads || !payload_bytes)) return acx_fail(ACX_E_INVAL, "acx_trie_to_ref_savefile: STORE_ANY needs the serialized values");
@@ -415,6 +436,7 @@ int acx_trie_to_ref_savefile(const acx_trie_t* t, int store, int key_type, const
         memcpy(data.data(), MAGIC, 16);
         wr32(data.data() + 16, (uint32_t)t->kind); wr32(data.data() + 20, (uint32_t)store); wr32(data.data() + 24, (uint32_t)key_type);
         wr64(data.data() + 32, (uint64_t)t->count); wr32(data.data() + 40, (uint32_t)t->longest_word);
+        if (letters_utf8) wr32(data.data() + 28, SAVE_UTF8_MARK);
         // node "addresses": any distinct non-zero numbers do (the loader only uses them as keys)
         auto addr = [](int32_t k) -> uint64_t { return 0x100000000ull + (uint64_t)k * 32u; };
         const bool has_fail = t->kind == ACX_KIND_AHOCORASICK;

@@ -291,7 +291,8 @@ AutomatonObject* automaton_alloc(PyTypeObject* type, int store, int key_type) {
 
 // the 7-tuple of __reduce__ (ours or the reference's bytes build): src/Automaton.c:107-149,
 // automaton_unpickle src/Automaton_pickle.c:326-488; parsing in libacx (acx_persist.cpp)
-PyObject* automaton_from_pickle(PyTypeObject* type, PyObject* args, int letter_bytes = 2) {
+// own_payload: written by this module with multi-byte letters (tagged "utf8"): node for node
+PyObject* automaton_from_pickle(PyTypeObject* type, PyObject* args, int letter_bytes = 2, bool own_payload = false) {
     PyObject *bytes_list = nullptr, *values = nullptr;
     int kind, store, key_type, count, longest;
     if (!PyArg_ParseTuple(args, "OiiiiiO", &bytes_list, &kind, &store, &key_type, &count, &longest, &values)) {
@@ -327,7 +328,8 @@ PyObject* automaton_from_pickle(PyTypeObject* type, PyObject* args, int letter_b
         sizes[(size_t)k] = (size_t)PyBytes_GET_SIZE(b);
     }
     int64_t n_eow = 0;
-    rc = acx_trie_from_ref_pickle(ptrs.data(), sizes.data(), (size_t)n, store == STORE_ANY, longest, letter_bytes, &a->trie, &n_eow);
+    rc = acx_trie_from_ref_pickle(ptrs.data(), sizes.data(), (size_t)n, store == STORE_ANY, longest, own_payload ? 2 : letter_bytes,
+                                  !own_payload && key_type == KEY_SEQUENCE, &a->trie, &n_eow);
     if (rc) {
         Py_DECREF(a);
         if (rc == ACX_E_NOMEM) return PyErr_NoMemory();
@@ -360,7 +362,7 @@ PyObject* automaton_new(PyTypeObject* type, PyObject* args, PyObject*) {
         }
         PyObject* seven = PyTuple_GetSlice(args, 0, 7);
         if (!seven) return nullptr;
-        PyObject* r = automaton_from_pickle(type, seven);
+        PyObject* r = automaton_from_pickle(type, seven, 2, true);
         Py_DECREF(seven);
         return r;
     }
@@ -852,7 +854,8 @@ PyObject* automaton_save(AutomatonObject* a, PyObject* args) {
         Py_DECREF(objs);
     }
     void* buf = nullptr; size_t nbytes = 0;
-    int rc = acx_trie_to_ref_savefile(a->trie, a->store, a->key_type, ptrs.data(), sizes.data(), &buf, &nbytes);
+    int rc = acx_trie_to_ref_savefile(a->trie, a->store, a->key_type, ACX_UNICODE_BUILD || a->key_type == KEY_SEQUENCE,
+                                      ptrs.data(), sizes.data(), &buf, &nbytes);
     release();
     if (rc) return set_acx_error(rc);
     FILE* f = fopen(path, "wb");

@@ -48,6 +48,18 @@ def main():
                                  list(A.values(*[bytes.fromhex(q) for q in p]))] for p in pats],
                 "probe_results": [[A.exists(p), A.match(p), A.longest_prefix(p), A.get(p, None), p in A] for p in probes]}
         A.make_automaton()
+        import pickle
+        import tempfile
+        cls, args = A.__reduce__()
+        case["reduce"] = {"chunks": [c.hex() for c in args[0]], "rest": list(args[1:6]),
+                          "values_pickle": None if args[6] is None else pickle.dumps(args[6], protocol=2).hex()}
+        with tempfile.TemporaryDirectory() as d:
+            path = os.path.join(d, "a.sav")
+            if store == ref.STORE_ANY:
+                A.save(path, lambda v: pickle.dumps(v, protocol=2))
+            else:
+                A.save(path)
+            case["savefile"] = open(path, "rb").read().hex()
         case["iter"] = [[list(m) for m in A.iter(tuple(h))] for h in hays]
         case["iter_long"] = [[list(m) for m in A.iter_long(tuple(h))] for h in hays]
         case["iter_range"] = [[list(m) for m in A.iter(tuple(h), 1, len(h) - 1)] if len(h) > 3 else None for h in hays]

@@ -70,6 +70,13 @@ def test_pickles_and_save_files_of_the_unicode_reference_load(U, tmp_path):
         path = str(tmp_path / "u.sav")
         open(path, "wb").write(bytes.fromhex(case["savefile"]))
         B = U.load(path, pickle.loads)
+        own = str(tmp_path / "own.sav")                                  # a file written by this flavour (marked UTF-8 payload)
+        if case["store"] == U.STORE_ANY:
+            B.save(own, lambda v: pickle.dumps(v, protocol=2))
+        else:
+            B.save(own)
+        C = U.load(own, pickle.loads)
+        assert sorted(C.keys()) == sorted(case["iter_keys"]) and len(C) == len(B) and C.kind == U.AHOCORASICK
         for X in (A, B):
             assert X.kind == U.AHOCORASICK and len(X) == len(case["keys"])
             assert list(X.keys()) == case["iter_keys"] and list(X.values()) == case["enum"][0][1]
