@@ -103,7 +103,8 @@ int acx_trie_stats(const acx_trie_t* t, int64_t* nodes, int64_t* words, int64_t*
  *     fail links are not taken from the dump: call acx_trie_make_automaton afterwards when
  *     the dump was an automaton.  Out-arrays are malloc'd: release with acx_blob_free.
  *     values_by_position (STORE_ANY): the values travel outside the dump, one per key in
- *     dump (pre-order) order; a loaded trie then stores that position as the key's value.
+ *     dump order; a loaded trie then stores that position as the key's value.  Dumps are written
+ *     in node creation order (parents first; the reference writes pre-order, reads any order).
  * ---------------------------------------------------------------------------------- */
 enum { ACX_STORE_LENGTH = 20, ACX_STORE_INTS = 10, ACX_STORE_ANY = 30 };    /* src/Automaton.h:22-27 */
 enum { ACX_KEY_STRING = 100, ACX_KEY_SEQUENCE = 200 };                      /* src/Automaton.h:29-32 */
@@ -120,7 +121,7 @@ int acx_trie_from_ref_pickle(const void* const* chunks, const size_t* chunk_byte
                              acx_trie_t** out, int64_t* n_eow);
 int acx_trie_to_ref_pickle(const acx_trie_t* t, int values_by_position, size_t chunk_limit,
                            void** buf, size_t** chunk_bytes, size_t* n_chunks);   /* chunks back to back in buf */
-/* values of the keys in dump order (what the `values` list of a STORE_ANY pickle is ordered by) */
+/* values of the keys in the order to_ref_pickle / to_ref_savefile write them (what the `values` list of a STORE_ANY pickle is ordered by) */
 int acx_trie_eow_values(const acx_trie_t* t, int64_t** values, int64_t* n);
 /* Automaton.save file (src/custompickle/save/automaton_save.c:36-138; loader
  * src/custompickle/load/module_automaton_load.c).  payload_off/len: byte range of the

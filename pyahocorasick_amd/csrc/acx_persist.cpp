@@ -1,7 +1,8 @@
 // acx_persist.cpp — the reference's two persistence formats <-> the arena trie.
 //
-// CPU only.  Both formats are dumps of the reference's pointer trie in trie_traverse order
-// (pre-order, children in array order: src/trie.c:197-225), one record per node:
+// CPU only.  Both formats are dumps of the reference's pointer trie, one record per node (the
+// reference writes them in trie_traverse order: pre-order, children in array order,
+// src/trie.c:197-225; its loaders accept any order):
 //
 //   record  = 24 bytes  { u64 output; u64 fail; u32 n; u8 eow; 3 bytes of padding (garbage) }
 //             = PICKLE_TRIENODE_SIZE, src/pickle/pickle.h:7 (TrieNode without its `next` pointer,
@@ -205,22 +206,28 @@ int build_trie_reinsert(const std::vector<RawNode>& raw, bool values_by_position
     return ACX_OK;
 }
 
-// pre-order list of the live nodes (arena indices), children in sibling order
+// The live nodes (reachable from the root) in ARENA order = the order they were created in.  Dumps
+// are written in this order: a parent is always older than its children (what the loaders need), the
+// reference's loader accepts any order, and a reload then recreates the arena as it was — which keeps
+// the enumeration order of multi-byte letters (acx_items.cpp orders them by creation).  For a trie
+// that was itself loaded from a reference dump this IS the reference's pre-order.
 int preorder(const acx_trie* t, std::vector<int32_t>& order) {
     order.clear();
     if (t->kind == ACX_KIND_EMPTY || t->nodes.empty()) return ACX_OK;
     try {
-        order.reserve((size_t)t->live_nodes);
-        std::vector<int32_t> stack, kids;
+        std::vector<uint8_t> live(t->nodes.size(), 0);
+        std::vector<int32_t> stack;
         stack.push_back(0);
+        size_t n_live = 0;
         while (!stack.empty()) {
             const int32_t k = stack.back();
             stack.pop_back();
-            order.push_back(k);
-            kids.clear();
-            for (int32_t c = t->nodes[k].first_child; c >= 0; c = t->nodes[c].next_sibling) kids.push_back(c);
-            for (size_t i = kids.size(); i-- > 0;) stack.push_back(kids[i]);
+            live[(size_t)k] = 1;
+            n_live++;
+            for (int32_t c = t->nodes[k].first_child; c >= 0; c = t->nodes[c].next_sibling) stack.push_back(c);
         }
+        order.reserve(n_live);
+        for (size_t k = 0; k < live.size(); k++) if (live[k]) order.push_back((int32_t)k);
     } catch (const std::bad_alloc&) {
         return acx_fail(ACX_E_NOMEM, "reference dump: out of memory");
     }
