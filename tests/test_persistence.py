@@ -204,6 +204,17 @@ def test_dumps_written_here_load_in_the_reference(tmp_path):
     `ahocorasick`): pickles and save files written by the drop-in extension"""
     D = dropin()
     jobs = []
+    # an automaton built here key by key: its dump order (node creation order) is not the pre-order
+    # the reference writes, which its loader must not care about
+    local_keys = [b"b", b"a", b"ba", b"ab", b"bab", b"c", b"abc", b"cab", b"aa"]
+    L = D.Automaton(D.STORE_INTS)
+    for i, k in enumerate(local_keys):
+        L.add_word(k, i)
+    L.make_automaton()
+    lp, ls = str(tmp_path / "local.pkl"), str(tmp_path / "local.sav")
+    open(lp, "wb").write(pickle.dumps(L, protocol=2))
+    L.save(ls)
+    jobs.append({"name": "__local__", "pkl": lp, "sav": ls, "haystacks": [b"abcabbabaacab".hex()]})
     for case in CASES:
         if case["kind"] != acx.AHOCORASICK:
             continue
@@ -236,6 +247,14 @@ print(json.dumps(out))
     r = subprocess.run([sys.executable, "-c", code], input=json.dumps(jobs), capture_output=True, text=True, timeout=120)
     assert r.returncode == 0, r.stderr
     got = json.loads(r.stdout)
+    for res in got["__local__"]:
+        assert sorted(res["keys"]) == sorted(k.hex() for k in local_keys) and res["stats"]["words_count"] == len(local_keys)
+        want = []
+        hay = b"abcabbabaacab"
+        for end in range(len(hay)):                     # every key ending here, longest first
+            for k in sorted((k for k in local_keys if hay[:end + 1].endswith(k)), key=len, reverse=True):
+                want.append([end, local_keys.index(k)])
+        assert res["iter"] == [want]
     for case in CASES:
         if case["kind"] != acx.AHOCORASICK:
             continue
