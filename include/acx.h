@@ -119,20 +119,23 @@ int acx_trie_from_ref_pickle(const void* const* chunks, const size_t* chunk_byte
                              int letter_bytes /* 2: bytes build; 4: unicode build (code points -> UTF-8 keys) */,
                              int sequence /* 1: a KEY_SEQUENCE dump: letters are integers, re-encoded like the hosts do */,
                              acx_trie_t** out, int64_t* n_eow);
-int acx_trie_to_ref_pickle(const acx_trie_t* t, int values_by_position, size_t chunk_limit,
-                           void** buf, size_t** chunk_bytes, size_t* n_chunks);   /* chunks back to back in buf */
-/* values of the keys in the order to_ref_pickle / to_ref_savefile write them (what the `values` list of a STORE_ANY pickle is ordered by) */
-int acx_trie_eow_values(const acx_trie_t* t, int64_t** values, int64_t* n);
+/* letter_bytes: 2 writes the bytes build's layout (uint16 letters), 4 the unicode build's (uint32).
+ * letters_multibyte = 0: every byte of the trie is a letter (byte keys).  1: the trie stores letters
+ * as multi-byte sequences (str flavour, KEY_SEQUENCE): they are decoded on the way out, so the dump
+ * is a genuine dump of the reference build that `letter_bytes` names. */
+int acx_trie_to_ref_pickle(const acx_trie_t* t, int values_by_position, size_t chunk_limit, int letter_bytes,
+                           int letters_multibyte, void** buf, size_t** chunk_bytes, size_t* n_chunks);   /* chunks back to back in buf */
+/* values of the keys in the order to_ref_pickle / to_ref_savefile write them (what the `values` list
+ * of a STORE_ANY pickle is ordered by) */
+int acx_trie_eow_values(const acx_trie_t* t, int letters_multibyte, int64_t** values, int64_t* n);
 /* Automaton.save file (src/custompickle/save/automaton_save.c:36-138; loader
  * src/custompickle/load/module_automaton_load.c).  payload_off/len: byte range of the
  * serialized value of each key, in dump order (STORE_ANY only, else NULL); *out is NULL
  * for the file of an empty automaton. */
 int acx_trie_from_ref_savefile(const void* data, size_t nbytes, int letter_bytes, acx_trie_t** out, acx_ref_meta_t* meta,
                                int64_t** payload_off, int64_t** payload_len);
-/* letters_utf8 = 1: the trie's letters are multi-byte sequences (str flavour, KEY_SEQUENCE): the file
- * is marked ("UTF8" in the header's first padding word) so that it is read back node for node */
-int acx_trie_to_ref_savefile(const acx_trie_t* t, int store, int key_type, int letters_utf8, const void* const* payloads,
-                             const size_t* payload_bytes, void** buf, size_t* nbytes);
+int acx_trie_to_ref_savefile(const acx_trie_t* t, int store, int key_type, int letter_bytes, int letters_multibyte,
+                             const void* const* payloads, const size_t* payload_bytes, void** buf, size_t* nbytes);
 
 /* ------------------------------------------------------------------------------------
  * 2. Flat image.  One contiguous, relocatable little-endian blob (layout: acx_blob.h):

@@ -69,12 +69,12 @@ SIGNATURES = {
     "acx_trie_stats": (C.c_int, [_P] + [C.POINTER(C.c_int64)] * 6),
     "acx_trie_from_ref_pickle": (C.c_int, [C.POINTER(C.c_void_p), C.POINTER(C.c_size_t), C.c_size_t, C.c_int, C.c_int64, C.c_int,
                                            C.c_int, _PP, C.POINTER(C.c_int64)]),
-    "acx_trie_to_ref_pickle": (C.c_int, [_P, C.c_int, C.c_size_t, _PP, C.POINTER(C.POINTER(C.c_size_t)),
+    "acx_trie_to_ref_pickle": (C.c_int, [_P, C.c_int, C.c_size_t, C.c_int, C.c_int, _PP, C.POINTER(C.POINTER(C.c_size_t)),
                                          C.POINTER(C.c_size_t)]),
-    "acx_trie_eow_values": (C.c_int, [_P, C.POINTER(C.POINTER(C.c_int64)), C.POINTER(C.c_int64)]),
+    "acx_trie_eow_values": (C.c_int, [_P, C.c_int, C.POINTER(C.POINTER(C.c_int64)), C.POINTER(C.c_int64)]),
     "acx_trie_from_ref_savefile": (C.c_int, [_P, C.c_size_t, C.c_int, _PP, _P, C.POINTER(C.POINTER(C.c_int64)),
                                              C.POINTER(C.POINTER(C.c_int64))]),
-    "acx_trie_to_ref_savefile": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t), _PP,
+    "acx_trie_to_ref_savefile": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t), _PP,
                                            C.POINTER(C.c_size_t)]),
     "acx_flatten": (C.c_int, [_P, _PP, C.POINTER(C.c_size_t)]),
     "acx_blob_free": (None, [_P]),

@@ -176,7 +176,7 @@ class Automaton:
             return (type(self), ())
         any_ = self._store == STORE_ANY
         buf, sizes, n = C.c_void_p(), C.POINTER(C.c_size_t)(), C.c_size_t()
-        check(lib().acx_trie_to_ref_pickle(self._trie, 1 if any_ else 0, 0, C.byref(buf), C.byref(sizes), C.byref(n)))
+        check(lib().acx_trie_to_ref_pickle(self._trie, 1 if any_ else 0, 0, 2, 0, C.byref(buf), C.byref(sizes), C.byref(n)))
         try:
             chunks, at = [], 0
             for k in range(n.value):
@@ -191,7 +191,7 @@ class Automaton:
 
     def _eow_values(self):
         vals, n = C.POINTER(C.c_int64)(), C.c_int64()
-        check(lib().acx_trie_eow_values(self._trie, C.byref(vals), C.byref(n)))
+        check(lib().acx_trie_eow_values(self._trie, 0, C.byref(vals), C.byref(n)))
         try:
             return [vals[i] for i in range(n.value)]
         finally:
@@ -218,7 +218,7 @@ class Automaton:
         ptrs = (C.c_void_p * max(n, 1))(*[C.cast(C.c_char_p(b), C.c_void_p) for b in (payloads or [])])
         sizes = (C.c_size_t * max(n, 1))(*[len(b) for b in (payloads or [])])
         buf, nbytes = C.c_void_p(), C.c_size_t()
-        check(lib().acx_trie_to_ref_savefile(self._trie, self._store, self._key_type, 0, ptrs, sizes, C.byref(buf), C.byref(nbytes)))
+        check(lib().acx_trie_to_ref_savefile(self._trie, self._store, self._key_type, 2, 0, ptrs, sizes, C.byref(buf), C.byref(nbytes)))
         try:
             with open(args[0], "wb") as f:
                 f.write(C.string_at(buf, nbytes.value))
@@ -494,7 +494,7 @@ class Automaton:
 
     def _trie_chunks(self):
         buf, sizes, n = C.c_void_p(), C.POINTER(C.c_size_t)(), C.c_size_t()
-        check(lib().acx_trie_to_ref_pickle(self._trie, 0, 0, C.byref(buf), C.byref(sizes), C.byref(n)))
+        check(lib().acx_trie_to_ref_pickle(self._trie, 0, 0, 2, 0, C.byref(buf), C.byref(sizes), C.byref(n)))
         try:
             out, at = [], 0
             for k in range(n.value):

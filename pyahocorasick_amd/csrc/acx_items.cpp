@@ -66,6 +66,26 @@ void letter_children(const acx_trie* t, const Item& parent, bool utf8, std::vect
 
 }  // namespace
 
+void acx_letter_children(const acx_trie* t, int32_t parent, bool multibyte, std::vector<AcxLetterChild>& out) {
+    Item p;
+    p.node = parent; p.depth = 0; p.nbytes = 0; p.len = 0; memset(p.b, 0, sizeof p.b);
+    std::vector<Item> kids;
+    letter_children(t, p, multibyte, kids);
+    out.clear();
+    for (const Item& k : kids) {
+        AcxLetterChild c;
+        c.node = k.node; c.len = k.len; memcpy(c.b, k.b, sizeof c.b);
+        out.push_back(c);
+    }
+}
+
+uint32_t acx_letter_value(const uint8_t* b, int len) {
+    if (len <= 1) return b[0];
+    uint32_t x = b[0] & (0xFFu >> (len + 1));
+    for (int k = 1; k < len; k++) x = (x << 6) | (b[k] & 0x3Fu);
+    return x;
+}
+
 extern "C" int acx_trie_items(const acx_trie_t* t, const uint8_t* pattern, size_t plen, const uint8_t* wildcard, size_t wlen,
                               int how, int letters_utf8, uint8_t** keys, int64_t** key_off, int64_t** values, int64_t* n) {
     if (!t || !keys || !key_off || !values || !n || (plen && !pattern) || (wlen && !wildcard) || wlen > 6)

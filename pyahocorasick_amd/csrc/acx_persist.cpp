@@ -23,7 +23,9 @@
 // Loading rebuilds the arena trie node for node (same child order, so keys() order and every
 // search result are the reference's); fail links are NOT taken from the file — the host calls
 // make_automaton again when the dump was an automaton.  Dumps written here carry the fail links
-// the reference's loader expects.
+// the reference's loader expects, and every dump written here is a valid dump of the corresponding
+// reference build: bytes build (uint16 letters) for byte keys and bytes-flavour KEY_SEQUENCE, unicode
+// build (uint32 letters) for the str flavour — multi-byte letters are decoded on the way out.
 #include "acx_trie_impl.h"
 
 #include <cstdlib>
@@ -35,7 +37,6 @@
 namespace {
 
 constexpr size_t REC = 24, PAIR = 10, PAIR_UCS4 = 12, SAVE_HEADER = 48, SAVE_FOOTER = 24;
-constexpr uint32_t SAVE_UTF8_MARK = 0x38465455u;      // "UTF8"
 const char MAGIC[16] = {'p', 'y', 'a', 'h', 'o', 'c', 'o', 'r', 'a', 's', 'i', 'c', 'k', '0', '0', '2'};
 
 inline uint64_t rd64(const uint8_t* p) { uint64_t v; memcpy(&v, p, 8); return v; }
@@ -234,10 +235,76 @@ int preorder(const acx_trie* t, std::vector<int32_t>& order) {
     return ACX_OK;
 }
 
-uint32_t n_children(const acx_trie* t, int32_t k) {
-    uint32_t n = 0;
-    for (int32_t c = t->nodes[k].first_child; c >= 0; c = t->nodes[c].next_sibling) n++;
-    return n;
+// The trie as the writers see it: one entry per letter-level node, in dump order, with its
+// children as (letter value, child position).
+//   multibyte = false (bytes build, string keys): every byte node is a letter node; dump order =
+//     creation order; the letter is the byte, sign-extended like the reference widens `char`.
+//   multibyte = true (str flavour, KEY_SEQUENCE): a letter is a whole byte sequence; only the nodes
+//     that end a letter are dumped, in pre-order with children in creation order — what the
+//     re-inserting loader (and the reference) reads back in the same order.
+struct LView {
+    std::vector<int32_t> node;                                   // arena index of each dumped node
+    std::vector<std::vector<std::pair<uint32_t, int64_t>>> kids; // per dumped node: (letter, child position)
+    std::vector<int64_t> pos_of;                                 // arena index -> position, -1 if not dumped
+};
+
+int letter_view(const acx_trie* t, bool multibyte, LView& v) {
+    v.node.clear(); v.kids.clear(); v.pos_of.assign(t->nodes.size(), -1);
+    if (t->kind == ACX_KIND_EMPTY || t->nodes.empty()) return ACX_OK;
+    try {
+        if (!multibyte) {
+            int rc = preorder(t, v.node);                        // (creation order)
+            if (rc) return rc;
+            for (size_t k = 0; k < v.node.size(); k++) v.pos_of[(size_t)v.node[k]] = (int64_t)k;
+            v.kids.resize(v.node.size());
+            for (size_t k = 0; k < v.node.size(); k++)
+                for (int32_t c = t->nodes[v.node[k]].first_child; c >= 0; c = t->nodes[c].next_sibling)
+                    v.kids[k].push_back({(uint32_t)(uint16_t)(int16_t)(int8_t)t->nodes[c].letter, v.pos_of[(size_t)c]});
+            return ACX_OK;
+        }
+        struct Frame { int32_t node; size_t pos; std::vector<AcxLetterChild> ch; size_t next; };
+        std::vector<Frame> stack;
+        auto enter = [&](int32_t node) {
+            Frame f;
+            f.node = node; f.pos = v.node.size(); f.next = 0;
+            acx_letter_children(t, node, true, f.ch);
+            v.pos_of[(size_t)node] = (int64_t)f.pos;
+            v.node.push_back(node);
+            v.kids.emplace_back();
+            stack.push_back(std::move(f));
+        };
+        enter(0);
+        while (!stack.empty()) {
+            Frame& f = stack.back();
+            if (f.next < f.ch.size()) {
+                const AcxLetterChild c = f.ch[f.next++];
+                const size_t parent_pos = f.pos;
+                const uint32_t letter = acx_letter_value(c.b, c.len);
+                const size_t child_pos = v.node.size();
+                enter(c.node);                                     // (invalidates f)
+                v.kids[parent_pos].push_back({letter, (int64_t)child_pos});
+            } else {
+                stack.pop_back();
+            }
+        }
+    } catch (const std::bad_alloc&) {
+        return acx_fail(ACX_E_NOMEM, "reference dump: out of memory");
+    }
+    return ACX_OK;
+}
+
+// fail link of a dumped node as a position (+1), 0 = none
+inline uint64_t fail_id(const acx_trie* t, const LView& v, size_t k) {
+    if (t->kind != ACX_KIND_AHOCORASICK) return 0;
+    const int32_t f = t->nodes[v.node[k]].fail;
+    if (f < 0) return 0;
+    const int64_t p = v.pos_of[(size_t)f];
+    return p < 0 ? 1 : (uint64_t)p + 1;                           // (a fail link always ends a letter; the root otherwise)
+}
+
+inline void write_pair(uint8_t* p, int letter_bytes, uint32_t letter, uint64_t child) {
+    if (letter_bytes == 4) { wr32(p, letter); wr64(p + 4, child); }
+    else { wr16(p, (uint16_t)letter); wr64(p + 2, child); }
 }
 
 }  // namespace
@@ -283,30 +350,30 @@ int acx_trie_from_ref_pickle(const void* const* chunks, const size_t* chunk_byte
                       out, n_eow);
 }
 
-int acx_trie_eow_values(const acx_trie_t* t, int64_t** values, int64_t* n) {
+int acx_trie_eow_values(const acx_trie_t* t, int letters_multibyte, int64_t** values, int64_t* n) {
     if (!t || !values || !n) return acx_fail(ACX_E_INVAL, "acx_trie_eow_values: NULL argument");
-    std::vector<int32_t> order;
-    int rc = preorder(t, order);
+    LView v;
+    int rc = letter_view(t, letters_multibyte != 0, v);
     if (rc) return rc;
-    int64_t* v = (int64_t*)malloc(((size_t)t->count + 1) * sizeof(int64_t));
-    if (!v) return acx_fail(ACX_E_NOMEM, "acx_trie_eow_values: out of memory");
+    int64_t* out = (int64_t*)malloc(((size_t)t->count + 1) * sizeof(int64_t));
+    if (!out) return acx_fail(ACX_E_NOMEM, "acx_trie_eow_values: out of memory");
     int64_t k = 0;
-    for (int32_t i : order) if (t->nodes[i].eow && k < t->count) v[k++] = t->nodes[i].value;
-    *values = v; *n = k;
+    for (int32_t i : v.node) if (t->nodes[i].eow && k < t->count) out[k++] = t->nodes[i].value;
+    *values = out; *n = k;
     return ACX_OK;
 }
 
-int acx_trie_to_ref_pickle(const acx_trie_t* t, int values_by_position, size_t chunk_limit, void** buf, size_t** chunk_bytes,
-                           size_t* n_chunks) {
+int acx_trie_to_ref_pickle(const acx_trie_t* t, int values_by_position, size_t chunk_limit, int letter_bytes, int letters_multibyte,
+                           void** buf, size_t** chunk_bytes, size_t* n_chunks) {
     if (!t || !buf || !chunk_bytes || !n_chunks) return acx_fail(ACX_E_INVAL, "acx_trie_to_ref_pickle: NULL argument");
+    if (letter_bytes != 2 && letter_bytes != 4) return acx_fail(ACX_E_INVAL, "acx_trie_to_ref_pickle: letter_bytes must be 2 or 4");
+    const size_t PAIR = letter_bytes == 4 ? PAIR_UCS4 : ::PAIR;
     if (chunk_limit < 8 + REC + 256 * PAIR) chunk_limit = (size_t)16 << 20;                // the reference's array size, src/Automaton_pickle.c:197
-    std::vector<int32_t> order;
-    int rc = preorder(t, order);
+    LView v;
+    int rc = letter_view(t, letters_multibyte != 0, v);
     if (rc) return rc;
-    if (order.empty()) return acx_fail(ACX_E_STATE, "acx_trie_to_ref_pickle: empty automaton (the reference pickles it as Automaton())");
+    if (v.node.empty()) return acx_fail(ACX_E_STATE, "acx_trie_to_ref_pickle: empty automaton (the reference pickles it as Automaton())");
     try {
-        std::vector<int64_t> id(t->nodes.size(), 0);                                      // arena index -> 1-based dump number
-        for (size_t k = 0; k < order.size(); k++) id[order[k]] = (int64_t)k + 1;
         std::vector<uint8_t> data;
         std::vector<size_t> sizes;
         size_t chunk_start = 0;
@@ -314,21 +381,20 @@ int acx_trie_to_ref_pickle(const acx_trie_t* t, int values_by_position, size_t c
         auto open_chunk = [&]() { chunk_start = data.size(); data.resize(data.size() + 8, 0); in_chunk = 0; };
         auto close_chunk = [&]() { wr64(data.data() + chunk_start, (uint64_t)in_chunk); sizes.push_back(data.size() - chunk_start); };
         open_chunk();
-        const bool has_fail = t->kind == ACX_KIND_AHOCORASICK;
-        for (int32_t k : order) {
-            const Node& nd = t->nodes[k];
-            const uint32_t nc = n_children(t, k);
-            const size_t need = REC + (size_t)nc * PAIR;
+        for (size_t k = 0; k < v.node.size(); k++) {
+            const Node& nd = t->nodes[v.node[k]];
+            const size_t nc = v.kids[k].size();
+            const size_t need = REC + nc * PAIR;
             if (in_chunk > 0 && data.size() - chunk_start + need > chunk_limit) { close_chunk(); open_chunk(); }
             const size_t at = data.size();
             data.resize(at + need, 0);
             uint8_t* p = data.data() + at;
             wr64(p, (nd.eow && !values_by_position) ? (uint64_t)nd.value : 0);
-            wr64(p + 8, (has_fail && nd.fail >= 0) ? (uint64_t)id[nd.fail] : 0);
-            wr32(p + 16, nc);
+            wr64(p + 8, fail_id(t, v, k));
+            wr32(p + 16, (uint32_t)nc);
             p[20] = nd.eow;
             p += REC;
-            for (int32_t c = nd.first_child; c >= 0; c = t->nodes[c].next_sibling, p += PAIR) { wr16(p, (uint16_t)(int16_t)(int8_t)t->nodes[c].letter); wr64(p + 2, (uint64_t)id[c]); }
+            for (const auto& kc : v.kids[k]) { write_pair(p, letter_bytes, kc.first, (uint64_t)kc.second + 1); p += PAIR; }
             in_chunk++;
         }
         close_chunk();
@@ -357,11 +423,7 @@ int acx_trie_from_ref_savefile(const void* data, size_t nbytes, int letter_bytes
     const uint64_t n_nodes = rd64(b + nbytes - SAVE_FOOTER);
     meta->n_nodes = (int64_t)n_nodes;
     const bool any = meta->store == ACX_STORE_ANY;
-    // files written HERE with multi-byte letters (the str flavour, KEY_SEQUENCE) carry "UTF8" in the
-    // header's first padding word: bytes-build records whose letters are the bytes of the encoding
-    const bool own_utf8 = rd32(b + 28) == SAVE_UTF8_MARK;
-    if (own_utf8) letter_bytes = 2;
-    const bool reinsert = !own_utf8 && (letter_bytes == 4 || meta->key_type == ACX_KEY_SEQUENCE);
+    const bool reinsert = letter_bytes == 4 || meta->key_type == ACX_KEY_SEQUENCE;
     const size_t PAIR = letter_bytes == 4 ? PAIR_UCS4 : ::PAIR;
     *out = nullptr;
     if (payload_off) *payload_off = nullptr;
@@ -430,45 +492,47 @@ int acx_trie_from_ref_savefile(const void* data, size_t nbytes, int letter_bytes
     return ACX_OK;
 }
 
-int acx_trie_to_ref_savefile(const acx_trie_t* t, int store, int key_type, int letters_utf8, const void* const* payloads,
-                             const size_t* payload_bytes, void** buf, size_t* nbytes) {
+int acx_trie_to_ref_savefile(const acx_trie_t* t, int store, int key_type, int letter_bytes, int letters_multibyte,
+                             const void* const* payloads, const size_t* payload_bytes, void** buf, size_t* nbytes) {
     if (!t || !buf || !nbytes) return acx_fail(ACX_E_INVAL, "acx_trie_to_ref_savefile: NULL argument");
+    if (letter_bytes != 2 && letter_bytes != 4) return acx_fail(ACX_E_INVAL, "acx_trie_to_ref_savefile: letter_bytes must be 2 or 4");
+    const size_t PAIR = letter_bytes == 4 ? PAIR_UCS4 : ::PAIR;
     const bool any = store == ACX_STORE_ANY;
     if (any && t->count > 0 && (!payloads || !payload_bytes)) return acx_fail(ACX_E_INVAL, "acx_trie_to_ref_savefile: STORE_ANY needs the serialized values");
-    std::vector<int32_t> order;
-    int rc = preorder(t, order);
+    LView v;
+    int rc = letter_view(t, letters_multibyte != 0, v);
     if (rc) return rc;
     try {
         std::vector<uint8_t> data(SAVE_HEADER, 0);
         memcpy(data.data(), MAGIC, 16);
         wr32(data.data() + 16, (uint32_t)t->kind); wr32(data.data() + 20, (uint32_t)store); wr32(data.data() + 24, (uint32_t)key_type);
+        // longest_word counts letters in the reference; here it counts bytes of the trie (>= letters): harmless
         wr64(data.data() + 32, (uint64_t)t->count); wr32(data.data() + 40, (uint32_t)t->longest_word);
-        if (letters_utf8) wr32(data.data() + 28, SAVE_UTF8_MARK);
         // node "addresses": any distinct non-zero numbers do (the loader only uses them as keys)
-        auto addr = [](int32_t k) -> uint64_t { return 0x100000000ull + (uint64_t)k * 32u; };
-        const bool has_fail = t->kind == ACX_KIND_AHOCORASICK;
+        auto addr = [](int64_t pos) -> uint64_t { return 0x100000000ull + (uint64_t)pos * 32u; };
         int64_t eow_seen = 0;
-        for (int32_t k : order) {
-            const Node& nd = t->nodes[k];
-            const uint32_t nc = n_children(t, k);
+        for (size_t k = 0; k < v.node.size(); k++) {
+            const Node& nd = t->nodes[v.node[k]];
+            const size_t nc = v.kids[k].size();
             const size_t pl = (any && nd.eow) ? payload_bytes[eow_seen] : 0;
             const size_t at = data.size();
-            data.resize(at + 8 + REC + (size_t)nc * PAIR + pl, 0);
+            data.resize(at + 8 + REC + nc * PAIR + pl, 0);
             uint8_t* p = data.data() + at;
-            wr64(p, addr(k));
+            wr64(p, addr((int64_t)k));
             p += 8;
             wr64(p, nd.eow ? (any ? (uint64_t)pl : (uint64_t)nd.value) : 0);
-            wr64(p + 8, (has_fail && nd.fail >= 0) ? addr(nd.fail) : 0);
-            wr32(p + 16, nc);
+            const uint64_t f = fail_id(t, v, k);
+            wr64(p + 8, f ? addr((int64_t)f - 1) : 0);
+            wr32(p + 16, (uint32_t)nc);
             p[20] = nd.eow;
             p += REC;
-            for (int32_t c = nd.first_child; c >= 0; c = t->nodes[c].next_sibling, p += PAIR) { wr16(p, (uint16_t)(int16_t)(int8_t)t->nodes[c].letter); wr64(p + 2, addr(c)); }
+            for (const auto& kc : v.kids[k]) { write_pair(p, letter_bytes, kc.first, addr(kc.second)); p += PAIR; }
             if (pl) memcpy(p, payloads[eow_seen], pl);
             if (nd.eow) eow_seen++;
         }
         const size_t at = data.size();
         data.resize(at + SAVE_FOOTER);
-        wr64(data.data() + at, (uint64_t)order.size());
+        wr64(data.data() + at, (uint64_t)v.node.size());
         memcpy(data.data() + at + 8, MAGIC, 16);
         uint8_t* ob = (uint8_t*)malloc(data.size());
         if (!ob) return acx_fail(ACX_E_NOMEM, "acx_trie_to_ref_savefile: out of memory");

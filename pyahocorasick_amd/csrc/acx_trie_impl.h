@@ -64,4 +64,16 @@ struct acx_trie {
 };
 
 
+
+// one whole letter below a node: the trie stores a multi-byte letter (UTF-8, continued to 6-byte
+// forms for KEY_SEQUENCE integers) as a chain of byte nodes.  acx_items.cpp.
+struct AcxLetterChild {
+    int32_t node;        // arena index of the letter's last byte node
+    uint8_t len;         // bytes of the letter
+    uint8_t b[6];
+};
+// children of `parent` one letter down, in the order their letters were first added (= arena order)
+void acx_letter_children(const acx_trie* t, int32_t parent, bool multibyte, std::vector<AcxLetterChild>& out);
+uint32_t acx_letter_value(const uint8_t* b, int len);     // decode one stored letter
+
 #endif

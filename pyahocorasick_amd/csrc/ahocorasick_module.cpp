@@ -65,6 +65,11 @@ PyObject* set_acx_error(int rc) {
 #define ACX_UNICODE_BUILD 0
 #endif
 
+// dump layout of this flavour (acx_persist.cpp): uint16 letters (bytes build) or uint32 (unicode build);
+// multi-byte letters (str keys, KEY_SEQUENCE) are decoded on the way out and re-encoded on the way in
+#define ACX_LETTER_BYTES (ACX_UNICODE_BUILD ? 4 : 2)
+inline int letters_multibyte(int key_type) { return (ACX_UNICODE_BUILD || key_type == KEY_SEQUENCE) ? 1 : 0; }
+
 struct Text {
     const uint8_t* data;     // the bytes the engine sees
     Py_ssize_t nbytes;
@@ -291,8 +296,7 @@ AutomatonObject* automaton_alloc(PyTypeObject* type, int store, int key_type) {
 
 // the 7-tuple of __reduce__ (ours or the reference's bytes build): src/Automaton.c:107-149,
 // automaton_unpickle src/Automaton_pickle.c:326-488; parsing in libacx (acx_persist.cpp)
-// own_payload: written by this module with multi-byte letters (tagged "utf8"): node for node
-PyObject* automaton_from_pickle(PyTypeObject* type, PyObject* args, int letter_bytes = 2, bool own_payload = false) {
+PyObject* automaton_from_pickle(PyTypeObject* type, PyObject* args) {
     PyObject *bytes_list = nullptr, *values = nullptr;
     int kind, store, key_type, count, longest;
     if (!PyArg_ParseTuple(args, "OiiiiiO", &bytes_list, &kind, &store, &key_type, &count, &longest, &values)) {
@@ -328,8 +332,8 @@ PyObject* automaton_from_pickle(PyTypeObject* type, PyObject* args, int letter_b
         sizes[(size_t)k] = (size_t)PyBytes_GET_SIZE(b);
     }
     int64_t n_eow = 0;
-    rc = acx_trie_from_ref_pickle(ptrs.data(), sizes.data(), (size_t)n, store == STORE_ANY, longest, own_payload ? 2 : letter_bytes,
-                                  !own_payload && key_type == KEY_SEQUENCE, &a->trie, &n_eow);
+    rc = acx_trie_from_ref_pickle(ptrs.data(), sizes.data(), (size_t)n, store == STORE_ANY, longest, ACX_LETTER_BYTES,
+                                  key_type == KEY_SEQUENCE, &a->trie, &n_eow);
     if (rc) {
         Py_DECREF(a);
         if (rc == ACX_E_NOMEM) return PyErr_NoMemory();
@@ -352,27 +356,8 @@ PyObject* automaton_from_pickle(PyTypeObject* type, PyObject* args, int letter_b
 }
 
 PyObject* automaton_new(PyTypeObject* type, PyObject* args, PyObject*) {
-    // an 8th element "utf8" marks a payload whose letters are multi-byte sequences in the byte trie
-    // (the str build; KEY_SEQUENCE automata): neither reference build mistakes it for its own
-    if (PyTuple_GET_SIZE(args) == 8) {
-        PyObject* tag = PyTuple_GET_ITEM(args, 7);
-        if (!PyUnicode_Check(tag) || PyUnicode_CompareWithASCIIString(tag, "utf8") != 0) {
-            PyErr_SetString(PyExc_ValueError, "Unable to load from pickle.");
-            return nullptr;
-        }
-        PyObject* seven = PyTuple_GetSlice(args, 0, 7);
-        if (!seven) return nullptr;
-        PyObject* r = automaton_from_pickle(type, seven, 2, true);
-        Py_DECREF(seven);
-        return r;
-    }
-#if ACX_UNICODE_BUILD
-    // 7 elements: a pickle written by the reference's unicode build (4-byte letters): its keys are
-    // re-inserted as UTF-8 (acx_persist.cpp)
-    if (PyTuple_GET_SIZE(args) == 7) return automaton_from_pickle(type, args, 4);
-#else
+    // the 7-tuple of __reduce__: a pickle written by the reference build of this flavour, or by this module
     if (PyTuple_GET_SIZE(args) == 7) return automaton_from_pickle(type, args);
-#endif
     int store = STORE_ANY, key_type = KEY_STRING;
     if (!PyArg_ParseTuple(args, "|ii", &store, &key_type)) return nullptr;
     if (!check_store_key(store, key_type)) return nullptr;
@@ -774,7 +759,7 @@ PyObject* automaton_iter_batch(AutomatonObject* a, PyObject* args, PyObject* kw)
 // objects of the keys in dump (pre-order) order: the `values` list of a STORE_ANY pickle
 PyObject* eow_objects(AutomatonObject* a) {
     int64_t* ids = nullptr; int64_t n = 0;
-    int rc = acx_trie_eow_values(a->trie, &ids, &n);
+    int rc = acx_trie_eow_values(a->trie, letters_multibyte(a->key_type), &ids, &n);
     if (rc) return set_acx_error(rc);
     PyObject* list = PyList_New((Py_ssize_t)n);
     for (int64_t k = 0; list && k < n; k++) {
@@ -791,7 +776,7 @@ PyObject* eow_objects(AutomatonObject* a) {
 PyObject* automaton_reduce(AutomatonObject* a, PyObject*) {
     if (acx_trie_num_keys(a->trie) == 0) return Py_BuildValue("O()", Py_TYPE(a));
     void* buf = nullptr; size_t* sizes = nullptr; size_t n = 0;
-    int rc = acx_trie_to_ref_pickle(a->trie, a->store == STORE_ANY, 0, &buf, &sizes, &n);
+    int rc = acx_trie_to_ref_pickle(a->trie, a->store == STORE_ANY, 0, ACX_LETTER_BYTES, letters_multibyte(a->key_type), &buf, &sizes, &n);
     if (rc) return set_acx_error(rc);
     PyObject* chunks = PyList_New((Py_ssize_t)n);
     size_t at = 0;
@@ -806,16 +791,8 @@ PyObject* automaton_reduce(AutomatonObject* a, PyObject*) {
     PyObject* values;
     if (a->store == STORE_ANY) { values = eow_objects(a); if (!values) { Py_DECREF(chunks); return nullptr; } }
     else { values = Py_None; Py_INCREF(values); }
-    if (!ACX_UNICODE_BUILD && a->key_type == KEY_SEQUENCE)          // multi-byte letters: tag it so the reference refuses it
-        return Py_BuildValue("O(NiiiiiNs)", Py_TYPE(a), chunks, acx_trie_kind(a->trie), a->store, a->key_type,
-                             (int)acx_trie_num_keys(a->trie), (int)acx_trie_longest_word(a->trie), values, "utf8");
-#if ACX_UNICODE_BUILD
-    return Py_BuildValue("O(NiiiiiNs)", Py_TYPE(a), chunks, acx_trie_kind(a->trie), a->store, a->key_type,
-                         (int)acx_trie_num_keys(a->trie), (int)acx_trie_longest_word(a->trie), values, "utf8");
-#else
     return Py_BuildValue("O(NiiiiiN)", Py_TYPE(a), chunks, acx_trie_kind(a->trie), a->store, a->key_type,
                          (int)acx_trie_num_keys(a->trie), (int)acx_trie_longest_word(a->trie), values);
-#endif
 }
 
 // argument rules of save()/load(): src/custompickle/pyhelpers.c:4-59
@@ -854,7 +831,7 @@ PyObject* automaton_save(AutomatonObject* a, PyObject* args) {
         Py_DECREF(objs);
     }
     void* buf = nullptr; size_t nbytes = 0;
-    int rc = acx_trie_to_ref_savefile(a->trie, a->store, a->key_type, ACX_UNICODE_BUILD || a->key_type == KEY_SEQUENCE,
+    int rc = acx_trie_to_ref_savefile(a->trie, a->store, a->key_type, ACX_LETTER_BYTES, letters_multibyte(a->key_type),
                                       ptrs.data(), sizes.data(), &buf, &nbytes);
     release();
     if (rc) return set_acx_error(rc);
@@ -892,7 +869,7 @@ PyObject* automaton_match(AutomatonObject* a, PyObject* args) {
 PyObject* automaton_dump(AutomatonObject* a, PyObject*) {
     if (acx_trie_kind(a->trie) == K_EMPTY) Py_RETURN_NONE;
     void* buf = nullptr; size_t* sizes = nullptr; size_t n_chunks = 0;
-    int rc = acx_trie_to_ref_pickle(a->trie, 0, 0, &buf, &sizes, &n_chunks);
+    int rc = acx_trie_to_ref_pickle(a->trie, 0, 0, 2, 0, &buf, &sizes, &n_chunks);
     if (rc) return set_acx_error(rc);
     PyObject *nodes = PyList_New(0), *edges = PyList_New(0), *fail = PyList_New(0);
     bool ok = nodes && edges && fail;

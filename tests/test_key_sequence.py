@@ -115,3 +115,41 @@ def test_sequence_search_matches_the_reference(D):
             A.find_all(h, lambda i, v: found.append([i, v]))
             assert found == it
         assert [[list(m) for m in r] for r in A.iter_batch([tuple(h) for h in case["hays"]])] == case["iter"]
+
+
+def test_sequence_dumps_written_here_load_in_the_reference(D, tmp_path):
+    """KEY_SEQUENCE pickles / save files written here carry the integers as the bytes build's uint16
+    letters: the live reference (subprocess) reads them"""
+    import subprocess
+    ref_dir = os.path.join(os.path.dirname(HERE), "oracle", "_ref")
+    if not any(f.startswith("ahocorasick") and f.endswith(".so") for f in (os.listdir(ref_dir) if os.path.isdir(ref_dir) else [])):
+        pytest.skip("oracle/_ref (the reference itself) is not built")
+    jobs = []
+    for i, case in enumerate(CASES[:9]):
+        A = build(D, case, finalise=True)
+        pkl, sav = str(tmp_path / ("c%d.pkl" % i)), str(tmp_path / ("c%d.sav" % i))
+        open(pkl, "wb").write(pickle.dumps(A, protocol=2))
+        if case["store"] == D.STORE_ANY:
+            A.save(sav, lambda v: pickle.dumps(v, protocol=2))
+        else:
+            A.save(sav)
+        jobs.append({"pkl": pkl, "sav": sav, "hays": case["hays"]})
+    code = r'''
+import sys, json, pickle
+sys.path.insert(0, %r)
+import ahocorasick as R
+assert R.unicode == 0 and "_ref" in R.__file__
+out = []
+for job in json.load(sys.stdin):
+    res = []
+    for x in (pickle.load(open(job["pkl"], "rb")), R.load(job["sav"], pickle.loads)):
+        res.append({"keys": [k.hex() for k in x.keys()], "values": list(x.values()),
+                    "iter": [[list(m) for m in x.iter(tuple(h))] for h in job["hays"]]})
+    out.append(res)
+print(json.dumps(out))
+''' % ref_dir
+    r = subprocess.run([sys.executable, "-c", code], input=json.dumps(jobs), capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr[-2000:]
+    for case, res2 in zip(CASES[:9], json.loads(r.stdout)):
+        for res in res2:
+            assert res["keys"] == case["enum_keys"] and res["values"] == case["enum_values"] and res["iter"] == case["iter"]

@@ -166,3 +166,46 @@ def test_letters_outside_the_bmp_against_the_bytes_build(U):
             sub = h[a:b].encode("utf-8")
             skip = len(h[:a].encode("utf-8"))
             assert list(A.iter(h, a, b)) == [(to_letter[e + skip], v) for e, v in B.iter(sub)]
+
+
+def test_dumps_written_by_the_str_flavour_load_in_the_unicode_reference(U, tmp_path):
+    """pickles and save files written here ARE dumps of the reference's unicode build (4-byte letters,
+    multi-byte letters decoded on the way out): the live reference (subprocess) reads them and
+    enumerates / searches the same"""
+    import subprocess
+    ref_dir = os.path.join(os.path.dirname(HERE), "oracle", "_ref", "unicode")
+    if not os.path.isdir(ref_dir):
+        pytest.skip("oracle/_ref/unicode (the reference's unicode build) is not built")
+    jobs = []
+    for i, case in enumerate(CASES[:9]):
+        A = build(U, case, finalise=True)
+        pkl, sav = str(tmp_path / ("c%d.pkl" % i)), str(tmp_path / ("c%d.sav" % i))
+        open(pkl, "wb").write(pickle.dumps(A, protocol=2))
+        if case["store"] == U.STORE_ANY:
+            A.save(sav, lambda v: pickle.dumps(v, protocol=2))
+        else:
+            A.save(sav)
+        jobs.append({"pkl": pkl, "sav": sav, "hays": [s["hay"] for s in case["searches"]]})
+    code = r'''
+import sys, json, pickle
+sys.path.insert(0, %r)
+import ahocorasick as R
+assert R.unicode == 1 and "_ref" in R.__file__
+out = []
+for job in json.load(sys.stdin):
+    res = []
+    for x in (pickle.load(open(job["pkl"], "rb")), R.load(job["sav"], pickle.loads)):
+        res.append({"keys": list(x.keys()), "values": list(x.values()), "kind": x.kind,
+                    "iter": [[list(m) for m in x.iter(h)] for h in job["hays"]],
+                    "iter_long": [[list(m) for m in x.iter_long(h)] for h in job["hays"]]})
+    out.append(res)
+print(json.dumps(out))
+''' % ref_dir
+    r = subprocess.run([sys.executable, "-c", code], input=json.dumps(jobs), capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr[-2000:]
+    for case, res2 in zip(CASES[:9], json.loads(r.stdout)):
+        for res in res2:
+            assert res["kind"] == U.AHOCORASICK
+            assert res["keys"] == case["iter_keys"] and res["values"] == case["enum"][0][1]
+            assert res["iter"] == [s["iter"] for s in case["searches"]]
+            assert res["iter_long"] == [s["iter_long"] for s in case["searches"]]
