@@ -70,6 +70,7 @@
  */
 #define ACX_ITOP_MAX_LEVELS   15
 #define ACX_ITOP_HDR_WORDS    16
+#define ACX_ITOP_FLAG_NOESC   1u
 
 #define ACX_BLOB_MAGIC        0x31424F4C42584341ull   /* "ACXBLOB1" */
 #define ACX_BLOB_VERSION      1u
@@ -135,7 +136,9 @@ typedef struct acx_blob_header {
     uint32_t itop_cell_bytes; /* 4 or 8 (0 without itop)                                      */
     uint64_t off_itop_ebits; /* uint32 [2^(bD+1)/32]  existence bitmap E, sentinel-indexed (global; slow path) */
     uint64_t off_itop_cells; /* uint32|uint64 [2^(bD)]  child cell of the level-D node with that code   */
-    uint8_t  reserved[ACX_BLOB_HEADER_BYTES - 240];
+    uint32_t itop_flags;     /* bit 0: the depth field of ND4 never escapes once D symbols have been
+                                seen (levels up to D-2 are complete): walk without the probe path */
+    uint8_t  reserved[ACX_BLOB_HEADER_BYTES - 244];
 } acx_blob_header;
 
 #endif

@@ -378,12 +378,12 @@ extern "C" int acx_scan_batch(acx_image_t* img, const acx_scan_params* p, acx_re
         HIP_TRY(acx_launch_chunk_fill(ca, n_items, s));
         if (use_itop) HIP_TRY(acx_launch_walk_itop(wa, r->ck.p, r->ck_first.p + p->n_hay, n_items, img->h.has_escape != 0,
                                                    img->itop_lds, img->h.itop_lds_bytes / 4, img->itop_entry, img->itop_ebits,
-                                                   img->itop_cells, img->tflags, img->h.itop_cell_bytes, (int)((p->variant >> 17) & 0x3f), s));
+                                                   img->itop_cells, img->tflags, img->h.itop_cell_bytes, img->h.itop_flags, (int)((p->variant >> 17) & 0x3f), s));
         else          HIP_TRY(acx_launch_walk_chunks(wa, r->ck.p, r->ck_first.p + p->n_hay, n_items, img->h.has_escape != 0, s));
     } else if (p->mode == ACX_SCAN_ALL) {
         if (use_itop) HIP_TRY(acx_launch_walk_itop(wa, nullptr, nullptr, p->n_hay, img->h.has_escape != 0,
                                                    img->itop_lds, img->h.itop_lds_bytes / 4, img->itop_entry, img->itop_ebits,
-                                                   img->itop_cells, img->tflags, img->h.itop_cell_bytes, (int)((p->variant >> 17) & 0x3f), s));
+                                                   img->itop_cells, img->tflags, img->h.itop_cell_bytes, img->h.itop_flags, (int)((p->variant >> 17) & 0x3f), s));
         else          HIP_TRY(acx_launch_walk_all(wa, img->h.has_escape != 0, p->variant, s));
     } else {
         HIP_TRY(acx_launch_walk_long(wa, p->variant, s));

@@ -87,7 +87,7 @@ hipError_t acx_launch_walk_chunks(const acx_walk_args& a, const acx_chunk_desc* 
 hipError_t acx_launch_walk_itop(const acx_walk_args& a, const acx_chunk_desc* ck, const int64_t* n_chunks_dev,
                                 int64_t n_items_bound, bool has_escape, const uint32_t* itop_lds, uint32_t itop_words,
                                 const uint32_t* itop_entry, const uint32_t* itop_ebits, const void* itop_cells,
-                                const uint32_t* tflags, uint32_t cell_bytes, int tune, hipStream_t s);
+                                const uint32_t* tflags, uint32_t cell_bytes, uint32_t itop_flags, int tune, hipStream_t s);
 // per-haystack match offsets from per-chunk ones: match_off[h] = ck_match_off[ck_first[h]]
 hipError_t acx_launch_hay_offsets(const int64_t* ck_first, const int64_t* ck_match_off, int64_t n_hay,
                                   int64_t* match_off, hipStream_t s);

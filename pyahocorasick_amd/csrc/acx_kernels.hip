@@ -368,7 +368,8 @@ struct ItopCtx {
     const uint8_t*  table_bytes;
     const uint32_t* out_off;
     uint32_t row_bytes, b, D, bD, LD1, has_other, maskD, cs, hmin, pseudo1;
-    uint2* evq;                 // LDS: event queue, slot k of this thread at evq[k * ACX_ITOP_BLOCK + tid]; nullptr = store directly
+    uint2* evq;                 // LDS: event queue, slot k of this thread at evq[k * evq_stride + tid]; nullptr = store directly
+    uint32_t evq_stride;        // = threads per block
 };
 
 // Events are queued per lane in LDS and written out ACX_ITOP_EVQ at a time: a store instruction
@@ -384,6 +385,11 @@ struct ItopLane {
     uint32_t cnt;
     uint32_t pend;   // events waiting in this lane's LDS queue (ILP == 1 only)
     uint2*   ev;
+    // the event of the previous steady-state step, reported one step late: when its entry had to
+    // be fetched (child with outputs, node with several outputs) that load has the whole next
+    // step's gather to complete under instead of putting a second memory latency into the step
+    uint32_t pf_raw, pf_or, pf_idx;
+    bool     pf_on;
 };
 
 // sentinel index of the k-gram made of the last sh/b symbols (sh = 0 -> 1, the root)
@@ -426,7 +432,7 @@ __device__ __forceinline__ void itop_report(uint32_t e, uint32_t c, uint32_t idx
             c = C.out_off[s + 1] - C.out_off[s];
         }
     }
-    if (C.evq) { C.evq[L.pend * ACX_ITOP_BLOCK + threadIdx.x] = make_uint2(idx, e); L.pend++; }
+    if (C.evq) { C.evq[L.pend * C.evq_stride + threadIdx.x] = make_uint2(idx, e); L.pend++; }
     else store_event<true>(L.ev++, idx, e);
     L.cnt += c;
 }
@@ -436,12 +442,22 @@ __device__ __forceinline__ void itop_flush(const ItopCtx& C, ItopLane& L) {
 #pragma unroll
     for (uint32_t k = 0; k < ACX_ITOP_EVQ; k++) {
         if (k < L.pend) {
-            const uint2 v = C.evq[k * ACX_ITOP_BLOCK + threadIdx.x];
+            const uint2 v = C.evq[k * C.evq_stride + threadIdx.x];
             store_event<true>(L.ev + k, v.x, v.y);
         }
     }
     L.ev += L.pend;
     L.pend = 0;
+}
+
+// report the deferred event of the last steady-state step, if any
+template <bool ESCAPE>
+__device__ __forceinline__ void itop_drain(const ItopCtx& C, ItopLane& L) {
+    if (L.pf_on) {
+        const uint32_t e = L.pf_raw | L.pf_or, c = e >> ACX_ENTRY_CNT_SHIFT(ACX_STATE_BITS_NARROW);
+        if (c) itop_report<ESCAPE>(e, c, L.pf_idx, C, L);
+        L.pf_on = false;
+    }
 }
 
 // One input byte, any situation (warm-up, bytes outside the key alphabet, ragged ends, halo).
@@ -494,7 +510,10 @@ __device__ __forceinline__ void itop_step(uint32_t sy, uint32_t idx, bool active
 
 // One input byte for each of the lane's ILP items in the steady state: every lane active and
 // reporting, D symbols seen since the last reset, no byte outside the key alphabet.
-template <bool ESCAPE, bool CELL8, int ILP>
+// The walk is bound by instruction issue as much as by memory latency (four waves per SIMD,
+// DESIGN.md §4), so this is written as straight-line selects: the only branches are the two
+// predicated loads, the report of the previous step's event and (NOESC = false) the probe path.
+template <bool ESCAPE, bool CELL8, bool NOESC, int ILP>
 __device__ __forceinline__ void itop_fast_step(const uint32_t (&sym)[ILP], const uint32_t (&idx)[ILP], const ItopCtx& C, ItopLane (&L)[ILP]) {
     constexpr int SB = ACX_STATE_BITS_NARROW;
     uint32_t hist[ILP], ndw[ILP];
@@ -517,36 +536,49 @@ __device__ __forceinline__ void itop_fast_step(const uint32_t (&sym)[ILP], const
         ndw[q] = C.ND[hist[q] >> 3];
     }
 #pragma unroll
+    for (int q = 0; q < ILP; q++) itop_drain<ESCAPE>(C, L[q]);      // the previous step's event: its fetch is older than this step's load
+#pragma unroll
     for (int q = 0; q < ILP; q++) {
         const uint32_t nib = ndw[q] >> ((hist[q] & 7u) << 2);       // low 4 bits: depth field, output class
+        const uint32_t dq = nib & 3u, oc = (nib >> 2) & 3u;          // (oc = 0 when the depth field escapes)
         const uint32_t e_tab_q = deep[q] ? raw[q].x : 0u;
         const uint2 cw_q = deep[q] ? make_uint2(0u, 0u) : raw[q];
-        uint32_t sh_nd = C.bD - __umul24(C.b, nib & 3u);
-        const uint32_t oc = (nib >> 2) & 3u;                         // (0 when the depth field escapes)
-        const bool stay = deep[q] && (e_tab_q & ACX_ENTRY_STATE_MASK(SB)) >= C.LD1;
+        uint32_t sh_nd = C.bD - __umul24(C.b, dq);
+        const bool stay = (e_tab_q & ACX_ENTRY_STATE_MASK(SB)) >= C.LD1;   // (0 unless deep; LD1 >= 1)
         const uint32_t cell_bits = itop_cell_bits<CELL8>(cw_q);    // 0 unless the lane is at depth D
         const bool kid = (cell_bits >> sym[q]) & 1u;
+        const uint32_t kid_out = (cell_bits >> (16 + sym[q])) & 1u;
         const uint32_t child = itop_cell_first<CELL8>(cw_q) + (uint32_t)__popc(cell_bits & ((1u << sym[q]) - 1u) & 0xFFFFu);
-        const bool esc = (nib & 3u) == 3u && !stay && !kid;          // fell below D - 2: probe (rare by the choice of D)
-        if (esc) sh_nd = itop_resolve_slow(hist[q], C.bD - 3u * C.b, C.Eg, C.b, C.cs);
+        bool esc = false;
+        if (!NOESC) {
+            esc = dq == 3u && !stay && !kid;                         // fell below D - 2: probe (rare by the choice of D)
+            if (esc) sh_nd = itop_resolve_slow(hist[q], C.bD - 3u * C.b, C.Eg, C.b, C.cs);
+        }
+        const bool down = stay | kid;
         L[q].hist = hist[q];
-        L[q].sh = (stay || kid) ? ACX_ITOP_EXPL : sh_nd;
+        L[q].sh = down ? ACX_ITOP_EXPL : sh_nd;
         L[q].st = stay ? e_tab_q : child;                           // read only while sh == EXPL
         // outputs: deep lanes carry them in the entry; a shallow node with exactly one output is
-        // reported as its pseudo state; the rest (child with outputs, several outputs) fetches
-        uint32_t ev_e = deep[q] ? e_tab_q : itop_x(hist[q], sh_nd) + C.pseudo1;
-        uint32_t ev_c = deep[q] ? e_tab_q >> ACX_ENTRY_CNT_SHIFT(SB) : ((!kid && oc == 1u) ? 1u : 0u);
-        const bool fetch = !deep[q] && (kid ? ((cell_bits >> (16 + sym[q])) & 1u) != 0 : (oc == 2u || (esc && sh_nd)));
-        if (fetch) {
-            ev_e = kid ? (child | C.tflags[child]) : C.ient[itop_x(hist[q], sh_nd)];
-            ev_c = ev_e >> ACX_ENTRY_CNT_SHIFT(SB);
-        }
-        if (ev_c) itop_report<ESCAPE>(ev_e, ev_c, idx[q], C, L[q]);
+        // reported as its pseudo state; the rest (child with outputs, several outputs) fetches an
+        // entry, which is consumed by the NEXT step (itop_drain)
+        const uint32_t x = itop_x(hist[q], sh_nd);
+        const bool fetch_k = kid & (kid_out != 0u);
+        const bool fetch_i = !deep[q] & !kid & ((oc == 2u) | (!NOESC && esc && sh_nd != 0u));
+        const uint32_t* fa = fetch_k ? C.tflags + child : C.ient + x;
+        uint32_t ev = deep[q] ? e_tab_q : x + C.pseudo1;
+        if (fetch_k | fetch_i) ev = *fa;                            // NOT used in this step
+        L[q].pf_raw = ev;
+        L[q].pf_or = fetch_k ? child : 0u;
+        L[q].pf_idx = idx[q];
+        L[q].pf_on = fetch_k | fetch_i | (deep[q] ? (e_tab_q >> ACX_ENTRY_CNT_SHIFT(SB)) != 0u : (!kid & (oc == 1u)));
     }
 }
 
-template <bool ESCAPE, bool CELL8, int ILP, int HB, bool HNT>
-__global__ void __launch_bounds__(ACX_ITOP_BLOCK) k_walk_itop(const acx_walk_args a, const acx_chunk_desc* ck,
+#ifndef ACX_ITOP_WPE
+#define ACX_ITOP_WPE 4
+#endif
+template <bool ESCAPE, bool CELL8, bool NOESC, int ILP, int HB>
+__global__ void __launch_bounds__(ACX_ITOP_BLOCK, ACX_ITOP_WPE) k_walk_itop(const acx_walk_args a, const acx_chunk_desc* ck,
                                                              const int64_t* n_chunks_dev, const uint32_t* itop_lds,
                                                              uint32_t itop_words, const uint32_t* itop_entry,
                                                              const uint32_t* itop_ebits, const uint32_t* itop_cells,
@@ -567,6 +599,7 @@ __global__ void __launch_bounds__(ACX_ITOP_BLOCK) k_walk_itop(const acx_walk_arg
     C.pseudo1 = s_mem[4] | (1u << ACX_ENTRY_CNT_SHIFT(ACX_STATE_BITS_NARROW));
     C.ND = s_mem + s_mem[8];
     C.cs = s_mem[11]; C.hmin = s_mem[12];
+    C.evq_stride = blockDim.x;
     C.evq = ILP == 1 ? (uint2*)(s_sym + 256) : nullptr;          // one lane, one item: a private queue fits the rest of LDS
 
     const int lane = threadIdx.x & (ACX_WAVE - 1);
@@ -602,6 +635,7 @@ __global__ void __launch_bounds__(ACX_ITOP_BLOCK) k_walk_itop(const acx_walk_arg
             }
             p[q] = a.hay + d[q].start;
             L[q].st = 0; L[q].sh = 0; L[q].hist = 0; L[q].valid = 0; L[q].cnt = 0; L[q].pend = 0;
+            L[q].pf_raw = 0; L[q].pf_or = 0; L[q].pf_idx = 0; L[q].pf_on = false;
             L[q].ev = a.events + d[q].start + d[q].emit;
             ev0[q] = L[q].ev;
         }
@@ -609,7 +643,7 @@ __global__ void __launch_bounds__(ACX_ITOP_BLOCK) k_walk_itop(const acx_walk_arg
         // The haystack is fetched HB x 16 bytes per lane at a time: lane-per-haystack means every
         // lane streams its own cache line, a line is re-read 16 bytes at a time ~20 us apart and is
         // usually evicted in between; 64 bytes per visit cut those re-fetches.
-        // (Non-temporal loads were measured slower: HNT stays a diagnostic switch.)
+        // (Non-temporal loads were measured slower.)
         for (int j0 = 0;; j0 += 16 * HB) {
             bool more = false;
 #pragma unroll
@@ -621,7 +655,7 @@ __global__ void __launch_bounds__(ACX_ITOP_BLOCK) k_walk_itop(const acx_walk_arg
 #pragma unroll
                 for (int t = 0; t < HB; t++) {
                     wq[q][t] = make_uint4(0, 0, 0, 0);
-                    if (d[q].len - (j0 + 16 * t) > 0) wq[q][t] = load16_guarded<HNT>(p[q] + j0 + 16 * t, limit);
+                    if (d[q].len - (j0 + 16 * t) > 0) wq[q][t] = load16_guarded<false>(p[q] + j0 + 16 * t, limit);
                 }
 #pragma unroll 1
             for (int t = 0; t < HB; t++) {                           // 16-byte blocks; the buffer rotates, indices stay constant
@@ -656,12 +690,14 @@ __global__ void __launch_bounds__(ACX_ITOP_BLOCK) k_walk_itop(const acx_walk_arg
                             uint32_t s1[ILP], ix[ILP];
 #pragma unroll
                             for (int q = 0; q < ILP; q++) { s1[q] = sy[q][i]; ix[q] = (uint32_t)d[q].idx0 + jb + k * 4 + i; }
-                            itop_fast_step<ESCAPE, CELL8, ILP>(s1, ix, C, L);
+                            itop_fast_step<ESCAPE, CELL8, NOESC, ILP>(s1, ix, C, L);
                             if (ILP == 1 && __any(L[0].pend == ACX_ITOP_EVQ)) itop_flush(C, L[0]);
                         }
                     } else {
 #pragma unroll
                         for (int q = 0; q < ILP; q++) {
+                            itop_drain<ESCAPE>(C, L[q]);
+                            if (ILP == 1 && __any(L[q].pend == ACX_ITOP_EVQ)) itop_flush(C, L[q]);
 #pragma unroll 1
                             for (int i = 0; i < 4; i++) {
                                 const int j = jb + k * 4 + i;
@@ -672,6 +708,11 @@ __global__ void __launch_bounds__(ACX_ITOP_BLOCK) k_walk_itop(const acx_walk_arg
                     }
                 }
             }
+        }
+#pragma unroll
+        for (int q = 0; q < ILP; q++) {
+            itop_drain<ESCAPE>(C, L[q]);
+            if (ILP == 1 && __any(L[q].pend == ACX_ITOP_EVQ)) itop_flush(C, L[q]);
         }
         if (ILP == 1) itop_flush(C, L[0]);
 #pragma unroll
@@ -1136,23 +1177,26 @@ hipError_t acx_launch_hay_offsets(const int64_t* ck_first, const int64_t* ck_mat
     return hipGetLastError();
 }
 
-// tune: bits 0-1 = items per lane - 1 (0 or 1); bit 2 = non-temporal instead of cached haystack loads (slower: measured);
+// tune: bits 0-1 = items per lane - 1 (0 or 1); bit 2 unused;
 // bits 4-5 = haystack bytes fetched per lane at a time (0: 64 (32 with 2 items per lane), 1: 16, 2: 32, 3: 64)
 hipError_t acx_launch_walk_itop(const acx_walk_args& a, const acx_chunk_desc* ck, const int64_t* n_chunks_dev,
                                 int64_t n_items_bound, bool has_escape, const uint32_t* itop_lds, uint32_t itop_words,
                                 const uint32_t* itop_entry, const uint32_t* itop_ebits, const void* itop_cells,
-                                const uint32_t* tflags, uint32_t cell_bytes, int tune, hipStream_t s) {
+                                const uint32_t* tflags, uint32_t cell_bytes, uint32_t itop_flags, int tune, hipStream_t s) {
     if (n_items_bound <= 0) return hipSuccess;
     const int ilp = (tune & 3) == 1 ? 2 : 1;
-    const size_t lds_bytes = (size_t)((itop_words + 3) & ~3u) * 4 + 1024 + (ilp == 1 ? (size_t)ACX_ITOP_EVQ * ACX_ITOP_BLOCK * 8 : 0);
-    if (lds_bytes > 160 * 1024 || (cell_bytes != 4 && cell_bytes != 8)) return hipErrorInvalidValue;
-    const bool cached = !((tune >> 2) & 1);
+    const bool noesc = (itop_flags & ACX_ITOP_FLAG_NOESC) != 0;
     int hb = (tune >> 4) & 3;
     hb = hb == 0 ? (ilp == 2 ? 2 : 4) : (hb == 1 ? 1 : (hb == 2 ? 2 : 4));
     if (ilp == 2 && hb == 4) hb = 2;                              // register budget: 1024 threads -> 128 VGPRs
-    const int bpc = lds_bytes * 2 <= 160 * 1024 ? 2 : 1;          // 1024-thread blocks: at most 2 per CU
+    int bpc_env = 0;
     int threads = ACX_ITOP_BLOCK;
+    if (const char* bv = getenv("ACX_ITOP_BPC")) { const int v = atoi(bv); if (v >= 1 && v <= 8) bpc_env = v; }
     if (const char* tv = getenv("ACX_ITOP_THREADS")) { const int v = atoi(tv); if (v == 256 || v == 512 || v == 768) threads = v; }   // occupancy experiments
+    const size_t lds_bytes = (size_t)((itop_words + 3) & ~3u) * 4 + 1024 + (ilp == 1 ? (size_t)ACX_ITOP_EVQ * threads * 8 : 0);
+    if (lds_bytes > 160 * 1024 || (cell_bytes != 4 && cell_bytes != 8)) return hipErrorInvalidValue;
+    int bpc = lds_bytes * 2 <= 160 * 1024 ? 2 : 1;          // 1024-thread blocks: at most 2 per CU
+    if (bpc_env) bpc = bpc_env;
     const int64_t waves_per_block = threads / ACX_WAVE;
     const int64_t n_tasks = (n_items_bound + ACX_WAVE * ilp - 1) / (ACX_WAVE * ilp);
     int64_t blocks = (n_tasks + waves_per_block - 1) / waves_per_block;
@@ -1165,18 +1209,17 @@ hipError_t acx_launch_walk_itop(const acx_walk_args& a, const acx_chunk_desc* ck
                            itop_lds, itop_words, itop_entry, itop_ebits, (const uint32_t*)itop_cells, tflags);
         return hipGetLastError();
     };
-#define ACX_ITOP_CASE(E, C8) \
+#define ACX_ITOP_CASE(E, C8, NE) \
     do { \
-        if (ilp == 2) { \
-            if (hb == 1) return cached ? launch(k_walk_itop<E, C8, 2, 1, false>) : launch(k_walk_itop<E, C8, 2, 1, true>); \
-            return cached ? launch(k_walk_itop<E, C8, 2, 2, false>) : launch(k_walk_itop<E, C8, 2, 2, true>); \
-        } \
-        if (hb == 1) return cached ? launch(k_walk_itop<E, C8, 1, 1, false>) : launch(k_walk_itop<E, C8, 1, 1, true>); \
-        if (hb == 2) return cached ? launch(k_walk_itop<E, C8, 1, 2, false>) : launch(k_walk_itop<E, C8, 1, 2, true>); \
-        return cached ? launch(k_walk_itop<E, C8, 1, 4, false>) : launch(k_walk_itop<E, C8, 1, 4, true>); \
+        if (ilp == 2) return launch(k_walk_itop<E, C8, NE, 2, 2>); \
+        if (hb == 1) return launch(k_walk_itop<E, C8, NE, 1, 1>); \
+        if (hb == 2) return launch(k_walk_itop<E, C8, NE, 1, 2>); \
+        return launch(k_walk_itop<E, C8, NE, 1, 4>); \
     } while (0)
-    if (has_escape) { if (cell_bytes == 8) ACX_ITOP_CASE(true, true); else ACX_ITOP_CASE(true, false); }
-    else            { if (cell_bytes == 8) ACX_ITOP_CASE(false, true); else ACX_ITOP_CASE(false, false); }
+#define ACX_ITOP_CASE2(E, C8) do { if (noesc) ACX_ITOP_CASE(E, C8, true); else ACX_ITOP_CASE(E, C8, false); } while (0)
+    if (has_escape) { if (cell_bytes == 8) ACX_ITOP_CASE2(true, true); else ACX_ITOP_CASE2(true, false); }
+    else            { if (cell_bytes == 8) ACX_ITOP_CASE2(false, true); else ACX_ITOP_CASE2(false, false); }
+#undef ACX_ITOP_CASE2
 #undef ACX_ITOP_CASE
     return hipErrorInvalidValue;
 }

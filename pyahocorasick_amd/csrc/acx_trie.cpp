@@ -296,6 +296,7 @@ int acx_flatten(const acx_trie_t* t, void** blob_out, size_t* nbytes_out) {
                    itop_b * (itop_D + 2) <= 24 && n + ((size_t)2 << (itop_b * (itop_D + 1))) < ((size_t)1 << ACX_STATE_BITS_NARROW) &&
                    (itop_b * (itop_D + 1) < 5 || itop_cost(itop_D + 1) <= budget_words))
                 itop_D++;
+            if (const char* cap = getenv("ACX_ITOP_MAX_D")) { const int v = atoi(cap); if (v > 0 && (uint32_t)v < itop_D) itop_D = (uint32_t)v; }   // tuning hook
             if (itop_b * itop_D < 5) itop_D = 0;      // a trie this small does not need it (ND4 needs whole words)
         }
         if (itop_D > 0) {
@@ -522,6 +523,7 @@ int acx_flatten(const acx_trie_t* t, void** blob_out, size_t* nbytes_out) {
         }
         h.itop_depth = itop_D; h.itop_bits = itop_b; h.itop_lds_bytes = (uint32_t)(itop_lds_words * 4);
         h.itop_cell_bytes = itop_cell_bytes;
+        h.itop_flags = (itop_complete + 2 >= itop_D) ? ACX_ITOP_FLAG_NOESC : 0u;
     }
 
     h.magic = ACX_BLOB_MAGIC;
