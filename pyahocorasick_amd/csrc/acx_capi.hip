@@ -85,6 +85,26 @@ struct acx_image {
     uint32_t* built_table = nullptr;        // table built in HBM (blob without a table section); owned
 };
 
+// The steady-state step of the itop walk uses 32-bit offsets: table and cells from the lower of
+// the two, tflags and the implicit entries likewise.  An image where either pair spans 4 GiB or
+// more walks with the plain kernels instead.
+static void image_check_itop_reach(acx_image* img) {
+    if (!img->itop_lds) return;
+    auto span = [](const void* a, size_t na, const void* b, size_t nb) {
+        const uint8_t* lo = (const uint8_t*)a < (const uint8_t*)b ? (const uint8_t*)a : (const uint8_t*)b;
+        const uint8_t* ea = (const uint8_t*)a + na;
+        const uint8_t* eb = (const uint8_t*)b + nb;
+        return (size_t)((ea > eb ? ea : eb) - lo);
+    };
+    const size_t n = (size_t)img->h.n_states;
+    const size_t tbytes = n * img->h.n_classes * 4 + 16;
+    const size_t cbytes = (size_t)img->h.itop_cell_bytes << (img->h.itop_bits * img->h.itop_depth);
+    const size_t ebytes = (size_t)8 << (img->h.itop_bits * img->h.itop_depth);      // 2^(bD+1) entries
+    const size_t lim = (size_t)1 << 32;
+    if (span(img->table, tbytes, img->itop_cells, cbytes) >= lim || span(img->tflags, n * 4, img->itop_entry, ebytes) >= lim)
+        img->itop_lds = nullptr;
+}
+
 // resolve section pointers; when the blob carries no table, build it in HBM from the sparse
 // form (acx_build.hip).  lvl_host = host copy of the level boundaries, or nullptr to fetch it.
 static int image_resolve(acx_image* img, const uint32_t* lvl_host) {
@@ -101,10 +121,19 @@ static int image_resolve(acx_image* img, const uint32_t* lvl_host) {
     }
     if (img->h.table_in_blob) {
         img->table = (const uint32_t*)(img->dev + img->h.off_table);
+        image_check_itop_reach(img);
         return ACX_OK;
     }
     const size_t tbytes = (size_t)img->h.n_states * img->h.n_classes * 4;
-    HIP_TRY(hipMalloc((void**)&img->built_table, tbytes + 16));      // the itop walk may read one entry past the end
+    // the itop walk addresses the table and the cells with 32-bit offsets from one base (and may
+    // read one entry past the end of the table): a table built here gets its own copy of the cells
+    const size_t cells_at = (tbytes + 16 + 255) & ~(size_t)255;
+    const size_t cbytes = img->itop_lds ? (size_t)img->h.itop_cell_bytes << (img->h.itop_bits * img->h.itop_depth) : 0;
+    HIP_TRY(hipMalloc((void**)&img->built_table, cells_at + cbytes));
+    if (cbytes) {
+        HIP_TRY(hipMemcpy((uint8_t*)img->built_table + cells_at, img->itop_cells, cbytes, hipMemcpyDeviceToDevice));
+        img->itop_cells = (const uint8_t*)img->built_table + cells_at;
+    }
     std::vector<uint32_t> lvl;
     if (!lvl_host) {
         lvl.resize((size_t)img->h.n_levels + 1);
@@ -117,6 +146,7 @@ static int image_resolve(acx_image* img, const uint32_t* lvl_host) {
                                    lvl_host, img->h.n_levels, img->h.n_classes, img->h.state_bits, nullptr));
     HIP_TRY(hipDeviceSynchronize());
     img->table = img->built_table;
+    image_check_itop_reach(img);
     return ACX_OK;
 }
 

@@ -366,16 +366,21 @@ struct ItopCtx {
     const uint32_t* cells;      // global: child cell of the level-D node with a given code
     const uint32_t* tflags;     // global: per-state entry bits
     const uint8_t*  table_bytes;
+    // 32-bit addressing for the steady-state step: table and cells from one base, tflags and the
+    // implicit entries from another (the host guarantees each pair lies within 4 GiB)
+    const uint8_t*  mem;        // min(table, cells)
+    const uint8_t*  aux;        // min(tflags, ient)
+    uint32_t toff, coff;        // table (+ 4 * has_other), cells: byte offsets from mem
+    uint32_t foff, ioff;        // tflags, ient: byte offsets from aux
     const uint32_t* out_off;
     uint32_t row_bytes, b, D, bD, LD1, has_other, maskD, cs, hmin, pseudo1;
-    uint2* evq;                 // LDS: event queue, slot k of this thread at evq[k * evq_stride + tid]; nullptr = store directly
-    uint32_t evq_stride;        // = threads per block
+    uint2* evq;                 // LDS: event queue, slot k of this thread at evq[tid * ACX_ITOP_EVQ + k]; nullptr = store directly
 };
 
-// Events are queued per lane in LDS and written out ACX_ITOP_EVQ at a time: a store instruction
-// occupies the vector-memory pipe like a gather does, whether 3 or 60 of its lanes have something
-// to write, and almost every step has SOME lane with a match.
-#define ACX_ITOP_EVQ 3
+// Events are queued per lane in LDS and written out two at a time: the walk is bound by the
+// rate of L2 requests and a 16-byte store is one request where two 8-byte
+// stores are two; it is also one store instruction for the whole wave instead of one per event.
+#define ACX_ITOP_EVQ 2
 
 struct ItopLane {
     uint32_t st;     // explicit (depth > D): raw entry (low 24 bits = state)
@@ -388,8 +393,7 @@ struct ItopLane {
     // the event of the previous steady-state step, reported one step late: when its entry had to
     // be fetched (child with outputs, node with several outputs) that load has the whole next
     // step's gather to complete under instead of putting a second memory latency into the step
-    uint32_t pf_raw, pf_or, pf_idx;
-    bool     pf_on;
+    uint32_t pf_raw, pf_or, pf_idx;   // (pf_raw | pf_or) has a zero count when there is nothing to report
 };
 
 // sentinel index of the k-gram made of the last sh/b symbols (sh = 0 -> 1, the root)
@@ -432,32 +436,37 @@ __device__ __forceinline__ void itop_report(uint32_t e, uint32_t c, uint32_t idx
             c = C.out_off[s + 1] - C.out_off[s];
         }
     }
-    if (C.evq) { C.evq[L.pend * C.evq_stride + threadIdx.x] = make_uint2(idx, e); L.pend++; }
+    if (C.evq) { C.evq[threadIdx.x * ACX_ITOP_EVQ + L.pend] = make_uint2(idx, e); L.pend++; }
     else store_event<true>(L.ev++, idx, e);
     L.cnt += c;
 }
 
-// write the queued events of every lane of the wave (wave-uniform call)
+// write out the queue of every lane that has a full pair (wave-uniform call)
 __device__ __forceinline__ void itop_flush(const ItopCtx& C, ItopLane& L) {
-#pragma unroll
-    for (uint32_t k = 0; k < ACX_ITOP_EVQ; k++) {
-        if (k < L.pend) {
-            const uint2 v = C.evq[k * C.evq_stride + threadIdx.x];
-            store_event<true>(L.ev + k, v.x, v.y);
-        }
+    if (L.pend == ACX_ITOP_EVQ) {
+        const u32x4 v = *(const u32x4*)(C.evq + threadIdx.x * ACX_ITOP_EVQ);
+        __builtin_nontemporal_store(v, (u32x4_unaligned*)L.ev);
+        L.ev += ACX_ITOP_EVQ;
+        L.pend = 0;
     }
-    L.ev += L.pend;
-    L.pend = 0;
+}
+// ... and what is left at the end of an item
+__device__ __forceinline__ void itop_flush_rest(const ItopCtx& C, ItopLane& L) {
+    itop_flush(C, L);
+    if (L.pend == 1) {
+        const uint2 v = C.evq[threadIdx.x * ACX_ITOP_EVQ];
+        store_event<true>(L.ev, v.x, v.y);
+        L.ev += 1;
+        L.pend = 0;
+    }
 }
 
 // report the deferred event of the last steady-state step, if any
 template <bool ESCAPE>
 __device__ __forceinline__ void itop_drain(const ItopCtx& C, ItopLane& L) {
-    if (L.pf_on) {
-        const uint32_t e = L.pf_raw | L.pf_or, c = e >> ACX_ENTRY_CNT_SHIFT(ACX_STATE_BITS_NARROW);
-        if (c) itop_report<ESCAPE>(e, c, L.pf_idx, C, L);
-        L.pf_on = false;
-    }
+    const uint32_t e = L.pf_raw | L.pf_or, c = e >> ACX_ENTRY_CNT_SHIFT(ACX_STATE_BITS_NARROW);
+    if (c) itop_report<ESCAPE>(e, c, L.pf_idx, C, L);
+    L.pf_raw = 0u; L.pf_or = 0u;
 }
 
 // One input byte, any situation (warm-up, bytes outside the key alphabet, ragged ends, halo).
@@ -516,21 +525,20 @@ __device__ __forceinline__ void itop_step(uint32_t sy, uint32_t idx, bool active
 template <bool ESCAPE, bool CELL8, bool NOESC, int ILP>
 __device__ __forceinline__ void itop_fast_step(const uint32_t (&sym)[ILP], const uint32_t (&idx)[ILP], const ItopCtx& C, ItopLane (&L)[ILP]) {
     constexpr int SB = ACX_STATE_BITS_NARROW;
-    uint32_t hist[ILP], ndw[ILP];
-    uint2 raw[ILP];
+    uint32_t hist[ILP], ndw[ILP], raw0[ILP], raw1[ILP];
     bool deep[ILP];
 #pragma unroll
     for (int q = 0; q < ILP; q++) {                                  // issue: ONE load (table entry | cell) and the ND4 word
         deep[q] = L[q].sh == ACX_ITOP_EXPL;
         const bool atD = L[q].sh == C.bD;
         // the vector-memory pipe charges per instruction, not per active lane:
-        // the two kinds of lanes share one load with per-lane addresses
-        const uint8_t* addr = deep[q] ? C.table_bytes + (__umul24(L[q].st, C.row_bytes) + ((sym[q] + C.has_other) << 2))
-                                      : (const uint8_t*)C.cells + (size_t)L[q].hist * (CELL8 ? 8u : 4u);
-        raw[q] = make_uint2(0u, 0u);
-        if (deep[q] || atD) {
-            if (CELL8) raw[q] = *(const uint2*)addr;
-            else raw[q].x = *(const uint32_t*)addr;
+        // the two kinds of lanes share one load with per-lane 32-bit offsets
+        const uint32_t moff = deep[q] ? __umul24(L[q].st, C.row_bytes) + (sym[q] << 2) + C.toff
+                                      : (L[q].hist << (CELL8 ? 3 : 2)) + C.coff;
+        raw0[q] = 0u; raw1[q] = 0u;
+        if (deep[q] | atD) {
+            if (CELL8) { const uint2 v = *(const uint2*)(C.mem + moff); raw0[q] = v.x; raw1[q] = v.y; }
+            else raw0[q] = *(const uint32_t*)(C.mem + moff);
         }
         hist[q] = ((L[q].hist << C.b) | sym[q]) & C.maskD;
         ndw[q] = C.ND[hist[q] >> 3];
@@ -539,38 +547,45 @@ __device__ __forceinline__ void itop_fast_step(const uint32_t (&sym)[ILP], const
     for (int q = 0; q < ILP; q++) itop_drain<ESCAPE>(C, L[q]);      // the previous step's event: its fetch is older than this step's load
 #pragma unroll
     for (int q = 0; q < ILP; q++) {
-        const uint32_t nib = ndw[q] >> ((hist[q] & 7u) << 2);       // low 4 bits: depth field, output class
-        const uint32_t dq = nib & 3u, oc = (nib >> 2) & 3u;          // (oc = 0 when the depth field escapes)
-        const uint32_t e_tab_q = deep[q] ? raw[q].x : 0u;
-        const uint2 cw_q = deep[q] ? make_uint2(0u, 0u) : raw[q];
+        const uint32_t s4 = hist[q] << 2;                            // (the bit-field extract takes the offset modulo 32)
+        const uint32_t dq = __builtin_amdgcn_ubfe(ndw[q], s4, 2u);  // depth field
+        const uint32_t oc = __builtin_amdgcn_ubfe(ndw[q], s4 + 2u, 2u);   // output class (0 when the depth field escapes)
         uint32_t sh_nd = C.bD - __umul24(C.b, dq);
-        const bool stay = (e_tab_q & ACX_ENTRY_STATE_MASK(SB)) >= C.LD1;   // (0 unless deep; LD1 >= 1)
-        const uint32_t cell_bits = itop_cell_bits<CELL8>(cw_q);    // 0 unless the lane is at depth D
-        const bool kid = (cell_bits >> sym[q]) & 1u;
-        const uint32_t kid_out = (cell_bits >> (16 + sym[q])) & 1u;
-        const uint32_t child = itop_cell_first<CELL8>(cw_q) + (uint32_t)__popc(cell_bits & ((1u << sym[q]) - 1u) & 0xFFFFu);
+        // raw0 is a table entry for a deep lane, a cell for a lane at depth D, 0 otherwise
+        const bool stay = deep[q] & ((raw0[q] & ACX_ENTRY_STATE_MASK(SB)) >= C.LD1);
+        bool kid, fetch_k;
+        uint32_t child;
+        if (CELL8) {
+            const uint32_t t = raw1[q] >> sym[q];
+            kid = !deep[q] & ((t & 1u) != 0u);
+            fetch_k = !deep[q] & ((t & 0x10001u) == 0x10001u);
+            child = raw0[q] + (uint32_t)__popc(__builtin_amdgcn_ubfe(raw1[q], 0u, sym[q]));
+        } else {                                                     // first_child[0..23] | mask[24..27] | outs[28..31]; sym < 4
+            const uint32_t t = raw0[q] >> (sym[q] + 24u);
+            kid = !deep[q] & ((t & 1u) != 0u);
+            fetch_k = !deep[q] & ((t & 0x11u) == 0x11u);
+            child = (raw0[q] & 0xFFFFFFu) + (uint32_t)__popc(__builtin_amdgcn_ubfe(raw0[q], 24u, sym[q]));
+        }
         bool esc = false;
         if (!NOESC) {
-            esc = dq == 3u && !stay && !kid;                         // fell below D - 2: probe (rare by the choice of D)
+            esc = (dq == 3u) & !stay & !kid;                         // fell below D - 2: probe (rare by the choice of D)
             if (esc) sh_nd = itop_resolve_slow(hist[q], C.bD - 3u * C.b, C.Eg, C.b, C.cs);
         }
         const bool down = stay | kid;
         L[q].hist = hist[q];
         L[q].sh = down ? ACX_ITOP_EXPL : sh_nd;
-        L[q].st = stay ? e_tab_q : child;                           // read only while sh == EXPL
+        L[q].st = stay ? raw0[q] : child;                            // read only while sh == EXPL
         // outputs: deep lanes carry them in the entry; a shallow node with exactly one output is
         // reported as its pseudo state; the rest (child with outputs, several outputs) fetches an
-        // entry, which is consumed by the NEXT step (itop_drain)
+        // entry, which is consumed by the NEXT step (itop_drain).  No output: entry 0 (count 0).
         const uint32_t x = itop_x(hist[q], sh_nd);
-        const bool fetch_k = kid & (kid_out != 0u);
         const bool fetch_i = !deep[q] & !kid & ((oc == 2u) | (!NOESC && esc && sh_nd != 0u));
-        const uint32_t* fa = fetch_k ? C.tflags + child : C.ient + x;
-        uint32_t ev = deep[q] ? e_tab_q : x + C.pseudo1;
-        if (fetch_k | fetch_i) ev = *fa;                            // NOT used in this step
+        const uint32_t fo = fetch_k ? (child << 2) + C.foff : (x << 2) + C.ioff;
+        uint32_t ev = deep[q] ? raw0[q] : ((!kid & (oc == 1u)) ? x + C.pseudo1 : 0u);
+        if (fetch_k | fetch_i) ev = *(const uint32_t*)(C.aux + fo);  // NOT used in this step
         L[q].pf_raw = ev;
         L[q].pf_or = fetch_k ? child : 0u;
         L[q].pf_idx = idx[q];
-        L[q].pf_on = fetch_k | fetch_i | (deep[q] ? (e_tab_q >> ACX_ENTRY_CNT_SHIFT(SB)) != 0u : (!kid & (oc == 1u)));
     }
 }
 
@@ -594,12 +609,17 @@ __global__ void __launch_bounds__(ACX_ITOP_BLOCK, ACX_ITOP_WPE) k_walk_itop(cons
     __syncthreads();
 
     ItopCtx C;
+    C.mem = (const uint8_t*)a.table < (const uint8_t*)itop_cells ? (const uint8_t*)a.table : (const uint8_t*)itop_cells;
+    C.toff = (uint32_t)((const uint8_t*)a.table - C.mem) + 4u * s_mem[5];
+    C.coff = (uint32_t)((const uint8_t*)itop_cells - C.mem);
+    C.aux = (const uint8_t*)tflags < (const uint8_t*)itop_entry ? (const uint8_t*)tflags : (const uint8_t*)itop_entry;
+    C.foff = (uint32_t)((const uint8_t*)tflags - C.aux);
+    C.ioff = (uint32_t)((const uint8_t*)itop_entry - C.aux);
     C.ient = itop_entry; C.Eg = itop_ebits; C.cells = itop_cells; C.tflags = tflags; C.table_bytes = (const uint8_t*)a.table; C.out_off = a.out_off; C.row_bytes = a.row_bytes;
     C.b = s_mem[0]; C.D = s_mem[1]; C.bD = s_mem[0] * s_mem[1]; C.LD1 = s_mem[2]; C.has_other = s_mem[5]; C.maskD = s_mem[7];
     C.pseudo1 = s_mem[4] | (1u << ACX_ENTRY_CNT_SHIFT(ACX_STATE_BITS_NARROW));
-    C.ND = s_mem + s_mem[8];
+    C.ND = s_mem + ACX_ITOP_HDR_WORDS;                               // (= s_mem[8]; the launcher checks)
     C.cs = s_mem[11]; C.hmin = s_mem[12];
-    C.evq_stride = blockDim.x;
     C.evq = ILP == 1 ? (uint2*)(s_sym + 256) : nullptr;          // one lane, one item: a private queue fits the rest of LDS
 
     const int lane = threadIdx.x & (ACX_WAVE - 1);
@@ -635,7 +655,7 @@ __global__ void __launch_bounds__(ACX_ITOP_BLOCK, ACX_ITOP_WPE) k_walk_itop(cons
             }
             p[q] = a.hay + d[q].start;
             L[q].st = 0; L[q].sh = 0; L[q].hist = 0; L[q].valid = 0; L[q].cnt = 0; L[q].pend = 0;
-            L[q].pf_raw = 0; L[q].pf_or = 0; L[q].pf_idx = 0; L[q].pf_on = false;
+            L[q].pf_raw = 0; L[q].pf_or = 0; L[q].pf_idx = 0;
             L[q].ev = a.events + d[q].start + d[q].emit;
             ev0[q] = L[q].ev;
         }
@@ -679,7 +699,8 @@ __global__ void __launch_bounds__(ACX_ITOP_BLOCK, ACX_ITOP_WPE) k_walk_itop(cons
                     bool steady = true;
 #pragma unroll
                     for (int q = 0; q < ILP; q++) {
-                        const uint32_t wk = k == 0 ? w[q].x : (k == 1 ? w[q].y : (k == 2 ? w[q].z : w[q].w));
+                        const uint32_t wk = w[q].x;                   // the block rotates one dword per iteration
+                        w[q].x = w[q].y; w[q].y = w[q].z; w[q].z = w[q].w;
 #pragma unroll
                         for (int i = 0; i < 4; i++) sy[q][i] = s_sym[(wk >> (i * 8)) & 0xffu];
                         steady = steady && L[q].valid >= C.D && !((sy[q][0] | sy[q][1] | sy[q][2] | sy[q][3]) & ACX_ITOP_SYM_OTHER);
@@ -714,7 +735,7 @@ __global__ void __launch_bounds__(ACX_ITOP_BLOCK, ACX_ITOP_WPE) k_walk_itop(cons
             itop_drain<ESCAPE>(C, L[q]);
             if (ILP == 1 && __any(L[q].pend == ACX_ITOP_EVQ)) itop_flush(C, L[q]);
         }
-        if (ILP == 1) itop_flush(C, L[0]);
+        if (ILP == 1) itop_flush_rest(C, L[0]);
 #pragma unroll
         for (int q = 0; q < ILP; q++) {
             if (ok[q]) {
