@@ -71,6 +71,7 @@
 #define ACX_ITOP_MAX_LEVELS   15
 #define ACX_ITOP_HDR_WORDS    16
 #define ACX_ITOP_FLAG_NOESC   1u
+#define ACX_ITOP_FLAG_TFLAGS_ID 2u
 
 #define ACX_BLOB_MAGIC        0x31424F4C42584341ull   /* "ACXBLOB1" */
 #define ACX_BLOB_VERSION      1u
@@ -128,7 +129,7 @@ typedef struct acx_blob_header {
     uint64_t off_edge_off;   /* uint32 [n_states + 1]   CSR offsets of the trie edges of s   */
     uint64_t off_edge_cls;   /* uint8  [n_edges]        class of the edge label              */
     uint64_t off_edge_dst;   /* uint32 [n_edges]        child state                          */
-    uint64_t off_tflags;     /* uint32 [n_states]       per-target bits of an entry (EOW, FAILEOW, CNT) */
+    uint64_t off_tflags;     /* uint32 [n_states]       per-target bits of an entry (EOW, FAILEOW, CNT) | s */
     uint64_t off_lvl_first;  /* uint32 [n_levels + 1]   first state id of each depth         */
     uint32_t n_levels;       /* max depth + 1                                                */
     uint32_t n_edges;
@@ -137,7 +138,9 @@ typedef struct acx_blob_header {
     uint64_t off_itop_ebits; /* uint32 [2^(bD+1)/32]  existence bitmap E, sentinel-indexed (global; slow path) */
     uint64_t off_itop_cells; /* uint32|uint64 [2^(bD)]  child cell of the level-D node with that code   */
     uint32_t itop_flags;     /* bit 0: the depth field of ND4 never escapes once D symbols have been
-                                seen (levels up to D-2 are complete): walk without the probe path */
+                                seen (levels up to D-2 are complete): walk without the probe path;
+                                bit 1: tflags[s] carries s in its state field (a whole packed entry):
+                                blobs without it walk with the plain kernels */
     uint8_t  reserved[ACX_BLOB_HEADER_BYTES - 244];
 } acx_blob_header;
 

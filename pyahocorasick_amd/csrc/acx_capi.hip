@@ -101,6 +101,7 @@ static void image_check_itop_reach(acx_image* img) {
     const size_t cbytes = (size_t)img->h.itop_cell_bytes << (img->h.itop_bits * img->h.itop_depth);
     const size_t ebytes = (size_t)8 << (img->h.itop_bits * img->h.itop_depth);      // 2^(bD+1) entries
     const size_t lim = (size_t)1 << 32;
+    if (!(img->h.itop_flags & ACX_ITOP_FLAG_TFLAGS_ID)) { img->itop_lds = nullptr; return; }
     if (span(img->table, tbytes, img->itop_cells, cbytes) >= lim || span(img->tflags, n * 4, img->itop_entry, ebytes) >= lim)
         img->itop_lds = nullptr;
 }

@@ -374,12 +374,13 @@ struct ItopCtx {
     uint32_t foff, ioff;        // tflags, ient: byte offsets from aux
     const uint32_t* out_off;
     uint32_t row_bytes, b, D, bD, LD1, has_other, maskD, cs, hmin, pseudo1;
-    uint2* evq;                 // LDS: event queue, slot k of this thread at evq[tid * ACX_ITOP_EVQ + k]; nullptr = store directly
+    uint32_t wlim;              // deepest shift a warm step may reach: inside the complete levels, above the shortest key
 };
 
-// Events are queued per lane in LDS and written out two at a time: the walk is bound by the
-// rate of L2 requests and a 16-byte store is one request where two 8-byte
-// stores are two; it is also one store instruction for the whole wave instead of one per event.
+// Events are queued per item (two registers pairs) and written out two at a time: the walk is
+// sensitive to the number of write transactions and a 16-byte store is one where
+// two 8-byte stores are two; it is also one store instruction for the whole wave, issued when
+// some lane has a full pair, instead of one per event.
 #define ACX_ITOP_EVQ 2
 
 struct ItopLane {
@@ -388,12 +389,13 @@ struct ItopLane {
     uint32_t hist;   // last D symbols, b bits each
     uint32_t valid;  // symbols seen since the last reset, saturating at D
     uint32_t cnt;
-    uint32_t pend;   // events waiting in this lane's LDS queue (ILP == 1 only)
+    uint32_t pend;   // events waiting in q0, q1
+    uint32_t q0i, q0e, q1i, q1e;
     uint2*   ev;
     // the event of the previous steady-state step, reported one step late: when its entry had to
     // be fetched (child with outputs, node with several outputs) that load has the whole next
     // step's gather to complete under instead of putting a second memory latency into the step
-    uint32_t pf_raw, pf_or, pf_idx;   // (pf_raw | pf_or) has a zero count when there is nothing to report
+    uint32_t pf;     // packed entry (count 0: nothing to report); it ended at the byte before
 };
 
 // sentinel index of the k-gram made of the last sh/b symbols (sh = 0 -> 1, the root)
@@ -436,26 +438,29 @@ __device__ __forceinline__ void itop_report(uint32_t e, uint32_t c, uint32_t idx
             c = C.out_off[s + 1] - C.out_off[s];
         }
     }
-    if (C.evq) { C.evq[threadIdx.x * ACX_ITOP_EVQ + L.pend] = make_uint2(idx, e); L.pend++; }
-    else store_event<true>(L.ev++, idx, e);
+    // selects, no branch: nearly every step of a wave has SOME lane with an event (c = 0: none).
+    // The queue shifts: q1 is the older event of a pair, q0 the newer (or the only) one.
+    const bool has = c != 0u;
+    L.q1i = has ? L.q0i : L.q1i; L.q1e = has ? L.q0e : L.q1e;
+    L.q0i = has ? idx : L.q0i;   L.q0e = has ? e : L.q0e;
+    L.pend += has ? 1u : 0u;
     L.cnt += c;
 }
 
 // write out the queue of every lane that has a full pair (wave-uniform call)
-__device__ __forceinline__ void itop_flush(const ItopCtx& C, ItopLane& L) {
+__device__ __forceinline__ void itop_flush(ItopLane& L) {
     if (L.pend == ACX_ITOP_EVQ) {
-        const u32x4 v = *(const u32x4*)(C.evq + threadIdx.x * ACX_ITOP_EVQ);
+        u32x4 v; v.x = L.q1i; v.y = L.q1e; v.z = L.q0i; v.w = L.q0e;
         __builtin_nontemporal_store(v, (u32x4_unaligned*)L.ev);
         L.ev += ACX_ITOP_EVQ;
         L.pend = 0;
     }
 }
 // ... and what is left at the end of an item
-__device__ __forceinline__ void itop_flush_rest(const ItopCtx& C, ItopLane& L) {
-    itop_flush(C, L);
+__device__ __forceinline__ void itop_flush_rest(ItopLane& L) {
+    itop_flush(L);
     if (L.pend == 1) {
-        const uint2 v = C.evq[threadIdx.x * ACX_ITOP_EVQ];
-        store_event<true>(L.ev, v.x, v.y);
+        store_event<true>(L.ev, L.q0i, L.q0e);
         L.ev += 1;
         L.pend = 0;
     }
@@ -463,10 +468,21 @@ __device__ __forceinline__ void itop_flush_rest(const ItopCtx& C, ItopLane& L) {
 
 // report the deferred event of the last steady-state step, if any
 template <bool ESCAPE>
-__device__ __forceinline__ void itop_drain(const ItopCtx& C, ItopLane& L) {
-    const uint32_t e = L.pf_raw | L.pf_or, c = e >> ACX_ENTRY_CNT_SHIFT(ACX_STATE_BITS_NARROW);
-    if (c) itop_report<ESCAPE>(e, c, L.pf_idx, C, L);
-    L.pf_raw = 0u; L.pf_or = 0u;
+__device__ __forceinline__ void itop_drain(uint32_t idx, const ItopCtx& C, ItopLane& L) {
+    itop_report<ESCAPE>(L.pf, L.pf >> ACX_ENTRY_CNT_SHIFT(ACX_STATE_BITS_NARROW), idx, C, L);
+    L.pf = 0u;
+}
+
+// One input byte right after a reset, while the lane is still inside the complete levels and
+// above the shortest key: it goes one level down, nothing to look up, nothing to report.
+// The caller checks (wave-uniformly) itop_warm_ok for every lane.
+__device__ __forceinline__ bool itop_warm_ok(uint32_t sy, bool active, const ItopCtx& C, const ItopLane& L) {
+    return active && !(sy & ACX_ITOP_SYM_OTHER) && L.sh + C.b <= C.wlim && __umul24(L.valid, C.b) == L.sh;
+}
+__device__ __forceinline__ void itop_warm_step(uint32_t sy, const ItopCtx& C, ItopLane& L) {
+    L.hist = ((L.hist << C.b) | sy) & C.maskD;
+    L.valid += 1u;
+    L.sh += C.b;
 }
 
 // One input byte, any situation (warm-up, bytes outside the key alphabet, ragged ends, halo).
@@ -514,7 +530,7 @@ __device__ __forceinline__ void itop_step(uint32_t sy, uint32_t idx, bool active
         L.sh = other ? 0u : new_sh;
         L.st = new_st;
     }
-    if (emit && (e >> ACX_ENTRY_CNT_SHIFT(SB))) itop_report<ESCAPE>(e, e >> ACX_ENTRY_CNT_SHIFT(SB), idx, C, L);
+    itop_report<ESCAPE>(emit ? e : 0u, emit ? e >> ACX_ENTRY_CNT_SHIFT(SB) : 0u, idx, C, L);
 }
 
 // One input byte for each of the lane's ILP items in the steady state: every lane active and
@@ -523,20 +539,18 @@ __device__ __forceinline__ void itop_step(uint32_t sy, uint32_t idx, bool active
 // DESIGN.md §4), so this is written as straight-line selects: the only branches are the two
 // predicated loads, the report of the previous step's event and (NOESC = false) the probe path.
 template <bool ESCAPE, bool CELL8, bool NOESC, int ILP>
-__device__ __forceinline__ void itop_fast_step(const uint32_t (&sym)[ILP], const uint32_t (&idx)[ILP], const ItopCtx& C, ItopLane (&L)[ILP]) {
+__device__ __forceinline__ void itop_fast_step(const uint32_t (&sym)[ILP], const uint32_t (&idx)[ILP], const uint32_t (&prev)[ILP], const ItopCtx& C, ItopLane (&L)[ILP]) {
     constexpr int SB = ACX_STATE_BITS_NARROW;
     uint32_t hist[ILP], ndw[ILP], raw0[ILP], raw1[ILP];
     bool deep[ILP];
 #pragma unroll
     for (int q = 0; q < ILP; q++) {                                  // issue: ONE load (table entry | cell) and the ND4 word
-        deep[q] = L[q].sh == ACX_ITOP_EXPL;
-        const bool atD = L[q].sh == C.bD;
-        // the vector-memory pipe charges per instruction, not per active lane:
-        // the two kinds of lanes share one load with per-lane 32-bit offsets
+        deep[q] = L[q].sh > C.bD;                                    // (= ACX_ITOP_EXPL)
+        // the two kinds of lanes that need memory share one load with per-lane 32-bit offsets
         const uint32_t moff = deep[q] ? __umul24(L[q].st, C.row_bytes) + (sym[q] << 2) + C.toff
                                       : (L[q].hist << (CELL8 ? 3 : 2)) + C.coff;
         raw0[q] = 0u; raw1[q] = 0u;
-        if (deep[q] | atD) {
+        if (L[q].sh >= C.bD) {                                       // deep, or at depth D
             if (CELL8) { const uint2 v = *(const uint2*)(C.mem + moff); raw0[q] = v.x; raw1[q] = v.y; }
             else raw0[q] = *(const uint32_t*)(C.mem + moff);
         }
@@ -544,27 +558,29 @@ __device__ __forceinline__ void itop_fast_step(const uint32_t (&sym)[ILP], const
         ndw[q] = C.ND[hist[q] >> 3];
     }
 #pragma unroll
-    for (int q = 0; q < ILP; q++) itop_drain<ESCAPE>(C, L[q]);      // the previous step's event: its fetch is older than this step's load
+    for (int q = 0; q < ILP; q++) itop_drain<ESCAPE>(prev[q], C, L[q]);       // the previous step's event: its fetch is older than this step's load
 #pragma unroll
     for (int q = 0; q < ILP; q++) {
         const uint32_t s4 = hist[q] << 2;                            // (the bit-field extract takes the offset modulo 32)
         const uint32_t dq = __builtin_amdgcn_ubfe(ndw[q], s4, 2u);  // depth field
         const uint32_t oc = __builtin_amdgcn_ubfe(ndw[q], s4 + 2u, 2u);   // output class (0 when the depth field escapes)
         uint32_t sh_nd = C.bD - __umul24(C.b, dq);
-        // raw0 is a table entry for a deep lane, a cell for a lane at depth D, 0 otherwise
-        const bool stay = deep[q] & ((raw0[q] & ACX_ENTRY_STATE_MASK(SB)) >= C.LD1);
+        const uint32_t ent = deep[q] ? raw0[q] : 0u;                // table entry of a deep lane
+        const uint32_t cw0 = deep[q] ? 0u : raw0[q];                // cell of a lane at depth D (0: no cell, no child)
+        const bool stay = (ent & ACX_ENTRY_STATE_MASK(SB)) >= C.LD1;
         bool kid, fetch_k;
         uint32_t child;
         if (CELL8) {
-            const uint32_t t = raw1[q] >> sym[q];
-            kid = !deep[q] & ((t & 1u) != 0u);
-            fetch_k = !deep[q] & ((t & 0x10001u) == 0x10001u);
-            child = raw0[q] + (uint32_t)__popc(__builtin_amdgcn_ubfe(raw1[q], 0u, sym[q]));
+            const uint32_t cw1 = deep[q] ? 0u : raw1[q];
+            const uint32_t t = cw1 >> sym[q];
+            kid = (t & 1u) != 0u;
+            fetch_k = (t & 0x10001u) == 0x10001u;
+            child = cw0 + (uint32_t)__popc(__builtin_amdgcn_ubfe(cw1, 0u, sym[q]));
         } else {                                                     // first_child[0..23] | mask[24..27] | outs[28..31]; sym < 4
-            const uint32_t t = raw0[q] >> (sym[q] + 24u);
-            kid = !deep[q] & ((t & 1u) != 0u);
-            fetch_k = !deep[q] & ((t & 0x11u) == 0x11u);
-            child = (raw0[q] & 0xFFFFFFu) + (uint32_t)__popc(__builtin_amdgcn_ubfe(raw0[q], 24u, sym[q]));
+            const uint32_t t = cw0 >> (sym[q] + 24u);
+            kid = (t & 1u) != 0u;
+            fetch_k = (t & 0x11u) == 0x11u;
+            child = (cw0 & 0xFFFFFFu) + (uint32_t)__popc(__builtin_amdgcn_ubfe(cw0, 24u, sym[q]));
         }
         bool esc = false;
         if (!NOESC) {
@@ -574,18 +590,17 @@ __device__ __forceinline__ void itop_fast_step(const uint32_t (&sym)[ILP], const
         const bool down = stay | kid;
         L[q].hist = hist[q];
         L[q].sh = down ? ACX_ITOP_EXPL : sh_nd;
-        L[q].st = stay ? raw0[q] : child;                            // read only while sh == EXPL
+        L[q].st = stay ? ent : child;                                // read only while sh == EXPL
         // outputs: deep lanes carry them in the entry; a shallow node with exactly one output is
-        // reported as its pseudo state; the rest (child with outputs, several outputs) fetches an
-        // entry, which is consumed by the NEXT step (itop_drain).  No output: entry 0 (count 0).
+        // reported as its pseudo state; the rest (child with outputs, several outputs) fetches a
+        // whole entry (tflags[s] carries s), which is consumed by the NEXT step (itop_drain).
+        // No output: entry 0 (count 0).
         const uint32_t x = itop_x(hist[q], sh_nd);
         const bool fetch_i = !deep[q] & !kid & ((oc == 2u) | (!NOESC && esc && sh_nd != 0u));
         const uint32_t fo = fetch_k ? (child << 2) + C.foff : (x << 2) + C.ioff;
-        uint32_t ev = deep[q] ? raw0[q] : ((!kid & (oc == 1u)) ? x + C.pseudo1 : 0u);
+        uint32_t ev = deep[q] ? ent : ((!kid & (oc == 1u)) ? x + C.pseudo1 : 0u);
         if (fetch_k | fetch_i) ev = *(const uint32_t*)(C.aux + fo);  // NOT used in this step
-        L[q].pf_raw = ev;
-        L[q].pf_or = fetch_k ? child : 0u;
-        L[q].pf_idx = idx[q];
+        L[q].pf = ev;
     }
 }
 
@@ -620,7 +635,8 @@ __global__ void __launch_bounds__(ACX_ITOP_BLOCK, ACX_ITOP_WPE) k_walk_itop(cons
     C.pseudo1 = s_mem[4] | (1u << ACX_ENTRY_CNT_SHIFT(ACX_STATE_BITS_NARROW));
     C.ND = s_mem + ACX_ITOP_HDR_WORDS;                               // (= s_mem[8]; the launcher checks)
     C.cs = s_mem[11]; C.hmin = s_mem[12];
-    C.evq = ILP == 1 ? (uint2*)(s_sym + 256) : nullptr;          // one lane, one item: a private queue fits the rest of LDS
+    C.wlim = C.hmin >= C.b ? (C.cs < C.hmin - C.b ? C.cs : C.hmin - C.b) : 0u;
+    if (C.wlim > C.bD - C.b) C.wlim = C.bD - C.b;                      // (a warm step never reaches depth D: valid stays below D)
 
     const int lane = threadIdx.x & (ACX_WAVE - 1);
     const int64_t n_items = ck ? *n_chunks_dev : a.n_hay;
@@ -633,31 +649,30 @@ __global__ void __launch_bounds__(ACX_ITOP_BLOCK, ACX_ITOP_WPE) k_walk_itop(cons
     const uint8_t* limit = a.hay + a.hay_cap;
 
     for (int64_t task = wave0; task < n_tasks; task += n_waves) {
-        int64_t item[ILP];
-        bool ok[ILP];
-        acx_chunk_desc d[ILP];
+        // per item: where it starts, how long it is, where reporting starts, the index of its first
+        // byte (registers are what limits two items per lane: nothing else is kept across the walk)
         const uint8_t* p[ILP];
+        int32_t len[ILP], emit[ILP];
+        uint32_t idx0[ILP];
         ItopLane L[ILP];
-        uint2* ev0[ILP];
 #pragma unroll
         for (int q = 0; q < ILP; q++) {
-            item[q] = task * per_task + q * ACX_WAVE + lane;
-            ok[q] = item[q] < n_items;
-            d[q].start = 0; d[q].emit = 0; d[q].len = 0; d[q].idx0 = 0; d[q].hay = 0; d[q].flags = 0; d[q].pad = 0;
-            if (ok[q]) {
-                if (ck) d[q] = ck[item[q]];
+            const int64_t item = task * per_task + q * ACX_WAVE + lane;
+            int64_t start = 0;
+            len[q] = 0; emit[q] = 0; idx0[q] = 0;
+            if (item < n_items) {
+                if (ck) { const acx_chunk_desc d = ck[item]; start = d.start; len[q] = d.len; emit[q] = d.emit; idx0[q] = (uint32_t)d.idx0; }
                 else {
-                    const int64_t b0 = a.off ? a.off[item[q]] : item[q] * a.stride;
-                    const int64_t e0 = a.off ? a.off[item[q] + 1] : b0 + a.stride;
-                    d[q].start = b0; d[q].len = (int32_t)(e0 - b0); d[q].hay = (int32_t)item[q]; d[q].flags = 3;
-                    d[q].idx0 = a.index_base ? a.index_base[item[q]] : 0;
+                    const int64_t b0 = a.off ? a.off[item] : item * a.stride;
+                    const int64_t e0 = a.off ? a.off[item + 1] : b0 + a.stride;
+                    start = b0; len[q] = (int32_t)(e0 - b0);
+                    idx0[q] = a.index_base ? (uint32_t)a.index_base[item] : 0u;
                 }
             }
-            p[q] = a.hay + d[q].start;
-            L[q].st = 0; L[q].sh = 0; L[q].hist = 0; L[q].valid = 0; L[q].cnt = 0; L[q].pend = 0;
-            L[q].pf_raw = 0; L[q].pf_or = 0; L[q].pf_idx = 0;
-            L[q].ev = a.events + d[q].start + d[q].emit;
-            ev0[q] = L[q].ev;
+            p[q] = a.hay + start;
+            L[q].st = 0; L[q].sh = 0; L[q].hist = 0; L[q].valid = 0; L[q].cnt = 0; L[q].pend = 0; L[q].q0i = 0; L[q].q0e = 0; L[q].q1i = 0; L[q].q1e = 0;
+            L[q].pf = 0;
+            L[q].ev = a.events + start + emit[q];
         }
 
         // The haystack is fetched HB x 16 bytes per lane at a time: lane-per-haystack means every
@@ -667,7 +682,7 @@ __global__ void __launch_bounds__(ACX_ITOP_BLOCK, ACX_ITOP_WPE) k_walk_itop(cons
         for (int j0 = 0;; j0 += 16 * HB) {
             bool more = false;
 #pragma unroll
-            for (int q = 0; q < ILP; q++) more = more || d[q].len - j0 > 0;
+            for (int q = 0; q < ILP; q++) more = more || len[q] - j0 > 0;
             if (!__any(more)) break;
             uint4 wq[ILP][HB];
 #pragma unroll
@@ -675,27 +690,26 @@ __global__ void __launch_bounds__(ACX_ITOP_BLOCK, ACX_ITOP_WPE) k_walk_itop(cons
 #pragma unroll
                 for (int t = 0; t < HB; t++) {
                     wq[q][t] = make_uint4(0, 0, 0, 0);
-                    if (d[q].len - (j0 + 16 * t) > 0) wq[q][t] = load16_guarded<false>(p[q] + j0 + 16 * t, limit);
+                    if (len[q] - (j0 + 16 * t) > 0) wq[q][t] = load16_guarded<false>(p[q] + j0 + 16 * t, limit);
                 }
 #pragma unroll 1
             for (int t = 0; t < HB; t++) {                           // 16-byte blocks; the buffer rotates, indices stay constant
                 const int jb = j0 + 16 * t;
-                bool blk_more = false, full = true;
+                bool blk_more = false;
                 uint4 w[ILP];
 #pragma unroll
                 for (int q = 0; q < ILP; q++) {
-                    blk_more = blk_more || d[q].len - jb > 0;
-                    full = full && d[q].len - jb >= 16 && jb >= d[q].emit;
+                    blk_more = blk_more || len[q] - jb > 0;
                     w[q] = wq[q][0];
 #pragma unroll
                     for (int u = 0; u + 1 < HB; u++) wq[q][u] = wq[q][u + 1];
                 }
                 if (!__any(blk_more)) break;
-                const bool blk_full = __all(full);                   // full block for every item, every step reports
                 // one dword (4 steps) per iteration, NOT unrolled: the instruction cache is shared
 #pragma unroll 1
                 for (int k = 0; k < 4; k++) {
                     uint32_t sy[ILP][4];
+                    const int jk = jb + k * 4;
                     bool steady = true;
 #pragma unroll
                     for (int q = 0; q < ILP; q++) {
@@ -703,27 +717,37 @@ __global__ void __launch_bounds__(ACX_ITOP_BLOCK, ACX_ITOP_WPE) k_walk_itop(cons
                         w[q].x = w[q].y; w[q].y = w[q].z; w[q].z = w[q].w;
 #pragma unroll
                         for (int i = 0; i < 4; i++) sy[q][i] = s_sym[(wk >> (i * 8)) & 0xffu];
-                        steady = steady && L[q].valid >= C.D && !((sy[q][0] | sy[q][1] | sy[q][2] | sy[q][3]) & ACX_ITOP_SYM_OTHER);
+                        // four whole steps, all reported, history full, no byte outside the key alphabet
+                        steady = steady && len[q] - jk >= 4 && jk >= emit[q] && L[q].valid >= C.D &&
+                                 !((sy[q][0] | sy[q][1] | sy[q][2] | sy[q][3]) & ACX_ITOP_SYM_OTHER);
                     }
-                    if (blk_full && __all(steady)) {
+                    if (__all(steady)) {
+                        uint32_t prev[ILP];
+#pragma unroll
+                        for (int q = 0; q < ILP; q++) prev[q] = idx0[q] + (uint32_t)jk - 1u;
 #pragma unroll
                         for (int i = 0; i < 4; i++) {
                             uint32_t s1[ILP], ix[ILP];
 #pragma unroll
-                            for (int q = 0; q < ILP; q++) { s1[q] = sy[q][i]; ix[q] = (uint32_t)d[q].idx0 + jb + k * 4 + i; }
-                            itop_fast_step<ESCAPE, CELL8, NOESC, ILP>(s1, ix, C, L);
-                            if (ILP == 1 && __any(L[0].pend == ACX_ITOP_EVQ)) itop_flush(C, L[0]);
+                            for (int q = 0; q < ILP; q++) { s1[q] = sy[q][i]; ix[q] = idx0[q] + (uint32_t)(jk + i); }
+                            itop_fast_step<ESCAPE, CELL8, NOESC, ILP>(s1, ix, prev, C, L);
+#pragma unroll
+                            for (int q = 0; q < ILP; q++) {
+                                prev[q] = ix[q];
+                                if (__any(L[q].pend == ACX_ITOP_EVQ)) itop_flush(L[q]);
+                            }
                         }
                     } else {
 #pragma unroll
                         for (int q = 0; q < ILP; q++) {
-                            itop_drain<ESCAPE>(C, L[q]);
-                            if (ILP == 1 && __any(L[q].pend == ACX_ITOP_EVQ)) itop_flush(C, L[q]);
+                            itop_drain<ESCAPE>(idx0[q] + (uint32_t)jk - 1u, C, L[q]);     // (a deferred event belongs to the byte before)
+                            if (__any(L[q].pend == ACX_ITOP_EVQ)) itop_flush(L[q]);
 #pragma unroll 1
                             for (int i = 0; i < 4; i++) {
-                                const int j = jb + k * 4 + i;
-                                itop_step<ESCAPE, CELL8>(sy[q][i], (uint32_t)d[q].idx0 + j, j < d[q].len, j < d[q].len && j >= d[q].emit, C, L[q]);
-                                if (ILP == 1 && __any(L[q].pend == ACX_ITOP_EVQ)) itop_flush(C, L[q]);
+                                const int j = jk + i;
+                                if (__all(itop_warm_ok(sy[q][i], j < len[q], C, L[q]))) { itop_warm_step(sy[q][i], C, L[q]); continue; }
+                                itop_step<ESCAPE, CELL8>(sy[q][i], idx0[q] + (uint32_t)j, j < len[q], j < len[q] && j >= emit[q], C, L[q]);
+                                if (__any(L[q].pend == ACX_ITOP_EVQ)) itop_flush(L[q]);
                             }
                         }
                     }
@@ -732,20 +756,22 @@ __global__ void __launch_bounds__(ACX_ITOP_BLOCK, ACX_ITOP_WPE) k_walk_itop(cons
         }
 #pragma unroll
         for (int q = 0; q < ILP; q++) {
-            itop_drain<ESCAPE>(C, L[q]);
-            if (ILP == 1 && __any(L[q].pend == ACX_ITOP_EVQ)) itop_flush(C, L[q]);
+            itop_drain<ESCAPE>(idx0[q] + (uint32_t)len[q] - 1u, C, L[q]);
+            itop_flush_rest(L[q]);
         }
-        if (ILP == 1) itop_flush_rest(C, L[0]);
 #pragma unroll
         for (int q = 0; q < ILP; q++) {
-            if (ok[q]) {
-                a.counts[item[q]] = (int32_t)L[q].cnt;
-                a.nev[item[q]] = (int32_t)(L[q].ev - ev0[q]);
-                if (a.final_state && (d[q].flags & 2)) {
+            const int64_t item = task * per_task + q * ACX_WAVE + lane;
+            if (item < n_items) {
+                a.counts[item] = (int32_t)L[q].cnt;
+                a.nev[item] = (int32_t)(L[q].ev - (a.events + (p[q] - a.hay) + emit[q]));
+                int32_t hay = (int32_t)item, flags = 3;
+                if (ck) { hay = ck[item].hay; flags = ck[item].flags; }
+                if (a.final_state && (flags & 2)) {
                     uint32_t fs = 0;
                     if (L[q].sh == ACX_ITOP_EXPL) fs = L[q].st & ACX_ENTRY_STATE_MASK(ACX_STATE_BITS_NARROW);
                     else if (L[q].sh > 0) fs = itop_entry[itop_x(L[q].hist, L[q].sh)] & ACX_ENTRY_STATE_MASK(ACX_STATE_BITS_NARROW);
-                    a.final_state[d[q].hay] = (int32_t)fs;
+                    a.final_state[hay] = (int32_t)fs;
                 }
             }
         }
@@ -1214,7 +1240,7 @@ hipError_t acx_launch_walk_itop(const acx_walk_args& a, const acx_chunk_desc* ck
     int threads = ACX_ITOP_BLOCK;
     if (const char* bv = getenv("ACX_ITOP_BPC")) { const int v = atoi(bv); if (v >= 1 && v <= 8) bpc_env = v; }
     if (const char* tv = getenv("ACX_ITOP_THREADS")) { const int v = atoi(tv); if (v == 256 || v == 512 || v == 768) threads = v; }   // occupancy experiments
-    const size_t lds_bytes = (size_t)((itop_words + 3) & ~3u) * 4 + 1024 + (ilp == 1 ? (size_t)ACX_ITOP_EVQ * threads * 8 : 0);
+    const size_t lds_bytes = (size_t)((itop_words + 3) & ~3u) * 4 + 1024;
     if (lds_bytes > 160 * 1024 || (cell_bytes != 4 && cell_bytes != 8)) return hipErrorInvalidValue;
     int bpc = lds_bytes * 2 <= 160 * 1024 ? 2 : 1;          // 1024-thread blocks: at most 2 per CU
     if (bpc_env) bpc = bpc_env;

@@ -437,7 +437,7 @@ int acx_flatten(const acx_trie_t* t, void** blob_out, size_t* nbytes_out) {
         uint32_t ne = 0;
         for (size_t i = 0; i < n; i++) {
             edge_off[i] = ne;
-            tfl[i] = tflags[i];
+            tfl[i] = (uint32_t)i | tflags[i];          // (every reader ORs the id in anyway; the itop walk takes the entry whole)
             for (int32_t ch = t->nodes[order[i]].first_child; ch >= 0; ch = t->nodes[ch].next_sibling) {
                 edge_cls[ne] = cls[t->nodes[ch].letter];
                 edge_dst[ne] = (uint32_t)id[ch];
@@ -523,7 +523,7 @@ int acx_flatten(const acx_trie_t* t, void** blob_out, size_t* nbytes_out) {
         }
         h.itop_depth = itop_D; h.itop_bits = itop_b; h.itop_lds_bytes = (uint32_t)(itop_lds_words * 4);
         h.itop_cell_bytes = itop_cell_bytes;
-        h.itop_flags = (itop_complete + 2 >= itop_D) ? ACX_ITOP_FLAG_NOESC : 0u;
+        h.itop_flags = ((itop_complete + 2 >= itop_D) ? ACX_ITOP_FLAG_NOESC : 0u) | ACX_ITOP_FLAG_TFLAGS_ID;
     }
 
     h.magic = ACX_BLOB_MAGIC;

@@ -6,7 +6,7 @@ cp pyahocorasick_amd/libacx.so /tmp/libacx_std.so
 run() {  # lib D threads bpc variants
   if [ "$1" = std ]; then cp /tmp/libacx_std.so pyahocorasick_amd/libacx.so; else cp pyahocorasick_amd/libacx_$1.so pyahocorasick_amd/libacx.so; fi
   echo "== lib=$1 D=$2 threads=$3 bpc=$4" | tee -a $LOG
-  ACX_ITOP_MAX_D=$2 ACX_ITOP_THREADS=$3 ACX_ITOP_BPC=$4 timeout 120 python tools/microbench.py --variants $5 --reps 5 2>&1 | grep -o '"variant": [0-9]*\|"matches_ok": [a-z]*\|"walk": [0-9.]*' | paste - - - | tee -a $LOG
+  ACX_ITOP_MAX_D=$2 ACX_ITOP_THREADS=$3 ACX_ITOP_BPC=$4 timeout 120 python tools/microbench.py --variants $5 --reps 5 2>&1 | grep -o '"variant": [0-9]*\|"matches": [0-9]*\|"walk": [0-9.]*\|"expand": [0-9.]*' | paste - - - - | tee -a $LOG
 }
 while read -r line; do [ -n "$line" ] && run $line; done <<< "$RUNS"
 cp /tmp/libacx_std.so pyahocorasick_amd/libacx.so
