@@ -34,6 +34,7 @@ namespace {
 
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 typedef u32x4 __attribute__((aligned(1))) u32x4_unaligned;
+typedef __attribute__((address_space(1))) u32x4_unaligned g_u32x4_unaligned;   // explicitly global (not flat)
 typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
 
 // NT = non-temporal (`nt` bit on the instruction): the haystack is read once and the events
@@ -49,8 +50,9 @@ __device__ __forceinline__ uint4 load16_unaligned(const uint8_t* p) {
 template <bool NT>
 __device__ __forceinline__ void store_event(uint2* dst, uint32_t idx, uint32_t entry) {
     u32x2 v; v.x = idx; v.y = entry;
-    if (NT) __builtin_nontemporal_store(v, (u32x2*)dst);
-    else    *(u32x2*)dst = v;
+    typedef __attribute__((address_space(1))) u32x2 g_u32x2;        // explicitly global (not flat)
+    if (NT) __builtin_nontemporal_store(v, (g_u32x2*)(uintptr_t)dst);
+    else    *(g_u32x2*)(uintptr_t)dst = v;
 }
 
 // 16 bytes starting at p, never touching bytes at or beyond `limit`
@@ -451,7 +453,7 @@ __device__ __forceinline__ void itop_report(uint32_t e, uint32_t c, uint32_t idx
 __device__ __forceinline__ void itop_flush(ItopLane& L) {
     if (L.pend == ACX_ITOP_EVQ) {
         u32x4 v; v.x = L.q1i; v.y = L.q1e; v.z = L.q0i; v.w = L.q0e;
-        __builtin_nontemporal_store(v, (u32x4_unaligned*)L.ev);
+        __builtin_nontemporal_store(v, (g_u32x4_unaligned*)(uintptr_t)L.ev);
         L.ev += ACX_ITOP_EVQ;
         L.pend = 0;
     }
@@ -584,10 +586,10 @@ __device__ __forceinline__ void itop_fast_step(const uint32_t (&sym)[ILP], const
         }
         bool esc = false;
         if (!NOESC) {
-            esc = (dq == 3u) & !stay & !kid;                         // fell below D - 2: probe (rare by the choice of D)
+            esc = dq == 3u && !stay && !kid;                         // fell below D - 2: probe (rare by the choice of D)
             if (esc) sh_nd = itop_resolve_slow(hist[q], C.bD - 3u * C.b, C.Eg, C.b, C.cs);
         }
-        const bool down = stay | kid;
+        const bool down = stay || kid;
         L[q].hist = hist[q];
         L[q].sh = down ? ACX_ITOP_EXPL : sh_nd;
         L[q].st = stay ? ent : child;                                // read only while sh == EXPL
@@ -596,10 +598,10 @@ __device__ __forceinline__ void itop_fast_step(const uint32_t (&sym)[ILP], const
         // whole entry (tflags[s] carries s), which is consumed by the NEXT step (itop_drain).
         // No output: entry 0 (count 0).
         const uint32_t x = itop_x(hist[q], sh_nd);
-        const bool fetch_i = !deep[q] & !kid & ((oc == 2u) | (!NOESC && esc && sh_nd != 0u));
+        const bool fetch_i = !deep[q] && !kid && (oc == 2u || (!NOESC && esc && sh_nd != 0u));
         const uint32_t fo = fetch_k ? (child << 2) + C.foff : (x << 2) + C.ioff;
-        uint32_t ev = deep[q] ? ent : ((!kid & (oc == 1u)) ? x + C.pseudo1 : 0u);
-        if (fetch_k | fetch_i) ev = *(const uint32_t*)(C.aux + fo);  // NOT used in this step
+        uint32_t ev = deep[q] ? ent : ((!kid && oc == 1u) ? x + C.pseudo1 : 0u);
+        if (fetch_k || fetch_i) ev = *(const uint32_t*)(C.aux + fo);  // NOT used in this step
         L[q].pf = ev;
     }
 }
