@@ -39,9 +39,11 @@
  * (symbol = class - 1): no row, no id.  The walk keeps the rolling history `hist` of the last D
  * symbols and reads, from a table that is resident in LDS, where that history puts it:
  *
- *   ND4[hist]  4 bits:  bits 0..2  delta = D - depth of the longest k-gram node that is a
- *                                  suffix of the history (0..6; 7 = deeper fall: slow path)
- *                       bit  3     that node has outputs (its packed entry is itop_entry[x])
+ *   ND4[hist]  4 bits:  bits 0..1  delta = D - depth of the longest k-gram node that is a
+ *                                  suffix of the history (0, 1, 2; 3 = deeper fall: probe E)
+ *                       bits 2..3  output class of that node: 0 none, 1 exactly one output (it is
+ *                                  reported as pseudo state n_states + x, see first_val), 2 more
+ *                                  (its packed entry is itop_entry[x])
  *
  * ND4 is exact once D symbols have been seen since the last reset (haystack start or a byte
  * that occurs in no key); before that the slow path probes the existence bitmap E level by
@@ -58,7 +60,7 @@
  *
  *   cell, 4 bytes (<= 4 symbols):  first_child[0..23] | child mask[24..27] | child-has-outputs[28..31]
  *   cell, 8 bytes (<= 16 symbols): first_child (low word); child mask[0..15] | child-has-outputs[16..31] (high word)
- *   (a child with outputs takes its packed entry from  id | tflags[id])
+ *   (a child with outputs takes its packed entry from tflags[id], which carries the id)
  *
  * Levels 0..D share ONE index space: node (d, code) is  x = (1 << b*d) | code  ("sentinel bit"
  * above the code; the root is x = 1).  E (global) and itop_entry (global) are indexed by x.
