@@ -146,9 +146,14 @@ __device__ __forceinline__ void block16(const uint4 w, uint32_t idx0, int rem, c
 }
 
 // second __launch_bounds__ argument = waves per SIMD the register allocation must allow:
-// the kernel is bound by memory latency/transactions, so ILP=1 wants all 8 (<= 64 VGPRs).
+// the kernel is bound by memory transactions, not by occupancy (2 blocks per CU are as fast as 8): 6
+// (<= 80 VGPRs) hold the 64 bytes of haystack per visit without spills; 8 (64 VGPRs) spilled 52-60 B and
+// was 3 % slower on config 2, the same elsewhere.
+#ifndef ACX_PLAIN_WPE
+#define ACX_PLAIN_WPE 6
+#endif
 template <int SB, bool ESCAPE, int ILP, bool EVENTS, int NT>
-__global__ void __launch_bounds__(ACX_BLOCK, ILP == 1 ? 8 : 5) k_walk_all(const acx_walk_args a) {
+__global__ void __launch_bounds__(ACX_BLOCK, ILP == 1 ? ACX_PLAIN_WPE : 5) k_walk_all(const acx_walk_args a) {
     __shared__ uint32_t s_cls4[256];
     s_cls4[threadIdx.x] = (uint32_t)a.cls[threadIdx.x] * 4u;   // blockDim.x == 256
     __syncthreads();

@@ -1,5 +1,9 @@
 #!/bin/bash
-# temporary experiment: occupancy sweeps of the itop walk (lib variant, D cap, threads per block, blocks per CU)
+# Occupancy / shape sweeps of the itop walk in ONE gpurun call (profiles/r02_experiments.md).
+# RUNS = lines of "lib D threads blocks_per_CU variants": lib = std (the built libacx.so) or the suffix of an
+# alternative build pyahocorasick_amd/libacx_<lib>.so (e.g. ACX_EXTRA_CFLAGS=-DACX_ITOP_WPE=8); D caps the
+# implicit depth (ACX_ITOP_MAX_D); threads / blocks per CU go to ACX_ITOP_THREADS / ACX_ITOP_BPC.
+# example: RUNS='std 9 1024 1 0,131072' TAG=x bash tools/itop_sweep.sh
 cd "${GRAFT_REPO_ROOT:-/root/repo}"; export TMPDIR=/tmp
 OUT=gpurun_out; mkdir -p $OUT; LOG=$OUT/${TAG:-wpe}.log; : > $LOG
 cp pyahocorasick_amd/libacx.so /tmp/libacx_std.so
