@@ -556,11 +556,12 @@ __device__ __forceinline__ void itop_fast_step(const uint32_t (&sym)[ILP], const
         // the two kinds of lanes that need memory share one load with per-lane 32-bit offsets
         const uint32_t moff = deep[q] ? __umul24(L[q].st, C.row_bytes) + (sym[q] << 2) + C.toff
                                       : (L[q].hist << (CELL8 ? 3 : 2)) + C.coff;
-        raw0[q] = 0u; raw1[q] = 0u;
-        if (L[q].sh >= C.bD) {                                       // deep, or at depth D
-            if (CELL8) { const uint2 v = *(const uint2*)(C.mem + moff); raw0[q] = v.x; raw1[q] = v.y; }
-            else raw0[q] = *(const uint32_t*)(C.mem + moff);
-        }
+        // every lane loads — a lane that needs nothing (depth < D) reads offset 0 and drops it: one
+        // select instead of an exec-mask branch around the load (the walk is bound by issue, §4)
+        const bool need = L[q].sh >= C.bD;                           // deep, or at depth D
+        const uint32_t mo = need ? moff : 0u;
+        if (CELL8) { const uint2 v = *(const uint2*)(C.mem + mo); raw0[q] = need ? v.x : 0u; raw1[q] = need ? v.y : 0u; }
+        else { const uint32_t v = *(const uint32_t*)(C.mem + mo); raw0[q] = need ? v : 0u; raw1[q] = 0u; }
         hist[q] = ((L[q].hist << C.b) | sym[q]) & C.maskD;
         ndw[q] = C.ND[hist[q] >> 3];
     }
