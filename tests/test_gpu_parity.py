@@ -406,6 +406,35 @@ def test_implicit_top_kernel_equals_plain_kernel():
             assert np.array_equal(fin, outs[0][3])
 
 
+def test_blob_without_itop_flags_walks_with_plain_kernels():
+    """a flat image written before `itop_flags` existed (header word 240 = 0: its tflags section carries
+    no state ids, which the itop walk now relies on) still scans correctly: the image falls back to the
+    plain kernels; with the flags it takes the itop walk; both equal the oracle"""
+    import struct
+    rng = np.random.default_rng(35)
+    a = np.frombuffer(b"ACGT", dtype=np.uint8)
+    keys = list({bytes(rng.choice(a, size=int(n)).tobytes()) for n in rng.integers(3, 14, size=4000)})
+    A, O = build_pair(keys)
+    blob = bytearray(A.flat_image_bytes())
+    assert struct.unpack_from("<I", blob, 140)[0] >= 2 and struct.unpack_from("<I", blob, 240)[0] & 2
+    old = bytearray(blob)
+    struct.pack_into("<I", old, 240, 0)                # (the header is not covered by the checksum)
+    n_states = struct.unpack_from("<I", blob, 24)[0]
+    off_tflags = struct.unpack_from("<Q", blob, 192)[0]
+    tf = np.frombuffer(old, dtype=np.uint32, count=n_states, offset=off_tflags)
+    assert np.array_equal(tf & 0xFFFFFF, np.arange(n_states, dtype=np.uint32))      # new blobs: id in the state field
+    n, L = 600, 160
+    reads = np.ascontiguousarray(a[rng.integers(0, 4, size=(n, L))])
+    off = np.arange(n + 1, dtype=np.int64) * L
+    mo, oe, ov = O.batch(reads.tobytes(), off, 0)
+    d_hay = DeviceBuffer.from_numpy(reads.reshape(-1), pad=64)
+    for b in (bytes(blob), bytes(old)):
+        sc = Scanner(Image.from_blob(b))
+        sc.scan(d_hay, n * L, n, stride=L)
+        moff, e, v = sc.fetch()[:3]
+        assert np.array_equal(moff, mo) and np.array_equal(e, oe) and np.array_equal(v, ov)
+
+
 def test_device_built_table_equals_host_built(monkeypatch):
     """blobs without a table section (ACX_FLATTEN_TABLE=device): the table is built in HBM level by
     level from the sparse form and must equal the host-built one bit for bit; scans agree too"""
