@@ -713,11 +713,43 @@ __global__ void __launch_bounds__(ACX_ITOP_BLOCK, ACX_ITOP_WPE) k_walk_itop(cons
                     for (int u = 0; u + 1 < HB; u++) wq[q][u] = wq[q][u + 1];
                 }
                 if (!__any(blk_more)) break;
-                // one dword (4 steps) per iteration, NOT unrolled: the instruction cache is shared
+                // one or two dwords (4 or 8 steps) per iteration, NOT unrolled: the instruction cache is
+                // shared.  The per-group overhead (symbols, the steady-state test, the loop) is a tenth
+                // of all instructions, so two dwords are taken together whenever both are steady.
 #pragma unroll 1
-                for (int k = 0; k < 4; k++) {
+                for (int k = 0; k < 4;) {
                     uint32_t sy[ILP][4];
                     const int jk = jb + k * 4;
+                    if (k <= 2) {                                     // (wave-uniform) a second dword in this block
+                        uint32_t sz[ILP][4];
+                        bool steady8 = true;
+#pragma unroll
+                        for (int q = 0; q < ILP; q++) {
+#pragma unroll
+                            for (int i = 0; i < 4; i++) { sy[q][i] = s_sym[(w[q].x >> (i * 8)) & 0xffu]; sz[q][i] = s_sym[(w[q].y >> (i * 8)) & 0xffu]; }
+                            steady8 = steady8 && len[q] - jk >= 8 && jk >= emit[q] && L[q].valid >= C.D &&
+                                      !((sy[q][0] | sy[q][1] | sy[q][2] | sy[q][3] | sz[q][0] | sz[q][1] | sz[q][2] | sz[q][3]) & ACX_ITOP_SYM_OTHER);
+                        }
+                        if (__all(steady8)) {
+                            uint32_t prev[ILP];
+#pragma unroll
+                            for (int q = 0; q < ILP; q++) { prev[q] = idx0[q] + (uint32_t)jk - 1u; w[q].x = w[q].z; w[q].y = w[q].w; }
+#pragma unroll
+                            for (int i = 0; i < 8; i++) {
+                                uint32_t s1[ILP], ix[ILP];
+#pragma unroll
+                                for (int q = 0; q < ILP; q++) { s1[q] = i < 4 ? sy[q][i & 3] : sz[q][i & 3]; ix[q] = idx0[q] + (uint32_t)(jk + i); }
+                                itop_fast_step<ESCAPE, CELL8, NOESC, ILP>(s1, ix, prev, C, L);
+#pragma unroll
+                                for (int q = 0; q < ILP; q++) {
+                                    prev[q] = ix[q];
+                                    if (__any(L[q].pend == ACX_ITOP_EVQ)) itop_flush(L[q]);
+                                }
+                            }
+                            k += 2;
+                            continue;
+                        }
+                    }
                     bool steady = true;
 #pragma unroll
                     for (int q = 0; q < ILP; q++) {
@@ -729,6 +761,7 @@ __global__ void __launch_bounds__(ACX_ITOP_BLOCK, ACX_ITOP_WPE) k_walk_itop(cons
                         steady = steady && len[q] - jk >= 4 && jk >= emit[q] && L[q].valid >= C.D &&
                                  !((sy[q][0] | sy[q][1] | sy[q][2] | sy[q][3]) & ACX_ITOP_SYM_OTHER);
                     }
+                    k += 1;
                     if (__all(steady)) {
                         uint32_t prev[ILP];
 #pragma unroll
