@@ -1090,7 +1090,9 @@ __global__ void __launch_bounds__(ACX_BLOCK) k_expand_grp(const acx_expand_args 
             const int32_t k = k0 + sub;
             const bool valid = k < n;
             uint2 v = make_uint2(0, 0);
-            if (valid) v = ev[k];
+            // events are read once and records written once: non-temporal, so that they do not push the
+            // table rows and cells of the NEXT walk out of L2 / Infinity Cache (walk 0.54 -> 0.51 ms)
+            if (valid) { const u32x2 t = __builtin_nontemporal_load((const u32x2*)(ev + k)); v = make_uint2(t.x, t.y); }
             const uint32_t s = v.y & state_mask;
             uint32_t c = 0;
             if (valid) {
@@ -1109,10 +1111,10 @@ __global__ void __launch_bounds__(ACX_BLOCK) k_expand_grp(const acx_expand_args 
             const uint32_t total = __shfl(incl, GROUP - 1, GROUP);
             uint2* out = a.matches + out_base + (incl - c);
             if (c == 1) {
-                *out = make_uint2(v.x, (uint32_t)a.first_val[s]);
+                store_event<true>(out, v.x, (uint32_t)a.first_val[s]);
             } else if (c > 1) {
                 const uint32_t o = a.out_off[s];
-                for (uint32_t r = 0; r < c; r++) out[r] = make_uint2(v.x, (uint32_t)a.out_val[o + r]);
+                for (uint32_t r = 0; r < c; r++) store_event<true>(out + r, v.x, (uint32_t)a.out_val[o + r]);
             }
             out_base += total;
         }
