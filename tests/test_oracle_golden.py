@@ -248,3 +248,36 @@ def test_implicit_top_dna_depth():
         for r in reads[:60]:
             got, _ = orc.flat_iter_itop(blob, r.tobytes())
             assert got == O.iter(r.tobytes())
+
+
+def test_itop_flags_of_the_flat_image():
+    """header word 240 (`itop_flags`): bit 0 promises the itop walk that the depth field of ND4 never escapes
+    once D symbols have been seen, i.e. that every level up to D - 2 holds EVERY k-gram over the key
+    alphabet (the kernel instantiation without the probe path relies on it); bit 1 that the tflags section
+    holds whole packed entries (the state id in the state field)"""
+    import struct
+    from pyahocorasick_amd.workloads import dna_workload
+    rng = random.Random(23)
+    cases = [dna_workload(n, 1, 10, seed=9)[0] for n in (40, 300, 3000, 30000)]
+    cases.append([bytes(rng.choice(b"ab") for _ in range(rng.randint(1, 14))) for _ in range(3000)])
+    cases.append([b"acgtacgtacgt", b"ac", b"g"])                       # sparse: nothing is complete beyond level 1
+    both = set()
+    for keys in cases:
+        keys = list(set(bytes(k) for k in keys))
+        A, _ = build_pair(keys)
+        blob = A.flat_image_bytes()
+        D, = struct.unpack_from("<I", blob, 140)
+        if D == 0:
+            continue
+        flags, = struct.unpack_from("<I", blob, 240)
+        n_states, = struct.unpack_from("<I", blob, 24)
+        off_tflags, = struct.unpack_from("<Q", blob, 192)
+        tf = struct.unpack_from("<%dI" % n_states, blob, off_tflags)
+        assert flags & 2 and all((v & 0xFFFFFF) == i for i, v in enumerate(tf))
+        sigma = len(set(b"".join(keys)))
+        complete = 0                                                   # levels 1..complete hold all sigma^d k-grams
+        while len({k[:complete + 1] for k in keys if len(k) > complete}) == sigma ** (complete + 1):
+            complete += 1
+        assert bool(flags & 1) == (complete + 2 >= D), (D, complete, flags)
+        both.add(flags & 1)
+    assert both == {0, 1}
