@@ -171,8 +171,9 @@ def main():
         step(k=k)
     for x in scs:
         x.wait()
-    # per-kernel times from HIP events on each scan's stream (separate passes, same pipelining as the
-    # timed loop: with P > 1 a walk shares the GPU with the previous step's expand, as it does there)
+    # per-kernel times from HIP events on each scan's stream: with P == 1 they are taken again over the
+    # timed steps below (these passes then only warm up); with P > 1 these separate passes, pipelined like
+    # the timed loop (a walk shares the GPU with the previous step's expand, as it does there), are what is reported
     kt = {"walk": [], "scan": [], "expand": [], "total": []}
     for _ in range(3):
         for k in range(P):
@@ -191,10 +192,20 @@ def main():
 
     barrier()
     t0 = time.perf_counter()
-    for k in range(args.steps):
-        step(k=k)
-    for x in scs:
-        x.wait()                                   # every step complete: totals read, records in HBM
+    if P == 1:
+        # the default: one step after the other, each with HIP events around its kernels on the stream
+        # they are launched on -> the per-kernel averages of THIS timed region (roofline.kernel_avg_ms)
+        kt = {k: [] for k in kt}
+        for k in range(args.steps):
+            step(timing=True, k=k)
+            t = sc.timing_ms()
+            for name in kt:
+                kt[name].append(t[name])
+    else:
+        for k in range(args.steps):
+            step(k=k)
+        for x in scs:
+            x.wait()                               # every step complete: totals read, records in HBM
     barrier()
     dt = time.perf_counter() - t0
     if dist is not None:
@@ -223,7 +234,7 @@ def main():
         ms_step = dt / args.steps * 1e3
         H = n * L                                     # haystack bytes per rank per step
         A_bytes = H + 8 * matches + 12 * n            # H + 8*M + 12*N
-        med = {k: float(np.median(v)) for k, v in kt.items()}
+        med = {k: float(np.mean(v)) for k, v in kt.items()}      # averages (P == 1: over the timed steps themselves)
         if args.mode != "iter":
             walk_kernel = "k_walk_long"
         elif image.itop_depth > 0 and not (args.variant >> 16) & 1:
