@@ -40,10 +40,11 @@ def parse():
     ap.add_argument("--read-len", type=int, default=150)
     ap.add_argument("--mode", choices=["iter", "iter_long"], default="iter")
     ap.add_argument("--variant", type=int, default=0)
-    ap.add_argument("--pipeline", type=int, default=1,
-                    help="result objects kept in flight per GPU (ACX_SCAN_ASYNC): the host queues step i+1 while "
-                         "step i runs.  1 (default) = synchronous call per step (on one stream the GPU does not "
-                         "idle between steps either way: measured)")
+    ap.add_argument("--pipeline", type=int, default=2,
+                    help="result objects kept in flight per GPU (ACX_SCAN_ASYNC): the host queues step i+1 and reads "
+                         "the counters of step i-1 while step i runs.  2 (default) = double-buffered results; on ONE "
+                         "stream the kernels of consecutive steps still run strictly one after the other.  "
+                         "1 = one synchronous call per step (the host's bookkeeping between two steps is then exposed)")
     ap.add_argument("--streams", type=int, default=1,
                     help="streams the in-flight steps are spread over.  1 (default): every kernel still runs alone, "
                          "one after the other, so kernel times are standalone durations.  2 lets consecutive steps "
@@ -171,9 +172,9 @@ def main():
         step(k=k)
     for x in scs:
         x.wait()
-    # per-kernel times from HIP events on each scan's stream: with P == 1 they are taken again over the
-    # timed steps below (these passes then only warm up); with P > 1 these separate passes, pipelined like
-    # the timed loop (a walk shares the GPU with the previous step's expand, as it does there), are what is reported
+    # per-kernel times from HIP events on each scan's stream: on one stream they are taken again over the
+    # timed steps below (these passes then only warm up); with several streams these separate passes, pipelined
+    # like the timed loop (a walk shares the GPU with the previous step's expand, as it does there), are reported
     kt = {"walk": [], "scan": [], "expand": [], "total": []}
     for _ in range(3):
         for k in range(P):
@@ -192,20 +193,30 @@ def main():
 
     barrier()
     t0 = time.perf_counter()
-    if P == 1:
-        # the default: one step after the other, each with HIP events around its kernels on the stream
-        # they are launched on -> the per-kernel averages of THIS timed region (roofline.kernel_avg_ms)
-        kt = {k: [] for k in kt}
+    if S == 1:
+        # the default: every kernel runs alone on ONE stream, each timed step with HIP events around its kernels
+        # on that stream -> the per-kernel averages of THIS timed region (roofline.kernel_avg_ms).  A result
+        # object's times are read when it is about to be reused, i.e. while a later step runs.
+        # Only the dominant kernel is bracketed inside the timed steps (timing = 2): every event between two
+        # kernels costs ~5 us of idle GPU; the scan and expand averages stay those of the passes above.
+        pre = {k: float(np.mean(v)) for k, v in kt.items()}
+        kt = {"walk": []}
+
+        def collect(x):
+            x.wait()
+            kt["walk"].append(x.timing_ms()["walk"])
+
         for k in range(args.steps):
-            step(timing=True, k=k)
-            t = sc.timing_ms()
-            for name in kt:
-                kt[name].append(t[name])
+            if k >= P:
+                collect(scs[k % P])
+            step(timing=2, k=k)
+        for k in range(max(0, args.steps - P), args.steps):
+            collect(scs[k % P])                    # every step complete: totals read, records in HBM
     else:
         for k in range(args.steps):
             step(k=k)
         for x in scs:
-            x.wait()                               # every step complete: totals read, records in HBM
+            x.wait()
     barrier()
     dt = time.perf_counter() - t0
     if dist is not None:
@@ -234,7 +245,9 @@ def main():
         ms_step = dt / args.steps * 1e3
         H = n * L                                     # haystack bytes per rank per step
         A_bytes = H + 8 * matches + 12 * n            # H + 8*M + 12*N
-        med = {k: float(np.mean(v)) for k, v in kt.items()}      # averages (P == 1: over the timed steps themselves)
+        med = {k: float(np.mean(v)) for k, v in kt.items()}      # averages (one stream: the walk over the timed steps themselves)
+        if "scan" not in med:
+            med.update({"scan": pre["scan"], "expand": pre["expand"], "total": med["walk"] + pre["scan"] + pre["expand"]})
         if args.mode != "iter":
             walk_kernel = "k_walk_long"
         elif image.itop_depth > 0 and not (args.variant >> 16) & 1:

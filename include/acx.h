@@ -211,7 +211,8 @@ typedef struct acx_scan_params {
     const int32_t* dev_init_state;
     const int32_t* dev_index_base;
     int32_t  want_final_state; /* 1 => fill final_state */
-    int32_t  timing;           /* 1 => record HIP events around each kernel */
+    int32_t  timing;           /* 1 => record HIP events around each kernel; 2 => around the walk only
+                                  (an event between two kernels costs a few microseconds of idle GPU) */
     int32_t  variant;          /* 0 = default; >0 selects an alternative kernel (bench/tuning) */
     int32_t  flags;            /* ACX_SCAN_ASYNC or 0 */
 } acx_scan_params;
@@ -238,7 +239,8 @@ const int32_t*     acx_result_final_state_dev(acx_result_t* r);
 int  acx_result_fetch_host(acx_result_t* r, const int64_t** off, const acx_match_t** matches,
                            const int32_t** final_state);
 /* kernel timing of the last scan (ms): walk, scan(prefix sum), expand, total GPU span.
- * Needs params.timing = 1.  Measured with hipEvents on the scan's stream. */
+ * Needs params.timing = 1 (or 2: then only walk_ms is measured, scan_ms and expand_ms are 0 and
+ * total_ms = walk_ms).  Measured with hipEvents on the scan's stream. */
 int  acx_result_timing(acx_result_t* r, float* walk_ms, float* scan_ms, float* expand_ms, float* total_ms);
 void acx_result_free(acx_result_t* r);
 

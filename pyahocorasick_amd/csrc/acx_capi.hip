@@ -254,7 +254,9 @@ struct acx_result {
     bool host_valid = false;
     hipStream_t stream = nullptr;
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+    hipEvent_t done = nullptr;  // recorded after the last operation of a scan: completion of THIS result, not of the whole stream
     bool timed = false;
+    bool timed_all = false;     // events around scan and expand too (params.timing == 1)
     float t_walk = 0, t_scan = 0, t_expand = 0, t_total = 0;
     // ACX_SCAN_ASYNC: kernels queued, not yet completed (see result_complete)
     bool pending = false;
@@ -268,6 +270,7 @@ struct acx_result {
         events.release(); matches.release(); h_off.release(); h_matches.release(); h_final.release(); h_total.release();
         in_hay.release(); in_off.release(); in_init.release(); in_base.release();
         for (auto& e : ev) if (e) (void)hipEventDestroy(e);
+        if (done) (void)hipEventDestroy(done);
     }
 };
 
@@ -277,13 +280,17 @@ static int result_complete(acx_result* r) {
     if (!r || !r->pending) return ACX_OK;
     r->pending = false;
     hipStream_t s = r->stream;
-    HIP_TRY(hipStreamSynchronize(s));
+    // wait for this scan only: later scans queued on the same stream (other result objects) keep running
+    if (r->done) HIP_TRY(hipEventSynchronize(r->done)); else HIP_TRY(hipStreamSynchronize(s));
     r->total = r->h_total.p[0];
     if (r->timed) {
         HIP_TRY(hipEventElapsedTime(&r->t_walk, r->ev[0], r->ev[1]));
-        HIP_TRY(hipEventElapsedTime(&r->t_scan, r->ev[1], r->ev[2]));
-        HIP_TRY(hipEventElapsedTime(&r->t_expand, r->ev[2], r->ev[3]));
-        HIP_TRY(hipEventElapsedTime(&r->t_total, r->ev[0], r->ev[3]));
+        r->t_scan = 0.f; r->t_expand = 0.f; r->t_total = r->t_walk;
+        if (r->timed_all) {
+            HIP_TRY(hipEventElapsedTime(&r->t_scan, r->ev[1], r->ev[2]));
+            HIP_TRY(hipEventElapsedTime(&r->t_expand, r->ev[2], r->ev[3]));
+            HIP_TRY(hipEventElapsedTime(&r->t_total, r->ev[0], r->ev[3]));
+        }
     }
     if (r->total > (int64_t)r->matches.cap) {
         // first call / larger batch than ever seen: grow and run expand again
@@ -291,11 +298,11 @@ static int result_complete(acx_result* r) {
         if ((rc = r->matches.ensure((size_t)r->total))) return rc;
         acx_expand_args ea = r->pend_ea;
         ea.matches = r->matches.p; ea.capacity = (int64_t)r->matches.cap;
-        if (r->timed) HIP_TRY(hipEventRecord(r->ev[2], s));
+        if (r->timed_all) HIP_TRY(hipEventRecord(r->ev[2], s));
         HIP_TRY(acx_launch_expand(ea, r->pend_variant, s));
-        if (r->timed) HIP_TRY(hipEventRecord(r->ev[3], s));
+        if (r->timed_all) HIP_TRY(hipEventRecord(r->ev[3], s));
         HIP_TRY(hipStreamSynchronize(s));
-        if (r->timed) {
+        if (r->timed_all) {
             HIP_TRY(hipEventElapsedTime(&r->t_expand, r->ev[2], r->ev[3]));
             r->t_total = r->t_walk + r->t_scan + r->t_expand;
         }
@@ -341,7 +348,7 @@ extern "C" int acx_scan_batch(acx_image_t* img, const acx_scan_params* p, acx_re
     }
     if (r->pending) { int rcw = result_complete(r); if (rcw) return rcw; }     // still in flight on its old stream
     r->stream = s; r->n_hay = p->n_hay; r->total = 0; r->host_valid = false;
-    r->has_final = p->want_final_state != 0; r->timed = p->timing != 0;
+    r->has_final = p->want_final_state != 0; r->timed = p->timing != 0; r->timed_all = p->timing == 1;
 
     const size_t n = (size_t)p->n_hay;
     int rc;
@@ -421,7 +428,7 @@ extern "C" int acx_scan_batch(acx_image_t* img, const acx_scan_params* p, acx_re
     }
     if (r->timed) HIP_TRY(hipEventRecord(r->ev[1], s));
     HIP_TRY(acx_launch_scan(r->counts.p, n_items, item_match_off, r->partials.p, s));
-    if (r->timed) HIP_TRY(hipEventRecord(r->ev[2], s));
+    if (r->timed_all) HIP_TRY(hipEventRecord(r->ev[2], s));
 
     acx_expand_args ea;
     ea.off = p->dev_off; ea.stride = p->stride; ea.n_hay = n_items; ea.nev = r->nev.p; ea.events = r->events.p;
@@ -433,8 +440,10 @@ extern "C" int acx_scan_batch(acx_image_t* img, const acx_scan_params* p, acx_re
     ea.matches = r->matches.p; ea.capacity = (int64_t)r->matches.cap;
     HIP_TRY(acx_launch_expand(ea, p->variant, s));
     if (chunked) HIP_TRY(acx_launch_hay_offsets(r->ck_first.p, r->ck_match_off.p, p->n_hay, r->match_off.p, s));
-    if (r->timed) HIP_TRY(hipEventRecord(r->ev[3], s));
+    if (r->timed_all) HIP_TRY(hipEventRecord(r->ev[3], s));
     HIP_TRY(hipMemcpyAsync(r->h_total.p, item_match_off + n_items, sizeof(int64_t), hipMemcpyDeviceToHost, s));
+    if (!r->done) HIP_TRY(hipEventCreateWithFlags(&r->done, hipEventDisableTiming));
+    HIP_TRY(hipEventRecord(r->done, s));
     r->pending = true; r->pend_ea = ea; r->pend_variant = p->variant;
     if (async) return ACX_OK;
     return result_complete(r);

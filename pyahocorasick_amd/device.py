@@ -152,7 +152,7 @@ class Scanner:
         p.dev_init_state = _addr(dev_init_state)
         p.dev_index_base = _addr(dev_index_base)
         p.want_final_state = 1 if want_final_state else 0
-        p.timing = 1 if timing else 0
+        p.timing = 2 if (timing == 2 and timing is not True) else (1 if timing else 0)   # 2: events around the walk only
         p.variant = int(variant)
         p.flags = ACX_SCAN_ASYNC if asynchronous else 0
         check(lib().acx_scan_batch(self.image.handle, C.byref(p), C.byref(self._res), _addr(stream)))
