@@ -216,10 +216,12 @@ typedef struct acx_scan_params {
     int32_t  variant;          /* 0 = default; >0 selects an alternative kernel (bench/tuning) */
     int32_t  flags;            /* ACX_SCAN_ASYNC or 0 */
 } acx_scan_params;
-/* Return as soon as the kernels are queued on `stream`.  The result completes (stream sync,
- * total read, expand re-run if the match buffer was too small) in acx_result_wait or in the
- * first accessor.  Lets one host thread keep several batches in flight on several streams:
- * the expand of batch i then overlaps the walk of batch i+1 (bench.py --pipeline). */
+/* Return as soon as the kernels are queued on `stream`.  The result completes (wait for THIS
+ * scan's completion event — later scans queued on the same stream keep running —, total read,
+ * expand re-run if the match buffer was too small) in acx_result_wait or in the first accessor.
+ * Lets one host thread keep several batches in flight, on one stream (the host's bookkeeping
+ * overlaps the next batch) or on several (the expand of batch i then overlaps the walk of
+ * batch i+1): bench.py --pipeline / --streams. */
 enum { ACX_SCAN_ASYNC = 1 };
 
 typedef struct acx_result acx_result_t;
