@@ -543,10 +543,11 @@ __device__ __forceinline__ void itop_step(uint32_t sy, uint32_t idx, bool active
 // One input byte for each of the lane's ILP items in the steady state: every lane active and
 // reporting, D symbols seen since the last reset, no byte outside the key alphabet.
 // The walk is bound by instruction issue as much as by memory latency (four waves per SIMD,
-// DESIGN.md §4), so this is written as straight-line selects: the only branches are the two
-// predicated loads, the report of the previous step's event and (NOESC = false) the probe path.
+// DESIGN.md §4), so this is written as straight-line selects: the only branches are the deferred
+// entry fetch, the flush of a full event pair and (NOESC = false) the probe path.
+// prev = end index of the byte before (where the deferred event of the last step belongs).
 template <bool ESCAPE, bool CELL8, bool NOESC, int ILP>
-__device__ __forceinline__ void itop_fast_step(const uint32_t (&sym)[ILP], const uint32_t (&idx)[ILP], const uint32_t (&prev)[ILP], const ItopCtx& C, ItopLane (&L)[ILP]) {
+__device__ __forceinline__ void itop_fast_step(const uint32_t (&sym)[ILP], const uint32_t (&prev)[ILP], const ItopCtx& C, ItopLane (&L)[ILP]) {
     constexpr int SB = ACX_STATE_BITS_NARROW;
     uint32_t hist[ILP], ndw[ILP], raw0[ILP], raw1[ILP];
     bool deep[ILP];
@@ -739,7 +740,7 @@ __global__ void __launch_bounds__(ACX_ITOP_BLOCK, ACX_ITOP_WPE) k_walk_itop(cons
                                 uint32_t s1[ILP], ix[ILP];
 #pragma unroll
                                 for (int q = 0; q < ILP; q++) { s1[q] = i < 4 ? sy[q][i & 3] : sz[q][i & 3]; ix[q] = idx0[q] + (uint32_t)(jk + i); }
-                                itop_fast_step<ESCAPE, CELL8, NOESC, ILP>(s1, ix, prev, C, L);
+                                itop_fast_step<ESCAPE, CELL8, NOESC, ILP>(s1, prev, C, L);
 #pragma unroll
                                 for (int q = 0; q < ILP; q++) {
                                     prev[q] = ix[q];
@@ -771,7 +772,7 @@ __global__ void __launch_bounds__(ACX_ITOP_BLOCK, ACX_ITOP_WPE) k_walk_itop(cons
                             uint32_t s1[ILP], ix[ILP];
 #pragma unroll
                             for (int q = 0; q < ILP; q++) { s1[q] = sy[q][i]; ix[q] = idx0[q] + (uint32_t)(jk + i); }
-                            itop_fast_step<ESCAPE, CELL8, NOESC, ILP>(s1, ix, prev, C, L);
+                            itop_fast_step<ESCAPE, CELL8, NOESC, ILP>(s1, prev, C, L);
 #pragma unroll
                             for (int q = 0; q < ILP; q++) {
                                 prev[q] = ix[q];
