@@ -243,6 +243,19 @@ def test_device_resident_fixed_stride_entry_point():
     assert sc.scan(d_hay, n * L, n, stride=L, timing=True) == total
     off2, e2, v2, _ = sc.fetch()
     assert np.array_equal(off2, mo) and np.array_equal(e2, oe) and np.array_equal(v2, ov)
+    # timing = 2 brackets the walk only (what bench.py does inside its timed steps)
+    assert sc.scan(d_hay, n * L, n, stride=L, timing=2) == total
+    t2 = sc.timing_ms()
+    assert t2["walk"] > 0 and t2["scan"] == 0 and t2["expand"] == 0 and t2["total"] == t2["walk"]
+    # several results in flight on ONE stream: waiting for the first does not need the second to finish first,
+    # and both are right
+    sc_b = Scanner(img)
+    sc.scan(d_hay, n * L, n, stride=L, timing=2, asynchronous=True)
+    sc_b.scan(d_hay, n * L, n, stride=L, timing=2, asynchronous=True)
+    sc.wait(); sc_b.wait()
+    for x in (sc, sc_b):
+        o3, e3, v3, _ = x.fetch()
+        assert np.array_equal(o3, mo) and np.array_equal(e3, oe) and np.array_equal(v3, ov) and x.timing_ms()["walk"] > 0
     # iter_long through the same entry
     total_l = sc.scan(d_hay, n * L, n, stride=L, mode=acx.ACX_SCAN_LONG)
     offl, el, vl, _ = sc.fetch()
