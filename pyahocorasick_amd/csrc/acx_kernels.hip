@@ -1282,8 +1282,11 @@ hipError_t acx_launch_walk_itop(const acx_walk_args& a, const acx_chunk_desc* ck
     if (ilp == 2 && hb == 4) hb = 2;                              // register budget: 1024 threads -> 128 VGPRs
     int bpc_env = 0;
     int threads = ACX_ITOP_BLOCK;
-    if (const char* bv = getenv("ACX_ITOP_BPC")) { const int v = atoi(bv); if (v >= 1 && v <= 8) bpc_env = v; }
-    if (const char* tv = getenv("ACX_ITOP_THREADS")) { const int v = atoi(tv); if (v == 256 || v == 512 || v == 768) threads = v; }   // occupancy experiments
+    // occupancy experiments (tools/itop_sweep.sh); read once per process
+    static const int env_bpc = [] { const char* v = getenv("ACX_ITOP_BPC"); const int x = v ? atoi(v) : 0; return x >= 1 && x <= 8 ? x : 0; }();
+    static const int env_threads = [] { const char* v = getenv("ACX_ITOP_THREADS"); const int x = v ? atoi(v) : 0; return (x == 256 || x == 512 || x == 768) ? x : 0; }();
+    bpc_env = env_bpc;
+    if (env_threads) threads = env_threads;
     const size_t lds_bytes = (size_t)((itop_words + 3) & ~3u) * 4 + 1024;
     if (lds_bytes > 160 * 1024 || (cell_bytes != 4 && cell_bytes != 8)) return hipErrorInvalidValue;
     int bpc = lds_bytes * 2 <= 160 * 1024 ? 2 : 1;          // 1024-thread blocks: at most 2 per CU
