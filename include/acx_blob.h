@@ -143,7 +143,64 @@ typedef struct acx_blob_header {
                                 seen (levels up to D-2 are complete): walk without the probe path;
                                 bit 1: tflags[s] carries s in its state field (a whole packed entry):
                                 blobs without it walk with the plain kernels */
-    uint8_t  reserved[ACX_BLOB_HEADER_BYTES - 244];
+    uint32_t reserved0;
+    uint64_t off_ppm;        /* acx_ppm_header + its sections (position-parallel scan, below); 0 = absent */
 } acx_blob_header;
+
+/*
+ * Position-parallel scan image ("ppm"), ACX_SCAN_ALL.
+ *
+ * automaton_search_iter_next (src/AutomatonSearchIter.c:243-300) reports, at every position e, the
+ * keys that are suffixes of text[..e], longest first (the state, then its fail chain:
+ * automaton_build_output, :157-197).  That set depends only on the last longest_word bytes, so it
+ * can be computed for every position independently: lane e walks the trie of REVERSED keys
+ * backwards from byte e (text[e], text[e-1], ...) and every end-of-word node it passes is one
+ * match ending at e.  No serial state, no fail links, no output lists: haystack bytes are read
+ * coalesced and staged in LDS as packed symbols, matches are placed with a wave prefix sum.
+ *
+ * symbol  = class - 1 (class 0 = "other": a byte no key contains; no match spans it); K symbols.
+ * code_d  = Horner value of the d newest symbols, newest first, radix K:
+ *           code_d = code_{d-1} * K + sym(e - d + 1)           (code_0 = 0)
+ * Levels 1..C of the reversed trie are direct-indexed by code (K^C <= 2^18):
+ *   G  (LDS)  bitmap over code_F (F = C + 1 when K^(C+1) bits fit, else C): "look at the cell".
+ *             Set iff the depth-F node exists (F = C + 1) or the cell of code_C is non-empty.
+ *   S_a,S_b (LDS) optional bitmaps over code_d for up to two levels d <= C that hold many keys:
+ *             bit set iff the k-gram IS a key.  Those levels are then left out of G and of the cell.
+ *   cell[code_C] (global, 16 bytes):
+ *       .x  eowmask: bit d-1 set iff the d newest symbols are a key (levels not covered by S)
+ *       .y  value of the depth-C key (when bit C-1 of .x is set)
+ *       .z  deep id of the depth-C node (0: absent or childless)
+ *       .w  K <= 4 only: children of that node: mask[0..3] | child is a key[4..7] |
+ *           grandchild (s1*4+s2) exists [8..23]; else 0
+ *   top_val[top_base[d] + code_d] (global): value of the key that is node (d, code_d), d <= C.
+ * Deeper nodes that have children carry deep ids 1..n_deep:
+ *   kids[id*K + sym] = child's deep id (0: childless) | child is a key << 31;   0 = no child
+ *   kval[id*K + sym] = value of that child when it is a key.
+ * All section offsets are relative to the start of the acx_ppm_header.
+ */
+#define ACX_PPM_MAGIC 0x314D5050u   /* "PPM1" */
+#define ACX_PPM_MAX_C 20
+#define ACX_PPM_TILE  256           /* end positions per wave and tile */
+typedef struct acx_ppm_header {
+    uint32_t magic;
+    uint32_t K;              /* symbols (bytes that occur in keys), 1..256 */
+    uint32_t sym_bits;       /* bits per symbol in the LDS staging: 2, 4 or 8 */
+    uint32_t pow2;           /* 1: K == 1 << sym_bits, codes are plain bit fields */
+    uint32_t C, F;
+    uint32_t n_s;            /* S bitmaps in use: 0..2 */
+    uint32_t s_depth[2];
+    uint32_t g_words, s_words[2];
+    uint32_t has_other;
+    uint32_t longest;        /* longest key */
+    uint32_t n_deep;         /* branch rows: deep ids 1..n_deep */
+    uint32_t n_top;          /* entries of top_val */
+    uint32_t min_len;        /* shortest key */
+    uint32_t n_chain;        /* chain records: deep ids n_deep+1 .. n_deep+n_chain */
+    uint64_t total_bytes;    /* header + sections */
+    uint64_t off_g, off_s[2], off_cells, off_top_val, off_kids, off_kval;
+    uint32_t top_base[ACX_PPM_MAX_C + 2];
+    uint64_t off_chains;
+    uint8_t  reserved[256 - 144 - 4 * (ACX_PPM_MAX_C + 2)];
+} acx_ppm_header;
 
 #endif

@@ -29,7 +29,7 @@ def lib():
     global _lib
     if _lib is None:
         src_newer = (not os.path.exists(LIB)) or any(
-            os.path.getmtime(os.path.join(HERE, f)) > os.path.getmtime(LIB) for f in ("ac_oracle.c", "flat_walk.c"))
+            os.path.getmtime(os.path.join(HERE, f)) > os.path.getmtime(LIB) for f in ("ac_oracle.c", "flat_walk.c", "ppm_walk.c"))
         if src_newer:
             build()
         l = C.CDLL(LIB)
@@ -53,6 +53,8 @@ def lib():
         l.flat_iter.argtypes = [P, P, I64, I32p, I64, P, P, I64]
         l.flat_iter_itop.restype = I64
         l.flat_iter_itop.argtypes = [P, P, I64, I64, I32p, P, P, I64]
+        l.ppm_iter.restype = I64
+        l.ppm_iter.argtypes = [P, P, I64, C.c_int32, P, P, I64]
         l.flat_iter_long.restype = I64
         l.flat_iter_long.argtypes = [P, P, I64, I64, P, P, I64]
         _lib = l
@@ -179,6 +181,23 @@ def flat_iter_itop(blob, hay, index_base=0):
             raise RuntimeError("flat_iter_itop failed: %d" % n)
         if n <= cap:
             return list(zip(e[:n].tolist(), v[:n].tolist())), st.value
+        cap = int(n)
+
+
+def ppm_iter(blob, hay, index_base=0):
+    """scan with the position-parallel image on the CPU (ppm_walk.c) -> list of (end, value);
+    None when the blob carries no ppm section"""
+    cap = max(16, 2 * len(hay))
+    while True:
+        e = np.empty(cap, dtype=np.int32)
+        v = np.empty(cap, dtype=np.int32)
+        n = lib().ppm_iter(blob, hay, len(hay), index_base, e.ctypes.data, v.ctypes.data, cap)
+        if n == -2:
+            return None
+        if n < 0:
+            raise RuntimeError("ppm_iter failed: %d" % n)
+        if n <= cap:
+            return list(zip(e[:n].tolist(), v[:n].tolist()))
         cap = int(n)
 
 

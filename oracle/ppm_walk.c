@@ -1,0 +1,110 @@
+/*
+ * ppm_walk.c — CPU walk of the position-parallel scan image (include/acx_blob.h "ppm").
+ * TEST INFRASTRUCTURE ONLY (see oracle/orc.py): it separates builder bugs (acx_ppm.cpp) from
+ * kernel bugs (acx_ppm_kernels.hip) — the same split oracle/flat_walk.c makes for the dense table.
+ *
+ * What it must reproduce: at every position e, the keys that are suffixes of hay[..e], longest
+ * first — what automaton_search_iter_next + automaton_build_output emit
+ * (/root/reference/src/AutomatonSearchIter.c:157-197, 243-300).  Every position is handled on its
+ * own: filter bit of the F newest symbols, 32-byte cell of the C newest, then the dense child rows
+ * of the reversed trie; matches come out shortest first and are reversed.
+ */
+#include <stdint.h>
+#include <string.h>
+#include "acx_blob.h"
+
+#define PPM_MAX_MATCH 4096
+
+int64_t ppm_iter(const uint8_t* blob, const uint8_t* hay, int64_t len, int32_t index_base,
+                 int32_t* out_end, int32_t* out_val, int64_t cap) {
+    acx_blob_header bh;
+    memcpy(&bh, blob, sizeof bh);
+    if (!bh.off_ppm) return -2;
+    const uint8_t* sec = blob + bh.off_ppm;
+    acx_ppm_header h;
+    memcpy(&h, sec, sizeof h);
+    if (h.magic != ACX_PPM_MAGIC) return -3;
+    const uint8_t* cls = blob + bh.off_cls;
+    const uint32_t* G = (const uint32_t*)(sec + h.off_g);
+    const uint32_t* cells = (const uint32_t*)(sec + h.off_cells);
+    const int32_t* top_val = (const int32_t*)(sec + h.off_top_val);
+    const uint32_t* kids = (const uint32_t*)(sec + h.off_kids);
+    const int32_t* kval = (const int32_t*)(sec + h.off_kval);
+    const uint32_t* chains = (const uint32_t*)(sec + h.off_chains);
+    const uint32_t K = h.K, C = h.C, F = h.F, ho = h.has_other, SB = h.sym_bits;
+    int64_t n = 0;
+    int64_t last_other = -1;            /* last position holding a byte no key contains */
+    static int32_t mv[PPM_MAX_MATCH];
+    for (int64_t e = 0; e < len; e++) {
+        if (ho && cls[hay[e]] == 0) { last_other = e; continue; }
+        int64_t L = e - last_other;     /* symbols available going back from e */
+        if (L > (int64_t)h.longest) L = h.longest;
+        /* codes of the newest d symbols, zero beyond L */
+        uint32_t codeC = 0, codeF = 0, code = 0;
+        for (uint32_t d = 1; d <= F; d++) {
+            const uint32_t s = (int64_t)d <= L ? (uint32_t)(cls[hay[e - (d - 1)]] - ho) : 0u;
+            code = code * K + s;
+            if (d == C) codeC = code;
+            if (d == F) codeF = code;
+        }
+        if (!((G[codeF >> 5] >> (codeF & 31)) & 1u)) continue;
+        const uint32_t* cell = cells + (size_t)codeC * 8;
+        int nm = 0;
+        uint32_t mask = cell[0];
+        if (L < 32) mask &= (1u << L) - 1u;
+        /* top levels, ascending depth */
+        {
+            uint32_t pc = 0;
+            for (uint32_t d = 1; d <= C; d++) {
+                const uint32_t s = (int64_t)d <= L ? (uint32_t)(cls[hay[e - (d - 1)]] - ho) : 0u;
+                pc = pc * K + s;
+                if ((mask >> (d - 1)) & 1u) {
+                    const int32_t v = (C - d < 5) ? (int32_t)cell[3 + (C - d)] : top_val[h.top_base[d] + pc];
+                    if (nm < PPM_MAX_MATCH) mv[nm++] = v;
+                }
+            }
+        }
+        /* deeper: dense child rows; K <= 4: the cell already knows children and grandchildren */
+        uint32_t id = cell[1];
+        int64_t d = C;                  /* depth of `id` */
+        if (id && L > d) {
+            int go = 1;
+            if (K <= 4 && cell[2]) {
+                const uint32_t s1 = (uint32_t)(cls[hay[e - d]] - ho);
+                if (!((cell[2] >> s1) & 1u)) go = 0;
+                else if (!((cell[2] >> (4 + s1)) & 1u)) {
+                    /* child exists, is no key: worth a row gather only if a grandchild continues */
+                    if (L > d + 1) {
+                        const uint32_t s2 = (uint32_t)(cls[hay[e - d - 1]] - ho);
+                        if (!((cell[2] >> (8 + s1 * 4 + s2)) & 1u)) go = 0;
+                    } else go = 0;
+                }
+            }
+            while (go && id && L > d) {
+                if (id <= h.n_deep) {                   /* branch: one symbol through its dense row */
+                    const uint32_t s = (uint32_t)(cls[hay[e - d]] - ho);
+                    const uint32_t en = kids[(size_t)id * K + s];
+                    if (!en) break;
+                    d++;
+                    if (en >> 31) { if (nm < PPM_MAX_MATCH) mv[nm++] = kval[(size_t)id * K + s]; }
+                    id = en & 0x7FFFFFFFu;
+                } else {                                /* chain: all of its symbols or nothing */
+                    const uint32_t* rec = chains + (size_t)(id - h.n_deep) * 4;
+                    const uint32_t len = rec[1] & 0xFFu;
+                    if (L < d + (int64_t)len) break;
+                    uint32_t label = 0;
+                    for (uint32_t i = 0; i < len; i++) label |= (uint32_t)(cls[hay[e - d - i]] - ho) << (32 - SB * (i + 1));
+                    if (label != rec[0]) break;
+                    d += len;
+                    if (rec[1] & 0x100u) { if (nm < PPM_MAX_MATCH) mv[nm++] = (int32_t)rec[2]; }
+                    id = rec[3];
+                }
+            }
+        }
+        for (int k = nm - 1; k >= 0; k--) {          /* longest first */
+            if (n < cap) { out_end[n] = (int32_t)e + index_base; out_val[n] = mv[k]; }
+            n++;
+        }
+    }
+    return n;
+}

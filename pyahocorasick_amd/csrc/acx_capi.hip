@@ -83,6 +83,14 @@ struct acx_image {
     const void* itop_cells = nullptr;
     const uint32_t* tflags = nullptr;
     uint32_t* built_table = nullptr;        // table built in HBM (blob without a table section); owned
+    // position-parallel scan image (include/acx_blob.h "ppm"); ppm_g == nullptr: absent
+    acx_ppm_header ppm;
+    const uint32_t* ppm_g = nullptr;
+    const uint32_t* ppm_cells = nullptr;
+    const int32_t*  ppm_top_val = nullptr;
+    const uint32_t* ppm_kids = nullptr;
+    const int32_t*  ppm_kval = nullptr;
+    const uint32_t* ppm_chains = nullptr;
 };
 
 // The steady-state step of the itop walk uses 32-bit offsets: table and cells from the lower of
@@ -110,6 +118,21 @@ static void image_check_itop_reach(acx_image* img) {
 // form (acx_build.hip).  lvl_host = host copy of the level boundaries, or nullptr to fetch it.
 static int image_resolve(acx_image* img, const uint32_t* lvl_host) {
     img->cls = img->dev + img->h.off_cls;
+    if (img->h.off_ppm) {
+        HIP_TRY(hipMemcpy(&img->ppm, img->dev + img->h.off_ppm, sizeof img->ppm, hipMemcpyDeviceToHost));
+        const acx_ppm_header& ph = img->ppm;
+        if (ph.magic != ACX_PPM_MAGIC || img->h.off_ppm + ph.total_bytes > img->nbytes || ph.C == 0 || ph.C > ACX_PPM_MAX_C || ph.F < ph.C ||
+            (ph.sym_bits != 2 && ph.sym_bits != 4 && ph.sym_bits != 8))
+            return acx_fail(ACX_E_FORMAT, "image: malformed ppm section");
+        const uint8_t* sec = img->dev + img->h.off_ppm;
+        img->ppm_g = (const uint32_t*)(sec + ph.off_g);
+        img->ppm_cells = (const uint32_t*)(sec + ph.off_cells);
+        img->ppm_top_val = (const int32_t*)(sec + ph.off_top_val);
+        img->ppm_kids = (const uint32_t*)(sec + ph.off_kids);
+        img->ppm_kval = (const int32_t*)(sec + ph.off_kval);
+        img->ppm_chains = (const uint32_t*)(sec + ph.off_chains);
+        if (acx_ppm_lds_layout(ph.g_words, ph.sym_bits, ph.longest).total_words * 4 > ACX_PPM_LDS_BYTES) img->ppm_g = nullptr;
+    }
     img->out_off = (const uint32_t*)(img->dev + img->h.off_out_off);
     img->out_val = (const int32_t*)(img->dev + img->h.off_out_val);
     img->first_val = (const int32_t*)(img->dev + img->h.off_first_val);
@@ -242,6 +265,13 @@ struct acx_result {
     DevBuf<uint2> events, matches;
     // chunked scans
     DevBuf<int32_t> nck; DevBuf<int64_t> ck_first, ck_match_off; DevBuf<acx_chunk_desc> ck;
+    // position-parallel scans: record pool, where each tile's records start, pool heads + overflow flag
+    DevBuf<uint2> scratch; DevBuf<uint32_t> scr_off; DevBuf<unsigned long long> ppm_ctl; DevBuf<int32_t> hay_local;
+    bool ppm = false;           // the pending scan is a position-parallel one
+    acx_ppm_args pend_pa; acx_ppm_compact_args pend_ca; int64_t pend_items = 0;
+    const int32_t* pend_counts = nullptr; int64_t* pend_item_off = nullptr;
+    acx_chunk_args pend_cka; acx_walk_args pend_tail; bool ppm_chunk = false, ppm_tail = false;
+    acx_image* pend_img = nullptr;
     PinBuf<int64_t> h_off;
     PinBuf<acx_match_t> h_matches;
     PinBuf<int32_t> h_final;
@@ -267,6 +297,7 @@ struct acx_result {
         if (pending) (void)hipStreamSynchronize(stream);
         counts.release(); nev.release(); final_state.release(); match_off.release(); partials.release();
         nck.release(); ck_first.release(); ck_match_off.release(); ck.release();
+        scratch.release(); scr_off.release(); ppm_ctl.release(); hay_local.release();
         events.release(); matches.release(); h_off.release(); h_matches.release(); h_final.release(); h_total.release();
         in_hay.release(); in_off.release(); in_init.release(); in_base.release();
         for (auto& e : ev) if (e) (void)hipEventDestroy(e);
@@ -274,11 +305,52 @@ struct acx_result {
     }
 };
 
+static int ppm_enqueue(acx_result* r, acx_image* img, const acx_chunk_args* ca, const acx_walk_args* tail, hipStream_t s);
+static int ppm_size_pool(acx_result* r, size_t records);
+
+// position-parallel scan: the record pool ran out (grow it and scan again) or the match buffer
+// is too small (grow it and copy again: the pool is intact)
+static int ppm_complete(acx_result* r) {
+    hipStream_t s = r->stream;
+    for (int attempt = 0;; attempt++) {
+        if (r->done) HIP_TRY(hipEventSynchronize(r->done)); else HIP_TRY(hipStreamSynchronize(s));
+        r->total = r->h_total.p[0];
+        const bool overflow = (int32_t)r->h_total.p[1] != 0;
+        const bool small = r->total > (int64_t)r->matches.cap;
+        if (!overflow && !small) break;
+        if (attempt >= 4) return acx_fail(ACX_E_NOMEM, "position-parallel scan: record pool still too small after %d attempts", attempt);
+        int rc;
+        if (small) {
+            if ((rc = r->matches.ensure((size_t)r->total))) return rc;
+            r->pend_ca.matches = r->matches.p; r->pend_ca.capacity = (int64_t)r->matches.cap;
+        }
+        if (overflow) {
+            const size_t have = r->scratch.cap, need = (size_t)r->total;
+            if ((rc = ppm_size_pool(r, (need > have ? need : have) + need / 2))) return rc;
+            if ((rc = ppm_enqueue(r, r->pend_img, r->ppm_chunk ? &r->pend_cka : nullptr, r->ppm_tail ? &r->pend_tail : nullptr, s))) return rc;
+        } else {
+            HIP_TRY(acx_launch_ppm_compact(r->pend_ca, r->pend_items, s));
+            HIP_TRY(hipEventRecord(r->done, s));
+        }
+    }
+    if (r->timed) {
+        HIP_TRY(hipEventElapsedTime(&r->t_walk, r->ev[0], r->ev[1]));
+        r->t_scan = 0.f; r->t_expand = 0.f; r->t_total = r->t_walk;
+        if (r->timed_all) {
+            HIP_TRY(hipEventElapsedTime(&r->t_scan, r->ev[1], r->ev[2]));
+            HIP_TRY(hipEventElapsedTime(&r->t_expand, r->ev[2], r->ev[3]));
+            HIP_TRY(hipEventElapsedTime(&r->t_total, r->ev[0], r->ev[3]));
+        }
+    }
+    return ACX_OK;
+}
+
 // Finish a scan whose kernels are queued: wait, read the total, and if the speculative expand did
 // not fit the match buffer grow it and run expand again (the events are intact).
 static int result_complete(acx_result* r) {
     if (!r || !r->pending) return ACX_OK;
     r->pending = false;
+    if (r->ppm) { r->ppm = false; return ppm_complete(r); }
     hipStream_t s = r->stream;
     // wait for this scan only: later scans queued on the same stream (other result objects) keep running
     if (r->done) HIP_TRY(hipEventSynchronize(r->done)); else HIP_TRY(hipStreamSynchronize(s));
@@ -322,6 +394,128 @@ extern "C" void acx_result_free(acx_result_t* r) { delete r; }
 // ------------------------------------------------------------------------------------
 static const int64_t ACX_MAX_LAUNCH_BYTES = (int64_t)4 << 30;   // event staging = 8 B per haystack byte
 
+
+// ------------------------------------------------------------------------------------
+// position-parallel scan driver (kernels: acx_ppm_kernels.hip)
+// ------------------------------------------------------------------------------------
+// (Re-)issue everything a position-parallel scan queues on its stream, from the arguments kept in
+// the result: a scan whose record pool ran out is issued again with a larger pool.
+static int ppm_enqueue(acx_result* r, acx_image* img, const acx_chunk_args* ca, const acx_walk_args* tail, hipStream_t s) {
+    const acx_ppm_args& pa = r->pend_pa;
+    const int64_t ni = r->pend_items;
+    HIP_TRY(hipMemsetAsync(r->ppm_ctl.p, 0, 16 * sizeof(unsigned long long), s));
+    if (ca) {
+        HIP_TRY(hipMemsetAsync(r->counts.p, 0, ((size_t)ni + 1) * sizeof(int32_t), s));   // tiles beyond the real chunk count read as empty
+        HIP_TRY(acx_launch_chunk_count(*ca, s));
+        HIP_TRY(acx_launch_scan(r->nck.p, ca->n_hay, r->ck_first.p, r->partials.p, s));
+        HIP_TRY(acx_launch_chunk_fill(*ca, ni, s));
+    }
+    if (r->timed) HIP_TRY(hipEventRecord(r->ev[0], s));
+    HIP_TRY(acx_launch_ppm_scan(pa, ni, s));
+    if (r->timed) HIP_TRY(hipEventRecord(r->ev[1], s));
+    HIP_TRY(acx_launch_scan(r->pend_counts, ni, r->pend_item_off, r->partials.p, s));
+    if (r->timed_all) HIP_TRY(hipEventRecord(r->ev[2], s));
+    HIP_TRY(acx_launch_ppm_compact(r->pend_ca, ni, s));
+    if (ca) HIP_TRY(acx_launch_hay_offsets(r->ck_first.p, r->ck_match_off.p, ca->n_hay, r->match_off.p, s));
+    if (r->timed_all) HIP_TRY(hipEventRecord(r->ev[3], s));
+    if (tail) HIP_TRY(acx_launch_tail_state(*tail, (int32_t)img->ppm.longest, s));
+    r->h_total.p[1] = 0;
+    HIP_TRY(hipMemcpyAsync(r->h_total.p, r->pend_item_off + ni, sizeof(int64_t), hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipMemcpyAsync(r->h_total.p + 1, r->ppm_ctl.p + 8, sizeof(int32_t), hipMemcpyDeviceToHost, s));
+    if (!r->done) HIP_TRY(hipEventCreateWithFlags(&r->done, hipEventDisableTiming));
+    HIP_TRY(hipEventRecord(r->done, s));
+    return ACX_OK;
+}
+
+// size the record pool: `records` of capacity plus one grant of slack per wave, cut into n_pools
+static int ppm_size_pool(acx_result* r, size_t records) {
+    acx_ppm_args& pa = r->pend_pa;
+    const int64_t blocks = acx_ppm_grid_blocks(pa.lds, r->pend_items);
+    pa.n_pools = (uint32_t)(blocks < 8 ? blocks : 8);
+    const size_t slack = (size_t)blocks * ACX_PPM_WAVES * 1024u;
+    size_t want = records + records / 4 + slack + 1024;
+    if (want >= 0xFFFFFFF0ull) want = 0xFFFFFFF0ull;                 // tile offsets into the pool are 32-bit
+    int rc = r->scratch.ensure(want);
+    if (rc) return rc;
+    size_t cap = r->scratch.cap < 0xFFFFFFF0ull ? r->scratch.cap : 0xFFFFFFF0ull;
+    pa.scratch = r->scratch.p; pa.pool_records = cap / pa.n_pools;
+    r->pend_ca.scratch = r->scratch.p;
+    return ACX_OK;
+}
+
+static int scan_ppm(acx_image_t* img, const acx_scan_params* p, acx_result* r, hipStream_t s) {
+    const acx_ppm_header& ph = img->ppm;
+    const size_t n = (size_t)p->n_hay;
+    const bool chunked = p->dev_off != nullptr;
+    const int64_t n_items = chunked ? p->n_hay + p->hay_capacity / ACX_PPM_TILE + 1
+                                    : (p->n_hay * p->stride + ACX_PPM_TILE - 1) / ACX_PPM_TILE;
+    const size_t ni = (size_t)n_items;
+    int rc;
+    if ((rc = r->counts.ensure(ni + 1))) return rc;
+    if ((rc = r->scr_off.ensure(ni + 1))) return rc;
+    if ((rc = r->match_off.ensure(n + 1))) return rc;
+    if ((rc = r->ck_match_off.ensure(ni + 1))) return rc;
+    if ((rc = r->partials.ensure((size_t)acx_scan_num_partials((int64_t)(ni > n ? ni : n)) + 2))) return rc;
+    if ((rc = r->ppm_ctl.ensure(16))) return rc;
+    if ((rc = r->h_total.ensure(2))) return rc;
+    if (r->has_final && (rc = r->final_state.ensure(n + 1))) return rc;
+    if (r->matches.cap == 0 && (rc = r->matches.ensure((size_t)(p->hay_capacity / 8) + 1024))) return rc;
+    if (chunked) {
+        if ((rc = r->nck.ensure(n + 1))) return rc;
+        if ((rc = r->ck_first.ensure(n + 1))) return rc;
+        if ((rc = r->ck.ensure(ni + 1))) return rc;
+    } else if ((rc = r->hay_local.ensure(n + 1))) return rc;
+    if (r->timed) for (auto& e : r->ev) if (!e) HIP_TRY(hipEventCreate(&e));
+
+    acx_ppm_args& pa = r->pend_pa;
+    memset(&pa, 0, sizeof pa);
+    pa.hay = p->dev_hay; pa.hay_cap = p->hay_capacity; pa.stride = p->stride; pa.n_hay = p->n_hay;
+    pa.stride_magic = p->stride > 1 ? ~0ull / (uint64_t)p->stride + 1 : 0;           // ceil(2^64 / stride) (stride is no power of two, or the +1 is still right)
+    if (p->stride > 1 && (p->stride & (p->stride - 1)) == 0) pa.stride_magic = ((uint64_t)1 << 63) / (uint64_t)p->stride * 2;
+    pa.index_base = chunked ? nullptr : p->dev_index_base;
+    pa.ck = chunked ? r->ck.p : nullptr; pa.n_items_dev = chunked ? r->ck_first.p + p->n_hay : nullptr;
+    pa.n_items = n_items;
+    pa.cls = img->cls; pa.g = img->ppm_g; pa.cells = img->ppm_cells; pa.top_val = img->ppm_top_val;
+    pa.kids = img->ppm_kids; pa.kval = img->ppm_kval; pa.chains = img->ppm_chains; pa.n_branch = ph.n_deep;
+    pa.K = ph.K; pa.sym_bits = ph.sym_bits; pa.pow2 = ph.pow2; pa.C = ph.C; pa.F = ph.F; pa.g_words = ph.g_words;
+    pa.has_other = ph.has_other; pa.longest = ph.longest; pa.min_len = ph.min_len ? ph.min_len : 1;
+    memcpy(pa.top_base, ph.top_base, sizeof pa.top_base);
+    pa.lds = acx_ppm_lds_layout(ph.g_words, ph.sym_bits, ph.longest);
+    pa.counts = r->counts.p; pa.scr_off = r->scr_off.p;
+    pa.heads = r->ppm_ctl.p; pa.overflow = (int32_t*)(r->ppm_ctl.p + 8);
+    pa.hay_local = chunked ? nullptr : r->hay_local.p;
+
+    acx_ppm_compact_args& ca = r->pend_ca;
+    memset(&ca, 0, sizeof ca);
+    ca.counts = r->counts.p; ca.scr_off = r->scr_off.p;
+    ca.item_off = r->ck_match_off.p; ca.n_items = n_items; ca.n_items_dev = nullptr;
+    ca.matches = r->matches.p; ca.capacity = (int64_t)r->matches.cap;
+    ca.hay_local = chunked ? nullptr : r->hay_local.p; ca.match_off = r->match_off.p; ca.n_hay = p->n_hay; ca.stride = p->stride;
+    r->pend_items = n_items; r->pend_counts = r->counts.p; r->pend_item_off = r->ck_match_off.p;
+    if ((rc = ppm_size_pool(r, r->matches.cap))) return rc;
+
+    r->ppm_chunk = chunked;
+    if (chunked) {
+        acx_chunk_args& cka = r->pend_cka;
+        cka.off = p->dev_off; cka.stride = p->stride; cka.n_hay = p->n_hay; cka.index_base = p->dev_index_base;
+        cka.chunk_bytes = ACX_PPM_TILE; cka.halo = ph.longest > 0 ? (int32_t)ph.longest - 1 : 0;
+        cka.nck = r->nck.p; cka.ck_first = r->ck_first.p; cka.ck = r->ck.p;
+    }
+    r->ppm_tail = r->has_final;
+    if (r->has_final) {
+        acx_walk_args& wa = r->pend_tail;
+        memset(&wa, 0, sizeof wa);
+        wa.hay = p->dev_hay; wa.hay_cap = p->hay_capacity; wa.off = p->dev_off; wa.stride = p->stride; wa.n_hay = p->n_hay;
+        wa.cls = img->cls; wa.table = img->table; wa.row_bytes = img->h.n_classes * 4u; wa.state_bits = img->h.state_bits;
+        wa.final_state = r->final_state.p;
+    }
+    r->pend_img = img;
+    if ((rc = ppm_enqueue(r, img, chunked ? &r->pend_cka : nullptr, r->has_final ? &r->pend_tail : nullptr, s))) return rc;
+    r->pending = true; r->ppm = true;
+    if (p->flags & ACX_SCAN_ASYNC) return ACX_OK;
+    return result_complete(r);
+}
+
 extern "C" int acx_scan_batch(acx_image_t* img, const acx_scan_params* p, acx_result_t** result, void* stream_v) {
     if (!img || !p || !result) return acx_fail(ACX_E_INVAL, "acx_scan_batch: NULL argument");
     if (p->struct_bytes != sizeof(acx_scan_params))
@@ -349,6 +543,12 @@ extern "C" int acx_scan_batch(acx_image_t* img, const acx_scan_params* p, acx_re
     if (r->pending) { int rcw = result_complete(r); if (rcw) return rcw; }     // still in flight on its old stream
     r->stream = s; r->n_hay = p->n_hay; r->total = 0; r->host_valid = false;
     r->has_final = p->want_final_state != 0; r->timed = p->timing != 0; r->timed_all = p->timing == 1;
+
+    // position-parallel kernels: ACX_SCAN_ALL on an image that carries the structures, no carried-in state
+    // (variant bit 23 turns them off: A/B against the serial walks)
+    if (p->mode == ACX_SCAN_ALL && img->ppm_g && !p->dev_init_state && p->n_hay > 0 && !((p->variant >> 23) & 1) &&
+        (p->dev_off || p->stride > 0))
+        return scan_ppm(img, p, r, s);
 
     const size_t n = (size_t)p->n_hay;
     int rc;

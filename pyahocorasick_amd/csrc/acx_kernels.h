@@ -5,6 +5,7 @@
 
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include "acx_ppm_layout.h"
 
 struct acx_walk_args {
     // input batch
@@ -92,6 +93,48 @@ hipError_t acx_launch_walk_itop(const acx_walk_args& a, const acx_chunk_desc* ck
 hipError_t acx_launch_hay_offsets(const int64_t* ck_first, const int64_t* ck_match_off, int64_t n_hay,
                                   int64_t* match_off, hipStream_t s);
 int64_t acx_scan_num_partials(int64_t n);
+
+// ---- position-parallel scan (acx_ppm_kernels.hip; image: include/acx_blob.h "ppm") ----------------
+// Work items are TILES of ACX_PPM_TILE end positions: tile i of the concatenated buffer (fixed-stride
+// batches: ck == nullptr) or one chunk of one haystack (ck != nullptr, chunks of at most
+// ACX_PPM_TILE bytes; their number lives in device memory).
+struct acx_ppm_args {
+    const uint8_t* hay; int64_t hay_cap;
+    int64_t stride; int64_t n_hay; uint64_t stride_magic;    // ceil(2^64 / stride); 0 for stride 1
+    const int32_t* index_base;                               // nullable (fixed-stride batches)
+    const acx_chunk_desc* ck; const int64_t* n_items_dev;
+    int64_t n_items;                                         // tiles of a fixed-stride batch
+    // image
+    const uint8_t* cls; const uint32_t* g; const uint32_t* cells; const int32_t* top_val;
+    const uint32_t* kids; const int32_t* kval; const uint32_t* chains; uint32_t n_branch;
+    uint32_t K, sym_bits, pow2, C, F, g_words, has_other, longest, min_len;
+    uint32_t top_base[ACX_PPM_MAX_C + 2];
+    acx_ppm_lds lds;
+    // outputs
+    int32_t*  counts;        // matches per tile
+    uint32_t* scr_off;       // where the tile's records start in `scratch` (0xFFFFFFFF: none)
+    uint2*    scratch;       // record pool: 8 sub-pools of pool_records each, one bump pointer per sub-pool
+    unsigned long long* heads;
+    uint32_t  n_pools;       // min(8, blocks): block b bumps heads[b % n_pools]
+    uint64_t  pool_records;
+    int32_t*  overflow;      // set when a sub-pool ran out: the host grows the pool and scans again
+    int32_t*  hay_local;     // fixed-stride batches: tile-local record offset of every haystack start
+};
+struct acx_ppm_compact_args {
+    const int32_t* counts; const uint32_t* scr_off; const uint2* scratch;
+    const int64_t* item_off;       // exclusive prefix sum of counts, [n_items + 1]
+    int64_t n_items; const int64_t* n_items_dev;
+    uint2* matches; int64_t capacity;
+    // fixed-stride batches: match_off[h] = item_off[h * stride / TILE] + hay_local[h]
+    const int32_t* hay_local; int64_t* match_off; int64_t n_hay; int64_t stride;
+};
+hipError_t acx_launch_ppm_scan(const acx_ppm_args& a, int64_t n_items_bound, hipStream_t s);
+hipError_t acx_launch_ppm_compact(const acx_ppm_compact_args& c, int64_t n_items_bound, hipStream_t s);
+int64_t acx_ppm_grid_blocks(const acx_ppm_lds& lds, int64_t n_items_bound);   // blocks of a k_ppm_scan launch
+// final_state of an ACX_SCAN_ALL scan when the matches came from the position-parallel kernels: the
+// state after a haystack = the state after its last longest_word bytes walked from the root
+hipError_t acx_launch_tail_state(const acx_walk_args& a, int32_t longest, hipStream_t s);
+int acx_num_cus();
 // build the dense transition table in HBM from the sparse form (acx_build.hip)
 hipError_t acx_launch_build_table(uint32_t* table, const int32_t* fail, const uint32_t* edge_off, const uint8_t* edge_cls,
                                   const uint32_t* edge_dst, const uint32_t* tflags, const uint32_t* lvl_first_host,

@@ -948,6 +948,28 @@ __global__ void __launch_bounds__(ACX_BLOCK) k_walk_long(const acx_walk_args a) 
     }
 }
 
+// final_state of every haystack from its last `longest` bytes (position-parallel scans keep no
+// state): the state reached from the root over a window is the longest suffix of the window that
+// is a trie node, and no node is longer than the longest key.
+template <int SB>
+__global__ void __launch_bounds__(ACX_BLOCK) k_tail_state(const acx_walk_args a, int32_t longest) {
+    __shared__ uint32_t s_cls4[256];
+    s_cls4[threadIdx.x] = (uint32_t)a.cls[threadIdx.x] * 4u;
+    __syncthreads();
+    const int64_t n_threads = (int64_t)gridDim.x * ACX_BLOCK;
+    const uint8_t* table_bytes = (const uint8_t*)a.table;
+    for (int64_t h = (int64_t)blockIdx.x * ACX_BLOCK + threadIdx.x; h < a.n_hay; h += n_threads) {
+        int64_t b, e;
+        if (a.off) { b = a.off[h]; e = a.off[h + 1]; }
+        else       { b = h * a.stride; e = b + a.stride; }
+        const int64_t n = e - b < longest ? e - b : longest;
+        const uint8_t* p = a.hay + (e - n);
+        uint32_t state = 0;
+        for (int64_t i = 0; i < n; i++) state = load_entry<SB>(table_bytes, state, a.row_bytes, s_cls4[p[i]]);
+        a.final_state[h] = (int32_t)(state & ACX_ENTRY_STATE_MASK(SB));
+    }
+}
+
 // ---------------------------------------------------------------------------------
 // scan: exclusive prefix sum int32 counts[n] -> int64 match_off[n+1]
 // three small launches (per-block sums, one-block scan of the sums, per-block rescan)
@@ -1125,7 +1147,7 @@ __global__ void __launch_bounds__(ACX_BLOCK) k_expand_grp(const acx_expand_args 
 inline int grid_for_waves(int64_t n_tasks) {
     // 256 CUs x 8 blocks of 4 waves = the chip's 32 waves/CU; grid-stride the rest
     const int64_t blocks = (n_tasks + (ACX_BLOCK / ACX_WAVE) - 1) / (ACX_BLOCK / ACX_WAVE);
-    const int64_t cap = 256 * 8;
+    const int64_t cap = (int64_t)acx_num_cus() * 8;
     return (int)(blocks < 1 ? 1 : (blocks > cap ? cap : blocks));
 }
 
@@ -1144,7 +1166,7 @@ static void launch_walk_all_t(const acx_walk_args& a, int blocks_per_cu, hipStre
     const int64_t per_task = (int64_t)ACX_WAVE * ILP;
     const int64_t n_tasks = (a.n_hay + per_task - 1) / per_task;
     const int64_t blocks = (n_tasks + (ACX_BLOCK / ACX_WAVE) - 1) / (ACX_BLOCK / ACX_WAVE);
-    const int64_t cap = 256 * (int64_t)blocks_per_cu;
+    const int64_t cap = (int64_t)acx_num_cus() * (int64_t)blocks_per_cu;
     const int grid = (int)(blocks < 1 ? 1 : (blocks > cap ? cap : blocks));
     hipLaunchKernelGGL((k_walk_all<SB, ESCAPE, ILP, EVENTS, NT>), dim3(grid), dim3(ACX_BLOCK), 0, s, a);
 }
@@ -1200,6 +1222,14 @@ hipError_t acx_launch_walk_long(const acx_walk_args& a, int variant, hipStream_t
     return hipGetLastError();
 }
 
+hipError_t acx_launch_tail_state(const acx_walk_args& a, int32_t longest, hipStream_t s) {
+    if (a.n_hay <= 0 || !a.final_state) return hipSuccess;
+    const int grid = grid_for_waves((a.n_hay + ACX_WAVE - 1) / ACX_WAVE);
+    if (a.state_bits == ACX_STATE_BITS_WIDE) hipLaunchKernelGGL(k_tail_state<ACX_STATE_BITS_WIDE>, dim3(grid), dim3(ACX_BLOCK), 0, s, a, longest);
+    else                                     hipLaunchKernelGGL(k_tail_state<ACX_STATE_BITS_NARROW>, dim3(grid), dim3(ACX_BLOCK), 0, s, a, longest);
+    return hipGetLastError();
+}
+
 hipError_t acx_launch_scan(const int32_t* counts, int64_t n, int64_t* match_off, int64_t* partials, hipStream_t s) {
     const int64_t np = acx_scan_num_partials(n);
     if (n <= 0) {   // match_off[0] = 0
@@ -1219,7 +1249,7 @@ hipError_t acx_launch_expand(const acx_expand_args& a, int variant, hipStream_t 
     const int group = ev == 1 ? 1 : ev == 2 ? 8 : ev == 3 ? 32 : ev == 4 ? 4 : 16;
     const int64_t per_block = ACX_BLOCK / group;
     const int64_t blocks = (a.n_hay + per_block - 1) / per_block;
-    const int64_t cap = 256 * 8 * 4;
+    const int64_t cap = (int64_t)acx_num_cus() * 8 * 4;
     const int grid = (int)(blocks > cap ? cap : blocks);
     switch (group) {
         case 1:  hipLaunchKernelGGL(k_expand, dim3(grid), dim3(ACX_BLOCK), 0, s, a); break;
@@ -1240,7 +1270,7 @@ hipError_t acx_launch_chunk_count(const acx_chunk_args& c, hipStream_t s) {
 hipError_t acx_launch_chunk_fill(const acx_chunk_args& c, int64_t n_chunks_bound, hipStream_t s) {
     if (c.n_hay <= 0) return hipSuccess;
     int64_t blocks = (n_chunks_bound + ACX_BLOCK - 1) / ACX_BLOCK;
-    if (blocks > 256 * 16) blocks = 256 * 16;
+    if (blocks > (int64_t)acx_num_cus() * 16) blocks = (int64_t)acx_num_cus() * 16;
     if (blocks < 1) blocks = 1;
     hipLaunchKernelGGL(k_chunk_fill, dim3((unsigned)blocks), dim3(ACX_BLOCK), 0, s, c);
     return hipGetLastError();
@@ -1294,7 +1324,7 @@ hipError_t acx_launch_walk_itop(const acx_walk_args& a, const acx_chunk_desc* ck
     const int64_t waves_per_block = threads / ACX_WAVE;
     const int64_t n_tasks = (n_items_bound + ACX_WAVE * ilp - 1) / (ACX_WAVE * ilp);
     int64_t blocks = (n_tasks + waves_per_block - 1) / waves_per_block;
-    if (blocks > 256 * bpc) blocks = 256 * bpc;
+    if (blocks > (int64_t)acx_num_cus() * bpc) blocks = (int64_t)acx_num_cus() * bpc;
     if (blocks < 1) blocks = 1;
     auto launch = [&](auto kernel) -> hipError_t {
         hipError_t e = hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);

@@ -1,0 +1,253 @@
+// acx_ppm.cpp — builds the position-parallel scan image ("ppm", include/acx_blob.h) from the host
+// trie: the trie of REVERSED keys, its top C levels direct-indexed by k-gram code (filter bitmap G
+// for LDS, 32-byte cells, top_val), deeper nodes as dense child rows (kids/kval).
+//
+// What it replaces: nothing in the reference is built like this.  The reference reports at every
+// position the current state's output chain (automaton_build_output,
+// src/AutomatonSearchIter.c:157-197) = the keys that are suffixes of the text read so far, longest
+// first.  A key is a suffix of text[..e] iff the reversed key is a path from the root of the
+// reversed trie along text[e], text[e-1], ...  That walk needs no state from position e-1.
+#include "acx_trie_impl.h"
+#include "acx_ppm_layout.h"
+
+#include <cstdlib>
+#include <cstring>
+#include <new>
+#include <vector>
+
+static_assert(sizeof(acx_ppm_header) == 256, "acx_ppm_header must be exactly 256 bytes");
+
+namespace {
+
+inline size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
+
+// insert every key of `t`, reversed, into `rev` (DFS with an explicit stack; children in list order)
+int build_reversed(const acx_trie* t, acx_trie* rev) {
+    struct Frame { int32_t node; int32_t next_child; };
+    std::vector<Frame> st;
+    std::vector<uint8_t> path, rkey;
+    st.push_back({0, t->nodes.empty() ? -1 : t->nodes[0].first_child});
+    while (!st.empty()) {
+        Frame& f = st.back();
+        if (f.next_child < 0) {
+            st.pop_back();
+            if (!path.empty()) path.pop_back();
+            continue;
+        }
+        const int32_t c = f.next_child;
+        f.next_child = t->nodes[c].next_sibling;
+        path.push_back(t->nodes[c].letter);
+        if (t->nodes[c].eow) {
+            rkey.assign(path.rbegin(), path.rend());
+            int is_new = 0;
+            const int rc = acx_trie_add_word(rev, rkey.data(), rkey.size(), t->nodes[c].value, &is_new);
+            if (rc) return rc;
+        }
+        st.push_back({c, t->nodes[c].first_child});
+    }
+    return ACX_OK;
+}
+
+}  // namespace
+
+// Returns ACX_OK with *out = nullptr when the automaton gets no ppm image (keys too long, deep rows
+// too large): the scan then uses the serial walk kernels.  *out is malloc'd.
+int acx_ppm_build(const acx_trie* t, const uint8_t* cls, uint32_t n_classes, bool has_other, uint8_t** out, size_t* nbytes) {
+    *out = nullptr; *nbytes = 0;
+    const char* off_env = getenv("ACX_NO_PPM");
+    if (off_env && off_env[0] == '1') return ACX_OK;
+    if (t->count <= 0 || t->longest_word <= 0 || t->longest_word > (int64_t)ACX_PPM_MAX_LONGEST) return ACX_OK;
+    try {
+        const uint32_t sigma = has_other ? n_classes - 1 : 256u;        // symbols = bytes that occur in keys
+        if (sigma == 0) return ACX_OK;
+        const uint32_t ho = has_other ? 1u : 0u;
+
+        acx_trie rev;
+        int rc = build_reversed(t, &rev);
+        if (rc) return rc;
+        const size_t n = rev.nodes.size();
+        if (n < 2) return ACX_OK;
+
+        // BFS over the reversed trie: depth, parent-first order
+        std::vector<int32_t> order; order.reserve(n);
+        std::vector<int32_t> depth(n, 0);
+        order.push_back(0);
+        int32_t max_depth = 0;
+        for (size_t head = 0; head < order.size(); head++) {
+            const int32_t u = order[head];
+            for (int32_t c = rev.nodes[u].first_child; c >= 0; c = rev.nodes[c].next_sibling) {
+                depth[c] = depth[u] + 1;
+                if (depth[c] > max_depth) max_depth = depth[c];
+                order.push_back(c);
+            }
+        }
+
+        // parameters
+        acx_ppm_header h;
+        memset(&h, 0, sizeof h);
+        h.magic = ACX_PPM_MAGIC; h.K = sigma; h.has_other = ho; h.longest = (uint32_t)t->longest_word;
+        h.sym_bits = sigma <= 4 ? 2u : (sigma <= 16 ? 4u : 8u);
+        h.pow2 = sigma == (1u << h.sym_bits) ? 1u : 0u;
+        const uint32_t max_syms = 32u / h.sym_bits;                     // a window is 32 bits
+        auto ipow = [&](uint32_t e) -> uint64_t { uint64_t p = 1; for (uint32_t i = 0; i < e; i++) { p *= sigma; if (p > ((uint64_t)1 << 40)) break; } return p; };
+        uint32_t C = 0;
+        while (C + 1 <= (uint32_t)max_depth && C + 1 <= max_syms && C + 1 <= 16 && ipow(C + 1) <= ((uint64_t)1 << 18)) C++;
+        if (C == 0) return ACX_OK;
+        const acx_ppm_lds base_layout = acx_ppm_lds_layout(0, h.sym_bits, h.longest);
+        if (base_layout.total_words + 64 > ACX_PPM_LDS_BYTES / 4) return ACX_OK;
+        const uint64_t gbits_cap = (uint64_t)(ACX_PPM_LDS_BYTES / 4 - base_layout.total_words - 8) * 32;
+        uint32_t F = C;
+        if (C + 1 <= (uint32_t)max_depth && C + 1 <= max_syms && ipow(C + 1) <= gbits_cap) F = C + 1;
+        if (const char* e = getenv("ACX_PPM_MAX_F")) { const uint32_t v = (uint32_t)atoi(e); if (v >= 1 && v < F) { F = v; if (C > F) C = F; } }   // tuning hook
+        if (ipow(F) > gbits_cap) return ACX_OK;                          // (F == C and even that does not fit: no image)
+        h.C = C; h.F = F;
+        const uint64_t nC = ipow(C), nF = ipow(F);
+        h.g_words = (uint32_t)((nF + 31) / 32);
+        h.top_base[0] = 0;
+        for (uint32_t d = 1; d <= C + 1; d++) h.top_base[d] = h.top_base[d - 1] + (uint32_t)ipow(d - 1);
+        h.n_top = h.top_base[C + 1];
+
+        // codes of the shallow nodes (depth <= F)
+        std::vector<uint32_t> code(n, 0);
+        std::vector<uint32_t> nkids(n, 0);
+        uint32_t min_len = 0xFFFFFFFFu;
+        for (size_t i = 0; i < order.size(); i++) {
+            const int32_t u = order[i];
+            const Node& nd = rev.nodes[u];
+            if (nd.eow && (uint32_t)depth[u] < min_len) min_len = (uint32_t)depth[u];
+            for (int32_t c = nd.first_child; c >= 0; c = rev.nodes[c].next_sibling) {
+                nkids[u]++;
+                if ((uint32_t)depth[u] < F) code[c] = code[u] * sigma + (uint32_t)(cls[rev.nodes[c].letter] - ho);
+            }
+        }
+        h.min_len = min_len;
+
+        // Deep structure: nodes at depth >= C that have children.  A node with two or more children is
+        // a BRANCH (a dense row of K child entries); a node with exactly one child starts a CHAIN: up
+        // to 32 / sym_bits symbols that must all match, ending at the first node that is a key, a
+        // branch or a leaf.  Random text leaves the trie within a level or two of the cells; the
+        // long walks are occurrences of long keys, whose tails are unbranched: a chain record per
+        // 16 (4, 2) symbols instead of one dependent gather per symbol.
+        std::vector<uint32_t> deep(n, 0);           // id of a node that the walk can stand on (0: none yet)
+        std::vector<int32_t> branch_nodes, chain_nodes;
+        {
+            std::vector<int32_t> work;
+            auto want = [&](int32_t u) {           // make sure node u (depth >= C, has children) gets an id
+                if (deep[u]) return;
+                if (nkids[u] >= 2) { branch_nodes.push_back(u); deep[u] = (uint32_t)branch_nodes.size(); }          // ids 1..n_branch
+                else { chain_nodes.push_back(u); deep[u] = 0x40000000u | (uint32_t)chain_nodes.size(); }            // renumbered below
+                work.push_back(u);
+            };
+            for (size_t i = 0; i < order.size(); i++) { const int32_t u = order[i]; if ((uint32_t)depth[u] == C && nkids[u]) want(u); }
+            while (!work.empty()) {
+                const int32_t u = work.back(); work.pop_back();
+                if (nkids[u] >= 2) {
+                    for (int32_t c = rev.nodes[u].first_child; c >= 0; c = rev.nodes[c].next_sibling) if (nkids[c]) want(c);
+                } else {
+                    int32_t v = u; uint32_t len = 0;
+                    do { v = rev.nodes[v].first_child; len++; } while (len < max_syms && !rev.nodes[v].eow && nkids[v] == 1);
+                    if (nkids[v]) want(v);
+                }
+            }
+        }
+        const uint32_t n_branch = (uint32_t)branch_nodes.size(), n_chain = (uint32_t)chain_nodes.size();
+        for (int32_t u : chain_nodes) deep[u] = n_branch + (deep[u] & 0x3FFFFFFFu);                                  // ids n_branch+1 ..
+        h.n_deep = n_branch; h.n_chain = n_chain;
+        const uint64_t row_bytes = (uint64_t)(n_branch + 1) * sigma * 4;
+        uint64_t cap = (uint64_t)3 << 30;                               // kids + kval
+        if (const char* e = getenv("ACX_PPM_MAX_DEEP_BYTES")) { const long long v = atoll(e); if (v > 0) cap = (uint64_t)v; }
+        if (row_bytes * 2 > cap || (uint64_t)n_branch + n_chain >= 0x3FFFFFFFu) return ACX_OK;
+
+        // layout
+        size_t off = sizeof h;
+        h.off_g = off;        off = align256(off + (size_t)h.g_words * 4);
+        h.off_cells = off;    off = align256(off + (size_t)nC * 32);
+        h.off_top_val = off;  off = align256(off + (size_t)h.n_top * 4);
+        h.off_kids = off;     off = align256(off + (size_t)row_bytes);
+        h.off_kval = off;     off = align256(off + (size_t)row_bytes);
+        h.off_chains = off;   off = align256(off + ((size_t)n_chain + 1) * 16);
+        h.total_bytes = off;
+        uint8_t* sec = (uint8_t*)calloc(1, off);
+        if (!sec) return acx_fail(ACX_E_NOMEM, "acx_ppm_build: cannot allocate %zu bytes", off);
+        uint32_t* G = (uint32_t*)(sec + h.off_g);
+        uint32_t* cells = (uint32_t*)(sec + h.off_cells);
+        int32_t* top_val = (int32_t*)(sec + h.off_top_val);
+        uint32_t* kids = (uint32_t*)(sec + h.off_kids);
+        int32_t* kval = (int32_t*)(sec + h.off_kval);
+        uint32_t* chains = (uint32_t*)(sec + h.off_chains);
+
+        auto val32 = [&](const Node& nd) -> int32_t { return (int32_t)(uint32_t)(uint64_t)nd.value; };   // "ii" truncation, src/AutomatonSearchIter.c:180-184
+        std::vector<uint8_t> top_eow(h.n_top, 0);
+        std::vector<int32_t> topC_node(nC, -1);                         // arena index of node (C, code)
+        for (size_t i = 1; i < order.size(); i++) {
+            const int32_t u = order[i];
+            const Node& nd = rev.nodes[u];
+            const uint32_t d = (uint32_t)depth[u];
+            if (d <= C) {
+                if (nd.eow) { top_eow[h.top_base[d] + code[u]] = 1; top_val[h.top_base[d] + code[u]] = val32(nd); }
+                if (d == C) topC_node[code[u]] = u;
+            }
+            if (d == F && F == C + 1) G[code[u] >> 5] |= 1u << (code[u] & 31);
+        }
+        for (uint32_t b = 0; b < n_branch; b++) {
+            const int32_t u = branch_nodes[b];
+            for (int32_t c = rev.nodes[u].first_child; c >= 0; c = rev.nodes[c].next_sibling) {
+                const uint32_t s = (uint32_t)(cls[rev.nodes[c].letter] - ho);
+                const size_t k = (size_t)(b + 1) * sigma + s;
+                kids[k] = deep[c] | (rev.nodes[c].eow ? 0x80000000u : 0u);
+                if (rev.nodes[c].eow) kval[k] = val32(rev.nodes[c]);
+            }
+        }
+        for (uint32_t k = 0; k < n_chain; k++) {
+            int32_t v = chain_nodes[k]; uint32_t len = 0, label = 0;
+            do {
+                v = rev.nodes[v].first_child; len++;
+                label |= (uint32_t)(cls[rev.nodes[v].letter] - ho) << (32 - h.sym_bits * len);
+            } while (len < max_syms && !rev.nodes[v].eow && nkids[v] == 1);
+            uint32_t* rec = chains + (size_t)(k + 1) * 4;               // record of id n_branch + 1 + k
+            rec[0] = label;
+            rec[1] = len | (rev.nodes[v].eow ? 0x100u : 0u);
+            rec[2] = rev.nodes[v].eow ? (uint32_t)val32(rev.nodes[v]) : 0u;
+            rec[3] = deep[v];
+        }
+        // cells: everything the d <= C newest symbols say
+        for (uint64_t cc = 0; cc < nC; cc++) {
+            uint32_t* cell = cells + cc * 8;
+            uint64_t div = nC;
+            uint32_t mask = 0;
+            for (uint32_t d = 0; d <= C; d++) {                          // prefix code of length d = cc / sigma^(C-d)
+                if (d > 0) {
+                    const uint32_t pc = (uint32_t)(cc / div);
+                    if (top_eow[h.top_base[d] + pc]) {
+                        mask |= 1u << (d - 1);
+                        if (C - d < 5) cell[3 + (C - d)] = (uint32_t)top_val[h.top_base[d] + pc];
+                    }
+                }
+                div /= sigma;
+            }
+            cell[0] = mask;
+            const int32_t u = topC_node[cc];
+            if (u >= 0 && deep[u]) {
+                cell[1] = deep[u];
+                if (sigma <= 4) {
+                    uint32_t w = 0;
+                    for (int32_t c = rev.nodes[u].first_child; c >= 0; c = rev.nodes[c].next_sibling) {
+                        const uint32_t s1 = (uint32_t)(cls[rev.nodes[c].letter] - ho);
+                        w |= 1u << s1;
+                        if (rev.nodes[c].eow) w |= 1u << (4 + s1);
+                        for (int32_t g = rev.nodes[c].first_child; g >= 0; g = rev.nodes[g].next_sibling)
+                            w |= 1u << (8 + s1 * 4 + (uint32_t)(cls[rev.nodes[g].letter] - ho));
+                    }
+                    cell[2] = w;
+                }
+            }
+            if (F == C) { if (cell[0] | cell[1]) G[cc >> 5] |= 1u << (cc & 31); }
+            else if (cell[0]) for (uint32_t s = 0; s < sigma; s++) { const uint64_t x = cc * sigma + s; G[x >> 5] |= 1u << (x & 31); }
+        }
+        memcpy(sec, &h, sizeof h);
+        *out = sec; *nbytes = off;
+        return ACX_OK;
+    } catch (const std::bad_alloc&) {
+        return acx_fail(ACX_E_NOMEM, "acx_ppm_build: out of memory");
+    }
+}

@@ -1,0 +1,541 @@
+// acx_ppm_kernels.hip — position-parallel scan (ACX_SCAN_ALL) for gfx950.  Layout of the image:
+// include/acx_blob.h "ppm"; builder: acx_ppm.cpp; CPU restatement: oracle/ppm_walk.c.
+//
+// The reference's search loop (automaton_search_iter_next, src/AutomatonSearchIter.c:243-300) carries
+// a state from byte to byte.  What it REPORTS at position e — the keys that are suffixes of the
+// text up to e, longest first (automaton_build_output, :157-197) — depends on the last
+// longest_word bytes only, so here every position is its own unit of work:
+//
+//   k_ppm_scan     a WAVE owns a tile of 256 end positions.  It loads the tile and its left halo
+//                  (longest_word-1 bytes) with coalesced dword loads, turns bytes into packed symbols
+//                  in LDS, and every lane tests 4 positions against the filter bitmap G (LDS: "the F
+//                  newest symbols may end a key").  Positions that pass are compacted into a queue
+//                  (ballot + mbcnt); the queue is worked off 64 entries at a time: one 32-byte cell
+//                  (global, indexed by the C newest symbols), then the dense child rows of the
+//                  reversed-key trie while the walk goes on.  Matches are counted, placed with a
+//                  wave prefix sum and written as final {end_index, value} records into a scratch
+//                  pool (the global position of a tile's records is not known yet).
+//   scan           exclusive prefix sum of the per-tile counts (acx_kernels.hip).
+//   k_ppm_compact  copies every tile's records to their final place and turns tile-local offsets of
+//                  the haystack starts into match_off[].
+//
+// Integer only, no MFMA: there is no contraction on this path.  Bound by LDS lookups (one random
+// bitmap probe per position) and by L2 requests (one cell per position that passes the filter).
+#include "acx_kernels.h"
+#include "acx_ppm_layout.h"
+
+#define PPM_TILE  ACX_PPM_TILE
+#define PPM_GRANT 1024u            // records a wave takes from the scratch pool at a time
+#define PPM_NOBASE 0xFFFFFFFFu
+
+namespace {
+
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+
+// LDS traffic of one wave is ordered in hardware; this only stops the compiler from moving LDS
+// accesses across the hand-over points between lanes of the same wave.
+__device__ __forceinline__ void wave_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+}
+
+__device__ __forceinline__ uint32_t div_magic(uint32_t e, uint64_t M, uint32_t d, uint32_t& r) {
+    if (M == 0) { r = 0; return e; }                                  // d == 1
+    const uint64_t t = (uint64_t)e * (uint32_t)M;
+    const uint64_t u = (uint64_t)e * (uint32_t)(M >> 32) + (t >> 32);
+    const uint32_t q = (uint32_t)(u >> 32);
+    r = e - q * d;
+    return q;
+}
+
+// wave64 exclusive prefix sum on the DPP network (row shifts, then the two row broadcasts gfx9 has):
+// no LDS round trips.  total = sum over the wave.
+__device__ __forceinline__ uint32_t wave_excl_scan(uint32_t v, uint32_t& total) {
+    uint32_t x = v;
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x111, 0xF, 0xF, false);    // row_shr:1
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x112, 0xF, 0xF, false);    // row_shr:2
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x114, 0xF, 0xF, false);    // row_shr:4
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x118, 0xF, 0xF, false);    // row_shr:8
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x142, 0xA, 0xF, false);    // row_bcast:15 -> rows 1, 3
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x143, 0xC, 0xF, false);    // row_bcast:31 -> rows 2, 3
+    total = (uint32_t)__builtin_amdgcn_readlane((int)x, 63);
+    return x - v;
+}
+
+struct Geo {                    // wave-uniform description of a tile
+    const uint8_t* abase;       // dword-aligned address of the first staged byte
+    uint32_t q0;                // staged position of the first end position
+    uint32_t ndw;               // dwords to stage
+    int32_t  npos;              // end positions in the tile (<= 256)
+    uint32_t idx_first;         // CHUNK: end_index of the first end position
+    uint32_t halo;              // CHUNK: bytes of the same haystack in front of it (<= longest - 1)
+    uint32_t e0;                // STRIDE: global byte index of the first end position
+};
+
+template <int SB, bool POW2, bool CHUNK>
+struct Ppm {
+    const acx_ppm_args& a;
+    const uint32_t* s_g;        // LDS: filter bitmap
+    const uint8_t*  s_map;      // LDS: byte -> symbol, 0xFF = other
+    uint32_t* s_sym;            // LDS, this wave: packed symbols (pad word in front)
+    uint8_t*  s_oth;            //                 per staged dword: which bytes are "other"
+    uint16_t* s_last;           //                 per staged dword: last other position at or before its end, +1
+    uint8_t*  s_queue;          //                 positions that passed the filter, ascending
+    uint32_t* s_qoff;           //                 exclusive record offset of every queue entry (u16 or u32)
+    Geo T;
+    uint32_t has_other;         // some staged byte of this tile occurs in no key
+
+    __device__ __forceinline__ Ppm(const acx_ppm_args& a_) : a(a_) {}
+
+    __device__ __forceinline__ uint32_t qoff_get(uint32_t i) const { return a.lds.cnt32 ? s_qoff[i] : ((const uint16_t*)s_qoff)[i]; }
+    __device__ __forceinline__ void qoff_set(uint32_t i, uint32_t v) { if (a.lds.cnt32) s_qoff[i] = v; else ((uint16_t*)s_qoff)[i] = (uint16_t)v; }
+
+    // the 32 bits of packed symbols that end with staged position q: newest symbol on top
+    __device__ __forceinline__ uint32_t window(uint32_t q) const {
+        const uint32_t endbit = SB * (q + 1) + 32;
+        const uint32_t w = endbit >> 5;
+        return __builtin_amdgcn_alignbit(s_sym[w], s_sym[w - 1], endbit & 31u);
+    }
+    __device__ __forceinline__ uint32_t sym_at(uint32_t q) const {
+        const uint32_t bit = SB * q + 32;
+        return (s_sym[bit >> 5] >> (bit & 31u)) & ((1u << SB) - 1u);
+    }
+    // symbols available going back from end position p (0 = none: no match can end here)
+    __device__ __forceinline__ uint32_t limit(uint32_t p, uint32_t r /* STRIDE: offset in its haystack */) const {
+        uint32_t L = CHUNK ? T.halo + p + 1 : r + 1;
+        if (L > a.longest) L = a.longest;
+        if (has_other) {
+            const uint32_t q = T.q0 + p, dw = q >> 2;
+            const uint32_t nib = s_oth[dw] & ((2u << (q & 3u)) - 1u);
+            uint32_t last;
+            if (nib) last = 4 * dw + (31 - __clz(nib)) + 1;
+            else last = dw ? s_last[dw - 1] : 0u;
+            const uint32_t lo = q + 1 - last;
+            if (lo < L) L = lo;
+        }
+        return (int32_t)p < T.npos ? L : 0u;
+    }
+    // code of the d newest symbols of window X when only L of them exist (the rest read as 0)
+    __device__ __forceinline__ uint32_t code_of(uint32_t X, uint32_t L, uint32_t d) const {
+        if (POW2) {
+            const uint32_t Xm = SB * L >= 32 ? X : (X & ~(0xFFFFFFFFu >> (SB * L)));
+            return Xm >> (32 - SB * d);
+        }
+        uint32_t c = 0;
+        for (uint32_t i = 1; i <= d; i++) {
+            const uint32_t s = i <= L ? __builtin_amdgcn_ubfe(X, 32 - SB * i, SB) : 0u;
+            c = c * a.K + s;
+        }
+        return c;
+    }
+    __device__ __forceinline__ void codes_CF(uint32_t X, uint32_t L, uint32_t& cC, uint32_t& cF) const {
+        if (POW2) {
+            const uint32_t Xm = SB * L >= 32 ? X : (X & ~(0xFFFFFFFFu >> (SB * L)));
+            cC = Xm >> (32 - SB * a.C);
+            cF = Xm >> (32 - SB * a.F);
+            return;
+        }
+        uint32_t c = 0; cC = 0;
+        for (uint32_t i = 1; i <= a.F; i++) {
+            const uint32_t s = i <= L ? __builtin_amdgcn_ubfe(X, 32 - SB * i, SB) : 0u;
+            c = c * a.K + s;
+            if (i == a.C) cC = c;
+        }
+        cF = c;
+    }
+
+    struct Ent { uint32_t p, X, L, idx; u32x4 c0, c1; };
+
+    __device__ __forceinline__ Ent load_ent(uint32_t p) const {
+        Ent E;
+        E.p = p;
+        uint32_t r = 0;
+        if (!CHUNK) {
+            const uint32_t h = div_magic(T.e0 + p, a.stride_magic, (uint32_t)a.stride, r);
+            E.idx = r + (a.index_base ? (uint32_t)a.index_base[h] : 0u);
+        } else E.idx = T.idx_first + p;
+        E.L = limit(p, r);
+        E.X = window(T.q0 + p);
+        uint32_t cC, cF;
+        codes_CF(E.X, E.L, cC, cF);
+        const u32x4* cell = (const u32x4*)(a.cells + (size_t)cC * 8);
+        E.c0 = cell[0]; E.c1 = cell[1];
+        return E;
+    }
+
+    // Every match ending at E's position, shortest first: f(k, value) for the k-th.  Matches at or
+    // beyond `from` get their values fetched; returns the number of matches.
+    template <typename F>
+    __device__ __forceinline__ uint32_t matches(const Ent& E, uint32_t from, uint32_t upto, F&& f) const {
+        uint32_t n = 0;
+        uint32_t mask = E.c0.x;
+        if (E.L < 32) mask &= (1u << E.L) - 1u;
+        while (mask) {                                                // top levels, ascending depth
+            const uint32_t d = (uint32_t)__ffs(mask);                // depth = bit + 1
+            mask &= mask - 1;
+            if (n >= from && n < upto) {
+                const uint32_t back = a.C - d;
+                int32_t v;
+                if (back == 0) v = (int32_t)E.c0.w;
+                else if (back == 1) v = (int32_t)E.c1.x;
+                else if (back == 2) v = (int32_t)E.c1.y;
+                else if (back == 3) v = (int32_t)E.c1.z;
+                else if (back == 4) v = (int32_t)E.c1.w;
+                else v = a.top_val[a.top_base[d] + code_of(E.X, E.L, d)];
+                f(n, v);
+            }
+            n++;
+        }
+        uint32_t id = E.c0.y, d = a.C;
+        if (id && E.L > d) {
+            const uint32_t q = T.q0 + E.p;
+            bool go = true;
+            if (SB == 2 && E.c0.z) {                                  // K <= 4: the cell knows children and grandchildren
+                const uint32_t s1 = sym_at(q - d);
+                if (!((E.c0.z >> s1) & 1u)) go = false;
+                else if (!((E.c0.z >> (4 + s1)) & 1u)) {
+                    if (E.L > d + 1) { const uint32_t s2 = sym_at(q - d - 1); go = ((E.c0.z >> (8 + s1 * 4 + s2)) & 1u) != 0; }
+                    else go = false;
+                }
+            }
+            while (go && id && E.L > d) {
+                if (id <= a.n_branch) {                               // branch: one symbol through its dense row
+                    const uint32_t s = sym_at(q - d);
+                    const size_t k = (size_t)id * a.K + s;
+                    const uint32_t en = a.kids[k];
+                    if (!en) break;
+                    d++;
+                    if (en >> 31) { if (n >= from && n < upto) f(n, a.kval[k]); n++; }
+                    id = en & 0x7FFFFFFFu;
+                } else {                                              // chain: all of its symbols or nothing
+                    const u32x4 rec = *(const u32x4*)(a.chains + (size_t)(id - a.n_branch) * 4);
+                    const uint32_t len = rec.y & 0xFFu;
+                    if (E.L < d + len) break;
+                    if ((window(q - d) ^ rec.x) >> (32 - SB * len)) break;
+                    d += len;
+                    if (rec.y & 0x100u) { if (n >= from && n < upto) f(n, (int32_t)rec.z); n++; }
+                    id = rec.w;
+                }
+            }
+        }
+        return n;
+    }
+};
+
+template <int SB, bool POW2, bool CHUNK>
+__global__ void __launch_bounds__(ACX_PPM_BLOCK) k_ppm_scan(const acx_ppm_args a) {
+    extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
+    for (uint32_t i = threadIdx.x; i < a.g_words; i += blockDim.x) smem[a.lds.g_off + i] = a.g[i];
+    if (threadIdx.x < 256) {
+        const uint32_t cl = a.cls[threadIdx.x];
+        ((uint8_t*)(smem + a.lds.map_off))[threadIdx.x] = (a.has_other && cl == 0) ? 0xFFu : (uint8_t)(cl - a.has_other);
+    }
+    __syncthreads();
+
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    Ppm<SB, POW2, CHUNK> P(a);
+    P.s_g = smem + a.lds.g_off;
+    P.s_map = (const uint8_t*)(smem + a.lds.map_off);
+    uint32_t* wbase = smem + a.lds.wave_off + (uint32_t)wid * a.lds.wave_words;
+    P.s_sym = wbase;
+    P.s_oth = (uint8_t*)(wbase + a.lds.sym_words);
+    P.s_last = (uint16_t*)(P.s_oth + ((a.lds.dwords + 3u) & ~3u));
+    P.s_queue = (uint8_t*)(wbase + a.lds.sym_words + a.lds.oth_words);
+    P.s_qoff = wbase + a.lds.sym_words + a.lds.oth_words + a.lds.queue_words;
+    if (lane == 0) { P.s_sym[0] = 0; }
+
+    const int64_t n_items = CHUNK ? *a.n_items_dev : a.n_items;
+    const int64_t wave0 = (int64_t)wid * gridDim.x + blockIdx.x;      // block-minor: a partial last round spreads over all CUs
+    const int64_t n_waves = (int64_t)gridDim.x * ACX_PPM_WAVES;
+    const uint32_t pool_x = blockIdx.x % a.n_pools;
+    uint32_t g_cur = 0, g_end = 0;                                    // this wave's current grant of the scratch pool (wave-uniform)
+    const int64_t H = CHUNK ? a.hay_cap : a.n_hay * a.stride;
+    const uint8_t* const hay_end = a.hay + a.hay_cap;
+
+    // geometry of a tile from its descriptor (CHUNK) or its number (STRIDE)
+    auto geo_of = [&](int64_t tile, const acx_chunk_desc& d) -> Geo {
+        Geo G;
+        int64_t g0; uint32_t halo;
+        if (CHUNK) {
+            g0 = d.start + d.emit; G.npos = d.len - d.emit; halo = (uint32_t)d.emit; G.halo = halo;
+            G.idx_first = (uint32_t)(d.idx0 + d.emit); G.e0 = 0;
+        } else {
+            g0 = tile * PPM_TILE;
+            const int64_t left = H - g0;
+            G.npos = left < PPM_TILE ? (int32_t)left : PPM_TILE;
+            const uint32_t want = a.longest - 1;
+            halo = g0 < (int64_t)want ? (uint32_t)g0 : want;
+            G.halo = 0; G.idx_first = 0; G.e0 = (uint32_t)g0;
+        }
+        const uint8_t* first = a.hay + (g0 - halo);
+        const uint32_t shift = (uint32_t)((uintptr_t)first & 3u);
+        G.abase = first - shift;
+        G.q0 = halo + shift;
+        G.ndw = (shift + halo + (uint32_t)G.npos + 3u) >> 2;
+        return G;
+    };
+    auto load_desc = [&](int64_t tile) -> acx_chunk_desc {
+        acx_chunk_desc d;
+        d.start = 0; d.emit = 0; d.len = 0; d.idx0 = 0; d.hay = 0; d.flags = 0; d.pad = 0;
+        if (CHUNK && tile < n_items) d = a.ck[tile];
+        return d;
+    };
+    // dword i of a tile's staging area; bytes outside [hay, hay + hay_cap) read as 0
+    auto load_dw = [&](const Geo& G, uint32_t i) -> uint32_t {
+        uint32_t w = 0;
+        if (i < G.ndw) {
+            const uint8_t* pw = G.abase + 4 * (size_t)i;
+            if (pw >= a.hay && pw + 4 <= hay_end) w = *(const uint32_t*)pw;
+            else {
+#pragma nounroll
+                for (int k = 0; k < 4; k++) if (pw + k >= a.hay && pw + k < hay_end) w |= (uint32_t)pw[k] << (8 * k);
+            }
+        }
+        return w;
+    };
+
+    // software pipeline: the haystack dwords of the NEXT tile are requested while this one is worked on
+    acx_chunk_desc d_n1 = load_desc(wave0 + n_waves);
+    Geo g_cur_tile = geo_of(wave0, load_desc(wave0));
+    uint32_t pre0 = 0, pre1 = 0;
+    if (wave0 < n_items) { pre0 = load_dw(g_cur_tile, lane); pre1 = load_dw(g_cur_tile, 64 + lane); }
+
+    for (int64_t tile = wave0; tile < n_items; tile += n_waves) {
+        P.T = g_cur_tile;
+        const Geo& T = P.T;
+        const uint32_t w0 = pre0, w1 = pre1;
+        // next tile: geometry now (its descriptor arrived an iteration ago), dwords requested now, descriptor after next
+        const bool has_next = tile + n_waves < n_items;
+        Geo g_next = geo_of(tile + n_waves, d_n1);
+        if (has_next) { pre0 = load_dw(g_next, lane); pre1 = load_dw(g_next, 64 + lane); }
+        d_n1 = load_desc(tile + 2 * n_waves);
+        g_cur_tile = g_next;
+
+        // ---- stage: bytes -> packed symbols ----------------------------------------------
+        uint32_t any_other = 0, carry = 0;
+        for (uint32_t i0 = 0; i0 < T.ndw; i0 += 64) {
+            const uint32_t i = i0 + lane;
+            const uint32_t w = i0 == 0 ? w0 : (i0 == 64 ? w1 : load_dw(T, i));
+            uint32_t packed = 0, nib = 0;
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const uint32_t s = P.s_map[(w >> (8 * k)) & 0xFFu];
+                const bool oth = a.has_other && s == 0xFFu;
+                nib |= (oth ? 1u : 0u) << k;
+                packed |= (oth ? 0u : s) << (SB * k);
+            }
+            if (i < T.ndw) {
+                if (SB == 2) ((uint8_t*)(P.s_sym + 1))[i] = (uint8_t)packed;
+                else if (SB == 4) ((uint16_t*)(P.s_sym + 1))[i] = (uint16_t)packed;
+                else P.s_sym[1 + i] = packed;
+                if (a.has_other) P.s_oth[i] = (uint8_t)nib;
+            } else nib = 0;
+            if (a.has_other && __any(nib != 0)) any_other = 1;
+        }
+        if (lane == 0) {                                              // the funnel shift of the newest window reads one word further
+            const uint32_t lastw = 1 + ((T.ndw * 4 * SB + 31) >> 5);
+            P.s_sym[lastw] = 0;
+        }
+        P.has_other = any_other;
+        if (any_other) {
+            // last "other" position (+1) at or before the end of every staged dword: running maximum
+            wave_sync();
+            for (uint32_t i0 = 0; i0 < T.ndw; i0 += 64) {
+                const uint32_t i = i0 + lane;
+                const uint32_t nib = i < T.ndw ? P.s_oth[i] : 0u;
+                uint32_t last = nib ? 4 * i + (31 - __clz(nib)) + 1 : 0u;
+#pragma unroll
+                for (int d = 1; d < 64; d <<= 1) { const uint32_t t = __shfl_up(last, d, 64); if (lane >= d && t > last) last = t; }
+                if (carry > last) last = carry;
+                if (i < T.ndw) P.s_last[i] = (uint16_t)last;
+                carry = __shfl(last, 63, 64);
+            }
+        }
+        wave_sync();
+
+        // ---- filter: 4 consecutive end positions per lane; the queue keeps position order --------
+        uint32_t pm = 0;                                              // which of this lane's 4 positions passed
+        uint32_t hs_r0 = 0, hs_h0 = 0;                                // STRIDE: haystack and offset of the lane's first position
+        {
+            if (!CHUNK) hs_h0 = div_magic(T.e0 + 4 * lane, a.stride_magic, (uint32_t)a.stride, hs_r0);
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const uint32_t p = 4 * lane + k;
+                uint32_t r = 0;
+                if (!CHUNK) { r = hs_r0 + k; while (r >= (uint32_t)a.stride) r -= (uint32_t)a.stride; }
+                const uint32_t L = P.limit(p, r);
+                if (L >= a.min_len) {
+                    const uint32_t X = P.window(T.q0 + p);
+                    uint32_t cC, cF;
+                    P.codes_CF(X, L, cC, cF);
+                    pm |= ((P.s_g[cF >> 5] >> (cF & 31u)) & 1u) << k;
+                }
+            }
+        }
+        uint32_t nq;
+        const uint32_t qb = wave_excl_scan((uint32_t)__popc(pm), nq);
+        {
+            uint32_t j = qb;
+#pragma unroll
+            for (int k = 0; k < 4; k++) if ((pm >> k) & 1u) P.s_queue[j++] = (uint8_t)(4 * lane + k);
+        }
+        wave_sync();
+
+        // ---- count: one queue entry per lane and round; the first two matches keep their values ----
+        typename Ppm<SB, POW2, CHUNK>::Ent E0;
+        uint32_t c0 = 0, off0 = 0, total = 0;
+        int32_t v0a = 0, v0b = 0;
+        for (uint32_t b = 0; b < nq; b += 64) {
+            const bool act = b + lane < nq;
+            uint32_t c = 0;
+            if (act) {
+                const auto E = P.load_ent(P.s_queue[b + lane]);
+                int32_t va = 0, vb = 0;
+                c = P.matches(E, 0u, 2u, [&](uint32_t k, int32_t v) { if (k == 0) va = v; else vb = v; });
+                if (b == 0) { E0 = E; c0 = c; v0a = va; v0b = vb; }
+            }
+            uint32_t rt;
+            const uint32_t ex = wave_excl_scan(c, rt);
+            if (act) P.qoff_set(b + lane, total + ex);
+            if (b == 0) off0 = ex;
+            total += rt;
+        }
+        wave_sync();
+
+        if (!CHUNK) {                                                 // haystacks that start in this tile: their tile-local offset
+            uint32_t r0 = hs_r0, h = hs_h0;
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                if (r0 >= (uint32_t)a.stride) { r0 -= (uint32_t)a.stride; h++; }
+                if (r0 == 0 && (int32_t)(4 * lane + k) < T.npos) {
+                    const uint32_t qi = qb + (uint32_t)__popc(pm & ((1u << k) - 1u));
+                    a.hay_local[h] = (int32_t)(qi < nq ? P.qoff_get(qi) : total);
+                }
+                r0++;
+            }
+        }
+        // where this tile's records go in the scratch pool
+        uint32_t base = PPM_NOBASE;
+        if (total) {
+            if (g_cur + total > g_end || g_end == 0) {
+                const uint32_t need = total > PPM_GRANT ? total : PPM_GRANT;
+                unsigned long long o = 0;
+                if (lane == 0) o = atomicAdd(a.heads + pool_x, (unsigned long long)need);
+                o = __shfl(o, 0, 64);
+                if (o + need > a.pool_records) { if (lane == 0) *a.overflow = 1; g_cur = 0; g_end = 0; }
+                else { g_cur = (uint32_t)((unsigned long long)pool_x * a.pool_records + o); g_end = g_cur + need; }
+            }
+            if (g_end) { base = g_cur; g_cur += total; }
+        }
+        if (lane == 0) { a.counts[tile] = (int32_t)total; a.scr_off[tile] = base; }
+
+        // ---- emit: final records, longest match of a position first ------------------------------------
+        if (total && base != PPM_NOBASE) {
+            uint2* out = a.scratch + base;
+            if ((uint32_t)lane < nq && c0) {
+                const uint32_t o = off0 + c0 - 1, idx = E0.idx;
+                out[o] = make_uint2(idx, (uint32_t)v0a);
+                if (c0 > 1) out[o - 1] = make_uint2(idx, (uint32_t)v0b);
+                if (c0 > 2) P.matches(E0, 2u, 0xFFFFFFFFu, [&](uint32_t k, int32_t v) { out[o - k] = make_uint2(idx, (uint32_t)v); });
+            }
+            for (uint32_t b = 64; b < nq; b += 64) {
+                if (b + lane < nq) {
+                    const auto E = P.load_ent(P.s_queue[b + lane]);
+                    const uint32_t c = P.matches(E, 0u, 0u, [](uint32_t, int32_t) {});
+                    if (c) {
+                        const uint32_t o = P.qoff_get(b + lane) + c - 1, idx = E.idx;
+                        P.matches(E, 0u, 0xFFFFFFFFu, [&](uint32_t k, int32_t v) { out[o - k] = make_uint2(idx, (uint32_t)v); });
+                    }
+                }
+            }
+        }
+        wave_sync();
+    }
+}
+
+// records of every tile -> their final place; STRIDE scans: match_off[] from the tile offsets
+__global__ void __launch_bounds__(256) k_ppm_compact(const acx_ppm_compact_args c) {
+    const int64_t n_items = c.n_items_dev ? *c.n_items_dev : c.n_items;
+    const int64_t total = c.item_off[n_items];
+    const int sub = threadIdx.x & 15;
+    const int64_t n_groups = (int64_t)gridDim.x * 16;
+    if (total <= c.capacity) {
+        for (int64_t i = (int64_t)blockIdx.x * 16 + (threadIdx.x >> 4); i < n_items; i += n_groups) {
+            const int32_t n = c.counts[i];
+            if (n == 0) continue;
+            const uint32_t so = c.scr_off[i];
+            if (so == PPM_NOBASE) continue;
+            const u32x2* src = (const u32x2*)(c.scratch + so);
+            u32x2* dst = (u32x2*)(c.matches + c.item_off[i]);
+            for (int32_t k = sub; k < n; k += 16) __builtin_nontemporal_store(__builtin_nontemporal_load(src + k), dst + k);
+        }
+    }
+    if (c.hay_local) {
+        const int64_t n_threads = (int64_t)gridDim.x * 256;
+        for (int64_t h = (int64_t)blockIdx.x * 256 + threadIdx.x; h <= c.n_hay; h += n_threads) {
+            if (h == c.n_hay) c.match_off[h] = total;
+            else c.match_off[h] = c.item_off[(h * c.stride) / PPM_TILE] + c.hay_local[h];
+        }
+    }
+}
+
+int g_num_cus = 0;
+int num_cus() {
+    if (g_num_cus == 0) {
+        int dev = 0; hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
+            g_num_cus = prop.multiProcessorCount;
+        else g_num_cus = 256;
+    }
+    return g_num_cus;
+}
+
+}  // namespace
+
+int acx_num_cus() { return num_cus(); }
+
+int64_t acx_ppm_grid_blocks(const acx_ppm_lds& lds, int64_t n_items_bound) {
+    const size_t lds_bytes = (size_t)lds.total_words * 4;
+    const int bpc = lds_bytes * 2 <= ACX_PPM_LDS_BYTES ? 2 : 1;       // 1024-thread blocks: at most 2 per CU
+    int64_t blocks = (n_items_bound + ACX_PPM_WAVES - 1) / ACX_PPM_WAVES;
+    const int64_t cap = (int64_t)num_cus() * bpc;
+    if (blocks > cap) blocks = cap;
+    return blocks < 1 ? 1 : blocks;
+}
+
+hipError_t acx_launch_ppm_scan(const acx_ppm_args& a, int64_t n_items_bound, hipStream_t s) {
+    if (n_items_bound <= 0) return hipSuccess;
+    const size_t lds_bytes = (size_t)a.lds.total_words * 4;
+    if (lds_bytes > ACX_PPM_LDS_BYTES || a.n_pools == 0) return hipErrorInvalidValue;
+    const int64_t blocks = acx_ppm_grid_blocks(a.lds, n_items_bound);
+    const bool chunk = a.ck != nullptr;
+    auto launch = [&](auto kernel) -> hipError_t {
+        hipError_t e = hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL(kernel, dim3((unsigned)blocks), dim3(ACX_PPM_BLOCK), lds_bytes, s, a);
+        return hipGetLastError();
+    };
+#define PPM_CASE(SB) \
+    do { \
+        if (a.pow2) { if (chunk) return launch(k_ppm_scan<SB, true, true>); return launch(k_ppm_scan<SB, true, false>); } \
+        if (chunk) return launch(k_ppm_scan<SB, false, true>); return launch(k_ppm_scan<SB, false, false>); \
+    } while (0)
+    if (a.sym_bits == 2) PPM_CASE(2);
+    if (a.sym_bits == 4) PPM_CASE(4);
+    if (a.sym_bits == 8) PPM_CASE(8);
+#undef PPM_CASE
+    return hipErrorInvalidValue;
+}
+
+hipError_t acx_launch_ppm_compact(const acx_ppm_compact_args& c, int64_t n_items_bound, hipStream_t s) {
+    int64_t blocks = (n_items_bound + 15) / 16;
+    const int64_t hb = c.hay_local ? (c.n_hay + 256) / 256 : 0;
+    if (hb > blocks) blocks = hb;
+    const int64_t cap = (int64_t)num_cus() * 32;
+    if (blocks > cap) blocks = cap;
+    if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(k_ppm_compact, dim3((unsigned)blocks), dim3(256), 0, s, c);
+    return hipGetLastError();
+}

@@ -1,0 +1,47 @@
+// acx_ppm_layout.h — LDS budget of the position-parallel scan (include/acx_blob.h "ppm"), shared by
+// the builder (acx_ppm.cpp: how large may the filter bitmap be?) and the launcher
+// (acx_ppm_kernels.hip: where does everything live?).  Internal to libacx.
+#ifndef ACX_PPM_LAYOUT_H_INCLUDED
+#define ACX_PPM_LAYOUT_H_INCLUDED
+
+#include <stddef.h>
+#include <stdint.h>
+#include "acx_blob.h"
+
+#define ACX_PPM_BLOCK      1024u                    /* threads per block: 16 waves share one filter bitmap */
+#define ACX_PPM_WAVES      (ACX_PPM_BLOCK / 64u)
+#define ACX_PPM_LDS_BYTES  (160u * 1024u)
+#define ACX_PPM_MAX_LONGEST 1024u                   /* longer keys: the serial walk kernels */
+
+// Per-wave staging, in 32-bit words.
+//   sym   : packed symbols of the tile and its left halo (longest - 1 bytes), one pad word in front
+//           (a window of 32 bits ends at every position) and one behind (the funnel shift reads it)
+//   oth   : one byte per staged dword: which of its 4 bytes occur in no key; then one uint16 per
+//           staged dword: the last such position at or before the dword's end (+1; 0 = none)
+//   queue : positions that passed the filter (one byte each)
+//   cnt   : matches per position, then their exclusive prefix sum (uint16, or uint32 for long keys)
+struct acx_ppm_lds {
+    uint32_t dwords;        // staged haystack dwords per tile
+    uint32_t sym_words, oth_words, queue_words, cnt_words, wave_words;
+    uint32_t g_off, map_off, wave_off, total_words;     // word offsets inside the block's LDS
+    uint32_t cnt32;         // 1: cnt/off entries are 32 bits wide
+};
+
+static inline acx_ppm_lds acx_ppm_lds_layout(uint32_t g_words, uint32_t sym_bits, uint32_t longest) {
+    acx_ppm_lds L;
+    const uint32_t halo = longest > 0 ? longest - 1 : 0;
+    L.dwords = (ACX_PPM_TILE + halo + 3) / 4 + 1;                       // unaligned start: one more
+    L.sym_words = ((L.dwords * 4 * sym_bits + 31) / 32 + 2 + 3u) & ~3u;
+    L.oth_words = ((L.dwords + 3) / 4 + (L.dwords * 2 + 3) / 4 + 3u) & ~3u;
+    L.queue_words = ACX_PPM_TILE / 4;
+    L.cnt32 = (uint64_t)longest * ACX_PPM_TILE >= 65536u ? 1u : 0u;
+    L.cnt_words = L.cnt32 ? ACX_PPM_TILE : ACX_PPM_TILE / 2;
+    L.wave_words = (L.sym_words + L.oth_words + L.queue_words + L.cnt_words + 3u) & ~3u;
+    L.g_off = 0;
+    L.map_off = (g_words + 3u) & ~3u;
+    L.wave_off = L.map_off + 64;                                       // byte -> symbol map: 256 bytes
+    L.total_words = L.wave_off + ACX_PPM_WAVES * L.wave_words;
+    return L;
+}
+
+#endif

@@ -339,6 +339,15 @@ int acx_flatten(const acx_trie_t* t, void** blob_out, size_t* nbytes_out) {
         return acx_fail(ACX_E_UNSUPPORTED, "acx_flatten: %llu output entries exceed uint32 CSR offsets",
                         (unsigned long long)n_out);
 
+    // 1c. position-parallel scan image (acx_ppm.cpp): its own relocatable section, appended last
+    uint8_t* ppm = nullptr;
+    size_t ppm_bytes = 0;
+    {
+        const int rcp = acx_ppm_build(t, cls, K, has_other, &ppm, &ppm_bytes);
+        if (rcp) return rcp;
+    }
+    struct PpmFree { uint8_t* p; ~PpmFree() { free(p); } } ppm_guard{ppm};
+
     // 2. layout
     acx_blob_header h;
     memset(&h, 0, sizeof h);
@@ -382,12 +391,14 @@ int acx_flatten(const acx_trie_t* t, void** blob_out, size_t* nbytes_out) {
         h.off_itop_ebits = off;  off = align_up(off + itop_bm_words(itop_D) * 4);
         h.off_itop_cells = off;  off = align_up(off + ((size_t)itop_cell_bytes << (itop_b * itop_D)));
     }
+    if (ppm) { h.off_ppm = off; off = align_up(off + ppm_bytes); }
     const size_t total = off;
 
     uint8_t* blob = (uint8_t*)calloc(1, total);
     if (!blob) return acx_fail(ACX_E_NOMEM, "acx_flatten: cannot allocate %zu bytes for the image", total);
 
     memcpy(blob + h.off_cls, cls, 256);
+    if (ppm) memcpy(blob + h.off_ppm, ppm, ppm_bytes);
     uint32_t* table   = (uint32_t*)(blob + h.off_table);
     int32_t*  fail    = (int32_t*)(blob + h.off_fail);
     int32_t*  nval    = (int32_t*)(blob + h.off_node_val);
@@ -581,6 +592,8 @@ int acx_blob_check_header(const acx_blob_header* h, size_t nbytes) {
     for (auto& s : sec)
         if (s.off % ACX_BLOB_ALIGN || s.off < ACX_BLOB_HEADER_BYTES || s.off + s.len > nbytes)
             return acx_fail(ACX_E_FORMAT, "image: section out of bounds");
+    if (h->off_ppm && (h->off_ppm % ACX_BLOB_ALIGN || h->off_ppm < ACX_BLOB_HEADER_BYTES || h->off_ppm + sizeof(acx_ppm_header) > nbytes))
+        return acx_fail(ACX_E_FORMAT, "image: ppm section out of bounds");
     if (h->state_bits == ACX_STATE_BITS_NARROW && n * K * 4 >= (1ull << 32))
         return acx_fail(ACX_E_FORMAT, "image: table too large for the narrow layout's 32-bit offsets");
     return ACX_OK;

@@ -191,7 +191,7 @@ def test_chunked_scan_equals_direct_scan_and_oracle():
     d_init = DeviceBuffer.from_numpy(init)
     d_base = DeviceBuffer.from_numpy(base)
     out = {}
-    for variant in (0, 1 << 13):
+    for variant in (0, 1 << 13):       # (a carried-in state: the serial walks, chunked and lane-per-haystack)
         sc = Scanner(img)
         sc.scan(d_hay, len(data), n, dev_off=d_off, dev_init_state=d_init, dev_index_base=d_base,
                 want_final_state=True, variant=variant)
@@ -408,7 +408,7 @@ def test_implicit_top_kernel_equals_plain_kernel():
         d_hay = DeviceBuffer.from_numpy(reads.reshape(-1), pad=64)
         d_off = DeviceBuffer.from_numpy(off)
         outs = []
-        for variant in (0, 1 << 17, 1 << 16):          # itop, itop with 2 items per lane, plain walk
+        for variant in (0, 1 << 23, (1 << 23) | (1 << 17), (1 << 23) | (1 << 16)):   # position-parallel; serial: itop, itop with 2 items per lane, plain walk
             sc = Scanner(img)
             sc.scan(d_hay, n * L, n, stride=L, want_final_state=True, variant=variant)
             outs.append(sc.fetch())
@@ -547,7 +547,7 @@ def _scan_all_ways(A, O, reads, n, L):
     d_hay = DeviceBuffer.from_numpy(reads.reshape(-1), pad=64)
     d_off = DeviceBuffer.from_numpy(off)
     fins = []
-    for variant in (0, 1 << 17, 1 << 16):
+    for variant in (0, 1 << 23, (1 << 23) | (1 << 17), (1 << 23) | (1 << 16)):
         sc = Scanner(img)
         for kw in (dict(stride=L), dict(dev_off=d_off)):
             sc.scan(d_hay, n * L, n, want_final_state=True, variant=variant, **kw)

@@ -1,0 +1,85 @@
+"""Position-parallel scan image (include/acx_blob.h "ppm", built by csrc/acx_ppm.cpp): the CPU
+restatement oracle/ppm_walk.c walks it position by position and must reproduce the reference's
+iter() output (the pinned oracle, the reference-generated fixtures) on every dictionary shape."""
+import random
+import struct
+
+import pytest
+
+from helpers import build_pair, expected_pairs, load_json, dna_workload
+from oracle import orc
+
+RANDOM = load_json("ref_random.json")
+VECTORS = load_json("ref_vectors.json")
+
+
+def _ppm_header(blob):
+    off_ppm = struct.unpack_from("<Q", blob, 248)[0]
+    if not off_ppm:
+        return None
+    names = ("magic", "K", "sym_bits", "pow2", "C", "F")
+    return dict(zip(names, struct.unpack_from("<6I", blob, off_ppm)))
+
+
+def _case_values(c):
+    keys = [bytes.fromhex(k) for k in c["keys_hex"]]
+    return keys, c.get("values")
+
+
+@pytest.mark.parametrize("c", RANDOM["cases"], ids=[c["id"] for c in RANDOM["cases"]])
+def test_ppm_walk_matches_reference_fixtures(c):
+    keys, values = _case_values(c)
+    A, O = build_pair(keys, values if c["store"] not in ("length", "ints_default") else None, c["store"])
+    blob = A.flat_image_bytes()
+    assert _ppm_header(blob) is not None
+    for h in c["hays"]:
+        hay = bytes.fromhex(h["hay_hex"])
+        assert orc.ppm_iter(blob, hay) == expected_pairs(h["iter"])
+
+
+def test_ppm_walk_randomised_vs_oracle():
+    rng = random.Random(23)
+    shapes = set()
+    for trial in range(60):
+        alpha = rng.choice([b"a", b"ab", b"abc", b"ACGT", b"ACGTN", bytes(range(97, 97 + 16)), bytes(range(97, 97 + 26)) + b" ",
+                            bytes([0x61, 0x80, 0xFF, 0x00]), bytes(range(256))])
+        maxlen = rng.choice([3, 9, 14, 40])
+        keys = list({bytes(rng.choice(alpha) for _ in range(rng.randint(1, maxlen))) for _ in range(rng.randint(1, 200))})
+        vals = [rng.randint(-2**40, 2**40) for _ in keys]
+        A, O = build_pair(keys, vals)
+        blob = A.flat_image_bytes()
+        hdr = _ppm_header(blob)
+        assert hdr is not None
+        shapes.add((hdr["sym_bits"], hdr["pow2"], hdr["F"] > hdr["C"]))
+        text_alpha = alpha if rng.random() < 0.5 else alpha + b"#"       # a byte no key contains
+        for _ in range(8):
+            hay = bytes(rng.choice(text_alpha) for _ in range(rng.randint(0, 300)))
+            assert orc.ppm_iter(blob, hay) == O.iter(hay), (alpha, keys[:5])
+    assert {s[0] for s in shapes} == {2, 4, 8} and {s[1] for s in shapes} == {0, 1}
+
+
+def test_ppm_walk_many_outputs_per_position():
+    keys = [b"a" * n for n in range(1, 41)]
+    A, O = build_pair(keys, list(range(100, 140)))
+    blob = A.flat_image_bytes()
+    hay = b"a" * 50 + b"b" + b"a" * 45
+    assert orc.ppm_iter(blob, hay) == O.iter(hay)
+
+
+def test_ppm_walk_dna_dictionary_deep_rows():
+    """config-2-like dictionary at reduced size: cells with child and grandchild summaries, deep rows"""
+    keys, reads = dna_workload(20000, 300, 150, seed=3)
+    A, O = build_pair(list(keys))
+    blob = A.flat_image_bytes()
+    hdr = _ppm_header(blob)
+    assert hdr["K"] == 4 and hdr["sym_bits"] == 2 and hdr["pow2"] == 1 and hdr["F"] == hdr["C"] + 1
+    for r in reads[:300]:
+        hay = r.tobytes()
+        assert orc.ppm_iter(blob, hay) == O.iter(hay)
+
+
+def test_ppm_absent_when_disabled(monkeypatch):
+    monkeypatch.setenv("ACX_NO_PPM", "1")
+    A, O = build_pair([b"he", b"she"])
+    assert _ppm_header(A.flat_image_bytes()) is None
+    assert orc.ppm_iter(A.flat_image_bytes(), b"ushers") is None
