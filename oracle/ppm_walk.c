@@ -28,9 +28,8 @@ int64_t ppm_iter(const uint8_t* blob, const uint8_t* hay, int64_t len, int32_t i
     const uint32_t* G = (const uint32_t*)(sec + h.off_g);
     const uint32_t* cells = (const uint32_t*)(sec + h.off_cells);
     const int32_t* top_val = (const int32_t*)(sec + h.off_top_val);
-    const uint32_t* kids = (const uint32_t*)(sec + h.off_kids);
-    const int32_t* kval = (const int32_t*)(sec + h.off_kval);
-    const uint32_t* chains = (const uint32_t*)(sec + h.off_chains);
+    const uint32_t* rows = (const uint32_t*)(sec + h.off_kids);        /* K 16-byte records per row */
+    const uint32_t* singles = (const uint32_t*)(sec + h.off_chains);   /* one 16-byte record per single */
     const uint32_t K = h.K, C = h.C, F = h.F, ho = h.has_other, SB = h.sym_bits;
     int64_t n = 0;
     int64_t last_other = -1;            /* last position holding a byte no key contains */
@@ -58,13 +57,13 @@ int64_t ppm_iter(const uint8_t* blob, const uint8_t* hay, int64_t len, int32_t i
             for (uint32_t d = 1; d <= C; d++) {
                 const uint32_t s = (int64_t)d <= L ? (uint32_t)(cls[hay[e - (d - 1)]] - ho) : 0u;
                 pc = pc * K + s;
-                if ((mask >> (d - 1)) & 1u) {
-                    const int32_t v = (C - d < 5) ? (int32_t)cell[3 + (C - d)] : top_val[h.top_base[d] + pc];
+                if ((mask >> (d - 1)) & 1u) {           /* the cell lists the values of its first five levels */
+                    const int32_t v = nm < 5 ? (int32_t)cell[3 + nm] : top_val[h.top_base[d] + pc];
                     if (nm < PPM_MAX_MATCH) mv[nm++] = v;
                 }
             }
         }
-        /* deeper: dense child rows; K <= 4: the cell already knows children and grandchildren */
+        /* deeper: one 16-byte record per step; K <= 4: the cell already knows children and grandchildren */
         uint32_t id = cell[1];
         int64_t d = C;                  /* depth of `id` */
         if (id && L > d) {
@@ -80,25 +79,23 @@ int64_t ppm_iter(const uint8_t* blob, const uint8_t* hay, int64_t len, int32_t i
                     } else go = 0;
                 }
             }
-            while (go && id && L > d) {
-                if (id <= h.n_deep) {                   /* branch: one symbol through its dense row */
-                    const uint32_t s = (uint32_t)(cls[hay[e - d]] - ho);
-                    const uint32_t en = kids[(size_t)id * K + s];
-                    if (!en) break;
-                    d++;
-                    if (en >> 31) { if (nm < PPM_MAX_MATCH) mv[nm++] = kval[(size_t)id * K + s]; }
-                    id = en & 0x7FFFFFFFu;
-                } else {                                /* chain: all of its symbols or nothing */
-                    const uint32_t* rec = chains + (size_t)(id - h.n_deep) * 4;
-                    const uint32_t len = rec[1] & 0xFFu;
-                    if (L < d + (int64_t)len) break;
-                    uint32_t label = 0;
-                    for (uint32_t i = 0; i < len; i++) label |= (uint32_t)(cls[hay[e - d - i]] - ho) << (32 - SB * (i + 1));
-                    if (label != rec[0]) break;
-                    d += len;
-                    if (rec[1] & 0x100u) { if (nm < PPM_MAX_MATCH) mv[nm++] = (int32_t)rec[2]; }
-                    id = rec[3];
+            while (go && id) {
+                const uint32_t* rec;
+                uint32_t first;
+                if (id >> 31) { rec = singles + (size_t)(id & 0x7FFFFFFFu) * 4; first = 0; }
+                else {
+                    if (L <= d) break;
+                    rec = rows + ((size_t)id * K + (uint32_t)(cls[hay[e - d]] - ho)) * 4; first = 1;
                 }
+                if (!(rec[1] & 0x200u)) break;          /* no child on this symbol */
+                const uint32_t len = rec[1] & 0xFFu;
+                if (L < d + (int64_t)first + len) break;
+                uint32_t label = 0;
+                for (uint32_t i = 0; i < len; i++) label |= (uint32_t)(cls[hay[e - d - first - i]] - ho) << (32 - SB * (i + 1));
+                if (label != rec[0]) break;
+                d += first + len;
+                if (rec[1] & 0x100u) { if (nm < PPM_MAX_MATCH) mv[nm++] = (int32_t)rec[2]; }
+                id = rec[3];
             }
         }
         for (int k = nm - 1; k >= 0; k--) {          /* longest first */

@@ -271,6 +271,7 @@ struct acx_result {
     acx_ppm_args pend_pa; acx_ppm_compact_args pend_ca; int64_t pend_items = 0;
     const int32_t* pend_counts = nullptr; int64_t* pend_item_off = nullptr;
     acx_chunk_args pend_cka; acx_walk_args pend_tail; bool ppm_chunk = false, ppm_tail = false;
+    bool ppm_stream = false; acx_ppm_gather_args pend_ga; DevBuf<uint32_t> wave_desc;
     acx_image* pend_img = nullptr;
     PinBuf<int64_t> h_off;
     PinBuf<acx_match_t> h_matches;
@@ -297,7 +298,7 @@ struct acx_result {
         if (pending) (void)hipStreamSynchronize(stream);
         counts.release(); nev.release(); final_state.release(); match_off.release(); partials.release();
         nck.release(); ck_first.release(); ck_match_off.release(); ck.release();
-        scratch.release(); scr_off.release(); ppm_ctl.release(); hay_local.release();
+        scratch.release(); scr_off.release(); ppm_ctl.release(); hay_local.release(); wave_desc.release();
         events.release(); matches.release(); h_off.release(); h_matches.release(); h_final.release(); h_total.release();
         in_hay.release(); in_off.release(); in_init.release(); in_base.release();
         for (auto& e : ev) if (e) (void)hipEventDestroy(e);
@@ -323,13 +324,15 @@ static int ppm_complete(acx_result* r) {
         if (small) {
             if ((rc = r->matches.ensure((size_t)r->total))) return rc;
             r->pend_ca.matches = r->matches.p; r->pend_ca.capacity = (int64_t)r->matches.cap;
+            r->pend_ga.matches = r->matches.p; r->pend_ga.capacity = (int64_t)r->matches.cap;
         }
         if (overflow) {
             const size_t have = r->scratch.cap, need = (size_t)r->total;
             if ((rc = ppm_size_pool(r, (need > have ? need : have) + need / 2))) return rc;
             if ((rc = ppm_enqueue(r, r->pend_img, r->ppm_chunk ? &r->pend_cka : nullptr, r->ppm_tail ? &r->pend_tail : nullptr, s))) return rc;
         } else {
-            HIP_TRY(acx_launch_ppm_compact(r->pend_ca, r->pend_items, s));
+            if (r->ppm_stream) HIP_TRY(acx_launch_ppm_gather(r->pend_pa.wave_desc, r->pend_ga.n_waves, r->pend_item_off, r->pend_ga, s));
+            else HIP_TRY(acx_launch_ppm_compact(r->pend_ca, r->pend_items, s));
             HIP_TRY(hipEventRecord(r->done, s));
         }
     }
@@ -413,14 +416,19 @@ static int ppm_enqueue(acx_result* r, acx_image* img, const acx_chunk_args* ca, 
     if (r->timed) HIP_TRY(hipEventRecord(r->ev[0], s));
     HIP_TRY(acx_launch_ppm_scan(pa, ni, s));
     if (r->timed) HIP_TRY(hipEventRecord(r->ev[1], s));
-    HIP_TRY(acx_launch_scan(r->pend_counts, ni, r->pend_item_off, r->partials.p, s));
-    if (r->timed_all) HIP_TRY(hipEventRecord(r->ev[2], s));
-    HIP_TRY(acx_launch_ppm_compact(r->pend_ca, ni, s));
-    if (ca) HIP_TRY(acx_launch_hay_offsets(r->ck_first.p, r->ck_match_off.p, ca->n_hay, r->match_off.p, s));
+    if (r->ppm_stream) {
+        if (r->timed_all) HIP_TRY(hipEventRecord(r->ev[2], s));
+        HIP_TRY(acx_launch_ppm_gather(pa.wave_desc, r->pend_ga.n_waves, r->pend_item_off, r->pend_ga, s));
+    } else {
+        HIP_TRY(acx_launch_scan(r->pend_counts, ni, r->pend_item_off, r->partials.p, s));
+        if (r->timed_all) HIP_TRY(hipEventRecord(r->ev[2], s));
+        HIP_TRY(acx_launch_ppm_compact(r->pend_ca, ni, s));
+        if (ca) HIP_TRY(acx_launch_hay_offsets(r->ck_first.p, r->ck_match_off.p, ca->n_hay, r->match_off.p, s));
+    }
     if (r->timed_all) HIP_TRY(hipEventRecord(r->ev[3], s));
     if (tail) HIP_TRY(acx_launch_tail_state(*tail, (int32_t)img->ppm.longest, s));
     r->h_total.p[1] = 0;
-    HIP_TRY(hipMemcpyAsync(r->h_total.p, r->pend_item_off + ni, sizeof(int64_t), hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipMemcpyAsync(r->h_total.p, r->pend_item_off + (r->ppm_stream ? r->pend_ga.n_waves : ni), sizeof(int64_t), hipMemcpyDeviceToHost, s));
     HIP_TRY(hipMemcpyAsync(r->h_total.p + 1, r->ppm_ctl.p + 8, sizeof(int32_t), hipMemcpyDeviceToHost, s));
     if (!r->done) HIP_TRY(hipEventCreateWithFlags(&r->done, hipEventDisableTiming));
     HIP_TRY(hipEventRecord(r->done, s));
@@ -433,13 +441,13 @@ static int ppm_size_pool(acx_result* r, size_t records) {
     const int64_t blocks = acx_ppm_grid_blocks(pa.lds, r->pend_items);
     pa.n_pools = (uint32_t)(blocks < 8 ? blocks : 8);
     const size_t slack = (size_t)blocks * ACX_PPM_WAVES * 1024u;
-    size_t want = records + records / 4 + slack + 1024;
+    size_t want = records + records / 2 + slack + 1024;
     if (want >= 0xFFFFFFF0ull) want = 0xFFFFFFF0ull;                 // tile offsets into the pool are 32-bit
     int rc = r->scratch.ensure(want);
     if (rc) return rc;
     size_t cap = r->scratch.cap < 0xFFFFFFF0ull ? r->scratch.cap : 0xFFFFFFF0ull;
     pa.scratch = r->scratch.p; pa.pool_records = cap / pa.n_pools;
-    r->pend_ca.scratch = r->scratch.p;
+    r->pend_ca.scratch = r->scratch.p; r->pend_ga.scratch = r->scratch.p;
     return ACX_OK;
 }
 
@@ -484,6 +492,37 @@ static int scan_ppm(acx_image_t* img, const acx_scan_params* p, acx_result* r, h
     pa.counts = r->counts.p; pa.scr_off = r->scr_off.p;
     pa.heads = r->ppm_ctl.p; pa.overflow = (int32_t*)(r->ppm_ctl.p + 8);
     pa.hay_local = chunked ? nullptr : r->hay_local.p;
+    pa.dbg = (uint32_t)(p->variant >> 25) & 7u;
+    {   // k_ppm_stream: fixed stride, aligned buffer, codes that are bit fields, a halo of at most one sub-step
+        const uint32_t unit = 32u / ph.sym_bits < 4u ? 4u : 32u / ph.sym_bits;
+        pa.halo_pos = ph.longest > 1 ? ((ph.longest - 1 + unit - 1) / unit) * unit : unit;
+        pa.fast = !chunked && ph.pow2 && p->stride >= 8 && ((uintptr_t)p->dev_hay & 3u) == 0 && pa.halo_pos <= ACX_PPM_TILE &&
+                  p->n_hay * p->stride <= 0xFFFFF000ll && !((p->variant >> 24) & 1);     // variant bit 24: the general kernel (A/B)
+    }
+    r->ppm_stream = pa.fast != 0;
+    int64_t stream_tiles = 0;
+    if (pa.fast) {
+        pa.nsub = 4;
+        while (pa.nsub > 1 && acx_ppm_stream_layout(ph.g_words, ph.sym_bits, pa.halo_pos, pa.nsub).total_words * 4 > ACX_PPM_LDS_BYTES) pa.nsub >>= 1;
+        pa.lds = acx_ppm_stream_layout(ph.g_words, ph.sym_bits, pa.halo_pos, pa.nsub);
+        if (pa.lds.total_words * 4 > ACX_PPM_LDS_BYTES) { pa.fast = 0; r->ppm_stream = false; pa.lds = acx_ppm_lds_layout(ph.g_words, ph.sym_bits, ph.longest); }
+    }
+    if (pa.fast) {
+        const int64_t tpos = (int64_t)pa.nsub * 256;
+        stream_tiles = (p->n_hay * p->stride + tpos - 1) / tpos;
+        pa.m24 = p->stride < 1024 ? (uint32_t)(((1u << 24) + (uint32_t)p->stride - 1) / (uint32_t)p->stride) : 0u;
+        const int64_t blocks = acx_ppm_grid_blocks(pa.lds, stream_tiles);
+        const int64_t n_waves = blocks * ACX_PPM_WAVES;
+        if ((rc = r->wave_desc.ensure((size_t)n_waves * ACX_PPM_DESC_WORDS))) return rc;
+        if ((rc = r->ck_match_off.ensure((size_t)n_waves + 1))) return rc;
+        pa.wave_desc = r->wave_desc.p;
+        acx_ppm_gather_args& ga = r->pend_ga;
+        memset(&ga, 0, sizeof ga);
+        ga.wave_desc = r->wave_desc.p; ga.wave_off = r->ck_match_off.p; ga.n_waves = n_waves;
+        ga.matches = r->matches.p; ga.capacity = (int64_t)r->matches.cap;
+        ga.hay_local = r->hay_local.p; ga.match_off = r->match_off.p; ga.n_hay = p->n_hay; ga.stride = p->stride;
+        ga.tile_pos = tpos; ga.tpw = (stream_tiles + n_waves - 1) / n_waves;
+    }
 
     acx_ppm_compact_args& ca = r->pend_ca;
     memset(&ca, 0, sizeof ca);
@@ -491,7 +530,7 @@ static int scan_ppm(acx_image_t* img, const acx_scan_params* p, acx_result* r, h
     ca.item_off = r->ck_match_off.p; ca.n_items = n_items; ca.n_items_dev = nullptr;
     ca.matches = r->matches.p; ca.capacity = (int64_t)r->matches.cap;
     ca.hay_local = chunked ? nullptr : r->hay_local.p; ca.match_off = r->match_off.p; ca.n_hay = p->n_hay; ca.stride = p->stride;
-    r->pend_items = n_items; r->pend_counts = r->counts.p; r->pend_item_off = r->ck_match_off.p;
+    r->pend_items = pa.fast ? stream_tiles : n_items; r->pend_counts = r->counts.p; r->pend_item_off = r->ck_match_off.p;
     if ((rc = ppm_size_pool(r, r->matches.cap))) return rc;
 
     r->ppm_chunk = chunked;

@@ -110,6 +110,12 @@ struct acx_ppm_args {
     uint32_t K, sym_bits, pow2, C, F, g_words, has_other, longest, min_len;
     uint32_t top_base[ACX_PPM_MAX_C + 2];
     acx_ppm_lds lds;
+    uint32_t fast;           // 1: k_ppm_stream (fixed stride >= 4, aligned buffer, bit-field codes, halo_pos <= 256)
+    uint32_t dbg;            // tuning only (variant bits 25..27): 1 = no exact phase, 2 = no emit, 4 = no filter
+    uint32_t nsub;           // k_ppm_stream: sub-steps of 256 positions per tile (1, 2 or 4)
+    uint32_t m24;            // k_ppm_stream: ceil(2^24 / stride) for strides below 1024, else 0
+    uint32_t* wave_desc;     // k_ppm_stream: per wave {records, grants, 16 x base, 16 x count}
+    uint32_t halo_pos;       // k_ppm_stream: staged halo positions (multiple of 32 / sym_bits and of 4, >= longest - 1)
     // outputs
     int32_t*  counts;        // matches per tile
     uint32_t* scr_off;       // where the tile's records start in `scratch` (0xFFFFFFFF: none)
@@ -128,6 +134,14 @@ struct acx_ppm_compact_args {
     // fixed-stride batches: match_off[h] = item_off[h * stride / TILE] + hay_local[h]
     const int32_t* hay_local; int64_t* match_off; int64_t n_hay; int64_t stride;
 };
+struct acx_ppm_gather_args {       // k_ppm_stream results -> final place
+    const uint32_t* wave_desc; const int64_t* wave_off; int64_t n_waves;
+    const uint2* scratch; uint2* matches; int64_t capacity;
+    const int32_t* hay_local; int64_t* match_off; int64_t n_hay; int64_t stride;
+    int64_t tile_pos, tpw;         // positions per tile, tiles per wave
+};
+#define ACX_PPM_DESC_WORDS 40
+hipError_t acx_launch_ppm_gather(const uint32_t* wave_desc, int64_t n_waves, int64_t* wave_off, const acx_ppm_gather_args& c, hipStream_t s);
 hipError_t acx_launch_ppm_scan(const acx_ppm_args& a, int64_t n_items_bound, hipStream_t s);
 hipError_t acx_launch_ppm_compact(const acx_ppm_compact_args& c, int64_t n_items_bound, hipStream_t s);
 int64_t acx_ppm_grid_blocks(const acx_ppm_lds& lds, int64_t n_items_bound);   // blocks of a k_ppm_scan launch

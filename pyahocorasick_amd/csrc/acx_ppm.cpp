@@ -122,41 +122,58 @@ int acx_ppm_build(const acx_trie* t, const uint8_t* cls, uint32_t n_classes, boo
         }
         h.min_len = min_len;
 
-        // Deep structure: nodes at depth >= C that have children.  A node with two or more children is
-        // a BRANCH (a dense row of K child entries); a node with exactly one child starts a CHAIN: up
-        // to 32 / sym_bits symbols that must all match, ending at the first node that is a key, a
-        // branch or a leaf.  Random text leaves the trie within a level or two of the cells; the
-        // long walks are occurrences of long keys, whose tails are unbranched: a chain record per
-        // 16 (4, 2) symbols instead of one dependent gather per symbol.
-        std::vector<uint32_t> deep(n, 0);           // id of a node that the walk can stand on (0: none yet)
-        std::vector<int32_t> branch_nodes, chain_nodes;
+        // Deep structure: what the walk needs below the cells.  The walk STANDS on a node that has
+        // children and takes one step per gather: a 16-byte record {label, len | flags, value, next}
+        // that consumes 1 + len symbols (rows) or len symbols (singles):
+        //   a node with two or more children owns a ROW of K records, indexed by the next symbol;
+        //   a node with exactly one child owns a SINGLE record (its id carries bit 31).
+        // A record follows the unbranched path below its first edge for up to 32 / sym_bits symbols,
+        // stopping at the first node that is a key, branches or is a leaf; `next` is the id of that
+        // node if it has children.  Random text leaves the trie within a level or two of the cells;
+        // the long walks are occurrences of long keys, whose tails are unbranched.
+        std::vector<uint32_t> deep(n, 0);           // id of a node the walk can stand on (0: none)
+        std::vector<int32_t> row_nodes, single_nodes;
+        auto path_end = [&](int32_t c, uint32_t& len, uint32_t& label, uint32_t first) -> int32_t {
+            // follow the unbranched, key-free path below node c (which was reached by `first` counted symbols)
+            int32_t v = c;
+            while (len < max_syms && !rev.nodes[v].eow && nkids[v] == 1) {
+                v = rev.nodes[v].first_child; len++;
+                label |= (uint32_t)(cls[rev.nodes[v].letter] - ho) << (32 - h.sym_bits * len);
+            }
+            (void)first;
+            return v;
+        };
         {
             std::vector<int32_t> work;
-            auto want = [&](int32_t u) {           // make sure node u (depth >= C, has children) gets an id
+            auto want = [&](int32_t u) {           // node u (has children) gets an id
                 if (deep[u]) return;
-                if (nkids[u] >= 2) { branch_nodes.push_back(u); deep[u] = (uint32_t)branch_nodes.size(); }          // ids 1..n_branch
-                else { chain_nodes.push_back(u); deep[u] = 0x40000000u | (uint32_t)chain_nodes.size(); }            // renumbered below
+                if (nkids[u] >= 2) { row_nodes.push_back(u); deep[u] = (uint32_t)row_nodes.size(); }
+                else { single_nodes.push_back(u); deep[u] = 0x80000000u | (uint32_t)single_nodes.size(); }
                 work.push_back(u);
             };
             for (size_t i = 0; i < order.size(); i++) { const int32_t u = order[i]; if ((uint32_t)depth[u] == C && nkids[u]) want(u); }
             while (!work.empty()) {
                 const int32_t u = work.back(); work.pop_back();
                 if (nkids[u] >= 2) {
-                    for (int32_t c = rev.nodes[u].first_child; c >= 0; c = rev.nodes[c].next_sibling) if (nkids[c]) want(c);
+                    for (int32_t c = rev.nodes[u].first_child; c >= 0; c = rev.nodes[c].next_sibling) {
+                        uint32_t len = 0, label = 0;
+                        const int32_t v = path_end(c, len, label, 1);
+                        if (nkids[v]) want(v);
+                    }
                 } else {
-                    int32_t v = u; uint32_t len = 0;
-                    do { v = rev.nodes[v].first_child; len++; } while (len < max_syms && !rev.nodes[v].eow && nkids[v] == 1);
+                    const int32_t c = rev.nodes[u].first_child;
+                    uint32_t len = 1, label = (uint32_t)(cls[rev.nodes[c].letter] - ho) << (32 - h.sym_bits);
+                    const int32_t v = path_end(c, len, label, 0);
                     if (nkids[v]) want(v);
                 }
             }
         }
-        const uint32_t n_branch = (uint32_t)branch_nodes.size(), n_chain = (uint32_t)chain_nodes.size();
-        for (int32_t u : chain_nodes) deep[u] = n_branch + (deep[u] & 0x3FFFFFFFu);                                  // ids n_branch+1 ..
-        h.n_deep = n_branch; h.n_chain = n_chain;
-        const uint64_t row_bytes = (uint64_t)(n_branch + 1) * sigma * 4;
-        uint64_t cap = (uint64_t)3 << 30;                               // kids + kval
+        const uint32_t n_rows = (uint32_t)row_nodes.size(), n_single = (uint32_t)single_nodes.size();
+        h.n_deep = n_rows; h.n_chain = n_single;
+        const uint64_t row_bytes = (uint64_t)(n_rows + 1) * sigma * 16;
+        uint64_t cap = (uint64_t)6 << 30;
         if (const char* e = getenv("ACX_PPM_MAX_DEEP_BYTES")) { const long long v = atoll(e); if (v > 0) cap = (uint64_t)v; }
-        if (row_bytes * 2 > cap || (uint64_t)n_branch + n_chain >= 0x3FFFFFFFu) return ACX_OK;
+        if (row_bytes > cap || n_rows >= 0x7FFFFFFFu || n_single >= 0x7FFFFFFFu) return ACX_OK;
 
         // layout
         size_t off = sizeof h;
@@ -164,17 +181,16 @@ int acx_ppm_build(const acx_trie* t, const uint8_t* cls, uint32_t n_classes, boo
         h.off_cells = off;    off = align256(off + (size_t)nC * 32);
         h.off_top_val = off;  off = align256(off + (size_t)h.n_top * 4);
         h.off_kids = off;     off = align256(off + (size_t)row_bytes);
-        h.off_kval = off;     off = align256(off + (size_t)row_bytes);
-        h.off_chains = off;   off = align256(off + ((size_t)n_chain + 1) * 16);
+        h.off_kval = 0;
+        h.off_chains = off;   off = align256(off + ((size_t)n_single + 1) * 16);
         h.total_bytes = off;
         uint8_t* sec = (uint8_t*)calloc(1, off);
         if (!sec) return acx_fail(ACX_E_NOMEM, "acx_ppm_build: cannot allocate %zu bytes", off);
         uint32_t* G = (uint32_t*)(sec + h.off_g);
         uint32_t* cells = (uint32_t*)(sec + h.off_cells);
         int32_t* top_val = (int32_t*)(sec + h.off_top_val);
-        uint32_t* kids = (uint32_t*)(sec + h.off_kids);
-        int32_t* kval = (int32_t*)(sec + h.off_kval);
-        uint32_t* chains = (uint32_t*)(sec + h.off_chains);
+        uint32_t* rows = (uint32_t*)(sec + h.off_kids);
+        uint32_t* singles = (uint32_t*)(sec + h.off_chains);
 
         auto val32 = [&](const Node& nd) -> int32_t { return (int32_t)(uint32_t)(uint64_t)nd.value; };   // "ii" truncation, src/AutomatonSearchIter.c:180-184
         std::vector<uint8_t> top_eow(h.n_top, 0);
@@ -189,38 +205,39 @@ int acx_ppm_build(const acx_trie* t, const uint8_t* cls, uint32_t n_classes, boo
             }
             if (d == F && F == C + 1) G[code[u] >> 5] |= 1u << (code[u] & 31);
         }
-        for (uint32_t b = 0; b < n_branch; b++) {
-            const int32_t u = branch_nodes[b];
-            for (int32_t c = rev.nodes[u].first_child; c >= 0; c = rev.nodes[c].next_sibling) {
-                const uint32_t s = (uint32_t)(cls[rev.nodes[c].letter] - ho);
-                const size_t k = (size_t)(b + 1) * sigma + s;
-                kids[k] = deep[c] | (rev.nodes[c].eow ? 0x80000000u : 0u);
-                if (rev.nodes[c].eow) kval[k] = val32(rev.nodes[c]);
-            }
-        }
-        for (uint32_t k = 0; k < n_chain; k++) {
-            int32_t v = chain_nodes[k]; uint32_t len = 0, label = 0;
-            do {
-                v = rev.nodes[v].first_child; len++;
-                label |= (uint32_t)(cls[rev.nodes[v].letter] - ho) << (32 - h.sym_bits * len);
-            } while (len < max_syms && !rev.nodes[v].eow && nkids[v] == 1);
-            uint32_t* rec = chains + (size_t)(k + 1) * 4;               // record of id n_branch + 1 + k
+        auto fill = [&](uint32_t* rec, int32_t v, uint32_t len, uint32_t label) {
             rec[0] = label;
-            rec[1] = len | (rev.nodes[v].eow ? 0x100u : 0u);
+            rec[1] = len | (rev.nodes[v].eow ? 0x100u : 0u) | 0x200u;   // 0x200: the record exists
             rec[2] = rev.nodes[v].eow ? (uint32_t)val32(rev.nodes[v]) : 0u;
             rec[3] = deep[v];
+        };
+        for (uint32_t b = 0; b < n_rows; b++) {
+            const int32_t u = row_nodes[b];
+            for (int32_t c = rev.nodes[u].first_child; c >= 0; c = rev.nodes[c].next_sibling) {
+                const uint32_t s1 = (uint32_t)(cls[rev.nodes[c].letter] - ho);
+                uint32_t len = 0, label = 0;
+                const int32_t v = path_end(c, len, label, 1);
+                fill(rows + ((size_t)(b + 1) * sigma + s1) * 4, v, len, label);
+            }
+        }
+        for (uint32_t k = 0; k < n_single; k++) {
+            const int32_t u = single_nodes[k];
+            const int32_t c = rev.nodes[u].first_child;
+            uint32_t len = 1, label = (uint32_t)(cls[rev.nodes[c].letter] - ho) << (32 - h.sym_bits);
+            const int32_t v = path_end(c, len, label, 0);
+            fill(singles + (size_t)(k + 1) * 4, v, len, label);
         }
         // cells: everything the d <= C newest symbols say
         for (uint64_t cc = 0; cc < nC; cc++) {
             uint32_t* cell = cells + cc * 8;
             uint64_t div = nC;
-            uint32_t mask = 0;
+            uint32_t mask = 0, nv = 0;
             for (uint32_t d = 0; d <= C; d++) {                          // prefix code of length d = cc / sigma^(C-d)
                 if (d > 0) {
                     const uint32_t pc = (uint32_t)(cc / div);
                     if (top_eow[h.top_base[d] + pc]) {
                         mask |= 1u << (d - 1);
-                        if (C - d < 5) cell[3 + (C - d)] = (uint32_t)top_val[h.top_base[d] + pc];
+                        if (nv < 5) cell[3 + nv++] = (uint32_t)top_val[h.top_base[d] + pc];   // values in match order (shortest first)
                     }
                 }
                 div /= sigma;

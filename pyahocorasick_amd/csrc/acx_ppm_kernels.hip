@@ -165,8 +165,8 @@ struct Ppm {
         return E;
     }
 
-    // Every match ending at E's position, shortest first: f(k, value) for the k-th.  Matches at or
-    // beyond `from` get their values fetched; returns the number of matches.
+    // Every match ending at E's position, shortest first: f(k, value) for the k-th.  Matches k in
+    // [from, upto) get their values; returns the number of matches.
     template <typename F>
     __device__ __forceinline__ uint32_t matches(const Ent& E, uint32_t from, uint32_t upto, F&& f) const {
         uint32_t n = 0;
@@ -176,13 +176,12 @@ struct Ppm {
             const uint32_t d = (uint32_t)__ffs(mask);                // depth = bit + 1
             mask &= mask - 1;
             if (n >= from && n < upto) {
-                const uint32_t back = a.C - d;
-                int32_t v;
-                if (back == 0) v = (int32_t)E.c0.w;
-                else if (back == 1) v = (int32_t)E.c1.x;
-                else if (back == 2) v = (int32_t)E.c1.y;
-                else if (back == 3) v = (int32_t)E.c1.z;
-                else if (back == 4) v = (int32_t)E.c1.w;
+                int32_t v;                                            // the cell lists the values of its first five levels
+                if (n == 0) v = (int32_t)E.c0.w;
+                else if (n == 1) v = (int32_t)E.c1.x;
+                else if (n == 2) v = (int32_t)E.c1.y;
+                else if (n == 3) v = (int32_t)E.c1.z;
+                else if (n == 4) v = (int32_t)E.c1.w;
                 else v = a.top_val[a.top_base[d] + code_of(E.X, E.L, d)];
                 f(n, v);
             }
@@ -200,24 +199,19 @@ struct Ppm {
                     else go = false;
                 }
             }
-            while (go && id && E.L > d) {
-                if (id <= a.n_branch) {                               // branch: one symbol through its dense row
-                    const uint32_t s = sym_at(q - d);
-                    const size_t k = (size_t)id * a.K + s;
-                    const uint32_t en = a.kids[k];
-                    if (!en) break;
-                    d++;
-                    if (en >> 31) { if (n >= from && n < upto) f(n, a.kval[k]); n++; }
-                    id = en & 0x7FFFFFFFu;
-                } else {                                              // chain: all of its symbols or nothing
-                    const u32x4 rec = *(const u32x4*)(a.chains + (size_t)(id - a.n_branch) * 4);
-                    const uint32_t len = rec.y & 0xFFu;
-                    if (E.L < d + len) break;
-                    if ((window(q - d) ^ rec.x) >> (32 - SB * len)) break;
-                    d += len;
-                    if (rec.y & 0x100u) { if (n >= from && n < upto) f(n, (int32_t)rec.z); n++; }
-                    id = rec.w;
-                }
+            while (go && id) {                                        // one 16-byte record per step
+                const bool single = (id >> 31) != 0;
+                if (!single && E.L <= d) break;
+                const uint32_t first = single ? 0u : 1u;
+                const size_t ri = single ? (size_t)(id & 0x7FFFFFFFu) : (size_t)id * a.K + sym_at(q - d);
+                const u32x4 rec = *(const u32x4*)((single ? a.chains : a.kids) + ri * 4);
+                if (!(rec.y & 0x200u)) break;
+                const uint32_t len = rec.y & 0xFFu;
+                if (E.L < d + first + len) break;
+                if (len && ((window(q - d - first) ^ rec.x) >> (32 - SB * len))) break;
+                d += first + len;
+                if (rec.y & 0x100u) { if (n >= from && n < upto) f(n, (int32_t)rec.z); n++; }
+                id = rec.w;
             }
         }
         return n;
@@ -455,6 +449,350 @@ __global__ void __launch_bounds__(ACX_PPM_BLOCK) k_ppm_scan(const acx_ppm_args a
     }
 }
 
+// ---------------------------------------------------------------------------------------------------
+// Fast path (k_ppm_stream): fixed-stride batch, 4-byte aligned buffer, codes that are plain bit
+// fields (K = 4, 16, 256), halo of at most 256 positions.  Same algorithm and the same match
+// enumeration (Ppm::matches) as k_ppm_scan; the structure around it is built for instruction
+// count, which is what bounds this kernel (one wave instruction per 4 cycles per SIMD):
+//   * a wave owns a contiguous RUN of tiles of NSUB x 256 positions; the left halo of a tile is what
+//     the previous tile left in LDS, so no byte is staged twice and every staging lane is busy;
+//   * positions that pass the filter, and the haystack starts ("markers"), go into a ring queue in
+//     position order; the queue is drained 64 entries at a time, so the exact phase runs with
+//     full waves; a marker's exclusive prefix IS the record offset of its haystack;
+//   * each round counts, places (DPP prefix sum) and writes its records at once: the wave's
+//     records form one ordered stream, appended to grants of the scratch pool that the wave lists
+//     in its descriptor; k_ppm_gather copies the streams to their final place.
+// ---------------------------------------------------------------------------------------------------
+#define PPM_QCAP 384u              // ring queue entries (uint16): < 64 left over + 256 passes + 64 markers of a sub-step
+#define PPM_DESC_WORDS 40u         // per wave: total, n_grants, 16 x base, 16 x count (+ pad)
+#define PPM_MAX_GRANTS 16u
+
+template <int SB, int NSUB>
+__global__ void __launch_bounds__(ACX_PPM_BLOCK) k_ppm_stream(const acx_ppm_args a) {
+    extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
+    for (uint32_t i = threadIdx.x; i < a.g_words; i += blockDim.x) smem[a.lds.g_off + i] = a.g[i];
+    if (threadIdx.x < 256) {
+        const uint32_t cl = a.cls[threadIdx.x];
+        ((uint8_t*)(smem + a.lds.map_off))[threadIdx.x] = (a.has_other && cl == 0) ? 0xFFu : (uint8_t)(cl - a.has_other);
+    }
+    __syncthreads();
+
+    constexpr uint32_t SPW = 32 / SB;                                  // symbols per word
+    constexpr uint32_t TPOS = NSUB * 256u;                             // positions per tile
+    constexpr uint32_t TW = TPOS / SPW;                                // words of a tile's symbols
+    constexpr uint32_t SMASK = (1u << SB) - 1u;
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    Ppm<SB, true, false> P(a);
+    P.s_g = smem + a.lds.g_off;
+    P.s_map = (const uint8_t*)(smem + a.lds.map_off);
+    uint32_t* wbase = smem + a.lds.wave_off + (uint32_t)wid * a.lds.wave_words;
+    uint32_t* const sym = wbase;                                       // [0,1] pad, halo words, tile words, pad
+    P.s_sym = wbase + 1;                                               // (Ppm counts one pad word)
+    const uint32_t HP = a.halo_pos, HW = HP / SPW;                     // halo: positions (multiple of SPW and 4), words
+    const uint32_t NDW = (HP + TPOS) / 4;                              // staged dwords
+    uint8_t* const oth = (uint8_t*)(wbase + a.lds.sym_words);          // per staged dword: which bytes are "other"
+    uint8_t* const odist = oth + ((NDW + 3u) & ~3u);                   // per staged dword: dwords back to the last one that has any (255: none)
+    uint16_t* const queue = (uint16_t*)(wbase + a.lds.sym_words + a.lds.oth_words);
+    uint8_t* const sym_tile_bytes = (uint8_t*)(sym + 2 + HW);
+    for (uint32_t i = lane; i < 2 + HW + TW + 1; i += 64) sym[i] = 0;
+    for (uint32_t i = lane; i < NDW; i += 64) { oth[i] = 0; odist[i] = 255; }
+    P.T.q0 = HP; P.T.halo = 0; P.T.idx_first = 0; P.T.ndw = 0; P.T.abase = nullptr; P.T.e0 = 0; P.T.npos = 0; P.has_other = 0;
+
+    const uint32_t H = (uint32_t)(a.n_hay * a.stride - 1) + 1u;       // (the launcher checks H <= 2^32 - 2^12)
+    const int64_t n_tiles = ((int64_t)H + TPOS - 1) / TPOS;
+    const int64_t n_waves = (int64_t)gridDim.x * ACX_PPM_WAVES;
+    const int64_t tpw = (n_tiles + n_waves - 1) / n_waves;            // tiles per wave: a contiguous run
+    const int64_t wave_id = (int64_t)blockIdx.x * ACX_PPM_WAVES + wid;
+    const int64_t t_begin = wave_id * tpw;
+    const int64_t t_end = t_begin + tpw < n_tiles ? t_begin + tpw : n_tiles;
+    uint32_t* const desc = a.wave_desc + (size_t)wave_id * PPM_DESC_WORDS;
+    const uint32_t pool_x = blockIdx.x % a.n_pools;
+    const uint32_t stride = (uint32_t)a.stride;
+    const uint32_t step_q = TPOS / stride, step_r = TPOS % stride;
+    wave_sync();
+    if (t_begin >= t_end) { if (lane == 0) { desc[0] = 0; desc[1] = 0; } return; }
+
+    // x = offset-in-haystack of the tile's first position + a position of the tile: haystacks crossed, new offset
+    auto divmod = [&](uint32_t x, uint32_t& r) -> uint32_t {
+        uint32_t q;
+        if (a.m24) q = (uint32_t)__umul24(x, a.m24) >> 24;             // stride < 1024: exact for x < stride + 1024 (the cast: a logical shift)
+        else q = x >= stride ? 1u : 0u;                                // stride >= 1024: one haystack start per tile at most
+        r = x - q * stride;
+        return q;
+    };
+    auto load_dw = [&](uint32_t b) -> uint32_t {                      // the dword at byte b of the buffer (b is a multiple of 4)
+        uint32_t w = 0;
+        if ((int64_t)b + 4 <= a.hay_cap) w = *(const uint32_t*)(a.hay + b);
+        else for (int k = 0; k < 4; k++) if ((int64_t)b + k < a.hay_cap) w |= (uint32_t)a.hay[b + k] << (8 * k);
+        return w;
+    };
+    auto convert = [&](uint32_t w, uint32_t& nib) -> uint32_t {       // bytes -> packed symbols; nib: bytes that occur in no key
+        uint32_t packed = 0, seen = 0;
+        nib = 0;
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const uint32_t sv = P.s_map[(w >> (8 * k)) & 0xFFu];
+            if (SB == 8) { const bool o = a.has_other && sv == 0xFFu; nib |= (o ? 1u : 0u) << k; packed |= (o ? 0u : sv) << (SB * k); }
+            else { seen |= sv; packed |= (sv & SMASK) << (SB * k); }
+        }
+        if (SB != 8 && (seen & 0x80u)) {                               // (symbols are < 16 here: bit 7 means 0xFF)
+#pragma unroll
+            for (int k = 0; k < 4; k++) if (P.s_map[(w >> (8 * k)) & 0xFFu] == 0xFFu) nib |= 1u << k;
+        }
+        return packed;
+    };
+    auto put_sym = [&](uint8_t* base, uint32_t i, uint32_t packed) {
+        if (SB == 2) base[i] = (uint8_t)packed; else if (SB == 4) ((uint16_t*)base)[i] = (uint16_t)packed; else ((uint32_t*)base)[i] = packed;
+    };
+    // symbols available going back from staged position q when "other" bytes are around
+    auto other_limit = [&](uint32_t q) -> uint32_t {
+        const uint32_t dw = q >> 2;
+        const uint32_t nb = oth[dw] & ((2u << (q & 3u)) - 1u);
+        uint32_t last = 0;
+        if (nb) last = 4 * dw + (31 - __clz(nb)) + 1;
+        else if (dw) {
+            const uint32_t dd = odist[dw - 1];
+            if (dd != 255u) { const uint32_t d2 = dw - 1 - dd; last = 4 * d2 + (31 - __clz((uint32_t)oth[d2])) + 1; }
+        }
+        return q + 1 - last;
+    };
+
+    // ---- prologue: the halo of the run's first tile -----------------------------------------
+    uint32_t e0 = (uint32_t)(t_begin * TPOS);
+    uint32_t any_prev = 0;
+    if (e0 > 0) {
+        const uint32_t have = e0 < HP ? e0 : HP;                       // bytes in front of the run (a multiple of 4)
+        uint32_t nib = 0, packed = 0;
+        if (4u * lane < have) {
+            packed = convert(*(const uint32_t*)(a.hay + (e0 - have) + 4u * lane), nib);
+            put_sym(sym_tile_bytes - (size_t)(have / 4) * (SB / 2), lane, packed);      // the halo ends where the tile begins
+            oth[(HP - have) / 4 + lane] = (uint8_t)nib;
+        }
+        if (__any(nib != 0)) any_prev = 1;
+    }
+    uint32_t h_tile, r_tile;
+    { uint32_t rr; h_tile = div_magic(e0, a.stride_magic, stride, rr); r_tile = rr; }
+    h_tile = (uint32_t)__builtin_amdgcn_readfirstlane((int)h_tile); r_tile = (uint32_t)__builtin_amdgcn_readfirstlane((int)r_tile);
+    uint32_t wnext[NSUB];
+#pragma unroll
+    for (int j = 0; j < NSUB; j++) wnext[j] = load_dw(e0 + 4u * (64 * j + lane));
+
+    // the wave's record stream
+    uint32_t run_off = 0;                                              // records so far
+    uint32_t g_base = 0, g_size = 0, g_used = 0, ng = 0;               // current grant of the pool
+    bool dead = false;                                                 // pool or grant list exhausted: keep counting, stop writing
+    uint32_t qhead = 0, qtail = 0, qcount = 0;
+
+    for (int64_t tile = t_begin; tile < t_end; tile++) {
+        const uint32_t left = H - e0;
+        const uint32_t npos = left < TPOS ? left : TPOS;
+        // ---- stage (and request the next tile's bytes) ---------------------------------------------
+        uint32_t anyo = 0;
+        uint32_t nibs[NSUB];
+#pragma unroll
+        for (int j = 0; j < NSUB; j++) {
+            const uint32_t packed = convert(wnext[j], nibs[j]);
+            put_sym(sym_tile_bytes, 64 * j + lane, packed);
+            anyo |= nibs[j];
+        }
+        if (tile + 1 < t_end) {
+#pragma unroll
+            for (int j = 0; j < NSUB; j++) wnext[j] = load_dw(e0 + TPOS + 4u * (64 * j + lane));
+        }
+        const uint32_t any_cur = a.has_other && __any(anyo != 0) ? 1u : 0u;
+        const uint32_t use_other = any_cur | any_prev;
+        if (use_other) {
+#pragma unroll
+            for (int j = 0; j < NSUB; j++) oth[HP / 4 + 64 * j + lane] = (uint8_t)nibs[j];
+            wave_sync();
+            uint32_t carry = 0;                                        // index + 1 of the last dword that holds an "other" byte
+            for (uint32_t i0 = 0; i0 < NDW; i0 += 64) {
+                const uint32_t i = i0 + lane;
+                uint32_t last = (i < NDW && oth[i]) ? i + 1 : 0u;
+#pragma unroll
+                for (int d = 1; d < 64; d <<= 1) { const uint32_t t = __shfl_up(last, d, 64); if (lane >= d && t > last) last = t; }
+                if (carry > last) last = carry;
+                if (i < NDW) { const uint32_t dd = last ? i + 1 - last : 255u; odist[i] = (uint8_t)(dd < 255u ? dd : 255u); }
+                carry = __shfl(last, 63, 64);
+            }
+        }
+        wave_sync();
+
+        // ---- sub-steps: filter 4 positions per lane, append, drain full rounds ---------------------------
+#pragma unroll 1
+        for (uint32_t sub = 0; sub < NSUB; sub++) {
+            if (sub * 256u >= npos) break;
+            const uint32_t pb = sub * 256u + 4u * lane;
+            uint32_t r0;
+            (void)divmod(r_tile + pb, r0);
+            uint32_t pm = 0, mm = 0;
+            {
+                const uint32_t endbit3 = SB * (HP + pb + 4u) + 64u;
+                const uint32_t wi = endbit3 >> 5, sh = endbit3 & 31u;
+                const uint32_t hi = sym[wi], mid = sym[wi - 1], lo = sym[wi - 2];
+                const uint32_t X3 = __builtin_amdgcn_alignbit(hi, mid, sh), Y = __builtin_amdgcn_alignbit(mid, lo, sh);
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    uint32_t r = r0 + k; if (r >= stride) r -= stride;
+                    const bool inside = pb + k < npos;
+                    uint32_t L = r + 1 < a.longest ? r + 1 : a.longest;
+                    if (use_other) { const uint32_t lo2 = other_limit(HP + pb + k); if (lo2 < L) L = lo2; }
+                    if (!inside) L = 0;
+                    const uint32_t X = k == 3 ? X3 : __builtin_amdgcn_alignbit(X3, Y, 32 - SB * (3 - k));
+                    const uint32_t Lc = L < SPW ? L : SPW;
+                    const uint32_t Xm = X & (uint32_t)((int32_t)0x80000000 >> ((SB * Lc - 1u) & 31u));
+                    const uint32_t cF = Xm >> (32 - SB * a.F);
+                    const uint32_t bit = __builtin_amdgcn_ubfe(P.s_g[cF >> 5], cF, 1u);
+                    pm |= (L >= a.min_len ? bit : 0u) << k;
+                    mm |= ((inside && r == 0) ? 1u : 0u) << k;
+                }
+            }
+            uint32_t nadd;
+            const uint32_t qb = wave_excl_scan((uint32_t)__popc(pm) + (uint32_t)__popc(mm), nadd);
+            {
+                uint32_t j = qtail + qb; if (j >= PPM_QCAP) j -= PPM_QCAP;
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    if ((mm >> k) & 1u) { queue[j] = (uint16_t)(0x8000u | (pb + k)); j = j + 1 == PPM_QCAP ? 0 : j + 1; }     // the marker goes first
+                    if ((pm >> k) & 1u) { queue[j] = (uint16_t)(pb + k); j = j + 1 == PPM_QCAP ? 0 : j + 1; }
+                }
+            }
+            qtail += nadd; if (qtail >= PPM_QCAP) qtail -= PPM_QCAP;
+            qcount += nadd;
+            wave_sync();
+            const bool last_sub = sub + 1 == NSUB || (sub + 1) * 256u >= npos;
+
+            // ---- rounds: 64 queue entries, in position order ---------------------------------------
+            while (qcount >= 64 || (last_sub && qcount > 0)) {
+                const uint32_t nr = qcount < 64 ? qcount : 64;
+                const bool act = (uint32_t)lane < nr;
+                uint32_t qi = qhead + lane; if (qi >= PPM_QCAP) qi -= PPM_QCAP;
+                const uint32_t ent = act ? queue[qi] : 0x8000u;
+                const bool marker = (ent >> 15) != 0;
+                const uint32_t p = ent & 0x7FFFu;
+                uint32_t r, c = 0;
+                const uint32_t h = h_tile + divmod(r_tile + p, r);
+                typename Ppm<SB, true, false>::Ent E;
+                int32_t va = 0, vb = 0;
+                if (act && !marker) {
+                    E.p = p; E.idx = r + (a.index_base ? (uint32_t)a.index_base[h] : 0u);
+                    uint32_t L = r + 1 < a.longest ? r + 1 : a.longest;
+                    if (use_other) { const uint32_t lo2 = other_limit(HP + p); if (lo2 < L) L = lo2; }
+                    E.L = L;
+                    E.X = P.window(HP + p);
+                    const uint32_t Lc = L < SPW ? L : SPW;
+                    const uint32_t Xm = E.X & (uint32_t)((int32_t)0x80000000 >> ((SB * Lc - 1u) & 31u));
+                    const u32x4* cell = (const u32x4*)(a.cells + (size_t)(Xm >> (32 - SB * a.C)) * 8);
+                    E.c0 = cell[0]; E.c1 = cell[1];
+                    if (!(a.dbg & 1u)) c = P.matches(E, 0u, 2u, [&](uint32_t k, int32_t v) { if (k == 0) va = v; else vb = v; });
+                }
+                uint32_t rt;
+                const uint32_t ex = wave_excl_scan(c, rt);
+                if (act && marker) a.hay_local[h] = (int32_t)(run_off + ex);
+#ifdef PPM_DEBUG
+                if (wave_id <= 1 && (lane < 3 || (act && !marker))) printf("w%d t%d sub%u nr%u lane%d ent%04x p%u h%u r%u c%u ex%u rt%u run%u htile%u rtile%u\n", (int)wave_id, (int)tile, sub, nr, lane, ent, p, h, r, c, ex, rt, run_off, h_tile, r_tile);
+#endif
+                if (rt && !dead) {
+                    if (g_used + rt > g_size) {                        // this round does not fit the current grant: open the next one
+                        if (ng == PPM_MAX_GRANTS) dead = true;
+                        else {
+                            uint32_t need = PPM_GRANT << (ng < 10 ? ng : 10);
+                            if (need < rt) need = rt;
+                            unsigned long long o = 0;
+                            if (lane == 0) o = atomicAdd(a.heads + pool_x, (unsigned long long)need);
+                            o = __shfl(o, 0, 64);
+                            if (o + need > a.pool_records) dead = true;
+                            else {
+                                if (lane == 0) { if (ng) desc[18 + ng - 1] = g_used; desc[2 + ng] = (uint32_t)((unsigned long long)pool_x * a.pool_records + o); }
+                                g_base = (uint32_t)((unsigned long long)pool_x * a.pool_records + o); g_size = need; g_used = 0; ng++;
+                            }
+                        }
+                        if (dead && lane == 0) *a.overflow = 1;
+                    }
+                    if (!dead && !(a.dbg & 2u)) {
+                        uint2* out = a.scratch + g_base + g_used;
+                        if (c) {
+                            const uint32_t o = ex + c - 1, idx = E.idx;
+                            out[o] = make_uint2(idx, (uint32_t)va);
+                            if (c > 1) out[o - 1] = make_uint2(idx, (uint32_t)vb);
+                            if (c > 2) P.matches(E, 2u, 0xFFFFFFFFu, [&](uint32_t k, int32_t v) { out[o - k] = make_uint2(idx, (uint32_t)v); });
+                        }
+                    }
+                    if (!dead) g_used += rt;
+                }
+                run_off += rt;
+                qhead += nr; if (qhead >= PPM_QCAP) qhead -= PPM_QCAP;
+                qcount -= nr;
+            }
+        }
+
+        // ---- the tail of this tile is the halo of the next ---------------------------------------
+        wave_sync();
+        {
+            uint32_t t = 0, tn = 0;
+            if ((uint32_t)lane < HW) t = sym[2 + TW + lane];
+            if (use_other && (uint32_t)lane < HP / 4) tn = oth[TPOS / 4 + lane];
+            wave_sync();
+            if ((uint32_t)lane < HW) sym[2 + lane] = t;
+            if (use_other && (uint32_t)lane < HP / 4) oth[lane] = (uint8_t)tn;
+        }
+        any_prev = any_cur;
+        e0 += TPOS;
+        r_tile += step_r; h_tile += step_q;
+        if (r_tile >= stride) { r_tile -= stride; h_tile++; }
+        wave_sync();
+    }
+    if (lane == 0) { desc[0] = run_off; desc[1] = ng; if (ng) desc[18 + ng - 1] = g_used; }
+}
+
+// exclusive prefix sum of the waves' record counts: wave_off[w], wave_off[n_waves] = total
+__global__ void __launch_bounds__(1024) k_ppm_wave_scan(const uint32_t* wave_desc, int64_t n_waves, int64_t* wave_off) {
+    __shared__ int64_t s_part[16];
+    __shared__ int64_t s_carry;
+    if (threadIdx.x == 0) s_carry = 0;
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    for (int64_t b = 0; b < n_waves; b += 1024) {
+        const int64_t i = b + threadIdx.x;
+        const int64_t v = i < n_waves ? (int64_t)wave_desc[(size_t)i * PPM_DESC_WORDS] : 0;
+        int64_t inc = v;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) { const int64_t t = __shfl_up(inc, d, 64); if (lane >= d) inc += t; }
+        if (lane == 63) s_part[wid] = inc;
+        __syncthreads();
+        int64_t before = s_carry, all = 0;
+        for (int w = 0; w < 16; w++) { if (w < wid) before += s_part[w]; all += s_part[w]; }
+        if (i < n_waves) wave_off[i] = before + inc - v;
+        __syncthreads();
+        if (threadIdx.x == 0) s_carry += all;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) wave_off[n_waves] = s_carry;
+}
+
+// one block per wave of k_ppm_stream: its grants, in order, to matches + wave_off[w]; then match_off[]
+__global__ void __launch_bounds__(256) k_ppm_gather(const acx_ppm_gather_args c) {
+    const int64_t total = c.wave_off[c.n_waves];
+    if (total <= c.capacity) {
+        for (int64_t w = blockIdx.x; w < c.n_waves; w += gridDim.x) {
+            const uint32_t* d = c.wave_desc + (size_t)w * PPM_DESC_WORDS;
+            const uint32_t ng = d[1];
+            u32x2* dst = (u32x2*)(c.matches + c.wave_off[w]);
+            for (uint32_t g = 0; g < ng; g++) {
+                const u32x2* src = (const u32x2*)(c.scratch + d[2 + g]);
+                const uint32_t n = d[18 + g];
+                for (uint32_t k = threadIdx.x; k < n; k += 256) __builtin_nontemporal_store(__builtin_nontemporal_load(src + k), dst + k);
+                dst += n;
+            }
+        }
+    }
+    const int64_t n_threads = (int64_t)gridDim.x * 256;
+    for (int64_t h = (int64_t)blockIdx.x * 256 + threadIdx.x; h <= c.n_hay; h += n_threads) {
+        if (h == c.n_hay) c.match_off[h] = total;
+        else c.match_off[h] = c.wave_off[((h * c.stride) / c.tile_pos) / c.tpw] + c.hay_local[h];
+    }
+}
+
 // records of every tile -> their final place; STRIDE scans: match_off[] from the tile offsets
 __global__ void __launch_bounds__(256) k_ppm_compact(const acx_ppm_compact_args c) {
     const int64_t n_items = c.n_items_dev ? *c.n_items_dev : c.n_items;
@@ -517,6 +855,13 @@ hipError_t acx_launch_ppm_scan(const acx_ppm_args& a, int64_t n_items_bound, hip
         hipLaunchKernelGGL(kernel, dim3((unsigned)blocks), dim3(ACX_PPM_BLOCK), lds_bytes, s, a);
         return hipGetLastError();
     };
+    if (a.fast) {
+#define PPM_STREAM(SB) do { if (a.nsub == 4) return launch(k_ppm_stream<SB, 4>); if (a.nsub == 2) return launch(k_ppm_stream<SB, 2>); return launch(k_ppm_stream<SB, 1>); } while (0)
+        if (a.sym_bits == 2) PPM_STREAM(2);
+        if (a.sym_bits == 4) PPM_STREAM(4);
+        PPM_STREAM(8);
+#undef PPM_STREAM
+    }
 #define PPM_CASE(SB) \
     do { \
         if (a.pow2) { if (chunk) return launch(k_ppm_scan<SB, true, true>); return launch(k_ppm_scan<SB, true, false>); } \
@@ -527,6 +872,17 @@ hipError_t acx_launch_ppm_scan(const acx_ppm_args& a, int64_t n_items_bound, hip
     if (a.sym_bits == 8) PPM_CASE(8);
 #undef PPM_CASE
     return hipErrorInvalidValue;
+}
+
+hipError_t acx_launch_ppm_gather(const uint32_t* wave_desc, int64_t n_waves, int64_t* wave_off, const acx_ppm_gather_args& c, hipStream_t s) {
+    hipLaunchKernelGGL(k_ppm_wave_scan, dim3(1), dim3(1024), 0, s, wave_desc, n_waves, wave_off);
+    int64_t blocks = n_waves;
+    const int64_t hb = (c.n_hay + 256) / 256;
+    if (blocks < hb) blocks = hb;
+    const int64_t cap = (int64_t)num_cus() * 32;
+    if (blocks > cap) blocks = cap;
+    hipLaunchKernelGGL(k_ppm_gather, dim3((unsigned)blocks), dim3(256), 0, s, c);
+    return hipGetLastError();
 }
 
 hipError_t acx_launch_ppm_compact(const acx_ppm_compact_args& c, int64_t n_items_bound, hipStream_t s) {

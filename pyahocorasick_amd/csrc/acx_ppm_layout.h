@@ -30,7 +30,7 @@ struct acx_ppm_lds {
 static inline acx_ppm_lds acx_ppm_lds_layout(uint32_t g_words, uint32_t sym_bits, uint32_t longest) {
     acx_ppm_lds L;
     const uint32_t halo = longest > 0 ? longest - 1 : 0;
-    L.dwords = (ACX_PPM_TILE + halo + 3) / 4 + 1;                       // unaligned start: one more
+    L.dwords = (ACX_PPM_TILE + halo + 3) / 4 + 1 + 8;                   // unaligned start: one more; halo rounded up to whole words: some more
     L.sym_words = ((L.dwords * 4 * sym_bits + 31) / 32 + 2 + 3u) & ~3u;
     L.oth_words = ((L.dwords + 3) / 4 + (L.dwords * 2 + 3) / 4 + 3u) & ~3u;
     L.queue_words = ACX_PPM_TILE / 4;
@@ -40,6 +40,24 @@ static inline acx_ppm_lds acx_ppm_lds_layout(uint32_t g_words, uint32_t sym_bits
     L.g_off = 0;
     L.map_off = (g_words + 3u) & ~3u;
     L.wave_off = L.map_off + 64;                                       // byte -> symbol map: 256 bytes
+    L.total_words = L.wave_off + ACX_PPM_WAVES * L.wave_words;
+    return L;
+}
+
+
+// k_ppm_stream: tiles of nsub x 256 positions, halo of halo_pos positions carried in LDS, a ring queue
+static inline acx_ppm_lds acx_ppm_stream_layout(uint32_t g_words, uint32_t sym_bits, uint32_t halo_pos, uint32_t nsub) {
+    acx_ppm_lds L;
+    const uint32_t tpos = nsub * 256u, spw = 32u / sym_bits;
+    L.dwords = (halo_pos + tpos) / 4;
+    L.sym_words = (2 + halo_pos / spw + tpos / spw + 1 + 3u) & ~3u;
+    L.oth_words = (2 * ((L.dwords + 3u) & ~3u)) / 4;                     // nibble byte + distance byte per staged dword
+    L.queue_words = 384 / 2;                                           // PPM_QCAP uint16 entries
+    L.cnt32 = 0; L.cnt_words = 0;
+    L.wave_words = (L.sym_words + L.oth_words + L.queue_words + 3u) & ~3u;
+    L.g_off = 0;
+    L.map_off = (g_words + 3u) & ~3u;
+    L.wave_off = L.map_off + 64;
     L.total_words = L.wave_off + ACX_PPM_WAVES * L.wave_words;
     return L;
 }
