@@ -501,6 +501,15 @@ static int scan_ppm(acx_image_t* img, const acx_scan_params* p, acx_result* r, h
     }
     r->ppm_stream = pa.fast != 0;
     int64_t stream_tiles = 0;
+    if (pa.fast) {   // rows and singles are addressed with 32-bit offsets from the lower of the two
+        const uint8_t* rows = (const uint8_t*)img->ppm_kids; const uint8_t* sing = (const uint8_t*)img->ppm_chains;
+        pa.deep_base = rows < sing ? rows : sing;
+        const uint64_t ro = (uint64_t)(rows - pa.deep_base), so = (uint64_t)(sing - pa.deep_base);
+        const uint64_t span = (ro + ((uint64_t)ph.n_deep + 1) * ph.K * 16 > so + ((uint64_t)ph.n_chain + 1) * 16) ? ro + ((uint64_t)ph.n_deep + 1) * ph.K * 16
+                                                                                                                   : so + ((uint64_t)ph.n_chain + 1) * 16;
+        if (span >= ((uint64_t)1 << 32)) { pa.fast = 0; r->ppm_stream = false; }
+        pa.row_off = (uint32_t)ro; pa.single_off = (uint32_t)so;
+    }
     if (pa.fast) {
         pa.nsub = 4;
         while (pa.nsub > 1 && acx_ppm_stream_layout(ph.g_words, ph.sym_bits, pa.halo_pos, pa.nsub).total_words * 4 > ACX_PPM_LDS_BYTES) pa.nsub >>= 1;

@@ -114,6 +114,7 @@ struct acx_ppm_args {
     uint32_t dbg;            // tuning only (variant bits 25..27): 1 = no exact phase, 2 = no emit, 4 = no filter
     uint32_t nsub;           // k_ppm_stream: sub-steps of 256 positions per tile (1, 2 or 4)
     uint32_t m24;            // k_ppm_stream: ceil(2^24 / stride) for strides below 1024, else 0
+    const uint8_t* deep_base; uint32_t row_off, single_off;   // k_ppm_stream: rows and singles as 32-bit offsets from one base
     uint32_t* wave_desc;     // k_ppm_stream: per wave {records, grants, 16 x base, 16 x count}
     uint32_t halo_pos;       // k_ppm_stream: staged halo positions (multiple of 32 / sym_bits and of 4, >= longest - 1)
     // outputs

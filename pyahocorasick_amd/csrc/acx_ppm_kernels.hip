@@ -631,20 +631,39 @@ __global__ void __launch_bounds__(ACX_PPM_BLOCK) k_ppm_stream(const acx_ppm_args
                 const uint32_t wi = endbit3 >> 5, sh = endbit3 & 31u;
                 const uint32_t hi = sym[wi], mid = sym[wi - 1], lo = sym[wi - 2];
                 const uint32_t X3 = __builtin_amdgcn_alignbit(hi, mid, sh), Y = __builtin_amdgcn_alignbit(mid, lo, sh);
+                if (!use_other && npos == TPOS) {
+                    // the common tile: whole, no byte outside the key alphabet.  Offset in the haystack of
+                    // position k: r0 + k, or r0 + k - stride past a haystack start (unsigned min picks it)
+                    const uint32_t u0 = r0 - stride;
+                    const uint32_t ks = stride - r0;                         // position of the next haystack start (>= 1)
+                    mm = (r0 == 0 ? 1u : 0u) | (ks < 4u ? 1u << ks : 0u);
+                    constexpr int LOG = SB == 2 ? 1 : (SB == 4 ? 2 : 3);
 #pragma unroll
-                for (int k = 0; k < 4; k++) {
-                    uint32_t r = r0 + k; if (r >= stride) r -= stride;
-                    const bool inside = pb + k < npos;
-                    uint32_t L = r + 1 < a.longest ? r + 1 : a.longest;
-                    if (use_other) { const uint32_t lo2 = other_limit(HP + pb + k); if (lo2 < L) L = lo2; }
-                    if (!inside) L = 0;
-                    const uint32_t X = k == 3 ? X3 : __builtin_amdgcn_alignbit(X3, Y, 32 - SB * (3 - k));
-                    const uint32_t Lc = L < SPW ? L : SPW;
-                    const uint32_t Xm = X & (uint32_t)((int32_t)0x80000000 >> ((SB * Lc - 1u) & 31u));
-                    const uint32_t cF = Xm >> (32 - SB * a.F);
-                    const uint32_t bit = __builtin_amdgcn_ubfe(P.s_g[cF >> 5], cF, 1u);
-                    pm |= (L >= a.min_len ? bit : 0u) << k;
-                    mm |= ((inside && r == 0) ? 1u : 0u) << k;
+                    for (int k = 0; k < 4; k++) {
+                        const uint32_t r = k == 0 ? r0 : (r0 + k < u0 + k ? r0 + k : u0 + k);
+                        const uint32_t m = r < SPW - 1 ? r : SPW - 1;         // symbols beyond the haystack start read as 0
+                        const uint32_t X = k == 3 ? X3 : __builtin_amdgcn_alignbit(X3, Y, 32 - SB * (3 - k));
+                        const uint32_t Xm = X & (uint32_t)((int32_t)0x80000000 >> ((m << LOG) + (SB - 1)));
+                        const uint32_t cF = Xm >> (32 - SB * a.F);
+                        const uint32_t bit = __builtin_amdgcn_ubfe(P.s_g[cF >> 5], cF, 1u);
+                        pm |= (r + 1 >= a.min_len ? bit : 0u) << k;
+                    }
+                } else {
+#pragma unroll
+                    for (int k = 0; k < 4; k++) {
+                        uint32_t r = r0 + k; if (r >= stride) r -= stride;
+                        const bool inside = pb + k < npos;
+                        uint32_t L = r + 1 < a.longest ? r + 1 : a.longest;
+                        if (use_other) { const uint32_t lo2 = other_limit(HP + pb + k); if (lo2 < L) L = lo2; }
+                        if (!inside) L = 0;
+                        const uint32_t X = k == 3 ? X3 : __builtin_amdgcn_alignbit(X3, Y, 32 - SB * (3 - k));
+                        const uint32_t Lc = L < SPW ? L : SPW;
+                        const uint32_t Xm = X & (uint32_t)((int32_t)0x80000000 >> ((SB * Lc - 1u) & 31u));
+                        const uint32_t cF = Xm >> (32 - SB * a.F);
+                        const uint32_t bit = __builtin_amdgcn_ubfe(P.s_g[cF >> 5], cF, 1u);
+                        pm |= (L >= a.min_len ? bit : 0u) << k;
+                        mm |= ((inside && r == 0) ? 1u : 0u) << k;
+                    }
                 }
             }
             uint32_t nadd;
@@ -659,6 +678,7 @@ __global__ void __launch_bounds__(ACX_PPM_BLOCK) k_ppm_stream(const acx_ppm_args
             }
             qtail += nadd; if (qtail >= PPM_QCAP) qtail -= PPM_QCAP;
             qcount += nadd;
+            if (a.dbg & 4u) { qhead = qtail; qcount = 0; }
             wave_sync();
             const bool last_sub = sub + 1 == NSUB || (sub + 1) * 256u >= npos;
 
@@ -674,17 +694,65 @@ __global__ void __launch_bounds__(ACX_PPM_BLOCK) k_ppm_stream(const acx_ppm_args
                 const uint32_t h = h_tile + divmod(r_tile + p, r);
                 typename Ppm<SB, true, false>::Ent E;
                 int32_t va = 0, vb = 0;
+                bool deep_go = false; uint32_t deep_id = 0;
+                E.L = 0; E.X = 0; E.p = p;
                 if (act && !marker) {
                     E.p = p; E.idx = r + (a.index_base ? (uint32_t)a.index_base[h] : 0u);
                     uint32_t L = r + 1 < a.longest ? r + 1 : a.longest;
                     if (use_other) { const uint32_t lo2 = other_limit(HP + p); if (lo2 < L) L = lo2; }
                     E.L = L;
-                    E.X = P.window(HP + p);
+                    const uint32_t q = HP + p;
+                    E.X = P.window(q);
                     const uint32_t Lc = L < SPW ? L : SPW;
                     const uint32_t Xm = E.X & (uint32_t)((int32_t)0x80000000 >> ((SB * Lc - 1u) & 31u));
-                    const u32x4* cell = (const u32x4*)(a.cells + (size_t)(Xm >> (32 - SB * a.C)) * 8);
+                    const u32x4* cell = (const u32x4*)((const uint8_t*)a.cells + ((Xm >> (32 - SB * a.C)) << 5));   // (32-bit offset: at most 2^18 cells)
                     E.c0 = cell[0]; E.c1 = cell[1];
-                    if (!(a.dbg & 1u)) c = P.matches(E, 0u, 2u, [&](uint32_t k, int32_t v) { if (k == 0) va = v; else vb = v; });
+                    if (!(a.dbg & 1u)) {
+                        // top levels: the cell lists their values in match order, so the first two are always c0.w, c1.x
+                        uint32_t mask = E.c0.x;
+                        if (L < 32) mask &= (1u << L) - 1u;
+                        c = (uint32_t)__popc(mask);
+                        va = (int32_t)E.c0.w; vb = (int32_t)E.c1.x;
+                        // deeper: one 16-byte record per step (rows: indexed by the next symbol; singles)
+                        uint32_t id = E.c0.y, d = a.C;
+                        bool go = id != 0 && L > d;
+                        if (SB == 2) {                               // K <= 4: the cell knows children and grandchildren; both symbols are in X
+                            const uint32_t t = __builtin_amdgcn_ubfe(E.X, 32 - SB * (a.C + 2), 4u), s1 = t >> 2, z = E.c0.z;
+                            const bool kid = ((z >> s1) & 1u) != 0, keow = ((z >> (4 + s1)) & 1u) != 0, gk = ((z >> (8 + t)) & 1u) != 0;
+                            go = go && kid && (keow || (gk && L > d + 1));
+                        }
+                        // (the loop itself is below, outside this branch: its trip count is wave-uniform)
+                        deep_go = go; deep_id = id;
+                    }
+                }
+                // deeper levels: one 16-byte record per step (rows: indexed by the next symbol; singles).  Every
+                // lane runs every iteration with selects instead of branches (a lane that is done re-reads
+                // record 0): a divergent loop costs several times more instructions than its body here.
+                if (__any(deep_go)) {
+                    const uint32_t q = HP + E.p;
+                    uint32_t d = a.C, id = deep_id;
+                    bool go = deep_go;
+                    uint32_t s1 = SB * (a.C + 1) <= 32 ? __builtin_amdgcn_ubfe(E.X, 32 - SB * (a.C + 1), (uint32_t)SB) : P.sym_at(q - d);
+                    for (;;) {
+                        const bool single = (id >> 31) != 0;
+                        const uint32_t first = single ? 0u : 1u;
+                        uint32_t off = single ? a.single_off + ((id & 0x7FFFFFFFu) << 4) : a.row_off + ((id * a.K + s1) << 4);
+                        off = go ? off : a.row_off;
+                        const u32x4 rec = *(const u32x4*)(a.deep_base + off);
+                        const uint32_t len = rec.y & 0xFFu;
+                        const uint32_t wq = go ? q - d - first : HP;     // (a lane that is done reads a harmless window)
+                        const uint32_t diff = (P.window(wq) ^ rec.x) >> ((32 - SB * len) & 31u);
+                        const bool ok = go && (rec.y & 0x200u) != 0 && E.L >= d + first + len && (len == 0 || diff == 0);
+                        const bool hit = ok && (rec.y & 0x100u) != 0;
+                        va = (hit && c == 0) ? (int32_t)rec.z : va;
+                        vb = (hit && c == 1) ? (int32_t)rec.z : vb;
+                        c += hit ? 1u : 0u;
+                        d += first + len;
+                        id = rec.w;
+                        go = ok && id != 0 && ((id >> 31) != 0 || E.L > d);
+                        if (!__any(go)) break;
+                        s1 = go ? P.sym_at(q - d) : 0u;
+                    }
                 }
                 uint32_t rt;
                 const uint32_t ex = wave_excl_scan(c, rt);
