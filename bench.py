@@ -1,22 +1,32 @@
 #!/usr/bin/env python3
 """bench.py — headline benchmark of the batch Aho-Corasick scan on MI355X.
 
-Workload (BASELINE.json configs[1], the configuration the metric is quoted on):
+Default workload (BASELINE.json configs[1], the configuration the metric is quoted on):
 100,000 unique ACGT keys of length U[8,32] (seed 0) -> one flattened automaton;
-1,000,000 x 150 B DNA-style reads (seed 1 + rank; every even read has a planted key),
-resident in HBM before the timed region.  A "step" is one pass of the hot path (walk +
-prefix-sum + expand kernels) over that batch, results left in HBM.
+batches of 1,000,000 x 150 B DNA-style reads (every even read has a planted key), resident in HBM
+before the timed region.  A "step" is one pass of the hot path over ONE batch (scan kernel +
+prefix sum + gather -> match records and per-read offsets in HBM).  The timed loop ROTATES over
+--batches distinct batches (default 4 x 150 MB = 600 MB, beyond the 256 MiB Infinity Cache), so the
+haystack bytes of a step come from HBM, not from a cache that the previous step filled.
 
     python bench.py [--gpus N --steps K --warmup W]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
-N > 1: one process per GPU; rank 0 builds + flattens the automaton and the flat image is
-replicated with ONE RCCL broadcast; every rank scans its own batch (weak scaling, no
-data-path collective); time = max over ranks, value = all ranks' bytes / time.
+    --mode iter_long           config 5 (AutomatonSearchIterLong on the same workload)
+    --workload c3              config-3 shape on one GPU: 100k multi-word text keys, one text shard,
+                               every step scans a different quarter of it as ONE haystack
+    --workload c4              config-4 shape on one GPU: Snort-style byte signatures (--keys, default
+                               1,000,000), ragged packets 64..1500 B
+    --scaling strong           N > 1: ONE fixed corpus (c2: the read batches, c3: the text) is cut into
+                               N contiguous shards (text: with a longest_word-1 halo); default "weak":
+                               every rank scans its own batches of the full size
 
-Prints one JSON line (rank 0).  `roofline` and `cpu_baseline` are explained in DESIGN.md.
+N > 1: one process per GPU; rank 0 builds + flattens the automaton and the flat image is replicated
+with ONE RCCL broadcast; no data-path collective; time = max over ranks, value = all ranks' bytes /
+time.  Prints one JSON line (rank 0).  `roofline` and `cpu_baseline` are explained in DESIGN.md.
 """
 import argparse
+import hashlib
 import json
 import os
 import sys
@@ -28,75 +38,108 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md
+KERNEL_SOURCES = ("acx_kernels.hip", "acx_ppm_kernels.hip", "acx_kernels.h", "acx_ppm_layout.h", "acx_capi.hip")
 
 
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--keys", type=int, default=100_000)
+    ap.add_argument("--warmup", type=int, default=4)
+    ap.add_argument("--workload", choices=["c2", "c3", "c4"], default="c2")
+    ap.add_argument("--keys", type=int, default=None, help="dictionary size (default: 100,000; c4: 1,000,000)")
     ap.add_argument("--reads", type=int, default=1_000_000)
     ap.add_argument("--read-len", type=int, default=150)
+    ap.add_argument("--batches", type=int, default=4, help="distinct pre-staged batches the timed loop rotates over")
+    ap.add_argument("--batch-mb", type=int, default=512, help="c3/c4: MiB of haystack per batch")
     ap.add_argument("--mode", choices=["iter", "iter_long"], default="iter")
+    ap.add_argument("--scaling", choices=["weak", "strong"], default="weak")
     ap.add_argument("--variant", type=int, default=0)
     ap.add_argument("--pipeline", type=int, default=2,
                     help="result objects kept in flight per GPU (ACX_SCAN_ASYNC): the host queues step i+1 and reads "
-                         "the counters of step i-1 while step i runs.  2 (default) = double-buffered results; on ONE "
-                         "stream the kernels of consecutive steps still run strictly one after the other.  "
-                         "1 = one synchronous call per step (the host's bookkeeping between two steps is then exposed)")
-    ap.add_argument("--streams", type=int, default=1,
-                    help="streams the in-flight steps are spread over.  1 (default): every kernel still runs alone, "
-                         "one after the other, so kernel times are standalone durations.  2 lets consecutive steps "
-                         "overlap on the GPU (needs --pipeline >= 2; +5-13 %% measured: 180-194 GB/s) but concurrent "
-                         "kernels stretch each other and the per-kernel roofline is then not a standalone figure")
-    ap.add_argument("--cpu-sample-reads", type=int, default=1_000_000,
-                    help="reads timed on the CPU baseline leg (0 disables it)")
-    ap.add_argument("--verify", action="store_true", help="check a sample of the GPU output against the oracle")
+                         "the counters of step i-1 while step i runs; on ONE stream the kernels of consecutive steps "
+                         "still run strictly one after the other.  1 = one synchronous call per step")
+    ap.add_argument("--cpu-sample-reads", type=int, default=None,
+                    help="haystacks timed on the CPU baseline legs (default: the whole first batch; 0 disables)")
+    ap.add_argument("--verify", action="store_true", help="check the first batch's GPU output against the oracle (all records)")
     return ap.parse_args()
 
 
-def cpu_baseline(keys, reads, n_sample, mode):
-    """Time the reference itself (oracle/_ref, kind 'reference') or, if the prebuilt module is
-    absent, the plain-C port (oracle/ac_oracle.c, kind 'port') on ONE host core over the first
-    n_sample reads of the same batch.  Baseline only — never on the product path."""
+def kernel_source_hash():
+    h = hashlib.sha256()
+    for name in KERNEL_SOURCES:
+        with open(os.path.join(ROOT, "pyahocorasick_amd", "csrc", name), "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()[:16]
+
+
+# ---- CPU baseline: the reference itself (oracle/_ref) or the plain-C port, 1 core and all cores --------------
+_CPU = {}
+
+
+def _cpu_worker(span):
+    a, b = span
+    scan, hays = _CPU["scan"], _CPU["hays"]
+    n = 0
+    t0 = time.perf_counter()
+    for i in range(a, b):
+        for _ in scan(hays[i]):
+            n += 1
+    return n, time.perf_counter() - t0
+
+
+def cpu_baseline(keys, hays, mode):
+    """hays: list of bytes.  Times Automaton.iter / iter_long of the reference drained per haystack on ONE
+    core, then on ALL host cores (multiprocessing fork, automaton inherited copy-on-write, haystacks
+    partitioned contiguously).  Falls back to the plain-C port (oracle/ac_oracle.c) when oracle/_ref is absent.
+    Baseline only — never on the product path."""
+    import multiprocessing as mp
     from oracle import orc
-    sample = [reads[i].tobytes() for i in range(n_sample)]
-    nbytes = sum(len(s) for s in sample)
+    nbytes = sum(len(h) for h in hays)
     ref = orc.load_reference()
-    if ref is not None:
-        A = ref.Automaton(ref.STORE_INTS)
-        for i, k in enumerate(keys):
-            A.add_word(k, i)
-        A.make_automaton()
-        scan = A.iter if mode == "iter" else A.iter_long
-        for r in sample[:2000]:          # warm-up pass, discarded
-            for _ in scan(r):
-                pass
-        n = 0
-        t0 = time.perf_counter()
-        for r in sample:
-            for _ in scan(r):
-                n += 1
-        dt = time.perf_counter() - t0
-        kind = "reference"
-    else:
+    cores = os.cpu_count() or 1
+    if ref is None:
         O = orc.Oracle()
         for i, k in enumerate(keys):
             O.add_word(k, i)
         O.make_automaton()
-        data = b"".join(sample)
-        off = np.arange(n_sample + 1, dtype=np.int64) * len(sample[0])
-        O.batch_count(data[: off[2000]], off[:2001], 0 if mode == "iter" else 1)
+        data = b"".join(hays)
+        off = np.concatenate([[0], np.cumsum([len(h) for h in hays])]).astype(np.int64)
+        m = 0 if mode == "iter" else 1
         t0 = time.perf_counter()
-        n = O.batch_count(data, off, 0 if mode == "iter" else 1)
-        dt = time.perf_counter() - t0
-        kind = "port"
-    return {"value": nbytes / dt / 1e9, "unit": "GB/s", "cores": 1, "kind": kind,
-            "matches_per_s": n / dt, "seconds": round(dt, 3),
-            "host_cpus": os.cpu_count(),
-            "sample": "first %d of the %d reads (%d B each, %.1f MB), Automaton.%s drained per read, 1 core"
-                      % (n_sample, len(reads), len(sample[0]), nbytes / 1e6, mode)}
+        n1 = O.batch_count(data, off, m)
+        dt1 = time.perf_counter() - t0
+        t0 = time.perf_counter()
+        mo, _, _ = O.batch_records(data, off, m, threads=cores)
+        dta = time.perf_counter() - t0
+        return {"value": nbytes / dt1 / 1e9, "unit": "GB/s", "cores": 1, "kind": "port", "matches_per_s": n1 / dt1, "seconds": round(dt1, 3),
+                "all_cores": {"value": nbytes / dta / 1e9, "unit": "GB/s", "cores": cores, "seconds": round(dta, 3), "matches_per_s": int(mo[-1]) / dta},
+                "host_cpus": cores, "sample": "%d haystacks, %.1f MB, oracle/ac_oracle.c" % (len(hays), nbytes / 1e6)}
+    A = ref.Automaton(ref.STORE_INTS)
+    for i, k in enumerate(keys):
+        A.add_word(k, i)
+    A.make_automaton()
+    _CPU["scan"] = A.iter if mode == "iter" else A.iter_long
+    _CPU["hays"] = hays
+    _cpu_worker((0, min(len(hays), 2000)))                  # warm-up pass, discarded
+    n1, dt1 = _cpu_worker((0, len(hays)))
+    # all cores: fork AFTER the automaton exists; each worker times its own contiguous share
+    workers = max(1, min(cores, len(hays)))
+    cuts = np.linspace(0, len(hays), workers + 1).astype(int)
+    spans = [(int(cuts[i]), int(cuts[i + 1])) for i in range(workers)]
+    ctx = mp.get_context("fork")
+    t0 = time.perf_counter()
+    with ctx.Pool(workers) as pool:
+        parts = pool.map(_cpu_worker, spans, chunksize=1)
+    dta = time.perf_counter() - t0
+    na = sum(p[0] for p in parts)
+    return {"value": nbytes / dt1 / 1e9, "unit": "GB/s", "cores": 1, "kind": "reference",
+            "matches_per_s": n1 / dt1, "seconds": round(dt1, 3),
+            "all_cores": {"value": nbytes / dta / 1e9, "unit": "GB/s", "cores": workers, "seconds": round(dta, 3),
+                          "matches_per_s": na / dta, "slowest_worker_s": round(max(p[1] for p in parts), 3)},
+            "host_cpus": cores,
+            "sample": "%d haystacks of batch 0 (%.1f MB), Automaton.%s of the reference drained per haystack; "
+                      "1 core, then %d forked workers (wall time incl. fork)" % (len(hays), nbytes / 1e6, mode, workers)}
 
 
 def main():
@@ -126,13 +169,22 @@ def main():
 
     import pyahocorasick_amd as acx
     from pyahocorasick_amd import _lib
-    from pyahocorasick_amd.device import Image, Scanner
-    from pyahocorasick_amd.parallel import broadcast_image
-    from pyahocorasick_amd.workloads import dna_keys, dna_reads
+    from pyahocorasick_amd.device import Scanner
+    from pyahocorasick_amd.parallel import broadcast_image, shard_range
+    from pyahocorasick_amd import workloads as W
     _lib.check(_lib.lib().acx_device_set(local_rank))
 
-    # ---- automaton: built on rank 0 (CPU), replicated by one RCCL broadcast -------------
-    keys = dna_keys(args.keys, seed=0)
+    # ---- dictionary: built on rank 0 (CPU), replicated by one RCCL broadcast ---------------------
+    n_keys = args.keys or (1_000_000 if args.workload == "c4" else 100_000)
+    vocab = None
+    if args.workload == "c2":
+        keys = W.dna_keys(n_keys, seed=0)
+    elif args.workload == "c3":
+        vocab = W.text_vocab(1_000_000 if n_keys >= 100_000 else 10 * n_keys, seed=2)
+        keys = W.text_keys(vocab, n_keys, seed=3)
+    else:
+        keys = W.snort_signatures(n_keys, seed=5)
+    longest = max(len(k) for k in keys)
     t0 = time.perf_counter()
     blob = None
     if rank == 0:
@@ -147,155 +199,197 @@ def main():
     torch.cuda.synchronize()
     t_bcast = time.perf_counter() - t0
 
-    # ---- this rank's batch, resident in HBM ----------------------------------------------
-    reads = dna_reads(keys, args.reads, args.read_len, seed=1 + rank)
-    n, L = reads.shape
-    d_hay = torch.empty(n * L + 64, dtype=torch.uint8, device=dev)
-    d_hay[: n * L].copy_(torch.from_numpy(reads.reshape(-1)))
+    # ---- this rank's batches, resident in HBM ---------------------------------------------------------
+    # a batch = (device bytes, capacity, n haystacks, device offsets or None, stride, host copy for batch 0)
+    strong = args.scaling == "strong" and world > 1
+    B = max(1, args.batches)
+    batches, host0 = [], None
+    t0 = time.perf_counter()
+    for b in range(B):
+        seed = 1 + b + (0 if strong else 16 * rank)
+        if args.workload == "c2":
+            reads = W.dna_reads(keys, args.reads, args.read_len, seed=seed)
+            if strong:
+                lo, hi = shard_range(len(reads), rank, world)
+                reads = reads[lo:hi]
+            n, L = reads.shape
+            flat, off = reads.reshape(-1), None
+            if b == 0:
+                host0 = [reads[i].tobytes() for i in range(n)]
+        elif args.workload == "c3":
+            nbytes = args.batch_mb << 20
+            flat = np.concatenate([W.text_corpus(vocab, min(64 << 20, nbytes - o), seed=4 + 64 * seed + o // (64 << 20))
+                                   for o in range(0, nbytes, 64 << 20)])
+            if strong:            # one corpus, contiguous shards, longest_word-1 bytes of left halo (exact for iter)
+                lo, hi = shard_range(len(flat), rank, world)
+                flat = flat[max(0, lo - (longest - 1)):hi]
+            n, L, off = 1, 0, np.array([0, len(flat)], dtype=np.int64)
+            if b == 0:
+                host0 = [flat[i:i + (1 << 16)].tobytes() for i in range(0, min(len(flat), 32 << 20), 1 << 16)]
+        else:
+            flat, off = W.packet_payloads(keys, args.batch_mb << 20, seed=6 + seed)
+            n, L = len(off) - 1, 0
+            if b == 0:
+                m = int(np.searchsorted(off, 32 << 20))
+                host0 = [flat[off[i]:off[i + 1]].tobytes() for i in range(m)]
+        d_hay = torch.empty(len(flat) + 64, dtype=torch.uint8, device=dev)
+        d_hay[: len(flat)].copy_(torch.from_numpy(np.ascontiguousarray(flat)))
+        d_off = torch.from_numpy(off).to(dev) if off is not None else None
+        batches.append((d_hay, len(flat), n, d_off, L))
     torch.cuda.synchronize()
+    t_stage = time.perf_counter() - t0
     mode = acx.ACX_SCAN_ALL if args.mode == "iter" else acx.ACX_SCAN_LONG
-    # every step is one complete batch scan (walk + prefix sum + expand -> match records in HBM) of
-    # the same resident batch; with --pipeline P, P result objects on P streams are kept in flight
     P = max(1, args.pipeline)
     scs = [Scanner(image) for _ in range(P)]
-    sc = scs[0]
     stream = torch.cuda.current_stream().cuda_stream
-    S = max(1, min(args.streams, P))
-    tstreams = [torch.cuda.Stream(device=dev) for _ in range(S)] if S > 1 else []
-    streams = [t.cuda_stream for t in tstreams] if S > 1 else [stream]
 
-    def step(timing=False, k=0):
-        return scs[k % P].scan(d_hay.data_ptr(), n * L, n, stride=L, mode=mode, timing=timing, variant=args.variant,
-                               stream=streams[k % P % S], asynchronous=P > 1)
+    def step(k, timing=False):
+        d_hay, cap, n, d_off, L = batches[k % B]
+        return scs[k % P].scan(d_hay.data_ptr(), cap, n, dev_off=d_off.data_ptr() if d_off is not None else None,
+                               stride=L, mode=mode, timing=timing, variant=args.variant, stream=stream, asynchronous=P > 1)
 
-    for k in range(max(args.warmup, P)):
-        step(k=k)
+    for k in range(max(args.warmup, P, B)):               # every batch scanned at least once before timing
+        step(k)
     for x in scs:
         x.wait()
-    # per-kernel times from HIP events on each scan's stream: on one stream they are taken again over the
-    # timed steps below (these passes then only warm up); with several streams these separate passes, pipelined
-    # like the timed loop (a walk shares the GPU with the previous step's expand, as it does there), are reported
-    kt = {"walk": [], "scan": [], "expand": [], "total": []}
-    for _ in range(3):
-        for k in range(P):
-            step(timing=True, k=k)
-        for x in scs:
-            x.wait()
-            t = x.timing_ms()
-            for k in kt:
-                kt[k].append(t[k])
-    matches = sc.num_matches()
+    # per-kernel times (HIP events around every kernel of a step) from separate passes over every batch
+    pre = {"walk": [], "scan": [], "expand": [], "total": []}
+    matches_per_batch = []
+    for k in range(B):
+        step(k, timing=True)
+        scs[k % P].wait()
+        t = scs[k % P].timing_ms()
+        for key in pre:
+            pre[key].append(t[key])
+        matches_per_batch.append(scs[k % P].num_matches())
+    pre = {k: float(np.mean(v)) for k, v in pre.items()}
 
     def barrier():
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize()
 
+    # ---- the timed region: K steps, rotating over the batches; the dominant kernel of every step is bracketed
+    #      by HIP events on the stream it runs on (timing = 2: an event between two kernels costs ~5 us of idle GPU)
+    walk_ms = []
+
+    def collect(x):
+        x.wait()
+        walk_ms.append(x.timing_ms()["walk"])
+
     barrier()
     t0 = time.perf_counter()
-    if S == 1:
-        # the default: every kernel runs alone on ONE stream, each timed step with HIP events around its kernels
-        # on that stream -> the per-kernel averages of THIS timed region (roofline.kernel_avg_ms).  A result
-        # object's times are read when it is about to be reused, i.e. while a later step runs.
-        # Only the dominant kernel is bracketed inside the timed steps (timing = 2): every event between two
-        # kernels costs ~5 us of idle GPU; the scan and expand averages stay those of the passes above.
-        pre = {k: float(np.mean(v)) for k, v in kt.items()}
-        kt = {"walk": []}
-
-        def collect(x):
-            x.wait()
-            kt["walk"].append(x.timing_ms()["walk"])
-
-        for k in range(args.steps):
-            if k >= P:
-                collect(scs[k % P])
-            step(timing=2, k=k)
-        for k in range(max(0, args.steps - P), args.steps):
-            collect(scs[k % P])                    # every step complete: totals read, records in HBM
-    else:
-        for k in range(args.steps):
-            step(k=k)
-        for x in scs:
-            x.wait()
+    for k in range(args.steps):
+        if k >= P:
+            collect(scs[k % P])
+        step(k, timing=2)
+    for k in range(max(0, args.steps - P), args.steps):
+        collect(scs[k % P])                                # every step complete: totals read, records in HBM
+    torch.cuda.synchronize()
+    dt_rank = time.perf_counter() - t0
     barrier()
     dt = time.perf_counter() - t0
+    bytes_rank = sum(batches[k % B][1] for k in range(args.steps))
+    matches_rank = sum(matches_per_batch[k % B] for k in range(args.steps))
+    per_rank = [bytes_rank / dt_rank / 1e9]
     if dist is not None:
         tt = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
-        mm = torch.tensor([matches], dtype=torch.int64, device=dev)
-        dist.all_reduce(mm, op=dist.ReduceOp.SUM)
-        matches_all = int(mm.item())
+        agg = torch.tensor([bytes_rank, matches_rank], dtype=torch.int64, device=dev)
+        dist.all_reduce(agg, op=dist.ReduceOp.SUM)
+        bytes_all, matches_all = int(agg[0].item()), int(agg[1].item())
+        pr = torch.zeros(world, dtype=torch.float64, device=dev)
+        pr[rank] = per_rank[0]
+        dist.all_reduce(pr, op=dist.ReduceOp.SUM)
+        per_rank = pr.tolist()
     else:
-        matches_all = matches
+        bytes_all, matches_all = bytes_rank, matches_rank
 
-    if args.verify and rank == 0:
+    if args.verify and rank == 0 and args.mode == "iter":
         from oracle import orc
         O = orc.Oracle()
         for i, k in enumerate(keys):
             O.add_word(k, i)
         O.make_automaton()
-        off, e, v, _ = sc.fetch()
-        for h in range(0, n, max(1, n // 2000)):
-            oe, ov, _ = O.iter_arrays(reads[h].tobytes()) if args.mode == "iter" else (None, None, None)
-            if oe is not None:
-                assert np.array_equal(e[off[h]:off[h + 1]], oe) and np.array_equal(v[off[h]:off[h + 1]], ov), h
+        d_hay, cap, n, d_off, L = batches[0]
+        scs[0].scan(d_hay.data_ptr(), cap, n, dev_off=d_off.data_ptr() if d_off is not None else None, stride=L, mode=mode, stream=stream)
+        off_g, e, v, _ = scs[0].fetch()
+        data = d_hay[:cap].cpu().numpy().tobytes()
+        offs = np.arange(n + 1, dtype=np.int64) * L if d_off is None else d_off.cpu().numpy()
+        mo, oe, ov = O.batch_records(data, offs, 0)
+        assert np.array_equal(off_g, mo) and np.array_equal(e, oe) and np.array_equal(v, ov), "GPU result differs from the oracle"
 
     if rank == 0:
+        d_hay, cap0, n0, d_off0, L0 = batches[0]
         ms_step = dt / args.steps * 1e3
-        H = n * L                                     # haystack bytes per rank per step
-        A_bytes = H + 8 * matches + 12 * n            # H + 8*M + 12*N
-        med = {k: float(np.mean(v)) for k, v in kt.items()}      # averages (one stream: the walk over the timed steps themselves)
-        if "scan" not in med:
-            med.update({"scan": pre["scan"], "expand": pre["expand"], "total": med["walk"] + pre["scan"] + pre["expand"]})
+        H = bytes_rank / args.steps                        # haystack bytes per rank per step (mean over the rotation)
+        M = matches_rank / args.steps
+        Nh = float(np.mean([batches[k % B][2] for k in range(args.steps)]))
+        A_bytes = H + 8 * M + 12 * Nh                      # H + 8*M + 12*N
+        walk = float(np.mean(walk_ms))
+        used_ppm = args.mode == "iter" and image.ppm_kernel(stride=L0, has_offsets=d_off0 is not None, variant=args.variant)
         if args.mode != "iter":
-            walk_kernel = "k_walk_long"
-        elif image.itop_depth > 0 and not (args.variant >> 16) & 1:
-            walk_kernel = "k_walk_itop"          # implicit top-of-trie walk
+            walk_kernel, walk_bytes = "k_walk_long", H + 12 * Nh
+        elif used_ppm == "stream":
+            # the scan kernel reads the haystack, writes every record (to the pool) and one offset per haystack
+            walk_kernel, walk_bytes = "k_ppm_stream", H + 8 * M + 4 * Nh
+        elif used_ppm == "scan":
+            walk_kernel, walk_bytes = "k_ppm_scan", H + 8 * M + 8 * (H / 256)
         else:
-            walk_kernel = "k_walk_all"
-        traffic = None
+            walk_kernel, walk_bytes = ("k_walk_itop" if image.itop_depth > 0 and not (args.variant >> 16) & 1 else "k_walk_all"), H + 12 * Nh
+        traffic, traffic_note = None, "profiles/traffic.json absent"
         tpath = os.path.join(ROOT, "profiles", "traffic.json")
+        src_hash = kernel_source_hash()
         if os.path.exists(tpath):
             try:
-                # measured offline with rocprofv3 --pmc (tools/gpu_round.sh stage pmc); bytes per launch
-                # of the dominant kernel that crossed the L2 -> fabric boundary (FETCH_SIZE + WRITE_SIZE)
-                ent = json.load(open(tpath)).get("%s_n%d_l%d_k%d" % (args.mode, n, L, args.keys))
-                traffic = ent["hbm_bytes_dominant_kernel"] if ent else None
-            except Exception:
-                traffic = None
+                tj = json.load(open(tpath))
+                ent = tj.get("%s_%s" % (args.workload, args.mode))
+                if not ent:
+                    traffic_note = "no PMC entry for this workload"
+                elif ent.get("kernel_source_sha") != src_hash:
+                    traffic_note = "PMC entry is for other kernel sources (%s, now %s): refused" % (ent.get("kernel_source_sha"), src_hash)
+                elif ent.get("kernel") != walk_kernel:
+                    traffic_note = "PMC entry is for kernel %s" % ent.get("kernel")
+                else:
+                    traffic, traffic_note = ent["hbm_bytes_dominant_kernel"], ent.get("note", "")
+            except Exception as ex:                       # noqa: BLE001
+                traffic_note = "unreadable: %s" % ex
+        names = {"c2": "config2: %d ACGT keys 8-32 B, %d x %d B reads per batch" % (n_keys, args.reads, args.read_len),
+                 "c3": "config3 shape: %d multi-word text keys, %d MiB of text per batch scanned as ONE haystack" % (n_keys, args.batch_mb),
+                 "c4": "config4 shape: %d Snort-style byte signatures 4-128 B, %d MiB of packets 64-1500 B per batch" % (n_keys, args.batch_mb)}
         out = {
-            "metric": "GB/s haystack scanned, 100k-pattern automaton",
-            "value": world * H / (dt / args.steps) / 1e9,
+            "metric": "GB/s haystack scanned, 100k-pattern automaton" if args.workload != "c4" else "GB/s haystack scanned, %d-signature automaton" % n_keys,
+            "value": bytes_all / dt / 1e9,
             "unit": "GB/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": ms_step, "higher_is_better": True, "scaling": "weak",
+            "ms_per_step": ms_step, "higher_is_better": True, "scaling": "strong" if strong else "weak",
             "vs_baseline": None, "dtype": "u8", "data": "synthetic",
-            "matches_per_s": matches_all / (dt / args.steps),
-            "matches_per_step": matches_all,
-            "config": {"workload": "config2: %d ACGT keys 8-32 B, %d x %d B reads per GPU, Automaton.%s"
-                                   % (args.keys, n, L, args.mode),
-                       "states": int(image.num_states), "classes": int(image.num_classes), "itop_depth": int(image.itop_depth),
-                       "image_mb": round(image.nbytes / 1e6, 1), "variant": args.variant, "pipeline_depth": P, "streams": S,
-                       "parallelism": "replicated automaton (1 RCCL broadcast), reads sharded x%d" % world},
-            # dominant kernel = the walk: it alone reads the haystack (H) and the per-haystack
-            # bookkeeping (12 B x N); the 8 B x M match records are written by k_expand.
+            "matches_per_s": matches_all / dt,
+            "matches_per_step": matches_all / args.steps / world,
+            "per_rank_GBps": {"min": min(per_rank), "max": max(per_rank)},
+            "config": {"workload": names[args.workload] + ", Automaton.%s; %d distinct batches rotated (%.0f MB resident per GPU)"
+                                   % (args.mode, B, sum(b[1] for b in batches) / 1e6),
+                       "states": int(image.num_states), "classes": int(image.num_classes),
+                       "image_mb": round(image.nbytes / 1e6, 1), "variant": args.variant, "pipeline_depth": P,
+                       "parallelism": "replicated automaton (1 RCCL broadcast), haystacks sharded x%d (%s)" % (world, "strong" if strong else "weak")},
             "roofline": {
                 "bound": "hbm", "kernel": walk_kernel,
-                "achieved": (H + 12 * n) / (med["walk"] * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": (H + 12 * n) / (med["walk"] * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                "algorithmic_bytes": H + 12 * n, "kernel_avg_ms": round(med["walk"], 4),
-                "traffic": traffic,
-                # the whole batch scan (walk + prefix sum + expand), A = H + 8*M + 12*N
-                "pipeline": {"algorithmic_bytes": A_bytes, "gpu_ms": round(med["total"], 4),
-                             "achieved": A_bytes / (med["total"] * 1e-3) / 1e9,
-                             "frac": A_bytes / (med["total"] * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                             "kernel_ms": {k: round(v, 4) for k, v in med.items()}},
+                "achieved": walk_bytes / (walk * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": walk_bytes / (walk * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                "algorithmic_bytes": walk_bytes, "kernel_avg_ms": round(walk, 4),
+                "traffic": traffic, "traffic_note": traffic_note, "kernel_source_sha": src_hash,
+                # the whole batch scan (scan kernel + prefix sum + gather), A = H + 8*M + 12*N
+                "pipeline": {"algorithmic_bytes": A_bytes, "gpu_ms": round(walk + pre["scan"] + pre["expand"], 4),
+                             "achieved": A_bytes / ((walk + pre["scan"] + pre["expand"]) * 1e-3) / 1e9,
+                             "frac": A_bytes / ((walk + pre["scan"] + pre["expand"]) * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                             "kernel_ms": {"walk": round(walk, 4), "scan": round(pre["scan"], 4), "expand": round(pre["expand"], 4)}},
             },
-            "setup": {"build_flatten_s": round(t_build, 3), "broadcast_upload_s": round(t_bcast, 3)},
+            "setup": {"build_flatten_s": round(t_build, 3), "broadcast_upload_s": round(t_bcast, 3), "stage_batches_s": round(t_stage, 3)},
         }
-        if world == 1 and args.cpu_sample_reads > 0:
-            out["cpu_baseline"] = cpu_baseline(keys, reads, min(args.cpu_sample_reads, n), args.mode)
+        if world == 1 and args.cpu_sample_reads != 0 and host0:
+            sample = host0 if not args.cpu_sample_reads else host0[: args.cpu_sample_reads]
+            out["cpu_baseline"] = cpu_baseline(keys, sample, args.mode)
         os.write(json_fd, (json.dumps(out) + "\n").encode())
     if dist is not None:
         dist.barrier()

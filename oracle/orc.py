@@ -49,6 +49,8 @@ def lib():
         l.orc_iter_long.argtypes = [P, P, I64, I64, I64, P, P, I64]
         l.orc_iter_batch_count.restype = I64
         l.orc_iter_batch_count.argtypes = [P, P, P, I64, C.c_int]
+        l.orc_iter_batch.restype = I64
+        l.orc_iter_batch.argtypes = [P, P, P, I64, C.c_int, P, P, P, I64]
         l.flat_iter.restype = I64
         l.flat_iter.argtypes = [P, P, I64, I32p, I64, P, P, I64]
         l.flat_iter_itop.restype = I64
@@ -131,6 +133,44 @@ class Oracle:
         off = np.ascontiguousarray(offsets, dtype=np.int64)
         buf = np.frombuffer(data, dtype=np.uint8)
         return lib().orc_iter_batch_count(self._a, buf.ctypes.data, off.ctypes.data, len(off) - 1, mode)
+
+    def batch_records(self, data, offsets, mode=0, threads=None):
+        """-> (match_off int64[n+1], end int32[], value int32[]) for the whole batch, computed in C
+        (ac_oracle.c:orc_iter_batch) on `threads` host threads (ctypes releases the GIL; the automaton
+        is only read).  What the full-size parity tests compare the GPU result with."""
+        from concurrent.futures import ThreadPoolExecutor
+        off = np.ascontiguousarray(offsets, dtype=np.int64)
+        buf = np.frombuffer(data, dtype=np.uint8)
+        n = len(off) - 1
+        threads = threads or min(64, os.cpu_count() or 1)
+        cuts = np.linspace(0, n, min(threads, max(1, n)) + 1).astype(np.int64)
+
+        def work(k):
+            a, b = int(cuts[k]), int(cuts[k + 1])
+            sub = np.ascontiguousarray(off[a:b + 1] - off[a])
+            base = buf[off[a]:off[b]] if off[b] > off[a] else np.zeros(1, dtype=np.uint8)
+            base = np.ascontiguousarray(base)
+            cap = max(1024, int(off[b] - off[a]) // 4)
+            while True:
+                mo = np.empty(b - a + 1, dtype=np.int64)
+                e = np.empty(cap, dtype=np.int32)
+                v = np.empty(cap, dtype=np.int32)
+                t = lib().orc_iter_batch(self._a, base.ctypes.data, sub.ctypes.data, b - a, mode,
+                                         mo.ctypes.data, e.ctypes.data, v.ctypes.data, cap)
+                if t < 0:
+                    raise AttributeError("oracle: automaton not finalised (code %d)" % t)
+                if t <= cap:
+                    return mo, e[:t], v[:t]
+                cap = int(t)
+
+        with ThreadPoolExecutor(max_workers=len(cuts) - 1) as ex:
+            parts = list(ex.map(work, range(len(cuts) - 1)))
+        mos, base = [], 0
+        for mo, e, v in parts:
+            mos.append(mo[:-1] + base)
+            base += int(mo[-1])
+        match_off = np.concatenate(mos + [np.array([base], dtype=np.int64)])
+        return match_off, np.concatenate([p[1] for p in parts]), np.concatenate([p[2] for p in parts])
 
     def batch(self, data, offsets, mode=0):
         """-> (match_off int64[n+1], end int32[], value int32[]) for the whole batch."""

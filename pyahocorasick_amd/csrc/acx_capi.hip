@@ -451,7 +451,38 @@ static int ppm_size_pool(acx_result* r, size_t records) {
     return ACX_OK;
 }
 
-static int scan_ppm(acx_image_t* img, const acx_scan_params* p, acx_result* r, hipStream_t s) {
+// which kernels an ACX_SCAN_ALL scan takes: 0 the serial walks, 1 k_ppm_scan (general position-parallel), 2 k_ppm_stream
+static uint32_t ppm_halo_pos(const acx_ppm_header& ph) {
+    const uint32_t unit = 32u / ph.sym_bits < 4u ? 4u : 32u / ph.sym_bits;
+    return ph.longest > 1 ? ((ph.longest - 1 + unit - 1) / unit) * unit : unit;
+}
+static int ppm_plan(const acx_image* img, const acx_scan_params* p) {
+    if (p->mode != ACX_SCAN_ALL || !img->ppm_g || p->dev_init_state || p->n_hay <= 0 || ((p->variant >> 23) & 1)) return 0;
+    if (!p->dev_off && p->stride <= 0) return 0;
+    const acx_ppm_header& ph = img->ppm;
+    // k_ppm_stream: fixed stride, aligned buffer, codes that are bit fields, a halo of at most one sub-step,
+    // rows and singles within 4 GiB of each other (variant bit 24: the general kernel instead, A/B)
+    const uint8_t* rows = (const uint8_t*)img->ppm_kids; const uint8_t* sing = (const uint8_t*)img->ppm_chains;
+    const uint8_t* lo = rows < sing ? rows : sing;
+    const uint64_t re = (uint64_t)(rows - lo) + ((uint64_t)ph.n_deep + 1) * ph.K * 16, se = (uint64_t)(sing - lo) + ((uint64_t)ph.n_chain + 1) * 16;
+    const uint32_t hp = ppm_halo_pos(ph);
+    if (!p->dev_off && ph.pow2 && p->stride >= 8 && ((uintptr_t)p->dev_hay & 3u) == 0 && hp <= ACX_PPM_TILE &&
+        p->n_hay * p->stride <= 0xFFFFF000ll && !((p->variant >> 24) & 1) && (re > se ? re : se) < ((uint64_t)1 << 32) &&
+        acx_ppm_stream_layout(ph.g_words, ph.sym_bits, hp, 1).total_words * 4 <= ACX_PPM_LDS_BYTES)
+        return 2;
+    // The general kernel (k_ppm_scan) pays ~4 instructions per position more than the serial walks when their table
+    // rows are cache resident; it wins when the dense table is far beyond the caches (measured: 200k binary
+    // signatures, 6.9 GB table: 77 vs 62 GB/s; 100k text keys, 185 MB: 110 vs 168).  variant bit 28 forces it.
+    if (((p->variant >> 28) & 1) || (uint64_t)img->h.n_states * img->h.n_classes * 4 > ((uint64_t)1 << 30)) return 1;
+    return 0;
+}
+
+extern "C" int acx_scan_plan(const acx_image_t* img, const acx_scan_params* p) {
+    if (!img || !p || p->struct_bytes != sizeof(acx_scan_params)) return -1;
+    return ppm_plan(img, p);
+}
+
+static int scan_ppm(acx_image_t* img, const acx_scan_params* p, acx_result* r, hipStream_t s, int plan) {
     const acx_ppm_header& ph = img->ppm;
     const size_t n = (size_t)p->n_hay;
     const bool chunked = p->dev_off != nullptr;
@@ -493,28 +524,19 @@ static int scan_ppm(acx_image_t* img, const acx_scan_params* p, acx_result* r, h
     pa.heads = r->ppm_ctl.p; pa.overflow = (int32_t*)(r->ppm_ctl.p + 8);
     pa.hay_local = chunked ? nullptr : r->hay_local.p;
     pa.dbg = (uint32_t)(p->variant >> 25) & 7u;
-    {   // k_ppm_stream: fixed stride, aligned buffer, codes that are bit fields, a halo of at most one sub-step
-        const uint32_t unit = 32u / ph.sym_bits < 4u ? 4u : 32u / ph.sym_bits;
-        pa.halo_pos = ph.longest > 1 ? ((ph.longest - 1 + unit - 1) / unit) * unit : unit;
-        pa.fast = !chunked && ph.pow2 && p->stride >= 8 && ((uintptr_t)p->dev_hay & 3u) == 0 && pa.halo_pos <= ACX_PPM_TILE &&
-                  p->n_hay * p->stride <= 0xFFFFF000ll && !((p->variant >> 24) & 1);     // variant bit 24: the general kernel (A/B)
-    }
+    pa.halo_pos = ppm_halo_pos(ph);
+    pa.fast = plan == 2;
     r->ppm_stream = pa.fast != 0;
     int64_t stream_tiles = 0;
     if (pa.fast) {   // rows and singles are addressed with 32-bit offsets from the lower of the two
         const uint8_t* rows = (const uint8_t*)img->ppm_kids; const uint8_t* sing = (const uint8_t*)img->ppm_chains;
         pa.deep_base = rows < sing ? rows : sing;
-        const uint64_t ro = (uint64_t)(rows - pa.deep_base), so = (uint64_t)(sing - pa.deep_base);
-        const uint64_t span = (ro + ((uint64_t)ph.n_deep + 1) * ph.K * 16 > so + ((uint64_t)ph.n_chain + 1) * 16) ? ro + ((uint64_t)ph.n_deep + 1) * ph.K * 16
-                                                                                                                   : so + ((uint64_t)ph.n_chain + 1) * 16;
-        if (span >= ((uint64_t)1 << 32)) { pa.fast = 0; r->ppm_stream = false; }
-        pa.row_off = (uint32_t)ro; pa.single_off = (uint32_t)so;
+        pa.row_off = (uint32_t)(rows - pa.deep_base); pa.single_off = (uint32_t)(sing - pa.deep_base);
     }
     if (pa.fast) {
         pa.nsub = 4;
         while (pa.nsub > 1 && acx_ppm_stream_layout(ph.g_words, ph.sym_bits, pa.halo_pos, pa.nsub).total_words * 4 > ACX_PPM_LDS_BYTES) pa.nsub >>= 1;
         pa.lds = acx_ppm_stream_layout(ph.g_words, ph.sym_bits, pa.halo_pos, pa.nsub);
-        if (pa.lds.total_words * 4 > ACX_PPM_LDS_BYTES) { pa.fast = 0; r->ppm_stream = false; pa.lds = acx_ppm_lds_layout(ph.g_words, ph.sym_bits, ph.longest); }
     }
     if (pa.fast) {
         const int64_t tpos = (int64_t)pa.nsub * 256;
@@ -595,8 +617,10 @@ extern "C" int acx_scan_batch(acx_image_t* img, const acx_scan_params* p, acx_re
     // position-parallel kernels: ACX_SCAN_ALL on an image that carries the structures, no carried-in state
     // (variant bit 23 turns them off: A/B against the serial walks)
     if (p->mode == ACX_SCAN_ALL && img->ppm_g && !p->dev_init_state && p->n_hay > 0 && !((p->variant >> 23) & 1) &&
-        (p->dev_off || p->stride > 0))
-        return scan_ppm(img, p, r, s);
+        (p->dev_off || p->stride > 0)) {
+        const int plan = ppm_plan(img, p);
+        if (plan) return scan_ppm(img, p, r, s, plan);
+    }
 
     const size_t n = (size_t)p->n_hay;
     int rc;

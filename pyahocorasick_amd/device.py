@@ -107,6 +107,20 @@ class Image:
     def itop_depth(self):
         return lib().acx_image_itop_depth(self.handle)
 
+    def ppm_kernel(self, stride=0, has_offsets=False, variant=0, dev_hay=0x1000, n_hay=1):
+        """which kernel family an ACX_SCAN_ALL scan of such a batch takes (acx_scan_plan): None = the serial
+        walks, "scan" = k_ppm_scan, "stream" = k_ppm_stream"""
+        p = ScanParams()
+        p.struct_bytes = C.sizeof(ScanParams)
+        p.mode = ACX_SCAN_ALL
+        p.dev_hay = dev_hay
+        p.hay_capacity = max(1, int(stride)) * n_hay
+        p.dev_off = 0x1000 if has_offsets else None
+        p.stride = int(stride)
+        p.n_hay = n_hay
+        p.variant = int(variant)
+        return {0: None, 1: "scan", 2: "stream"}.get(lib().acx_scan_plan(self.handle, C.byref(p)))
+
     def download_table(self):
         """the dense transition table the scans read, as uint32[n_states, n_classes] (tests/tools)"""
         n, K = self.num_states, self.num_classes

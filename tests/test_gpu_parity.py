@@ -306,15 +306,23 @@ def test_config2_full_size_properties(config2):
     assert np.all(de[same_h] >= 0)
     tie = same_h & (de == 0)
     assert np.all(ml[1:][tie] < ml[:-1][tie])
-    # (3) completeness on a deterministic 1% sample against the oracle (full lists)
+    # (3) completeness: the WHOLE batch against the oracle — every offset, every one of the 11.77 M records
     O = orc.Oracle()
     for i, k in enumerate(keys):
         O.add_word(k, i)
     O.make_automaton()
-    sample = np.arange(0, n, 100)
-    for h in sample[:4000]:
-        oe, ov, _ = O.iter_arrays(reads[h].tobytes())
-        assert np.array_equal(e[off[h]:off[h + 1]], oe) and np.array_equal(v[off[h]:off[h + 1]], ov), h
+    mo, oe, ov = O.batch_records(reads.reshape(-1), np.arange(n + 1, dtype=np.int64) * L, 0)
+    assert total == mo[-1] and np.array_equal(off, mo) and np.array_equal(e, oe) and np.array_equal(v, ov)
+    # ... and the reference ITSELF (oracle/_ref, when it travelled) on a deterministic 1 % sample
+    ref = orc.load_reference()
+    if ref is not None:
+        R = ref.Automaton(ref.STORE_INTS)
+        for i, k in enumerate(keys):
+            R.add_word(k, i)
+        R.make_automaton()
+        for h in range(0, n, 100):
+            got = list(zip(e[off[h]:off[h + 1]].tolist(), v[off[h]:off[h + 1]].tolist()))
+            assert got == list(R.iter(reads[h].tobytes())), h
     # (4) planted keys are found: every even read had a key planted
     # (5) batch-split invariance: scanning the two halves separately gives the same records
     half = n // 2
@@ -329,7 +337,7 @@ def test_config2_full_size_properties(config2):
 
 
 @pytest.mark.slow
-def test_config5_iter_long_full_size_sample(config2):
+def test_config5_iter_long_full_size(config2):
     keys, reads, A, img, d_hay = config2
     n, L = reads.shape
     sc = Scanner(img)
@@ -340,14 +348,17 @@ def test_config5_iter_long_full_size_sample(config2):
     for i, k in enumerate(keys):
         O.add_word(k, i)
     O.make_automaton()
-    for h in range(0, n, 500):
-        exp = O.iter_long(reads[h].tobytes())
-        got = list(zip(e[off[h]:off[h + 1]].tolist(), v[off[h]:off[h + 1]].tolist()))
-        assert got == exp, h
-    # non-overlap property of iter_long: strictly increasing end indices inside a haystack
-    hay_of = np.repeat(np.arange(n), np.diff(off))
-    same_h = hay_of[1:] == hay_of[:-1]
-    assert np.all(np.diff(e.astype(np.int64))[same_h] > 0)
+    mo, oe, ov = O.batch_records(reads.reshape(-1), np.arange(n + 1, dtype=np.int64) * L, 1)     # the whole batch
+    assert total == mo[-1] and np.array_equal(off, mo) and np.array_equal(e, oe) and np.array_equal(v, ov)
+    ref = orc.load_reference()
+    if ref is not None:
+        R = ref.Automaton(ref.STORE_INTS)
+        for i, k in enumerate(keys):
+            R.add_word(k, i)
+        R.make_automaton()
+        for h in range(0, n, 100):
+            got = list(zip(e[off[h]:off[h + 1]].tolist(), v[off[h]:off[h + 1]].tolist()))
+            assert got == list(R.iter_long(reads[h].tobytes())), h
 
 
 def test_wide_layout_on_gpu(monkeypatch):

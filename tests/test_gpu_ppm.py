@@ -16,7 +16,7 @@ from helpers import build_pair
 pytestmark = pytest.mark.gpu
 
 SERIAL = 1 << 23          # serial walk kernels instead of the position-parallel ones
-GENERAL = 1 << 24         # k_ppm_scan (any batch) instead of k_ppm_tiles (fixed stride, aligned, bit-field codes)
+GENERAL = (1 << 24) | (1 << 28)   # k_ppm_scan (any batch; bit 28: even where the serial walks would be chosen) instead of k_ppm_stream
 
 
 def _ppm_fields(blob):
@@ -39,7 +39,7 @@ def _three_way(A, O, data, off, stride=None, index_base=None, want_final=True):
     d_base = DeviceBuffer.from_numpy(np.asarray(index_base, dtype=np.int32)) if index_base is not None else None
     fins = []
     entries = [dict(dev_off=d_off)] + ([dict(stride=stride)] if stride else [])
-    for variant in (0, GENERAL, SERIAL):
+    for variant in (1 << 28, GENERAL, SERIAL):
         for kw in entries:
             sc = Scanner(img)
             sc.scan(d_hay, len(data), n, dev_index_base=d_base, want_final_state=want_final, variant=variant, **kw)
