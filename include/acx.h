@@ -186,12 +186,15 @@ const void* acx_image_table_dev_ptr(const acx_image_t* img);
  *    Optional per-haystack device arrays (NULL = absent):
  *           dev_init_state  int32[n_hay]  start state  (streaming continuation; the
  *                           state that AutomatonSearchIter.set(chunk, reset=False) keeps,
- *                           src/AutomatonSearchIter.c:344-352).  State ids are image ids.
+ *                           src/AutomatonSearchIter.c:344-352).  State ids are image ids; an id
+ *                           that the image does not have is taken as the root.
  *           dev_index_base  int32[n_hay]  added to every reported end_index (`shift`,
  *                           src/AutomatonSearchIter.c:178, or the `start` of a slice).
  *    Output (acx_result_t, device resident, optionally copied to pinned host memory):
  *           match_off int64[n_hay+1]; matches acx_match_t[match_off[n_hay]] in haystack
- *           order; final_state int32[n_hay] (ACX_SCAN_ALL only).
+ *           order; final_state int32[n_hay] (ACX_SCAN_LONG: the trie node the walk stands on when the
+ *           haystack ends — what AutomatonSearchIterLong.set(chunk, reset=False) continues from,
+ *           src/AutomatonSearchIterLong.c:194-211).
  * ---------------------------------------------------------------------------------- */
 typedef struct acx_match {
     int32_t end_index;   /* index of the LAST byte of the match within its haystack */

@@ -17,6 +17,8 @@ runs on the GPU through the C-ABI (include/acx.h); there is NO CPU search path h
 without a GPU, iter()/iter_long()/find_all()/iter_batch() raise.
 """
 import ctypes as C
+import functools
+import threading
 
 import numpy as np
 
@@ -109,6 +111,15 @@ class BatchResult:
         return [list(zip(ends[off[k]:off[k + 1]], vals[off[k]:off[k + 1]])) for k in range(len(off) - 1)]
 
 
+def _locked(fn):
+    """one mutation or scan at a time per Automaton (ctypes drops the GIL inside libacx calls)"""
+    @functools.wraps(fn)
+    def wrapper(self, *a, **kw):
+        with self._lock:
+            return fn(self, *a, **kw)
+    return wrapper
+
+
 class Automaton:
     def __init__(self, *args):
         """Automaton([store, [key_type]]) — or the 7-tuple of `__reduce__`
@@ -117,6 +128,8 @@ class Automaton:
         self._trie = C.c_void_p()
         self._image = None
         self._result = C.c_void_p()                          # reusable device/pinned buffers
+        self._lock = threading.RLock()
+        self._free_slots = []                                # STORE_ANY: value slots freed by remove_word / pop
         pickled = None
         if len(args) == 7:
             pickled = args
@@ -262,6 +275,7 @@ class Automaton:
             raise TypeError(what)
         return key
 
+    @_locked
     def add_word(self, key, *value):
         key = self._key(key)
         if self._store == STORE_ANY:
@@ -274,6 +288,9 @@ class Automaton:
                 return False
             if found.value:
                 vid = old.value
+                self._values[vid] = value[0]
+            elif self._free_slots:                     # reuse a slot that remove_word / pop freed
+                vid = self._free_slots.pop()
                 self._values[vid] = value[0]
             else:
                 vid = len(self._values)
@@ -320,6 +337,7 @@ class Automaton:
         check(lib().acx_trie_longest_prefix(self._trie, key, len(key), C.byref(n)))
         return n.value
 
+    @_locked
     def _remove(self, key):
         key = self._key(key)
         found = C.c_int(0)
@@ -330,6 +348,7 @@ class Automaton:
         if self._store == STORE_ANY:
             obj = self._values[val.value]
             self._values[val.value] = None
+            self._free_slots.append(val.value)
             return True, obj
         return True, val.value
 
@@ -342,12 +361,15 @@ class Automaton:
             raise KeyError(key)
         return v
 
+    @_locked
     def clear(self):
         lib().acx_trie_clear(self._trie)
         if self._values is not None:
             self._values = []
+            self._free_slots = []
         self._drop_image()
 
+    @_locked
     def make_automaton(self):
         changed = C.c_int(0)
         check(lib().acx_trie_make_automaton(self._trie, C.byref(changed)))
@@ -394,7 +416,6 @@ class Automaton:
         if self.kind != AHOCORASICK:
             raise AttributeError("Not an Aho-Corasick automaton yet: call add_word to add some keys and call "
                                  "make_automaton to convert the trie to an automaton.")
-        img = self._ensure_image()
         buf = np.frombuffer(data, dtype=np.uint8) if not isinstance(data, np.ndarray) else np.ascontiguousarray(data, dtype=np.uint8)
         off = np.ascontiguousarray(offsets, dtype=np.int64)
         n = len(off) - 1
@@ -402,6 +423,16 @@ class Automaton:
             raise ValueError("bad offsets")
         init = None if init_state is None else np.ascontiguousarray(init_state, dtype=np.int32)
         base = None if index_base is None else np.ascontiguousarray(index_base, dtype=np.int32)
+        if (init is not None and init.shape != (n,)) or (base is not None and base.shape != (n,)):
+            raise ValueError("init_state and index_base need one entry per haystack")
+        # ctypes drops the GIL inside every libacx call, and the image and the result buffers belong to this
+        # Automaton: one scan (image refresh, kernels, fetch) at a time per object.  The reference holds the
+        # GIL for the whole of every call, so sharing an automaton between threads is safe there too.
+        with self._lock:
+            return self._scan_locked(buf, off, n, mode, init, base)
+
+    def _scan_locked(self, buf, off, n, mode, init, base):
+        img = self._ensure_image()
         check(lib().acx_scan_host(img.handle, mode, buf.ctypes.data if buf.size else None, off.ctypes.data, n,
                                   init.ctypes.data if init is not None else None,
                                   base.ctypes.data if base is not None else None,
@@ -465,6 +496,8 @@ class Automaton:
     def match(self, key):
         """True iff `key` is a prefix of some key (src/Automaton.c:460-479)"""
         key = self._key(key)
+        if self.kind == EMPTY:             # trie_find on a NULL root (src/trie.c:136-152)
+            return False
         return self.longest_prefix(key) == len(key)
 
     def dump(self):
@@ -556,10 +589,13 @@ _WS[[9, 10, 11, 12, 13, 32]] = True      # iswspace() over the letters the bytes
 
 
 class AutomatonSearchIter:
-    """iterator of (end_index, value); mirrors src/AutomatonSearchIter.c.
+    """iterator of (end_index, value); mirrors src/AutomatonSearchIter.c and, with long_mode,
+    src/AutomatonSearchIterLong.c (same rules as the CPython extension, csrc/ahocorasick_module.cpp).
 
     The whole range is scanned on the GPU at construction / set(); next() hands the tuples
     out one by one and re-checks the automaton version like the reference (:247-250)."""
+
+    _long = False
 
     def __init__(self, automaton, string, start, end, ignore_white_space=False):
         self._a = automaton
@@ -569,7 +605,7 @@ class AutomatonSearchIter:
         self._shift = 0
         self._load(string, start, end)
 
-    def _load(self, string, start, end):
+    def _scan(self, string, start, end, state, shift):
         chunk = string[start:end]
         remap = None
         if self._ws:
@@ -578,14 +614,21 @@ class AutomatonSearchIter:
             arr = np.frombuffer(chunk, dtype=np.uint8)
             remap = np.flatnonzero(~_WS[arr])
             chunk = arr[remap].tobytes()
-        res = self._a.scan_batch(chunk, [0, len(chunk)], ACX_SCAN_ALL, init_state=[self._state],
-                                 index_base=[0 if remap is not None else start + self._shift])
+        res = self._a.scan_batch(chunk, [0, len(chunk)], ACX_SCAN_LONG if self._long else ACX_SCAN_ALL,
+                                 init_state=[state] if state else None,      # (the root needs none: such a scan may take the position-parallel kernels)
+                                 index_base=[0 if remap is not None else start + shift])
         if remap is not None and res.num_matches():
-            res.end_index = (remap[res.end_index] + (start + self._shift)).astype(np.int32)
-        self._pending = res.tolists()[0]
+            res.end_index = (remap[res.end_index] + (start + shift)).astype(np.int32)
+        return res.tolists()[0], (int(res.final_state[0]) if res.final_state is not None else 0)
+
+    def _load(self, string, start, end):
+        self._src, self._start, self._state0 = string, start, self._state
+        self._pending = []
+        if self._version == self._a._version:             # a stale iterator raises from next(); its state id belongs to an old image
+            self._pending, self._state = self._scan(string, start, end, self._state, self._shift)
         self._pos = 0
-        self._state = int(res.final_state[0]) if res.final_state is not None else 0
         self._end = end
+        self._exhausted = False          # StopIteration seen: the reference has walked the whole chunk
         self._ref_index = start - 1     # the reference's iter->index (src/AutomatonSearchIter.c:123)
 
     def __iter__(self):
@@ -596,6 +639,7 @@ class AutomatonSearchIter:
             raise ValueError("underlaying automaton has changed, iterator is not valid anymore")
         if self._pos >= len(self._pending):
             self._ref_index = self._end
+            self._exhausted = True
             raise StopIteration
         item = self._pending[self._pos]
         self._pos += 1
@@ -603,39 +647,35 @@ class AutomatonSearchIter:
         return item
 
     def set(self, string, reset=False):
-        """src/AutomatonSearchIter.c:303-368: continue on a new chunk (keep state, accumulate
-        shift) or reset to the root."""
+        """src/AutomatonSearchIter.c:303-368 / src/AutomatonSearchIterLong.c:156-216: continue on a new chunk
+        (keep the state, accumulate the shift) or reset to the root."""
         if not isinstance(string, bytes):
             raise TypeError("bytes expected")
         if reset:
             self._state = 0
             self._shift = 0
         else:
+            if not self._exhausted and self._version == self._a._version:
+                # set() before StopIteration (the chunk was scanned eagerly, the reference has only walked up to the
+                # last match it returned): iter_long is at the root after every match (src/AutomatonSearchIterLong.c:
+                # 101-110); iter holds the state after the last yielded position, found by scanning that prefix of
+                # the old chunk again
+                if self._long:
+                    self._state = 0 if self._ref_index >= self._start else self._state0   # (nothing returned yet: untouched)
+                else:
+                    upto = max(self._ref_index + 1, self._start)
+                    _, self._state = self._scan(self._src, self._start, upto, self._state0, 0)
             self._shift += self._ref_index if self._ref_index >= 0 else 0   # :344-352
         self._load(string, 0, len(string))
 
 
-class AutomatonSearchIterLong:
+class AutomatonSearchIterLong(AutomatonSearchIter):
     """mirrors src/AutomatonSearchIterLong.c (longest, non-overlapping; see the oracle for quirks)."""
 
+    _long = True
+
     def __init__(self, automaton, string, start, end):
-        self._a = automaton
-        self._version = automaton._version
-        res = automaton.scan_batch(string[start:end], [0, end - start], ACX_SCAN_LONG, index_base=[start])
-        self._pending = res.tolists()[0]
-        self._pos = 0
-
-    def __iter__(self):
-        return self
-
-    def __next__(self):
-        if self._version != self._a._version:
-            raise ValueError("underlaying automaton has changed, iterator is not valid anymore")
-        if self._pos >= len(self._pending):
-            raise StopIteration
-        item = self._pending[self._pos]
-        self._pos += 1
-        return item
+        AutomatonSearchIter.__init__(self, automaton, string, start, end, False)
 
 
 class _RefMeta(C.Structure):

@@ -576,7 +576,7 @@ static int scan_ppm(acx_image_t* img, const acx_scan_params* p, acx_result* r, h
         acx_walk_args& wa = r->pend_tail;
         memset(&wa, 0, sizeof wa);
         wa.hay = p->dev_hay; wa.hay_cap = p->hay_capacity; wa.off = p->dev_off; wa.stride = p->stride; wa.n_hay = p->n_hay;
-        wa.cls = img->cls; wa.table = img->table; wa.row_bytes = img->h.n_classes * 4u; wa.state_bits = img->h.state_bits;
+        wa.cls = img->cls; wa.table = img->table; wa.row_bytes = img->h.n_classes * 4u; wa.state_bits = img->h.state_bits; wa.n_states = img->h.n_states;
         wa.final_state = r->final_state.p;
     }
     r->pend_img = img;
@@ -600,8 +600,6 @@ extern "C" int acx_scan_batch(acx_image_t* img, const acx_scan_params* p, acx_re
     if (p->hay_capacity > ACX_MAX_LAUNCH_BYTES)
         return acx_fail(ACX_E_UNSUPPORTED, "acx_scan_batch: %lld haystack bytes in one call; split the batch into calls of <= %lld bytes",
                         (long long)p->hay_capacity, (long long)ACX_MAX_LAUNCH_BYTES);
-    if (p->mode == ACX_SCAN_LONG && p->dev_init_state)
-        return acx_fail(ACX_E_UNSUPPORTED, "acx_scan_batch: init_state is not supported for ACX_SCAN_LONG");
 
     hipStream_t s = (hipStream_t)stream_v;
     acx_result* r = *result;
@@ -665,6 +663,7 @@ extern "C" int acx_scan_batch(acx_image_t* img, const acx_scan_params* p, acx_re
     wa.hay = p->dev_hay; wa.hay_cap = p->hay_capacity; wa.off = p->dev_off; wa.stride = p->stride; wa.n_hay = p->n_hay;
     wa.init_state = p->dev_init_state; wa.index_base = p->dev_index_base;
     wa.cls = img->cls; wa.table = img->table; wa.out_off = img->out_off; wa.row_bytes = img->h.n_classes * 4u; wa.state_bits = img->h.state_bits;
+    wa.n_states = img->h.n_states;
     wa.counts = r->counts.p; wa.nev = r->nev.p; wa.events = r->events.p;
     wa.final_state = r->has_final ? r->final_state.p : nullptr;
 
@@ -788,7 +787,7 @@ static int scan_host_once(acx_image_t* img, int mode, const uint8_t* hay, const 
     p.dev_hay = r->in_hay.p; p.hay_capacity = total_bytes; p.dev_off = r->in_off.p; p.stride = 0; p.n_hay = n_hay;
     p.dev_init_state = init_state ? r->in_init.p : nullptr;
     p.dev_index_base = index_base ? r->in_base.p : nullptr;
-    p.want_final_state = mode == ACX_SCAN_ALL ? 1 : 0;
+    p.want_final_state = 1;
     return acx_scan_batch(img, &p, result, nullptr);
 }
 

@@ -22,6 +22,7 @@ struct acx_walk_args {
     const uint32_t* out_off;   // uint32[n_states+1]
     uint32_t        row_bytes; // K*4
     uint32_t        state_bits; // entry layout: 24 (narrow) or 27 (wide), include/acx_blob.h
+    uint32_t        n_states;   // init_state entries at or beyond it are taken as the root
     // outputs
     int32_t* counts;           // matches per haystack
     int32_t* nev;              // events per haystack

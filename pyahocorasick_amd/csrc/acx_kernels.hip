@@ -187,6 +187,7 @@ __global__ void __launch_bounds__(ACX_BLOCK, ILP == 1 ? ACX_PLAIN_WPE : 5) k_wal
             len[q] = (int)(e - b);
             p[q] = a.hay + b;
             L[q].state = (valid[q] && a.init_state) ? (uint32_t)a.init_state[h[q]] : 0u;
+            if (L[q].state >= a.n_states) L[q].state = 0u;
             L[q].cnt = 0;
             L[q].ev = a.events + b;
             ev0[q] = L[q].ev;
@@ -293,6 +294,7 @@ __global__ void __launch_bounds__(ACX_BLOCK, 8) k_walk_chunks(const acx_walk_arg
         const int len = d.len, emit = d.emit;
         LaneState L;
         L.state = (valid && a.init_state && (d.flags & 1)) ? (uint32_t)a.init_state[d.hay] : 0u;
+        if (L.state >= a.n_states) L.state = 0u;
         L.cnt = 0;
         L.ev = a.events + d.start + emit;
         uint2* const ev0 = L.ev;
@@ -897,7 +899,10 @@ __global__ void __launch_bounds__(ACX_BLOCK) k_walk_long(const acx_walk_args a) 
         uint2* const ev0 = ev;
         const uint32_t base = a.index_base ? (uint32_t)a.index_base[h] : 0u;
 
-        uint32_t state = 0;
+        // a carried-in state (AutomatonSearchIterLong.set(chunk, reset=False) keeps iter->state,
+        // src/AutomatonSearchIterLong.c:194-211) is the trie node the unfinished walk stood on
+        uint32_t state = a.init_state ? (uint32_t)a.init_state[h] : 0u;
+        if (state >= a.n_states) state = 0u;
         int index = 0;
         bool have_last = false;
         int last_index = -1;
@@ -944,7 +949,7 @@ __global__ void __launch_bounds__(ACX_BLOCK) k_walk_long(const acx_walk_args a) 
         const int32_t n = (int32_t)(ev - ev0);
         a.counts[h] = n;
         a.nev[h] = n;
-        if (a.final_state) a.final_state[h] = 0;
+        if (a.final_state) a.final_state[h] = (int32_t)(state & ACX_ENTRY_STATE_MASK(SB));   // where the walk stands when the haystack ends
     }
 }
 

@@ -93,7 +93,11 @@ int build_trie(const std::vector<RawNode>& raw, bool values_by_position, int64_t
                 // the bytes build widens `char` key bytes to uint16 letters, so bytes >= 0x80 arrive
                 // sign-extended (0xFF80..0xFFFF)
                 const uint16_t letter = rd16(raw[k].pairs + (size_t)j * PAIR);
-                if (letter > 0x7F && letter < 0xFF80) { rc = acx_fail(ACX_E_FORMAT, "reference dump: node #%zu has letter %u: not a bytes-build dump", k, letter); break; }
+                // ... or zero-extended (0x0080..0x00FF) where the reference was built with an unsigned `char` (aarch64)
+                if (letter > 0xFF && letter < 0xFF80) { rc = acx_fail(ACX_E_FORMAT, "reference dump: node #%zu has letter %u: not a bytes-build dump", k, letter); break; }
+                for (int32_t sib = nd.first_child; sib >= 0 && rc == ACX_OK; sib = t->nodes[sib].next_sibling)
+                    if (t->nodes[sib].letter == (uint8_t)letter) rc = acx_fail(ACX_E_FORMAT, "reference dump: node #%zu has two edges with letter %u", k, (unsigned)(uint8_t)letter);
+                if (rc != ACX_OK) break;
                 linked[c] = 1;
                 depth[c] = depth[k] + 1;
                 t->nodes[c].letter = (uint8_t)letter;
@@ -318,21 +322,49 @@ int acx_trie_from_ref_pickle(const void* const* chunks, const size_t* chunk_byte
     const size_t PAIR = letter_bytes == 4 ? PAIR_UCS4 : ::PAIR;
     std::vector<RawNode> raw;
     try {
+        // automaton_unpickle__validate_bytes_list (src/Automaton_pickle.c:288-322): every chunk starts with a
+        // positive node count; their sum is what links are checked against
+        uint64_t count = 0;
         for (size_t c = 0; c < n_chunks; c++) {
             const uint8_t* p = (const uint8_t*)chunks[c];
-            const uint8_t* end = p + chunk_bytes[c];
-            if (!p || chunk_bytes[c] < 8) return acx_fail(ACX_E_FORMAT, "pickle chunk #%zu: too short", c);
+            if (!p || chunk_bytes[c] < 8) return acx_fail(ACX_E_FORMAT, "Data truncated [parsing the nodes count]: chunk #%zu has %zu bytes", c, chunk_bytes[c]);
             const int64_t cnt = (int64_t)rd64(p);
-            if (cnt <= 0) return acx_fail(ACX_E_FORMAT, "pickle chunk #%zu: nodes count is not positive", c);   // src/Automaton_pickle.c:306-311
-            p += 8;
+            if (cnt <= 0) return acx_fail(ACX_E_FORMAT, "Nodes count for item #%zu on the bytes list is not positive (%llu)", c, (unsigned long long)cnt);
+            count += (uint64_t)cnt;
+        }
+        // 1. the records (src/Automaton_pickle.c:362-418)
+        std::vector<uint64_t> fail_raw;
+        for (size_t c = 0; c < n_chunks; c++) {
+            const uint8_t* data = (const uint8_t*)chunks[c];
+            const uint8_t* p = data + 8;
+            const uint8_t* end = data + chunk_bytes[c];
+            const int64_t cnt = (int64_t)rd64(data);
             for (int64_t i = 0; i < cnt; i++) {
-                if ((size_t)(end - p) < REC) return acx_fail(ACX_E_FORMAT, "pickle chunk #%zu: data truncated in the header of node #%lld", c, (long long)i);
+                if ((size_t)(end - p) < REC)
+                    return acx_fail(ACX_E_FORMAT, "Data truncated [parsing header of node #%lld]: chunk #%zu @ offset %zu, expected at least %zu bytes",
+                                    (long long)i, c, (size_t)(p - data), REC);
                 RawNode r;
                 r.output = rd64(p); r.n = rd32(p + 16); r.eow = p[20]; r.pairs = p + REC;
+                fail_raw.push_back(rd64(p + 8));
                 p += REC;
-                if ((size_t)(end - p) < (size_t)r.n * PAIR) return acx_fail(ACX_E_FORMAT, "pickle chunk #%zu: data truncated in the children of node #%lld", c, (long long)i);
+                if ((size_t)(end - p) < (size_t)r.n * PAIR)
+                    return acx_fail(ACX_E_FORMAT, "Data truncated [parsing children of node #%lld]: chunk #%zu @ offset %zu, expected at least %zu bytes",
+                                    (long long)i, c, (size_t)(p - data) + (size_t)i, (size_t)r.n * PAIR);
                 p += (size_t)r.n * PAIR;
                 raw.push_back(r);
+            }
+        }
+        // 2. the links (src/Automaton_pickle.c:421-456): ids are 1-based, 0 = NULL, at most `count`
+        const size_t lb = (size_t)letter_bytes;
+        for (size_t k = 0; k < raw.size(); k++) {
+            if (fail_raw[k] > count)
+                return acx_fail(ACX_E_FORMAT, "Node #%zu malformed: the fail link points to node #%llu, while there are %llu nodes",
+                                k, (unsigned long long)fail_raw[k], (unsigned long long)count);
+            for (uint32_t j = 0; j < raw[k].n; j++) {
+                const uint64_t child = rd64(raw[k].pairs + (size_t)j * PAIR + lb);
+                if (child > count)
+                    return acx_fail(ACX_E_FORMAT, "Node #%zu malformed: next link #%u points to node #%llu, while there are %llu nodes",
+                                    k, j, (unsigned long long)child, (unsigned long long)count);
             }
         }
     } catch (const std::bad_alloc&) {

@@ -44,6 +44,7 @@ struct AutomatonObject {
     acx_image_t* image;        // device image, valid for image_version
     int64_t image_version;
     acx_result_t* result;      // reusable device / pinned buffers
+    std::vector<Py_ssize_t>* free_slots;   // STORE_ANY: slots of `values` freed by remove_word / pop, reused by add_word
 };
 
 PyObject* set_acx_error(int rc) {
@@ -112,9 +113,14 @@ bool get_sequence(PyObject* o, Text* t, bool haystack) {
     for (Py_ssize_t i = 0; i < n; i++) {
         const Py_ssize_t v = PyNumber_AsSsize_t(PyTuple_GET_ITEM(o, i), PyExc_ValueError);
         if (v == -1 && PyErr_Occurred()) { PyErr_Format(PyExc_ValueError, "item #%zd is not a number", i); return false; }
-        const unsigned long max_val = ACX_UNICODE_BUILD ? 2147483647ul : 65535ul;     // (the unicode build allows 2^32-1)
+        // the reference's range and wording (src/utils.c:258-268); letters are stored in 31 bits here
+        const unsigned long max_val = ACX_UNICODE_BUILD ? 4294967295ul : 65535ul;
         if (v < 0 || (unsigned long)v > max_val) {
             PyErr_Format(PyExc_ValueError, "item #%zd: value %zd outside range [%d..%lu]", i, v, 0, max_val);
+            return false;
+        }
+        if ((unsigned long)v > 2147483647ul) {
+            PyErr_Format(PyExc_ValueError, "item #%zd: value %zd is beyond the 31 bits this build stores per sequence letter", i, v);
             return false;
         }
         encode_letter((uint32_t)v, t->own);
@@ -241,9 +247,10 @@ bool gpu_sync(AutomatonObject* a) {
     void* blob = nullptr; size_t nbytes = 0;
     int rc = acx_flatten(a->trie, &blob, &nbytes);
     if (rc) { set_acx_error(rc); return false; }
-    Py_BEGIN_ALLOW_THREADS
+    // the GIL stays held, here and around the scan: the image and the result buffers belong to this
+    // Automaton object and the reference never releases it either (sharing an automaton between
+    // threads is safe there: src/Automaton.c holds the GIL for the whole of every call)
     rc = acx_image_upload(blob, nbytes, &a->image);
-    Py_END_ALLOW_THREADS
     acx_blob_free(blob);
     if (rc) { set_acx_error(rc); return false; }
     a->image_version = v;
@@ -255,11 +262,8 @@ bool run_scan(AutomatonObject* a, int mode, const uint8_t* data, const int64_t* 
               const int32_t* init_state, const int32_t* index_base,
               const int64_t** moff, const acx_match_t** m, const int32_t** fin) {
     if (!gpu_sync(a)) return false;
-    int rc;
-    Py_BEGIN_ALLOW_THREADS      // the reference never releases the GIL; a GPU scan can
-    rc = acx_scan_host(a->image, mode, data, off, n, init_state, index_base, &a->result);
+    int rc = acx_scan_host(a->image, mode, data, off, n, init_state, index_base, &a->result);
     if (!rc) rc = acx_result_fetch_host(a->result, moff, m, fin);
-    Py_END_ALLOW_THREADS
     if (rc) { set_acx_error(rc); return false; }
     return true;
 }
@@ -290,6 +294,7 @@ AutomatonObject* automaton_alloc(PyTypeObject* type, int store, int key_type) {
     AutomatonObject* a = (AutomatonObject*)type->tp_alloc(type, 0);
     if (!a) return nullptr;
     a->trie = nullptr; a->values = nullptr; a->image = nullptr; a->result = nullptr; a->image_version = -1;
+    a->free_slots = new (std::nothrow) std::vector<Py_ssize_t>();
     a->store = store; a->key_type = key_type;
     return a;
 }
@@ -374,6 +379,7 @@ void automaton_dealloc(AutomatonObject* a) {
     if (a->result) acx_result_free(a->result);
     if (a->trie) acx_trie_free(a->trie);
     Py_XDECREF(a->values);
+    delete a->free_slots;
     Py_TYPE(a)->tp_free((PyObject*)a);
 }
 
@@ -396,6 +402,7 @@ PyObject* automaton_add_word(AutomatonObject* a, PyObject* args) {
         int rc = acx_trie_get(a->trie, key, (size_t)len, &found, &old);
         if (rc) return set_acx_error(rc);
         if (found) slot = (Py_ssize_t)old;
+        else if (a->free_slots && !a->free_slots->empty()) { slot = a->free_slots->back(); a->free_slots->pop_back(); }
         else {
             slot = PyList_GET_SIZE(a->values);
             if (PyList_Append(a->values, Py_None) < 0) return nullptr;
@@ -467,7 +474,10 @@ PyObject* automaton_longest_prefix(AutomatonObject* a, PyObject* args) {
     size_t n = 0;
     int rc = acx_trie_longest_prefix(a->trie, key, (size_t)len, &n);
     if (rc) return set_acx_error(rc);
-    // (multi-byte letters: a prefix that ends inside a letter still counts only whole letters)
+    // one byte is one letter for bytes keys (KEY_STRING of the bytes build): bytes 0x80..0xBF are letters
+    // like any other.  Multi-byte letters (str build, KEY_SEQUENCE): a prefix that ends inside a letter
+    // still counts only whole letters.
+    if (!ACX_UNICODE_BUILD && a->key_type != KEY_SEQUENCE) return PyLong_FromSize_t(n);
     while (n > 0 && n < (size_t)len && !is_char_start(key[n])) n--;
     return PyLong_FromSize_t((size_t)chars_in(key, (Py_ssize_t)n));
 }
@@ -487,6 +497,7 @@ int remove_common(AutomatonObject* a, PyObject* args, PyObject** out) {
         Py_INCREF(o);
         Py_INCREF(Py_None);
         PyList_SetItem(a->values, (Py_ssize_t)v, Py_None);
+        if (a->free_slots) a->free_slots->push_back((Py_ssize_t)v);
         *out = o;
     } else *out = PyLong_FromLongLong((long long)v);
     return 1;
@@ -512,15 +523,14 @@ PyObject* automaton_pop(AutomatonObject* a, PyObject* args) {
 PyObject* automaton_clear(AutomatonObject* a, PyObject*) {
     acx_trie_clear(a->trie);
     if (a->values) { if (PyList_SetSlice(a->values, 0, PyList_GET_SIZE(a->values), nullptr) < 0) return nullptr; }
+    if (a->free_slots) a->free_slots->clear();
     if (a->image) { acx_image_free(a->image); a->image = nullptr; }
     Py_RETURN_NONE;
 }
 
 PyObject* automaton_make_automaton(AutomatonObject* a, PyObject*) {
-    int changed = 0, rc;
-    Py_BEGIN_ALLOW_THREADS
-    rc = acx_trie_make_automaton(a->trie, &changed);
-    Py_END_ALLOW_THREADS
+    int changed = 0;
+    const int rc = acx_trie_make_automaton(a->trie, &changed);       // (GIL held: the trie is being rewritten)
     if (rc) return set_acx_error(rc);
     if (changed) Py_RETURN_NONE;
     Py_RETURN_FALSE;                                               // src/Automaton.c:574-575
@@ -542,6 +552,12 @@ struct SearchIterObject {
     Py_ssize_t end;
     bool ignore_ws;
     bool is_long;
+    // what set() needs when it is called before the iterator is exhausted: the state the reference holds
+    // then is the one after the last yielded position, found by scanning that prefix of this chunk again
+    PyObject* src;          // the object being scanned (strong reference)
+    Py_ssize_t start;       // first letter of the scanned slice
+    int32_t state0;         // state before this chunk
+    bool exhausted;         // StopIteration seen: the reference has walked the whole chunk
 };
 
 extern PyTypeObject SearchIterType;
@@ -573,7 +589,8 @@ bool scan_text(AutomatonObject* a, int mode, const Text& t, Py_ssize_t start, Py
     }
     const int64_t* moff; const acx_match_t* m; const int32_t* fin;
     int32_t init = state_io ? *state_io : 0;
-    if (!run_scan(a, mode, scan_src, off, 1, state_io ? &init : nullptr, nullptr, &moff, &m, &fin)) return false;
+    // (the root needs no init_state array: such a scan may take the position-parallel kernels)
+    if (!run_scan(a, mode, scan_src, off, 1, (state_io && init != 0) ? &init : nullptr, nullptr, &moff, &m, &fin)) return false;
     out->assign(m, m + moff[1]);
     for (auto& r : *out) {
         int32_t byte_off = ignore_ws ? remap[(size_t)r.end_index] : r.end_index;
@@ -585,27 +602,34 @@ bool scan_text(AutomatonObject* a, int mode, const Text& t, Py_ssize_t start, Py
 }
 
 bool iter_load(SearchIterObject* it, const Text& t, Py_ssize_t start, Py_ssize_t end) {
-    if (!scan_text(it->automaton, it->is_long ? ACX_SCAN_LONG : ACX_SCAN_ALL, t, start, end, it->ignore_ws,
-                   it->is_long ? nullptr : &it->state, it->shift, it->pending)) return false;
-    it->pos = 0;
+    it->pending->clear();
+    it->start = start; it->state0 = it->state;
+    // an iterator whose automaton has changed raises from next() (src/AutomatonSearchIter.c:247-250): its state id
+    // belongs to an image that no longer exists, so nothing is scanned for it
+    if (it->version == acx_trie_version(it->automaton->trie) &&
+        !scan_text(it->automaton, it->is_long ? ACX_SCAN_LONG : ACX_SCAN_ALL, t, start, end, it->ignore_ws,
+                   &it->state, it->shift, it->pending)) return false;
+    it->pos = 0; it->exhausted = false;
     it->end = end;
     it->ref_index = start - 1;                                     // src/AutomatonSearchIter.c:123
     return true;
 }
 
-PyObject* search_iter_create(AutomatonObject* a, const Text& t, Py_ssize_t start, Py_ssize_t end, bool ws, bool is_long) {
+PyObject* search_iter_create(AutomatonObject* a, PyObject* srcobj, const Text& t, Py_ssize_t start, Py_ssize_t end, bool ws, bool is_long) {
     SearchIterObject* it = PyObject_New(SearchIterObject, &SearchIterType);
     if (!it) return nullptr;
     it->automaton = a; Py_INCREF(a);
     it->version = acx_trie_version(a->trie);
     it->pending = new std::vector<acx_match_t>();
     it->pos = 0; it->state = 0; it->shift = 0; it->ref_index = -1; it->end = 0; it->ignore_ws = ws; it->is_long = is_long;
+    Py_INCREF(srcobj); it->src = srcobj; it->start = 0; it->state0 = 0;
     if (!iter_load(it, t, start, end)) { Py_DECREF(it); return nullptr; }
     return (PyObject*)it;
 }
 
 void search_iter_dealloc(SearchIterObject* it) {
     Py_XDECREF(it->automaton);
+    Py_XDECREF(it->src);
     delete it->pending;
     PyObject_Del(it);
 }
@@ -617,7 +641,7 @@ PyObject* search_iter_next(SearchIterObject* it) {
         PyErr_SetString(PyExc_ValueError, "underlaying automaton has changed, iterator is not valid anymore");
         return nullptr;
     }
-    if (it->pos >= it->pending->size()) { it->ref_index = it->end; return nullptr; }   // StopIteration
+    if (it->pos >= it->pending->size()) { it->ref_index = it->end; it->exhausted = true; return nullptr; }   // StopIteration
     const acx_match_t r = (*it->pending)[it->pos++];
     it->ref_index = (Py_ssize_t)r.end_index - it->shift;
     return make_pair(it->automaton, r.end_index, r.value);
@@ -629,7 +653,26 @@ PyObject* search_iter_set(SearchIterObject* it, PyObject* args) {  // src/Automa
     Text t;
     if (!get_text(s, &t, true, it->automaton->key_type)) return nullptr;
     if (reset) { it->state = 0; it->shift = 0; }
-    else it->shift += it->ref_index >= 0 ? it->ref_index : 0;
+    else {
+        if (!it->exhausted && it->version == acx_trie_version(it->automaton->trie)) {
+            // set() before StopIteration.  iter_long: the reference is at the root after every match it returned
+            // (src/AutomatonSearchIterLong.c:101-110).  iter: it holds the state after the last yielded position:
+            // scan that prefix of the old chunk again (the whole chunk was scanned eagerly, so it->state is the
+            // state at the chunk's END, which is not what the reference continues from)
+            if (it->is_long) it->state = it->ref_index >= it->start ? 0 : it->state0;      // (nothing returned yet: untouched)
+            else if (it->src) {
+                Text old;
+                if (!get_text(it->src, &old, true, it->automaton->key_type)) return nullptr;
+                std::vector<acx_match_t> drop;
+                int32_t st = it->state0;
+                const Py_ssize_t upto = it->ref_index + 1 > it->start ? it->ref_index + 1 : it->start;
+                if (!scan_text(it->automaton, ACX_SCAN_ALL, old, it->start, upto, it->ignore_ws, &st, 0, &drop)) return nullptr;
+                it->state = st;
+            }
+        }
+        it->shift += it->ref_index >= 0 ? it->ref_index : 0;
+    }
+    Py_INCREF(s); Py_XSETREF(it->src, s);
     if (!iter_load(it, t, 0, t.nchars)) return nullptr;
     Py_RETURN_NONE;
 }
@@ -656,7 +699,7 @@ PyObject* automaton_iter(AutomatonObject* a, PyObject* args, PyObject* kw) {
     if (st > n) st = n;
     if (en > n) en = n;
     if (en < st) en = st;
-    return search_iter_create(a, t, st, en, ws == 1, false);
+    return search_iter_create(a, s, t, st, en, ws == 1, false);
 }
 
 PyObject* automaton_iter_long(AutomatonObject* a, PyObject* args) {
@@ -670,7 +713,7 @@ PyObject* automaton_iter_long(AutomatonObject* a, PyObject* args) {
     Py_ssize_t st, en;
     if (!parse_start_end(args, 1, 2, 0, t.nchars, &st, &en)) return nullptr;
     if (en < st) en = st;
-    return search_iter_create(a, t, st, en, false, true);
+    return search_iter_create(a, PyTuple_GET_ITEM(args, 0), t, st, en, false, true);
 }
 
 PyObject* automaton_find_all(AutomatonObject* a, PyObject* args) {
@@ -857,6 +900,7 @@ PyObject* automaton_match(AutomatonObject* a, PyObject* args) {
     if (PyTuple_GET_SIZE(args) < 1) { PyErr_SetString(PyExc_TypeError, "match() takes a key"); return nullptr; }
     Text kt;
     if (!get_text(PyTuple_GET_ITEM(args, 0), &kt, false, a->key_type)) return nullptr;
+    if (acx_trie_kind(a->trie) == K_EMPTY) Py_RETURN_FALSE;         // trie_find on a NULL root (src/trie.c:136-152)
     size_t n = 0;
     int rc = acx_trie_longest_prefix(a->trie, kt.data, (size_t)kt.nbytes, &n);
     if (rc) return set_acx_error(rc);

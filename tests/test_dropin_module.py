@@ -156,3 +156,54 @@ def test_dropin_generated_fixtures_and_objects(ahocorasick):
     B.add_word(b"zzz", "zzz")
     with pytest.raises(ValueError):
         next(it)
+
+
+def test_longest_prefix_and_match_with_high_bytes_vs_reference(ahocorasick):
+    """bytes 0x80..0xBF are letters like any other in the bytes build (a key's byte is one letter): they must
+    not be mistaken for UTF-8 continuation bytes.  Cross-checked with the reference itself when it is present."""
+    import random
+    import pyahocorasick_amd as acx
+    from oracle import orc
+    ref = orc.load_reference()
+    rng = random.Random(5)
+    A, M = ahocorasick.Automaton(), acx.Automaton()
+    R = ref.Automaton() if ref is not None else None
+    keys = [b"\x88\x88\x90", b"3", b"\x80", b"a\xbf\xbfb", b"\xc3\xa9t\xc3\xa9"] + \
+           [bytes(rng.choice([0x80, 0x90, 0xBF, 0x41, 0xC3]) for _ in range(rng.randint(1, 6))) for _ in range(40)]
+    for k in keys:
+        A.add_word(k, k)
+        M.add_word(k, k)
+        if R is not None:
+            R.add_word(k, k)
+    assert A.longest_prefix(b"\x88\x88\x90") == 3 and A.longest_prefix(b"3\x88") == 1      # the advisor's two cases
+    probes = keys + [k[:-1] + b"\x80" for k in keys] + [k + b"\x90\x90" for k in keys] + [b"", b"\x90"]
+    for p in probes:
+        want = R.longest_prefix(p) if R is not None else M.longest_prefix(p)
+        assert A.longest_prefix(p) == want == M.longest_prefix(p), p
+        if R is not None:
+            assert A.match(p) == R.match(p) == M.match(p), p
+    E = ahocorasick.Automaton()
+    assert E.match(b"") is False and acx.Automaton().match(b"") is False                   # trie_find on an empty trie
+    if ref is not None:
+        assert ref.Automaton().match(b"") is False
+
+
+def test_store_any_value_slots_are_reused(ahocorasick):
+    A = ahocorasick.Automaton()
+    for round_ in range(50):
+        for i in range(20):
+            A.add_word(b"k%d" % i, ("v", round_, i))
+        for i in range(20):
+            assert A.pop(b"k%d" % i) == ("v", round_, i)
+    A.add_word(b"x", 1)
+    cls, args = A.__reduce__()                      # (what pickle calls)
+    B = cls(*args)
+    assert list(B.items()) == [(b"x", 1)]
+    import pyahocorasick_amd as acx
+    M = acx.Automaton()
+    for round_ in range(50):
+        for i in range(20):
+            M.add_word(b"k%d" % i, (round_, i))
+        for i in range(20):
+            assert M.pop(b"k%d" % i) == (round_, i)
+    assert len(M._values) <= 20
