@@ -155,6 +155,16 @@ int  acx_image_upload(const void* blob, size_t nbytes, acx_image_t** out);
  * broadcast).  The image does not own `dev_blob`; the caller keeps it alive.
  * `host_header` = the first ACX_BLOB_HEADER_BYTES of the blob in host memory. */
 int  acx_image_adopt(void* dev_blob, size_t nbytes, const void* host_header, acx_image_t** out);
+/* Replicate a flat image to every rank of an RCCL communicator with ONE ncclBroadcast of the blob over xGMI
+ * (plus an 8-byte one for its size) and adopt it in place: the multi-GPU set-up step of SURVEY.md §8(e) for
+ * hosts that have no torch (the reference's own C extension).  The scan itself needs no
+ * collective: every rank scans its own shard of the haystacks.
+ *   host_blob, nbytes : the blob from acx_flatten; read on `root` only (NULL / 0 elsewhere)
+ *   nccl_comm         : the caller's ncclComm_t (RCCL), passed as void*; this rank's device must be current
+ *   stream            : hipStream_t the broadcast is queued on (NULL = default); the call returns after it completed
+ * RCCL is resolved at run time from the process (the library that created `nccl_comm`), else librccl.so is
+ * opened: libacx has no link-time dependency on it.  The image owns its device copy. */
+int  acx_image_broadcast(const void* host_blob, size_t nbytes, void* nccl_comm, int root, int rank, void* stream, acx_image_t** out);
 void acx_image_free(acx_image_t* img);
 int64_t acx_image_num_states(const acx_image_t* img);
 int64_t acx_image_num_classes(const acx_image_t* img);

@@ -90,6 +90,7 @@ SIGNATURES = {
     "acx_image_table_dev_ptr": (C.c_void_p, [_P]),
     "acx_scan_batch": (C.c_int, [_P, C.POINTER(ScanParams), _PP, _P]),
     "acx_scan_plan": (C.c_int, [_P, C.POINTER(ScanParams)]),
+    "acx_image_broadcast": (C.c_int, [_P, C.c_size_t, _P, C.c_int, C.c_int, _P, _PP]),
     "acx_result_wait": (C.c_int, [_P]),
     "acx_result_num_matches": (C.c_int64, [_P]),
     "acx_result_offsets_dev": (C.c_void_p, [_P]),

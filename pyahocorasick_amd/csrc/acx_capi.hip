@@ -214,6 +214,63 @@ extern "C" int acx_image_adopt(void* dev_blob, size_t nbytes, const void* host_h
     return ACX_OK;
 }
 
+// ---- one RCCL broadcast of the blob (no link-time dependency on librccl: resolved from the process) ----
+#include <dlfcn.h>
+namespace {
+typedef int (*nccl_bcast_fn)(const void*, void*, size_t, int /*ncclDataType_t*/, int, void* /*ncclComm_t*/, hipStream_t);
+typedef const char* (*nccl_errstr_fn)(int);
+nccl_bcast_fn g_nccl_bcast = nullptr;
+nccl_errstr_fn g_nccl_errstr = nullptr;
+bool resolve_rccl() {
+    if (g_nccl_bcast) return true;
+    void* sym = dlsym(RTLD_DEFAULT, "ncclBroadcast");               // the RCCL already in the process (it made the communicator)
+    void* lib = nullptr;
+    if (!sym) {
+        for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1", "/opt/rocm/lib/librccl.so"}) {
+            lib = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+            if (lib) break;
+        }
+        if (lib) sym = dlsym(lib, "ncclBroadcast");
+    }
+    if (!sym) return false;
+    g_nccl_bcast = (nccl_bcast_fn)sym;
+    g_nccl_errstr = (nccl_errstr_fn)(lib ? dlsym(lib, "ncclGetErrorString") : dlsym(RTLD_DEFAULT, "ncclGetErrorString"));
+    return true;
+}
+}  // namespace
+
+extern "C" int acx_image_broadcast(const void* host_blob, size_t nbytes, void* nccl_comm, int root, int rank, void* stream_v, acx_image_t** out) {
+    if (!nccl_comm || !out || root < 0 || rank < 0) return acx_fail(ACX_E_INVAL, "acx_image_broadcast: bad argument");
+    if (rank == root && (!host_blob || nbytes < ACX_BLOB_HEADER_BYTES)) return acx_fail(ACX_E_INVAL, "acx_image_broadcast: the root rank needs the blob");
+    if (!resolve_rccl()) return acx_fail(ACX_E_UNSUPPORTED, "acx_image_broadcast: no RCCL in this process and librccl.so cannot be opened");
+    hipStream_t s = (hipStream_t)stream_v;
+    enum { NCCL_UINT8 = 1, NCCL_UINT64 = 5 };                       // ncclDataType_t, rccl.h
+    auto nccl_try = [&](int rc, const char* what) -> int {
+        if (rc == 0) return ACX_OK;
+        return acx_fail(ACX_E_HIP, "acx_image_broadcast: %s failed: %s", what, g_nccl_errstr ? g_nccl_errstr(rc) : "RCCL error");
+    };
+    unsigned long long* d_size = nullptr;
+    HIP_TRY(hipMalloc((void**)&d_size, sizeof *d_size));
+    unsigned long long h_size = rank == root ? (unsigned long long)nbytes : 0;
+    hipError_t e = hipMemcpyAsync(d_size, &h_size, sizeof h_size, hipMemcpyHostToDevice, s);
+    int rc = e == hipSuccess ? nccl_try(g_nccl_bcast(d_size, d_size, 1, NCCL_UINT64, root, nccl_comm, s), "ncclBroadcast(size)") : acx_fail(ACX_E_HIP, "acx_image_broadcast: %s", hipGetErrorString(e));
+    if (!rc) { e = hipMemcpyAsync(&h_size, d_size, sizeof h_size, hipMemcpyDeviceToHost, s); if (e == hipSuccess) e = hipStreamSynchronize(s); if (e != hipSuccess) rc = acx_fail(ACX_E_HIP, "acx_image_broadcast: %s", hipGetErrorString(e)); }
+    (void)hipFree(d_size);
+    if (rc) return rc;
+    if (h_size < ACX_BLOB_HEADER_BYTES) return acx_fail(ACX_E_FORMAT, "acx_image_broadcast: the root announced %llu bytes", h_size);
+    uint8_t* d_blob = nullptr;
+    HIP_TRY(hipMalloc((void**)&d_blob, (size_t)h_size));
+    if (rank == root) e = hipMemcpyAsync(d_blob, host_blob, (size_t)h_size, hipMemcpyHostToDevice, s); else e = hipSuccess;
+    if (e == hipSuccess) rc = nccl_try(g_nccl_bcast(d_blob, d_blob, (size_t)h_size, NCCL_UINT8, root, nccl_comm, s), "ncclBroadcast(blob)");
+    else rc = acx_fail(ACX_E_HIP, "acx_image_broadcast: %s", hipGetErrorString(e));
+    acx_blob_header hdr;
+    if (!rc) { e = hipMemcpyAsync(&hdr, d_blob, sizeof hdr, hipMemcpyDeviceToHost, s); if (e == hipSuccess) e = hipStreamSynchronize(s); if (e != hipSuccess) rc = acx_fail(ACX_E_HIP, "acx_image_broadcast: %s", hipGetErrorString(e)); }
+    if (!rc) rc = acx_image_adopt(d_blob, (size_t)h_size, &hdr, out);
+    if (rc) { (void)hipFree(d_blob); return rc; }
+    (*out)->owns = true;                                             // the image keeps (and frees) its device copy
+    return ACX_OK;
+}
+
 extern "C" void acx_image_free(acx_image_t* img) {
     if (!img) return;
     if (img->owns && img->dev) (void)hipFree(img->dev);

@@ -728,3 +728,51 @@ def test_iterator_set_semantics_vs_reference():
                 # that corner (iter only, take not None) is the one documented difference: compare up to there
                 if long_mode or take is None:
                     assert got == want, (keys, chunks, long_mode, take)
+
+
+def test_image_broadcast_over_rccl_single_rank():
+    """acx_image_broadcast (C-ABI, RCCL resolved at run time): a one-rank communicator made with librccl through
+    ctypes; the image that comes out of the broadcast scans exactly like an uploaded one.  (N > 1 ranks take the
+    same two ncclBroadcast calls; the driver's multi-GPU bench runs them over xGMI.)"""
+    import ctypes as C
+    from pyahocorasick_amd import _lib
+    try:
+        rccl = C.CDLL("librccl.so.1", mode=C.RTLD_GLOBAL)
+    except OSError:
+        try:
+            rccl = C.CDLL("/opt/rocm/lib/librccl.so", mode=C.RTLD_GLOBAL)
+        except OSError:
+            pytest.skip("librccl not found")
+
+    class UniqueId(C.Structure):
+        _fields_ = [("internal", C.c_char * 128)]
+
+    uid = UniqueId()
+    assert rccl.ncclGetUniqueId(C.byref(uid)) == 0
+    comm = C.c_void_p()
+    rccl.ncclCommInitRank.argtypes = [C.POINTER(C.c_void_p), C.c_int, UniqueId, C.c_int]
+    assert rccl.ncclCommInitRank(C.byref(comm), 1, uid, 0) == 0
+    try:
+        keys, reads = dna_workload(3000, 2000, 150, seed=5)
+        A, O = build_pair(list(keys))
+        blob = A.flat_image_bytes()
+        h = C.c_void_p()
+        buf = (C.c_char * len(blob)).from_buffer_copy(blob)
+        _lib.check(_lib.lib().acx_image_broadcast(buf, len(blob), comm, 0, 0, None, C.byref(h)))
+        img = Image(h)
+        n, L = reads.shape
+        d_hay = DeviceBuffer.from_numpy(reads.reshape(-1), pad=64)
+        sc = Scanner(img)
+        sc.scan(d_hay, n * L, n, stride=L)
+        moff, e, v, _ = sc.fetch()
+        mo, oe, ov = O.batch_records(reads.reshape(-1), np.arange(n + 1, dtype=np.int64) * L, 0)
+        assert np.array_equal(moff, mo) and np.array_equal(e, oe) and np.array_equal(v, ov)
+        for mode in (acx.ACX_SCAN_LONG,):
+            sc.scan(d_hay, n * L, n, stride=L, mode=mode)
+            moff, e, v, _ = sc.fetch()
+            mo, oe, ov = O.batch_records(reads.reshape(-1), np.arange(n + 1, dtype=np.int64) * L, 1)
+            assert np.array_equal(moff, mo) and np.array_equal(e, oe) and np.array_equal(v, ov)
+        img.free()
+    finally:
+        rccl.ncclCommDestroy.argtypes = [C.c_void_p]
+        rccl.ncclCommDestroy(comm)
