@@ -235,7 +235,9 @@ def main():
         d_hay = torch.empty(len(flat) + 64, dtype=torch.uint8, device=dev)
         d_hay[: len(flat)].copy_(torch.from_numpy(np.ascontiguousarray(flat)))
         d_off = torch.from_numpy(off).to(dev) if off is not None else None
-        batches.append((d_hay, len(flat), n, d_off, L))
+        # offsets batches: the shortest haystack, which the caller of acx_scan_batch vouches for (min_hay_len)
+        shortest = int(np.diff(off).min()) if off is not None else 0
+        batches.append((d_hay, len(flat), n, d_off, L, shortest))
     torch.cuda.synchronize()
     t_stage = time.perf_counter() - t0
     mode = acx.ACX_SCAN_ALL if args.mode == "iter" else acx.ACX_SCAN_LONG
@@ -244,9 +246,10 @@ def main():
     stream = torch.cuda.current_stream().cuda_stream
 
     def step(k, timing=False):
-        d_hay, cap, n, d_off, L = batches[k % B]
+        d_hay, cap, n, d_off, L, shortest = batches[k % B]
         return scs[k % P].scan(d_hay.data_ptr(), cap, n, dev_off=d_off.data_ptr() if d_off is not None else None,
-                               stride=L, mode=mode, timing=timing, variant=args.variant, stream=stream, asynchronous=P > 1)
+                               stride=L, mode=mode, timing=timing, variant=args.variant, stream=stream, asynchronous=P > 1,
+                               min_hay_len=shortest)
 
     for k in range(max(args.warmup, P, B)):               # every batch scanned at least once before timing
         step(k)
@@ -312,8 +315,8 @@ def main():
         for i, k in enumerate(keys):
             O.add_word(k, i)
         O.make_automaton()
-        d_hay, cap, n, d_off, L = batches[0]
-        scs[0].scan(d_hay.data_ptr(), cap, n, dev_off=d_off.data_ptr() if d_off is not None else None, stride=L, mode=mode, stream=stream)
+        d_hay, cap, n, d_off, L, shortest = batches[0]
+        scs[0].scan(d_hay.data_ptr(), cap, n, dev_off=d_off.data_ptr() if d_off is not None else None, stride=L, mode=mode, stream=stream, min_hay_len=shortest)
         off_g, e, v, _ = scs[0].fetch()
         data = d_hay[:cap].cpu().numpy().tobytes()
         offs = np.arange(n + 1, dtype=np.int64) * L if d_off is None else d_off.cpu().numpy()
@@ -321,19 +324,20 @@ def main():
         assert np.array_equal(off_g, mo) and np.array_equal(e, oe) and np.array_equal(v, ov), "GPU result differs from the oracle"
 
     if rank == 0:
-        d_hay, cap0, n0, d_off0, L0 = batches[0]
+        d_hay, cap0, n0, d_off0, L0, shortest0 = batches[0]
         ms_step = dt / args.steps * 1e3
         H = bytes_rank / args.steps                        # haystack bytes per rank per step (mean over the rotation)
         M = matches_rank / args.steps
         Nh = float(np.mean([batches[k % B][2] for k in range(args.steps)]))
         A_bytes = H + 8 * M + 12 * Nh                      # H + 8*M + 12*N
         walk = float(np.mean(walk_ms))
-        used_ppm = args.mode == "iter" and image.ppm_kernel(stride=L0, has_offsets=d_off0 is not None, variant=args.variant)
+        used_ppm = args.mode == "iter" and image.ppm_kernel(stride=L0, has_offsets=d_off0 is not None, variant=args.variant, min_hay_len=shortest0,
+                                                              dev_hay=d_hay.data_ptr(), n_hay=n0)
         if args.mode != "iter":
             walk_kernel, walk_bytes = "k_walk_long", H + 12 * Nh
         elif used_ppm == "stream":
             # the scan kernel reads the haystack, writes every record (to the pool) and one offset per haystack
-            walk_kernel, walk_bytes = "k_ppm_stream", H + 8 * M + 4 * Nh
+            walk_kernel, walk_bytes = "k_ppm_stream", H + 8 * M + (4 if d_off0 is None else 12) * Nh
         elif used_ppm == "scan":
             walk_kernel, walk_bytes = "k_ppm_scan", H + 8 * M + 8 * (H / 256)
         else:

@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define ACX_ABI_VERSION 1
+#define ACX_ABI_VERSION 2
 
 typedef enum acx_status {
     ACX_OK            =  0,
@@ -228,6 +228,12 @@ typedef struct acx_scan_params {
                                   (an event between two kernels costs a few microseconds of idle GPU) */
     int32_t  variant;          /* 0 = default; >0 selects an alternative kernel (bench/tuning) */
     int32_t  flags;            /* ACX_SCAN_ASYNC or 0 */
+    int32_t  min_hay_len;      /* offsets batches: a lower bound on the haystack lengths that the caller vouches for
+                                  (0 = unknown).  With >= 8 the position-parallel stream kernel takes the batch (it
+                                  keeps at most one haystack start per four positions); a haystack shorter than
+                                  promised gets wrong offsets, never an out-of-bounds access.  acx_scan_host derives it
+                                  from the host offsets. */
+    int32_t  reserved0;
 } acx_scan_params;
 /* Return as soon as the kernels are queued on `stream`.  The result completes (wait for THIS
  * scan's completion event — later scans queued on the same stream keep running —, total read,

@@ -187,7 +187,7 @@ typedef struct acx_ppm_header {
     uint32_t sym_bits;       /* bits per symbol in the LDS staging: 2, 4 or 8 */
     uint32_t pow2;           /* 1: K == 1 << sym_bits, codes are plain bit fields */
     uint32_t C, F;
-    uint32_t n_s;            /* S bitmaps in use: 0..2 */
+    uint32_t g_global;       /* 1: G has more bits than LDS holds and is read from global memory (stream kernel only) */
     uint32_t s_depth[2];
     uint32_t g_words, s_words[2];
     uint32_t has_other;

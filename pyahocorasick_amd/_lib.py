@@ -40,6 +40,7 @@ class ScanParams(C.Structure):
         ("dev_init_state", C.c_void_p), ("dev_index_base", C.c_void_p),
         ("want_final_state", C.c_int32), ("timing", C.c_int32),
         ("variant", C.c_int32), ("flags", C.c_int32),
+        ("min_hay_len", C.c_int32), ("reserved0", C.c_int32),
     ]
 
 
@@ -143,8 +144,8 @@ def lib():
                               "`python -m pyahocorasick_amd.build --force`)" % (LIB_PATH, name))
         fn.restype = res
         fn.argtypes = args
-    if l.acx_abi_version() != 1:
-        raise ImportError("pyahocorasick_amd: libacx ABI version %d, binding expects 1" % l.acx_abi_version())
+    if l.acx_abi_version() != 2:
+        raise ImportError("pyahocorasick_amd: libacx ABI version %d, binding expects 2" % l.acx_abi_version())
     _lib = l
     return l
 

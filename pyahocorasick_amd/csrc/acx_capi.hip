@@ -131,7 +131,7 @@ static int image_resolve(acx_image* img, const uint32_t* lvl_host) {
         img->ppm_kids = (const uint32_t*)(sec + ph.off_kids);
         img->ppm_kval = (const int32_t*)(sec + ph.off_kval);
         img->ppm_chains = (const uint32_t*)(sec + ph.off_chains);
-        if (acx_ppm_lds_layout(ph.g_words, ph.sym_bits, ph.longest).total_words * 4 > ACX_PPM_LDS_BYTES) img->ppm_g = nullptr;
+        if (!ph.g_global && acx_ppm_lds_layout(ph.g_words, ph.sym_bits, ph.longest).total_words * 4 > ACX_PPM_LDS_BYTES) img->ppm_g = nullptr;
     }
     img->out_off = (const uint32_t*)(img->dev + img->h.off_out_off);
     img->out_val = (const int32_t*)(img->dev + img->h.off_out_val);
@@ -470,6 +470,7 @@ static int ppm_enqueue(acx_result* r, acx_image* img, const acx_chunk_args* ca, 
         HIP_TRY(acx_launch_scan(r->nck.p, ca->n_hay, r->ck_first.p, r->partials.p, s));
         HIP_TRY(acx_launch_chunk_fill(*ca, ni, s));
     }
+    if (r->ppm_stream && pa.off) HIP_TRY(acx_launch_ppm_first_h(pa.off, pa.n_hay, ni, (int64_t)pa.nsub * 256, (int64_t*)pa.first_h, s));
     if (r->timed) HIP_TRY(hipEventRecord(r->ev[0], s));
     HIP_TRY(acx_launch_ppm_scan(pa, ni, s));
     if (r->timed) HIP_TRY(hipEventRecord(r->ev[1], s));
@@ -513,6 +514,15 @@ static uint32_t ppm_halo_pos(const acx_ppm_header& ph) {
     const uint32_t unit = 32u / ph.sym_bits < 4u ? 4u : 32u / ph.sym_bits;
     return ph.longest > 1 ? ((ph.longest - 1 + unit - 1) / unit) * unit : unit;
 }
+// sub-steps of 256 positions per tile that fit LDS for this image (0: none): the kernel is instantiated for 4 and,
+// on fixed-stride batches of 2- and 4-bit symbols, 2
+static uint32_t ppm_stream_nsub(const acx_ppm_header& ph, uint32_t halo_pos, bool offs) {
+    const uint32_t gw = ph.g_global ? 0u : ph.g_words;
+    if (acx_ppm_stream_layout(gw, ph.sym_bits, halo_pos, 4).total_words * 4 <= ACX_PPM_LDS_BYTES) return 4;
+    if (!offs && ph.sym_bits != 8 && acx_ppm_stream_layout(gw, ph.sym_bits, halo_pos, 2).total_words * 4 <= ACX_PPM_LDS_BYTES) return 2;
+    return 0;
+}
+
 static int ppm_plan(const acx_image* img, const acx_scan_params* p) {
     if (p->mode != ACX_SCAN_ALL || !img->ppm_g || p->dev_init_state || p->n_hay <= 0 || ((p->variant >> 23) & 1)) return 0;
     if (!p->dev_off && p->stride <= 0) return 0;
@@ -523,10 +533,12 @@ static int ppm_plan(const acx_image* img, const acx_scan_params* p) {
     const uint8_t* lo = rows < sing ? rows : sing;
     const uint64_t re = (uint64_t)(rows - lo) + ((uint64_t)ph.n_deep + 1) * ph.K * 16, se = (uint64_t)(sing - lo) + ((uint64_t)ph.n_chain + 1) * 16;
     const uint32_t hp = ppm_halo_pos(ph);
-    if (!p->dev_off && ph.pow2 && p->stride >= 8 && ((uintptr_t)p->dev_hay & 3u) == 0 && hp <= ACX_PPM_TILE &&
-        p->n_hay * p->stride <= 0xFFFFF000ll && !((p->variant >> 24) & 1) && (re > se ? re : se) < ((uint64_t)1 << 32) &&
-        acx_ppm_stream_layout(ph.g_words, ph.sym_bits, hp, 1).total_words * 4 <= ACX_PPM_LDS_BYTES)
+    const bool offs = p->dev_off != nullptr;
+    const int64_t total = offs ? p->hay_capacity : p->n_hay * p->stride;
+    if ((offs ? p->min_hay_len >= 8 : p->stride >= 8) && ((uintptr_t)p->dev_hay & 3u) == 0 && hp <= ACX_PPM_TILE &&
+        total <= 0xFFFFF000ll && !((p->variant >> 24) & 1) && (re > se ? re : se) < ((uint64_t)1 << 32) && ppm_stream_nsub(ph, hp, offs))
         return 2;
+    if (ph.g_global) return 0;                     // (only the stream kernel reads the filter from global memory)
     // The general kernel (k_ppm_scan) pays ~4 instructions per position more than the serial walks when their table
     // rows are cache resident; it wins when the dense table is far beyond the caches (measured: 200k binary
     // signatures, 6.9 GB table: 77 vs 62 GB/s; 100k text keys, 185 MB: 110 vs 168).  variant bit 28 forces it.
@@ -591,28 +603,39 @@ static int scan_ppm(acx_image_t* img, const acx_scan_params* p, acx_result* r, h
         pa.row_off = (uint32_t)(rows - pa.deep_base); pa.single_off = (uint32_t)(sing - pa.deep_base);
     }
     if (pa.fast) {
-        pa.nsub = 4;
-        while (pa.nsub > 1 && acx_ppm_stream_layout(ph.g_words, ph.sym_bits, pa.halo_pos, pa.nsub).total_words * 4 > ACX_PPM_LDS_BYTES) pa.nsub >>= 1;
-        pa.lds = acx_ppm_stream_layout(ph.g_words, ph.sym_bits, pa.halo_pos, pa.nsub);
+        pa.nsub = ppm_stream_nsub(ph, pa.halo_pos, chunked);
+        pa.g_global = ph.g_global;
+        pa.lds = acx_ppm_stream_layout(ph.g_global ? 0u : ph.g_words, ph.sym_bits, pa.halo_pos, pa.nsub);
     }
     if (pa.fast) {
         const int64_t tpos = (int64_t)pa.nsub * 256;
-        stream_tiles = (p->n_hay * p->stride + tpos - 1) / tpos;
-        pa.m24 = p->stride < 1024 ? (uint32_t)(((1u << 24) + (uint32_t)p->stride - 1) / (uint32_t)p->stride) : 0u;
+        const int64_t total = chunked ? p->hay_capacity : p->n_hay * p->stride;
+        stream_tiles = (total + tpos - 1) / tpos;
+        pa.m24 = (!chunked && p->stride < 1024) ? (uint32_t)(((1u << 24) + (uint32_t)p->stride - 1) / (uint32_t)p->stride) : 0u;
         const int64_t blocks = acx_ppm_grid_blocks(pa.lds, stream_tiles);
         const int64_t n_waves = blocks * ACX_PPM_WAVES;
         if ((rc = r->wave_desc.ensure((size_t)n_waves * ACX_PPM_DESC_WORDS))) return rc;
         if ((rc = r->ck_match_off.ensure((size_t)n_waves + 1))) return rc;
+        if ((rc = r->hay_local.ensure(n + 1))) return rc;
         pa.wave_desc = r->wave_desc.p;
+        pa.hay_local = r->hay_local.p;
+        pa.n_items = stream_tiles;
+        pa.ck = nullptr; pa.n_items_dev = nullptr;
+        pa.index_base = p->dev_index_base;
+        if (chunked) {                              // offsets batch: first haystack at or after every tile (one binary search per tile)
+            if ((rc = r->ck_first.ensure((size_t)stream_tiles + 2))) return rc;
+            pa.off = p->dev_off; pa.first_h = r->ck_first.p;
+        }
         acx_ppm_gather_args& ga = r->pend_ga;
         memset(&ga, 0, sizeof ga);
         ga.wave_desc = r->wave_desc.p; ga.wave_off = r->ck_match_off.p; ga.n_waves = n_waves;
         ga.matches = r->matches.p; ga.capacity = (int64_t)r->matches.cap;
         ga.hay_local = r->hay_local.p; ga.match_off = r->match_off.p; ga.n_hay = p->n_hay; ga.stride = p->stride;
+        ga.off = chunked ? p->dev_off : nullptr;
         ga.tile_pos = tpos; ga.tpw = (stream_tiles + n_waves - 1) / n_waves;
     }
 
-    acx_ppm_compact_args& ca = r->pend_ca;
+    acx_ppm_compact_args& ca = r->pend_ca;            // (the general kernel: per-tile counts, scan, compact)
     memset(&ca, 0, sizeof ca);
     ca.counts = r->counts.p; ca.scr_off = r->scr_off.p;
     ca.item_off = r->ck_match_off.p; ca.n_items = n_items; ca.n_items_dev = nullptr;
@@ -621,8 +644,8 @@ static int scan_ppm(acx_image_t* img, const acx_scan_params* p, acx_result* r, h
     r->pend_items = pa.fast ? stream_tiles : n_items; r->pend_counts = r->counts.p; r->pend_item_off = r->ck_match_off.p;
     if ((rc = ppm_size_pool(r, r->matches.cap))) return rc;
 
-    r->ppm_chunk = chunked;
-    if (chunked) {
+    r->ppm_chunk = chunked && !pa.fast;
+    if (r->ppm_chunk) {
         acx_chunk_args& cka = r->pend_cka;
         cka.off = p->dev_off; cka.stride = p->stride; cka.n_hay = p->n_hay; cka.index_base = p->dev_index_base;
         cka.chunk_bytes = ACX_PPM_TILE; cka.halo = ph.longest > 0 ? (int32_t)ph.longest - 1 : 0;
@@ -637,7 +660,7 @@ static int scan_ppm(acx_image_t* img, const acx_scan_params* p, acx_result* r, h
         wa.final_state = r->final_state.p;
     }
     r->pend_img = img;
-    if ((rc = ppm_enqueue(r, img, chunked ? &r->pend_cka : nullptr, r->has_final ? &r->pend_tail : nullptr, s))) return rc;
+    if ((rc = ppm_enqueue(r, img, r->ppm_chunk ? &r->pend_cka : nullptr, r->has_final ? &r->pend_tail : nullptr, s))) return rc;
     r->pending = true; r->ppm = true;
     if (p->flags & ACX_SCAN_ASYNC) return ACX_OK;
     return result_complete(r);
@@ -845,6 +868,9 @@ static int scan_host_once(acx_image_t* img, int mode, const uint8_t* hay, const 
     p.dev_init_state = init_state ? r->in_init.p : nullptr;
     p.dev_index_base = index_base ? r->in_base.p : nullptr;
     p.want_final_state = 1;
+    int64_t shortest = INT32_MAX;
+    for (int64_t h = 0; h < n_hay && shortest >= 8; h++) if (off[h + 1] - off[h] < shortest) shortest = off[h + 1] - off[h];
+    p.min_hay_len = n_hay > 0 ? (int32_t)shortest : 0;
     return acx_scan_batch(img, &p, result, nullptr);
 }
 

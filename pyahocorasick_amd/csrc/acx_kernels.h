@@ -115,6 +115,8 @@ struct acx_ppm_args {
     uint32_t dbg;            // tuning only (variant bits 25..27): 1 = no exact phase, 2 = no emit, 4 = no filter
     uint32_t nsub;           // k_ppm_stream: sub-steps of 256 positions per tile (1, 2 or 4)
     uint32_t m24;            // k_ppm_stream: ceil(2^24 / stride) for strides below 1024, else 0
+    const int64_t* off; const int64_t* first_h;    // k_ppm_stream on an offsets batch: offsets, first haystack at or after every tile
+    uint32_t g_global;       // the filter bitmap is read from global memory (not copied to LDS)
     const uint8_t* deep_base; uint32_t row_off, single_off;   // k_ppm_stream: rows and singles as 32-bit offsets from one base
     uint32_t* wave_desc;     // k_ppm_stream: per wave {records, grants, 16 x base, 16 x count}
     uint32_t halo_pos;       // k_ppm_stream: staged halo positions (multiple of 32 / sym_bits and of 4, >= longest - 1)
@@ -140,9 +142,11 @@ struct acx_ppm_gather_args {       // k_ppm_stream results -> final place
     const uint32_t* wave_desc; const int64_t* wave_off; int64_t n_waves;
     const uint2* scratch; uint2* matches; int64_t capacity;
     const int32_t* hay_local; int64_t* match_off; int64_t n_hay; int64_t stride;
+    const int64_t* off;            // offsets batch (else nullptr: fixed stride)
     int64_t tile_pos, tpw;         // positions per tile, tiles per wave
 };
 #define ACX_PPM_DESC_WORDS 40
+hipError_t acx_launch_ppm_first_h(const int64_t* off, int64_t n_hay, int64_t n_tiles, int64_t tile_pos, int64_t* first_h, hipStream_t s);
 hipError_t acx_launch_ppm_gather(const uint32_t* wave_desc, int64_t n_waves, int64_t* wave_off, const acx_ppm_gather_args& c, hipStream_t s);
 hipError_t acx_launch_ppm_scan(const acx_ppm_args& a, int64_t n_items_bound, hipStream_t s);
 hipError_t acx_launch_ppm_compact(const acx_ppm_compact_args& c, int64_t n_items_bound, hipStream_t s);

@@ -467,10 +467,17 @@ __global__ void __launch_bounds__(ACX_PPM_BLOCK) k_ppm_scan(const acx_ppm_args a
 #define PPM_DESC_WORDS 40u         // per wave: total, n_grants, 16 x base, 16 x count (+ pad)
 #define PPM_MAX_GRANTS 16u
 
-template <int SB, int NSUB>
+// OFFS: the batch is given by a device offsets array instead of a fixed stride (ragged packets, one long
+//       haystack).  Contract: no haystack shorter than 8 bytes (acx_scan_params.min_hay_len), so a lane's four
+//       positions hold at most one haystack start, as with a stride of at least 8.  The starts of a tile come
+//       from first_h[] (k_ppm_first_h: one binary search per tile) and live in LDS as a bitmap with per-word
+//       "last start" and "starts before" tables.
+// POW2: codes are plain bit fields of the window; otherwise Horner in radix K over its symbols.
+// GG:   the filter bitmap is read from global memory (wide alphabets: one level deeper than LDS could hold).
+template <int SB, int NSUB, bool POW2, bool OFFS, bool GG>
 __global__ void __launch_bounds__(ACX_PPM_BLOCK) k_ppm_stream(const acx_ppm_args a) {
     extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
-    for (uint32_t i = threadIdx.x; i < a.g_words; i += blockDim.x) smem[a.lds.g_off + i] = a.g[i];
+    if (!GG) for (uint32_t i = threadIdx.x; i < a.g_words; i += blockDim.x) smem[a.lds.g_off + i] = a.g[i];
     if (threadIdx.x < 256) {
         const uint32_t cl = a.cls[threadIdx.x];
         ((uint8_t*)(smem + a.lds.map_off))[threadIdx.x] = (a.has_other && cl == 0) ? 0xFFu : (uint8_t)(cl - a.has_other);
@@ -480,10 +487,12 @@ __global__ void __launch_bounds__(ACX_PPM_BLOCK) k_ppm_stream(const acx_ppm_args
     constexpr uint32_t SPW = 32 / SB;                                  // symbols per word
     constexpr uint32_t TPOS = NSUB * 256u;                             // positions per tile
     constexpr uint32_t TW = TPOS / SPW;                                // words of a tile's symbols
+    constexpr uint32_t BW = TPOS / 32;                                 // words of the start bitmap
     constexpr uint32_t SMASK = (1u << SB) - 1u;
+    constexpr int LOG = SB == 2 ? 1 : (SB == 4 ? 2 : 3);
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
-    Ppm<SB, true, false> P(a);
-    P.s_g = smem + a.lds.g_off;
+    Ppm<SB, POW2, false> P(a);
+    P.s_g = GG ? a.g : smem + a.lds.g_off;
     P.s_map = (const uint8_t*)(smem + a.lds.map_off);
     uint32_t* wbase = smem + a.lds.wave_off + (uint32_t)wid * a.lds.wave_words;
     uint32_t* const sym = wbase;                                       // [0,1] pad, halo words, tile words, pad
@@ -493,13 +502,19 @@ __global__ void __launch_bounds__(ACX_PPM_BLOCK) k_ppm_stream(const acx_ppm_args
     uint8_t* const oth = (uint8_t*)(wbase + a.lds.sym_words);          // per staged dword: which bytes are "other"
     uint8_t* const odist = oth + ((NDW + 3u) & ~3u);                   // per staged dword: dwords back to the last one that has any (255: none)
     uint16_t* const queue = (uint16_t*)(wbase + a.lds.sym_words + a.lds.oth_words);
+    uint32_t* const sbits = wbase + a.lds.sym_words + a.lds.oth_words + a.lds.queue_words;   // OFFS: haystack starts of the tile, one bit per position
+    uint16_t* const slast = (uint16_t*)(sbits + BW);                   //       last start (+1) at or before the end of each bitmap word
+    uint16_t* const scnt = slast + BW;                                 //       starts before each bitmap word
     uint8_t* const sym_tile_bytes = (uint8_t*)(sym + 2 + HW);
     for (uint32_t i = lane; i < 2 + HW + TW + 1; i += 64) sym[i] = 0;
     for (uint32_t i = lane; i < NDW; i += 64) { oth[i] = 0; odist[i] = 255; }
     P.T.q0 = HP; P.T.halo = 0; P.T.idx_first = 0; P.T.ndw = 0; P.T.abase = nullptr; P.T.e0 = 0; P.T.npos = 0; P.has_other = 0;
 
-    const uint32_t H = (uint32_t)(a.n_hay * a.stride - 1) + 1u;       // (the launcher checks H <= 2^32 - 2^12)
-    const int64_t n_tiles = ((int64_t)H + TPOS - 1) / TPOS;
+    // the batch: H bytes, cut into tiles; a wave takes a contiguous run of them
+    const uint32_t stride = (uint32_t)a.stride;
+    uint32_t H;
+    if (OFFS) H = (uint32_t)a.off[a.n_hay]; else H = (uint32_t)(a.n_hay * a.stride - 1) + 1u;   // (the launcher checks the size)
+    const int64_t n_tiles = OFFS ? a.n_items : ((int64_t)H + TPOS - 1) / TPOS;
     const int64_t n_waves = (int64_t)gridDim.x * ACX_PPM_WAVES;
     const int64_t tpw = (n_tiles + n_waves - 1) / n_waves;            // tiles per wave: a contiguous run
     const int64_t wave_id = (int64_t)blockIdx.x * ACX_PPM_WAVES + wid;
@@ -507,10 +522,9 @@ __global__ void __launch_bounds__(ACX_PPM_BLOCK) k_ppm_stream(const acx_ppm_args
     const int64_t t_end = t_begin + tpw < n_tiles ? t_begin + tpw : n_tiles;
     uint32_t* const desc = a.wave_desc + (size_t)wave_id * PPM_DESC_WORDS;
     const uint32_t pool_x = blockIdx.x % a.n_pools;
-    const uint32_t stride = (uint32_t)a.stride;
-    const uint32_t step_q = TPOS / stride, step_r = TPOS % stride;
+    const uint32_t step_q = OFFS ? 0u : TPOS / stride, step_r = OFFS ? 0u : TPOS % stride;
     wave_sync();
-    if (t_begin >= t_end) { if (lane == 0) { desc[0] = 0; desc[1] = 0; } return; }
+    if (t_begin >= t_end || (uint64_t)t_begin * TPOS >= H) { if (lane == 0) { desc[0] = 0; desc[1] = 0; } return; }
 
     // x = offset-in-haystack of the tile's first position + a position of the tile: haystacks crossed, new offset
     auto divmod = [&](uint32_t x, uint32_t& r) -> uint32_t {
@@ -556,6 +570,14 @@ __global__ void __launch_bounds__(ACX_PPM_BLOCK) k_ppm_stream(const acx_ppm_args
         }
         return q + 1 - last;
     };
+    // code of the n newest symbols of a (masked) window
+    auto code_n = [&](uint32_t Xm, uint32_t n) -> uint32_t {
+        if (POW2) return Xm >> (32 - SB * n);
+        uint32_t c = 0;
+        for (uint32_t i = 1; i <= n; i++) c = c * a.K + __builtin_amdgcn_ubfe(Xm, 32 - SB * i, (uint32_t)SB);
+        return c;
+    };
+    auto filter_bit = [&](uint32_t cF) -> uint32_t { return __builtin_amdgcn_ubfe(P.s_g[cF >> 5], cF, 1u); };
 
     // ---- prologue: the halo of the run's first tile -----------------------------------------
     uint32_t e0 = (uint32_t)(t_begin * TPOS);
@@ -570,12 +592,15 @@ __global__ void __launch_bounds__(ACX_PPM_BLOCK) k_ppm_stream(const acx_ppm_args
         }
         if (__any(nib != 0)) any_prev = 1;
     }
-    uint32_t h_tile, r_tile;
-    { uint32_t rr; h_tile = div_magic(e0, a.stride_magic, stride, rr); r_tile = rr; }
-    h_tile = (uint32_t)__builtin_amdgcn_readfirstlane((int)h_tile); r_tile = (uint32_t)__builtin_amdgcn_readfirstlane((int)r_tile);
+    uint32_t h_tile = 0, r_tile = 0;                                   // STRIDE: haystack of the tile's first byte, its offset in it
+    if (!OFFS) {
+        uint32_t rr; h_tile = div_magic(e0, a.stride_magic, stride, rr); r_tile = rr;
+        h_tile = (uint32_t)__builtin_amdgcn_readfirstlane((int)h_tile); r_tile = (uint32_t)__builtin_amdgcn_readfirstlane((int)r_tile);
+    }
     uint32_t wnext[NSUB];
 #pragma unroll
     for (int j = 0; j < NSUB; j++) wnext[j] = load_dw(e0 + 4u * (64 * j + lane));
+    int64_t fh_next = OFFS ? a.first_h[t_begin] : 0;
 
     // the wave's record stream
     uint32_t run_off = 0;                                              // records so far
@@ -584,6 +609,7 @@ __global__ void __launch_bounds__(ACX_PPM_BLOCK) k_ppm_stream(const acx_ppm_args
     uint32_t qhead = 0, qtail = 0, qcount = 0;
 
     for (int64_t tile = t_begin; tile < t_end; tile++) {
+        if (e0 >= H) break;
         const uint32_t left = H - e0;
         const uint32_t npos = left < TPOS ? left : TPOS;
         // ---- stage (and request the next tile's bytes) ---------------------------------------------
@@ -598,6 +624,33 @@ __global__ void __launch_bounds__(ACX_PPM_BLOCK) k_ppm_stream(const acx_ppm_args
         if (tile + 1 < t_end) {
 #pragma unroll
             for (int j = 0; j < NSUB; j++) wnext[j] = load_dw(e0 + TPOS + 4u * (64 * j + lane));
+        }
+        // OFFS: the haystack starts of this tile -> bitmap, last-start and count tables
+        uint32_t hbase = 0, base_r = 0;                                // haystack covering the tile's first byte; that byte's offset in it
+        if (OFFS) {
+            const int64_t fh = fh_next;
+            fh_next = a.first_h[tile + 1];
+            int64_t fe = fh_next < a.n_hay ? fh_next : a.n_hay;
+            uint32_t m = fe > fh ? (uint32_t)(fe - fh) : 0u;
+            if (m > TPOS / 8) m = TPOS / 8;                             // (the contract: no haystack shorter than 8 bytes)
+            if ((uint32_t)lane < BW) sbits[lane] = 0;
+            wave_sync();
+            for (uint32_t j = lane; j < m; j += 64) {
+                const uint32_t sp = (uint32_t)(a.off[fh + j] - (int64_t)e0);
+                if (sp < TPOS) atomicOr(&sbits[sp >> 5], 1u << (sp & 31u));
+            }
+            wave_sync();
+            {
+                const uint32_t wv = (uint32_t)lane < BW ? sbits[lane] : 0u;
+                uint32_t tot;
+                const uint32_t before = wave_excl_scan((uint32_t)__popc(wv), tot);
+                uint32_t last = wv ? 32u * lane + (31 - __clz(wv)) + 1 : 0u;
+#pragma unroll
+                for (int d = 1; d < 32; d <<= 1) { const uint32_t t = __shfl_up(last, d, 64); if (lane >= d && t > last) last = t; }
+                if ((uint32_t)lane < BW) { slast[lane] = (uint16_t)last; scnt[lane] = (uint16_t)before; }
+            }
+            hbase = (uint32_t)(fh - 1);                                 // (fh = 0: wraps; every position of that tile has rank >= 1)
+            base_r = fh > 0 ? (uint32_t)((int64_t)e0 - a.off[fh - 1]) : 0u;
         }
         const uint32_t any_cur = a.has_other && __any(anyo != 0) ? 1u : 0u;
         const uint32_t use_other = any_cur | any_prev;
@@ -618,40 +671,51 @@ __global__ void __launch_bounds__(ACX_PPM_BLOCK) k_ppm_stream(const acx_ppm_args
         }
         wave_sync();
 
+        // where position p (a multiple of 4 for the filter) sits: its offset in its haystack, and — OFFS — how many
+        // haystacks start at or before it
+        auto where = [&](uint32_t p, uint32_t& r, uint32_t& rank) {
+            if (!OFFS) { rank = divmod(r_tile + p, r); return; }
+            const uint32_t w = p >> 5;
+            const uint32_t prev = sbits[w] & (0xFFFFFFFFu >> (31u - (p & 31u)));      // starts of this word at or before p
+            const uint32_t lw = w ? slast[w - 1] : 0u;
+            rank = scnt[w] + (uint32_t)__popc(prev);
+            if (prev) r = p - (32u * w + (31 - __clz(prev)));
+            else if (lw) r = p - (lw - 1u);
+            else r = base_r + p;
+        };
+
         // ---- sub-steps: filter 4 positions per lane, append, drain full rounds ---------------------------
 #pragma unroll 1
         for (uint32_t sub = 0; sub < NSUB; sub++) {
             if (sub * 256u >= npos) break;
             const uint32_t pb = sub * 256u + 4u * lane;
-            uint32_t r0;
-            (void)divmod(r_tile + pb, r0);
+            uint32_t r0, rk0, ks;                                       // offset of position pb; where the next haystack starts among pb+1..pb+3 (else big)
+            where(pb, r0, rk0);
+            if (OFFS) { const uint32_t nb = (sbits[pb >> 5] >> (pb & 31u)) & 0xEu; ks = nb ? (uint32_t)__ffs(nb) - 1u : 0x7FFFFFFFu; }
+            else ks = stride - r0;
             uint32_t pm = 0, mm = 0;
             {
                 const uint32_t endbit3 = SB * (HP + pb + 4u) + 64u;
                 const uint32_t wi = endbit3 >> 5, sh = endbit3 & 31u;
                 const uint32_t hi = sym[wi], mid = sym[wi - 1], lo = sym[wi - 2];
                 const uint32_t X3 = __builtin_amdgcn_alignbit(hi, mid, sh), Y = __builtin_amdgcn_alignbit(mid, lo, sh);
+                const uint32_t u0 = 0u - ks;                             // past the start: offset k - ks (unsigned min picks it)
                 if (!use_other && npos == TPOS) {
-                    // the common tile: whole, no byte outside the key alphabet.  Offset in the haystack of
-                    // position k: r0 + k, or r0 + k - stride past a haystack start (unsigned min picks it)
-                    const uint32_t u0 = r0 - stride;
-                    const uint32_t ks = stride - r0;                         // position of the next haystack start (>= 1)
+                    // the common tile: whole, no byte outside the key alphabet
                     mm = (r0 == 0 ? 1u : 0u) | (ks < 4u ? 1u << ks : 0u);
-                    constexpr int LOG = SB == 2 ? 1 : (SB == 4 ? 2 : 3);
 #pragma unroll
                     for (int k = 0; k < 4; k++) {
                         const uint32_t r = k == 0 ? r0 : (r0 + k < u0 + k ? r0 + k : u0 + k);
                         const uint32_t m = r < SPW - 1 ? r : SPW - 1;         // symbols beyond the haystack start read as 0
                         const uint32_t X = k == 3 ? X3 : __builtin_amdgcn_alignbit(X3, Y, 32 - SB * (3 - k));
                         const uint32_t Xm = X & (uint32_t)((int32_t)0x80000000 >> ((m << LOG) + (SB - 1)));
-                        const uint32_t cF = Xm >> (32 - SB * a.F);
-                        const uint32_t bit = __builtin_amdgcn_ubfe(P.s_g[cF >> 5], cF, 1u);
+                        const uint32_t bit = filter_bit(code_n(Xm, a.F));
                         pm |= (r + 1 >= a.min_len ? bit : 0u) << k;
                     }
                 } else {
 #pragma unroll
                     for (int k = 0; k < 4; k++) {
-                        uint32_t r = r0 + k; if (r >= stride) r -= stride;
+                        const uint32_t r = k == 0 ? r0 : (r0 + k < u0 + k ? r0 + k : u0 + k);
                         const bool inside = pb + k < npos;
                         uint32_t L = r + 1 < a.longest ? r + 1 : a.longest;
                         if (use_other) { const uint32_t lo2 = other_limit(HP + pb + k); if (lo2 < L) L = lo2; }
@@ -659,8 +723,7 @@ __global__ void __launch_bounds__(ACX_PPM_BLOCK) k_ppm_stream(const acx_ppm_args
                         const uint32_t X = k == 3 ? X3 : __builtin_amdgcn_alignbit(X3, Y, 32 - SB * (3 - k));
                         const uint32_t Lc = L < SPW ? L : SPW;
                         const uint32_t Xm = X & (uint32_t)((int32_t)0x80000000 >> ((SB * Lc - 1u) & 31u));
-                        const uint32_t cF = Xm >> (32 - SB * a.F);
-                        const uint32_t bit = __builtin_amdgcn_ubfe(P.s_g[cF >> 5], cF, 1u);
+                        const uint32_t bit = L ? filter_bit(code_n(Xm, a.F)) : 0u;
                         pm |= (L >= a.min_len ? bit : 0u) << k;
                         mm |= ((inside && r == 0) ? 1u : 0u) << k;
                     }
@@ -690,9 +753,10 @@ __global__ void __launch_bounds__(ACX_PPM_BLOCK) k_ppm_stream(const acx_ppm_args
                 const uint32_t ent = act ? queue[qi] : 0x8000u;
                 const bool marker = (ent >> 15) != 0;
                 const uint32_t p = ent & 0x7FFFu;
-                uint32_t r, c = 0;
-                const uint32_t h = h_tile + divmod(r_tile + p, r);
-                typename Ppm<SB, true, false>::Ent E;
+                uint32_t r, rk, c = 0;
+                where(p, r, rk);
+                const uint32_t h = OFFS ? hbase + rk : h_tile + rk;
+                typename Ppm<SB, POW2, false>::Ent E;
                 int32_t va = 0, vb = 0;
                 bool deep_go = false; uint32_t deep_id = 0;
                 E.L = 0; E.X = 0; E.p = p;
@@ -705,7 +769,7 @@ __global__ void __launch_bounds__(ACX_PPM_BLOCK) k_ppm_stream(const acx_ppm_args
                     E.X = P.window(q);
                     const uint32_t Lc = L < SPW ? L : SPW;
                     const uint32_t Xm = E.X & (uint32_t)((int32_t)0x80000000 >> ((SB * Lc - 1u) & 31u));
-                    const u32x4* cell = (const u32x4*)((const uint8_t*)a.cells + ((Xm >> (32 - SB * a.C)) << 5));   // (32-bit offset: at most 2^18 cells)
+                    const u32x4* cell = (const u32x4*)((const uint8_t*)a.cells + (code_n(Xm, a.C) << 5));   // (32-bit offset: at most 2^18 cells)
                     E.c0 = cell[0]; E.c1 = cell[1];
                     if (!(a.dbg & 1u)) {
                         // top levels: the cell lists their values in match order, so the first two are always c0.w, c1.x
@@ -713,16 +777,14 @@ __global__ void __launch_bounds__(ACX_PPM_BLOCK) k_ppm_stream(const acx_ppm_args
                         if (L < 32) mask &= (1u << L) - 1u;
                         c = (uint32_t)__popc(mask);
                         va = (int32_t)E.c0.w; vb = (int32_t)E.c1.x;
-                        // deeper: one 16-byte record per step (rows: indexed by the next symbol; singles)
                         uint32_t id = E.c0.y, d = a.C;
                         bool go = id != 0 && L > d;
-                        if (SB == 2) {                               // K <= 4: the cell knows children and grandchildren; both symbols are in X
+                        if (SB == 2 && E.c0.z && SB * (a.C + 2) <= 32) {   // K <= 4: the cell knows children and grandchildren; both symbols are in X
                             const uint32_t t = __builtin_amdgcn_ubfe(E.X, 32 - SB * (a.C + 2), 4u), s1 = t >> 2, z = E.c0.z;
                             const bool kid = ((z >> s1) & 1u) != 0, keow = ((z >> (4 + s1)) & 1u) != 0, gk = ((z >> (8 + t)) & 1u) != 0;
                             go = go && kid && (keow || (gk && L > d + 1));
                         }
-                        // (the loop itself is below, outside this branch: its trip count is wave-uniform)
-                        deep_go = go; deep_id = id;
+                        deep_go = go; deep_id = id;                    // (the loop is below: its trip count is wave-uniform)
                     }
                 }
                 // deeper levels: one 16-byte record per step (rows: indexed by the next symbol; singles).  Every
@@ -732,7 +794,7 @@ __global__ void __launch_bounds__(ACX_PPM_BLOCK) k_ppm_stream(const acx_ppm_args
                     const uint32_t q = HP + E.p;
                     uint32_t d = a.C, id = deep_id;
                     bool go = deep_go;
-                    uint32_t s1 = SB * (a.C + 1) <= 32 ? __builtin_amdgcn_ubfe(E.X, 32 - SB * (a.C + 1), (uint32_t)SB) : P.sym_at(q - d);
+                    uint32_t s1 = SB * (a.C + 1) <= 32 ? __builtin_amdgcn_ubfe(E.X, (32 - SB * (a.C + 1)) & 31u, (uint32_t)SB) : P.sym_at(q - d);
                     for (;;) {
                         const bool single = (id >> 31) != 0;
                         const uint32_t first = single ? 0u : 1u;
@@ -757,9 +819,6 @@ __global__ void __launch_bounds__(ACX_PPM_BLOCK) k_ppm_stream(const acx_ppm_args
                 uint32_t rt;
                 const uint32_t ex = wave_excl_scan(c, rt);
                 if (act && marker) a.hay_local[h] = (int32_t)(run_off + ex);
-#ifdef PPM_DEBUG
-                if (wave_id <= 1 && (lane < 3 || (act && !marker))) printf("w%d t%d sub%u nr%u lane%d ent%04x p%u h%u r%u c%u ex%u rt%u run%u htile%u rtile%u\n", (int)wave_id, (int)tile, sub, nr, lane, ent, p, h, r, c, ex, rt, run_off, h_tile, r_tile);
-#endif
                 if (rt && !dead) {
                     if (g_used + rt > g_size) {                        // this round does not fit the current grant: open the next one
                         if (ng == PPM_MAX_GRANTS) dead = true;
@@ -806,11 +865,25 @@ __global__ void __launch_bounds__(ACX_PPM_BLOCK) k_ppm_stream(const acx_ppm_args
         }
         any_prev = any_cur;
         e0 += TPOS;
-        r_tile += step_r; h_tile += step_q;
-        if (r_tile >= stride) { r_tile -= stride; h_tile++; }
+        if (!OFFS) {
+            r_tile += step_r; h_tile += step_q;
+            if (r_tile >= stride) { r_tile -= stride; h_tile++; }
+        }
         wave_sync();
     }
     if (lane == 0) { desc[0] = run_off; desc[1] = ng; if (ng) desc[18 + ng - 1] = g_used; }
+}
+
+// first_h[t] = the first haystack that starts at or after byte t * tile_pos (n_hay + 1 entries of `off`; the last
+// one, the end of the batch, counts): one binary search per tile
+__global__ void __launch_bounds__(256) k_ppm_first_h(const int64_t* off, int64_t n_hay, int64_t n_tiles, int64_t tile_pos, int64_t* first_h) {
+    const int64_t n_threads = (int64_t)gridDim.x * 256;
+    for (int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x; t <= n_tiles; t += n_threads) {
+        const int64_t x = t * tile_pos;
+        int64_t lo = 0, hi = n_hay + 1;                                // smallest h in [0, n_hay + 1) with off[h] >= x, else n_hay + 1
+        while (lo < hi) { const int64_t mid = (lo + hi) >> 1; if (off[mid] >= x) hi = mid; else lo = mid + 1; }
+        first_h[t] = lo;
+    }
 }
 
 // exclusive prefix sum of the waves' record counts: wave_off[w], wave_off[n_waves] = total
@@ -857,7 +930,7 @@ __global__ void __launch_bounds__(256) k_ppm_gather(const acx_ppm_gather_args c)
     const int64_t n_threads = (int64_t)gridDim.x * 256;
     for (int64_t h = (int64_t)blockIdx.x * 256 + threadIdx.x; h <= c.n_hay; h += n_threads) {
         if (h == c.n_hay) c.match_off[h] = total;
-        else c.match_off[h] = c.wave_off[((h * c.stride) / c.tile_pos) / c.tpw] + c.hay_local[h];
+        else c.match_off[h] = c.wave_off[((c.off ? c.off[h] : h * c.stride) / c.tile_pos) / c.tpw] + c.hay_local[h];
     }
 }
 
@@ -924,11 +997,15 @@ hipError_t acx_launch_ppm_scan(const acx_ppm_args& a, int64_t n_items_bound, hip
         return hipGetLastError();
     };
     if (a.fast) {
-#define PPM_STREAM(SB) do { if (a.nsub == 4) return launch(k_ppm_stream<SB, 4>); if (a.nsub == 2) return launch(k_ppm_stream<SB, 2>); return launch(k_ppm_stream<SB, 1>); } while (0)
-        if (a.sym_bits == 2) PPM_STREAM(2);
-        if (a.sym_bits == 4) PPM_STREAM(4);
-        PPM_STREAM(8);
-#undef PPM_STREAM
+        const bool offs = a.off != nullptr, p2 = a.pow2 != 0;
+#define PPM_S(SB, N, GG) do { \
+            if (p2) { if (offs) return launch(k_ppm_stream<SB, N, true, true, GG>); return launch(k_ppm_stream<SB, N, true, false, GG>); } \
+            if (offs) return launch(k_ppm_stream<SB, N, false, true, GG>); return launch(k_ppm_stream<SB, N, false, false, GG>); } while (0)
+        if (a.sym_bits == 8) { if (a.g_global) PPM_S(8, 4, true); PPM_S(8, 4, false); }
+        if (a.sym_bits == 4) { if (a.nsub == 4) PPM_S(4, 4, false); PPM_S(4, 2, false); }
+        if (a.nsub == 4) PPM_S(2, 4, false);
+        PPM_S(2, 2, false);
+#undef PPM_S
     }
 #define PPM_CASE(SB) \
     do { \
@@ -940,6 +1017,14 @@ hipError_t acx_launch_ppm_scan(const acx_ppm_args& a, int64_t n_items_bound, hip
     if (a.sym_bits == 8) PPM_CASE(8);
 #undef PPM_CASE
     return hipErrorInvalidValue;
+}
+
+hipError_t acx_launch_ppm_first_h(const int64_t* off, int64_t n_hay, int64_t n_tiles, int64_t tile_pos, int64_t* first_h, hipStream_t s) {
+    int64_t blocks = (n_tiles + 1 + 255) / 256;
+    const int64_t cap = (int64_t)num_cus() * 16;
+    if (blocks > cap) blocks = cap;
+    hipLaunchKernelGGL(k_ppm_first_h, dim3((unsigned)blocks), dim3(256), 0, s, off, n_hay, n_tiles, tile_pos, first_h);
+    return hipGetLastError();
 }
 
 hipError_t acx_launch_ppm_gather(const uint32_t* wave_desc, int64_t n_waves, int64_t* wave_off, const acx_ppm_gather_args& c, hipStream_t s) {

@@ -53,8 +53,8 @@ static inline acx_ppm_lds acx_ppm_stream_layout(uint32_t g_words, uint32_t sym_b
     L.sym_words = (2 + halo_pos / spw + tpos / spw + 1 + 3u) & ~3u;
     L.oth_words = (2 * ((L.dwords + 3u) & ~3u)) / 4;                     // nibble byte + distance byte per staged dword
     L.queue_words = 384 / 2 + 2;                                       // PPM_QCAP uint16 entries + a spare slot
-    L.cnt32 = 0; L.cnt_words = 0;
-    L.wave_words = (L.sym_words + L.oth_words + L.queue_words + 3u) & ~3u;
+    L.cnt32 = 0; L.cnt_words = (tpos / 32) * 2 + 2;                     // offsets batches: start bitmap, last-start and count tables
+    L.wave_words = (L.sym_words + L.oth_words + L.queue_words + L.cnt_words + 3u) & ~3u;
     L.g_off = 0;
     L.map_off = (g_words + 3u) & ~3u;
     L.wave_off = L.map_off + 64;

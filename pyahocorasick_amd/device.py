@@ -107,7 +107,7 @@ class Image:
     def itop_depth(self):
         return lib().acx_image_itop_depth(self.handle)
 
-    def ppm_kernel(self, stride=0, has_offsets=False, variant=0, dev_hay=0x1000, n_hay=1):
+    def ppm_kernel(self, stride=0, has_offsets=False, variant=0, dev_hay=0x1000, n_hay=1, min_hay_len=0):
         """which kernel family an ACX_SCAN_ALL scan of such a batch takes (acx_scan_plan): None = the serial
         walks, "scan" = k_ppm_scan, "stream" = k_ppm_stream"""
         p = ScanParams()
@@ -119,6 +119,7 @@ class Image:
         p.stride = int(stride)
         p.n_hay = n_hay
         p.variant = int(variant)
+        p.min_hay_len = int(min_hay_len)
         return {0: None, 1: "scan", 2: "stream"}.get(lib().acx_scan_plan(self.handle, C.byref(p)))
 
     def download_table(self):
@@ -151,7 +152,7 @@ class Scanner:
 
     def scan(self, dev_hay, hay_capacity, n_hay, dev_off=None, stride=0, mode=ACX_SCAN_ALL,
              dev_init_state=None, dev_index_base=None, want_final_state=False, timing=False,
-             variant=0, stream=None, asynchronous=False):
+             variant=0, stream=None, asynchronous=False, min_hay_len=0):
         """All pointer arguments are raw device addresses (int / c_void_p / None).
         asynchronous=True: return as soon as the kernels are queued on `stream` (returns None);
         `wait()`, `num_matches()`, `fetch()` complete the scan."""
@@ -168,6 +169,7 @@ class Scanner:
         p.want_final_state = 1 if want_final_state else 0
         p.timing = 2 if (timing == 2 and timing is not True) else (1 if timing else 0)   # 2: events around the walk only
         p.variant = int(variant)
+        p.min_hay_len = int(min_hay_len)
         p.flags = ACX_SCAN_ASYNC if asynchronous else 0
         check(lib().acx_scan_batch(self.image.handle, C.byref(p), C.byref(self._res), _addr(stream)))
         self.n_hay = int(n_hay)

@@ -38,7 +38,9 @@ def _three_way(A, O, data, off, stride=None, index_base=None, want_final=True):
     d_off = DeviceBuffer.from_numpy(np.asarray(off, dtype=np.int64))
     d_base = DeviceBuffer.from_numpy(np.asarray(index_base, dtype=np.int32)) if index_base is not None else None
     fins = []
-    entries = [dict(dev_off=d_off)] + ([dict(stride=stride)] if stride else [])
+    shortest = int(np.diff(np.asarray(off)).min()) if n else 0
+    # offsets entry twice: with the caller's lower bound on the haystack lengths (>= 8: the stream kernel) and without
+    entries = [dict(dev_off=d_off), dict(dev_off=d_off, min_hay_len=shortest)] + ([dict(stride=stride)] if stride else [])
     for variant in (1 << 28, GENERAL, SERIAL):
         for kw in entries:
             sc = Scanner(img)
