@@ -98,7 +98,7 @@ int acx_ppm_build(const acx_trie* t, const uint8_t* cls, uint32_t n_classes, boo
         const uint64_t gbits_cap = (uint64_t)(ACX_PPM_LDS_BYTES / 4 - base_layout.total_words - 8) * 32;
         uint32_t F = C;
         if (C + 1 <= (uint32_t)max_depth && C + 1 <= max_syms && ipow(C + 1) <= gbits_cap) F = C + 1;
-        else if (C + 1 <= (uint32_t)max_depth && C + 1 <= max_syms && ipow(C + 1) <= ((uint64_t)1 << 27)) {
+        else if (h.sym_bits == 8 && C + 1 <= (uint32_t)max_depth && C + 1 <= max_syms && ipow(C + 1) <= ((uint64_t)1 << 27)) {
             // one level below the cells does not fit LDS (wide alphabets: 256^3 bits = 2 MB) but it is what tells most
             // positions apart from key ends: keep it in global memory (L2 resident), the stream kernel reads it there
             const char* gg = getenv("ACX_PPM_GLOBAL_FILTER");
