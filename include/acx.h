@@ -240,7 +240,10 @@ typedef struct acx_scan_params {
  * expand re-run if the match buffer was too small) in acx_result_wait or in the first accessor.
  * Lets one host thread keep several batches in flight, on one stream (the host's bookkeeping
  * overlaps the next batch) or on several (the expand of batch i then overlaps the walk of
- * batch i+1): bench.py --pipeline / --streams. */
+ * batch i+1): bench.py --pipeline / --streams.
+ * An asynchronous scan is complete when acx_result_wait (or an accessor) returns — NOT when `stream` has
+ * drained: the library queues the final copy of the records on a stream of the result's own, so that it
+ * overlaps the next scan kernel that the caller queues on `stream`. */
 enum { ACX_SCAN_ASYNC = 1 };
 
 typedef struct acx_result acx_result_t;

@@ -83,6 +83,7 @@ struct acx_image {
     const void* itop_cells = nullptr;
     const uint32_t* tflags = nullptr;
     uint32_t* built_table = nullptr;        // table built in HBM (blob without a table section); owned
+    std::vector<uint32_t> lvl_host;         // level boundaries, kept for a table that is built on first use
     // position-parallel scan image (include/acx_blob.h "ppm"); ppm_g == nullptr: absent
     acx_ppm_header ppm;
     const uint32_t* ppm_g = nullptr;
@@ -116,6 +117,8 @@ static void image_check_itop_reach(acx_image* img) {
 
 // resolve section pointers; when the blob carries no table, build it in HBM from the sparse
 // form (acx_build.hip).  lvl_host = host copy of the level boundaries, or nullptr to fetch it.
+static int image_build_table(acx_image* img, const uint32_t* lvl_host);
+
 static int image_resolve(acx_image* img, const uint32_t* lvl_host) {
     img->cls = img->dev + img->h.off_cls;
     if (img->h.off_ppm) {
@@ -148,6 +151,19 @@ static int image_resolve(acx_image* img, const uint32_t* lvl_host) {
         image_check_itop_reach(img);
         return ACX_OK;
     }
+    // The blob carries only the sparse form.  An image that has the position-parallel structures builds the dense
+    // table on first use by a serial walk (iter_long, carried-in states, final states): 34.8 GB and most of the
+    // set-up time for the 1M-signature dictionary, which an ACX_SCAN_ALL-only user never needs.
+    if (img->ppm_g && !getenv("ACX_EAGER_TABLE")) {
+        if (lvl_host) img->lvl_host.assign(lvl_host, lvl_host + (size_t)img->h.n_levels + 1);
+        return ACX_OK;
+    }
+    return image_build_table(img, lvl_host);
+}
+
+// build the dense transition table in HBM from the sparse form (acx_build.hip); lvl_host = host copy of the level
+// boundaries, or nullptr to fetch it
+static int image_build_table(acx_image* img, const uint32_t* lvl_host) {
     const size_t tbytes = (size_t)img->h.n_states * img->h.n_classes * 4;
     // the itop walk addresses the table and the cells with 32-bit offsets from one base (and may
     // read one entry past the end of the table): a table built here gets its own copy of the cells
@@ -159,6 +175,7 @@ static int image_resolve(acx_image* img, const uint32_t* lvl_host) {
         img->itop_cells = (const uint8_t*)img->built_table + cells_at;
     }
     std::vector<uint32_t> lvl;
+    if (!lvl_host && !img->lvl_host.empty()) lvl_host = img->lvl_host.data();
     if (!lvl_host) {
         lvl.resize((size_t)img->h.n_levels + 1);
         HIP_TRY(hipMemcpy(lvl.data(), img->dev + img->h.off_lvl_first, lvl.size() * 4, hipMemcpyDeviceToHost));
@@ -172,6 +189,12 @@ static int image_resolve(acx_image* img, const uint32_t* lvl_host) {
     img->table = img->built_table;
     image_check_itop_reach(img);
     return ACX_OK;
+}
+
+// the serial walks read the dense table: make sure it exists
+static int image_ensure_table(acx_image* img) {
+    if (img->table) return ACX_OK;
+    return image_build_table(img, nullptr);
 }
 
 extern "C" int acx_image_upload(const void* blob, size_t nbytes, acx_image_t** out) {
@@ -281,7 +304,10 @@ extern "C" int64_t acx_image_num_states(const acx_image_t* img) { return img ? i
 extern "C" int64_t acx_image_num_classes(const acx_image_t* img) { return img ? img->h.n_classes : 0; }
 extern "C" size_t  acx_image_nbytes(const acx_image_t* img) { return img ? img->nbytes : 0; }
 extern "C" void*   acx_image_dev_ptr(const acx_image_t* img) { return img ? img->dev : nullptr; }
-extern "C" const void* acx_image_table_dev_ptr(const acx_image_t* img) { return img ? img->table : nullptr; }
+extern "C" const void* acx_image_table_dev_ptr(const acx_image_t* img) {
+    if (!img || image_ensure_table(const_cast<acx_image_t*>(img))) return nullptr;
+    return img->table;
+}
 extern "C" int     acx_image_itop_depth(const acx_image_t* img) { return (img && img->itop_lds) ? (int)img->h.itop_depth : 0; }
 
 // ------------------------------------------------------------------------------------
@@ -329,6 +355,9 @@ struct acx_result {
     const int32_t* pend_counts = nullptr; int64_t* pend_item_off = nullptr;
     acx_chunk_args pend_cka; acx_walk_args pend_tail; bool ppm_chunk = false, ppm_tail = false;
     bool ppm_stream = false; acx_ppm_gather_args pend_ga; DevBuf<uint32_t> wave_desc;
+    // ACX_SCAN_ASYNC scans: the gather (memory bound) runs on a stream of the result's own, so that the next
+    // scan kernel (instruction bound) of another result on the caller's stream overlaps it
+    bool use_side = false; hipStream_t side = nullptr; hipEvent_t ev_scan = nullptr;
     acx_image* pend_img = nullptr;
     PinBuf<int64_t> h_off;
     PinBuf<acx_match_t> h_matches;
@@ -360,6 +389,8 @@ struct acx_result {
         in_hay.release(); in_off.release(); in_init.release(); in_base.release();
         for (auto& e : ev) if (e) (void)hipEventDestroy(e);
         if (done) (void)hipEventDestroy(done);
+        if (ev_scan) (void)hipEventDestroy(ev_scan);
+        if (side) (void)hipStreamDestroy(side);
     }
 };
 
@@ -388,9 +419,10 @@ static int ppm_complete(acx_result* r) {
             if ((rc = ppm_size_pool(r, (need > have ? need : have) + need / 2))) return rc;
             if ((rc = ppm_enqueue(r, r->pend_img, r->ppm_chunk ? &r->pend_cka : nullptr, r->ppm_tail ? &r->pend_tail : nullptr, s))) return rc;
         } else {
-            if (r->ppm_stream) HIP_TRY(acx_launch_ppm_gather(r->pend_pa.wave_desc, r->pend_ga.n_waves, r->pend_item_off, r->pend_ga, s));
-            else HIP_TRY(acx_launch_ppm_compact(r->pend_ca, r->pend_items, s));
-            HIP_TRY(hipEventRecord(r->done, s));
+            hipStream_t g = (r->ppm_stream && r->use_side && r->side) ? r->side : s;
+            if (r->ppm_stream) HIP_TRY(acx_launch_ppm_gather(r->pend_pa.wave_desc, r->pend_ga.n_waves, r->pend_item_off, r->pend_ga, g));
+            else HIP_TRY(acx_launch_ppm_compact(r->pend_ca, r->pend_items, g));
+            HIP_TRY(hipEventRecord(r->done, g));
         }
     }
     if (r->timed) {
@@ -474,22 +506,30 @@ static int ppm_enqueue(acx_result* r, acx_image* img, const acx_chunk_args* ca, 
     if (r->timed) HIP_TRY(hipEventRecord(r->ev[0], s));
     HIP_TRY(acx_launch_ppm_scan(pa, ni, s));
     if (r->timed) HIP_TRY(hipEventRecord(r->ev[1], s));
+    if (tail) HIP_TRY(acx_launch_tail_state(*tail, (int32_t)img->ppm.longest, s));
+    hipStream_t g = s;                                 // where the rest of this scan is queued
     if (r->ppm_stream) {
-        if (r->timed_all) HIP_TRY(hipEventRecord(r->ev[2], s));
-        HIP_TRY(acx_launch_ppm_gather(pa.wave_desc, r->pend_ga.n_waves, r->pend_item_off, r->pend_ga, s));
+        if (r->use_side) {
+            if (!r->side) HIP_TRY(hipStreamCreateWithFlags(&r->side, hipStreamNonBlocking));
+            if (!r->ev_scan) HIP_TRY(hipEventCreateWithFlags(&r->ev_scan, hipEventDisableTiming));
+            HIP_TRY(hipEventRecord(r->ev_scan, s));
+            HIP_TRY(hipStreamWaitEvent(r->side, r->ev_scan, 0));
+            g = r->side;
+        }
+        if (r->timed_all) HIP_TRY(hipEventRecord(r->ev[2], g));
+        HIP_TRY(acx_launch_ppm_gather(pa.wave_desc, r->pend_ga.n_waves, r->pend_item_off, r->pend_ga, g));
     } else {
         HIP_TRY(acx_launch_scan(r->pend_counts, ni, r->pend_item_off, r->partials.p, s));
         if (r->timed_all) HIP_TRY(hipEventRecord(r->ev[2], s));
         HIP_TRY(acx_launch_ppm_compact(r->pend_ca, ni, s));
         if (ca) HIP_TRY(acx_launch_hay_offsets(r->ck_first.p, r->ck_match_off.p, ca->n_hay, r->match_off.p, s));
     }
-    if (r->timed_all) HIP_TRY(hipEventRecord(r->ev[3], s));
-    if (tail) HIP_TRY(acx_launch_tail_state(*tail, (int32_t)img->ppm.longest, s));
+    if (r->timed_all) HIP_TRY(hipEventRecord(r->ev[3], g));
     r->h_total.p[1] = 0;
-    HIP_TRY(hipMemcpyAsync(r->h_total.p, r->pend_item_off + (r->ppm_stream ? r->pend_ga.n_waves : ni), sizeof(int64_t), hipMemcpyDeviceToHost, s));
-    HIP_TRY(hipMemcpyAsync(r->h_total.p + 1, r->ppm_ctl.p + 8, sizeof(int32_t), hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipMemcpyAsync(r->h_total.p, r->pend_item_off + (r->ppm_stream ? r->pend_ga.n_waves : ni), sizeof(int64_t), hipMemcpyDeviceToHost, g));
+    HIP_TRY(hipMemcpyAsync(r->h_total.p + 1, r->ppm_ctl.p + 8, sizeof(int32_t), hipMemcpyDeviceToHost, g));
     if (!r->done) HIP_TRY(hipEventCreateWithFlags(&r->done, hipEventDisableTiming));
-    HIP_TRY(hipEventRecord(r->done, s));
+    HIP_TRY(hipEventRecord(r->done, g));
     return ACX_OK;
 }
 
@@ -653,6 +693,7 @@ static int scan_ppm(acx_image_t* img, const acx_scan_params* p, acx_result* r, h
     }
     r->ppm_tail = r->has_final;
     if (r->has_final) {
+        if ((rc = image_ensure_table(img))) return rc;
         acx_walk_args& wa = r->pend_tail;
         memset(&wa, 0, sizeof wa);
         wa.hay = p->dev_hay; wa.hay_cap = p->hay_capacity; wa.off = p->dev_off; wa.stride = p->stride; wa.n_hay = p->n_hay;
@@ -660,6 +701,7 @@ static int scan_ppm(acx_image_t* img, const acx_scan_params* p, acx_result* r, h
         wa.final_state = r->final_state.p;
     }
     r->pend_img = img;
+    r->use_side = (p->flags & ACX_SCAN_ASYNC) != 0 && r->ppm_stream && !getenv("ACX_NO_SIDE_STREAM");
     if ((rc = ppm_enqueue(r, img, r->ppm_chunk ? &r->pend_cka : nullptr, r->has_final ? &r->pend_tail : nullptr, s))) return rc;
     r->pending = true; r->ppm = true;
     if (p->flags & ACX_SCAN_ASYNC) return ACX_OK;
@@ -702,6 +744,7 @@ extern "C" int acx_scan_batch(acx_image_t* img, const acx_scan_params* p, acx_re
 
     const size_t n = (size_t)p->n_hay;
     int rc;
+    if ((rc = image_ensure_table(img))) return rc;           // (an image with position-parallel structures builds it on first use)
 
     // ---- work decomposition -----------------------------------------------------------
     // direct : one lane per haystack (fixed-length short reads — config 2/5)
