@@ -10,6 +10,9 @@
 #include "acx_trie_impl.h"
 #include "acx_ppm_layout.h"
 
+#include <algorithm>
+#include <chrono>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <new>
@@ -21,30 +24,76 @@ namespace {
 
 inline size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
 
-// insert every key of `t`, reversed, into `rev` (DFS with an explicit stack; children in list order)
+// The trie of the REVERSED keys of `t`, built in one pass over the sorted reversed keys (a key shares a prefix
+// with its predecessor: pop to that depth, append the rest).  Children come out in ascending letter order and are
+// linked in O(1); acx_trie_add_word would walk sibling lists, which are 256 long at the top of a signature trie.
 int build_reversed(const acx_trie* t, acx_trie* rev) {
-    struct Frame { int32_t node; int32_t next_child; };
-    std::vector<Frame> st;
-    std::vector<uint8_t> path, rkey;
-    st.push_back({0, t->nodes.empty() ? -1 : t->nodes[0].first_child});
-    while (!st.empty()) {
-        Frame& f = st.back();
-        if (f.next_child < 0) {
-            st.pop_back();
-            if (!path.empty()) path.pop_back();
-            continue;
+    // 1. collect: DFS with an explicit stack; every key reversed into one buffer
+    std::vector<uint8_t> buf;
+    std::vector<uint64_t> koff;                 // key k = buf[koff[k] .. koff[k+1])
+    std::vector<int64_t> kval;
+    {
+        struct Frame { int32_t node; int32_t next_child; };
+        std::vector<Frame> st;
+        std::vector<uint8_t> path;
+        st.push_back({0, t->nodes.empty() ? -1 : t->nodes[0].first_child});
+        koff.push_back(0);
+        while (!st.empty()) {
+            Frame& f = st.back();
+            if (f.next_child < 0) { st.pop_back(); if (!path.empty()) path.pop_back(); continue; }
+            const int32_t c = f.next_child;
+            f.next_child = t->nodes[c].next_sibling;
+            path.push_back(t->nodes[c].letter);
+            if (t->nodes[c].eow) {
+                buf.insert(buf.end(), path.rbegin(), path.rend());
+                koff.push_back(buf.size());
+                kval.push_back(t->nodes[c].value);
+            }
+            st.push_back({c, t->nodes[c].first_child});
         }
-        const int32_t c = f.next_child;
-        f.next_child = t->nodes[c].next_sibling;
-        path.push_back(t->nodes[c].letter);
-        if (t->nodes[c].eow) {
-            rkey.assign(path.rbegin(), path.rend());
-            int is_new = 0;
-            const int rc = acx_trie_add_word(rev, rkey.data(), rkey.size(), t->nodes[c].value, &is_new);
-            if (rc) return rc;
-        }
-        st.push_back({c, t->nodes[c].first_child});
     }
+    const size_t nk = kval.size();
+    // 2. sort the reversed keys
+    std::vector<uint32_t> idx(nk);
+    for (size_t i = 0; i < nk; i++) idx[i] = (uint32_t)i;
+    const uint8_t* b = buf.data();
+    std::sort(idx.begin(), idx.end(), [&](uint32_t x, uint32_t y) {
+        const size_t lx = (size_t)(koff[x + 1] - koff[x]), ly = (size_t)(koff[y + 1] - koff[y]);
+        const int c = memcmp(b + koff[x], b + koff[y], lx < ly ? lx : ly);
+        return c != 0 ? c < 0 : lx < ly;
+    });
+    // 3. build
+    rev->nodes.clear();
+    rev->nodes.reserve(buf.size() / 2 + 16);
+    rev->new_node(0);
+    std::vector<int32_t> last_child;            // per node: its most recent child (siblings are appended in order)
+    last_child.push_back(-1);
+    std::vector<int32_t> stack;                 // stack[d] = node at depth d on the current key's path
+    stack.push_back(0);
+    const uint8_t* prev = nullptr; size_t prev_len = 0;
+    for (size_t q = 0; q < nk; q++) {
+        const uint8_t* key = b + koff[idx[q]];
+        const size_t len = (size_t)(koff[idx[q] + 1] - koff[idx[q]]);
+        size_t lcp = 0;
+        const size_t m = len < prev_len ? len : prev_len;
+        while (lcp < m && key[lcp] == prev[lcp]) lcp++;
+        stack.resize(lcp + 1);
+        for (size_t d = lcp; d < len; d++) {
+            const int32_t parent = stack[d];
+            const int32_t c = rev->new_node(key[d]);
+            last_child.push_back(-1);
+            if (last_child[parent] < 0) rev->nodes[parent].first_child = c; else rev->nodes[last_child[parent]].next_sibling = c;
+            last_child[parent] = c;
+            if (parent == 0) rev->root_child[key[d]] = c;
+            stack.push_back(c);
+        }
+        Node& nd = rev->nodes[stack[len]];
+        nd.eow = 1; nd.value = kval[idx[q]];
+        prev = key; prev_len = len;
+    }
+    rev->kind = ACX_KIND_TRIE;
+    rev->count = (int64_t)nk;
+    rev->longest_word = t->longest_word;
     return ACX_OK;
 }
 
@@ -62,8 +111,12 @@ int acx_ppm_build(const acx_trie* t, const uint8_t* cls, uint32_t n_classes, boo
         if (sigma == 0) return ACX_OK;
         const uint32_t ho = has_other ? 1u : 0u;
 
+        const bool timing = getenv("ACX_PPM_TIMING") != nullptr;
+        auto t0 = std::chrono::steady_clock::now();
+        auto lap = [&](const char* what) { if (timing) { auto t1 = std::chrono::steady_clock::now(); fprintf(stderr, "[acx_ppm_build] %s: %.3f s\n", what, std::chrono::duration<double>(t1 - t0).count()); t0 = t1; } };
         acx_trie rev;
         int rc = build_reversed(t, &rev);
+        lap("reversed trie");
         if (rc) return rc;
         const size_t n = rev.nodes.size();
         if (n < 2) return ACX_OK;
@@ -82,6 +135,7 @@ int acx_ppm_build(const acx_trie* t, const uint8_t* cls, uint32_t n_classes, boo
             }
         }
 
+        lap("bfs");
         // parameters
         acx_ppm_header h;
         memset(&h, 0, sizeof h);
@@ -174,6 +228,7 @@ int acx_ppm_build(const acx_trie* t, const uint8_t* cls, uint32_t n_classes, boo
                 }
             }
         }
+        lap("codes + deep ids");
         const uint32_t n_rows = (uint32_t)row_nodes.size(), n_single = (uint32_t)single_nodes.size();
         h.n_deep = n_rows; h.n_chain = n_single;
         const uint64_t row_bytes = (uint64_t)(n_rows + 1) * sigma * 16;
@@ -233,6 +288,7 @@ int acx_ppm_build(const acx_trie* t, const uint8_t* cls, uint32_t n_classes, boo
             const int32_t v = path_end(c, len, label, 0);
             fill(singles + (size_t)(k + 1) * 4, v, len, label);
         }
+        lap("rows + singles");
         // cells: everything the d <= C newest symbols say
         for (uint64_t cc = 0; cc < nC; cc++) {
             uint32_t* cell = cells + cc * 8;
@@ -267,6 +323,7 @@ int acx_ppm_build(const acx_trie* t, const uint8_t* cls, uint32_t n_classes, boo
             if (F == C) { if (cell[0] | cell[1]) G[cc >> 5] |= 1u << (cc & 31); }
             else if (cell[0]) for (uint32_t s = 0; s < sigma; s++) { const uint64_t x = cc * sigma + s; G[x >> 5] |= 1u << (x & 31); }
         }
+        lap("cells + filter");
         memcpy(sec, &h, sizeof h);
         *out = sec; *nbytes = off;
         return ACX_OK;
