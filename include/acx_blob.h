@@ -162,20 +162,23 @@ typedef struct acx_blob_header {
  * code_d  = Horner value of the d newest symbols, newest first, radix K:
  *           code_d = code_{d-1} * K + sym(e - d + 1)           (code_0 = 0)
  * Levels 1..C of the reversed trie are direct-indexed by code (K^C <= 2^18):
- *   G  (LDS)  bitmap over code_F (F = C + 1 when K^(C+1) bits fit, else C): "look at the cell".
- *             Set iff the depth-F node exists (F = C + 1) or the cell of code_C is non-empty.
- *   S_a,S_b (LDS) optional bitmaps over code_d for up to two levels d <= C that hold many keys:
- *             bit set iff the k-gram IS a key.  Those levels are then left out of G and of the cell.
- *   cell[code_C] (global, 16 bytes):
- *       .x  eowmask: bit d-1 set iff the d newest symbols are a key (levels not covered by S)
- *       .y  value of the depth-C key (when bit C-1 of .x is set)
- *       .z  deep id of the depth-C node (0: absent or childless)
- *       .w  K <= 4 only: children of that node: mask[0..3] | child is a key[4..7] |
- *           grandchild (s1*4+s2) exists [8..23]; else 0
- *   top_val[top_base[d] + code_d] (global): value of the key that is node (d, code_d), d <= C.
- * Deeper nodes that have children carry deep ids 1..n_deep:
- *   kids[id*K + sym] = child's deep id (0: childless) | child is a key << 31;   0 = no child
- *   kval[id*K + sym] = value of that child when it is a key.
+ *   G    filter bitmap over code_F (F = C + 1 when K^(C+1) bits fit LDS, else C; g_global = 1: F = C + 1 and the
+ *        bitmap is read from global memory — 8-bit symbols only): "look at the cell".  Set iff the depth-F node
+ *        exists (F = C + 1) or the cell of code_C is non-empty.
+ *   cell[code_C] (global, 32 bytes = 8 words):
+ *       [0]  eowmask: bit d-1 set iff the d newest symbols are a key (d <= C)
+ *       [1]  deep id of the depth-C node (0: absent or childless)
+ *       [2]  K <= 4 only: children of that node: mask[0..3] | child is a key[4..7] |
+ *            grandchild (s1*4+s2) exists [8..23]; else 0
+ *       [3..7] the values of the first five keys of eowmask, shortest first (= the order matches are produced in)
+ *   top_val[top_base[d] + code_d] (global): value of the key that is node (d, code_d), d <= C (the sixth key on).
+ * Deeper: the walk stands on a node that has children and takes one 16-byte record per step
+ *       { label, len | is_key << 8 | exists << 9, value, next id }
+ *   a node with two or more children owns a ROW of K records (section `kids`, row = deep id), indexed by the next
+ *   symbol; a node with exactly one child owns a SINGLE record (section `chains`; its id carries bit 31).  A record
+ *   consumes 1 + len symbols (row) or len symbols (single): it follows the unbranched, key-free path below its first
+ *   edge for up to 32 / sym_bits symbols (label: their symbols, first one in the top bits); `next` is the id of the
+ *   node it ends on if that node has children.
  * All section offsets are relative to the start of the acx_ppm_header.
  */
 #define ACX_PPM_MAGIC 0x314D5050u   /* "PPM1" */
@@ -192,14 +195,14 @@ typedef struct acx_ppm_header {
     uint32_t g_words, s_words[2];
     uint32_t has_other;
     uint32_t longest;        /* longest key */
-    uint32_t n_deep;         /* branch rows: deep ids 1..n_deep */
+    uint32_t n_deep;         /* rows: deep ids 1..n_deep */
     uint32_t n_top;          /* entries of top_val */
     uint32_t min_len;        /* shortest key */
-    uint32_t n_chain;        /* chain records: deep ids n_deep+1 .. n_deep+n_chain */
+    uint32_t n_chain;        /* single records: ids 0x80000000 | 1..n_chain */
     uint64_t total_bytes;    /* header + sections */
-    uint64_t off_g, off_s[2], off_cells, off_top_val, off_kids, off_kval;
+    uint64_t off_g, off_s[2], off_cells, off_top_val, off_kids /* rows */, off_kval /* unused */;
     uint32_t top_base[ACX_PPM_MAX_C + 2];
-    uint64_t off_chains;
+    uint64_t off_chains;     /* singles */
     uint8_t  reserved[256 - 144 - 4 * (ACX_PPM_MAX_C + 2)];
 } acx_ppm_header;
 
