@@ -135,11 +135,14 @@ def cpu_baseline(keys, hays, mode):
     na = sum(p[0] for p in parts)
     return {"value": nbytes / dt1 / 1e9, "unit": "GB/s", "cores": 1, "kind": "reference",
             "matches_per_s": n1 / dt1, "seconds": round(dt1, 3),
-            "all_cores": {"value": nbytes / dta / 1e9, "unit": "GB/s", "cores": workers, "seconds": round(dta, 3),
-                          "matches_per_s": na / dta, "slowest_worker_s": round(max(p[1] for p in parts), 3)},
+            # value: the parallel compute time = the slowest worker's own loop (what a long-lived pool would deliver);
+            # wall_incl_fork_s also counts forking and joining the workers
+            "all_cores": {"value": nbytes / max(p[1] for p in parts) / 1e9, "unit": "GB/s", "cores": workers,
+                          "seconds": round(max(p[1] for p in parts), 3), "wall_incl_fork_s": round(dta, 3),
+                          "matches_per_s": na / max(p[1] for p in parts)},
             "host_cpus": cores,
             "sample": "%d haystacks of batch 0 (%.1f MB), Automaton.%s of the reference drained per haystack; "
-                      "1 core, then %d forked workers (wall time incl. fork)" % (len(hays), nbytes / 1e6, mode, workers)}
+                      "1 core, then %d forked workers (automaton inherited copy-on-write, contiguous shares)" % (len(hays), nbytes / 1e6, mode, workers)}
 
 
 def main():
