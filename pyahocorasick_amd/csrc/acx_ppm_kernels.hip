@@ -490,7 +490,8 @@ __global__ void __launch_bounds__(ACX_PPM_BLOCK) k_ppm_stream(const acx_ppm_args
     constexpr uint32_t BW = TPOS / 32;                                 // words of the start bitmap
     constexpr uint32_t SMASK = (1u << SB) - 1u;
     constexpr int LOG = SB == 2 ? 1 : (SB == 4 ? 2 : 3);
-    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63;
+    const int wid = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));   // (wave-uniform, and the compiler is told so)
     Ppm<SB, POW2, false> P(a);
     P.s_g = GG ? a.g : smem + a.lds.g_off;
     P.s_map = (const uint8_t*)(smem + a.lds.map_off);
@@ -529,10 +530,9 @@ __global__ void __launch_bounds__(ACX_PPM_BLOCK) k_ppm_stream(const acx_ppm_args
     // x = offset-in-haystack of the tile's first position + a position of the tile: haystacks crossed, new offset
     auto divmod = [&](uint32_t x, uint32_t& r) -> uint32_t {
         uint32_t q;
-        if (a.m24) q = (uint32_t)__umul24(x, a.m24) >> 24;             // stride < 1024: exact for x < stride + 1024 (the cast: a logical shift)
-        else q = x >= stride ? 1u : 0u;                                // stride >= 1024: one haystack start per tile at most
-        r = x - q * stride;
-        return q;
+        if (a.m24) { q = (uint32_t)__umul24(x, a.m24) >> 24; r = x - (uint32_t)__umul24(q, stride); }   // stride < 1024: exact for x < stride + 1024
+        else { q = x >= stride ? 1u : 0u; r = x - (q ? stride : 0u); }   // stride >= 1024: one haystack start per tile at most
+        return q;                                                      // (24-bit multiplies: full rate; the cast: a logical shift)
     };
     auto load_dw = [&](uint32_t b) -> uint32_t {                      // the dword at byte b of the buffer (b is a multiple of 4)
         uint32_t w = 0;
