@@ -32,6 +32,8 @@ namespace {
 
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+typedef uint32_t u32x4a __attribute__((ext_vector_type(4), aligned(4)));   // (global loads need dword alignment only)
+typedef uint32_t u32x2a __attribute__((ext_vector_type(2), aligned(4)));
 
 // LDS traffic of one wave is ordered in hardware; this only stops the compiler from moving LDS
 // accesses across the hand-over points between lanes of the same wave.
@@ -480,7 +482,9 @@ __global__ void __launch_bounds__(ACX_PPM_BLOCK) k_ppm_stream(const acx_ppm_args
     if (!GG) for (uint32_t i = threadIdx.x; i < a.g_words; i += blockDim.x) smem[a.lds.g_off + i] = a.g[i];
     if (threadIdx.x < 256) {
         const uint32_t cl = a.cls[threadIdx.x];
-        ((uint8_t*)(smem + a.lds.map_off))[threadIdx.x] = (a.has_other && cl == 0) ? 0xFFu : (uint8_t)(cl - a.has_other);
+        // a byte of no key: 0xFF with 8-bit symbols (staged as symbol 0 by convert), 0x80 with narrower ones — its
+        // symbol bits are 0 then, which keeps every staged field below K (the filter reads windows unmasked)
+        ((uint8_t*)(smem + a.lds.map_off))[threadIdx.x] = (a.has_other && cl == 0) ? (SB == 8 ? 0xFFu : 0x80u) : (uint8_t)(cl - a.has_other);
     }
     __syncthreads();
 
@@ -489,7 +493,11 @@ __global__ void __launch_bounds__(ACX_PPM_BLOCK) k_ppm_stream(const acx_ppm_args
     constexpr uint32_t TW = TPOS / SPW;                                // words of a tile's symbols
     constexpr uint32_t BW = TPOS / 32;                                 // words of the start bitmap
     constexpr uint32_t SMASK = (1u << SB) - 1u;
-    constexpr int LOG = SB == 2 ? 1 : (SB == 4 ? 2 : 3);
+    constexpr uint32_t PPL = TPOS / 64;                                // positions per lane: 16 or 8, contiguous
+    constexpr uint32_t DPL = PPL / 4;                                  // haystack dwords per lane
+    constexpr uint32_t OWN = PPL * SB;                                 // bits of packed symbols a lane makes: 16 .. 128
+    constexpr uint32_t OW = OWN >= 32 ? OWN / 32 : 1;                  // ... in words
+    constexpr uint32_t LPS = 256 / PPL;                                // lanes of a sub-step (256 positions)
     const int lane = threadIdx.x & 63;
     const int wid = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));   // (wave-uniform, and the compiler is told so)
     Ppm<SB, POW2, false> P(a);
@@ -549,9 +557,9 @@ __global__ void __launch_bounds__(ACX_PPM_BLOCK) k_ppm_stream(const acx_ppm_args
             if (SB == 8) { const bool o = a.has_other && sv == 0xFFu; nib |= (o ? 1u : 0u) << k; packed |= (o ? 0u : sv) << (SB * k); }
             else { seen |= sv; packed |= (sv & SMASK) << (SB * k); }
         }
-        if (SB != 8 && (seen & 0x80u)) {                               // (symbols are < 16 here: bit 7 means 0xFF)
+        if (SB != 8 && (seen & 0x80u)) {                               // (symbols are < 16 here: bit 7 means "no key has it")
 #pragma unroll
-            for (int k = 0; k < 4; k++) if (P.s_map[(w >> (8 * k)) & 0xFFu] == 0xFFu) nib |= 1u << k;
+            for (int k = 0; k < 4; k++) if (P.s_map[(w >> (8 * k)) & 0xFFu] == 0x80u) nib |= 1u << k;
         }
         return packed;
     };
@@ -577,7 +585,6 @@ __global__ void __launch_bounds__(ACX_PPM_BLOCK) k_ppm_stream(const acx_ppm_args
         for (uint32_t i = 1; i <= n; i++) c = c * a.K + __builtin_amdgcn_ubfe(Xm, 32 - SB * i, (uint32_t)SB);
         return c;
     };
-    auto filter_bit = [&](uint32_t cF) -> uint32_t { return __builtin_amdgcn_ubfe(P.s_g[cF >> 5], cF, 1u); };
 
     // ---- prologue: the halo of the run's first tile -----------------------------------------
     uint32_t e0 = (uint32_t)(t_begin * TPOS);
@@ -597,9 +604,18 @@ __global__ void __launch_bounds__(ACX_PPM_BLOCK) k_ppm_stream(const acx_ppm_args
         uint32_t rr; h_tile = div_magic(e0, a.stride_magic, stride, rr); r_tile = rr;
         h_tile = (uint32_t)__builtin_amdgcn_readfirstlane((int)h_tile); r_tile = (uint32_t)__builtin_amdgcn_readfirstlane((int)r_tile);
     }
-    uint32_t wnext[NSUB];
+    // a lane's PPL bytes of a tile (contiguous: one vector load)
+    auto load_lane = [&](uint32_t b, uint32_t (&w)[DPL]) {
+        if ((int64_t)b + PPL <= a.hay_cap) {
+            if (DPL == 4) { const u32x4a v = *(const u32x4a*)(a.hay + b); w[0] = v.x; w[1] = v.y; w[2 % DPL] = v.z; w[3 % DPL] = v.w; }
+            else { const u32x2a v = *(const u32x2a*)(a.hay + b); w[0] = v.x; w[1] = v.y; }
+        } else {
 #pragma unroll
-    for (int j = 0; j < NSUB; j++) wnext[j] = load_dw(e0 + 4u * (64 * j + lane));
+            for (int j = 0; j < (int)DPL; j++) w[j] = load_dw(b + 4u * j);
+        }
+    };
+    uint32_t wnext[DPL];
+    load_lane(e0 + PPL * (uint32_t)lane, wnext);
     int64_t fh_next = OFFS ? a.first_h[t_begin] : 0;
 
     // the wave's record stream
@@ -613,18 +629,23 @@ __global__ void __launch_bounds__(ACX_PPM_BLOCK) k_ppm_stream(const acx_ppm_args
         const uint32_t left = H - e0;
         const uint32_t npos = left < TPOS ? left : TPOS;
         // ---- stage (and request the next tile's bytes) ---------------------------------------------
-        uint32_t anyo = 0;
-        uint32_t nibs[NSUB];
+        // W[0]: the 32 bits of symbols in front of the lane's own (read back from LDS below), W[1..]: its own
+        uint32_t anyo = 0;                                             // which of the lane's positions hold a byte of no key
+        uint32_t nibs[DPL];
+        uint32_t W[OW + 1];
 #pragma unroll
-        for (int j = 0; j < NSUB; j++) {
+        for (int k = 0; k <= (int)OW; k++) W[k] = 0;
+#pragma unroll
+        for (int j = 0; j < (int)DPL; j++) {
             const uint32_t packed = convert(wnext[j], nibs[j]);
-            put_sym(sym_tile_bytes, 64 * j + lane, packed);
-            anyo |= nibs[j];
+            W[1 + (4 * SB * j) / 32] |= packed << ((4 * SB * j) & 31);
+            anyo |= nibs[j] << (4 * j);
         }
-        if (tile + 1 < t_end) {
+        if (OWN >= 32) {
 #pragma unroll
-            for (int j = 0; j < NSUB; j++) wnext[j] = load_dw(e0 + TPOS + 4u * (64 * j + lane));
-        }
+            for (int k = 0; k < (int)OW; k++) ((uint32_t*)sym_tile_bytes)[OW * lane + k] = W[1 + k];
+        } else ((uint16_t*)sym_tile_bytes)[lane] = (uint16_t)W[1];
+        if (tile + 1 < t_end) load_lane(e0 + TPOS + PPL * (uint32_t)lane, wnext);
         // OFFS: the haystack starts of this tile -> bitmap, last-start and count tables
         uint32_t hbase = 0, base_r = 0;                                // haystack covering the tile's first byte; that byte's offset in it
         if (OFFS) {
@@ -656,7 +677,7 @@ __global__ void __launch_bounds__(ACX_PPM_BLOCK) k_ppm_stream(const acx_ppm_args
         const uint32_t use_other = any_cur | any_prev;
         if (use_other) {
 #pragma unroll
-            for (int j = 0; j < NSUB; j++) oth[HP / 4 + 64 * j + lane] = (uint8_t)nibs[j];
+            for (int j = 0; j < (int)DPL; j++) oth[HP / 4 + DPL * lane + j] = (uint8_t)nibs[j];
             wave_sync();
             uint32_t carry = 0;                                        // index + 1 of the last dword that holds an "other" byte
             for (uint32_t i0 = 0; i0 < NDW; i0 += 64) {
@@ -684,66 +705,69 @@ __global__ void __launch_bounds__(ACX_PPM_BLOCK) k_ppm_stream(const acx_ppm_args
             else r = base_r + p;
         };
 
-        // ---- sub-steps: filter 4 positions per lane, append, drain full rounds ---------------------------
-#pragma unroll 1
-        for (uint32_t sub = 0; sub < NSUB; sub++) {
-            if (sub * 256u >= npos) break;
-            const uint32_t pb = sub * 256u + 4u * lane;
-            uint32_t r0, rk0, ks;                                       // offset of position pb; where the next haystack starts among pb+1..pb+3 (else big)
-            where(pb, r0, rk0);
-            if (OFFS) { const uint32_t nb = (sbits[pb >> 5] >> (pb & 31u)) & 0xEu; ks = nb ? (uint32_t)__ffs(nb) - 1u : 0x7FFFFFFFu; }
-            else ks = stride - r0;
-            uint32_t pm = 0, mm = 0;
+        // ---- filter: every lane tests its own PPL positions, windows in registers ------------------------
+        // The bitmap is asked about the F newest symbols as they stand — bytes of the previous haystack and
+        // bytes of no key (staged as symbol 0) included: that can only add candidates (a key of length l needs
+        // its own l symbols only, and G says yes for any older ones), and the rounds below bound every match
+        // by the symbols that really exist.
+        if (OWN >= 32) W[0] = ((const uint32_t*)sym_tile_bytes)[(int)(OW * lane) - 1];
+        else W[0] = ((uint32_t)((const uint16_t*)sym_tile_bytes)[lane - 1] << 16) | ((const uint16_t*)sym_tile_bytes)[lane - 2];
+        uint32_t pw = 0;                                               // positions that pass
+        {
+            uint32_t gw[PPL], cf[PPL];
+#pragma unroll
+            for (int i = 0; i < (int)PPL; i++) {
+                const uint32_t e = SB * (i + 1), k = e >> 5, sh = e & 31u;
+                const uint32_t X = sh ? __builtin_amdgcn_alignbit(W[k + 1 <= OW ? k + 1 : OW], W[k], sh) : W[k];
+                cf[i] = code_n(X, a.F);
+                gw[i] = P.s_g[cf[i] >> 5];
+            }
+#pragma unroll
+            for (int i = 0; i < (int)PPL; i++) pw |= __builtin_amdgcn_ubfe(gw[i], cf[i], 1u) << i;
+        }
+        // haystack starts among the lane's positions
+        uint32_t sw = 0;
+        if (OFFS) sw = PPL == 16 ? ((const uint16_t*)sbits)[lane] : ((const uint8_t*)sbits)[lane];
+        else {
+            uint32_t r;
+            (void)divmod(r_tile + PPL * (uint32_t)lane, r);
+            const uint32_t o = r ? stride - r : 0u;                        // (stride >= 8: two starts in 16 positions at most)
+            sw = (o < PPL ? 1u << o : 0u) | (o + stride < PPL ? 1u << ((o + stride) & 31u) : 0u);
+        }
+        {
+            const uint32_t lp = PPL * (uint32_t)lane;
+            const uint32_t nv = npos > lp ? (npos - lp < PPL ? npos - lp : PPL) : 0u;
+            const uint32_t vm = (1u << nv) - 1u;
+            pw &= vm & ~anyo;                                          // (a byte of no key ends no key)
+            sw &= vm;
+        }
+        // ---- expansion: candidates and haystack starts -> the queue, in position order; then full rounds -----
+        // Everything at once when the queue has the room (the usual case), else a sub-step (256 positions) at a time.
+        uint32_t xw = pw | sw, x_tot;
+        const uint32_t x_ex = wave_excl_scan((uint32_t)__popc(xw), x_tot);
+        uint32_t seg_lo = 0;
+        while (seg_lo < 64u) {
+            const uint32_t ex_lo = seg_lo ? (uint32_t)__builtin_amdgcn_readlane((int)x_ex, (int)seg_lo) : 0u;
+            uint32_t seg_hi = 64u, n_seg = x_tot - ex_lo;
+            if (n_seg > PPM_QCAP - qcount) { seg_hi = seg_lo + LPS; n_seg = (seg_hi < 64u ? (uint32_t)__builtin_amdgcn_readlane((int)x_ex, (int)seg_hi) : x_tot) - ex_lo; }
             {
-                const uint32_t endbit3 = SB * (HP + pb + 4u) + 64u;
-                const uint32_t wi = endbit3 >> 5, sh = endbit3 & 31u;
-                const uint32_t hi = sym[wi], mid = sym[wi - 1], lo = sym[wi - 2];
-                const uint32_t X3 = __builtin_amdgcn_alignbit(hi, mid, sh), Y = __builtin_amdgcn_alignbit(mid, lo, sh);
-                const uint32_t u0 = 0u - ks;                             // past the start: offset k - ks (unsigned min picks it)
-                if (!use_other && npos == TPOS) {
-                    // the common tile: whole, no byte outside the key alphabet
-                    mm = (r0 == 0 ? 1u : 0u) | (ks < 4u ? 1u << ks : 0u);
-#pragma unroll
-                    for (int k = 0; k < 4; k++) {
-                        const uint32_t r = k == 0 ? r0 : (r0 + k < u0 + k ? r0 + k : u0 + k);
-                        const uint32_t m = r < SPW - 1 ? r : SPW - 1;         // symbols beyond the haystack start read as 0
-                        const uint32_t X = k == 3 ? X3 : __builtin_amdgcn_alignbit(X3, Y, 32 - SB * (3 - k));
-                        const uint32_t Xm = X & (uint32_t)((int32_t)0x80000000 >> ((m << LOG) + (SB - 1)));
-                        const uint32_t bit = filter_bit(code_n(Xm, a.F));
-                        pm |= (r + 1 >= a.min_len ? bit : 0u) << k;
-                    }
-                } else {
-#pragma unroll
-                    for (int k = 0; k < 4; k++) {
-                        const uint32_t r = k == 0 ? r0 : (r0 + k < u0 + k ? r0 + k : u0 + k);
-                        const bool inside = pb + k < npos;
-                        uint32_t L = r + 1 < a.longest ? r + 1 : a.longest;
-                        if (use_other) { const uint32_t lo2 = other_limit(HP + pb + k); if (lo2 < L) L = lo2; }
-                        if (!inside) L = 0;
-                        const uint32_t X = k == 3 ? X3 : __builtin_amdgcn_alignbit(X3, Y, 32 - SB * (3 - k));
-                        const uint32_t Lc = L < SPW ? L : SPW;
-                        const uint32_t Xm = X & (uint32_t)((int32_t)0x80000000 >> ((SB * Lc - 1u) & 31u));
-                        const uint32_t bit = L ? filter_bit(code_n(Xm, a.F)) : 0u;
-                        pm |= (L >= a.min_len ? bit : 0u) << k;
-                        mm |= ((inside && r == 0) ? 1u : 0u) << k;
+                uint32_t w = ((uint32_t)lane >= seg_lo && (uint32_t)lane < seg_hi) ? xw : 0u;
+                uint32_t j = qtail + (x_ex - ex_lo); if (j >= PPM_QCAP) j -= PPM_QCAP;
+                while (__any(w != 0u)) {
+                    if (w) {
+                        const uint32_t b = (uint32_t)__builtin_ctz(w);
+                        w &= w - 1u;
+                        queue[j] = (uint16_t)((PPL * (uint32_t)lane + b) | (((pw >> b) & 1u) ? 0u : 0x8000u));     // 0x8000: a start that is no candidate
+                        j = j + 1 == PPM_QCAP ? 0 : j + 1;
                     }
                 }
             }
-            uint32_t nadd;
-            const uint32_t qb = wave_excl_scan((uint32_t)__popc(pm) + (uint32_t)__popc(mm), nadd);
-            {
-                uint32_t j = qtail + qb; if (j >= PPM_QCAP) j -= PPM_QCAP;
-#pragma unroll
-                for (int k = 0; k < 4; k++) {
-                    if ((mm >> k) & 1u) { queue[j] = (uint16_t)(0x8000u | (pb + k)); j = j + 1 == PPM_QCAP ? 0 : j + 1; }     // the marker goes first
-                    if ((pm >> k) & 1u) { queue[j] = (uint16_t)(pb + k); j = j + 1 == PPM_QCAP ? 0 : j + 1; }
-                }
-            }
-            qtail += nadd; if (qtail >= PPM_QCAP) qtail -= PPM_QCAP;
-            qcount += nadd;
+            qtail += n_seg; if (qtail >= PPM_QCAP) qtail -= PPM_QCAP;
+            qcount += n_seg;
+            seg_lo = seg_hi;
             if (a.dbg & 4u) { qhead = qtail; qcount = 0; }
             wave_sync();
-            const bool last_sub = sub + 1 == NSUB || (sub + 1) * 256u >= npos;
+            const bool last_sub = seg_lo >= 64u;
 
             // ---- rounds: 64 queue entries, in position order ---------------------------------------
             while (qcount >= 64 || (last_sub && qcount > 0)) {
@@ -818,7 +842,7 @@ __global__ void __launch_bounds__(ACX_PPM_BLOCK) k_ppm_stream(const acx_ppm_args
                 }
                 uint32_t rt;
                 const uint32_t ex = wave_excl_scan(c, rt);
-                if (act && marker) a.hay_local[h] = (int32_t)(run_off + ex);
+                if (act && r == 0u) a.hay_local[h] = (int32_t)(run_off + ex);     // a haystack starts here: the records in front of it
                 if (rt && !dead) {
                     if (g_used + rt > g_size) {                        // this round does not fit the current grant: open the next one
                         if (ng == PPM_MAX_GRANTS) dead = true;
