@@ -174,14 +174,15 @@ typedef struct acx_blob_header {
  *   top_val[top_base[d] + code_d] (global): value of the key that is node (d, code_d), d <= C (the sixth key on).
  * Deeper: the walk stands on a node that has children and takes one 16-byte record per step
  *       { label, len | is_key << 8 | exists << 9, value, next id }
- *   a node with two or more children owns a ROW of K records (section `kids`, row = deep id), indexed by the next
+ *   a node with two or more children owns a ROW of K records (section `kids`; its id is the index of the row's first
+ *   record, row number x K, so that the device adds the symbol and never multiplies), indexed by the next
  *   symbol; a node with exactly one child owns a SINGLE record (section `chains`; its id carries bit 31).  A record
  *   consumes 1 + len symbols (row) or len symbols (single): it follows the unbranched, key-free path below its first
  *   edge for up to 32 / sym_bits symbols (label: their symbols, first one in the top bits); `next` is the id of the
  *   node it ends on if that node has children.
  * All section offsets are relative to the start of the acx_ppm_header.
  */
-#define ACX_PPM_MAGIC 0x314D5050u   /* "PPM1" */
+#define ACX_PPM_MAGIC 0x324D5050u   /* "PPM2" */
 #define ACX_PPM_MAX_C 20
 #define ACX_PPM_TILE  256           /* end positions per wave and tile */
 typedef struct acx_ppm_header {
@@ -195,7 +196,7 @@ typedef struct acx_ppm_header {
     uint32_t g_words, s_words[2];
     uint32_t has_other;
     uint32_t longest;        /* longest key */
-    uint32_t n_deep;         /* rows: deep ids 1..n_deep */
+    uint32_t n_deep;         /* rows: deep ids K, 2K, .. n_deep * K */
     uint32_t n_top;          /* entries of top_val */
     uint32_t min_len;        /* shortest key */
     uint32_t n_chain;        /* single records: ids 0x80000000 | 1..n_chain */

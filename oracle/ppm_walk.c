@@ -85,7 +85,7 @@ int64_t ppm_iter(const uint8_t* blob, const uint8_t* hay, int64_t len, int32_t i
                 if (id >> 31) { rec = singles + (size_t)(id & 0x7FFFFFFFu) * 4; first = 0; }
                 else {
                     if (L <= d) break;
-                    rec = rows + ((size_t)id * K + (uint32_t)(cls[hay[e - d]] - ho)) * 4; first = 1;
+                    rec = rows + ((size_t)id + (uint32_t)(cls[hay[e - d]] - ho)) * 4; first = 1;   /* a row's id is the index of its first record */
                 }
                 if (!(rec[1] & 0x200u)) break;          /* no child on this symbol */
                 const uint32_t len = rec[1] & 0xFFu;

@@ -145,7 +145,9 @@ int acx_ppm_build(const acx_trie* t, const uint8_t* cls, uint32_t n_classes, boo
         const uint32_t max_syms = 32u / h.sym_bits;                     // a window is 32 bits
         auto ipow = [&](uint32_t e) -> uint64_t { uint64_t p = 1; for (uint32_t i = 0; i < e; i++) { p *= sigma; if (p > ((uint64_t)1 << 40)) break; } return p; };
         uint32_t C = 0;
-        while (C + 1 <= (uint32_t)max_depth && C + 1 <= max_syms && C + 1 <= 16 && ipow(C + 1) <= ((uint64_t)1 << 18)) C++;
+        uint32_t cell_bits = 18;                                        // cells: 32 bytes each, at most 2^cell_bits of them
+        if (const char* e = getenv("ACX_PPM_CELL_BITS")) { const int v = atoi(e); if (v >= 4 && v <= 22) cell_bits = (uint32_t)v; }   // tuning hook
+        while (C + 1 <= (uint32_t)max_depth && C + 1 <= max_syms && C + 1 <= 16 && ipow(C + 1) <= ((uint64_t)1 << cell_bits)) C++;
         if (C == 0) return ACX_OK;
         const acx_ppm_lds base_layout = acx_ppm_lds_layout(0, h.sym_bits, h.longest);
         if (base_layout.total_words + 64 > ACX_PPM_LDS_BYTES / 4) return ACX_OK;
@@ -266,11 +268,14 @@ int acx_ppm_build(const acx_trie* t, const uint8_t* cls, uint32_t n_classes, boo
             }
             if (d == F && F == C + 1) G[code[u] >> 5] |= 1u << (code[u] & 31);
         }
+        // ids as the kernels read them: a row's id is its first record's index (row number x K: no multiply on the
+        // device), a single's id is its number with bit 31 set
+        auto stored_id = [&](int32_t v) -> uint32_t { const uint32_t d = deep[v]; return (d >> 31) ? d : d * sigma; };
         auto fill = [&](uint32_t* rec, int32_t v, uint32_t len, uint32_t label) {
             rec[0] = label;
             rec[1] = len | (rev.nodes[v].eow ? 0x100u : 0u) | 0x200u;   // 0x200: the record exists
             rec[2] = rev.nodes[v].eow ? (uint32_t)val32(rev.nodes[v]) : 0u;
-            rec[3] = deep[v];
+            rec[3] = stored_id(v);
         };
         for (uint32_t b = 0; b < n_rows; b++) {
             const int32_t u = row_nodes[b];
@@ -307,7 +312,7 @@ int acx_ppm_build(const acx_trie* t, const uint8_t* cls, uint32_t n_classes, boo
             cell[0] = mask;
             const int32_t u = topC_node[cc];
             if (u >= 0 && deep[u]) {
-                cell[1] = deep[u];
+                cell[1] = stored_id(u);
                 if (sigma <= 4) {
                     uint32_t w = 0;
                     for (int32_t c = rev.nodes[u].first_child; c >= 0; c = rev.nodes[c].next_sibling) {

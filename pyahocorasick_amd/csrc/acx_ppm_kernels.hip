@@ -24,6 +24,8 @@
 #include "acx_kernels.h"
 #include "acx_ppm_layout.h"
 
+#include <type_traits>
+
 #define PPM_TILE  ACX_PPM_TILE
 #define PPM_GRANT 1024u            // records a wave takes from the scratch pool at a time
 #define PPM_NOBASE 0xFFFFFFFFu
@@ -205,7 +207,7 @@ struct Ppm {
                 const bool single = (id >> 31) != 0;
                 if (!single && E.L <= d) break;
                 const uint32_t first = single ? 0u : 1u;
-                const size_t ri = single ? (size_t)(id & 0x7FFFFFFFu) : (size_t)id * a.K + sym_at(q - d);
+                const size_t ri = single ? (size_t)(id & 0x7FFFFFFFu) : (size_t)id + sym_at(q - d);      // (a row's id: the index of its first record)
                 const u32x4 rec = *(const u32x4*)((single ? a.chains : a.kids) + ri * 4);
                 if (!(rec.y & 0x200u)) break;
                 const uint32_t len = rec.y & 0xFFu;
@@ -769,80 +771,118 @@ __global__ void __launch_bounds__(ACX_PPM_BLOCK) k_ppm_stream(const acx_ppm_args
             wave_sync();
             const bool last_sub = seg_lo >= 64u;
 
-            // ---- rounds: 64 queue entries, in position order ---------------------------------------
-            while (qcount >= 64 || (last_sub && qcount > 0)) {
-                const uint32_t nr = qcount < 64 ? qcount : 64;
-                const bool act = (uint32_t)lane < nr;
-                uint32_t qi = qhead + lane; if (qi >= PPM_QCAP) qi -= PPM_QCAP;
-                const uint32_t ent = act ? queue[qi] : 0x8000u;
-                const bool marker = (ent >> 15) != 0;
-                const uint32_t p = ent & 0x7FFFu;
-                uint32_t r, rk, c = 0;
-                where(p, r, rk);
-                const uint32_t h = OFFS ? hbase + rk : h_tile + rk;
-                typename Ppm<SB, POW2, false>::Ent E;
-                int32_t va = 0, vb = 0;
-                bool deep_go = false; uint32_t deep_id = 0;
-                E.L = 0; E.X = 0; E.p = p;
-                if (act && !marker) {
-                    E.p = p; E.idx = r + (a.index_base ? (uint32_t)a.index_base[h] : 0u);
+            // ---- rounds: the queue is worked off in position order, 64 entries at a time — or 128, two per lane, when
+            // it holds that many: the gathers of a round (one cell per entry, then one record per step of the deeper
+            // walk) depend on each other, and with 4 waves per SIMD there is little else to run while they are in
+            // flight, so two entries per lane halve the waiting per entry.
+            // Straight-line code: every lane computes, a lane without a candidate (past the end of the queue, or a
+            // haystack start that did not pass the filter) works on position 0 with L = 0, which matches nothing.
+            // (Nested divergent branches cost more scalar bookkeeping here than the work they skip.)
+            auto do_round = [&](auto ne_tag) {
+                constexpr int NE = decltype(ne_tag)::value;
+                const uint32_t nr = qcount < 64u * NE ? qcount : 64u * NE;
+                uint32_t pq[NE], rr[NE], hh[NE], cn[NE], LL[NE], XX[NE], ix[NE], did[NE];
+                u32x4 c0[NE], c1[NE];
+                int32_t va[NE], vb[NE];
+                bool act[NE], go[NE];
+#pragma unroll
+                for (int e = 0; e < NE; e++) {
+                    act[e] = (uint32_t)lane + 64u * e < nr;
+                    uint32_t qi = qhead + lane + 64u * e; if (qi >= PPM_QCAP) qi -= PPM_QCAP;
+                    uint32_t ent = queue[qi];
+                    ent = act[e] ? ent : 0x8000u;
+                    const bool cand = ent < 0x8000u;
+                    const uint32_t p = ent & 0x7FFFu;
+                    uint32_t r, rk;
+                    where(p, r, rk);
+                    pq[e] = HP + p; rr[e] = r;
+                    hh[e] = OFFS ? hbase + rk : h_tile + rk;
+                    ix[e] = r + (a.index_base ? (uint32_t)a.index_base[hh[e]] : 0u);
                     uint32_t L = r + 1 < a.longest ? r + 1 : a.longest;
                     if (use_other) { const uint32_t lo2 = other_limit(HP + p); if (lo2 < L) L = lo2; }
-                    E.L = L;
-                    const uint32_t q = HP + p;
-                    E.X = P.window(q);
-                    const uint32_t Lc = L < SPW ? L : SPW;
-                    const uint32_t Xm = E.X & (uint32_t)((int32_t)0x80000000 >> ((SB * Lc - 1u) & 31u));
-                    const u32x4* cell = (const u32x4*)((const uint8_t*)a.cells + (code_n(Xm, a.C) << 5));   // (32-bit offset: at most 2^18 cells)
-                    E.c0 = cell[0]; E.c1 = cell[1];
+                    LL[e] = cand ? L : 0u;
+                    XX[e] = P.window(HP + p);
+                    // the cell of the C newest symbols as they stand: what it says about depths <= L does not depend on
+                    // the older ones, and nothing deeper is asked when L <= C
+                    const u32x4* cell = (const u32x4*)((const uint8_t*)a.cells + (code_n(XX[e], a.C) << 5));   // (32-bit offset)
+                    c0[e] = cell[0]; c1[e] = cell[1];
+                }
+                bool any_go = false;
+#pragma unroll
+                for (int e = 0; e < NE; e++) {
+                    cn[e] = 0; va[e] = 0; vb[e] = 0; go[e] = false; did[e] = 0;
                     if (!(a.dbg & 1u)) {
                         // top levels: the cell lists their values in match order, so the first two are always c0.w, c1.x
-                        uint32_t mask = E.c0.x;
-                        if (L < 32) mask &= (1u << L) - 1u;
-                        c = (uint32_t)__popc(mask);
-                        va = (int32_t)E.c0.w; vb = (int32_t)E.c1.x;
-                        uint32_t id = E.c0.y, d = a.C;
-                        bool go = id != 0 && L > d;
-                        if (SB == 2 && E.c0.z && SB * (a.C + 2) <= 32) {   // K <= 4: the cell knows children and grandchildren; both symbols are in X
-                            const uint32_t t = __builtin_amdgcn_ubfe(E.X, 32 - SB * (a.C + 2), 4u), s1 = t >> 2, z = E.c0.z;
-                            const bool kid = ((z >> s1) & 1u) != 0, keow = ((z >> (4 + s1)) & 1u) != 0, gk = ((z >> (8 + t)) & 1u) != 0;
-                            go = go && kid && (keow || (gk && L > d + 1));
+                        const uint32_t L = LL[e];
+                        const uint32_t mask = c0[e].x & (L < 32 ? (1u << L) - 1u : 0xFFFFFFFFu);
+                        cn[e] = (uint32_t)__popc(mask);
+                        va[e] = (int32_t)c0[e].w; vb[e] = (int32_t)c1[e].x;
+                        const uint32_t id = c0[e].y, d = a.C;
+                        bool g = id != 0 && L > d;
+                        if (SB == 2 && SB * (a.C + 2) <= 32) {         // K <= 4: the cell knows children and grandchildren; both symbols are in X
+                            const uint32_t t = __builtin_amdgcn_ubfe(XX[e], 32 - SB * (a.C + 2), 4u), s1 = t >> 2, z = c0[e].z;
+                            const uint32_t kid = z >> s1, keow = z >> (4 + s1), gk = (L > d + 1 ? z : 0u) >> (8 + t);
+                            g = g && (z == 0 || ((kid & (keow | gk)) & 1u) != 0);
                         }
-                        deep_go = go; deep_id = id;                    // (the loop is below: its trip count is wave-uniform)
+                        go[e] = g; did[e] = id;
+                        any_go = any_go || g;
                     }
                 }
                 // deeper levels: one 16-byte record per step (rows: indexed by the next symbol; singles).  Every
                 // lane runs every iteration with selects instead of branches (a lane that is done re-reads
                 // record 0): a divergent loop costs several times more instructions than its body here.
-                if (__any(deep_go)) {
-                    const uint32_t q = HP + E.p;
-                    uint32_t d = a.C, id = deep_id;
-                    bool go = deep_go;
-                    uint32_t s1 = SB * (a.C + 1) <= 32 ? __builtin_amdgcn_ubfe(E.X, (32 - SB * (a.C + 1)) & 31u, (uint32_t)SB) : P.sym_at(q - d);
+                if (__any(any_go)) {
+                    uint32_t dd[NE], s1[NE];
+#pragma unroll
+                    for (int e = 0; e < NE; e++) {
+                        dd[e] = a.C;
+                        s1[e] = SB * (a.C + 1) <= 32 ? __builtin_amdgcn_ubfe(XX[e], (32 - SB * (a.C + 1)) & 31u, (uint32_t)SB) : P.sym_at(pq[e] - a.C);
+                    }
                     for (;;) {
-                        const bool single = (id >> 31) != 0;
-                        const uint32_t first = single ? 0u : 1u;
-                        uint32_t off = single ? a.single_off + ((id & 0x7FFFFFFFu) << 4) : a.row_off + ((id * a.K + s1) << 4);
-                        off = go ? off : a.row_off;
-                        const u32x4 rec = *(const u32x4*)(a.deep_base + off);
-                        const uint32_t len = rec.y & 0xFFu;
-                        const uint32_t wq = go ? q - d - first : HP;     // (a lane that is done reads a harmless window)
-                        const uint32_t diff = (P.window(wq) ^ rec.x) >> ((32 - SB * len) & 31u);
-                        const bool ok = go && (rec.y & 0x200u) != 0 && E.L >= d + first + len && (len == 0 || diff == 0);
-                        const bool hit = ok && (rec.y & 0x100u) != 0;
-                        va = (hit && c == 0) ? (int32_t)rec.z : va;
-                        vb = (hit && c == 1) ? (int32_t)rec.z : vb;
-                        c += hit ? 1u : 0u;
-                        d += first + len;
-                        id = rec.w;
-                        go = ok && id != 0 && ((id >> 31) != 0 || E.L > d);
-                        if (!__any(go)) break;
-                        s1 = go ? P.sym_at(q - d) : 0u;
+                        // the records of all entries first (their gathers overlap), then what they say; flags are 0/1
+                        // words combined with & and |: no short-circuit branches
+                        u32x4 rec[NE];
+                        uint32_t first[NE];
+#pragma unroll
+                        for (int e = 0; e < NE; e++) {
+                            const uint32_t id = did[e], single = id >> 31;
+                            first[e] = single ^ 1u;
+                            uint32_t off = single ? a.single_off + (id << 4) : a.row_off + ((id + s1[e]) << 4);   // (bit 31 shifts out; a row's id is a record index)
+                            off = go[e] ? off : a.row_off;
+                            rec[e] = *(const u32x4*)(a.deep_base + off);
+                        }
+                        uint32_t more = 0;
+#pragma unroll
+                        for (int e = 0; e < NE; e++) {
+                            const uint32_t g = go[e] ? 1u : 0u;
+                            const uint32_t len = rec[e].y & 0xFFu;
+                            const uint32_t dn = dd[e] + first[e] + len;
+                            const uint32_t wq = g ? pq[e] - dd[e] - first[e] : HP;   // (a lane that is done reads a harmless window)
+                            const uint32_t diff = (P.window(wq) ^ rec[e].x) >> ((0u - SB * len) & 31u);
+                            const uint32_t ok = g & (rec[e].y >> 9) & (LL[e] >= dn ? 1u : 0u) & ((len == 0u ? 1u : 0u) | (diff == 0u ? 1u : 0u));
+                            const uint32_t hit = ok & (rec[e].y >> 8);
+                            va[e] = (hit & (cn[e] == 0u ? 1u : 0u)) ? (int32_t)rec[e].z : va[e];
+                            vb[e] = (hit & (cn[e] == 1u ? 1u : 0u)) ? (int32_t)rec[e].z : vb[e];
+                            cn[e] += hit & 1u;
+                            dd[e] = dn;
+                            did[e] = rec[e].w;
+                            const uint32_t g2 = ok & 1u & (rec[e].w != 0u ? 1u : 0u) & ((rec[e].w >> 31) | (LL[e] > dn ? 1u : 0u));
+                            go[e] = g2 != 0u;
+                            more |= g2;
+                        }
+                        if (!__any(more != 0u)) break;
+#pragma unroll
+                        for (int e = 0; e < NE; e++) s1[e] = go[e] ? P.sym_at(pq[e] - dd[e]) : 0u;
                     }
                 }
-                uint32_t rt;
-                const uint32_t ex = wave_excl_scan(c, rt);
-                if (act && r == 0u) a.hay_local[h] = (int32_t)(run_off + ex);     // a haystack starts here: the records in front of it
+                uint32_t ex[NE], rt = 0;
+#pragma unroll
+                for (int e = 0; e < NE; e++) {
+                    uint32_t t;
+                    ex[e] = rt + wave_excl_scan(cn[e], t);
+                    rt += t;
+                    if (act[e] && rr[e] == 0u) a.hay_local[hh[e]] = (int32_t)(run_off + ex[e]);   // a haystack starts here: the records in front of it
+                }
                 if (rt && !dead) {
                     if (g_used + rt > g_size) {                        // this round does not fit the current grant: open the next one
                         if (ng == PPM_MAX_GRANTS) dead = true;
@@ -862,11 +902,19 @@ __global__ void __launch_bounds__(ACX_PPM_BLOCK) k_ppm_stream(const acx_ppm_args
                     }
                     if (!dead && !(a.dbg & 2u)) {
                         uint2* out = a.scratch + g_base + g_used;
-                        if (c) {
-                            const uint32_t o = ex + c - 1, idx = E.idx;
-                            out[o] = make_uint2(idx, (uint32_t)va);
-                            if (c > 1) out[o - 1] = make_uint2(idx, (uint32_t)vb);
-                            if (c > 2) P.matches(E, 2u, 0xFFFFFFFFu, [&](uint32_t k, int32_t v) { out[o - k] = make_uint2(idx, (uint32_t)v); });
+#pragma unroll
+                        for (int e = 0; e < NE; e++) {
+                            const uint32_t c = cn[e];
+                            if (c) {
+                                const uint32_t o = ex[e] + c - 1, idx = ix[e];
+                                out[o] = make_uint2(idx, (uint32_t)va[e]);
+                                if (c > 1) out[o - 1] = make_uint2(idx, (uint32_t)vb[e]);
+                                if (c > 2) {
+                                    typename Ppm<SB, POW2, false>::Ent E;
+                                    E.p = pq[e] - HP; E.X = XX[e]; E.L = LL[e]; E.idx = idx; E.c0 = c0[e]; E.c1 = c1[e];
+                                    P.matches(E, 2u, 0xFFFFFFFFu, [&](uint32_t k, int32_t v) { out[o - k] = make_uint2(idx, (uint32_t)v); });
+                                }
+                            }
                         }
                     }
                     if (!dead) g_used += rt;
@@ -874,6 +922,11 @@ __global__ void __launch_bounds__(ACX_PPM_BLOCK) k_ppm_stream(const acx_ppm_args
                 run_off += rt;
                 qhead += nr; if (qhead >= PPM_QCAP) qhead -= PPM_QCAP;
                 qcount -= nr;
+            };
+            while (qcount >= 128u) do_round(std::integral_constant<int, 2>{});
+            if (last_sub) {
+                if (qcount > 64u) do_round(std::integral_constant<int, 2>{});
+                else if (qcount > 0u) do_round(std::integral_constant<int, 1>{});
             }
         }
 
