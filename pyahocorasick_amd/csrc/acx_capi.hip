@@ -550,16 +550,18 @@ static int ppm_size_pool(acx_result* r, size_t records) {
 }
 
 // which kernels an ACX_SCAN_ALL scan takes: 0 the serial walks, 1 k_ppm_scan (general position-parallel), 2 k_ppm_stream
-static uint32_t ppm_halo_pos(const acx_ppm_header& ph) {
-    const uint32_t unit = 32u / ph.sym_bits < 4u ? 4u : 32u / ph.sym_bits;
-    return ph.longest > 1 ? ((ph.longest - 1 + unit - 1) / unit) * unit : unit;
+static uint32_t ppm_halo_pos(const acx_ppm_header& ph) {         // whole words of the symbol and "no key" bitmaps
+    return ph.longest > 1 ? ((ph.longest - 1 + 31u) / 32u) * 32u : 32u;
 }
-// sub-steps of 256 positions per tile that fit LDS for this image (0: none): the kernel is instantiated for 4 and,
-// on fixed-stride batches of 2- and 4-bit symbols, 2
+// sub-steps of 256 positions per tile: the most that fit LDS for this image (0: none).  Larger tiles fill the rounds
+// better (a tile's candidates are worked off before the next one is staged).
 static uint32_t ppm_stream_nsub(const acx_ppm_header& ph, uint32_t halo_pos, bool offs) {
     const uint32_t gw = ph.g_global ? 0u : ph.g_words;
-    if (acx_ppm_stream_layout(gw, ph.sym_bits, halo_pos, 4).total_words * 4 <= ACX_PPM_LDS_BYTES) return 4;
-    if (!offs && ph.sym_bits != 8 && acx_ppm_stream_layout(gw, ph.sym_bits, halo_pos, 2).total_words * 4 <= ACX_PPM_LDS_BYTES) return 2;
+    static const uint32_t forced = [] { const char* v = getenv("ACX_PPM_NSUB"); const int x = v ? atoi(v) : 0; return (x == 2 || x == 4 || x == 8) ? (uint32_t)x : 0u; }();   // tuning hook
+    for (uint32_t nsub = 8; nsub >= 2; nsub >>= 1) {
+        if (forced && nsub > forced) continue;
+        if (acx_ppm_stream_layout(gw, ph.sym_bits, halo_pos, nsub, offs).total_words * 4 <= ACX_PPM_LDS_BYTES) return nsub;
+    }
     return 0;
 }
 
@@ -645,13 +647,13 @@ static int scan_ppm(acx_image_t* img, const acx_scan_params* p, acx_result* r, h
     if (pa.fast) {
         pa.nsub = ppm_stream_nsub(ph, pa.halo_pos, chunked);
         pa.g_global = ph.g_global;
-        pa.lds = acx_ppm_stream_layout(ph.g_global ? 0u : ph.g_words, ph.sym_bits, pa.halo_pos, pa.nsub);
+        pa.lds = acx_ppm_stream_layout(ph.g_global ? 0u : ph.g_words, ph.sym_bits, pa.halo_pos, pa.nsub, chunked);
     }
     if (pa.fast) {
         const int64_t tpos = (int64_t)pa.nsub * 256;
         const int64_t total = chunked ? p->hay_capacity : p->n_hay * p->stride;
         stream_tiles = (total + tpos - 1) / tpos;
-        pa.m24 = (!chunked && p->stride < 1024) ? (uint32_t)(((1u << 24) + (uint32_t)p->stride - 1) / (uint32_t)p->stride) : 0u;
+        pa.m24 = (!chunked && p->stride < 2048) ? (uint32_t)(((1u << 23) + (uint32_t)p->stride - 1) / (uint32_t)p->stride) : 0u;
         const int64_t blocks = acx_ppm_grid_blocks(pa.lds, stream_tiles);
         const int64_t n_waves = blocks * ACX_PPM_WAVES;
         if ((rc = r->wave_desc.ensure((size_t)n_waves * ACX_PPM_DESC_WORDS))) return rc;

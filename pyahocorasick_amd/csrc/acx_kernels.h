@@ -114,7 +114,7 @@ struct acx_ppm_args {
     uint32_t fast;           // 1: k_ppm_stream (fixed stride >= 4, aligned buffer, bit-field codes, halo_pos <= 256)
     uint32_t dbg;            // tuning only (variant bits 25..27): 1 = no exact phase, 2 = no emit, 4 = no filter
     uint32_t nsub;           // k_ppm_stream: sub-steps of 256 positions per tile (1, 2 or 4)
-    uint32_t m24;            // k_ppm_stream: ceil(2^24 / stride) for strides below 1024, else 0
+    uint32_t m24;            // k_ppm_stream: ceil(2^23 / stride) for strides below 2048 (a 24-bit multiply divides), else 0
     const int64_t* off; const int64_t* first_h;    // k_ppm_stream on an offsets batch: offsets, first haystack at or after every tile
     uint32_t g_global;       // the filter bitmap is read from global memory (not copied to LDS)
     const uint8_t* deep_base; uint32_t row_off, single_off;   // k_ppm_stream: rows and singles as 32-bit offsets from one base

@@ -509,16 +509,15 @@ __global__ void __launch_bounds__(ACX_PPM_BLOCK) k_ppm_stream(const acx_ppm_args
     uint32_t* const sym = wbase;                                       // [0,1] pad, halo words, tile words, pad
     P.s_sym = wbase + 1;                                               // (Ppm counts one pad word)
     const uint32_t HP = a.halo_pos, HW = HP / SPW;                     // halo: positions (multiple of SPW and 4), words
-    const uint32_t NDW = (HP + TPOS) / 4;                              // staged dwords
-    uint8_t* const oth = (uint8_t*)(wbase + a.lds.sym_words);          // per staged dword: which bytes are "other"
-    uint8_t* const odist = oth + ((NDW + 3u) & ~3u);                   // per staged dword: dwords back to the last one that has any (255: none)
+    uint32_t* const obits = wbase + a.lds.sym_words;                   // one bit per staged position: a byte that occurs in no key
+    uint32_t* const obits_tile = obits + HP / 32;                      // (the halo is a whole number of words)
     uint16_t* const queue = (uint16_t*)(wbase + a.lds.sym_words + a.lds.oth_words);
     uint32_t* const sbits = wbase + a.lds.sym_words + a.lds.oth_words + a.lds.queue_words;   // OFFS: haystack starts of the tile, one bit per position
     uint16_t* const slast = (uint16_t*)(sbits + BW);                   //       last start (+1) at or before the end of each bitmap word
     uint16_t* const scnt = slast + BW;                                 //       starts before each bitmap word
     uint8_t* const sym_tile_bytes = (uint8_t*)(sym + 2 + HW);
     for (uint32_t i = lane; i < 2 + HW + TW + 1; i += 64) sym[i] = 0;
-    for (uint32_t i = lane; i < NDW; i += 64) { oth[i] = 0; odist[i] = 255; }
+    for (uint32_t i = lane; i < (HP + TPOS) / 32 + 1; i += 64) obits[i] = 0;
     P.T.q0 = HP; P.T.halo = 0; P.T.idx_first = 0; P.T.ndw = 0; P.T.abase = nullptr; P.T.e0 = 0; P.T.npos = 0; P.has_other = 0;
 
     // the batch: H bytes, cut into tiles; a wave takes a contiguous run of them
@@ -540,8 +539,8 @@ __global__ void __launch_bounds__(ACX_PPM_BLOCK) k_ppm_stream(const acx_ppm_args
     // x = offset-in-haystack of the tile's first position + a position of the tile: haystacks crossed, new offset
     auto divmod = [&](uint32_t x, uint32_t& r) -> uint32_t {
         uint32_t q;
-        if (a.m24) { q = (uint32_t)__umul24(x, a.m24) >> 24; r = x - (uint32_t)__umul24(q, stride); }   // stride < 1024: exact for x < stride + 1024
-        else { q = x >= stride ? 1u : 0u; r = x - (q ? stride : 0u); }   // stride >= 1024: one haystack start per tile at most
+        if (a.m24) { q = (uint32_t)__umul24(x, a.m24) >> 23; r = x - (uint32_t)__umul24(q, stride); }   // stride < 2048: exact for x < stride + 2048
+        else { q = x >= stride ? 1u : 0u; r = x - (q ? stride : 0u); }   // stride >= 2048: one haystack start per tile at most
         return q;                                                      // (24-bit multiplies: full rate; the cast: a logical shift)
     };
     auto load_dw = [&](uint32_t b) -> uint32_t {                      // the dword at byte b of the buffer (b is a multiple of 4)
@@ -568,16 +567,13 @@ __global__ void __launch_bounds__(ACX_PPM_BLOCK) k_ppm_stream(const acx_ppm_args
     auto put_sym = [&](uint8_t* base, uint32_t i, uint32_t packed) {
         if (SB == 2) base[i] = (uint8_t)packed; else if (SB == 4) ((uint16_t*)base)[i] = (uint16_t)packed; else ((uint32_t*)base)[i] = packed;
     };
-    // symbols available going back from staged position q when "other" bytes are around
+    // symbols available going back from staged position q when bytes of no key are around: the distance to the last
+    // one at or before q (the halo is as long as the longest key, so running out of bitmap means "far enough")
     auto other_limit = [&](uint32_t q) -> uint32_t {
-        const uint32_t dw = q >> 2;
-        const uint32_t nb = oth[dw] & ((2u << (q & 3u)) - 1u);
-        uint32_t last = 0;
-        if (nb) last = 4 * dw + (31 - __clz(nb)) + 1;
-        else if (dw) {
-            const uint32_t dd = odist[dw - 1];
-            if (dd != 255u) { const uint32_t d2 = dw - 1 - dd; last = 4 * d2 + (31 - __clz((uint32_t)oth[d2])) + 1; }
-        }
+        uint32_t w = q >> 5;
+        uint32_t m = obits[w] & (0xFFFFFFFFu >> (31u - (q & 31u)));
+        while (m == 0u && w > 0u) m = obits[--w];
+        const uint32_t last = m ? 32u * w + (31u - (uint32_t)__clz(m)) + 1u : 0u;
         return q + 1 - last;
     };
     // code of the n newest symbols of a (masked) window
@@ -597,7 +593,7 @@ __global__ void __launch_bounds__(ACX_PPM_BLOCK) k_ppm_stream(const acx_ppm_args
         if (4u * lane < have) {
             packed = convert(*(const uint32_t*)(a.hay + (e0 - have) + 4u * lane), nib);
             put_sym(sym_tile_bytes - (size_t)(have / 4) * (SB / 2), lane, packed);      // the halo ends where the tile begins
-            oth[(HP - have) / 4 + lane] = (uint8_t)nib;
+            if (nib) { const uint32_t qs = HP - have + 4u * lane; atomicOr(&obits[qs >> 5], nib << (qs & 31u)); }
         }
         if (__any(nib != 0)) any_prev = 1;
     }
@@ -606,11 +602,16 @@ __global__ void __launch_bounds__(ACX_PPM_BLOCK) k_ppm_stream(const acx_ppm_args
         uint32_t rr; h_tile = div_magic(e0, a.stride_magic, stride, rr); r_tile = rr;
         h_tile = (uint32_t)__builtin_amdgcn_readfirstlane((int)h_tile); r_tile = (uint32_t)__builtin_amdgcn_readfirstlane((int)r_tile);
     }
-    // a lane's PPL bytes of a tile (contiguous: one vector load)
+    // a lane's PPL bytes of a tile (contiguous: vector loads)
     auto load_lane = [&](uint32_t b, uint32_t (&w)[DPL]) {
         if ((int64_t)b + PPL <= a.hay_cap) {
-            if (DPL == 4) { const u32x4a v = *(const u32x4a*)(a.hay + b); w[0] = v.x; w[1] = v.y; w[2 % DPL] = v.z; w[3 % DPL] = v.w; }
-            else { const u32x2a v = *(const u32x2a*)(a.hay + b); w[0] = v.x; w[1] = v.y; }
+            if (DPL >= 4) {
+#pragma unroll
+                for (int j = 0; j < (int)DPL / 4; j++) {
+                    const u32x4a v = *(const u32x4a*)(a.hay + b + 16u * j);
+                    w[(4 * j) % DPL] = v.x; w[(4 * j + 1) % DPL] = v.y; w[(4 * j + 2) % DPL] = v.z; w[(4 * j + 3) % DPL] = v.w;
+                }
+            } else { const u32x2a v = *(const u32x2a*)(a.hay + b); w[0] = v.x; w[1 % DPL] = v.y; }
         } else {
 #pragma unroll
             for (int j = 0; j < (int)DPL; j++) w[j] = load_dw(b + 4u * j);
@@ -669,7 +670,7 @@ __global__ void __launch_bounds__(ACX_PPM_BLOCK) k_ppm_stream(const acx_ppm_args
                 const uint32_t before = wave_excl_scan((uint32_t)__popc(wv), tot);
                 uint32_t last = wv ? 32u * lane + (31 - __clz(wv)) + 1 : 0u;
 #pragma unroll
-                for (int d = 1; d < 32; d <<= 1) { const uint32_t t = __shfl_up(last, d, 64); if (lane >= d && t > last) last = t; }
+                for (int d = 1; d < 64; d <<= 1) { const uint32_t t = __shfl_up(last, d, 64); if (lane >= d && t > last) last = t; }
                 if ((uint32_t)lane < BW) { slast[lane] = (uint16_t)last; scnt[lane] = (uint16_t)before; }
             }
             hbase = (uint32_t)(fh - 1);                                 // (fh = 0: wraps; every position of that tile has rank >= 1)
@@ -677,21 +678,9 @@ __global__ void __launch_bounds__(ACX_PPM_BLOCK) k_ppm_stream(const acx_ppm_args
         }
         const uint32_t any_cur = a.has_other && __any(anyo != 0) ? 1u : 0u;
         const uint32_t use_other = any_cur | any_prev;
-        if (use_other) {
-#pragma unroll
-            for (int j = 0; j < (int)DPL; j++) oth[HP / 4 + DPL * lane + j] = (uint8_t)nibs[j];
-            wave_sync();
-            uint32_t carry = 0;                                        // index + 1 of the last dword that holds an "other" byte
-            for (uint32_t i0 = 0; i0 < NDW; i0 += 64) {
-                const uint32_t i = i0 + lane;
-                uint32_t last = (i < NDW && oth[i]) ? i + 1 : 0u;
-#pragma unroll
-                for (int d = 1; d < 64; d <<= 1) { const uint32_t t = __shfl_up(last, d, 64); if (lane >= d && t > last) last = t; }
-                if (carry > last) last = carry;
-                if (i < NDW) { const uint32_t dd = last ? i + 1 - last : 255u; odist[i] = (uint8_t)(dd < 255u ? dd : 255u); }
-                carry = __shfl(last, 63, 64);
-            }
-        }
+        if (PPL == 32) obits_tile[lane] = anyo;
+        else if (PPL == 16) ((uint16_t*)obits_tile)[lane] = (uint16_t)anyo;
+        else ((uint8_t*)obits_tile)[lane] = (uint8_t)anyo;
         wave_sync();
 
         // where position p (a multiple of 4 for the filter) sits: its offset in its haystack, and — OFFS — how many
@@ -715,31 +704,34 @@ __global__ void __launch_bounds__(ACX_PPM_BLOCK) k_ppm_stream(const acx_ppm_args
         if (OWN >= 32) W[0] = ((const uint32_t*)sym_tile_bytes)[(int)(OW * lane) - 1];
         else W[0] = ((uint32_t)((const uint16_t*)sym_tile_bytes)[lane - 1] << 16) | ((const uint16_t*)sym_tile_bytes)[lane - 2];
         uint32_t pw = 0;                                               // positions that pass
-        {
-            uint32_t gw[PPL], cf[PPL];
 #pragma unroll
-            for (int i = 0; i < (int)PPL; i++) {
-                const uint32_t e = SB * (i + 1), k = e >> 5, sh = e & 31u;
+        for (int i0 = 0; i0 < (int)PPL; i0 += 16) {                    // (16 probes in flight at a time: registers)
+            constexpr int NB = PPL < 16 ? (int)PPL : 16;
+            uint32_t gw[NB], cf[NB];
+#pragma unroll
+            for (int i = 0; i < NB; i++) {
+                const uint32_t e = SB * (i0 + i + 1), k = e >> 5, sh = e & 31u;
                 const uint32_t X = sh ? __builtin_amdgcn_alignbit(W[k + 1 <= OW ? k + 1 : OW], W[k], sh) : W[k];
                 cf[i] = code_n(X, a.F);
                 gw[i] = P.s_g[cf[i] >> 5];
             }
 #pragma unroll
-            for (int i = 0; i < (int)PPL; i++) pw |= __builtin_amdgcn_ubfe(gw[i], cf[i], 1u) << i;
+            for (int i = 0; i < NB; i++) pw |= __builtin_amdgcn_ubfe(gw[i], cf[i], 1u) << (i0 + i);
         }
         // haystack starts among the lane's positions
         uint32_t sw = 0;
-        if (OFFS) sw = PPL == 16 ? ((const uint16_t*)sbits)[lane] : ((const uint8_t*)sbits)[lane];
+        if (OFFS) sw = PPL == 32 ? sbits[lane] : (PPL == 16 ? ((const uint16_t*)sbits)[lane] : ((const uint8_t*)sbits)[lane]);
         else {
             uint32_t r;
             (void)divmod(r_tile + PPL * (uint32_t)lane, r);
-            const uint32_t o = r ? stride - r : 0u;                        // (stride >= 8: two starts in 16 positions at most)
-            sw = (o < PPL ? 1u << o : 0u) | (o + stride < PPL ? 1u << ((o + stride) & 31u) : 0u);
+            uint32_t o = r ? stride - r : 0u;                           // (stride >= 8: PPL / 8 starts at most)
+#pragma unroll
+            for (int k = 0; k < (int)PPL / 8; k++) { sw |= o < PPL ? 1u << (o & 31u) : 0u; o += stride; }
         }
         {
             const uint32_t lp = PPL * (uint32_t)lane;
             const uint32_t nv = npos > lp ? (npos - lp < PPL ? npos - lp : PPL) : 0u;
-            const uint32_t vm = (1u << nv) - 1u;
+            const uint32_t vm = nv >= 32u ? 0xFFFFFFFFu : (1u << nv) - 1u;
             pw &= vm & ~anyo;                                          // (a byte of no key ends no key)
             sw &= vm;
         }
@@ -935,10 +927,10 @@ __global__ void __launch_bounds__(ACX_PPM_BLOCK) k_ppm_stream(const acx_ppm_args
         {
             uint32_t t = 0, tn = 0;
             if ((uint32_t)lane < HW) t = sym[2 + TW + lane];
-            if (use_other && (uint32_t)lane < HP / 4) tn = oth[TPOS / 4 + lane];
+            if ((uint32_t)lane < HP / 32) tn = obits[TPOS / 32 + lane];
             wave_sync();
             if ((uint32_t)lane < HW) sym[2 + lane] = t;
-            if (use_other && (uint32_t)lane < HP / 4) oth[lane] = (uint8_t)tn;
+            if ((uint32_t)lane < HP / 32) obits[lane] = tn;
         }
         any_prev = any_cur;
         e0 += TPOS;
@@ -1078,8 +1070,12 @@ hipError_t acx_launch_ppm_scan(const acx_ppm_args& a, int64_t n_items_bound, hip
 #define PPM_S(SB, N, GG) do { \
             if (p2) { if (offs) return launch(k_ppm_stream<SB, N, true, true, GG>); return launch(k_ppm_stream<SB, N, true, false, GG>); } \
             if (offs) return launch(k_ppm_stream<SB, N, false, true, GG>); return launch(k_ppm_stream<SB, N, false, false, GG>); } while (0)
-        if (a.sym_bits == 8) { if (a.g_global) PPM_S(8, 4, true); PPM_S(8, 4, false); }
-        if (a.sym_bits == 4) { if (a.nsub == 4) PPM_S(4, 4, false); PPM_S(4, 2, false); }
+        if (a.sym_bits == 8) {
+            if (a.g_global) { if (a.nsub == 8) PPM_S(8, 8, true); if (a.nsub == 4) PPM_S(8, 4, true); PPM_S(8, 2, true); }
+            if (a.nsub == 8) PPM_S(8, 8, false); if (a.nsub == 4) PPM_S(8, 4, false); PPM_S(8, 2, false);
+        }
+        if (a.sym_bits == 4) { if (a.nsub == 8) PPM_S(4, 8, false); if (a.nsub == 4) PPM_S(4, 4, false); PPM_S(4, 2, false); }
+        if (a.nsub == 8) PPM_S(2, 8, false);
         if (a.nsub == 4) PPM_S(2, 4, false);
         PPM_S(2, 2, false);
 #undef PPM_S

@@ -45,15 +45,16 @@ static inline acx_ppm_lds acx_ppm_lds_layout(uint32_t g_words, uint32_t sym_bits
 }
 
 
-// k_ppm_stream: tiles of nsub x 256 positions, halo of halo_pos positions carried in LDS, a ring queue
-static inline acx_ppm_lds acx_ppm_stream_layout(uint32_t g_words, uint32_t sym_bits, uint32_t halo_pos, uint32_t nsub) {
+// k_ppm_stream: tiles of nsub x 256 positions, halo of halo_pos positions (a multiple of 32) carried in LDS, a ring
+// queue.  oth: one bit per staged position (a byte of no key); cnt: the start tables of offsets batches.
+static inline acx_ppm_lds acx_ppm_stream_layout(uint32_t g_words, uint32_t sym_bits, uint32_t halo_pos, uint32_t nsub, int offs) {
     acx_ppm_lds L;
     const uint32_t tpos = nsub * 256u, spw = 32u / sym_bits;
     L.dwords = (halo_pos + tpos) / 4;
     L.sym_words = (2 + halo_pos / spw + tpos / spw + 1 + 3u) & ~3u;
-    L.oth_words = (2 * ((L.dwords + 3u) & ~3u)) / 4;                     // nibble byte + distance byte per staged dword
+    L.oth_words = ((halo_pos + tpos) / 32 + 1 + 3u) & ~3u;
     L.queue_words = 384 / 2 + 2;                                       // PPM_QCAP uint16 entries + a spare slot
-    L.cnt32 = 0; L.cnt_words = (tpos / 32) * 2 + 2;                     // offsets batches: start bitmap, last-start and count tables
+    L.cnt32 = 0; L.cnt_words = offs ? (tpos / 32) * 2 + 2 : 0;          // offsets batches: start bitmap, last-start and count tables
     L.wave_words = (L.sym_words + L.oth_words + L.queue_words + L.cnt_words + 3u) & ~3u;
     L.g_off = 0;
     L.map_off = (g_words + 3u) & ~3u;
