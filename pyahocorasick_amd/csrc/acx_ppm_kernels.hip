@@ -915,9 +915,11 @@ __global__ void __launch_bounds__(ACX_PPM_BLOCK) k_ppm_stream(const acx_ppm_args
                 qhead += nr; if (qhead >= PPM_QCAP) qhead -= PPM_QCAP;
                 qcount -= nr;
             };
-            while (qcount >= 128u) do_round(std::integral_constant<int, 2>{});
+            while (qcount >= 192u) do_round(std::integral_constant<int, 3>{});
+            if (!last_sub && qcount > PPM_QCAP - 256u) do_round(std::integral_constant<int, 2>{});   // room for the next sub-step's entries
             if (last_sub) {
-                if (qcount > 64u) do_round(std::integral_constant<int, 2>{});
+                if (qcount > 128u) do_round(std::integral_constant<int, 3>{});
+                else if (qcount > 64u) do_round(std::integral_constant<int, 2>{});
                 else if (qcount > 0u) do_round(std::integral_constant<int, 1>{});
             }
         }
