@@ -536,7 +536,7 @@ static int ppm_enqueue(acx_result* r, acx_image* img, const acx_chunk_args* ca, 
 // size the record pool: `records` of capacity plus one grant of slack per wave, cut into n_pools
 static int ppm_size_pool(acx_result* r, size_t records) {
     acx_ppm_args& pa = r->pend_pa;
-    const int64_t blocks = acx_ppm_grid_blocks(pa.lds, r->pend_items);
+    const int64_t blocks = acx_ppm_grid_blocks(pa.lds, r->pend_items, pa.reserve_cus);
     pa.n_pools = (uint32_t)(blocks < 8 ? blocks : 8);
     const size_t slack = (size_t)blocks * ACX_PPM_WAVES * 1024u;
     size_t want = records + records / 2 + slack + 1024;
@@ -558,7 +558,9 @@ static uint32_t ppm_halo_pos(const acx_ppm_header& ph) {         // whole words 
 static uint32_t ppm_stream_nsub(const acx_ppm_header& ph, uint32_t halo_pos, bool offs) {
     const uint32_t gw = ph.g_global ? 0u : ph.g_words;
     static const uint32_t forced = [] { const char* v = getenv("ACX_PPM_NSUB"); const int x = v ? atoi(v) : 0; return (x == 2 || x == 4 || x == 8) ? (uint32_t)x : 0u; }();   // tuning hook
-    for (uint32_t nsub = 8; nsub >= 2; nsub >>= 1) {
+    // (8-bit symbols with the filter in LDS — text-like alphabets: 2048-position tiles measured slower than 1024, 203 vs 218 GB/s)
+    const uint32_t top = (ph.sym_bits == 8 && !ph.g_global) ? 4u : 8u;
+    for (uint32_t nsub = top; nsub >= 2; nsub >>= 1) {
         if (forced && nsub > forced) continue;
         if (acx_ppm_stream_layout(gw, ph.sym_bits, halo_pos, nsub, offs).total_words * 4 <= ACX_PPM_LDS_BYTES) return nsub;
     }
@@ -654,7 +656,13 @@ static int scan_ppm(acx_image_t* img, const acx_scan_params* p, acx_result* r, h
         const int64_t total = chunked ? p->hay_capacity : p->n_hay * p->stride;
         stream_tiles = (total + tpos - 1) / tpos;
         pa.m24 = (!chunked && p->stride < 2048) ? (uint32_t)(((1u << 23) + (uint32_t)p->stride - 1) / (uint32_t)p->stride) : 0u;
-        const int64_t blocks = acx_ppm_grid_blocks(pa.lds, stream_tiles);
+        // An asynchronous scan finishes on a side stream.  Leaving CUs free for that copy while the NEXT batch is
+        // scanned did not pay (config 2, 4 / 8 / 16 CUs: 364 / 363 / 355 GB/s against 375 with none): hook only.
+        if ((p->flags & ACX_SCAN_ASYNC) && !getenv("ACX_NO_SIDE_STREAM")) {
+            static const int env_res = [] { const char* v = getenv("ACX_PPM_RESERVE_CUS"); return v ? atoi(v) : 0; }();
+            pa.reserve_cus = env_res > 0 ? (uint32_t)env_res : 0u;
+        }
+        const int64_t blocks = acx_ppm_grid_blocks(pa.lds, stream_tiles, pa.reserve_cus);
         const int64_t n_waves = blocks * ACX_PPM_WAVES;
         if ((rc = r->wave_desc.ensure((size_t)n_waves * ACX_PPM_DESC_WORDS))) return rc;
         if ((rc = r->ck_match_off.ensure((size_t)n_waves + 1))) return rc;

@@ -126,6 +126,7 @@ struct acx_ppm_args {
     uint2*    scratch;       // record pool: 8 sub-pools of pool_records each, one bump pointer per sub-pool
     unsigned long long* heads;
     uint32_t  n_pools;       // min(8, blocks): block b bumps heads[b % n_pools]
+    uint32_t  reserve_cus;   // k_ppm_stream: CUs the grid leaves free (asynchronous scans: the gather of the previous batch runs there)
     uint64_t  pool_records;
     int32_t*  overflow;      // set when a sub-pool ran out: the host grows the pool and scans again
     int32_t*  hay_local;     // fixed-stride batches: tile-local record offset of every haystack start
@@ -150,7 +151,7 @@ hipError_t acx_launch_ppm_first_h(const int64_t* off, int64_t n_hay, int64_t n_t
 hipError_t acx_launch_ppm_gather(const uint32_t* wave_desc, int64_t n_waves, int64_t* wave_off, const acx_ppm_gather_args& c, hipStream_t s);
 hipError_t acx_launch_ppm_scan(const acx_ppm_args& a, int64_t n_items_bound, hipStream_t s);
 hipError_t acx_launch_ppm_compact(const acx_ppm_compact_args& c, int64_t n_items_bound, hipStream_t s);
-int64_t acx_ppm_grid_blocks(const acx_ppm_lds& lds, int64_t n_items_bound);   // blocks of a k_ppm_scan launch
+int64_t acx_ppm_grid_blocks(const acx_ppm_lds& lds, int64_t n_items_bound, uint32_t reserve_cus = 0);   // blocks of a k_ppm_scan launch
 // final_state of an ACX_SCAN_ALL scan when the matches came from the position-parallel kernels: the
 // state after a haystack = the state after its last longest_word bytes walked from the root
 hipError_t acx_launch_tail_state(const acx_walk_args& a, int32_t longest, hipStream_t s);

@@ -1046,11 +1046,13 @@ int num_cus() {
 
 int acx_num_cus() { return num_cus(); }
 
-int64_t acx_ppm_grid_blocks(const acx_ppm_lds& lds, int64_t n_items_bound) {
+int64_t acx_ppm_grid_blocks(const acx_ppm_lds& lds, int64_t n_items_bound, uint32_t reserve_cus) {
     const size_t lds_bytes = (size_t)lds.total_words * 4;
     const int bpc = lds_bytes * 2 <= ACX_PPM_LDS_BYTES ? 2 : 1;       // 1024-thread blocks: at most 2 per CU
     int64_t blocks = (n_items_bound + ACX_PPM_WAVES - 1) / ACX_PPM_WAVES;
-    const int64_t cap = (int64_t)num_cus() * bpc;
+    int64_t cus = num_cus();
+    if ((int64_t)reserve_cus < cus) cus -= reserve_cus;
+    const int64_t cap = cus * bpc;
     if (blocks > cap) blocks = cap;
     return blocks < 1 ? 1 : blocks;
 }
@@ -1059,7 +1061,7 @@ hipError_t acx_launch_ppm_scan(const acx_ppm_args& a, int64_t n_items_bound, hip
     if (n_items_bound <= 0) return hipSuccess;
     const size_t lds_bytes = (size_t)a.lds.total_words * 4;
     if (lds_bytes > ACX_PPM_LDS_BYTES || a.n_pools == 0) return hipErrorInvalidValue;
-    const int64_t blocks = acx_ppm_grid_blocks(a.lds, n_items_bound);
+    const int64_t blocks = acx_ppm_grid_blocks(a.lds, n_items_bound, a.reserve_cus);
     const bool chunk = a.ck != nullptr;
     auto launch = [&](auto kernel) -> hipError_t {
         hipError_t e = hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
