@@ -21,7 +21,38 @@
 #include <cstdio>
 #include <ctime>
 #include <new>
+#include <atomic>
+#include <thread>
 #include <vector>
+
+// Host loops over tens of millions of trie nodes are bound by cache misses (the arena is in insertion order, the
+// passes run in BFS order): they are cut into contiguous ranges for a handful of threads.  f(a, b) gets disjoint
+// sub-ranges of [lo, hi); small ranges run inline.  ACX_HOST_THREADS overrides the thread count (1: serial).
+static unsigned host_threads() {
+    static const unsigned n = [] {
+        const char* e = getenv("ACX_HOST_THREADS");
+        unsigned v = e ? (unsigned)atoi(e) : std::thread::hardware_concurrency();
+        if (v < 1) v = 1;
+        return v > 32 ? 32u : v;
+    }();
+    return n;
+}
+template <typename F>
+static void parallel_range(size_t lo, size_t hi, F&& f) {
+    const size_t n = hi > lo ? hi - lo : 0, grain = 16384;
+    size_t T = host_threads();
+    if (T > n / grain) T = n / grain;
+    if (T <= 1) { if (n) f(lo, hi); return; }
+    const size_t step = (n + T - 1) / T;
+    std::vector<std::thread> th;
+    th.reserve(T - 1);
+    for (size_t k = 1; k < T; k++) {
+        const size_t a = lo + k * step, b = a + step < hi ? a + step : hi;
+        if (a < b) th.emplace_back([&f, a, b] { f(a, b); });
+    }
+    f(lo, lo + step < hi ? lo + step : hi);
+    for (auto& x : th) x.join();
+}
 
 extern "C" {
 
@@ -40,6 +71,7 @@ void acx_trie_clear(acx_trie_t* t) {
     // automaton_clear, src/Automaton.c:405-416
     t->nodes.clear(); t->nodes.shrink_to_fit();
     t->bfs.clear(); t->bfs.shrink_to_fit();
+    t->level_first.clear();
     for (auto& c : t->root_child) c = -1;
     t->kind = ACX_KIND_EMPTY;
     t->count = 0; t->longest_word = 0; t->live_nodes = 0;
@@ -176,26 +208,50 @@ int acx_trie_make_automaton(acx_trie_t* t, int* changed) {
             return -1;
         };
 
+        // Level-synchronous BFS (src/Automaton.c:582-637 visits the same nodes in the same order with one queue).
+        // Per level: count the children of every node (parallel), prefix sum (the order of the next level), then
+        // place the children and compute their failure links (parallel: a link only reads links of shallower
+        // levels, which are complete).
         std::vector<int32_t>& q = t->bfs;
-        q.clear();
+        std::vector<int64_t>& lvl = t->level_first;
+        q.clear(); lvl.clear();
         q.reserve((size_t)t->live_nodes);
         q.push_back(0);
+        lvl.push_back(0); lvl.push_back(1);
         t->nodes[0].fail = -1;                          // root->fail stays NULL (src/trienode.c:19)
-        for (int32_t c = t->nodes[0].first_child; c >= 0; c = t->nodes[c].next_sibling) {
-            t->nodes[c].fail = 0;                       // src/Automaton.c:582-596
-            q.push_back(c);
+        std::vector<uint32_t> cnt;
+        for (size_t d = 0; lvl[d] < lvl[d + 1]; d++) {
+            const size_t lo = (size_t)lvl[d], hi = (size_t)lvl[d + 1];
+            cnt.assign(hi - lo + 1, 0);
+            parallel_range(lo, hi, [&](size_t a, size_t b) {
+                for (size_t i = a; i < b; i++) {
+                    uint32_t k = 0;
+                    for (int32_t c = t->nodes[q[i]].first_child; c >= 0; c = t->nodes[c].next_sibling) k++;
+                    cnt[i - lo] = k;
+                }
+            });
+            size_t total = 0;
+            for (size_t i = 0; i < hi - lo; i++) { const uint32_t k = cnt[i]; cnt[i] = (uint32_t)total; total += k; }
+            if (total >= ((size_t)1 << 31)) return acx_fail(ACX_E_UNSUPPORTED, "acx_trie_make_automaton: too many nodes");
+            q.resize(hi + total);
+            parallel_range(lo, hi, [&](size_t a, size_t b) {
+                for (size_t i = a; i < b; i++) {
+                    const int32_t node = q[i];
+                    size_t o = hi + cnt[i - lo];
+                    for (int32_t c = t->nodes[node].first_child; c >= 0; c = t->nodes[c].next_sibling) {
+                        q[o++] = c;
+                        if (node == 0) { t->nodes[c].fail = 0; continue; }     // src/Automaton.c:582-596
+                        const uint8_t letter = t->nodes[c].letter;
+                        int32_t state = t->nodes[node].fail;
+                        while (state != 0 && child_fast(state, letter) < 0) state = t->nodes[state].fail;
+                        const int32_t f = child_fast(state, letter);
+                        t->nodes[c].fail = f < 0 ? 0 : f;
+                    }
+                }
+            });
+            lvl.push_back((int64_t)(hi + total));
         }
-        for (size_t head = 1; head < q.size(); head++) {   // src/Automaton.c:599-637
-            int32_t node = q[head];
-            for (int32_t c = t->nodes[node].first_child; c >= 0; c = t->nodes[c].next_sibling) {
-                q.push_back(c);
-                uint8_t letter = t->nodes[c].letter;
-                int32_t state = t->nodes[node].fail;
-                while (state != 0 && child_fast(state, letter) < 0) state = t->nodes[state].fail;
-                int32_t f = child_fast(state, letter);
-                t->nodes[c].fail = f < 0 ? 0 : f;
-            }
-        }
+        lvl.pop_back();                                 // (the last level is empty: lvl[d] .. lvl[d + 1] for d < size - 1)
     } catch (const std::bad_alloc&) {
         return acx_fail(ACX_E_NOMEM, "acx_trie_make_automaton: out of memory");
     }
@@ -293,12 +349,10 @@ int acx_flatten(const acx_trie_t* t, void** blob_out, size_t* nbytes_out) {
     try {
         order = t->bfs;
         adepth.assign(t->nodes.size(), 0);
-        int32_t max_depth = 0;
-        for (size_t i = 0; i < n; i++)
-            for (int32_t ch = t->nodes[order[i]].first_child; ch >= 0; ch = t->nodes[ch].next_sibling) {
-                adepth[ch] = adepth[order[i]] + 1;
-                if (adepth[ch] > max_depth) max_depth = adepth[ch];
-            }
+        const std::vector<int64_t>& lvl = t->level_first;           // level d = ids lvl[d] .. lvl[d + 1] (make_automaton)
+        const int32_t max_depth = (int32_t)lvl.size() - 2;
+        for (int32_t d = 0; d <= max_depth; d++)
+            parallel_range((size_t)lvl[d], (size_t)lvl[d + 1], [&](size_t a, size_t b) { for (size_t i = a; i < b; i++) adepth[order[i]] = d; });
         const size_t budget_words = (size_t)156 * 1024 / 4;          // of the CU's 160 KiB of LDS (+1 KiB class map)
         const char* no_itop = getenv("ACX_NO_ITOP");
         if (SB == ACX_STATE_BITS_NARROW && sigma <= 16 && !(no_itop && no_itop[0] == '1')) {
@@ -308,7 +362,7 @@ int acx_flatten(const acx_trie_t* t, void** blob_out, size_t* nbytes_out) {
             // the 2-bit depth field of ND4 (D - depth: 0, 1, 2; 3 = shallower, resolved by probing)
             // almost never escapes.
             std::vector<uint64_t> per_level((size_t)max_depth + 1, 0);
-            for (size_t i = 0; i < n; i++) per_level[adepth[order[i]]]++;
+            for (int32_t d = 0; d <= max_depth; d++) per_level[d] = (uint64_t)(lvl[d + 1] - lvl[d]);
             uint64_t full = 1;
             while ((int32_t)itop_complete < max_depth && full * sigma == per_level[itop_complete + 1]) { full *= sigma; itop_complete++; }
             uint32_t dense = itop_complete;
@@ -346,14 +400,25 @@ int acx_flatten(const acx_trie_t* t, void** blob_out, size_t* nbytes_out) {
     uint32_t max_cnt = 0;
     try {
         id.assign(t->nodes.size(), -1);
-        for (size_t i = 0; i < n; i++) id[order[i]] = (int32_t)i;
+        parallel_range(0, n, [&](size_t a, size_t b) { for (size_t i = a; i < b; i++) id[order[i]] = (int32_t)i; });
         out_cnt.assign(n, 0);
-        for (size_t i = 1; i < n; i++) {  // BFS order: fail(s) is shallower, hence already done
-            const Node& nd = t->nodes[order[i]];
-            uint32_t c = (nd.eow ? 1u : 0u) + out_cnt[id[nd.fail]];
-            out_cnt[i] = c;
-            n_out += c;
-            if (c > max_cnt) max_cnt = c;
+        const std::vector<int64_t>& lvl = t->level_first;
+        for (size_t d = 1; d + 1 < lvl.size(); d++) {     // level by level: fail(s) is shallower, hence already done
+            std::vector<uint64_t> part_sum(64, 0); std::vector<uint32_t> part_max(64, 0);
+            std::atomic<unsigned> slot{0};
+            parallel_range((size_t)lvl[d], (size_t)lvl[d + 1], [&](size_t a, size_t b) {
+                uint64_t sum = 0; uint32_t mx = 0;
+                for (size_t i = a; i < b; i++) {
+                    const Node& nd = t->nodes[order[i]];
+                    const uint32_t c = (nd.eow ? 1u : 0u) + out_cnt[id[nd.fail]];
+                    out_cnt[i] = c;
+                    sum += c;
+                    if (c > mx) mx = c;
+                }
+                const unsigned k = slot.fetch_add(1);
+                part_sum[k] = sum; part_max[k] = mx;
+            });
+            for (unsigned k = 0; k < slot.load(); k++) { n_out += part_sum[k]; if (part_max[k] > max_cnt) max_cnt = part_max[k]; }
         }
     } catch (const std::bad_alloc&) {
         return acx_fail(ACX_E_NOMEM, "acx_flatten: out of memory");
@@ -385,8 +450,7 @@ int acx_flatten(const acx_trie_t* t, void** blob_out, size_t* nbytes_out) {
     bool table_in_blob = table_entries * 4 < ((size_t)64 << 20);
     if (tbl_env && !strcmp(tbl_env, "host")) table_in_blob = true;
     if (tbl_env && !strcmp(tbl_env, "device")) table_in_blob = false;
-    uint32_t n_levels = 0;
-    for (size_t i = 0; i < n; i++) if ((uint32_t)adepth[order[i]] + 1 > n_levels) n_levels = (uint32_t)adepth[order[i]] + 1;
+    const uint32_t n_levels = (uint32_t)t->level_first.size() - 1;
     const size_t n_edges = n - 1;
 
     size_t off = ACX_BLOB_HEADER_BYTES;
@@ -437,28 +501,36 @@ int acx_flatten(const acx_trie_t* t, void** blob_out, size_t* nbytes_out) {
     std::vector<uint32_t> tflags;
     try { tflags.assign(n, 0); } catch (const std::bad_alloc&) { free(blob); return acx_fail(ACX_E_NOMEM, "acx_flatten: out of memory"); }
     {
-        uint32_t o = 0;
+        // offsets: a prefix sum of the counts (contiguous); then every level in parallel: a state's list is its own
+        // value followed by a copy of fail(s)'s list, which belongs to a shallower level and is complete
         fail[0] = -1;
-        for (size_t i = 0; i < n; i++) {
-            const Node& nd = t->nodes[order[i]];
-            out_off[i] = o;
-            if (i == 0) continue;
-            const int32_t f = id[nd.fail];
-            fail[i] = f;
-            nval[i] = nd.eow ? (int32_t)(uint32_t)(uint64_t)nd.value : 0;   // "ii" truncation, src/AutomatonSearchIter.c:180-184
-            nflags[i] = nd.eow ? 1 : 0;
-            if (nd.eow) out_val[o++] = nval[i];
-            const uint32_t fc = out_cnt[f];
-            if (fc) { memcpy(out_val + o, out_val + out_off[f], (size_t)fc * 4); o += fc; }
-            uint32_t fl = 0;
-            if (nd.eow) fl |= ACX_ENTRY_EOW(SB);
-            if (f != 0 && t->nodes[nd.fail].eow) fl |= ACX_ENTRY_FAILEOW(SB);   // src/AutomatonSearchIterLong.c:123
-            const uint32_t c = out_cnt[i];
-            fl |= (c >= ESC ? ESC : c) << ACX_ENTRY_CNT_SHIFT(SB);
-            tflags[i] = fl;
-            first_val[i] = c ? out_val[out_off[i]] : 0;
+        {
+            uint32_t o = 0;
+            for (size_t i = 0; i < n; i++) { out_off[i] = o; o += out_cnt[i]; }
+            out_off[n] = o;
         }
-        out_off[n] = o;
+        const std::vector<int64_t>& lvl = t->level_first;
+        for (size_t d = 1; d + 1 < lvl.size(); d++)
+            parallel_range((size_t)lvl[d], (size_t)lvl[d + 1], [&](size_t a, size_t b) {
+                for (size_t i = a; i < b; i++) {
+                    const Node& nd = t->nodes[order[i]];
+                    uint32_t o = out_off[i];
+                    const int32_t f = id[nd.fail];
+                    fail[i] = f;
+                    nval[i] = nd.eow ? (int32_t)(uint32_t)(uint64_t)nd.value : 0;   // "ii" truncation, src/AutomatonSearchIter.c:180-184
+                    nflags[i] = nd.eow ? 1 : 0;
+                    if (nd.eow) out_val[o++] = nval[i];
+                    const uint32_t fc = out_cnt[f];
+                    if (fc) memcpy(out_val + o, out_val + out_off[f], (size_t)fc * 4);
+                    uint32_t fl = 0;
+                    if (nd.eow) fl |= ACX_ENTRY_EOW(SB);
+                    if (f != 0 && t->nodes[nd.fail].eow) fl |= ACX_ENTRY_FAILEOW(SB);   // src/AutomatonSearchIterLong.c:123
+                    const uint32_t c = out_cnt[i];
+                    fl |= (c >= ESC ? ESC : c) << ACX_ENTRY_CNT_SHIFT(SB);
+                    tflags[i] = fl;
+                    first_val[i] = c ? out_val[out_off[i]] : 0;
+                }
+            });
     }
 
     lap("outputs");
@@ -472,19 +544,29 @@ int acx_flatten(const acx_trie_t* t, void** blob_out, size_t* nbytes_out) {
         uint32_t* edge_dst = (uint32_t*)(blob + h.off_edge_dst);
         uint32_t* tfl      = (uint32_t*)(blob + h.off_tflags);
         uint32_t* lvl      = (uint32_t*)(blob + h.off_lvl_first);
-        uint32_t ne = 0;
-        for (size_t i = 0; i < n; i++) {
-            edge_off[i] = ne;
-            tfl[i] = (uint32_t)i | tflags[i];          // (every reader ORs the id in anyway; the itop walk takes the entry whole)
-            for (int32_t ch = t->nodes[order[i]].first_child; ch >= 0; ch = t->nodes[ch].next_sibling) {
-                edge_cls[ne] = cls[t->nodes[ch].letter];
-                edge_dst[ne] = (uint32_t)id[ch];
-                ne++;
+        // children per state (parallel), prefix sum, then the edge lists (parallel)
+        parallel_range(0, n, [&](size_t a, size_t b) {
+            for (size_t i = a; i < b; i++) {
+                uint32_t k = 0;
+                for (int32_t ch = t->nodes[order[i]].first_child; ch >= 0; ch = t->nodes[ch].next_sibling) k++;
+                edge_off[i] = k;
+                tfl[i] = (uint32_t)i | tflags[i];      // (every reader ORs the id in anyway; the itop walk takes the entry whole)
             }
-        }
+        });
+        uint32_t ne = 0;
+        for (size_t i = 0; i < n; i++) { const uint32_t k = edge_off[i]; edge_off[i] = ne; ne += k; }
         edge_off[n] = ne;
-        for (uint32_t d = 0; d <= n_levels; d++) lvl[d] = (uint32_t)n;
-        for (size_t i = n; i-- > 0;) lvl[adepth[order[i]]] = (uint32_t)i;      // depths are non-decreasing in id order
+        parallel_range(0, n, [&](size_t a, size_t b) {
+            for (size_t i = a; i < b; i++) {
+                uint32_t e = edge_off[i];
+                for (int32_t ch = t->nodes[order[i]].first_child; ch >= 0; ch = t->nodes[ch].next_sibling) {
+                    edge_cls[e] = cls[t->nodes[ch].letter];
+                    edge_dst[e] = (uint32_t)id[ch];
+                    e++;
+                }
+            }
+        });
+        for (uint32_t d = 0; d <= n_levels; d++) lvl[d] = (uint32_t)t->level_first[d];      // (level_first[n_levels] = n)
     }
     if (table_in_blob) {
         for (size_t i = 0; i < n; i++) {

@@ -22,6 +22,7 @@ struct acx_trie {
     std::vector<Node> nodes;        // nodes[0] = root once kind != EMPTY
     int32_t root_child[256];        // direct index for the root's children (-1 = none)
     std::vector<int32_t> bfs;       // BFS order recorded by make_automaton (root first)
+    std::vector<int64_t> level_first;   // ... and where its levels start: level d = bfs[level_first[d] .. level_first[d + 1])
     int kind = ACX_KIND_EMPTY;
     int64_t count = 0;
     int64_t longest_word = 0;
