@@ -993,15 +993,24 @@ __global__ void __launch_bounds__(256) k_ppm_gather(const acx_ppm_gather_args c)
             for (uint32_t g = 0; g < ng; g++) {
                 const u32x2* src = (const u32x2*)(c.scratch + d[2 + g]);
                 const uint32_t n = d[18 + g];
-                for (uint32_t k = threadIdx.x; k < n; k += 256) __builtin_nontemporal_store(__builtin_nontemporal_load(src + k), dst + k);
+                // two records per access where the destination allows 16-byte stores (the source only needs dword alignment)
+                const uint32_t head = (n && (((uintptr_t)dst >> 3) & 1u)) ? 1u : 0u;
+                if (head && threadIdx.x == 0) __builtin_nontemporal_store(__builtin_nontemporal_load(src), dst);
+                const uint32_t pairs = (n - head) >> 1;
+                const u32x4a* src2 = (const u32x4a*)(src + head);
+                u32x4* dst2 = (u32x4*)(dst + head);
+                for (uint32_t k = threadIdx.x; k < pairs; k += 256) { const u32x4a v = src2[k]; u32x4 o; o.x = v.x; o.y = v.y; o.z = v.z; o.w = v.w; __builtin_nontemporal_store(o, dst2 + k); }
+                if (((n - head) & 1u) && threadIdx.x == 255) __builtin_nontemporal_store(__builtin_nontemporal_load(src + n - 1), dst + n - 1);
                 dst += n;
             }
         }
     }
     const int64_t n_threads = (int64_t)gridDim.x * 256;
+    const int tile_shift = 63 - __clzll((unsigned long long)c.tile_pos);       // (tiles are 512, 1024 or 2048 positions; the batch is below 4 GiB)
+    const uint32_t tpw = (uint32_t)c.tpw;
     for (int64_t h = (int64_t)blockIdx.x * 256 + threadIdx.x; h <= c.n_hay; h += n_threads) {
         if (h == c.n_hay) c.match_off[h] = total;
-        else c.match_off[h] = c.wave_off[((c.off ? c.off[h] : h * c.stride) / c.tile_pos) / c.tpw] + c.hay_local[h];
+        else c.match_off[h] = c.wave_off[(uint32_t)((c.off ? c.off[h] : h * c.stride) >> tile_shift) / tpw] + c.hay_local[h];
     }
 }
 
