@@ -879,17 +879,22 @@ __global__ void __launch_bounds__(ACX_BLOCK) k_hay_offsets(const int64_t* ck_fir
 // step of the next loop iteration — which is exactly the fail-resolved transition.
 // Every event is one final match: {end_index, state whose first output is the value}.
 // ---------------------------------------------------------------------------------
-template <int SB>
-__global__ void __launch_bounds__(ACX_BLOCK) k_walk_long(const acx_walk_args a) {
+// TOP: the rows of the first `n_top` states (BFS numbering: the shallowest) live in LDS.  The walk falls back to the
+// root after every match, so a large share of its steps stands on a shallow state; each of those is an LDS read
+// instead of an L2 request (the kernel is bound by the L2 request rate: one divergent 4-byte gather per byte).
+template <int SB, bool TOP>
+__global__ void __launch_bounds__(TOP ? 1024 : ACX_BLOCK) k_walk_long(const acx_walk_args a, uint32_t n_top) {
     __shared__ uint32_t s_cls4[256];
-    s_cls4[threadIdx.x] = (uint32_t)a.cls[threadIdx.x] * 4u;
+    extern __shared__ __attribute__((aligned(16))) uint32_t s_top[];
+    if (threadIdx.x < 256) s_cls4[threadIdx.x] = (uint32_t)a.cls[threadIdx.x] * 4u;
+    if (TOP) for (uint32_t i = threadIdx.x; i < n_top * (a.row_bytes >> 2); i += blockDim.x) s_top[i] = a.table[i];
     __syncthreads();
 
-    const int64_t n_threads = (int64_t)gridDim.x * ACX_BLOCK;
+    const int64_t n_threads = (int64_t)gridDim.x * blockDim.x;
     const uint8_t* table_bytes = (const uint8_t*)a.table;
     const uint8_t* limit = a.hay + a.hay_cap;
 
-    for (int64_t h = (int64_t)blockIdx.x * ACX_BLOCK + threadIdx.x; h < a.n_hay; h += n_threads) {
+    for (int64_t h = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; h < a.n_hay; h += n_threads) {
         int64_t b, e;
         if (a.off) { b = a.off[h]; e = a.off[h + 1]; }
         else       { b = h * a.stride; e = b + a.stride; }
@@ -920,7 +925,9 @@ __global__ void __launch_bounds__(ACX_BLOCK) k_walk_long(const acx_walk_args a) 
                 const int dw = (index >> 2) & 3;
                 const uint32_t wsel = dw == 0 ? blkw.x : (dw == 1 ? blkw.y : (dw == 2 ? blkw.z : blkw.w));
                 const uint32_t c4 = s_cls4[(wsel >> ((index & 3) * 8)) & 0xffu];
-                const uint32_t en = load_entry<SB>(table_bytes, state, a.row_bytes, c4);
+                uint32_t en;
+                if (TOP && state < n_top) en = *(const uint32_t*)((const uint8_t*)s_top + (state * a.row_bytes + c4));
+                else en = load_entry<SB>(table_bytes, state, a.row_bytes, c4);
                 const uint32_t next = en & ACX_ENTRY_STATE_MASK(SB);
                 if (!(en & ACX_ENTRY_EDGE(SB)) && have_last) {
                     emit = true;
@@ -1219,11 +1226,29 @@ hipError_t acx_launch_walk_all(const acx_walk_args& a, bool has_escape, int vari
 }
 
 hipError_t acx_launch_walk_long(const acx_walk_args& a, int variant, hipStream_t s) {
-    (void)variant;
     if (a.n_hay <= 0) return hipSuccess;
+    // rows of the shallowest states in LDS (variant bit 21: without, A/B): 76 KiB of them, two 1024-thread blocks per
+    // CU; config 5: 0.873 -> 0.774 ms.  Only for batches that fill the chip.
+    static const uint32_t budget_kb = [] { const char* v = getenv("ACX_LONG_TOP_KB"); const int x = v ? atoi(v) : 0; return (x >= 4 && x <= 156) ? (uint32_t)x : 76u; }();   // tuning hook (76: two blocks per CU; 24 .. 150 KiB measured within 4 %)
+    const uint32_t budget = budget_kb * 1024u;
+    uint32_t n_top = a.row_bytes ? budget / a.row_bytes : 0u;
+    if (n_top > a.n_states) n_top = a.n_states;
+    const int64_t cus = acx_num_cus();
+    if (!((variant >> 21) & 1) && n_top >= 64 && a.n_hay >= cus * 1024) {
+        const size_t lds = (size_t)n_top * a.row_bytes;
+        auto launch = [&](auto kernel) -> hipError_t {
+            hipError_t e = hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            if (e != hipSuccess) return e;
+            const unsigned bpc = (lds + 1024) * 2 <= 160u * 1024u ? 2u : 1u;      // two blocks per CU when the rows leave the room
+            hipLaunchKernelGGL(kernel, dim3((unsigned)cus * bpc), dim3(1024), lds, s, a, n_top);
+            return hipGetLastError();
+        };
+        if (a.state_bits == ACX_STATE_BITS_WIDE) return launch(k_walk_long<ACX_STATE_BITS_WIDE, true>);
+        return launch(k_walk_long<ACX_STATE_BITS_NARROW, true>);
+    }
     const int grid = grid_for_waves((a.n_hay + ACX_WAVE - 1) / ACX_WAVE);
-    if (a.state_bits == ACX_STATE_BITS_WIDE) hipLaunchKernelGGL(k_walk_long<ACX_STATE_BITS_WIDE>, dim3(grid), dim3(ACX_BLOCK), 0, s, a);
-    else                                     hipLaunchKernelGGL(k_walk_long<ACX_STATE_BITS_NARROW>, dim3(grid), dim3(ACX_BLOCK), 0, s, a);
+    if (a.state_bits == ACX_STATE_BITS_WIDE) hipLaunchKernelGGL((k_walk_long<ACX_STATE_BITS_WIDE, false>), dim3(grid), dim3(ACX_BLOCK), 0, s, a, 0u);
+    else                                     hipLaunchKernelGGL((k_walk_long<ACX_STATE_BITS_NARROW, false>), dim3(grid), dim3(ACX_BLOCK), 0, s, a, 0u);
     return hipGetLastError();
 }
 

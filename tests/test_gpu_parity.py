@@ -361,6 +361,50 @@ def test_config5_iter_long_full_size(config2):
             assert got == list(R.iter_long(reads[h].tobytes())), h
 
 
+def test_iter_long_rows_in_lds_vs_plain_vs_oracle():
+    """iter_long on a batch that fills the chip keeps the rows of the shallowest states in LDS (k_walk_long<.., true>);
+    variant bit 21 takes the plain kernel.  Both against the oracle, record for record: fixed stride with carried-in
+    states and an index base, and ragged offsets; an alphabet whose rows do not all fit, and a tiny one that fits whole."""
+    rng = np.random.default_rng(23)
+    for sigma, n_keys, kmax in ((4, 3000, 12), (20, 4000, 6), (2, 40, 9)):
+        alpha = rng.choice(256, size=sigma, replace=False).astype(np.uint8)
+        keys = list({bytes(rng.choice(alpha, size=int(k)).tobytes()) for k in rng.integers(1, kmax + 1, size=n_keys)})
+        A, O = build_pair(keys)
+        img = Image.from_automaton(A)
+        n, L = 300_000, 29
+        reads = np.ascontiguousarray(alpha[rng.integers(0, sigma, size=(n, L))])
+        flat = reads.reshape(-1)
+        d_hay = DeviceBuffer.from_numpy(flat, pad=64)
+        off = np.arange(n + 1, dtype=np.int64) * L
+        cuts = np.unique(np.concatenate([[0, n * L], rng.integers(0, n * L + 1, size=n)]))
+        for o_arr in (off, cuts.astype(np.int64)):
+            nh = len(o_arr) - 1
+            mo, oe, ov = O.batch_records(flat, o_arr, 1)
+            d_off = DeviceBuffer.from_numpy(o_arr)
+            for variant in (0, 1 << 21):
+                sc = Scanner(img)
+                sc.scan(d_hay, n * L, nh, dev_off=d_off, mode=acx.ACX_SCAN_LONG, want_final_state=True, variant=variant)
+                moff, e, v, fin = sc.fetch()
+                assert np.array_equal(moff, mo) and np.array_equal(e, oe) and np.array_equal(v, ov), (sigma, variant, nh)
+                if variant == 0:
+                    fin0 = fin
+                else:
+                    assert np.array_equal(fin, fin0)
+        # a second chunk continued from the final states of the first, with an index base (iter_long().set())
+        base = np.full(n, L, dtype=np.int32)
+        sc = Scanner(img)
+        sc.scan(d_hay, n * L, n, stride=L, mode=acx.ACX_SCAN_LONG, want_final_state=True)
+        _, _, _, fin_a = sc.fetch()
+        d_init = DeviceBuffer.from_numpy(np.ascontiguousarray(fin_a, dtype=np.int32))
+        d_base = DeviceBuffer.from_numpy(base)
+        outs = []
+        for variant in (0, 1 << 21):
+            sc = Scanner(img)
+            sc.scan(d_hay, n * L, n, stride=L, mode=acx.ACX_SCAN_LONG, dev_init_state=d_init, dev_index_base=d_base, variant=variant)
+            outs.append(sc.fetch()[:3])
+        assert all(np.array_equal(x, y) for x, y in zip(outs[0], outs[1]))
+
+
 def test_wide_layout_on_gpu(monkeypatch):
     """27-bit states, 64-bit table addressing, 2-bit counts (escape from 3 outputs on):
     same fixtures, layout forced on small automata"""
