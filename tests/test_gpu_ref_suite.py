@@ -37,5 +37,6 @@ def test_reference_suite_against_dropin(flavour):
     unexpected = sorted(f for f in failed if not any(f.endswith(x) for x in XFAIL))
     summary = out.strip().splitlines()[-1] if out.strip() else ""
     assert not unexpected, "reference tests failing against the %s drop-in:\n%s\n%s" % (flavour, "\n".join(unexpected), out[-3000:])
+    print("reference suite against the %s drop-in: %s" % (flavour, summary))          # (pytest -s shows it)
     m = re.search(r"(\d+) passed", summary)
     assert m and int(m.group(1)) >= (140 if flavour == "bytes" else 144), summary
