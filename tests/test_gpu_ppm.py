@@ -91,7 +91,7 @@ def test_alphabets_three_way(name, alpha, hay_alpha):
     assert _three_way(A, O, reads.tobytes(), off, stride=L) > 0
 
 
-@pytest.mark.parametrize("stride", [1, 2, 3, 5, 64, 255, 256, 257, 1000, 4099])
+@pytest.mark.parametrize("stride", [1, 2, 3, 5, 8, 9, 64, 150, 255, 256, 257, 1000, 1023, 1024, 2047, 2048, 2049, 4099])
 def test_fixed_stride_shapes(stride):
     rng = np.random.default_rng(stride)
     a = np.frombuffer(b"ACGT", dtype=np.uint8)
@@ -102,6 +102,20 @@ def test_fixed_stride_shapes(stride):
     off = np.arange(n + 1, dtype=np.int64) * stride
     base = rng.integers(0, 1000, size=n).astype(np.int32)
     _three_way(A, O, reads.tobytes(), off, stride=stride, index_base=base)
+
+
+@pytest.mark.parametrize("stride", [9, 1999, 2047, 2048])
+def test_runs_of_tiles_per_wave_around_the_division_thresholds(stride):
+    """> 8.4 M positions: every wave of k_ppm_stream takes a run of tiles, so the offset of a tile's first byte in its
+    haystack is carried from tile to tile; strides at both ends of the 24-bit-multiply division and just past it"""
+    rng = np.random.default_rng(stride)
+    a = np.frombuffer(b"ACGT", dtype=np.uint8)
+    keys = list({bytes(rng.choice(a, size=int(k)).tobytes()) for k in rng.integers(6, 14, size=3000)})
+    A, O = build_pair(keys)
+    n = 9_500_000 // stride
+    reads = np.ascontiguousarray(a[rng.integers(0, 4, size=(n, stride))])
+    off = np.arange(n + 1, dtype=np.int64) * stride
+    assert _three_way(A, O, reads.tobytes(), off, stride=stride) > 0
 
 
 def test_ragged_offsets_with_empty_haystacks_and_long_ones():
