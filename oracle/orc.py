@@ -57,6 +57,8 @@ def lib():
         l.flat_iter_itop.argtypes = [P, P, I64, I64, I32p, P, P, I64]
         l.ppm_iter.restype = I64
         l.ppm_iter.argtypes = [P, P, I64, C.c_int32, P, P, I64]
+        l.ppm_iter_fill.restype = I64
+        l.ppm_iter_fill.argtypes = [P, P, I64, C.c_int32, P, P, I64, C.c_uint32]
         l.flat_iter_long.restype = I64
         l.flat_iter_long.argtypes = [P, P, I64, I64, P, P, I64]
         _lib = l
@@ -224,14 +226,15 @@ def flat_iter_itop(blob, hay, index_base=0):
         cap = int(n)
 
 
-def ppm_iter(blob, hay, index_base=0):
+def ppm_iter(blob, hay, index_base=0, fill=0):
     """scan with the position-parallel image on the CPU (ppm_walk.c) -> list of (end, value);
-    None when the blob carries no ppm section"""
+    None when the blob carries no ppm section.  fill != 0: symbols that do not exist at a position (before the
+    haystack, behind a byte of no key) read as pseudo-random ones in the filter and cell codes, as on the GPU."""
     cap = max(16, 2 * len(hay))
     while True:
         e = np.empty(cap, dtype=np.int32)
         v = np.empty(cap, dtype=np.int32)
-        n = lib().ppm_iter(blob, hay, len(hay), index_base, e.ctypes.data, v.ctypes.data, cap)
+        n = lib().ppm_iter_fill(blob, hay, len(hay), index_base, e.ctypes.data, v.ctypes.data, cap, fill)
         if n == -2:
             return None
         if n < 0:

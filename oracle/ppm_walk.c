@@ -15,8 +15,12 @@
 
 #define PPM_MAX_MATCH 4096
 
-int64_t ppm_iter(const uint8_t* blob, const uint8_t* hay, int64_t len, int32_t index_base,
-                 int32_t* out_end, int32_t* out_val, int64_t cap) {
+/* fill != 0: symbols older than what the haystack holds at a position (before its start, behind a byte of no key)
+ * read as pseudo-random symbols instead of 0 wherever a code is formed — the kernels read whatever the previous
+ * haystack left there (acx_ppm_kernels.hip: the filters and the cell index are asked "as the symbols stand"), and
+ * the image must give the same matches for ANY such filling. */
+int64_t ppm_iter_fill(const uint8_t* blob, const uint8_t* hay, int64_t len, int32_t index_base,
+                      int32_t* out_end, int32_t* out_val, int64_t cap, uint32_t fill) {
     acx_blob_header bh;
     memcpy(&bh, blob, sizeof bh);
     if (!bh.off_ppm) return -2;
@@ -41,7 +45,9 @@ int64_t ppm_iter(const uint8_t* blob, const uint8_t* hay, int64_t len, int32_t i
         /* codes of the newest d symbols, zero beyond L */
         uint32_t codeC = 0, codeF = 0, code = 0;
         for (uint32_t d = 1; d <= F; d++) {
-            const uint32_t s = (int64_t)d <= L ? (uint32_t)(cls[hay[e - (d - 1)]] - ho) : 0u;
+            uint32_t s = 0;
+            if ((int64_t)d <= L) s = (uint32_t)(cls[hay[e - (d - 1)]] - ho);
+            else if (fill) { uint32_t x = (uint32_t)e * 2654435761u ^ d * 40503u ^ fill * 2246822519u; x ^= x >> 15; x *= 2654435761u; x ^= x >> 13; s = x % K; }
             code = code * K + s;
             if (d == C) codeC = code;
             if (d == F) codeF = code;
@@ -104,4 +110,9 @@ int64_t ppm_iter(const uint8_t* blob, const uint8_t* hay, int64_t len, int32_t i
         }
     }
     return n;
+}
+
+int64_t ppm_iter(const uint8_t* blob, const uint8_t* hay, int64_t len, int32_t index_base,
+                 int32_t* out_end, int32_t* out_val, int64_t cap) {
+    return ppm_iter_fill(blob, hay, len, index_base, out_end, out_val, cap, 0u);
 }

@@ -35,6 +35,7 @@ def test_ppm_walk_matches_reference_fixtures(c):
     for h in c["hays"]:
         hay = bytes.fromhex(h["hay_hex"])
         assert orc.ppm_iter(blob, hay) == expected_pairs(h["iter"])
+        assert orc.ppm_iter(blob, hay, fill=5) == expected_pairs(h["iter"])
 
 
 def test_ppm_walk_randomised_vs_oracle():
@@ -54,7 +55,12 @@ def test_ppm_walk_randomised_vs_oracle():
         text_alpha = alpha if rng.random() < 0.5 else alpha + b"#"       # a byte no key contains
         for _ in range(8):
             hay = bytes(rng.choice(text_alpha) for _ in range(rng.randint(0, 300)))
-            assert orc.ppm_iter(blob, hay) == O.iter(hay), (alpha, keys[:5])
+            want = O.iter(hay)
+            assert orc.ppm_iter(blob, hay) == want, (alpha, keys[:5])
+            # the kernels ask the filter and pick the cell with the symbols "as they stand": what lies before a
+            # haystack or behind a byte of no key is arbitrary there, and must not matter
+            for fill in (1, 2):
+                assert orc.ppm_iter(blob, hay, fill=fill) == want, (alpha, keys[:5], fill)
     assert {s[0] for s in shapes} == {2, 4, 8} and {s[1] for s in shapes} == {0, 1}
 
 
