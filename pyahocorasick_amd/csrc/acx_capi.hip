@@ -780,7 +780,14 @@ extern "C" int acx_scan_batch(acx_image_t* img, const acx_scan_params* p, acx_re
     if ((rc = r->nev.ensure(ni + 1))) return rc;
     if ((rc = r->match_off.ensure(n + 1))) return rc;
     if ((rc = r->partials.ensure((size_t)acx_scan_num_partials(n_items > p->n_hay ? n_items : p->n_hay) + 2))) return rc;
-    if ((rc = r->events.ensure((size_t)p->hay_capacity + 1))) return rc;
+    // iter_long: matches do not overlap (the walk restarts behind every match it reports), each is a key, so a haystack
+    // of len bytes has at most len / shortest_key + 1: its event slots are packed by that factor (a power of two)
+    int ev_shift = 0;
+    if (p->mode == ACX_SCAN_LONG && !chunked && img->h.off_ppm && img->ppm.magic == ACX_PPM_MAGIC) {
+        const uint32_t m = img->ppm.min_len;
+        ev_shift = m >= 16 ? 4 : (m >= 8 ? 3 : (m >= 4 ? 2 : (m >= 2 ? 1 : 0)));
+    }
+    if ((rc = r->events.ensure(ev_shift ? ((size_t)p->hay_capacity >> ev_shift) + n + 2 : (size_t)p->hay_capacity + 1))) return rc;
     if (r->has_final && (rc = r->final_state.ensure(n + 1))) return rc;
     if ((rc = r->h_total.ensure(1))) return rc;
     if (r->matches.cap == 0 && (rc = r->matches.ensure((size_t)(p->hay_capacity / 8) + 1024))) return rc;
@@ -799,6 +806,7 @@ extern "C" int acx_scan_batch(acx_image_t* img, const acx_scan_params* p, acx_re
     wa.n_states = img->h.n_states;
     wa.counts = r->counts.p; wa.nev = r->nev.p; wa.events = r->events.p;
     wa.final_state = r->has_final ? r->final_state.p : nullptr;
+    wa.ev_shift = ev_shift;
 
     int64_t* item_match_off = chunked ? r->ck_match_off.p : r->match_off.p;
     // implicit top-of-trie kernel: ACX_SCAN_ALL, narrow image that carries the structures, no carried-in
@@ -837,7 +845,7 @@ extern "C" int acx_scan_batch(acx_image_t* img, const acx_scan_params* p, acx_re
     acx_expand_args ea;
     ea.off = p->dev_off; ea.stride = p->stride; ea.n_hay = n_items; ea.nev = r->nev.p; ea.events = r->events.p;
     ea.match_off = item_match_off; ea.out_off = img->out_off; ea.out_val = img->out_val; ea.first_val = img->first_val;
-    ea.long_mode = p->mode == ACX_SCAN_LONG ? 1 : 0; ea.state_bits = img->h.state_bits;
+    ea.long_mode = p->mode == ACX_SCAN_LONG ? 1 : 0; ea.state_bits = img->h.state_bits; ea.ev_shift = ev_shift;
     ea.ck = chunked ? r->ck.p : nullptr; ea.n_items_dev = nullptr;
     // Speculative launch with the capacity we already have: no host round trip between
     // scan and expand in the steady state.  The kernel is a no-op if the total does not fit.

@@ -28,6 +28,9 @@ struct acx_walk_args {
     int32_t* nev;              // events per haystack
     uint2*   events;           // staging: one slot per haystack byte; haystack h starts at slot off[h]
     int32_t* final_state;      // nullable
+    // iter_long: matches do not overlap, so a haystack of len bytes reports at most len / shortest_key + 1 of them: its
+    // events start at slot (byte offset >> ev_shift) + h instead of one slot per byte (0: one slot per byte)
+    int32_t  ev_shift;
 };
 
 // One unit of work of the chunked scan (long haystacks): walk bytes [start, start+len) of the
@@ -66,6 +69,7 @@ struct acx_expand_args {
     uint2*   matches;          // acx_match_t[capacity]
     int64_t  capacity;
     int32_t  long_mode;        // 1: every event is exactly one match (iter_long)
+    int32_t  ev_shift;         // as in acx_walk_args
     uint32_t state_bits;       // entry layout of the image
     // chunked scans: items are chunks; event base = ck[c].start + ck[c].emit; the number of
     // items lives in device memory (n_items_dev) and n_hay is only an upper bound for the grid

@@ -900,7 +900,7 @@ __global__ void __launch_bounds__(TOP ? 1024 : ACX_BLOCK) k_walk_long(const acx_
         else       { b = h * a.stride; e = b + a.stride; }
         const int len = (int)(e - b);
         const uint8_t* p = a.hay + b;
-        uint2* ev = a.events + b;
+        uint2* ev = a.events + (a.ev_shift ? (b >> a.ev_shift) + h : b);
         uint2* const ev0 = ev;
         const uint32_t base = a.index_base ? (uint32_t)a.index_base[h] : 0u;
 
@@ -1080,7 +1080,9 @@ __global__ void __launch_bounds__(ACX_BLOCK) k_expand(const acx_expand_args a) {
     for (int64_t h = (int64_t)blockIdx.x * ACX_BLOCK + threadIdx.x; h < n_items; h += n_threads) {
         const int32_t n = a.nev[h];
         if (n == 0) continue;
-        const uint2* ev = a.events + (a.ck ? a.ck[h].start + a.ck[h].emit : (a.off ? a.off[h] : h * a.stride));
+        int64_t ev_at = a.ck ? a.ck[h].start + a.ck[h].emit : (a.off ? a.off[h] : h * a.stride);
+        if (a.ev_shift) ev_at = (ev_at >> a.ev_shift) + h;
+        const uint2* ev = a.events + ev_at;
         uint2* out = a.matches + a.match_off[h];
         if (a.long_mode) {
             for (int32_t k = 0; k < n; k++) {
@@ -1119,7 +1121,9 @@ __global__ void __launch_bounds__(ACX_BLOCK) k_expand_grp(const acx_expand_args 
     for (int64_t h = (int64_t)blockIdx.x * groups_per_block + threadIdx.x / GROUP; h < n_items; h += n_groups) {
         const int32_t n = a.nev[h];            // group-uniform
         if (n == 0) continue;
-        const uint2* ev = a.events + (a.ck ? a.ck[h].start + a.ck[h].emit : (a.off ? a.off[h] : h * a.stride));
+        int64_t ev_at = a.ck ? a.ck[h].start + a.ck[h].emit : (a.off ? a.off[h] : h * a.stride);
+        if (a.ev_shift) ev_at = (ev_at >> a.ev_shift) + h;
+        const uint2* ev = a.events + ev_at;
         int64_t out_base = a.match_off[h];
         for (int32_t k0 = 0; k0 < n; k0 += GROUP) {
             const int32_t k = k0 + sub;
