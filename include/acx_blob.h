@@ -171,6 +171,10 @@ typedef struct acx_blob_header {
  *       [2]  K <= 4 only: children of that node: mask[0..3] | child is a key[4..7] |
  *            grandchild (s1*4+s2) exists [8..23]; else 0
  *       [3..7] the values of the first five keys of eowmask, shortest first (= the order matches are produced in)
+ *   G2[code_F2] (global, L2 resident, at most 2^25 bits; optional): the same question as G asked with F2 > F symbols,
+ *       put to the positions that passed G before they become candidates: set iff the depth-F2 node exists or a key
+ *       shorter than F2 ends here.  For alphabets whose filter passes many positions that end no key (text: a 32-bit
+ *       window holds four 8-bit symbols, F2 = 5 takes one more from the symbol array).
  *   top_val[top_base[d] + code_d] (global): value of the key that is node (d, code_d), d <= C (the sixth key on).
  * Deeper: the walk stands on a node that has children and takes one 16-byte record per step
  *       { label, len | is_key << 8 | exists << 9, value, next id }
@@ -192,8 +196,8 @@ typedef struct acx_ppm_header {
     uint32_t pow2;           /* 1: K == 1 << sym_bits, codes are plain bit fields */
     uint32_t C, F;
     uint32_t g_global;       /* 1: G has more bits than LDS holds and is read from global memory (stream kernel only) */
-    uint32_t s_depth[2];
-    uint32_t g_words, s_words[2];
+    uint32_t F2, rsv_d;      /* second-level filter (global memory): symbols it is asked about (0: none) */
+    uint32_t g_words, g2_words, rsv_w;
     uint32_t has_other;
     uint32_t longest;        /* longest key */
     uint32_t n_deep;         /* rows: deep ids K, 2K, .. n_deep * K */
@@ -201,7 +205,7 @@ typedef struct acx_ppm_header {
     uint32_t min_len;        /* shortest key */
     uint32_t n_chain;        /* single records: ids 0x80000000 | 1..n_chain */
     uint64_t total_bytes;    /* header + sections */
-    uint64_t off_g, off_s[2], off_cells, off_top_val, off_kids /* rows */, off_kval /* unused */;
+    uint64_t off_g, off_g2, rsv_o, off_cells, off_top_val, off_kids /* rows */, off_kval /* unused */;
     uint32_t top_base[ACX_PPM_MAX_C + 2];
     uint64_t off_chains;     /* singles */
     uint8_t  reserved[256 - 144 - 4 * (ACX_PPM_MAX_C + 2)];

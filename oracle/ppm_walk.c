@@ -34,7 +34,8 @@ int64_t ppm_iter_fill(const uint8_t* blob, const uint8_t* hay, int64_t len, int3
     const int32_t* top_val = (const int32_t*)(sec + h.off_top_val);
     const uint32_t* rows = (const uint32_t*)(sec + h.off_kids);        /* K 16-byte records per row */
     const uint32_t* singles = (const uint32_t*)(sec + h.off_chains);   /* one 16-byte record per single */
-    const uint32_t K = h.K, C = h.C, F = h.F, ho = h.has_other, SB = h.sym_bits;
+    const uint32_t K = h.K, C = h.C, F = h.F, F2 = h.F2, ho = h.has_other, SB = h.sym_bits;
+    const uint32_t* G2 = F2 ? (const uint32_t*)(sec + h.off_g2) : 0;      /* second-level filter */
     int64_t n = 0;
     int64_t last_other = -1;            /* last position holding a byte no key contains */
     static int32_t mv[PPM_MAX_MATCH];
@@ -43,16 +44,18 @@ int64_t ppm_iter_fill(const uint8_t* blob, const uint8_t* hay, int64_t len, int3
         int64_t L = e - last_other;     /* symbols available going back from e */
         if (L > (int64_t)h.longest) L = h.longest;
         /* codes of the newest d symbols, zero beyond L */
-        uint32_t codeC = 0, codeF = 0, code = 0;
-        for (uint32_t d = 1; d <= F; d++) {
+        uint32_t codeC = 0, codeF = 0, codeF2 = 0, code = 0;
+        for (uint32_t d = 1; d <= (F2 > F ? F2 : F); d++) {
             uint32_t s = 0;
             if ((int64_t)d <= L) s = (uint32_t)(cls[hay[e - (d - 1)]] - ho);
             else if (fill) { uint32_t x = (uint32_t)e * 2654435761u ^ d * 40503u ^ fill * 2246822519u; x ^= x >> 15; x *= 2654435761u; x ^= x >> 13; s = x % K; }
             code = code * K + s;
             if (d == C) codeC = code;
             if (d == F) codeF = code;
+            if (d == F2) codeF2 = code;
         }
         if (!((G[codeF >> 5] >> (codeF & 31)) & 1u)) continue;
+        if (F2 && !((G2[codeF2 >> 5] >> (codeF2 & 31)) & 1u)) continue;
         const uint32_t* cell = cells + (size_t)codeC * 8;
         int nm = 0;
         uint32_t mask = cell[0];

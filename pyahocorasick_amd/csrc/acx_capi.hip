@@ -88,6 +88,7 @@ struct acx_image {
     acx_ppm_header ppm;
     const uint32_t* ppm_g = nullptr;
     const uint32_t* ppm_cells = nullptr;
+    const uint32_t* ppm_g2 = nullptr;          // second-level filter (nullptr: none)
     const int32_t*  ppm_top_val = nullptr;
     const uint32_t* ppm_kids = nullptr;
     const int32_t*  ppm_kval = nullptr;
@@ -130,6 +131,7 @@ static int image_resolve(acx_image* img, const uint32_t* lvl_host) {
         const uint8_t* sec = img->dev + img->h.off_ppm;
         img->ppm_g = (const uint32_t*)(sec + ph.off_g);
         img->ppm_cells = (const uint32_t*)(sec + ph.off_cells);
+        img->ppm_g2 = ph.F2 ? (const uint32_t*)(sec + ph.off_g2) : nullptr;
         img->ppm_top_val = (const int32_t*)(sec + ph.off_top_val);
         img->ppm_kids = (const uint32_t*)(sec + ph.off_kids);
         img->ppm_kval = (const int32_t*)(sec + ph.off_kval);
@@ -558,10 +560,10 @@ static uint32_t ppm_halo_pos(const acx_ppm_header& ph) {         // whole words 
 static uint32_t ppm_stream_nsub(const acx_ppm_header& ph, uint32_t halo_pos, bool offs) {
     const uint32_t gw = ph.g_global ? 0u : ph.g_words;
     static const uint32_t forced = [] { const char* v = getenv("ACX_PPM_NSUB"); const int x = v ? atoi(v) : 0; return (x == 2 || x == 4 || x == 8) ? (uint32_t)x : 0u; }();   // tuning hook
-    // (8-bit symbols with the filter in LDS — text-like alphabets: 2048-position tiles measured slower than 1024, 203 vs 218 GB/s)
-    const uint32_t top = (ph.sym_bits == 8 && !ph.g_global) ? 4u : 8u;
+    // (8-bit symbols with the filter in LDS and no second-level filter: 2048-position tiles measured slower than 1024,
+    //  203 vs 218 GB/s — too many candidates per tile for the queue; with the second level: 353 vs 340)
+    const uint32_t top = forced ? forced : ((ph.sym_bits == 8 && !ph.g_global && !ph.F2) ? 4u : 8u);
     for (uint32_t nsub = top; nsub >= 2; nsub >>= 1) {
-        if (forced && nsub > forced) continue;
         if (acx_ppm_stream_layout(gw, ph.sym_bits, halo_pos, nsub, offs).total_words * 4 <= ACX_PPM_LDS_BYTES) return nsub;
     }
     return 0;
@@ -630,6 +632,7 @@ static int scan_ppm(acx_image_t* img, const acx_scan_params* p, acx_result* r, h
     pa.cls = img->cls; pa.g = img->ppm_g; pa.cells = img->ppm_cells; pa.top_val = img->ppm_top_val;
     pa.kids = img->ppm_kids; pa.kval = img->ppm_kval; pa.chains = img->ppm_chains; pa.n_branch = ph.n_deep;
     pa.K = ph.K; pa.sym_bits = ph.sym_bits; pa.pow2 = ph.pow2; pa.C = ph.C; pa.F = ph.F; pa.g_words = ph.g_words;
+    pa.g2 = ((p->variant >> 20) & 1) ? nullptr : img->ppm_g2; pa.F2 = pa.g2 ? ph.F2 : 0u;      // (variant bit 20: without the second-level filter, A/B)
     pa.has_other = ph.has_other; pa.longest = ph.longest; pa.min_len = ph.min_len ? ph.min_len : 1;
     memcpy(pa.top_base, ph.top_base, sizeof pa.top_base);
     pa.lds = acx_ppm_lds_layout(ph.g_words, ph.sym_bits, ph.longest);

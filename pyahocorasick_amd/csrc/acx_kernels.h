@@ -130,6 +130,8 @@ struct acx_ppm_args {
     uint2*    scratch;       // record pool: 8 sub-pools of pool_records each, one bump pointer per sub-pool
     unsigned long long* heads;
     uint32_t  n_pools;       // min(8, blocks): block b bumps heads[b % n_pools]
+    const uint32_t* g2;      // k_ppm_stream: second-level filter bitmap (global), asked about F2 symbols; nullptr: none
+    uint32_t  F2;
     uint32_t  reserve_cus;   // k_ppm_stream: CUs the grid leaves free (asynchronous scans: the gather of the previous batch runs there)
     uint64_t  pool_records;
     int32_t*  overflow;      // set when a sub-pool ran out: the host grows the pool and scans again

@@ -163,7 +163,26 @@ int acx_ppm_build(const acx_trie* t, const uint8_t* cls, uint32_t n_classes, boo
         if (const char* e = getenv("ACX_PPM_MAX_F")) { const uint32_t v = (uint32_t)atoi(e); if (v >= 1 && v < F) { F = v; if (C > F) C = F; } }   // tuning hook
         if (!h.g_global && ipow(F) > gbits_cap) return ACX_OK;           // (F == C and even that does not fit: no image)
         h.C = C; h.F = F;
-        const uint64_t nC = ipow(C), nF = ipow(F);
+        // Second-level filter: the same question with more symbols, in global memory (L2 resident), asked only for the
+        // positions that pass G.  It pays where G passes many positions that end no key and every candidate costs
+        // dependent gathers: alphabets whose F is capped by the 32-bit window (text: four 8-bit symbols; config 3:
+        // 219 -> 328 GB/s).  With 2-bit symbols G is not capped; a 12-symbol second level halved the candidates there
+        // and gained nothing.
+        uint32_t F2 = 0;
+        {
+            uint32_t g2_bits = 25;
+            const char* e = getenv("ACX_PPM_G2_BITS");                   // tuning hook: 0 none, 10..27 the size cap
+            if (e) { const int v = atoi(e); g2_bits = (v >= 10 && v <= 27) ? (uint32_t)v : 0u; }
+            // (the kernel extends the code of F = max_syms symbols by older ones: only where the window caps F)
+            if (g2_bits && !h.g_global && F == max_syms) {
+                uint32_t f = F;
+                while (f + 1 <= (uint32_t)max_depth && f + 1 < 2 * max_syms && ipow(f + 1) <= ((uint64_t)1 << g2_bits)) f++;
+                if (f > F) F2 = f;
+            }
+        }
+        h.F2 = F2;
+        const uint64_t nC = ipow(C), nF = ipow(F), nF2 = F2 ? ipow(F2) : 0;
+        h.g2_words = (uint32_t)((nF2 + 31) / 32);
         h.g_words = (uint32_t)((nF + 31) / 32);
         h.top_base[0] = 0;
         for (uint32_t d = 1; d <= C + 1; d++) h.top_base[d] = h.top_base[d - 1] + (uint32_t)ipow(d - 1);
@@ -179,7 +198,7 @@ int acx_ppm_build(const acx_trie* t, const uint8_t* cls, uint32_t n_classes, boo
             if (nd.eow && (uint32_t)depth[u] < min_len) min_len = (uint32_t)depth[u];
             for (int32_t c = nd.first_child; c >= 0; c = rev.nodes[c].next_sibling) {
                 nkids[u]++;
-                if ((uint32_t)depth[u] < F) code[c] = code[u] * sigma + (uint32_t)(cls[rev.nodes[c].letter] - ho);
+                if ((uint32_t)depth[u] < (F2 > F ? F2 : F)) code[c] = code[u] * sigma + (uint32_t)(cls[rev.nodes[c].letter] - ho);
             }
         }
         h.min_len = min_len;
@@ -241,6 +260,7 @@ int acx_ppm_build(const acx_trie* t, const uint8_t* cls, uint32_t n_classes, boo
         // layout
         size_t off = sizeof h;
         h.off_g = off;        off = align256(off + (size_t)h.g_words * 4);
+        if (F2) { h.off_g2 = off; off = align256(off + (size_t)h.g2_words * 4); }
         h.off_cells = off;    off = align256(off + (size_t)nC * 32);
         h.off_top_val = off;  off = align256(off + (size_t)h.n_top * 4);
         h.off_kids = off;     off = align256(off + (size_t)row_bytes);
@@ -267,6 +287,17 @@ int acx_ppm_build(const acx_trie* t, const uint8_t* cls, uint32_t n_classes, boo
                 if (d == C) topC_node[code[u]] = u;
             }
             if (d == F && F == C + 1) G[code[u] >> 5] |= 1u << (code[u] & 31);
+            if (F2) {
+                uint32_t* G2 = (uint32_t*)(sec + h.off_g2);
+                if (d == F2) G2[code[u] >> 5] |= 1u << (code[u] & 31);
+                else if (d < F2 && nd.eow) {                              // a shorter key: every filling of the older symbols
+                    const uint64_t span = ipow(F2 - d), lo = (uint64_t)code[u] * span, hi = lo + span;
+                    for (uint64_t x = lo; x < hi;) {
+                        if ((x & 31) == 0 && x + 32 <= hi) { G2[x >> 5] = 0xFFFFFFFFu; x += 32; }
+                        else { G2[x >> 5] |= 1u << (x & 31); x++; }
+                    }
+                }
+            }
         }
         // ids as the kernels read them: a row's id is its first record's index (row number x K: no multiply on the
         // device), a single's id is its number with bit 31 set

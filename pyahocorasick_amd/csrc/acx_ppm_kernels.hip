@@ -704,6 +704,18 @@ __global__ void __launch_bounds__(ACX_PPM_BLOCK) k_ppm_stream(const acx_ppm_args
         if (OWN >= 32) W[0] = ((const uint32_t*)sym_tile_bytes)[(int)(OW * lane) - 1];
         else W[0] = ((uint32_t)((const uint16_t*)sym_tile_bytes)[lane - 1] << 16) | ((const uint16_t*)sym_tile_bytes)[lane - 2];
         uint32_t pw = 0;                                               // positions that pass
+        // Second-level filter (optional: include/acx_blob.h "G2"): a position that passes G is asked again with F2 > F
+        // symbols in a bitmap in global memory (L2 resident) before it costs a queue entry, a cell gather and the
+        // dependent gathers of the deeper walk.  Its code extends the first one by the older symbols, which sit in the
+        // lane's registers too (Wm: the second word in front of its own); the probe is issued only where G said yes.
+        const uint32_t F2 = OWN >= 32 ? a.F2 : 0u;
+        uint32_t Wm = 0;
+        if (F2) Wm = ((const uint32_t*)sym_tile_bytes)[(int)(OW * lane) - 2];
+        auto old_sym = [&](int p, int d) -> uint32_t {                // the symbol d positions before the lane's position p (p, d: constants)
+            const int b = (int)SB * (p - d);                           // its bit offset from the lane's first symbol
+            const uint32_t word = b >= 0 ? W[1 + b / 32] : (b >= -32 ? W[0] : Wm);
+            return __builtin_amdgcn_ubfe(word, (uint32_t)(b & 31), (uint32_t)SB);
+        };
 #pragma unroll
         for (int i0 = 0; i0 < (int)PPL; i0 += 16) {                    // (16 probes in flight at a time: registers)
             constexpr int NB = PPL < 16 ? (int)PPL : 16;
@@ -715,8 +727,24 @@ __global__ void __launch_bounds__(ACX_PPM_BLOCK) k_ppm_stream(const acx_ppm_args
                 cf[i] = code_n(X, a.F);
                 gw[i] = P.s_g[cf[i] >> 5];
             }
+            uint32_t pm = 0;
 #pragma unroll
-            for (int i = 0; i < NB; i++) pw |= __builtin_amdgcn_ubfe(gw[i], cf[i], 1u) << (i0 + i);
+            for (int i = 0; i < NB; i++) pm |= __builtin_amdgcn_ubfe(gw[i], cf[i], 1u) << i;
+            if (F2) {
+#pragma unroll
+                for (int i = 0; i < NB; i++) {
+                    uint32_t c2 = cf[i];
+#pragma unroll
+                    for (int d = (int)SPW; d < 2 * (int)SPW; d++)       // (G2 exists only where F fills the window: F = SPW; two words of older symbols are at hand)
+                        if ((uint32_t)d < F2) c2 = (uint32_t)__umul24(c2, a.K) + old_sym(i0 + i, d);   // (codes stay below 2^25: 24-bit multiply)
+                    cf[i] = c2;
+                    gw[i] = 0xFFFFFFFFu;
+                    if ((pm >> i) & 1u) gw[i] = a.g2[c2 >> 5];
+                }
+#pragma unroll
+                for (int i = 0; i < NB; i++) pm &= ~((__builtin_amdgcn_ubfe(gw[i], cf[i], 1u) ^ 1u) << i);
+            }
+            pw |= pm << i0;
         }
         // haystack starts among the lane's positions
         uint32_t sw = 0;
