@@ -708,7 +708,7 @@ __global__ void __launch_bounds__(ACX_PPM_BLOCK) k_ppm_stream(const acx_ppm_args
         // symbols in a bitmap in global memory (L2 resident) before it costs a queue entry, a cell gather and the
         // dependent gathers of the deeper walk.  Its code extends the first one by the older symbols, which sit in the
         // lane's registers too (Wm: the second word in front of its own); the probe is issued only where G said yes.
-        const uint32_t F2 = OWN >= 32 ? a.F2 : 0u;
+        const uint32_t F2 = (OWN >= 32 && !GG) ? a.F2 : 0u;             // (a filter in global memory has no second level)
         uint32_t Wm = 0;
         if (F2) Wm = ((const uint32_t*)sym_tile_bytes)[(int)(OW * lane) - 2];
         auto old_sym = [&](int p, int d) -> uint32_t {                // the symbol d positions before the lane's position p (p, d: constants)
