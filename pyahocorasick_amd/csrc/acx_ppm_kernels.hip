@@ -580,7 +580,7 @@ __global__ void __launch_bounds__(ACX_PPM_BLOCK) k_ppm_stream(const acx_ppm_args
     auto code_n = [&](uint32_t Xm, uint32_t n) -> uint32_t {
         if (POW2) return Xm >> (32 - SB * n);
         uint32_t c = 0;
-        for (uint32_t i = 1; i <= n; i++) c = c * a.K + __builtin_amdgcn_ubfe(Xm, 32 - SB * i, (uint32_t)SB);
+        for (uint32_t i = 1; i <= n; i++) c = (uint32_t)__umul24(c, a.K) + __builtin_amdgcn_ubfe(Xm, 32 - SB * i, (uint32_t)SB);   // (codes stay below 2^27 / K < 2^24 before the last step: a full-rate 24-bit multiply)
         return c;
     };
 
