@@ -22,8 +22,8 @@ GENERAL = (1 << 24) | (1 << 28)   # k_ppm_scan (any batch; bit 28: even where th
 def _ppm_fields(blob):
     off = struct.unpack_from("<Q", blob, 248)[0]
     assert off, "image carries no ppm section"
-    magic, K, sb, pow2, C, F = struct.unpack_from("<6I", blob, off)
-    return dict(K=K, sym_bits=sb, pow2=pow2, C=C, F=F)
+    magic, K, sb, pow2, C, F, g_global, F2 = struct.unpack_from("<8I", blob, off)
+    return dict(K=K, sym_bits=sb, pow2=pow2, C=C, F=F, g_global=g_global, F2=F2)
 
 
 def _three_way(A, O, data, off, stride=None, index_base=None, want_final=True):
@@ -116,6 +116,34 @@ def test_runs_of_tiles_per_wave_around_the_division_thresholds(stride):
     reads = np.ascontiguousarray(a[rng.integers(0, 4, size=(n, stride))])
     off = np.arange(n + 1, dtype=np.int64) * stride
     assert _three_way(A, O, reads.tobytes(), off, stride=stride) > 0
+
+
+def test_second_level_filter_text_one_long_haystack():
+    """text-like alphabet (27 symbols of 8 bits: the first filter is capped at the 4 symbols of a 32-bit window) gets
+    the second-level filter in L2; one haystack of 10 MB (every wave takes a run of tiles), as config 3 is scanned.
+    With and without it (variant bit 20), against the oracle, record for record."""
+    rng = np.random.default_rng(41)
+    alpha = np.frombuffer(bytes(range(97, 123)) + b" ", dtype=np.uint8)
+    words = [bytes(rng.choice(alpha[:26], size=int(k)).tobytes()) for k in rng.integers(2, 9, size=4000)]
+    keys = list({b" ".join(words[int(j)] for j in rng.integers(0, len(words), size=int(m)))[:int(t)]
+                 for m, t in zip(rng.integers(1, 5, size=6000), rng.integers(5, 30, size=6000))})
+    keys = [k for k in keys if k]
+    A, O = build_pair(keys)
+    f = _ppm_fields(A.flat_image_bytes())
+    assert f["sym_bits"] == 8 and not f["pow2"] and f["F"] == 4 and f["F2"] > f["F"], f
+    text = b" ".join(words[int(j)] for j in rng.integers(0, len(words), size=1_700_000))
+    text = text[:10_000_000] + b" " + keys[0] + b"." + keys[1]          # a byte of no key near the end
+    off = np.array([0, len(text)], dtype=np.int64)
+    mo, oe, ov = O.batch_records(np.frombuffer(text, dtype=np.uint8), off, 0)
+    assert mo[-1] > 1000
+    img = Image.from_automaton(A)
+    d_hay = DeviceBuffer.from_numpy(np.frombuffer(text, dtype=np.uint8), pad=64)
+    d_off = DeviceBuffer.from_numpy(off)
+    for variant in (0, 1 << 20):
+        sc = Scanner(img)
+        sc.scan(d_hay, len(text), 1, dev_off=d_off, min_hay_len=len(text), variant=variant)
+        moff, e, v, _ = sc.fetch()
+        assert np.array_equal(moff, mo) and np.array_equal(e, oe) and np.array_equal(v, ov), variant
 
 
 def test_ragged_offsets_with_empty_haystacks_and_long_ones():
