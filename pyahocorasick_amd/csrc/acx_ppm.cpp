@@ -16,6 +16,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <new>
+#include <thread>
 #include <vector>
 
 static_assert(sizeof(acx_ppm_header) == 256, "acx_ppm_header must be exactly 256 bytes");
@@ -27,7 +28,7 @@ inline size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
 // The trie of the REVERSED keys of `t`, built in one pass over the sorted reversed keys (a key shares a prefix
 // with its predecessor: pop to that depth, append the rest).  Children come out in ascending letter order and are
 // linked in O(1); acx_trie_add_word would walk sibling lists, which are 256 long at the top of a signature trie.
-int build_reversed(const acx_trie* t, acx_trie* rev) {
+int build_reversed(const acx_trie* t, acx_trie* rev, std::vector<int32_t>* depth_out) {
     // 1. collect: DFS with an explicit stack; every key reversed into one buffer
     std::vector<uint8_t> buf;
     std::vector<uint64_t> koff;                 // key k = buf[koff[k] .. koff[k+1])
@@ -57,15 +58,39 @@ int build_reversed(const acx_trie* t, acx_trie* rev) {
     std::vector<uint32_t> idx(nk);
     for (size_t i = 0; i < nk; i++) idx[i] = (uint32_t)i;
     const uint8_t* b = buf.data();
-    std::sort(idx.begin(), idx.end(), [&](uint32_t x, uint32_t y) {
+    auto less = [&](uint32_t x, uint32_t y) {
         const size_t lx = (size_t)(koff[x + 1] - koff[x]), ly = (size_t)(koff[y + 1] - koff[y]);
         const int c = memcmp(b + koff[x], b + koff[y], lx < ly ? lx : ly);
         return c != 0 ? c < 0 : lx < ly;
-    });
+    };
+    {   // sorted runs on the host threads, then pairwise merges (keys are unique: any stable or unstable order is the same)
+        size_t T = acx_host_threads();
+        while (T > 1 && nk / T < 20000) T >>= 1;
+        size_t runs = 1; while (runs * 2 <= T) runs *= 2;          // a power of two
+        std::vector<size_t> cut(runs + 1);
+        for (size_t r = 0; r <= runs; r++) cut[r] = nk * r / runs;
+        {
+            std::vector<std::thread> th;
+            for (size_t r = 1; r < runs; r++) th.emplace_back([&, r] { std::sort(idx.begin() + cut[r], idx.begin() + cut[r + 1], less); });
+            std::sort(idx.begin() + cut[0], idx.begin() + cut[1], less);
+            for (auto& x : th) x.join();
+        }
+        for (size_t w = 1; w < runs; w *= 2) {
+            std::vector<std::thread> th;
+            for (size_t r = 0; r + w < runs; r += 2 * w) {
+                const size_t a = cut[r], m = cut[r + w], e = cut[r + 2 * w < runs ? r + 2 * w : runs];
+                th.emplace_back([&, a, m, e] { std::inplace_merge(idx.begin() + a, idx.begin() + m, idx.begin() + e, less); });
+            }
+            for (auto& x : th) x.join();
+        }
+    }
     // 3. build
     rev->nodes.clear();
     rev->nodes.reserve(buf.size() / 2 + 16);
     rev->new_node(0);
+    std::vector<int32_t>& depth = *depth_out;   // per node; the arena comes out in pre-order (a parent before its children)
+    depth.clear(); depth.reserve(buf.size() / 2 + 16);
+    depth.push_back(0);
     std::vector<int32_t> last_child;            // per node: its most recent child (siblings are appended in order)
     last_child.push_back(-1);
     std::vector<int32_t> stack;                 // stack[d] = node at depth d on the current key's path
@@ -81,6 +106,7 @@ int build_reversed(const acx_trie* t, acx_trie* rev) {
         for (size_t d = lcp; d < len; d++) {
             const int32_t parent = stack[d];
             const int32_t c = rev->new_node(key[d]);
+            depth.push_back((int32_t)d + 1);
             last_child.push_back(-1);
             if (last_child[parent] < 0) rev->nodes[parent].first_child = c; else rev->nodes[last_child[parent]].next_sibling = c;
             last_child[parent] = c;
@@ -115,27 +141,19 @@ int acx_ppm_build(const acx_trie* t, const uint8_t* cls, uint32_t n_classes, boo
         auto t0 = std::chrono::steady_clock::now();
         auto lap = [&](const char* what) { if (timing) { auto t1 = std::chrono::steady_clock::now(); fprintf(stderr, "[acx_ppm_build] %s: %.3f s\n", what, std::chrono::duration<double>(t1 - t0).count()); t0 = t1; } };
         acx_trie rev;
-        int rc = build_reversed(t, &rev);
+        std::vector<int32_t> depth;
+        int rc = build_reversed(t, &rev, &depth);
         lap("reversed trie");
         if (rc) return rc;
         const size_t n = rev.nodes.size();
         if (n < 2) return ACX_OK;
 
-        // BFS over the reversed trie: depth, parent-first order
-        std::vector<int32_t> order; order.reserve(n);
-        std::vector<int32_t> depth(n, 0);
-        order.push_back(0);
+        // Parent-first order: the arena itself (build_reversed creates the nodes in pre-order from the sorted keys), which
+        // is also the order they lie in memory — the passes below stream through it instead of hopping level by level.
+        std::vector<int32_t> order(n);
         int32_t max_depth = 0;
-        for (size_t head = 0; head < order.size(); head++) {
-            const int32_t u = order[head];
-            for (int32_t c = rev.nodes[u].first_child; c >= 0; c = rev.nodes[c].next_sibling) {
-                depth[c] = depth[u] + 1;
-                if (depth[c] > max_depth) max_depth = depth[c];
-                order.push_back(c);
-            }
-        }
-
-        lap("bfs");
+        for (size_t i = 0; i < n; i++) { order[i] = (int32_t)i; if (depth[i] > max_depth) max_depth = depth[i]; }
+        lap("order");
         // parameters
         acx_ppm_header h;
         memset(&h, 0, sizeof h);
@@ -308,22 +326,26 @@ int acx_ppm_build(const acx_trie* t, const uint8_t* cls, uint32_t n_classes, boo
             rec[2] = rev.nodes[v].eow ? (uint32_t)val32(rev.nodes[v]) : 0u;
             rec[3] = stored_id(v);
         };
-        for (uint32_t b = 0; b < n_rows; b++) {
-            const int32_t u = row_nodes[b];
-            for (int32_t c = rev.nodes[u].first_child; c >= 0; c = rev.nodes[c].next_sibling) {
-                const uint32_t s1 = (uint32_t)(cls[rev.nodes[c].letter] - ho);
-                uint32_t len = 0, label = 0;
-                const int32_t v = path_end(c, len, label, 1);
-                fill(rows + ((size_t)(b + 1) * sigma + s1) * 4, v, len, label);
+        parallel_range(0, n_rows, [&](size_t lo, size_t hi) {
+            for (size_t b = lo; b < hi; b++) {
+                const int32_t u = row_nodes[b];
+                for (int32_t c = rev.nodes[u].first_child; c >= 0; c = rev.nodes[c].next_sibling) {
+                    const uint32_t s1 = (uint32_t)(cls[rev.nodes[c].letter] - ho);
+                    uint32_t len = 0, label = 0;
+                    const int32_t v = path_end(c, len, label, 1);
+                    fill(rows + ((size_t)(b + 1) * sigma + s1) * 4, v, len, label);
+                }
             }
-        }
-        for (uint32_t k = 0; k < n_single; k++) {
-            const int32_t u = single_nodes[k];
-            const int32_t c = rev.nodes[u].first_child;
-            uint32_t len = 1, label = (uint32_t)(cls[rev.nodes[c].letter] - ho) << (32 - h.sym_bits);
-            const int32_t v = path_end(c, len, label, 0);
-            fill(singles + (size_t)(k + 1) * 4, v, len, label);
-        }
+        });
+        parallel_range(0, n_single, [&](size_t lo, size_t hi) {
+            for (size_t k = lo; k < hi; k++) {
+                const int32_t u = single_nodes[k];
+                const int32_t c = rev.nodes[u].first_child;
+                uint32_t len = 1, label = (uint32_t)(cls[rev.nodes[c].letter] - ho) << (32 - h.sym_bits);
+                const int32_t v = path_end(c, len, label, 0);
+                fill(singles + (size_t)(k + 1) * 4, v, len, label);
+            }
+        });
         lap("rows + singles");
         // cells: everything the d <= C newest symbols say
         for (uint64_t cc = 0; cc < nC; cc++) {

@@ -22,37 +22,7 @@
 #include <ctime>
 #include <new>
 #include <atomic>
-#include <thread>
 #include <vector>
-
-// Host loops over tens of millions of trie nodes are bound by cache misses (the arena is in insertion order, the
-// passes run in BFS order): they are cut into contiguous ranges for a handful of threads.  f(a, b) gets disjoint
-// sub-ranges of [lo, hi); small ranges run inline.  ACX_HOST_THREADS overrides the thread count (1: serial).
-static unsigned host_threads() {
-    static const unsigned n = [] {
-        const char* e = getenv("ACX_HOST_THREADS");
-        unsigned v = e ? (unsigned)atoi(e) : std::thread::hardware_concurrency();
-        if (v < 1) v = 1;
-        return v > 32 ? 32u : v;
-    }();
-    return n;
-}
-template <typename F>
-static void parallel_range(size_t lo, size_t hi, F&& f) {
-    const size_t n = hi > lo ? hi - lo : 0, grain = 16384;
-    size_t T = host_threads();
-    if (T > n / grain) T = n / grain;
-    if (T <= 1) { if (n) f(lo, hi); return; }
-    const size_t step = (n + T - 1) / T;
-    std::vector<std::thread> th;
-    th.reserve(T - 1);
-    for (size_t k = 1; k < T; k++) {
-        const size_t a = lo + k * step, b = a + step < hi ? a + step : hi;
-        if (a < b) th.emplace_back([&f, a, b] { f(a, b); });
-    }
-    f(lo, lo + step < hi ? lo + step : hi);
-    for (auto& x : th) x.join();
-}
 
 extern "C" {
 
