@@ -16,6 +16,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <new>
+#include <atomic>
 #include <thread>
 #include <vector>
 
@@ -34,23 +35,51 @@ int build_reversed(const acx_trie* t, acx_trie* rev, std::vector<int32_t>* depth
     std::vector<uint64_t> koff;                 // key k = buf[koff[k] .. koff[k+1])
     std::vector<int64_t> kval;
     {
-        struct Frame { int32_t node; int32_t next_child; };
-        std::vector<Frame> st;
-        std::vector<uint8_t> path;
-        st.push_back({0, t->nodes.empty() ? -1 : t->nodes[0].first_child});
-        koff.push_back(0);
-        while (!st.empty()) {
-            Frame& f = st.back();
-            if (f.next_child < 0) { st.pop_back(); if (!path.empty()) path.pop_back(); continue; }
-            const int32_t c = f.next_child;
-            f.next_child = t->nodes[c].next_sibling;
-            path.push_back(t->nodes[c].letter);
-            if (t->nodes[c].eow) {
-                buf.insert(buf.end(), path.rbegin(), path.rend());
-                koff.push_back(buf.size());
-                kval.push_back(t->nodes[c].value);
+        // one depth-first walk per subtree of the root, on the host threads (the order of the keys does not matter:
+        // they are sorted below)
+        struct Part { std::vector<uint8_t> buf; std::vector<uint64_t> len; std::vector<int64_t> val; };
+        std::vector<int32_t> tops;
+        if (!t->nodes.empty())
+            for (int32_t c = t->nodes[0].first_child; c >= 0; c = t->nodes[c].next_sibling) tops.push_back(c);
+        std::vector<Part> parts(tops.size());
+        std::atomic<size_t> next{0};
+        auto worker = [&] {
+            struct Frame { int32_t node; int32_t next_child; };
+            std::vector<Frame> st;
+            std::vector<uint8_t> path;
+            for (size_t k = next.fetch_add(1); k < tops.size(); k = next.fetch_add(1)) {
+                Part& P = parts[k];
+                st.clear(); path.clear();
+                const int32_t top = tops[k];
+                path.push_back(t->nodes[top].letter);
+                if (t->nodes[top].eow) { P.buf.insert(P.buf.end(), path.rbegin(), path.rend()); P.len.push_back(path.size()); P.val.push_back(t->nodes[top].value); }
+                st.push_back({top, t->nodes[top].first_child});
+                while (!st.empty()) {
+                    Frame& f = st.back();
+                    if (f.next_child < 0) { st.pop_back(); path.pop_back(); continue; }
+                    const int32_t c = f.next_child;
+                    f.next_child = t->nodes[c].next_sibling;
+                    path.push_back(t->nodes[c].letter);
+                    if (t->nodes[c].eow) { P.buf.insert(P.buf.end(), path.rbegin(), path.rend()); P.len.push_back(path.size()); P.val.push_back(t->nodes[c].value); }
+                    st.push_back({c, t->nodes[c].first_child});
+                }
             }
-            st.push_back({c, t->nodes[c].first_child});
+        };
+        {
+            size_t T = acx_host_threads();
+            if (t->nodes.size() < 200000 || T > tops.size()) T = t->nodes.size() < 200000 ? 1 : tops.size();
+            std::vector<std::thread> th;
+            for (size_t k = 1; k < T; k++) th.emplace_back(worker);
+            worker();
+            for (auto& x : th) x.join();
+        }
+        size_t total = 0, nkeys = 0;
+        for (const Part& P : parts) { total += P.buf.size(); nkeys += P.val.size(); }
+        buf.reserve(total); koff.reserve(nkeys + 1); kval.reserve(nkeys);
+        koff.push_back(0);
+        for (const Part& P : parts) {
+            buf.insert(buf.end(), P.buf.begin(), P.buf.end());
+            for (size_t i = 0; i < P.val.size(); i++) { koff.push_back(koff.back() + P.len[i]); kval.push_back(P.val[i]); }
         }
     }
     const size_t nk = kval.size();
