@@ -6,7 +6,10 @@
 // text up to e, longest first (automaton_build_output, :157-197) — depends on the last
 // longest_word bytes only, so here every position is its own unit of work:
 //
-//   k_ppm_scan     a WAVE owns a tile of 256 end positions.  It loads the tile and its left halo
+//   k_ppm_stream   the default (further down): runs of tiles per wave, register windows, a ring queue, wide rounds;
+//                  then k_ppm_wave_scan + k_ppm_gather.
+//   k_ppm_scan     the general form (any stride, chunks, unaligned buffers):
+//                  a WAVE owns a tile of 256 end positions.  It loads the tile and its left halo
 //                  (longest_word-1 bytes) with coalesced dword loads, turns bytes into packed symbols
 //                  in LDS, and every lane tests 4 positions against the filter bitmap G (LDS: "the F
 //                  newest symbols may end a key").  Positions that pass are compacted into a queue
@@ -19,8 +22,9 @@
 //   k_ppm_compact  copies every tile's records to their final place and turns tile-local offsets of
 //                  the haystack starts into match_off[].
 //
-// Integer only, no MFMA: there is no contraction on this path.  Bound by LDS lookups (one random
-// bitmap probe per position) and by L2 requests (one cell per position that passes the filter).
+// Integer only, no MFMA: there is no contraction on this path.  Bound by instruction issue (one LDS
+// bitmap probe per position costs 8 instructions) and by the dependent gathers of the positions that
+// pass the filter (a cell, then deep records).
 #include "acx_kernels.h"
 #include "acx_ppm_layout.h"
 
@@ -454,28 +458,30 @@ __global__ void __launch_bounds__(ACX_PPM_BLOCK) k_ppm_scan(const acx_ppm_args a
 }
 
 // ---------------------------------------------------------------------------------------------------
-// Fast path (k_ppm_stream): fixed-stride batch, 4-byte aligned buffer, codes that are plain bit
-// fields (K = 4, 16, 256), halo of at most 256 positions.  Same algorithm and the same match
-// enumeration (Ppm::matches) as k_ppm_scan; the structure around it is built for instruction
-// count, which is what bounds this kernel (one wave instruction per 4 cycles per SIMD):
-//   * a wave owns a contiguous RUN of tiles of NSUB x 256 positions; the left halo of a tile is what
-//     the previous tile left in LDS, so no byte is staged twice and every staging lane is busy;
-//   * positions that pass the filter, and the haystack starts ("markers"), go into a ring queue in
-//     position order; the queue is drained 64 entries at a time, so the exact phase runs with
-//     full waves; a marker's exclusive prefix IS the record offset of its haystack;
-//   * each round counts, places (DPP prefix sum) and writes its records at once: the wave's
-//     records form one ordered stream, appended to grants of the scratch pool that the wave lists
-//     in its descriptor; k_ppm_gather copies the streams to their final place.
+// Fast path (k_ppm_stream): fixed-stride batches and offset batches whose haystacks are at least 8 bytes long, a
+// 4-byte aligned buffer below 4 GiB, a halo of at most 256 positions.  Same image and the same match enumeration
+// (Ppm::matches) as k_ppm_scan; the structure around it is built for instruction count and for few dependent gathers,
+// which is what bounds this kernel:
+//   * a wave owns a contiguous RUN of tiles of NSUB x 256 positions; the left halo of a tile is what the previous
+//     tile left in LDS, so no byte is staged twice;
+//   * a lane owns 4 * NSUB CONTIGUOUS positions: their symbols stay in its registers, every window is a funnel shift by
+//     a constant, the filter is asked about the symbols as they stand (no offsets, masks or haystack boundaries: the
+//     rounds bound every match by the symbols that exist), the outcome is a pass word per lane;
+//   * the set bits of the pass words and of the words of haystack starts go into a ring queue in position order; the
+//     queue is worked off 64 entries at a time, or two / three per lane when it holds that many; the exclusive prefix
+//     of an entry that is a haystack start IS the record offset of its haystack;
+//   * each round counts, places (DPP prefix sums) and writes its records at once: the wave's records form one ordered
+//     stream, appended to grants of the scratch pool that the wave lists in its descriptor; k_ppm_gather copies the
+//     streams to their final place.
 // ---------------------------------------------------------------------------------------------------
-#define PPM_QCAP 384u              // ring queue entries (uint16): < 64 left over + 256 passes + 64 markers of a sub-step
+#define PPM_QCAP 384u              // ring queue entries (uint16): at most 128 left over + the 256 positions of a sub-step
 #define PPM_DESC_WORDS 40u         // per wave: total, n_grants, 16 x base, 16 x count (+ pad)
 #define PPM_MAX_GRANTS 16u
 
 // OFFS: the batch is given by a device offsets array instead of a fixed stride (ragged packets, one long
-//       haystack).  Contract: no haystack shorter than 8 bytes (acx_scan_params.min_hay_len), so a lane's four
-//       positions hold at most one haystack start, as with a stride of at least 8.  The starts of a tile come
-//       from first_h[] (k_ppm_first_h: one binary search per tile) and live in LDS as a bitmap with per-word
-//       "last start" and "starts before" tables.
+//       haystack).  Contract: no haystack shorter than 8 bytes (acx_scan_params.min_hay_len), as with a stride of
+//       at least 8: a tile holds at most TPOS / 8 starts.  They come from first_h[] (k_ppm_first_h: one binary
+//       search per tile) and live in LDS as a bitmap with per-word "last start" and "starts before" tables.
 // POW2: codes are plain bit fields of the window; otherwise Horner in radix K over its symbols.
 // GG:   the filter bitmap is read from global memory (wide alphabets: one level deeper than LDS could hold).
 template <int SB, int NSUB, bool POW2, bool OFFS, bool GG>
