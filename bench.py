@@ -68,7 +68,51 @@ def parse():
     ap.add_argument("--cpu-sample-reads", type=int, default=None,
                     help="haystacks timed on the CPU baseline legs (default: the whole first batch; 0 disables)")
     ap.add_argument("--verify", action="store_true", help="check the first batch's GPU output against the oracle (all records)")
+    ap.add_argument("--launch-check", action="store_true",
+                    help="start the ranks (gloo, no GPU), agree on the world size, print {\"n_gpus\": N, \"launch_check\": true} and exit: "
+                         "tests/test_parallel_cpu.py runs the self-launch path of --gpus N with it")
     return ap.parse_args()
+
+
+def self_launch(args):
+    """`python bench.py --gpus N` outside torch.distributed.run: start the N ranks here (one process per GPU,
+    rendezvous on 127.0.0.1) and hand their exit code back.  Under torch.distributed.run (WORLD_SIZE set) this is a no-op."""
+    if args.gpus <= 1 or "WORLD_SIZE" in os.environ:
+        return
+    import socket
+    import subprocess
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    print("[bench] --gpus %d without WORLD_SIZE: launching %s" % (args.gpus, " ".join(cmd)), file=sys.stderr, flush=True)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    sys.exit(subprocess.call(cmd, env=env))
+
+
+def launch_check(args):
+    """--launch-check: the ranks come up (gloo), agree on the world size, rank 0 prints one JSON line"""
+    import torch
+    import torch.distributed as dist
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    if world > 1:
+        dist.init_process_group("gloo")
+        t = torch.ones(1, dtype=torch.int64)
+        dist.all_reduce(t)
+        seen = int(t.item())
+        rank = dist.get_rank()
+        dist.barrier()
+        dist.destroy_process_group()
+    else:
+        seen, rank = 1, 0
+    if seen != args.gpus:
+        raise SystemExit("launch check: %d ranks answered, --gpus %d" % (seen, args.gpus))
+    if rank == 0:
+        print(json.dumps({"n_gpus": seen, "launch_check": True}), flush=True)
 
 
 def kernel_source_hash():
@@ -153,6 +197,9 @@ def cpu_baseline(keys, hays, mode):
 
 def main():
     args = parse()
+    self_launch(args)                                      # --gpus N > 1 outside torch.distributed.run: N ranks are started here
+    if args.launch_check:
+        return launch_check(args)
     # stdout must carry exactly ONE JSON line: RCCL prints a version banner on fd 1 when its
     # communicator comes up, so everything until the final print goes to stderr instead.
     sys.stdout.flush()
@@ -162,10 +209,12 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if args.gpus != world and world > 1:
+    if args.gpus != world:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the scan has no CPU fallback")
+    if torch.cuda.device_count() <= local_rank:
+        raise SystemExit("rank %d (local %d) has no GPU: %d visible" % (rank, local_rank, torch.cuda.device_count()))
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
@@ -175,6 +224,8 @@ def main():
         import torch.distributed as dist
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         dist.init_process_group("nccl", device_id=dev)
+        if dist.get_world_size() != args.gpus:              # RCCL sees fewer (or more) ranks than the line will claim
+            raise SystemExit("--gpus %d but the process group has %d ranks" % (args.gpus, dist.get_world_size()))
 
     import pyahocorasick_amd as acx
     from pyahocorasick_amd import _lib

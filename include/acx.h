@@ -190,7 +190,8 @@ const void* acx_image_table_dev_ptr(const acx_image_t* img);
  *                         (src/AutomatonSearchIterLong.c:89-153).
  *
  *    Input: n_hay haystacks concatenated in device buffer `dev_hay`;
- *           haystack h = bytes [off[h], off[h+1])  (dev_off: int64[n_hay+1], device),
+ *           haystack h = bytes [off[h], off[h+1])  (dev_off: int64[n_hay+1], device; off[0] = 0, monotone:
+ *           bytes in front of off[0] would belong to no haystack — the kernels report nothing for them),
  *           or, when dev_off == NULL, bytes [h*stride, (h+1)*stride) (fixed-length reads).
  *           hay_capacity = number of readable bytes at dev_hay (>= the last offset).
  *    Optional per-haystack device arrays (NULL = absent):
@@ -230,9 +231,10 @@ typedef struct acx_scan_params {
     int32_t  flags;            /* ACX_SCAN_ASYNC or 0 */
     int32_t  min_hay_len;      /* offsets batches: a lower bound on the haystack lengths that the caller vouches for
                                   (0 = unknown).  With >= 8 the position-parallel stream kernel takes the batch (it
-                                  keeps at most one haystack start per four positions); a haystack shorter than
-                                  promised gets wrong offsets, never an out-of-bounds access.  acx_scan_host derives it
-                                  from the host offsets. */
+                                  keeps room for one haystack start per eight positions of a tile).  A batch that breaks
+                                  the promise is noticed on the device (a flag, like the pool overflow) and scanned
+                                  again on the general kernels when the result completes: slower, never wrong.
+                                  acx_scan_host derives it from the host offsets. */
     int32_t  reserved0;
 } acx_scan_params;
 /* Return as soon as the kernels are queued on `stream`.  The result completes (wait for THIS

@@ -158,7 +158,10 @@ typedef struct acx_blob_header {
  * match ending at e.  No serial state, no fail links, no output lists: haystack bytes are read
  * coalesced and staged in LDS as packed symbols, matches are placed with a wave prefix sum.
  *
- * symbol  = class - 1 (class 0 = "other": a byte no key contains; no match spans it); K symbols.
+ * symbol  = symtab[byte] (0xFF = "other": a byte no key contains; no match spans it); K symbols.  Symbols are numbered
+ *           in byte order, except for alphabets of exactly four bytes that some shift tells apart ((byte >> s) & 3 is
+ *           distinct: ACGT with s = 1): there symbol = (byte >> s) & 3, so that the stream kernel turns four bytes into
+ *           four symbols with a shift and a mask instead of four table lookups (sym_arith, sym_lut).
  * code_d  = Horner value of the d newest symbols, newest first, radix K:
  *           code_d = code_{d-1} * K + sym(e - d + 1)           (code_0 = 0)
  * Levels 1..C of the reversed trie are direct-indexed by code (K^C <= 2^18):
@@ -171,6 +174,13 @@ typedef struct acx_blob_header {
  *       [2]  K <= 4 only: children of that node: mask[0..3] | child is a key[4..7] |
  *            grandchild (s1*4+s2) exists [8..23]; else 0
  *       [3..7] the values of the first five keys of eowmask, shortest first (= the order matches are produced in)
+ *   hot[code_C] (global, 8 bytes: 2 MiB for 2^18 cells, resident in every XCD's 4 MiB L2 — the 32-byte cells are not):
+ *       what the stream kernel asks first about a position that passed G; most positions need nothing else.
+ *       [0]  bits 0..C-1  eowmask, as in the cell.
+ *            sym_bits == 2 (C <= 12): bits 12..15 child s1 of the depth-C node is a key, bits 16..31 its grandchild
+ *            (s1 * 4 + s2) exists — the walk goes deeper iff one of the two bits of the next two symbols is set;
+ *            (bits 12..31) != 0 iff the node has children.  Wider symbols: bit 31 = the node has children.
+ *       [1]  the node has children: its deep id (as cell[1]); else the value of the shallowest key of eowmask (else 0).
  *   G2[code_F2] (global, L2 resident, at most 2^25 bits; optional): the same question as G asked with F2 > F symbols,
  *       put to the positions that passed G before they become candidates: set iff the depth-F2 node exists or a key
  *       shorter than F2 ends here.  For alphabets whose filter passes many positions that end no key (text: a 32-bit
@@ -186,7 +196,7 @@ typedef struct acx_blob_header {
  *   node it ends on if that node has children.
  * All section offsets are relative to the start of the acx_ppm_header.
  */
-#define ACX_PPM_MAGIC 0x324D5050u   /* "PPM2" */
+#define ACX_PPM_MAGIC 0x334D5050u   /* "PPM3" */
 #define ACX_PPM_MAX_C 20
 #define ACX_PPM_TILE  256           /* end positions per wave and tile */
 typedef struct acx_ppm_header {
@@ -196,8 +206,10 @@ typedef struct acx_ppm_header {
     uint32_t pow2;           /* 1: K == 1 << sym_bits, codes are plain bit fields */
     uint32_t C, F;
     uint32_t g_global;       /* 1: G has more bits than LDS holds and is read from global memory (stream kernel only) */
-    uint32_t F2, rsv_d;      /* second-level filter (global memory): symbols it is asked about (0: none) */
-    uint32_t g_words, g2_words, rsv_w;
+    uint32_t F2;             /* second-level filter (global memory): symbols it is asked about (0: none) */
+    uint32_t sym_arith;      /* K == 4 only: 1 + s when symbol(byte) = (byte >> s) & 3 for the four key bytes (0: table only) */
+    uint32_t g_words, g2_words;
+    uint32_t sym_lut;        /* sym_arith != 0: byte j = the key byte whose symbol is j (a byte b is "other" iff lut[(b >> s) & 3] != b) */
     uint32_t has_other;
     uint32_t longest;        /* longest key */
     uint32_t n_deep;         /* rows: deep ids K, 2K, .. n_deep * K */
@@ -205,7 +217,10 @@ typedef struct acx_ppm_header {
     uint32_t min_len;        /* shortest key */
     uint32_t n_chain;        /* single records: ids 0x80000000 | 1..n_chain */
     uint64_t total_bytes;    /* header + sections */
-    uint64_t off_g, off_g2, rsv_o, off_cells, off_top_val, off_kids /* rows */, off_kval /* unused */;
+    uint64_t off_g, off_g2;
+    uint64_t off_symtab;     /* uint8 [256]: byte -> symbol, 0xFF = a byte no key contains */
+    uint64_t off_cells, off_top_val, off_kids /* rows */;
+    uint64_t off_hot;        /* uint32 [2 * K^C]: the 8-byte hot cells (stream kernel) */
     uint32_t top_base[ACX_PPM_MAX_C + 2];
     uint64_t off_chains;     /* singles */
     uint8_t  reserved[256 - 144 - 4 * (ACX_PPM_MAX_C + 2)];

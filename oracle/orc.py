@@ -57,6 +57,8 @@ def lib():
         l.flat_iter_itop.argtypes = [P, P, I64, I64, I32p, P, P, I64]
         l.ppm_iter.restype = I64
         l.ppm_iter.argtypes = [P, P, I64, C.c_int32, P, P, I64]
+        l.ppm_check_hot.restype = I64
+        l.ppm_check_hot.argtypes = [P]
         l.ppm_iter_fill.restype = I64
         l.ppm_iter_fill.argtypes = [P, P, I64, C.c_int32, P, P, I64, C.c_uint32]
         l.flat_iter_long.restype = I64
@@ -224,6 +226,11 @@ def flat_iter_itop(blob, hay, index_base=0):
         if n <= cap:
             return list(zip(e[:n].tolist(), v[:n].tolist())), st.value
         cap = int(n)
+
+
+def ppm_check_hot(blob):
+    """cells of the position-parallel image whose 8-byte hot form disagrees with the 32-byte form (0 = consistent)"""
+    return int(lib().ppm_check_hot(blob))
 
 
 def ppm_iter(blob, hay, index_base=0, fill=0):

@@ -28,26 +28,26 @@ int64_t ppm_iter_fill(const uint8_t* blob, const uint8_t* hay, int64_t len, int3
     acx_ppm_header h;
     memcpy(&h, sec, sizeof h);
     if (h.magic != ACX_PPM_MAGIC) return -3;
-    const uint8_t* cls = blob + bh.off_cls;
+    const uint8_t* symtab = sec + h.off_symtab;                        /* byte -> symbol, 0xFF = a byte of no key */
     const uint32_t* G = (const uint32_t*)(sec + h.off_g);
     const uint32_t* cells = (const uint32_t*)(sec + h.off_cells);
     const int32_t* top_val = (const int32_t*)(sec + h.off_top_val);
     const uint32_t* rows = (const uint32_t*)(sec + h.off_kids);        /* K 16-byte records per row */
     const uint32_t* singles = (const uint32_t*)(sec + h.off_chains);   /* one 16-byte record per single */
-    const uint32_t K = h.K, C = h.C, F = h.F, F2 = h.F2, ho = h.has_other, SB = h.sym_bits;
+    const uint32_t K = h.K, C = h.C, F = h.F, F2 = h.F2, SB = h.sym_bits;
     const uint32_t* G2 = F2 ? (const uint32_t*)(sec + h.off_g2) : 0;      /* second-level filter */
     int64_t n = 0;
     int64_t last_other = -1;            /* last position holding a byte no key contains */
     static int32_t mv[PPM_MAX_MATCH];
     for (int64_t e = 0; e < len; e++) {
-        if (ho && cls[hay[e]] == 0) { last_other = e; continue; }
+        if (symtab[hay[e]] == 0xFFu) { last_other = e; continue; }
         int64_t L = e - last_other;     /* symbols available going back from e */
         if (L > (int64_t)h.longest) L = h.longest;
         /* codes of the newest d symbols, zero beyond L */
         uint32_t codeC = 0, codeF = 0, codeF2 = 0, code = 0;
         for (uint32_t d = 1; d <= (F2 > F ? F2 : F); d++) {
             uint32_t s = 0;
-            if ((int64_t)d <= L) s = (uint32_t)(cls[hay[e - (d - 1)]] - ho);
+            if ((int64_t)d <= L) s = (uint32_t)symtab[hay[e - (d - 1)]];
             else if (fill) { uint32_t x = (uint32_t)e * 2654435761u ^ d * 40503u ^ fill * 2246822519u; x ^= x >> 15; x *= 2654435761u; x ^= x >> 13; s = x % K; }
             code = code * K + s;
             if (d == C) codeC = code;
@@ -64,7 +64,7 @@ int64_t ppm_iter_fill(const uint8_t* blob, const uint8_t* hay, int64_t len, int3
         {
             uint32_t pc = 0;
             for (uint32_t d = 1; d <= C; d++) {
-                const uint32_t s = (int64_t)d <= L ? (uint32_t)(cls[hay[e - (d - 1)]] - ho) : 0u;
+                const uint32_t s = (int64_t)d <= L ? (uint32_t)symtab[hay[e - (d - 1)]] : 0u;
                 pc = pc * K + s;
                 if ((mask >> (d - 1)) & 1u) {           /* the cell lists the values of its first five levels */
                     const int32_t v = nm < 5 ? (int32_t)cell[3 + nm] : top_val[h.top_base[d] + pc];
@@ -78,12 +78,12 @@ int64_t ppm_iter_fill(const uint8_t* blob, const uint8_t* hay, int64_t len, int3
         if (id && L > d) {
             int go = 1;
             if (K <= 4 && cell[2]) {
-                const uint32_t s1 = (uint32_t)(cls[hay[e - d]] - ho);
+                const uint32_t s1 = (uint32_t)symtab[hay[e - d]];
                 if (!((cell[2] >> s1) & 1u)) go = 0;
                 else if (!((cell[2] >> (4 + s1)) & 1u)) {
                     /* child exists, is no key: worth a row gather only if a grandchild continues */
                     if (L > d + 1) {
-                        const uint32_t s2 = (uint32_t)(cls[hay[e - d - 1]] - ho);
+                        const uint32_t s2 = (uint32_t)symtab[hay[e - d - 1]];
                         if (!((cell[2] >> (8 + s1 * 4 + s2)) & 1u)) go = 0;
                     } else go = 0;
                 }
@@ -94,13 +94,13 @@ int64_t ppm_iter_fill(const uint8_t* blob, const uint8_t* hay, int64_t len, int3
                 if (id >> 31) { rec = singles + (size_t)(id & 0x7FFFFFFFu) * 4; first = 0; }
                 else {
                     if (L <= d) break;
-                    rec = rows + ((size_t)id + (uint32_t)(cls[hay[e - d]] - ho)) * 4; first = 1;   /* a row's id is the index of its first record */
+                    rec = rows + ((size_t)id + (uint32_t)symtab[hay[e - d]]) * 4; first = 1;   /* a row's id is the index of its first record */
                 }
                 if (!(rec[1] & 0x200u)) break;          /* no child on this symbol */
                 const uint32_t len = rec[1] & 0xFFu;
                 if (L < d + (int64_t)first + len) break;
                 uint32_t label = 0;
-                for (uint32_t i = 0; i < len; i++) label |= (uint32_t)(cls[hay[e - d - first - i]] - ho) << (32 - SB * (i + 1));
+                for (uint32_t i = 0; i < len; i++) label |= (uint32_t)symtab[hay[e - d - first - i]] << (32 - SB * (i + 1));
                 if (label != rec[0]) break;
                 d += first + len;
                 if (rec[1] & 0x100u) { if (nm < PPM_MAX_MATCH) mv[nm++] = (int32_t)rec[2]; }
@@ -118,4 +118,45 @@ int64_t ppm_iter_fill(const uint8_t* blob, const uint8_t* hay, int64_t len, int3
 int64_t ppm_iter(const uint8_t* blob, const uint8_t* hay, int64_t len, int32_t index_base,
                  int32_t* out_end, int32_t* out_val, int64_t cap) {
     return ppm_iter_fill(blob, hay, len, index_base, out_end, out_val, cap, 0u);
+}
+
+/* The 8-byte hot cells (what the stream kernel reads first) against the 32-byte cells they summarise:
+ * returns the number of cells that disagree (0 = consistent), < 0 on a malformed image. */
+int64_t ppm_check_hot(const uint8_t* blob) {
+    acx_blob_header bh;
+    memcpy(&bh, blob, sizeof bh);
+    if (!bh.off_ppm) return -2;
+    const uint8_t* sec = blob + bh.off_ppm;
+    acx_ppm_header h;
+    memcpy(&h, sec, sizeof h);
+    if (h.magic != ACX_PPM_MAGIC || !h.off_hot) return -3;
+    const uint32_t* cells = (const uint32_t*)(sec + h.off_cells);
+    const uint32_t* hot = (const uint32_t*)(sec + h.off_hot);
+    uint64_t nC = 1;
+    for (uint32_t i = 0; i < h.C; i++) nC *= h.K;
+    int64_t bad = 0;
+    for (uint64_t c = 0; c < nC; c++) {
+        const uint32_t* cell = cells + c * 8;
+        const uint32_t hw = hot[2 * c], hx = hot[2 * c + 1];
+        const uint32_t cmask = h.C >= 32 ? 0xFFFFFFFFu : (1u << h.C) - 1u;
+        int ok = (hw & cmask) == cell[0];
+        if (h.sym_bits == 2) {
+            ok = ok && h.C <= 12 && ((hw >> 12) & 0xFu) == ((cell[2] >> 4) & 0xFu) && (hw >> 16) == ((cell[2] >> 8) & 0xFFFFu);
+            ok = ok && (((hw >> 12) != 0) == (cell[1] != 0));          /* children <=> some child is a key or has a child */
+        } else ok = ok && ((hw >> 31) == (cell[1] != 0 ? 1u : 0u)) && (hw & 0x7FFFFFFFu & ~cmask) == 0;
+        if (cell[1]) ok = ok && hx == cell[1];
+        else ok = ok && hx == (cell[0] ? cell[3] : 0u);
+        if (!ok) bad++;
+    }
+    /* the arithmetic symbol map, where the image has one */
+    const uint8_t* symtab = sec + h.off_symtab;
+    if (h.sym_arith) {
+        const uint32_t sh = h.sym_arith - 1;
+        for (int b = 0; b < 256; b++) {
+            const uint32_t s = ((uint32_t)b >> sh) & 3u;
+            const int is_key_byte = ((h.sym_lut >> (8 * s)) & 0xFFu) == (uint32_t)b;
+            if (is_key_byte ? symtab[b] != s : symtab[b] != 0xFFu) bad++;
+        }
+    }
+    return bad;
 }

@@ -91,7 +91,8 @@ struct acx_image {
     const uint32_t* ppm_g2 = nullptr;          // second-level filter (nullptr: none)
     const int32_t*  ppm_top_val = nullptr;
     const uint32_t* ppm_kids = nullptr;
-    const int32_t*  ppm_kval = nullptr;
+    const uint32_t* ppm_hot = nullptr;         // 8-byte hot cells (stream kernel)
+    const uint8_t*  ppm_symtab = nullptr;      // byte -> symbol, 0xFF = a byte of no key
     const uint32_t* ppm_chains = nullptr;
 };
 
@@ -134,7 +135,8 @@ static int image_resolve(acx_image* img, const uint32_t* lvl_host) {
         img->ppm_g2 = ph.F2 ? (const uint32_t*)(sec + ph.off_g2) : nullptr;
         img->ppm_top_val = (const int32_t*)(sec + ph.off_top_val);
         img->ppm_kids = (const uint32_t*)(sec + ph.off_kids);
-        img->ppm_kval = (const int32_t*)(sec + ph.off_kval);
+        img->ppm_hot = (const uint32_t*)(sec + ph.off_hot);
+        img->ppm_symtab = sec + ph.off_symtab;
         img->ppm_chains = (const uint32_t*)(sec + ph.off_chains);
         if (!ph.g_global && acx_ppm_lds_layout(ph.g_words, ph.sym_bits, ph.longest).total_words * 4 > ACX_PPM_LDS_BYTES) img->ppm_g = nullptr;
     }
@@ -361,6 +363,7 @@ struct acx_result {
     // scan kernel (instruction bound) of another result on the caller's stream overlaps it
     bool use_side = false; hipStream_t side = nullptr; hipEvent_t ev_scan = nullptr;
     acx_image* pend_img = nullptr;
+    acx_scan_params pend_params;                // the scan as it was asked for (a stream scan that must be issued again)
     PinBuf<int64_t> h_off;
     PinBuf<acx_match_t> h_matches;
     PinBuf<int32_t> h_final;
@@ -405,6 +408,15 @@ static int ppm_complete(acx_result* r) {
     hipStream_t s = r->stream;
     for (int attempt = 0;; attempt++) {
         if (r->done) HIP_TRY(hipEventSynchronize(r->done)); else HIP_TRY(hipStreamSynchronize(s));
+        if (r->ppm_stream && (int32_t)r->h_total.p[2] != 0) {
+            // An offsets batch held a haystack shorter than its min_hay_len promised (acx.h): the stream kernel saw more
+            // starts in a tile than it has room for and said so.  Its result is void; the same scan is issued again
+            // without the promise (the general kernel or the serial walks take it).
+            acx_scan_params p = r->pend_params;
+            p.min_hay_len = 0; p.flags &= ~(int32_t)ACX_SCAN_ASYNC;
+            acx_result* self = r;
+            return acx_scan_batch(r->pend_img, &p, &self, (void*)s);
+        }
         r->total = r->h_total.p[0];
         const bool overflow = (int32_t)r->h_total.p[1] != 0;
         const bool small = r->total > (int64_t)r->matches.cap;
@@ -527,9 +539,10 @@ static int ppm_enqueue(acx_result* r, acx_image* img, const acx_chunk_args* ca, 
         if (ca) HIP_TRY(acx_launch_hay_offsets(r->ck_first.p, r->ck_match_off.p, ca->n_hay, r->match_off.p, s));
     }
     if (r->timed_all) HIP_TRY(hipEventRecord(r->ev[3], g));
-    r->h_total.p[1] = 0;
+    r->h_total.p[1] = 0; r->h_total.p[2] = 0;
     HIP_TRY(hipMemcpyAsync(r->h_total.p, r->pend_item_off + (r->ppm_stream ? r->pend_ga.n_waves : ni), sizeof(int64_t), hipMemcpyDeviceToHost, g));
     HIP_TRY(hipMemcpyAsync(r->h_total.p + 1, r->ppm_ctl.p + 8, sizeof(int32_t), hipMemcpyDeviceToHost, g));
+    HIP_TRY(hipMemcpyAsync(r->h_total.p + 2, r->ppm_ctl.p + 9, sizeof(int32_t), hipMemcpyDeviceToHost, g));
     if (!r->done) HIP_TRY(hipEventCreateWithFlags(&r->done, hipEventDisableTiming));
     HIP_TRY(hipEventRecord(r->done, g));
     return ACX_OK;
@@ -559,11 +572,12 @@ static uint32_t ppm_halo_pos(const acx_ppm_header& ph) {         // whole words 
 // better (a tile's candidates are worked off before the next one is staged).
 static uint32_t ppm_stream_nsub(const acx_ppm_header& ph, uint32_t halo_pos, bool offs) {
     const uint32_t gw = ph.g_global ? 0u : ph.g_words;
-    static const uint32_t forced = [] { const char* v = getenv("ACX_PPM_NSUB"); const int x = v ? atoi(v) : 0; return (x == 2 || x == 4 || x == 8) ? (uint32_t)x : 0u; }();   // tuning hook
+    static const uint32_t forced = [] { const char* v = getenv("ACX_PPM_NSUB"); const int x = v ? atoi(v) : 0; return (x == 4 || x == 8) ? (uint32_t)x : 0u; }();   // tuning hook
     // (8-bit symbols with the filter in LDS and no second-level filter: 2048-position tiles measured slower than 1024,
     //  203 vs 218 GB/s — too many candidates per tile for the queue; with the second level: 353 vs 340)
     const uint32_t top = forced ? forced : ((ph.sym_bits == 8 && !ph.g_global && !ph.F2) ? 4u : 8u);
-    for (uint32_t nsub = top; nsub >= 2; nsub >>= 1) {
+    if (ph.pow2 && ph.sym_bits * ph.F < 5) return 0;               // (the stream kernel's probe: a code of at least 5 bits)
+    for (uint32_t nsub = top; nsub >= 4; nsub >>= 1) {
         if (acx_ppm_stream_layout(gw, ph.sym_bits, halo_pos, nsub, offs).total_words * 4 <= ACX_PPM_LDS_BYTES) return nsub;
     }
     return 0;
@@ -611,7 +625,7 @@ static int scan_ppm(acx_image_t* img, const acx_scan_params* p, acx_result* r, h
     if ((rc = r->ck_match_off.ensure(ni + 1))) return rc;
     if ((rc = r->partials.ensure((size_t)acx_scan_num_partials((int64_t)(ni > n ? ni : n)) + 2))) return rc;
     if ((rc = r->ppm_ctl.ensure(16))) return rc;
-    if ((rc = r->h_total.ensure(2))) return rc;
+    if ((rc = r->h_total.ensure(3))) return rc;
     if (r->has_final && (rc = r->final_state.ensure(n + 1))) return rc;
     if (r->matches.cap == 0 && (rc = r->matches.ensure((size_t)(p->hay_capacity / 8) + 1024))) return rc;
     if (chunked) {
@@ -630,16 +644,29 @@ static int scan_ppm(acx_image_t* img, const acx_scan_params* p, acx_result* r, h
     pa.ck = chunked ? r->ck.p : nullptr; pa.n_items_dev = chunked ? r->ck_first.p + p->n_hay : nullptr;
     pa.n_items = n_items;
     pa.cls = img->cls; pa.g = img->ppm_g; pa.cells = img->ppm_cells; pa.top_val = img->ppm_top_val;
-    pa.kids = img->ppm_kids; pa.kval = img->ppm_kval; pa.chains = img->ppm_chains; pa.n_branch = ph.n_deep;
+    pa.kids = img->ppm_kids; pa.chains = img->ppm_chains; pa.n_branch = ph.n_deep;
+    pa.hot = img->ppm_hot; pa.symtab = img->ppm_symtab; pa.sym_arith = ph.sym_arith; pa.sym_lut = ph.sym_lut;
     pa.K = ph.K; pa.sym_bits = ph.sym_bits; pa.pow2 = ph.pow2; pa.C = ph.C; pa.F = ph.F; pa.g_words = ph.g_words;
     pa.g2 = ((p->variant >> 20) & 1) ? nullptr : img->ppm_g2; pa.F2 = pa.g2 ? ph.F2 : 0u;      // (variant bit 20: without the second-level filter, A/B)
     pa.has_other = ph.has_other; pa.longest = ph.longest; pa.min_len = ph.min_len ? ph.min_len : 1;
     memcpy(pa.top_base, ph.top_base, sizeof pa.top_base);
     pa.lds = acx_ppm_lds_layout(ph.g_words, ph.sym_bits, ph.longest);
     pa.counts = r->counts.p; pa.scr_off = r->scr_off.p;
-    pa.heads = r->ppm_ctl.p; pa.overflow = (int32_t*)(r->ppm_ctl.p + 8);
+    pa.heads = r->ppm_ctl.p; pa.overflow = (int32_t*)(r->ppm_ctl.p + 8); pa.short_hay = (int32_t*)(r->ppm_ctl.p + 9);
     pa.hay_local = chunked ? nullptr : r->hay_local.p;
-    pa.dbg = (uint32_t)(p->variant >> 25) & 7u;
+    pa.dbg = 0;
+    if (const char* e = getenv("ACX_PPM_DBG")) pa.dbg = (uint32_t)atoi(e);
+    static unsigned long long* g_phase = nullptr;
+    if (getenv("ACX_PPM_PHASES")) {
+        if (!g_phase) { if (hipMalloc((void**)&g_phase, 64) != hipSuccess) g_phase = nullptr; }
+        if (g_phase) {
+            unsigned long long hph[8];
+            if (hipMemcpy(hph, g_phase, 64, hipMemcpyDeviceToHost) == hipSuccess && hph[7])
+                fprintf(stderr, "[phases of the previous scan, clocks summed over waves] stage+filter %llu push %llu fetch %llu tops %llu deep %llu place+records %llu rest %llu\n", hph[0], hph[1], hph[2], hph[3], hph[4], hph[5], hph[7]);
+            (void)hipMemset(g_phase, 0, 64);
+        }
+    }
+    pa.phase_out = g_phase;                      // development builds (-DACX_PPM_DEV): phase switches, timing only
     pa.halo_pos = ppm_halo_pos(ph);
     pa.fast = plan == 2;
     r->ppm_stream = pa.fast != 0;
@@ -713,7 +740,7 @@ static int scan_ppm(acx_image_t* img, const acx_scan_params* p, acx_result* r, h
         wa.cls = img->cls; wa.table = img->table; wa.row_bytes = img->h.n_classes * 4u; wa.state_bits = img->h.state_bits; wa.n_states = img->h.n_states;
         wa.final_state = r->final_state.p;
     }
-    r->pend_img = img;
+    r->pend_img = img; r->pend_params = *p;
     r->use_side = (p->flags & ACX_SCAN_ASYNC) != 0 && r->ppm_stream && !getenv("ACX_NO_SIDE_STREAM");
     if ((rc = ppm_enqueue(r, img, r->ppm_chunk ? &r->pend_cka : nullptr, r->has_final ? &r->pend_tail : nullptr, s))) return rc;
     r->pending = true; r->ppm = true;

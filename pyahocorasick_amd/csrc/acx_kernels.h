@@ -111,13 +111,16 @@ struct acx_ppm_args {
     int64_t n_items;                                         // tiles of a fixed-stride batch
     // image
     const uint8_t* cls; const uint32_t* g; const uint32_t* cells; const int32_t* top_val;
-    const uint32_t* kids; const int32_t* kval; const uint32_t* chains; uint32_t n_branch;
+    const uint32_t* kids; const uint32_t* chains; uint32_t n_branch;
+    const uint32_t* hot;     // k_ppm_stream: 8-byte hot cells
+    const uint8_t* symtab;   // byte -> symbol, 0xFF = a byte of no key
+    uint32_t sym_arith, sym_lut;   // K == 4: symbol = (byte >> (sym_arith - 1)) & 3, sym_lut = the four key bytes (0: table only)
     uint32_t K, sym_bits, pow2, C, F, g_words, has_other, longest, min_len;
     uint32_t top_base[ACX_PPM_MAX_C + 2];
     acx_ppm_lds lds;
     uint32_t fast;           // 1: k_ppm_stream (fixed stride >= 4, aligned buffer, bit-field codes, halo_pos <= 256)
     uint32_t dbg;            // tuning only (variant bits 25..27): 1 = no exact phase, 2 = no emit, 4 = no filter
-    uint32_t nsub;           // k_ppm_stream: sub-steps of 256 positions per tile (1, 2 or 4)
+    uint32_t nsub;           // k_ppm_stream: sub-steps of 256 positions per tile (4 or 8)
     uint32_t m24;            // k_ppm_stream: ceil(2^23 / stride) for strides below 2048 (a 24-bit multiply divides), else 0
     const int64_t* off; const int64_t* first_h;    // k_ppm_stream on an offsets batch: offsets, first haystack at or after every tile
     uint32_t g_global;       // the filter bitmap is read from global memory (not copied to LDS)
@@ -135,6 +138,8 @@ struct acx_ppm_args {
     uint32_t  reserve_cus;   // k_ppm_stream: CUs the grid leaves free (asynchronous scans: the gather of the previous batch runs there)
     uint64_t  pool_records;
     int32_t*  overflow;      // set when a sub-pool ran out: the host grows the pool and scans again
+    unsigned long long* phase_out;   // development builds: 8 clock sums over all waves (stage+filter, push, -, fetch, tops, deep, place+records, rest)
+    int32_t*  short_hay;     // k_ppm_stream on an offsets batch: set when a tile holds more haystack starts than min_hay_len >= 8 allows
     int32_t*  hay_local;     // fixed-stride batches: tile-local record offset of every haystack start
 };
 struct acx_ppm_compact_args {

@@ -165,6 +165,18 @@ int acx_ppm_build(const acx_trie* t, const uint8_t* cls, uint32_t n_classes, boo
         const uint32_t sigma = has_other ? n_classes - 1 : 256u;        // symbols = bytes that occur in keys
         if (sigma == 0) return ACX_OK;
         const uint32_t ho = has_other ? 1u : 0u;
+        // byte -> symbol: byte order (class - 1), or (byte >> s) & 3 where a shift tells exactly four key bytes apart
+        uint8_t symof[256];
+        uint32_t sym_arith = 0, sym_lut = 0;
+        for (int b = 0; b < 256; b++) symof[b] = (has_other && cls[b] == 0) ? 0xFFu : (uint8_t)(cls[b] - ho);
+        if (sigma == 4 && !getenv("ACX_PPM_NO_ARITH")) {
+            for (uint32_t sh = 0; sh <= 6 && !sym_arith; sh++) {
+                uint32_t seen = 0, lut = 0;
+                for (int b = 0; b < 256; b++) if (symof[b] != 0xFFu) { seen |= 1u << ((b >> sh) & 3); lut |= (uint32_t)b << (8 * ((b >> sh) & 3)); }
+                if (seen == 0xFu) { sym_arith = 1 + sh; sym_lut = lut; }
+            }
+            if (sym_arith) for (int b = 0; b < 256; b++) if (symof[b] != 0xFFu) symof[b] = (uint8_t)((b >> (sym_arith - 1)) & 3);
+        }
 
         const bool timing = getenv("ACX_PPM_TIMING") != nullptr;
         auto t0 = std::chrono::steady_clock::now();
@@ -194,7 +206,8 @@ int acx_ppm_build(const acx_trie* t, const uint8_t* cls, uint32_t n_classes, boo
         uint32_t C = 0;
         uint32_t cell_bits = 18;                                        // cells: 32 bytes each, at most 2^cell_bits of them
         if (const char* e = getenv("ACX_PPM_CELL_BITS")) { const int v = atoi(e); if (v >= 4 && v <= 22) cell_bits = (uint32_t)v; }   // tuning hook
-        while (C + 1 <= (uint32_t)max_depth && C + 1 <= max_syms && C + 1 <= 16 && ipow(C + 1) <= ((uint64_t)1 << cell_bits)) C++;
+        const uint32_t c_cap = h.sym_bits == 2 ? 12u : 16u;            // (the hot cell: eowmask beside the child bits)
+        while (C + 1 <= (uint32_t)max_depth && C + 1 <= max_syms && C + 1 <= c_cap && ipow(C + 1) <= ((uint64_t)1 << cell_bits)) C++;
         if (C == 0) return ACX_OK;
         const acx_ppm_lds base_layout = acx_ppm_lds_layout(0, h.sym_bits, h.longest);
         if (base_layout.total_words + 64 > ACX_PPM_LDS_BYTES / 4) return ACX_OK;
@@ -245,7 +258,7 @@ int acx_ppm_build(const acx_trie* t, const uint8_t* cls, uint32_t n_classes, boo
             if (nd.eow && (uint32_t)depth[u] < min_len) min_len = (uint32_t)depth[u];
             for (int32_t c = nd.first_child; c >= 0; c = rev.nodes[c].next_sibling) {
                 nkids[u]++;
-                if ((uint32_t)depth[u] < (F2 > F ? F2 : F)) code[c] = code[u] * sigma + (uint32_t)(cls[rev.nodes[c].letter] - ho);
+                if ((uint32_t)depth[u] < (F2 > F ? F2 : F)) code[c] = code[u] * sigma + (uint32_t)symof[rev.nodes[c].letter];
             }
         }
         h.min_len = min_len;
@@ -266,7 +279,7 @@ int acx_ppm_build(const acx_trie* t, const uint8_t* cls, uint32_t n_classes, boo
             int32_t v = c;
             while (len < max_syms && !rev.nodes[v].eow && nkids[v] == 1) {
                 v = rev.nodes[v].first_child; len++;
-                label |= (uint32_t)(cls[rev.nodes[v].letter] - ho) << (32 - h.sym_bits * len);
+                label |= (uint32_t)symof[rev.nodes[v].letter] << (32 - h.sym_bits * len);
             }
             (void)first;
             return v;
@@ -290,7 +303,7 @@ int acx_ppm_build(const acx_trie* t, const uint8_t* cls, uint32_t n_classes, boo
                     }
                 } else {
                     const int32_t c = rev.nodes[u].first_child;
-                    uint32_t len = 1, label = (uint32_t)(cls[rev.nodes[c].letter] - ho) << (32 - h.sym_bits);
+                    uint32_t len = 1, label = (uint32_t)symof[rev.nodes[c].letter] << (32 - h.sym_bits);
                     const int32_t v = path_end(c, len, label, 0);
                     if (nkids[v]) want(v);
                 }
@@ -308,16 +321,20 @@ int acx_ppm_build(const acx_trie* t, const uint8_t* cls, uint32_t n_classes, boo
         size_t off = sizeof h;
         h.off_g = off;        off = align256(off + (size_t)h.g_words * 4);
         if (F2) { h.off_g2 = off; off = align256(off + (size_t)h.g2_words * 4); }
+        h.sym_arith = sym_arith; h.sym_lut = sym_lut;
+        h.off_symtab = off;   off = align256(off + 256);
         h.off_cells = off;    off = align256(off + (size_t)nC * 32);
+        h.off_hot = off;      off = align256(off + (size_t)nC * 8);
         h.off_top_val = off;  off = align256(off + (size_t)h.n_top * 4);
         h.off_kids = off;     off = align256(off + (size_t)row_bytes);
-        h.off_kval = 0;
         h.off_chains = off;   off = align256(off + ((size_t)n_single + 1) * 16);
         h.total_bytes = off;
         uint8_t* sec = (uint8_t*)calloc(1, off);
         if (!sec) return acx_fail(ACX_E_NOMEM, "acx_ppm_build: cannot allocate %zu bytes", off);
         uint32_t* G = (uint32_t*)(sec + h.off_g);
         uint32_t* cells = (uint32_t*)(sec + h.off_cells);
+        uint32_t* hot = (uint32_t*)(sec + h.off_hot);
+        memcpy(sec + h.off_symtab, symof, 256);
         int32_t* top_val = (int32_t*)(sec + h.off_top_val);
         uint32_t* rows = (uint32_t*)(sec + h.off_kids);
         uint32_t* singles = (uint32_t*)(sec + h.off_chains);
@@ -359,7 +376,7 @@ int acx_ppm_build(const acx_trie* t, const uint8_t* cls, uint32_t n_classes, boo
             for (size_t b = lo; b < hi; b++) {
                 const int32_t u = row_nodes[b];
                 for (int32_t c = rev.nodes[u].first_child; c >= 0; c = rev.nodes[c].next_sibling) {
-                    const uint32_t s1 = (uint32_t)(cls[rev.nodes[c].letter] - ho);
+                    const uint32_t s1 = (uint32_t)symof[rev.nodes[c].letter];
                     uint32_t len = 0, label = 0;
                     const int32_t v = path_end(c, len, label, 1);
                     fill(rows + ((size_t)(b + 1) * sigma + s1) * 4, v, len, label);
@@ -370,7 +387,7 @@ int acx_ppm_build(const acx_trie* t, const uint8_t* cls, uint32_t n_classes, boo
             for (size_t k = lo; k < hi; k++) {
                 const int32_t u = single_nodes[k];
                 const int32_t c = rev.nodes[u].first_child;
-                uint32_t len = 1, label = (uint32_t)(cls[rev.nodes[c].letter] - ho) << (32 - h.sym_bits);
+                uint32_t len = 1, label = (uint32_t)symof[rev.nodes[c].letter] << (32 - h.sym_bits);
                 const int32_t v = path_end(c, len, label, 0);
                 fill(singles + (size_t)(k + 1) * 4, v, len, label);
             }
@@ -398,14 +415,24 @@ int acx_ppm_build(const acx_trie* t, const uint8_t* cls, uint32_t n_classes, boo
                 if (sigma <= 4) {
                     uint32_t w = 0;
                     for (int32_t c = rev.nodes[u].first_child; c >= 0; c = rev.nodes[c].next_sibling) {
-                        const uint32_t s1 = (uint32_t)(cls[rev.nodes[c].letter] - ho);
+                        const uint32_t s1 = (uint32_t)symof[rev.nodes[c].letter];
                         w |= 1u << s1;
                         if (rev.nodes[c].eow) w |= 1u << (4 + s1);
                         for (int32_t g = rev.nodes[c].first_child; g >= 0; g = rev.nodes[g].next_sibling)
-                            w |= 1u << (8 + s1 * 4 + (uint32_t)(cls[rev.nodes[g].letter] - ho));
+                            w |= 1u << (8 + s1 * 4 + (uint32_t)symof[rev.nodes[g].letter]);
                     }
                     cell[2] = w;
                 }
+            }
+            // the hot cell: the same facts in 8 bytes
+            {
+                uint32_t hw = mask, hx = mask ? cell[3] : 0u;
+                if (cell[1]) {
+                    hx = cell[1];
+                    if (h.sym_bits == 2) hw |= ((cell[2] >> 4) & 0xFu) << 12 | ((cell[2] >> 8) & 0xFFFFu) << 16;
+                    else hw |= 0x80000000u;
+                }
+                hot[cc * 2] = hw; hot[cc * 2 + 1] = hx;
             }
             if (F == C) { if (cell[0] | cell[1]) G[cc >> 5] |= 1u << (cc & 31); }
             else if (cell[0]) for (uint32_t s = 0; s < sigma; s++) { const uint64_t x = cc * sigma + s; G[x >> 5] |= 1u << (x & 31); }

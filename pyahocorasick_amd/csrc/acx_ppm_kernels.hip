@@ -33,6 +33,9 @@
 #define PPM_TILE  ACX_PPM_TILE
 #define PPM_GRANT 1024u            // records a wave takes from the scratch pool at a time
 #define PPM_NOBASE 0xFFFFFFFFu
+#ifndef ACX_PPM_NE
+#define ACX_PPM_NE 6               // k_ppm_stream: queue entries per lane and round (at most)
+#endif
 
 namespace {
 
@@ -56,6 +59,13 @@ __device__ __forceinline__ uint32_t div_magic(uint32_t e, uint64_t M, uint32_t d
     const uint32_t q = (uint32_t)(u >> 32);
     r = e - q * d;
     return q;
+}
+
+// the dword at byte b of a buffer of cap bytes that ends inside it (the last tile of a batch): out of line, it is cold
+__device__ __attribute__((noinline)) uint32_t load_dw_tail(const uint8_t* hay, int64_t cap, uint32_t b) {
+    uint32_t w = 0;
+    for (int k = 0; k < 4; k++) if ((int64_t)b + k < cap) w |= (uint32_t)hay[b + k] << (8 * k);
+    return w;
 }
 
 // wave64 exclusive prefix sum on the DPP network (row shifts, then the two row broadcasts gfx9 has):
@@ -230,10 +240,7 @@ template <int SB, bool POW2, bool CHUNK>
 __global__ void __launch_bounds__(ACX_PPM_BLOCK) k_ppm_scan(const acx_ppm_args a) {
     extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
     for (uint32_t i = threadIdx.x; i < a.g_words; i += blockDim.x) smem[a.lds.g_off + i] = a.g[i];
-    if (threadIdx.x < 256) {
-        const uint32_t cl = a.cls[threadIdx.x];
-        ((uint8_t*)(smem + a.lds.map_off))[threadIdx.x] = (a.has_other && cl == 0) ? 0xFFu : (uint8_t)(cl - a.has_other);
-    }
+    if (threadIdx.x < 256) ((uint8_t*)(smem + a.lds.map_off))[threadIdx.x] = a.symtab[threadIdx.x];   // (0xFF: a byte of no key)
     __syncthreads();
 
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
@@ -459,41 +466,57 @@ __global__ void __launch_bounds__(ACX_PPM_BLOCK) k_ppm_scan(const acx_ppm_args a
 
 // ---------------------------------------------------------------------------------------------------
 // Fast path (k_ppm_stream): fixed-stride batches and offset batches whose haystacks are at least 8 bytes long, a
-// 4-byte aligned buffer below 4 GiB, a halo of at most 256 positions.  Same image and the same match enumeration
-// (Ppm::matches) as k_ppm_scan; the structure around it is built for instruction count and for few dependent gathers,
-// which is what bounds this kernel:
+// 4-byte aligned buffer below 4 GiB, a halo of at most 256 positions.  Same image as k_ppm_scan.  What bounds it
+// (profiles/r3a_*): instruction issue — an integer instruction costs 1.2 (add, shift, and/or/xor) to 2 ns (everything
+// else) per wave and SIMD — and the rate at which the L2s take requests: every divergent lane of a gather is one,
+// ~260 G requests/s over the chip while the table fits an XCD's 4 MiB L2, half of that at 8 MiB.  So the structure is
+// built for few instructions per position, ONE 8-byte gather per candidate from a table that stays L2 resident, and
+// little code (the loop of a wave must stay in the instruction cache it shares with its neighbours):
 //   * a wave owns a contiguous RUN of tiles of NSUB x 256 positions; the left halo of a tile is what the previous
 //     tile left in LDS, so no byte is staged twice;
-//   * a lane owns 4 * NSUB CONTIGUOUS positions: their symbols stay in its registers, every window is a funnel shift by
-//     a constant, the filter is asked about the symbols as they stand (no offsets, masks or haystack boundaries: the
-//     rounds bound every match by the symbols that exist), the outcome is a pass word per lane;
+//   * a lane owns 4 * NSUB CONTIGUOUS positions.  Four-letter alphabets: bytes -> 2-bit symbols by shift, mask and
+//     one multiply per dword (no table lookup); a byte that is none of the four letters shows up as a mismatch against
+//     a byte permute of the letters;
+//   * the symbols stay in the lane's registers; a filter probe is two funnel shifts by constants, one LDS read and
+//     three more instructions; the filter is asked about the symbols as they stand (no offsets, masks or haystack
+//     boundaries: the rounds bound every match by the symbols that exist); the outcome is a pass word per lane;
 //   * the set bits of the pass words and of the words of haystack starts go into a ring queue in position order; the
-//     queue is worked off 64 entries at a time, or two / three per lane when it holds that many; the exclusive prefix
-//     of an entry that is a haystack start IS the record offset of its haystack;
+//     queue is worked off NE x 64 entries at a time (a ROUND).  An entry asks the 8-byte hot cell of its C newest
+//     symbols: which of them end keys, the value of the shallowest, whether the walk can go deeper.  The cells of the
+//     NEXT round are requested before this round's deeper walks start: their latencies hide behind each other;
 //   * each round counts, places (DPP prefix sums) and writes its records at once: the wave's records form one ordered
 //     stream, appended to grants of the scratch pool that the wave lists in its descriptor; k_ppm_gather copies the
-//     streams to their final place.
+//     streams to their final place.  The exclusive prefix of an entry that is a haystack start IS the record offset
+//     of its haystack.
 // ---------------------------------------------------------------------------------------------------
-#define PPM_QCAP 384u              // ring queue entries (uint16): at most 128 left over + the 256 positions of a sub-step
+#define PPM_QCAP 384u              // queue entries (uint16): 64 x NE, NE = 6 — a round takes them all
 #define PPM_DESC_WORDS 40u         // per wave: total, n_grants, 16 x base, 16 x count (+ pad)
 #define PPM_MAX_GRANTS 16u
 
-// OFFS: the batch is given by a device offsets array instead of a fixed stride (ragged packets, one long
-//       haystack).  Contract: no haystack shorter than 8 bytes (acx_scan_params.min_hay_len), as with a stride of
-//       at least 8: a tile holds at most TPOS / 8 starts.  They come from first_h[] (k_ppm_first_h: one binary
-//       search per tile) and live in LDS as a bitmap with per-word "last start" and "starts before" tables.
-// POW2: codes are plain bit fields of the window; otherwise Horner in radix K over its symbols.
-// GG:   the filter bitmap is read from global memory (wide alphabets: one level deeper than LDS could hold).
-template <int SB, int NSUB, bool POW2, bool OFFS, bool GG>
+// OFFS:  the batch is given by a device offsets array instead of a fixed stride (ragged packets, one long
+//        haystack).  Contract: off[0] = 0 and no haystack shorter than 8 bytes (acx_scan_params.min_hay_len), as with a
+//        stride of at least 8: a tile holds at most TPOS / 8 starts.  A tile that has more raises a.short_hay and the
+//        host issues the scan again on the general kernel.  The starts come from first_h[] (k_ppm_first_h: one binary
+//        search per tile) and live in LDS as a bitmap with per-word "last start" and "starts before" tables.
+// POW2:  codes are plain bit fields of the window; otherwise Horner in radix K over its symbols.
+// GG:    the filter bitmap is read from global memory (wide alphabets: one level deeper than LDS could hold).
+// ARITH: SB == 2, four letters that a shift tells apart: symbol = (byte >> shift) & 3.
+// M24:   fixed stride below 2048: a position's haystack by a 24-bit multiply; else (stride >= 2048) by a compare.
+// NE:    queue entries per lane and round.
+// (Wave-uniform facts that the slots of a round depend on are template parameters or select a copy of the round: a
+//  branch between two slots, even one that never diverges, keeps the scheduler from overlapping their LDS reads.)
+template <int SB, int NSUB, bool POW2, bool OFFS, bool GG, bool ARITH, bool M24, int NE>
 __global__ void __launch_bounds__(ACX_PPM_BLOCK) k_ppm_stream(const acx_ppm_args a) {
     extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
+    static_assert(!ARITH || (SB == 2 && POW2), "arithmetic symbols: four letters");
     if (!GG) for (uint32_t i = threadIdx.x; i < a.g_words; i += blockDim.x) smem[a.lds.g_off + i] = a.g[i];
     if (threadIdx.x < 256) {
-        const uint32_t cl = a.cls[threadIdx.x];
         // a byte of no key: 0xFF with 8-bit symbols (staged as symbol 0 by convert), 0x80 with narrower ones — its
         // symbol bits are 0 then, which keeps every staged field below K (the filter reads windows unmasked)
-        ((uint8_t*)(smem + a.lds.map_off))[threadIdx.x] = (a.has_other && cl == 0) ? (SB == 8 ? 0xFFu : 0x80u) : (uint8_t)(cl - a.has_other);
+        const uint32_t sy = a.symtab[threadIdx.x];
+        ((uint8_t*)(smem + a.lds.map_off))[threadIdx.x] = sy == 0xFFu ? (SB == 8 ? 0xFFu : 0x80u) : (uint8_t)sy;
     }
+    if (threadIdx.x < ACX_PPM_MAX_C + 2) smem[a.lds.map_off + 64 + threadIdx.x] = a.top_base[threadIdx.x];
     __syncthreads();
 
     constexpr uint32_t SPW = 32 / SB;                                  // symbols per word
@@ -501,16 +524,18 @@ __global__ void __launch_bounds__(ACX_PPM_BLOCK) k_ppm_stream(const acx_ppm_args
     constexpr uint32_t TW = TPOS / SPW;                                // words of a tile's symbols
     constexpr uint32_t BW = TPOS / 32;                                 // words of the start bitmap
     constexpr uint32_t SMASK = (1u << SB) - 1u;
-    constexpr uint32_t PPL = TPOS / 64;                                // positions per lane: 16 or 8, contiguous
+    constexpr uint32_t PPL = TPOS / 64;                                // positions per lane: 32 or 16, contiguous
     constexpr uint32_t DPL = PPL / 4;                                  // haystack dwords per lane
-    constexpr uint32_t OWN = PPL * SB;                                 // bits of packed symbols a lane makes: 16 .. 128
-    constexpr uint32_t OW = OWN >= 32 ? OWN / 32 : 1;                  // ... in words
+    constexpr uint32_t OWN = PPL * SB;                                 // bits of packed symbols a lane makes: 32 .. 256
+    constexpr uint32_t OW = OWN / 32;                                  // ... in words
     constexpr uint32_t LPS = 256 / PPL;                                // lanes of a sub-step (256 positions)
+    static_assert(OWN >= 32 && DPL >= 4, "tiles of 1024 or 2048 positions");
     const int lane = threadIdx.x & 63;
     const int wid = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));   // (wave-uniform, and the compiler is told so)
     Ppm<SB, POW2, false> P(a);
     P.s_g = GG ? a.g : smem + a.lds.g_off;
     P.s_map = (const uint8_t*)(smem + a.lds.map_off);
+    const uint32_t* const s_tb = smem + a.lds.map_off + 64;            // top_base[]
     uint32_t* wbase = smem + a.lds.wave_off + (uint32_t)wid * a.lds.wave_words;
     uint32_t* const sym = wbase;                                       // [0,1] pad, halo words, tile words, pad
     P.s_sym = wbase + 1;                                               // (Ppm counts one pad word)
@@ -527,7 +552,7 @@ __global__ void __launch_bounds__(ACX_PPM_BLOCK) k_ppm_stream(const acx_ppm_args
     P.T.q0 = HP; P.T.halo = 0; P.T.idx_first = 0; P.T.ndw = 0; P.T.abase = nullptr; P.T.e0 = 0; P.T.npos = 0; P.has_other = 0;
 
     // the batch: H bytes, cut into tiles; a wave takes a contiguous run of them
-    const uint32_t stride = (uint32_t)a.stride;
+    const uint32_t stride = (uint32_t)a.stride, m24 = a.m24;
     uint32_t H;
     if (OFFS) H = (uint32_t)a.off[a.n_hay]; else H = (uint32_t)(a.n_hay * a.stride - 1) + 1u;   // (the launcher checks the size)
     const int64_t n_tiles = OFFS ? a.n_items : ((int64_t)H + TPOS - 1) / TPOS;
@@ -545,19 +570,27 @@ __global__ void __launch_bounds__(ACX_PPM_BLOCK) k_ppm_stream(const acx_ppm_args
     // x = offset-in-haystack of the tile's first position + a position of the tile: haystacks crossed, new offset
     auto divmod = [&](uint32_t x, uint32_t& r) -> uint32_t {
         uint32_t q;
-        if (a.m24) { q = (uint32_t)__umul24(x, a.m24) >> 23; r = x - (uint32_t)__umul24(q, stride); }   // stride < 2048: exact for x < stride + 2048
+        if (M24) { q = (uint32_t)__umul24(x, m24) >> 23; r = x - (uint32_t)__umul24(q, stride); }   // stride < 2048: exact for x < stride + 2048
         else { q = x >= stride ? 1u : 0u; r = x - (q ? stride : 0u); }   // stride >= 2048: one haystack start per tile at most
         return q;                                                      // (24-bit multiplies: full rate; the cast: a logical shift)
     };
     auto load_dw = [&](uint32_t b) -> uint32_t {                      // the dword at byte b of the buffer (b is a multiple of 4)
-        uint32_t w = 0;
-        if ((int64_t)b + 4 <= a.hay_cap) w = *(const uint32_t*)(a.hay + b);
-        else for (int k = 0; k < 4; k++) if ((int64_t)b + k < a.hay_cap) w |= (uint32_t)a.hay[b + k] << (8 * k);
-        return w;
+        if ((int64_t)b + 4 <= a.hay_cap) return *(const uint32_t*)(a.hay + b);
+        return load_dw_tail(a.hay, a.hay_cap, b);
     };
-    auto convert = [&](uint32_t w, uint32_t& nib) -> uint32_t {       // bytes -> packed symbols; nib: bytes that occur in no key
-        uint32_t packed = 0, seen = 0;
+    // bytes -> packed symbols (4 x SB bits); nib: which of the four bytes occur in no key
+    const uint32_t ar_shift = ARITH ? a.sym_arith - 1u : 0u, ar_lut = a.sym_lut;
+    auto convert = [&](uint32_t w, uint32_t& nib) -> uint32_t {
         nib = 0;
+        if (ARITH) {
+            // symbol = (byte >> shift) & 3; the four letters permuted by the symbols give the bytes back iff all four are
+            // letters; one multiply gathers the four 2-bit fields into the top byte (no two partial products overlap)
+            const uint32_t x = (w >> ar_shift) & 0x03030303u;
+            const uint32_t d = __builtin_amdgcn_perm(0u, ar_lut, x) ^ w;
+            if (d) nib = ((d & 0xFFu) ? 1u : 0u) | ((d & 0xFF00u) ? 2u : 0u) | ((d & 0xFF0000u) ? 4u : 0u) | ((d >> 24) ? 8u : 0u);
+            return (x * 0x01041040u) >> 24;
+        }
+        uint32_t packed = 0, seen = 0;
 #pragma unroll
         for (int k = 0; k < 4; k++) {
             const uint32_t sv = P.s_map[(w >> (8 * k)) & 0xFFu];
@@ -582,7 +615,7 @@ __global__ void __launch_bounds__(ACX_PPM_BLOCK) k_ppm_stream(const acx_ppm_args
         const uint32_t last = m ? 32u * w + (31u - (uint32_t)__clz(m)) + 1u : 0u;
         return q + 1 - last;
     };
-    // code of the n newest symbols of a (masked) window
+    // code of the n newest symbols of a window
     auto code_n = [&](uint32_t Xm, uint32_t n) -> uint32_t {
         if (POW2) return Xm >> (32 - SB * n);
         uint32_t c = 0;
@@ -590,6 +623,10 @@ __global__ void __launch_bounds__(ACX_PPM_BLOCK) k_ppm_stream(const acx_ppm_args
         return c;
     };
 
+#ifdef ACX_PPM_DEV
+    // experiment: waves of one SIMD (w, w + 4, w + 8, w + 12) start a quarter of a tile period apart
+    { const uint32_t st = (a.dbg >> 8) & 0xFFu; for (uint32_t i = 0; i < st * ((uint32_t)wid >> 2); i++) __builtin_amdgcn_s_sleep(32); }
+#endif
     // ---- prologue: the halo of the run's first tile -----------------------------------------
     uint32_t e0 = (uint32_t)(t_begin * TPOS);
     uint32_t any_prev = 0;
@@ -605,19 +642,17 @@ __global__ void __launch_bounds__(ACX_PPM_BLOCK) k_ppm_stream(const acx_ppm_args
     }
     uint32_t h_tile = 0, r_tile = 0;                                   // STRIDE: haystack of the tile's first byte, its offset in it
     if (!OFFS) {
-        uint32_t rr; h_tile = div_magic(e0, a.stride_magic, stride, rr); r_tile = rr;
+        uint32_t rr0; h_tile = div_magic(e0, a.stride_magic, stride, rr0); r_tile = rr0;
         h_tile = (uint32_t)__builtin_amdgcn_readfirstlane((int)h_tile); r_tile = (uint32_t)__builtin_amdgcn_readfirstlane((int)r_tile);
     }
-    // a lane's PPL bytes of a tile (contiguous: vector loads)
+    // a lane's PPL bytes of a tile (contiguous: 16-byte loads; read once: they need not stay in the caches)
     auto load_lane = [&](uint32_t b, uint32_t (&w)[DPL]) {
         if ((int64_t)b + PPL <= a.hay_cap) {
-            if (DPL >= 4) {
 #pragma unroll
-                for (int j = 0; j < (int)DPL / 4; j++) {
-                    const u32x4a v = *(const u32x4a*)(a.hay + b + 16u * j);
-                    w[(4 * j) % DPL] = v.x; w[(4 * j + 1) % DPL] = v.y; w[(4 * j + 2) % DPL] = v.z; w[(4 * j + 3) % DPL] = v.w;
-                }
-            } else { const u32x2a v = *(const u32x2a*)(a.hay + b); w[0] = v.x; w[1 % DPL] = v.y; }
+            for (int j = 0; j < (int)DPL / 4; j++) {
+                const u32x4a v = __builtin_nontemporal_load((const u32x4a*)(a.hay + b + 16u * j));
+                w[4 * j] = v.x; w[4 * j + 1] = v.y; w[4 * j + 2] = v.z; w[4 * j + 3] = v.w;
+            }
         } else {
 #pragma unroll
             for (int j = 0; j < (int)DPL; j++) w[j] = load_dw(b + 4u * j);
@@ -631,29 +666,61 @@ __global__ void __launch_bounds__(ACX_PPM_BLOCK) k_ppm_stream(const acx_ppm_args
     uint32_t run_off = 0;                                              // records so far
     uint32_t g_base = 0, g_size = 0, g_used = 0, ng = 0;               // current grant of the pool
     bool dead = false;                                                 // pool or grant list exhausted: keep counting, stop writing
-    uint32_t qhead = 0, qtail = 0, qcount = 0;
+    uint32_t qcount = 0;
+    static_assert(64 * NE == PPM_QCAP, "a round takes the whole queue");
+    const uint32_t Cn = a.C;
+    const uint32_t cmask = (1u << Cn) - 1u;                            // (C <= 16)
+    const uint32_t longest = a.longest;
 
+#ifdef ACX_PPM_PHASES
+    unsigned long long ph[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tph = __builtin_amdgcn_s_memtime();
+#define PH(i) do { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); ph[i] += t_ - tph; tph = t_; } while (0)
+#elif defined(ACX_PPM_MARK)
+#define PH(i) asm volatile("; MARK " #i)
+#else
+#define PH(i) do { } while (0)
+#endif
     for (int64_t tile = t_begin; tile < t_end; tile++) {
         if (e0 >= H) break;
+        PH(7);
         const uint32_t left = H - e0;
         const uint32_t npos = left < TPOS ? left : TPOS;
         // ---- stage (and request the next tile's bytes) ---------------------------------------------
         // W[0]: the 32 bits of symbols in front of the lane's own (read back from LDS below), W[1..]: its own
         uint32_t anyo = 0;                                             // which of the lane's positions hold a byte of no key
-        uint32_t nibs[DPL];
-        uint32_t W[OW + 1];
+        uint32_t W[OW + 2];
 #pragma unroll
-        for (int k = 0; k <= (int)OW; k++) W[k] = 0;
+        for (int k = 0; k <= (int)OW + 1; k++) W[k] = 0;
+        if (ARITH) {
+            // four dwords (16 positions) make one word of symbols: the top bytes of the four products
+            uint32_t diff = 0;
 #pragma unroll
-        for (int j = 0; j < (int)DPL; j++) {
-            const uint32_t packed = convert(wnext[j], nibs[j]);
-            W[1 + (4 * SB * j) / 32] |= packed << ((4 * SB * j) & 31);
-            anyo |= nibs[j] << (4 * j);
+            for (int g = 0; g < (int)DPL / 4; g++) {
+                uint32_t pr[4];
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    const uint32_t w = wnext[4 * g + j];
+                    const uint32_t x = (w >> ar_shift) & 0x03030303u;
+                    diff |= __builtin_amdgcn_perm(0u, ar_lut, x) ^ w;
+                    pr[j] = x * 0x01041040u;
+                }
+                W[1 + g] = __builtin_amdgcn_perm(pr[1], pr[0], 0x0c0c0703u) | __builtin_amdgcn_perm(pr[3], pr[2], 0x07030c0cu);
+            }
+            if (__any(diff != 0u)) {                                   // some byte of the tile is none of the four letters
+#pragma unroll
+                for (int j = 0; j < (int)DPL; j++) { uint32_t nb; (void)convert(wnext[j], nb); anyo |= nb << (4 * j); }
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < (int)DPL; j++) {
+                uint32_t nb;
+                const uint32_t packed = convert(wnext[j], nb);
+                W[1 + (4 * SB * j) / 32] |= packed << ((4 * SB * j) & 31);
+                anyo |= nb << (4 * j);
+            }
         }
-        if (OWN >= 32) {
 #pragma unroll
-            for (int k = 0; k < (int)OW; k++) ((uint32_t*)sym_tile_bytes)[OW * lane + k] = W[1 + k];
-        } else ((uint16_t*)sym_tile_bytes)[lane] = (uint16_t)W[1];
+        for (int k = 0; k < (int)OW; k++) ((uint32_t*)sym_tile_bytes)[OW * lane + k] = W[1 + k];
         if (tile + 1 < t_end) load_lane(e0 + TPOS + PPL * (uint32_t)lane, wnext);
         // OFFS: the haystack starts of this tile -> bitmap, last-start and count tables
         uint32_t hbase = 0, base_r = 0;                                // haystack covering the tile's first byte; that byte's offset in it
@@ -662,7 +729,10 @@ __global__ void __launch_bounds__(ACX_PPM_BLOCK) k_ppm_stream(const acx_ppm_args
             fh_next = a.first_h[tile + 1];
             int64_t fe = fh_next < a.n_hay ? fh_next : a.n_hay;
             uint32_t m = fe > fh ? (uint32_t)(fe - fh) : 0u;
-            if (m > TPOS / 8) m = TPOS / 8;                             // (the contract: no haystack shorter than 8 bytes)
+            if (m > TPOS / 8) {                                         // the contract is broken (a haystack shorter than 8 bytes):
+                m = TPOS / 8;                                           // say so; the host scans again on the general kernel
+                if (lane == 0) *a.short_hay = 1;
+            }
             if ((uint32_t)lane < BW) sbits[lane] = 0;
             wave_sync();
             for (uint32_t j = lane; j < m; j += 64) {
@@ -679,18 +749,16 @@ __global__ void __launch_bounds__(ACX_PPM_BLOCK) k_ppm_stream(const acx_ppm_args
                 for (int d = 1; d < 64; d <<= 1) { const uint32_t t = __shfl_up(last, d, 64); if (lane >= d && t > last) last = t; }
                 if ((uint32_t)lane < BW) { slast[lane] = (uint16_t)last; scnt[lane] = (uint16_t)before; }
             }
-            hbase = (uint32_t)(fh - 1);                                 // (fh = 0: wraps; every position of that tile has rank >= 1)
+            hbase = (uint32_t)(fh - 1);                                 // (fh = 0: wraps; off[0] = 0, so every position of that tile has rank >= 1)
             base_r = fh > 0 ? (uint32_t)((int64_t)e0 - a.off[fh - 1]) : 0u;
         }
         const uint32_t any_cur = a.has_other && __any(anyo != 0) ? 1u : 0u;
         const uint32_t use_other = any_cur | any_prev;
         if (PPL == 32) obits_tile[lane] = anyo;
-        else if (PPL == 16) ((uint16_t*)obits_tile)[lane] = (uint16_t)anyo;
-        else ((uint8_t*)obits_tile)[lane] = (uint8_t)anyo;
+        else ((uint16_t*)obits_tile)[lane] = (uint16_t)anyo;
         wave_sync();
 
-        // where position p (a multiple of 4 for the filter) sits: its offset in its haystack, and — OFFS — how many
-        // haystacks start at or before it
+        // where position p sits: its offset in its haystack, and how many haystacks start at or before it
         auto where = [&](uint32_t p, uint32_t& r, uint32_t& rank) {
             if (!OFFS) { rank = divmod(r_tile + p, r); return; }
             const uint32_t w = p >> 5;
@@ -707,54 +775,87 @@ __global__ void __launch_bounds__(ACX_PPM_BLOCK) k_ppm_stream(const acx_ppm_args
         // bytes of no key (staged as symbol 0) included: that can only add candidates (a key of length l needs
         // its own l symbols only, and G says yes for any older ones), and the rounds below bound every match
         // by the symbols that really exist.
-        if (OWN >= 32) W[0] = ((const uint32_t*)sym_tile_bytes)[(int)(OW * lane) - 1];
-        else W[0] = ((uint32_t)((const uint16_t*)sym_tile_bytes)[lane - 1] << 16) | ((const uint16_t*)sym_tile_bytes)[lane - 2];
+        W[0] = ((const uint32_t*)sym_tile_bytes)[(int)(OW * lane) - 1];
         uint32_t pw = 0;                                               // positions that pass
-        // Second-level filter (optional: include/acx_blob.h "G2"): a position that passes G is asked again with F2 > F
-        // symbols in a bitmap in global memory (L2 resident) before it costs a queue entry, a cell gather and the
-        // dependent gathers of the deeper walk.  Its code extends the first one by the older symbols, which sit in the
-        // lane's registers too (Wm: the second word in front of its own); the probe is issued only where G said yes.
-        const uint32_t F2 = (OWN >= 32 && !GG) ? a.F2 : 0u;             // (a filter in global memory has no second level)
-        uint32_t Wm = 0;
-        if (F2) Wm = ((const uint32_t*)sym_tile_bytes)[(int)(OW * lane) - 2];
-        auto old_sym = [&](int p, int d) -> uint32_t {                // the symbol d positions before the lane's position p (p, d: constants)
-            const int b = (int)SB * (p - d);                           // its bit offset from the lane's first symbol
-            const uint32_t word = b >= 0 ? W[1 + b / 32] : (b >= -32 ? W[0] : Wm);
-            return __builtin_amdgcn_ubfe(word, (uint32_t)(b & 31), (uint32_t)SB);
-        };
+#ifdef ACX_PPM_DEV
+        if (a.dbg & 16u) { pw = W[1] & W[2 <= OW ? 2 : 1]; } else       // timing only: no filter
+#endif
+        if (POW2) {
+            // The stream of the lane: W[0] (32 older bits), W[1..OW].  Symbol i ends at stream bit 32 + SB (i + 1) and the code
+            // of the F newest symbols is the FB = SB F bits below that.  U = the stream shifted right by 32 - FB (a
+            // wave-uniform amount, once per tile): now the code of position i starts at the CONSTANT bit SB (i + 1) of U.  Its
+            // word index, times 4 (the byte address in the bitmap), is a funnel shift of U by a constant and a mask; its bit
+            // index is the low 5 bits of another (a shift reads no more of its amount); the pass bit enters the accumulator
+            // from the top, so that after PPL of them position i sits at bit i.
+            const uint32_t FB = SB * a.F;                              // 5 .. 24 bits (the launcher checks)
+            const uint32_t amask = ((1u << (FB - 5u)) - 1u) << 2;
+            const uint32_t ush = 32u - FB;
+            uint32_t U[OW + 3];
 #pragma unroll
-        for (int i0 = 0; i0 < (int)PPL; i0 += 16) {                    // (16 probes in flight at a time: registers)
-            constexpr int NB = PPL < 16 ? (int)PPL : 16;
-            uint32_t gw[NB], cf[NB];
+            for (int k = 0; k < (int)OW; k++) U[k] = __builtin_amdgcn_alignbit(W[k + 1], W[k], ush);
+            U[OW] = W[OW] >> ush; U[OW + 1] = 0; U[OW + 2] = 0;
+            uint32_t acc = 0;
 #pragma unroll
-            for (int i = 0; i < NB; i++) {
-                const uint32_t e = SB * (i0 + i + 1), k = e >> 5, sh = e & 31u;
-                const uint32_t X = sh ? __builtin_amdgcn_alignbit(W[k + 1 <= OW ? k + 1 : OW], W[k], sh) : W[k];
-                cf[i] = code_n(X, a.F);
-                gw[i] = P.s_g[cf[i] >> 5];
-            }
-            uint32_t pm = 0;
+            for (int i0 = 0; i0 < (int)PPL; i0 += 16) {                // (16 probes in flight at a time: registers)
+                uint32_t gw[16], bs[16];
 #pragma unroll
-            for (int i = 0; i < NB; i++) pm |= __builtin_amdgcn_ubfe(gw[i], cf[i], 1u) << i;
-            if (F2) {
-#pragma unroll
-                for (int i = 0; i < NB; i++) {
-                    uint32_t c2 = cf[i];
-#pragma unroll
-                    for (int d = (int)SPW; d < 2 * (int)SPW; d++)       // (G2 exists only where F fills the window: F = SPW; two words of older symbols are at hand)
-                        if ((uint32_t)d < F2) c2 = (uint32_t)__umul24(c2, a.K) + old_sym(i0 + i, d);   // (codes stay below 2^25: 24-bit multiply)
-                    cf[i] = c2;
-                    gw[i] = 0xFFFFFFFFu;
-                    if ((pm >> i) & 1u) gw[i] = a.g2[c2 >> 5];
+                for (int i = 0; i < 16; i++) {
+                    const uint32_t b = SB * (uint32_t)(i0 + i + 1), k = b >> 5, sh = b & 31u;    // (constants after unrolling)
+                    bs[i] = sh ? __builtin_amdgcn_alignbit(U[k + 1], U[k], sh) : U[k];      // the code, and above it newer symbols
+                    const uint32_t A = (bs[i] >> 3) & amask;
+                    gw[i] = GG ? *(const uint32_t*)((const uint8_t*)a.g + A) : *(const uint32_t*)((const uint8_t*)smem + A);   // (the bitmap is the first thing in LDS: g_off = 0)
                 }
 #pragma unroll
-                for (int i = 0; i < NB; i++) pm &= ~((__builtin_amdgcn_ubfe(gw[i], cf[i], 1u) ^ 1u) << i);
+                for (int i = 0; i < 16; i++) acc = __builtin_amdgcn_alignbit(gw[i] >> (bs[i] & 31u), acc, 1u);
             }
-            pw |= pm << i0;
+            pw = PPL == 32 ? acc : acc >> (32 - PPL);
+        } else {
+            // Horner codes; optional second-level filter (include/acx_blob.h "G2"): a position that passes G is asked again
+            // with F2 > F symbols in a bitmap in global memory (L2 resident) before it costs a queue entry.  Its code
+            // extends the first one by the older symbols, which sit in the lane's registers too (Wm: the second word in
+            // front of its own); the probe is issued only where G said yes.
+            const uint32_t F2 = !GG ? a.F2 : 0u;                        // (a filter in global memory has no second level)
+            uint32_t Wm = 0;
+            if (F2) Wm = ((const uint32_t*)sym_tile_bytes)[(int)(OW * lane) - 2];
+            auto old_sym = [&](int p, int d) -> uint32_t {            // the symbol d positions before the lane's position p (p, d: constants)
+                const int b = (int)SB * (p - d);                       // its bit offset from the lane's first symbol
+                const uint32_t word = b >= 0 ? W[1 + b / 32] : (b >= -32 ? W[0] : Wm);
+                return __builtin_amdgcn_ubfe(word, (uint32_t)(b & 31), (uint32_t)SB);
+            };
+#pragma unroll
+            for (int i0 = 0; i0 < (int)PPL; i0 += 16) {
+                uint32_t gw[16], cf[16];
+#pragma unroll
+                for (int i = 0; i < 16; i++) {
+                    const uint32_t e = SB * (i0 + i + 1), k = e >> 5, sh = e & 31u;
+                    const uint32_t X = sh ? __builtin_amdgcn_alignbit(W[k + 1], W[k], sh) : W[k];
+                    cf[i] = code_n(X, a.F);
+                    gw[i] = P.s_g[cf[i] >> 5];
+                }
+                uint32_t pm = 0;
+#pragma unroll
+                for (int i = 0; i < 16; i++) pm |= __builtin_amdgcn_ubfe(gw[i], cf[i], 1u) << i;
+                if (F2) {
+#pragma unroll
+                    for (int i = 0; i < 16; i++) {
+                        uint32_t c2 = cf[i];
+#pragma unroll
+                        for (int d = (int)SPW; d < 2 * (int)SPW; d++)       // (G2 exists only where F fills the window: F = SPW; two words of older symbols are at hand)
+                            if ((uint32_t)d < F2) c2 = (uint32_t)__umul24(c2, a.K) + old_sym(i0 + i, d);   // (codes stay below 2^25: 24-bit multiply)
+                        cf[i] = c2;
+                        gw[i] = 0xFFFFFFFFu;
+                        if ((pm >> i) & 1u) gw[i] = a.g2[c2 >> 5];
+                    }
+#pragma unroll
+                    for (int i = 0; i < 16; i++) pm &= ~((__builtin_amdgcn_ubfe(gw[i], cf[i], 1u) ^ 1u) << i);
+                }
+                pw |= pm << i0;
+            }
         }
+        PH(0);                                                           // stage + filter
         // haystack starts among the lane's positions
         uint32_t sw = 0;
-        if (OFFS) sw = PPL == 32 ? sbits[lane] : (PPL == 16 ? ((const uint16_t*)sbits)[lane] : ((const uint8_t*)sbits)[lane]);
+        if (OFFS) sw = PPL == 32 ? sbits[lane] : ((const uint16_t*)sbits)[lane];
         else {
             uint32_t r;
             (void)divmod(r_tile + PPL * (uint32_t)lane, r);
@@ -769,193 +870,285 @@ __global__ void __launch_bounds__(ACX_PPM_BLOCK) k_ppm_stream(const acx_ppm_args
             pw &= vm & ~anyo;                                          // (a byte of no key ends no key)
             sw &= vm;
         }
-        // ---- expansion: candidates and haystack starts -> the queue, in position order; then full rounds -----
-        // Everything at once when the queue has the room (the usual case), else a sub-step (256 positions) at a time.
+        // ---- expansion: candidates and haystack starts -> the queue, in position order; then a round -----
+        // Everything at once when the queue has the room (the usual case), else a sub-step (256 positions) at a time,
+        // with a round in between when the next sub-step does not fit.
         uint32_t xw = pw | sw, x_tot;
         const uint32_t x_ex = wave_excl_scan((uint32_t)__popc(xw), x_tot);
-        uint32_t seg_lo = 0;
-        while (seg_lo < 64u) {
-            const uint32_t ex_lo = seg_lo ? (uint32_t)__builtin_amdgcn_readlane((int)x_ex, (int)seg_lo) : 0u;
-            uint32_t seg_hi = 64u, n_seg = x_tot - ex_lo;
-            if (n_seg > PPM_QCAP - qcount) { seg_hi = seg_lo + LPS; n_seg = (seg_hi < 64u ? (uint32_t)__builtin_amdgcn_readlane((int)x_ex, (int)seg_hi) : x_tot) - ex_lo; }
-            {
-                uint32_t w = ((uint32_t)lane >= seg_lo && (uint32_t)lane < seg_hi) ? xw : 0u;
-                uint32_t j = qtail + (x_ex - ex_lo); if (j >= PPM_QCAP) j -= PPM_QCAP;
-                while (__any(w != 0u)) {
-                    if (w) {
-                        const uint32_t b = (uint32_t)__builtin_ctz(w);
-                        w &= w - 1u;
-                        queue[j] = (uint16_t)((PPL * (uint32_t)lane + b) | (((pw >> b) & 1u) ? 0u : 0x8000u));     // 0x8000: a start that is no candidate
-                        j = j + 1 == PPM_QCAP ? 0 : j + 1;
+
+        // ---- a round: every entry of the queue (n <= 64 NE, in position order).  Lane l owns entries l, 64 + l, ..: k = ceil(n / 64)
+        // of them (a store of one slot's records covers consecutive addresses); the hot cells of all its entries are requested
+        // before the first is looked at; the walks below the cells — one entry in six asks for one — are collected over the
+        // whole round and run on all 64 lanes at once, their entries handed over through the queue's memory, which is
+        // free by then.  Straight-line code per entry slot; slots >= k are skipped (wave-uniform).
+        auto do_round = [&]() {
+            const uint32_t n = qcount;
+            uint32_t pp[NE], XX[NE], rr[NE], LL[NE], cn[NE];
+            u32x2 hc[NE];
+            int32_t va[NE], vb[NE];
+            // 0. bytes of no key around (rare): the symbols that exist going back from every entry.  Done apart from the
+            // slots below, which must stay one basic block: a branch between two of them, even one that never diverges,
+            // keeps the scheduler from overlapping their LDS reads.
+#pragma unroll
+            for (int e = 0; e < NE; e++) LL[e] = longest;
+            if (use_other) {
+#pragma unroll
+                for (int e = 0; e < NE; e++) {
+                    const uint32_t qi = 64u * (uint32_t)e + (uint32_t)lane;
+                    const uint32_t lo2 = other_limit(HP + (qi < n ? (uint32_t)queue[qi] & 0x7FFFu : 0u));
+                    if (lo2 < LL[e]) LL[e] = lo2;
+                }
+            }
+            // 1. where the entries sit, their windows, the requests for their hot cells.  Straight-line over all NE slots
+            // (a slot beyond the queue's end works on position 0 with L = 0, which matches nothing): the LDS reads and
+            // the gathers of the slots overlap.
+#pragma unroll
+            for (int e = 0; e < NE; e++) {
+                const uint32_t qi = 64u * (uint32_t)e + (uint32_t)lane;
+                const bool act = qi < n;
+                uint32_t ent = queue[qi];                                // (within the queue's memory for any qi < 64 NE)
+                ent = act ? ent : 0x18000u;                              // bit 15: no candidate, bit 16: no entry
+                bool cand = ent < 0x8000u;
+                const uint32_t p = ent & 0x7FFFu;
+                uint32_t r, rk;
+                where(p, r, rk);
+                if (OFFS && hbase == 0xFFFFFFFFu && rk == 0u) cand = false;          // (a byte in front of off[0]: belongs to no haystack)
+                const uint32_t L = r + 1 < LL[e] ? r + 1 : LL[e];
+                pp[e] = ent; rr[e] = act ? r : 1u;
+                LL[e] = cand ? L : 0u;
+                XX[e] = P.window(HP + p);
+                // the cell of the C newest symbols as they stand: what it says about depths <= L does not depend on
+                // the older ones, and nothing deeper is asked when L <= C
+                hc[e] = *(const u32x2*)((const uint8_t*)a.hot + (code_n(XX[e], Cn) << 3));   // (32-bit offset)
+            }
+            wave_sync();                                                 // (the queue's memory is free from here on)
+            PH(2);
+            // 2. top levels: how many keys end here, the value of the shallowest, whether the walk goes deeper
+            uint32_t n_go = 0, gomask = 0, tvany = 0;
+            uint32_t tvm[NE];
+#pragma unroll
+            for (int e = 0; e < NE; e++) {
+                const uint32_t hw = hc[e].x, hx = hc[e].y, L = LL[e];
+                const uint32_t m = hw & cmask & ((1u << (L < 16u ? L : 16u)) - 1u);
+                cn[e] = (uint32_t)__popc(m);
+                // (0 / 1 words combined with & and |: a short-circuit && would put a divergent branch into every slot)
+                uint32_t g, has_id;
+                if (SB == 2) {                                           // the cell knows which children are keys and which grandchildren exist; both symbols are in X
+                    has_id = (hw >> 12) != 0u ? 1u : 0u;
+                    const uint32_t t = __builtin_amdgcn_ubfe(XX[e], (32u - 2u * (Cn + 2u)) & 31u, 4u), s1 = t >> 2;
+                    const uint32_t kk = hw >> (12u + s1), gk = (L > Cn + 1u ? hw : 0u) >> (16u + t);
+                    g = (L > Cn ? 1u : 0u) & (kk | gk) & 1u;
+                } else { has_id = hw >> 31; g = has_id & (L > Cn ? 1u : 0u); }
+                gomask |= g << e; n_go += g;
+                va[e] = (int32_t)hx; vb[e] = 0;                          // (the shallowest key's value, unless the word holds the id)
+                tvm[e] = ((cn[e] >= 2u ? 1u : 0u) | ((cn[e] == 1u ? 1u : 0u) & has_id)) ? m : 0u;
+                tvany |= tvm[e];
+            }
+            // values that the cell does not hold: its second word is the id, or a second key ends here
+            if (__any(tvany != 0u)) {
+#pragma unroll
+                for (int e = 0; e < NE; e++) {
+                    if (tvm[e]) {
+                        const uint32_t d1 = (uint32_t)__ffs(tvm[e]), m2 = tvm[e] & (tvm[e] - 1u);
+                        va[e] = a.top_val[s_tb[d1] + code_n(XX[e], d1)];
+                        if (m2) { const uint32_t d2 = (uint32_t)__ffs(m2); vb[e] = a.top_val[s_tb[d2] + code_n(XX[e], d2)]; }
                     }
                 }
             }
-            qtail += n_seg; if (qtail >= PPM_QCAP) qtail -= PPM_QCAP;
-            qcount += n_seg;
-            seg_lo = seg_hi;
-            if (a.dbg & 4u) { qhead = qtail; qcount = 0; }
-            wave_sync();
-            const bool last_sub = seg_lo >= 64u;
-
-            // ---- rounds: the queue is worked off in position order, 64 entries at a time — or 128, two per lane, when
-            // it holds that many: the gathers of a round (one cell per entry, then one record per step of the deeper
-            // walk) depend on each other, and with 4 waves per SIMD there is little else to run while they are in
-            // flight, so two entries per lane halve the waiting per entry.
-            // Straight-line code: every lane computes, a lane without a candidate (past the end of the queue, or a
-            // haystack start that did not pass the filter) works on position 0 with L = 0, which matches nothing.
-            // (Nested divergent branches cost more scalar bookkeeping here than the work they skip.)
-            auto do_round = [&](auto ne_tag) {
-                constexpr int NE = decltype(ne_tag)::value;
-                const uint32_t nr = qcount < 64u * NE ? qcount : 64u * NE;
-                uint32_t pq[NE], rr[NE], hh[NE], cn[NE], LL[NE], XX[NE], ix[NE], did[NE];
-                u32x4 c0[NE], c1[NE];
-                int32_t va[NE], vb[NE];
-                bool act[NE], go[NE];
-#pragma unroll
-                for (int e = 0; e < NE; e++) {
-                    act[e] = (uint32_t)lane + 64u * e < nr;
-                    uint32_t qi = qhead + lane + 64u * e; if (qi >= PPM_QCAP) qi -= PPM_QCAP;
-                    uint32_t ent = queue[qi];
-                    ent = act[e] ? ent : 0x8000u;
-                    const bool cand = ent < 0x8000u;
-                    const uint32_t p = ent & 0x7FFFu;
-                    uint32_t r, rk;
-                    where(p, r, rk);
-                    pq[e] = HP + p; rr[e] = r;
-                    hh[e] = OFFS ? hbase + rk : h_tile + rk;
-                    ix[e] = r + (a.index_base ? (uint32_t)a.index_base[hh[e]] : 0u);
-                    uint32_t L = r + 1 < a.longest ? r + 1 : a.longest;
-                    if (use_other) { const uint32_t lo2 = other_limit(HP + p); if (lo2 < L) L = lo2; }
-                    LL[e] = cand ? L : 0u;
-                    XX[e] = P.window(HP + p);
-                    // the cell of the C newest symbols as they stand: what it says about depths <= L does not depend on
-                    // the older ones, and nothing deeper is asked when L <= C
-                    const u32x4* cell = (const u32x4*)((const uint8_t*)a.cells + (code_n(XX[e], a.C) << 5));   // (32-bit offset)
-                    c0[e] = cell[0]; c1[e] = cell[1];
-                }
-                bool any_go = false;
-#pragma unroll
-                for (int e = 0; e < NE; e++) {
-                    cn[e] = 0; va[e] = 0; vb[e] = 0; go[e] = false; did[e] = 0;
-                    if (!(a.dbg & 1u)) {
-                        // top levels: the cell lists their values in match order, so the first two are always c0.w, c1.x
-                        const uint32_t L = LL[e];
-                        const uint32_t mask = c0[e].x & (L < 32 ? (1u << L) - 1u : 0xFFFFFFFFu);
-                        cn[e] = (uint32_t)__popc(mask);
-                        va[e] = (int32_t)c0[e].w; vb[e] = (int32_t)c1[e].x;
-                        const uint32_t id = c0[e].y, d = a.C;
-                        bool g = id != 0 && L > d;
-                        if (SB == 2 && SB * (a.C + 2) <= 32) {         // K <= 4: the cell knows children and grandchildren; both symbols are in X
-                            const uint32_t t = __builtin_amdgcn_ubfe(XX[e], 32 - SB * (a.C + 2), 4u), s1 = t >> 2, z = c0[e].z;
-                            const uint32_t kid = z >> s1, keow = z >> (4 + s1), gk = (L > d + 1 ? z : 0u) >> (8 + t);
-                            g = g && (z == 0 || ((kid & (keow | gk)) & 1u) != 0);
-                        }
-                        go[e] = g; did[e] = id;
-                        any_go = any_go || g;
-                    }
-                }
-                // deeper levels: one 16-byte record per step (rows: indexed by the next symbol; singles).  Every
-                // lane runs every iteration with selects instead of branches (a lane that is done re-reads
-                // record 0): a divergent loop costs several times more instructions than its body here.
-                if (__any(any_go)) {
-                    uint32_t dd[NE], s1[NE];
+            PH(3);
+            // 3. deeper levels: the entries that go on, 64 at a time, one per lane.  One 16-byte record per step (rows:
+            // indexed by the next symbol; singles); every walker runs every iteration with selects instead of branches
+            // (one that is done re-reads record 0).
+            uint32_t n_deep;
+            const uint32_t d_base = wave_excl_scan(n_go, n_deep);
+            uint32_t* const dq = (uint32_t*)queue;                       // [0..127]: {staged position | L << 12, id} -> {first, second value}; then 64 counts
+            uint16_t* const dcnt = (uint16_t*)(dq + 130);              // (dq[128..129]: the dump slot)
+            for (uint32_t d0 = 0; d0 < n_deep; d0 += 64u) {
+                {
+                    uint32_t rnk = d_base - d0;                          // (unsigned: ranks below d0 wrap far beyond 64)
 #pragma unroll
                     for (int e = 0; e < NE; e++) {
-                        dd[e] = a.C;
-                        s1[e] = SB * (a.C + 1) <= 32 ? __builtin_amdgcn_ubfe(XX[e], (32 - SB * (a.C + 1)) & 31u, (uint32_t)SB) : P.sym_at(pq[e] - a.C);
-                    }
-                    for (;;) {
-                        // the records of all entries first (their gathers overlap), then what they say; flags are 0/1
-                        // words combined with & and |: no short-circuit branches
-                        u32x4 rec[NE];
-                        uint32_t first[NE];
-#pragma unroll
-                        for (int e = 0; e < NE; e++) {
-                            const uint32_t id = did[e], single = id >> 31;
-                            first[e] = single ^ 1u;
-                            uint32_t off = single ? a.single_off + (id << 4) : a.row_off + ((id + s1[e]) << 4);   // (bit 31 shifts out; a row's id is a record index)
-                            off = go[e] ? off : a.row_off;
-                            rec[e] = *(const u32x4*)(a.deep_base + off);
-                        }
-                        uint32_t more = 0;
-#pragma unroll
-                        for (int e = 0; e < NE; e++) {
-                            const uint32_t g = go[e] ? 1u : 0u;
-                            const uint32_t len = rec[e].y & 0xFFu;
-                            const uint32_t dn = dd[e] + first[e] + len;
-                            const uint32_t wq = g ? pq[e] - dd[e] - first[e] : HP;   // (a lane that is done reads a harmless window)
-                            const uint32_t diff = (P.window(wq) ^ rec[e].x) >> ((0u - SB * len) & 31u);
-                            const uint32_t ok = g & (rec[e].y >> 9) & (LL[e] >= dn ? 1u : 0u) & ((len == 0u ? 1u : 0u) | (diff == 0u ? 1u : 0u));
-                            const uint32_t hit = ok & (rec[e].y >> 8);
-                            va[e] = (hit & (cn[e] == 0u ? 1u : 0u)) ? (int32_t)rec[e].z : va[e];
-                            vb[e] = (hit & (cn[e] == 1u ? 1u : 0u)) ? (int32_t)rec[e].z : vb[e];
-                            cn[e] += hit & 1u;
-                            dd[e] = dn;
-                            did[e] = rec[e].w;
-                            const uint32_t g2 = ok & 1u & (rec[e].w != 0u ? 1u : 0u) & ((rec[e].w >> 31) | (LL[e] > dn ? 1u : 0u));
-                            go[e] = g2 != 0u;
-                            more |= g2;
-                        }
-                        if (!__any(more != 0u)) break;
-#pragma unroll
-                        for (int e = 0; e < NE; e++) s1[e] = go[e] ? P.sym_at(pq[e] - dd[e]) : 0u;
+                        const uint32_t g = (gomask >> e) & 1u;
+                        const uint32_t slot = (g != 0u && rnk < 64u) ? rnk : 64u;       // (slot 64: nobody reads it)
+                        u32x2 v; v.x = (HP + (pp[e] & 0x7FFFu)) | (LL[e] << 12); v.y = (uint32_t)hc[e].y;
+                        *(u32x2*)(dq + 2 * slot) = v;
+                        rnk += g;
                     }
                 }
-                uint32_t ex[NE], rt = 0;
+                wave_sync();
+                {
+                    bool go = d0 + (uint32_t)lane < n_deep;
+                    const uint32_t pk = go ? dq[2 * lane] : HP;
+                    uint32_t did = go ? dq[2 * lane + 1] : 0u;
+                    const uint32_t wpq = pk & 0xFFFu, wL = pk >> 12;
+                    uint32_t dd = Cn, wc = 0;
+                    int32_t wa = 0, wb = 0;
+                    uint32_t s1 = P.sym_at(wpq - Cn);
+                    for (;;) {
+                        const uint32_t single = did >> 31, first = single ^ 1u;
+                        uint32_t off = single ? a.single_off + (did << 4) : a.row_off + ((did + s1) << 4);   // (bit 31 shifts out; a row's id is a record index)
+                        off = go ? off : a.row_off;
+                        const u32x4 rec = *(const u32x4*)(a.deep_base + off);
+                        const uint32_t g = go ? 1u : 0u;
+                        const uint32_t len = rec.y & 0xFFu;
+                        const uint32_t dn = dd + first + len;
+                        const uint32_t wq = go ? wpq - dd - first : HP;      // (a walker that is done reads a harmless window)
+                        const uint32_t diff = (P.window(wq) ^ rec.x) >> ((0u - SB * len) & 31u);
+                        const uint32_t ok = g & (rec.y >> 9) & (wL >= dn ? 1u : 0u) & ((len == 0u ? 1u : 0u) | (diff == 0u ? 1u : 0u));
+                        const uint32_t hit = ok & (rec.y >> 8) & 1u;
+                        wa = (hit & (wc == 0u ? 1u : 0u)) ? (int32_t)rec.z : wa;
+                        wb = (hit & (wc == 1u ? 1u : 0u)) ? (int32_t)rec.z : wb;
+                        wc += hit;
+                        dd = dn;
+                        did = rec.w;
+                        const uint32_t g2 = ok & 1u & (rec.w != 0u ? 1u : 0u) & ((rec.w >> 31) | (wL > dn ? 1u : 0u));
+                        go = g2 != 0u;
+                        if (!__any(go)) break;
+                        s1 = go ? P.sym_at(wpq - dd) : 0u;
+                    }
+                    dq[2 * lane] = (uint32_t)wa; dq[2 * lane + 1] = (uint32_t)wb; dcnt[lane] = (uint16_t)wc;
+                }
+                wave_sync();
+                {
+                    uint32_t rnk = d_base - d0;
+#pragma unroll
+                    for (int e = 0; e < NE; e++) {
+                        const uint32_t g = (gomask >> e) & 1u;
+                        const bool mine = g != 0u && rnk < 64u;
+                        const uint32_t slot = mine ? rnk : 64u;
+                        const u32x2 dv = *(const u32x2*)(dq + 2 * slot);
+                        const uint32_t c2 = mine ? (uint32_t)dcnt[slot] : 0u;
+                        const bool c0 = mine && cn[e] == 0u, c1 = mine && cn[e] == 1u;
+                        va[e] = c0 ? (int32_t)dv.x : va[e];
+                        vb[e] = c0 ? (int32_t)dv.y : (c1 ? (int32_t)dv.x : vb[e]);
+                        cn[e] += c2;
+                        rnk += g;
+                    }
+                }
+                wave_sync();
+            }
+            PH(4);
+            // 4. place: entry e * 64 + lane; the records of a slot follow those of the slots below it
+            // (two slots per prefix sum, 16 bits each: a slot has at most 64 x longest < 65536 records)
+            uint32_t ex[NE], rt = 0;
+            static_assert(NE % 2 == 0, "slots are placed in pairs");
+#pragma unroll
+            for (int e = 0; e < NE; e += 2) {
+                uint32_t t;
+                const uint32_t x2 = wave_excl_scan(cn[e] | (cn[e + 1] << 16), t);
+                ex[e] = rt + (x2 & 0xFFFFu); rt += t & 0xFFFFu;
+                ex[e + 1] = rt + (x2 >> 16); rt += t >> 16;
+            }
+            if (rt && !dead) {
+                if (g_used + rt + 1u > g_size) {                       // this round (and the spare slot behind it) does not fit the current grant: open the next one
+                    if (ng == PPM_MAX_GRANTS) dead = true;
+                    else {
+                        uint32_t need = PPM_GRANT << (ng < 10 ? ng : 10);
+                        if (need < rt + 1u) need = rt + 1u;
+                        unsigned long long oo = 0;
+                        if (lane == 0) oo = atomicAdd(a.heads + pool_x, (unsigned long long)need);
+                        oo = __shfl(oo, 0, 64);
+                        if (oo + need > a.pool_records) dead = true;
+                        else {
+                            if (lane == 0) { if (ng) desc[18 + ng - 1] = g_used; desc[2 + ng] = (uint32_t)((unsigned long long)pool_x * a.pool_records + oo); }
+                            g_base = (uint32_t)((unsigned long long)pool_x * a.pool_records + oo); g_size = need; g_used = 0; ng++;
+                        }
+                    }
+                    if (dead && lane == 0) *a.overflow = 1;
+                }
+            }
+#ifdef ACX_PPM_DEV
+            const bool wr = rt && !dead && !(a.dbg & 2u);                // timing only: no record writes
+#else
+            const bool wr = rt && !dead;
+#endif
+            // 5. the record offsets of the haystacks that start here (and the caller's index bases).  Stores are not
+            // predicated: a lane with nothing to say writes to a spare element (divergent branches cost more than that)
+            {
+                uint32_t startany = 0;
+#pragma unroll
+                for (int e = 0; e < NE; e++) startany |= rr[e] == 0u ? 1u : 0u;       // (no entry: rr = 1)
+                if (__any(startany != 0u) || a.index_base) {
+                    const uint32_t dump = (uint32_t)a.n_hay;             // hay_local[n_hay]: spare
+#pragma unroll
+                    for (int e = 0; e < NE; e++) {
+                        uint32_t r, rk;
+                        where(pp[e] & 0x7FFFu, r, rk);
+                        const uint32_t hh = OFFS ? hbase + rk : h_tile + rk;
+                        a.hay_local[rr[e] == 0u ? hh : dump] = (int32_t)(run_off + ex[e]);   // the records in front of this haystack
+                        if (a.index_base) rr[e] += cn[e] ? (uint32_t)a.index_base[hh] : 0u;
+                    }
+                }
+            }
+            // 6. records, longest key of a position first.  Slot rt of the round (one past its last record; the grant has
+            // the room) takes the stores of the lanes that have no first / second record.
+            uint32_t slow = 0;                                           // slots with more than two records: the general enumeration
+            uint8_t* const out8 = (uint8_t*)(a.scratch + g_base + g_used);
+            uint2* const out = (uint2*)out8;
+            if (wr) {
 #pragma unroll
                 for (int e = 0; e < NE; e++) {
-                    uint32_t t;
-                    ex[e] = rt + wave_excl_scan(cn[e], t);
-                    rt += t;
-                    if (act[e] && rr[e] == 0u) a.hay_local[hh[e]] = (int32_t)(run_off + ex[e]);   // a haystack starts here: the records in front of it
+                    const uint32_t c = cn[e], oe = ex[e] + c - 1u, idx = rr[e];
+                    *(uint2*)(out8 + ((c ? oe : rt) << 3)) = make_uint2(idx, (uint32_t)va[e]);
+                    *(uint2*)(out8 + ((c > 1u ? oe - 1u : rt) << 3)) = make_uint2(idx, (uint32_t)vb[e]);
+                    slow |= (c > 2u ? 1u : 0u) << e;
                 }
-                if (rt && !dead) {
-                    if (g_used + rt > g_size) {                        // this round does not fit the current grant: open the next one
-                        if (ng == PPM_MAX_GRANTS) dead = true;
-                        else {
-                            uint32_t need = PPM_GRANT << (ng < 10 ? ng : 10);
-                            if (need < rt) need = rt;
-                            unsigned long long o = 0;
-                            if (lane == 0) o = atomicAdd(a.heads + pool_x, (unsigned long long)need);
-                            o = __shfl(o, 0, 64);
-                            if (o + need > a.pool_records) dead = true;
-                            else {
-                                if (lane == 0) { if (ng) desc[18 + ng - 1] = g_used; desc[2 + ng] = (uint32_t)((unsigned long long)pool_x * a.pool_records + o); }
-                                g_base = (uint32_t)((unsigned long long)pool_x * a.pool_records + o); g_size = need; g_used = 0; ng++;
-                            }
-                        }
-                        if (dead && lane == 0) *a.overflow = 1;
-                    }
-                    if (!dead && !(a.dbg & 2u)) {
-                        uint2* out = a.scratch + g_base + g_used;
+                while (__any(slow != 0u)) {                              // rare: one slot per lane and pass, from the 32-byte cell
+                    if (slow) {
+                        const uint32_t se = (uint32_t)__ffs(slow) - 1u;
+                        slow &= slow - 1u;
+                        typename Ppm<SB, POW2, false>::Ent E;
+                        uint32_t oe = 0;
+                        E.p = 0; E.X = 0; E.L = 0; E.idx = 0;
 #pragma unroll
-                        for (int e = 0; e < NE; e++) {
-                            const uint32_t c = cn[e];
-                            if (c) {
-                                const uint32_t o = ex[e] + c - 1, idx = ix[e];
-                                out[o] = make_uint2(idx, (uint32_t)va[e]);
-                                if (c > 1) out[o - 1] = make_uint2(idx, (uint32_t)vb[e]);
-                                if (c > 2) {
-                                    typename Ppm<SB, POW2, false>::Ent E;
-                                    E.p = pq[e] - HP; E.X = XX[e]; E.L = LL[e]; E.idx = idx; E.c0 = c0[e]; E.c1 = c1[e];
-                                    P.matches(E, 2u, 0xFFFFFFFFu, [&](uint32_t k, int32_t v) { out[o - k] = make_uint2(idx, (uint32_t)v); });
-                                }
-                            }
+                        for (int e = 0; e < NE; e++) if (se == (uint32_t)e) { E.p = pp[e] & 0x7FFFu; E.X = XX[e]; E.L = LL[e]; E.idx = rr[e]; oe = ex[e] + cn[e] - 1; }
+                        const u32x4* cell = (const u32x4*)((const uint8_t*)a.cells + (code_n(E.X, Cn) << 5));
+                        E.c0 = cell[0]; E.c1 = cell[1];
+                        const uint32_t idx = E.idx;
+                        P.matches(E, 2u, 0xFFFFFFFFu, [&](uint32_t kk2, int32_t v) { out[oe - kk2] = make_uint2(idx, (uint32_t)v); });
+                    }
+                }
+            }
+            if (rt && !dead) g_used += rt;
+            run_off += rt;
+            qcount = 0;
+            wave_sync();
+            PH(5);
+        };
+
+        // (one call site of the round: its code exists once)
+        uint32_t seg_lo = 0;
+        for (;;) {
+            if (seg_lo < 64u) {
+                const uint32_t ex_lo = seg_lo ? (uint32_t)__builtin_amdgcn_readlane((int)x_ex, (int)seg_lo) : 0u;
+                uint32_t seg_hi = 64u, n_seg = x_tot - ex_lo;
+                if (n_seg > PPM_QCAP - qcount) { seg_hi = seg_lo + LPS; n_seg = (seg_hi < 64u ? (uint32_t)__builtin_amdgcn_readlane((int)x_ex, (int)seg_hi) : x_tot) - ex_lo; }
+                if (n_seg <= PPM_QCAP - qcount) {                        // (else: a round first — a sub-step has at most 256 entries, it fits the empty queue)
+                    uint32_t w = ((uint32_t)lane >= seg_lo && (uint32_t)lane < seg_hi) ? xw : 0u;
+                    uint32_t j = qcount + (x_ex - ex_lo);
+                    const uint32_t lp = PPL * (uint32_t)lane;
+#ifdef ACX_PPM_DEV
+                    if (a.dbg & 8u) w = 0;                               // timing only: no queue
+#endif
+                    while (__any(w != 0u)) {
+                        if (w) {
+                            const uint32_t b = (uint32_t)__builtin_ctz(w);
+                            w &= w - 1u;
+                            queue[j++] = (uint16_t)((lp + b) | (((pw >> b) & 1u) ? 0u : 0x8000u));     // 0x8000: a start that is no candidate
                         }
                     }
-                    if (!dead) g_used += rt;
+                    qcount += n_seg;
+                    seg_lo = seg_hi;
+#ifdef ACX_PPM_DEV
+                    if (a.dbg & 4u) qcount = 0;                          // timing only: no rounds
+#endif
+                    wave_sync();
+                    if (seg_lo < 64u) continue;
                 }
-                run_off += rt;
-                qhead += nr; if (qhead >= PPM_QCAP) qhead -= PPM_QCAP;
-                qcount -= nr;
-            };
-            while (qcount >= 192u) do_round(std::integral_constant<int, 3>{});
-            if (!last_sub && qcount > PPM_QCAP - 256u) do_round(std::integral_constant<int, 2>{});   // room for the next sub-step's entries
-            if (last_sub) {
-                if (qcount > 128u) do_round(std::integral_constant<int, 3>{});
-                else if (qcount > 64u) do_round(std::integral_constant<int, 2>{});
-                else if (qcount > 0u) do_round(std::integral_constant<int, 1>{});
             }
+            PH(1);                                                       // starts, scan, push
+            if (qcount) do_round();                                      // (the queue is full, or the symbols of this tile are about to move)
+            if (seg_lo >= 64u) break;
         }
 
         // ---- the tail of this tile is the halo of the next ---------------------------------------
@@ -977,6 +1170,10 @@ __global__ void __launch_bounds__(ACX_PPM_BLOCK) k_ppm_stream(const acx_ppm_args
         wave_sync();
     }
     if (lane == 0) { desc[0] = run_off; desc[1] = ng; if (ng) desc[18 + ng - 1] = g_used; }
+#ifdef ACX_PPM_PHASES
+    PH(7);
+    if (lane == 0 && a.phase_out) for (int i = 0; i < 8; i++) atomicAdd(a.phase_out + i, ph[i]);
+#endif
 }
 
 // first_h[t] = the first haystack that starts at or after byte t * tile_pos (n_hay + 1 entries of `off`; the last
@@ -1113,19 +1310,27 @@ hipError_t acx_launch_ppm_scan(const acx_ppm_args& a, int64_t n_items_bound, hip
         return hipGetLastError();
     };
     if (a.fast) {
-        const bool offs = a.off != nullptr, p2 = a.pow2 != 0;
-#define PPM_S(SB, N, GG) do { \
-            if (p2) { if (offs) return launch(k_ppm_stream<SB, N, true, true, GG>); return launch(k_ppm_stream<SB, N, true, false, GG>); } \
-            if (offs) return launch(k_ppm_stream<SB, N, false, true, GG>); return launch(k_ppm_stream<SB, N, false, false, GG>); } while (0)
+        const bool offs = a.off != nullptr, p2 = a.pow2 != 0, ar = a.sym_arith != 0 && a.sym_bits == 2 && p2;
+        constexpr int NE = ACX_PPM_NE;
+#define PPM_S5(SB, N, P2, GG, AR) do { if (offs) return launch(k_ppm_stream<SB, N, P2, true, GG, AR, false, NE>); \
+            if (a.m24) return launch(k_ppm_stream<SB, N, P2, false, GG, AR, true, NE>); return launch(k_ppm_stream<SB, N, P2, false, GG, AR, false, NE>); } while (0)
+#define PPM_S(SB, N, GG) do { if (p2) PPM_S5(SB, N, true, GG, false); PPM_S5(SB, N, false, GG, false); } while (0)
+        if (a.nsub != 8 && a.nsub != 4) return hipErrorInvalidValue;
+#ifdef ACX_PPM_DEV      /* development builds: the config-2 kernel only (compile time) */
+        if (a.sym_bits == 2 && a.nsub == 8 && ar && !offs && a.m24) return launch(k_ppm_stream<2, 8, true, false, false, true, true, NE>);
+        return hipErrorInvalidValue;
+#else
         if (a.sym_bits == 8) {
-            if (a.g_global) { if (a.nsub == 8) PPM_S(8, 8, true); if (a.nsub == 4) PPM_S(8, 4, true); PPM_S(8, 2, true); }
-            if (a.nsub == 8) PPM_S(8, 8, false); if (a.nsub == 4) PPM_S(8, 4, false); PPM_S(8, 2, false);
+            if (a.g_global) { if (a.nsub == 8) PPM_S(8, 8, true); PPM_S(8, 4, true); }
+            if (a.nsub == 8) PPM_S(8, 8, false); PPM_S(8, 4, false);
         }
-        if (a.sym_bits == 4) { if (a.nsub == 8) PPM_S(4, 8, false); if (a.nsub == 4) PPM_S(4, 4, false); PPM_S(4, 2, false); }
+        if (a.sym_bits == 4) { if (a.nsub == 8) PPM_S(4, 8, false); PPM_S(4, 4, false); }
+        if (ar) { if (a.nsub == 8) PPM_S5(2, 8, true, false, true); PPM_S5(2, 4, true, false, true); }
         if (a.nsub == 8) PPM_S(2, 8, false);
-        if (a.nsub == 4) PPM_S(2, 4, false);
-        PPM_S(2, 2, false);
+        PPM_S(2, 4, false);
+#endif
 #undef PPM_S
+#undef PPM_S5
     }
 #define PPM_CASE(SB) \
     do { \

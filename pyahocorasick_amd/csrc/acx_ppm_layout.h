@@ -58,7 +58,7 @@ static inline acx_ppm_lds acx_ppm_stream_layout(uint32_t g_words, uint32_t sym_b
     L.wave_words = (L.sym_words + L.oth_words + L.queue_words + L.cnt_words + 3u) & ~3u;
     L.g_off = 0;
     L.map_off = (g_words + 3u) & ~3u;
-    L.wave_off = L.map_off + 64;
+    L.wave_off = L.map_off + 64 + 24;                                  // byte -> symbol map (256 bytes), top_base[] (22 words)
     L.total_words = L.wave_off + ACX_PPM_WAVES * L.wave_words;
     return L;
 }

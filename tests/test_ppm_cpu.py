@@ -52,6 +52,7 @@ def test_ppm_walk_randomised_vs_oracle():
         hdr = _ppm_header(blob)
         assert hdr is not None
         shapes.add((hdr["sym_bits"], hdr["pow2"], hdr["F"] > hdr["C"]))
+        assert orc.ppm_check_hot(blob) == 0
         text_alpha = alpha if rng.random() < 0.5 else alpha + b"#"       # a byte no key contains
         for _ in range(8):
             hay = bytes(rng.choice(text_alpha) for _ in range(rng.randint(0, 300)))
@@ -89,3 +90,22 @@ def test_ppm_absent_when_disabled(monkeypatch):
     A, O = build_pair([b"he", b"she"])
     assert _ppm_header(A.flat_image_bytes()) is None
     assert orc.ppm_iter(A.flat_image_bytes(), b"ushers") is None
+
+
+def test_arithmetic_symbol_map_for_four_letter_alphabets():
+    """alphabets of exactly four bytes that a shift tells apart get symbol = (byte >> s) & 3 (the stream kernel then
+    needs no table lookup); others keep the table; results are the same either way"""
+    rng = random.Random(5)
+    for alpha, want_arith in ((b"ACGT", True), (b"acgt", True), (b"\x00\x01\x02\x03", True), (b"ACGU", True), (b"AEIM", True), (b"ABCDE", False), (b"ACG", False)):
+        keys = list({bytes(rng.choice(alpha) for _ in range(rng.randint(2, 14))) for _ in range(150)})
+        A, O = build_pair(keys, list(range(len(keys))))
+        blob = A.flat_image_bytes()
+        off_ppm = struct.unpack_from("<Q", blob, 248)[0]
+        sym_arith, _gw, _g2w, sym_lut = struct.unpack_from("<4I", blob, off_ppm + 32)
+        assert (sym_arith != 0) == want_arith, (alpha, sym_arith)
+        if sym_arith:
+            assert sorted(sym_lut.to_bytes(4, "little")) == sorted(alpha)
+        assert orc.ppm_check_hot(blob) == 0
+        for _ in range(6):
+            hay = bytes(rng.choice(alpha + b"N") for _ in range(rng.randint(0, 200)))
+            assert orc.ppm_iter(blob, hay) == O.iter(hay)
