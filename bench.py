@@ -230,7 +230,7 @@ def main():
     import pyahocorasick_amd as acx
     from pyahocorasick_amd import _lib
     from pyahocorasick_amd.device import Scanner
-    from pyahocorasick_amd.parallel import broadcast_image, shard_range
+    from pyahocorasick_amd.parallel import broadcast_image, halo_shard, shard_range
     from pyahocorasick_amd import workloads as W
     _lib.check(_lib.lib().acx_device_set(local_rank))
 
@@ -281,8 +281,8 @@ def main():
             flat = np.concatenate([W.text_corpus(vocab, min(64 << 20, nbytes - o), seed=4 + 64 * seed + o // (64 << 20))
                                    for o in range(0, nbytes, 64 << 20)])
             if strong:            # one corpus, contiguous shards, longest_word-1 bytes of left halo (exact for iter)
-                lo, hi = shard_range(len(flat), rank, world)
-                flat = flat[max(0, lo - (longest - 1)):hi]
+                s0, lo, hi = halo_shard(len(flat), rank, world, longest)
+                flat = flat[s0:hi]
             n, L, off = 1, 0, np.array([0, len(flat)], dtype=np.int64)
             if b == 0:
                 host0 = [flat[i:i + (1 << 16)].tobytes() for i in range(0, min(len(flat), 32 << 20), 1 << 16)]

@@ -558,6 +558,7 @@ struct SearchIterObject {
     Py_ssize_t start;       // first letter of the scanned slice
     int32_t state0;         // state before this chunk
     bool exhausted;         // StopIteration seen: the reference has walked the whole chunk
+    bool loaded;            // the chunk has been scanned (lazily: at the first next(), as the reference walks nothing in iter())
 };
 
 extern PyTypeObject SearchIterType;
@@ -601,17 +602,27 @@ bool scan_text(AutomatonObject* a, int mode, const Text& t, Py_ssize_t start, Py
     return true;
 }
 
+// A chunk is scanned when its first match is asked for, not when iter() / set() hands it over: the reference walks
+// nothing there either (src/AutomatonSearchIter.c:65-131), and code that creates iterators it never drains
+// (tests/test_issue_9.py: two million of them) must not pay a GPU scan each.
 bool iter_load(SearchIterObject* it, const Text& t, Py_ssize_t start, Py_ssize_t end) {
+    (void)t;
     it->pending->clear();
     it->start = start; it->state0 = it->state;
-    // an iterator whose automaton has changed raises from next() (src/AutomatonSearchIter.c:247-250): its state id
-    // belongs to an image that no longer exists, so nothing is scanned for it
-    if (it->version == acx_trie_version(it->automaton->trie) &&
-        !scan_text(it->automaton, it->is_long ? ACX_SCAN_LONG : ACX_SCAN_ALL, t, start, end, it->ignore_ws,
-                   &it->state, it->shift, it->pending)) return false;
-    it->pos = 0; it->exhausted = false;
+    it->pos = 0; it->exhausted = false; it->loaded = false;
     it->end = end;
     it->ref_index = start - 1;                                     // src/AutomatonSearchIter.c:123
+    return true;
+}
+
+bool iter_ensure_loaded(SearchIterObject* it) {
+    if (it->loaded) return true;
+    Text t;
+    if (!get_text(it->src, &t, true, it->automaton->key_type)) return false;
+    Py_ssize_t end = it->end > t.nchars ? t.nchars : it->end;
+    if (!scan_text(it->automaton, it->is_long ? ACX_SCAN_LONG : ACX_SCAN_ALL, t, it->start, end, it->ignore_ws,
+                   &it->state, it->shift, it->pending)) return false;
+    it->pos = 0; it->loaded = true;
     return true;
 }
 
@@ -622,7 +633,7 @@ PyObject* search_iter_create(AutomatonObject* a, PyObject* srcobj, const Text& t
     it->version = acx_trie_version(a->trie);
     it->pending = new std::vector<acx_match_t>();
     it->pos = 0; it->state = 0; it->shift = 0; it->ref_index = -1; it->end = 0; it->ignore_ws = ws; it->is_long = is_long;
-    Py_INCREF(srcobj); it->src = srcobj; it->start = 0; it->state0 = 0;
+    Py_INCREF(srcobj); it->src = srcobj; it->start = 0; it->state0 = 0; it->exhausted = false; it->loaded = false;
     if (!iter_load(it, t, start, end)) { Py_DECREF(it); return nullptr; }
     return (PyObject*)it;
 }
@@ -641,6 +652,7 @@ PyObject* search_iter_next(SearchIterObject* it) {
         PyErr_SetString(PyExc_ValueError, "underlaying automaton has changed, iterator is not valid anymore");
         return nullptr;
     }
+    if (!iter_ensure_loaded(it)) return nullptr;
     if (it->pos >= it->pending->size()) { it->ref_index = it->end; it->exhausted = true; return nullptr; }   // StopIteration
     const acx_match_t r = (*it->pending)[it->pos++];
     it->ref_index = (Py_ssize_t)r.end_index - it->shift;
@@ -654,7 +666,8 @@ PyObject* search_iter_set(SearchIterObject* it, PyObject* args) {  // src/Automa
     if (!get_text(s, &t, true, it->automaton->key_type)) return nullptr;
     if (reset) { it->state = 0; it->shift = 0; }
     else {
-        if (!it->exhausted && it->version == acx_trie_version(it->automaton->trie)) {
+        if (!it->loaded) it->state = it->state0;                   // nothing of the old chunk was asked for: the reference has not moved
+        else if (!it->exhausted && it->version == acx_trie_version(it->automaton->trie)) {
             // set() before StopIteration.  iter_long: the reference is at the root after every match it returned
             // (src/AutomatonSearchIterLong.c:101-110).  iter: it holds the state after the last yielded position:
             // scan that prefix of the old chunk again (the whole chunk was scanned eagerly, so it->state is the

@@ -34,6 +34,17 @@ def shard_range_by_bytes(offsets, rank, world):
     return cuts[rank], cuts[rank + 1]
 
 
+def halo_shard(total_len, rank, world, longest_word):
+    """One long haystack cut for `world` ranks: rank r owns the end positions [lo, hi) and scans the
+    bytes [s0, hi), s0 = lo - (longest_word - 1) clipped at 0 — every match ending in [lo, hi) depends only on the
+    longest_word bytes up to its end, so the shards are independent (exact for iter, not for iter_long).  The rank
+    keeps the matches whose end index is >= lo; concatenated in rank order they are the sequential result.
+    Returns (s0, lo, hi)."""
+    lo, hi = shard_range(total_len, rank, world)
+    s0 = max(0, lo - max(0, int(longest_word) - 1))
+    return s0, lo, hi
+
+
 def broadcast_blob(blob, src=0, device=None):
     """Replicate the flat image bytes.  Returns a uint8 tensor on `device` holding the blob on
     every rank.  ONE broadcast for the payload (preceded by an 8-byte size broadcast so the

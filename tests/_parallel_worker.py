@@ -15,7 +15,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import pyahocorasick_amd as acx  # noqa: E402
 from pyahocorasick_amd import _lib  # noqa: E402
-from pyahocorasick_amd.parallel import broadcast_blob, gather_csr, shard_range, shard_range_by_bytes  # noqa: E402
+from pyahocorasick_amd.parallel import broadcast_blob, gather_csr, halo_shard, shard_range, shard_range_by_bytes  # noqa: E402
 from pyahocorasick_amd.workloads import dna_workload  # noqa: E402
 from oracle import orc  # noqa: E402
 
@@ -67,6 +67,43 @@ def main():
             assert np.array_equal(res[0], mo) and np.array_equal(res[1], e) and np.array_equal(res[2], v)
         else:
             assert res is None
+    # one long haystack (config-3 style), cut with a longest_word - 1 halo: every rank scans its own shard plus the
+    # halo in front of it, keeps the matches that end in its own range; rank order = the sequential result
+    from pyahocorasick_amd.workloads import text_corpus, text_keys, text_vocab
+    vocab = text_vocab(3000, seed=2)
+    tkeys = text_keys(vocab, 400, seed=3)
+    corpus = text_corpus(vocab, 60_000, seed=4)
+    for k in tkeys[:40]:
+        pos = int.from_bytes(k[:4], "little") % (len(corpus) - 64)
+        corpus[pos:pos + len(k)] = np.frombuffer(k, dtype=np.uint8)
+    tblob = None
+    if rank == 0:
+        B = acx.Automaton(acx.STORE_INTS)
+        for i, k in enumerate(tkeys):
+            B.add_word(k, i)
+        B.make_automaton()
+        tblob = B.flat_image_bytes()
+    tgot = broadcast_blob(tblob, src=0).numpy().tobytes()
+    longest = max(len(k) for k in tkeys)
+    hay = corpus.tobytes()
+    s0, lo, hi = halo_shard(len(hay), rank, world, longest)
+    pairs, _ = orc.flat_iter(tgot, hay[s0:hi])
+    mine = [(e + s0, v) for e, v in pairs if e + s0 >= lo]
+    parts = [None] * world
+    dist.all_gather_object(parts, mine)
+    if rank == 0:
+        O = orc.Oracle()
+        for i, k in enumerate(tkeys):
+            O.add_word(k, i)
+        O.make_automaton()
+        whole = O.iter(hay)
+        assert len(whole) >= 40
+        assert [x for part in parts for x in part] == whole
+        # without the halo the cut loses the matches that straddle it (the test would not notice a missing halo otherwise)
+        lo1, hi1 = shard_range(len(hay), 1, world)
+        no_halo, _ = orc.flat_iter(tgot, hay[lo1:hi1])
+        straddle = [m for m in whole if lo1 <= m[0] < lo1 + longest - 1]
+        assert len([1 for e, v in no_halo if e + lo1 < lo1 + longest - 1]) <= len(straddle)
     dist.barrier()
     dist.destroy_process_group()
     if rank == 0:

@@ -23,4 +23,10 @@ with open(os.path.join(DST, "README.md"), "w") as f:
             "`tests/golden/make_ref_suite.py`.  Test infrastructure only: run by `tests/test_gpu_ref_suite.py`\n"
             "against the drop-in `ahocorasick` module.  pytest does not collect this directory on its own\n"
             "(`conftest.py` ignores it).\n")
+# tests/test_issue_9.py reads the first 2 KiB of <suite>/../README.rst as its haystack: a stand-in of the same kind of
+# text (the reference's own README is not copied)
+with open(os.path.join(os.path.dirname(DST), "README.rst"), "w") as f:
+    para = ("pyahocorasick_amd test fixture: plain English text that the reference's test_issue_9 slices into two thousand "
+            "start offsets. The automaton in that test holds the single key SSSSS, which this text does not contain. ")
+    f.write("Stand-in for README.rst\n=======================\n\n" + para * 12 + "\n")
 print("copied %d files to %s" % (n, DST))

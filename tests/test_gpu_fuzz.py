@@ -1,0 +1,68 @@
+"""A fixed-seed slice of tools/fuzz_gpu.py inside the GPU suite (random alphabets of 2..256 symbols, key sets, equal and
+ragged batches, the stream / general / serial kernels, iter_long, final states: everything against the oracle), and the
+`min_hay_len` contract of acx_scan_params: a batch that breaks its promise is noticed on the device and scanned again."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+
+from helpers import build_pair                                     # noqa: E402
+from pyahocorasick_amd.device import DeviceBuffer, Image, Scanner   # noqa: E402
+
+
+def test_fuzz_slice_fixed_seed():
+    import fuzz_gpu
+    rng = np.random.default_rng(20240924)
+    matches = 0
+    for trial in range(110):                                         # ~ 60 s on an MI355X
+        m, _ = fuzz_gpu.one_case(rng, trial)
+        matches += m
+    assert matches > 0
+
+
+def _check(A, O, flat, off, **kw):
+    img = Image.from_automaton(A)
+    sc = Scanner(img)
+    d_hay = DeviceBuffer.from_numpy(flat, pad=64)
+    d_off = DeviceBuffer.from_numpy(off)
+    sc.scan(d_hay, len(flat), len(off) - 1, dev_off=d_off, **kw)
+    moff, e, v, _ = sc.fetch()
+    mo, oe, ov = O.batch(flat.tobytes(), off, 0)
+    assert np.array_equal(moff, mo) and np.array_equal(e, oe) and np.array_equal(v, ov)
+    return img
+
+
+def test_min_hay_len_promise_broken_is_detected_and_rescanned():
+    rng = np.random.default_rng(3)
+    alpha = np.frombuffer(b"ACGT", dtype=np.uint8)
+    keys = list({bytes(alpha[rng.integers(0, 4, size=int(k))]) for k in rng.integers(2, 12, size=400)})
+    A, O = build_pair(keys)
+    # (a) one 3-byte haystack in a batch that promises 8: few starts per tile, the stream kernel copes
+    lens = [200] * 50 + [3] + [200] * 50
+    off = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+    flat = np.ascontiguousarray(alpha[rng.integers(0, 4, size=int(off[-1]))])
+    img = _check(A, O, flat, off, min_hay_len=8)
+    assert img.ppm_kernel(stride=0, has_offsets=True, variant=0, min_hay_len=8, dev_hay=0, n_hay=len(lens)) == "stream"
+    # (b) thousands of 3-byte haystacks, still promising 8: more starts in a tile than the kernel has room for;
+    # it raises its flag and the result comes from a second scan on the general kernels
+    lens = [3] * 5000 + [300] * 20 + [1] * 3000 + [0] * 10 + [2] * 999
+    off = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+    flat = np.ascontiguousarray(alpha[rng.integers(0, 4, size=int(off[-1]))])
+    _check(A, O, flat, off, min_hay_len=8)
+    _check(A, O, flat, off, min_hay_len=0)
+    # the same through the asynchronous entry
+    img = Image.from_automaton(A)
+    sc = Scanner(img)
+    d_hay = DeviceBuffer.from_numpy(flat, pad=64)
+    d_off = DeviceBuffer.from_numpy(off)
+    sc.scan(d_hay, len(flat), len(off) - 1, dev_off=d_off, min_hay_len=8, asynchronous=True)
+    sc.wait()
+    moff, e, v, _ = sc.fetch()
+    mo, oe, ov = O.batch(flat.tobytes(), off, 0)
+    assert np.array_equal(moff, mo) and np.array_equal(e, oe) and np.array_equal(v, ov)

@@ -41,3 +41,31 @@ def test_world_size_2_gloo_broadcast_shard_gather():
     p = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=240)
     out = p.stdout.decode(errors="replace")
     assert p.returncode == 0 and "PARALLEL_CPU_OK" in out, out[-3000:]
+
+
+def test_halo_shard_ranges():
+    from pyahocorasick_amd.parallel import halo_shard
+    for total in (0, 1, 100, 12345):
+        for w in (1, 2, 8):
+            cuts = [halo_shard(total, r, w, 32) for r in range(w)]
+            assert cuts[0][0] == 0 and cuts[0][1] == 0 and cuts[-1][2] == total
+            assert all(a[2] == b[1] for a, b in zip(cuts, cuts[1:]))
+            assert all(lo - s0 == min(lo, 31) for s0, lo, hi in cuts)
+
+
+def test_bench_gpus_n_launches_its_own_ranks():
+    """`python bench.py --gpus 2` with no WORLD_SIZE in the environment must start 2 ranks itself (the driver's 8-GPU
+    run is launched exactly like that).  --launch-check stops after the ranks have met (gloo, no GPU)."""
+    import json
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["OMP_NUM_THREADS"] = "1"
+    bench = os.path.join(os.path.dirname(HERE), "bench.py")
+    p = subprocess.run([sys.executable, bench, "--gpus", "2", "--launch-check"], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=240)
+    out = p.stdout.decode(errors="replace").strip().splitlines()
+    assert p.returncode == 0, p.stderr.decode(errors="replace")[-3000:]
+    line = json.loads([x for x in out if x.startswith("{")][-1])
+    assert line == {"n_gpus": 2, "launch_check": True}
+    # a rank count that does not match --gpus is an error, not a silent N = 1 line
+    env2 = dict(env, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
+    p2 = subprocess.run([sys.executable, bench, "--gpus", "2", "--launch-check"], env=env2, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=120)
+    assert p2.returncode != 0 and b"WORLD_SIZE=1" in p2.stderr
