@@ -76,7 +76,7 @@
 #define ACX_ITOP_FLAG_TFLAGS_ID 2u
 
 #define ACX_BLOB_MAGIC        0x31424F4C42584341ull   /* "ACXBLOB1" */
-#define ACX_BLOB_VERSION      1u
+#define ACX_BLOB_VERSION      2u          /* 2: the checksum below, the "PPM3" section (hot cells, symbol table) */
 #define ACX_BLOB_HEADER_BYTES 256u
 #define ACX_BLOB_ALIGN        256u
 
@@ -114,7 +114,11 @@ typedef struct acx_blob_header {
     uint64_t off_node_flags; /* uint8  [n_states]       bit0 = eow                       */
     uint64_t off_out_off;    /* uint32 [n_states + 1]   CSR offsets into out_val         */
     uint64_t off_out_val;    /* int32  [n_out]          values in fail-chain order       */
-    uint64_t fnv1a64;        /* FNV-1a of bytes [header_bytes, total_bytes)              */
+    uint64_t fnv1a64;        /* checksum of bytes [header_bytes, total_bytes): FNV-1a's xor-multiply step (offset basis
+                                0xcbf29ce484222325 + k, prime 0x100000001b3) applied to little-endian 8-byte WORDS in 8
+                                interleaved lanes k = 0..7 (word i of every 64-byte block goes to lane i), then plain
+                                byte-wise FNV-1a over the 64 bytes of the lanes (lane 0 first, low byte first) and over
+                                the tail bytes that do not fill a 64-byte block (acx_fnv1a64, acx_trie.cpp) */
     uint64_t off_first_val;  /* int32  [n_states]       out_val[out_off[s]] (first output of s:
                                 the value iter_long reports, and the only one when CNT == 1) */
     uint32_t state_bits;     /* SB of the entry layout: 24 or 27                         */

@@ -29,7 +29,8 @@ def lib():
     global _lib
     if _lib is None:
         src_newer = (not os.path.exists(LIB)) or any(
-            os.path.getmtime(os.path.join(HERE, f)) > os.path.getmtime(LIB) for f in ("ac_oracle.c", "flat_walk.c", "ppm_walk.c"))
+            os.path.getmtime(os.path.join(HERE, f)) > os.path.getmtime(LIB)
+            for f in ("ac_oracle.c", "flat_walk.c", "ppm_walk.c", os.path.join("..", "include", "acx_blob.h")))
         if src_newer:
             build()
         l = C.CDLL(LIB)

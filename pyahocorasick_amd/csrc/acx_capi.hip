@@ -11,6 +11,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <new>
 #include <vector>
 
@@ -84,6 +85,7 @@ struct acx_image {
     const uint32_t* tflags = nullptr;
     uint32_t* built_table = nullptr;        // table built in HBM (blob without a table section); owned
     std::vector<uint32_t> lvl_host;         // level boundaries, kept for a table that is built on first use
+    std::mutex table_mu;                    // the dense table is built on first use: one builder, and everybody who needs the table asks under it
     // position-parallel scan image (include/acx_blob.h "ppm"); ppm_g == nullptr: absent
     acx_ppm_header ppm;
     const uint32_t* ppm_g = nullptr;
@@ -126,9 +128,27 @@ static int image_resolve(acx_image* img, const uint32_t* lvl_host) {
     if (img->h.off_ppm) {
         HIP_TRY(hipMemcpy(&img->ppm, img->dev + img->h.off_ppm, sizeof img->ppm, hipMemcpyDeviceToHost));
         const acx_ppm_header& ph = img->ppm;
-        if (ph.magic != ACX_PPM_MAGIC || img->h.off_ppm + ph.total_bytes > img->nbytes || ph.C == 0 || ph.C > ACX_PPM_MAX_C || ph.F < ph.C ||
-            (ph.sym_bits != 2 && ph.sym_bits != 4 && ph.sym_bits != 8))
-            return acx_fail(ACX_E_FORMAT, "image: malformed ppm section");
+        // a corrupt or foreign section must not make the kernels read out of bounds: every sub-section lies inside it
+        auto pw = [&](uint64_t base, uint32_t e) -> uint64_t { uint64_t p = 1; for (uint32_t i = 0; i < e; i++) { p *= base; if (p > ((uint64_t)1 << 40)) return (uint64_t)1 << 40; } return p; };
+        const uint64_t tb = ph.total_bytes;
+        auto inside = [&](uint64_t off, uint64_t len) { return off >= sizeof(acx_ppm_header) && off <= tb && len <= tb - off; };
+        bool ok = ph.magic == ACX_PPM_MAGIC && img->h.off_ppm <= img->nbytes && tb <= img->nbytes - img->h.off_ppm && tb >= sizeof(acx_ppm_header) &&
+                  ph.C >= 1 && ph.C <= 16 && ph.C <= ACX_PPM_MAX_C && ph.F >= ph.C && ph.F <= ph.C + 1 &&
+                  (ph.sym_bits == 2 || ph.sym_bits == 4 || ph.sym_bits == 8) && ph.K >= 1 && ph.K <= (1u << ph.sym_bits) &&
+                  (ph.sym_bits != 2 || ph.C <= 12) && ph.longest >= 1;
+        if (ok) {
+            const uint64_t nC = pw(ph.K, ph.C), nF = pw(ph.K, ph.F), nF2 = ph.F2 ? pw(ph.K, ph.F2) : 0;
+            ok = nC <= ((uint64_t)1 << 22) && nF <= ((uint64_t)1 << 32) && ph.g_words == (uint32_t)((nF + 31) / 32) &&
+                 (ph.F2 == 0 || (ph.F2 > ph.F && nF2 <= ((uint64_t)1 << 32) && ph.g2_words == (uint32_t)((nF2 + 31) / 32))) &&
+                 inside(ph.off_g, (uint64_t)ph.g_words * 4) && (ph.F2 == 0 || inside(ph.off_g2, (uint64_t)ph.g2_words * 4)) &&
+                 inside(ph.off_symtab, 256) && inside(ph.off_cells, nC * 32) && inside(ph.off_hot, nC * 8) &&
+                 inside(ph.off_top_val, (uint64_t)ph.n_top * 4) && inside(ph.off_kids, ((uint64_t)ph.n_deep + 1) * ph.K * 16) &&
+                 inside(ph.off_chains, ((uint64_t)ph.n_chain + 1) * 16);
+            uint64_t tbase = 0;
+            for (uint32_t d = 0; ok && d <= ph.C; d++) { ok = ph.top_base[d] == tbase; tbase += pw(ph.K, d); }
+            ok = ok && ph.n_top == tbase && (ph.sym_arith == 0 || (ph.K == 4 && ph.sym_arith <= 7));
+        }
+        if (!ok) return acx_fail(ACX_E_FORMAT, "image: malformed ppm section");
         const uint8_t* sec = img->dev + img->h.off_ppm;
         img->ppm_g = (const uint32_t*)(sec + ph.off_g);
         img->ppm_cells = (const uint32_t*)(sec + ph.off_cells);
@@ -173,30 +193,42 @@ static int image_build_table(acx_image* img, const uint32_t* lvl_host) {
     // read one entry past the end of the table): a table built here gets its own copy of the cells
     const size_t cells_at = (tbytes + 16 + 255) & ~(size_t)255;
     const size_t cbytes = img->itop_lds ? (size_t)img->h.itop_cell_bytes << (img->h.itop_bits * img->h.itop_depth) : 0;
-    HIP_TRY(hipMalloc((void**)&img->built_table, cells_at + cbytes));
-    if (cbytes) {
-        HIP_TRY(hipMemcpy((uint8_t*)img->built_table + cells_at, img->itop_cells, cbytes, hipMemcpyDeviceToDevice));
-        img->itop_cells = (const uint8_t*)img->built_table + cells_at;
-    }
+    uint32_t* built = nullptr;
+    HIP_TRY(hipMalloc((void**)&built, cells_at + cbytes));
+    auto fail = [&](hipError_t e, const char* what) {
+        (void)hipFree(built);
+        return acx_fail(e == hipErrorOutOfMemory ? ACX_E_NOMEM : ACX_E_HIP, "building the dense table: %s failed: %s", what, hipGetErrorString(e));
+    };
+    hipError_t e = hipSuccess;
+    if (cbytes) { e = hipMemcpy((uint8_t*)built + cells_at, img->itop_cells, cbytes, hipMemcpyDeviceToDevice); if (e != hipSuccess) return fail(e, "hipMemcpy(cells)"); }
     std::vector<uint32_t> lvl;
     if (!lvl_host && !img->lvl_host.empty()) lvl_host = img->lvl_host.data();
     if (!lvl_host) {
         lvl.resize((size_t)img->h.n_levels + 1);
-        HIP_TRY(hipMemcpy(lvl.data(), img->dev + img->h.off_lvl_first, lvl.size() * 4, hipMemcpyDeviceToHost));
+        e = hipMemcpy(lvl.data(), img->dev + img->h.off_lvl_first, lvl.size() * 4, hipMemcpyDeviceToHost);
+        if (e != hipSuccess) return fail(e, "hipMemcpy(levels)");
         lvl_host = lvl.data();
     }
-    HIP_TRY(acx_launch_build_table(img->built_table, (const int32_t*)(img->dev + img->h.off_fail),
-                                   (const uint32_t*)(img->dev + img->h.off_edge_off), img->dev + img->h.off_edge_cls,
-                                   (const uint32_t*)(img->dev + img->h.off_edge_dst), (const uint32_t*)(img->dev + img->h.off_tflags),
-                                   lvl_host, img->h.n_levels, img->h.n_classes, img->h.state_bits, nullptr));
-    HIP_TRY(hipDeviceSynchronize());
-    img->table = img->built_table;
+    e = acx_launch_build_table(built, (const int32_t*)(img->dev + img->h.off_fail),
+                               (const uint32_t*)(img->dev + img->h.off_edge_off), img->dev + img->h.off_edge_cls,
+                               (const uint32_t*)(img->dev + img->h.off_edge_dst), (const uint32_t*)(img->dev + img->h.off_tflags),
+                               lvl_host, img->h.n_levels, img->h.n_classes, img->h.state_bits, nullptr);
+    if (e != hipSuccess) return fail(e, "the build kernels");
+    e = hipDeviceSynchronize();
+    if (e != hipSuccess) return fail(e, "hipDeviceSynchronize");
+    // publish: everything else first, the table pointer last (readers ask image_ensure_table, under the same mutex)
+    img->built_table = built;
+    if (cbytes) img->itop_cells = (const uint8_t*)built + cells_at;
+    img->table = built;
     image_check_itop_reach(img);
     return ACX_OK;
 }
 
-// the serial walks read the dense table: make sure it exists
+// the serial walks read the dense table: make sure it exists.  Thread-safe: two host threads that share an image and
+// both need the table find one builder; scans that never need it (ACX_SCAN_ALL on the position-parallel kernels
+// without carried states) do not come here.
 static int image_ensure_table(acx_image* img) {
+    std::lock_guard<std::mutex> g(img->table_mu);
     if (img->table) return ACX_OK;
     return image_build_table(img, nullptr);
 }

@@ -6,6 +6,8 @@
 #include "acx_internal.h"
 
 #include <cstdlib>
+#include <exception>
+#include <mutex>
 #include <thread>
 #include <vector>
 
@@ -89,12 +91,20 @@ static inline void parallel_range(size_t lo, size_t hi, F&& f) {
     const size_t step = (n + T - 1) / T;
     std::vector<std::thread> th;
     th.reserve(T - 1);
+    // an exception in a worker (std::bad_alloc) would end the process: it is carried to the calling thread instead
+    std::exception_ptr err;
+    std::mutex err_mu;
+    auto guarded = [&](size_t a, size_t b) {
+        try { f(a, b); }
+        catch (...) { std::lock_guard<std::mutex> g(err_mu); if (!err) err = std::current_exception(); }
+    };
     for (size_t k = 1; k < T; k++) {
         const size_t a = lo + k * step, b = a + step < hi ? a + step : hi;
-        if (a < b) th.emplace_back([&f, a, b] { f(a, b); });
+        if (a < b) th.emplace_back([&guarded, a, b] { guarded(a, b); });
     }
-    f(lo, lo + step < hi ? lo + step : hi);
+    guarded(lo, lo + step < hi ? lo + step : hi);
     for (auto& x : th) x.join();
+    if (err) std::rethrow_exception(err);
 }
 
 
