@@ -63,6 +63,13 @@ void acx_trie_free(acx_trie_t* t);
 /* add (or overwrite the value of) a key.  *is_new = 1 if the key was not present.
  * len == 0 is accepted and ignored (*is_new = 0), as src/Automaton.c:257 does. */
 int  acx_trie_add_word(acx_trie_t* t, const uint8_t* key, size_t len, int64_t value, int* is_new);
+/* Many keys in one call (no counterpart in the reference, which adds one word per Python call: src/Automaton.c:201-300
+ * — 4.4 s of interpreter time for a million signatures).  Key i = keys[key_off[i] .. key_off[i+1]); its value is
+ * values[i], or with values == NULL what add_word's defaults give: value_mode 1 = the number of keys after the
+ * insertion (STORE_INTS default, src/Automaton.c:238-242), 2 = the key's length in bytes (STORE_LENGTH, :245-247).
+ * Same semantics as n calls of acx_trie_add_word, in order; *n_new = how many keys were not present before. */
+int  acx_trie_add_words(acx_trie_t* t, const uint8_t* keys, const int64_t* key_off, const int64_t* values, int64_t n,
+                        int value_mode, int64_t* n_new);
 /* exact lookup; *found = 1 and *value set when key is present (trie_find + eow test) */
 int  acx_trie_get(const acx_trie_t* t, const uint8_t* key, size_t len, int* found, int64_t* value);
 /* remove a key (trie_remove_word, src/trie.c:66-133); *found = 0 when absent */

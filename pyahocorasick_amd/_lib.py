@@ -55,6 +55,7 @@ SIGNATURES = {
     "acx_trie_new": (C.c_int, [_PP]),
     "acx_trie_free": (None, [_P]),
     "acx_trie_add_word": (C.c_int, [_P, _u8p, C.c_size_t, C.c_int64, C.POINTER(C.c_int)]),
+    "acx_trie_add_words": (C.c_int, [_P, _P, _P, _P, C.c_int64, C.c_int, C.POINTER(C.c_int64)]),
     "acx_trie_get": (C.c_int, [_P, _u8p, C.c_size_t, C.POINTER(C.c_int), C.POINTER(C.c_int64)]),
     "acx_trie_remove_word": (C.c_int, [_P, _u8p, C.c_size_t, C.POINTER(C.c_int), C.POINTER(C.c_int64)]),
     "acx_trie_longest_prefix": (C.c_int, [_P, _u8p, C.c_size_t, C.POINTER(C.c_size_t)]),

@@ -312,6 +312,27 @@ class Automaton:
         check(lib().acx_trie_add_word(self._trie, key, len(key), v, C.byref(is_new)))
         return bool(is_new.value)
 
+    def add_words(self, keys, values=None):
+        """Many keys in one call (not in the reference): the same as add_word(k, v) for every pair in order, without
+        a Python call per key — one acx_trie_add_words for STORE_INTS / STORE_LENGTH.  Returns how many keys were new."""
+        keys = [self._key(k) for k in keys]
+        if self._store == STORE_ANY:
+            if values is None:
+                raise ValueError("A value object is required as second argument.")
+            return sum(1 for k, v in zip(keys, values) if self.add_word(k, v))
+        off = np.zeros(len(keys) + 1, dtype=np.int64)
+        np.cumsum([len(k) for k in keys], out=off[1:])
+        buf = np.frombuffer(b"".join(keys), dtype=np.uint8) if off[-1] else np.zeros(1, dtype=np.uint8)
+        vals = None
+        if self._store == STORE_INTS and values is not None:
+            vals = np.array([((int(v) + (1 << 63)) % (1 << 64)) - (1 << 63) for v in values], dtype=np.int64)
+            if len(vals) != len(keys):
+                raise ValueError("add_words: %d keys, %d values" % (len(keys), len(vals)))
+        n_new = C.c_int64(0)
+        check(lib().acx_trie_add_words(self._trie, buf.ctypes.data, off.ctypes.data, vals.ctypes.data if vals is not None else None,
+                                       len(keys), 1 if self._store == STORE_INTS else 2, C.byref(n_new)))
+        return int(n_new.value)
+
     def exists(self, key):
         key = self._key(key)
         found = C.c_int(0)

@@ -27,8 +27,15 @@ def _hipcc():
     raise RuntimeError("hipcc not found (set HIPCC or install ROCm)")
 
 
+FLAGS_STAMP = LIB + ".flags"
+
+
 def needs_build():
     if not os.path.exists(LIB):
+        return True
+    want = os.environ.get("ACX_EXTRA_CFLAGS", "").strip()
+    have = open(FLAGS_STAMP).read().strip() if os.path.exists(FLAGS_STAMP) else ""
+    if want != have:                      # the library in place was built with other flags (e.g. a development build)
         return True
     t = os.path.getmtime(LIB)
     deps = [os.path.join(CSRC, s) for s in SOURCES] + HEADERS
@@ -66,6 +73,8 @@ def build_libacx(force=False, verbose=True):
     if verbose:
         print("[pyahocorasick_amd.build]", " ".join(cmd), flush=True)
     subprocess.check_call(cmd)
+    with open(FLAGS_STAMP, "w") as f:
+        f.write(os.environ.get("ACX_EXTRA_CFLAGS", "").strip())
     return LIB
 
 

@@ -881,8 +881,12 @@ __global__ void __launch_bounds__(ACX_PPM_BLOCK) k_ppm_stream(const acx_ppm_args
         // before the first is looked at; the walks below the cells — one entry in six asks for one — are collected over the
         // whole round and run on all 64 lanes at once, their entries handed over through the queue's memory, which is
         // free by then.  Straight-line code per entry slot; slots >= k are skipped (wave-uniform).
+        // Slots are worked in PAIRS: a pair beyond the queue's end is skipped (tiles of sparse dictionaries hold a handful of
+        // entries), and the two slots of a pair stay one basic block, so their LDS reads and gathers overlap.
+#define PPM_SLOTS(e, ...) _Pragma("unroll") for (int g_ = 0; g_ < NE; g_ += 2) { if (g_ == 0 || (uint32_t)g_ < k) { _Pragma("unroll") for (int e = g_; e < g_ + 2; e++) { __VA_ARGS__ } } }
         auto do_round = [&]() {
             const uint32_t n = qcount;
+            const uint32_t k = (n + 63u) >> 6;                           // slots that hold entries
             uint32_t pp[NE], XX[NE], rr[NE], LL[NE], cn[NE];
             u32x2 hc[NE];
             int32_t va[NE], vb[NE];
@@ -890,20 +894,18 @@ __global__ void __launch_bounds__(ACX_PPM_BLOCK) k_ppm_stream(const acx_ppm_args
             // slots below, which must stay one basic block: a branch between two of them, even one that never diverges,
             // keeps the scheduler from overlapping their LDS reads.
 #pragma unroll
-            for (int e = 0; e < NE; e++) LL[e] = longest;
+            for (int e = 0; e < NE; e++) { LL[e] = longest; pp[e] = 0x18000u; XX[e] = 0; rr[e] = 1; cn[e] = 0; va[e] = 0; vb[e] = 0; hc[e].x = 0; hc[e].y = 0; }
             if (use_other) {
-#pragma unroll
-                for (int e = 0; e < NE; e++) {
+                PPM_SLOTS(e,
                     const uint32_t qi = 64u * (uint32_t)e + (uint32_t)lane;
                     const uint32_t lo2 = other_limit(HP + (qi < n ? (uint32_t)queue[qi] & 0x7FFFu : 0u));
                     if (lo2 < LL[e]) LL[e] = lo2;
-                }
+                )
             }
             // 1. where the entries sit, their windows, the requests for their hot cells.  Straight-line over all NE slots
             // (a slot beyond the queue's end works on position 0 with L = 0, which matches nothing): the LDS reads and
             // the gathers of the slots overlap.
-#pragma unroll
-            for (int e = 0; e < NE; e++) {
+            PPM_SLOTS(e,
                 const uint32_t qi = 64u * (uint32_t)e + (uint32_t)lane;
                 const bool act = qi < n;
                 uint32_t ent = queue[qi];                                // (within the queue's memory for any qi < 64 NE)
@@ -914,20 +916,21 @@ __global__ void __launch_bounds__(ACX_PPM_BLOCK) k_ppm_stream(const acx_ppm_args
                 where(p, r, rk);
                 if (OFFS && hbase == 0xFFFFFFFFu && rk == 0u) cand = false;          // (a byte in front of off[0]: belongs to no haystack)
                 const uint32_t L = r + 1 < LL[e] ? r + 1 : LL[e];
-                pp[e] = ent; rr[e] = act ? r : 1u;
+                pp[e] = ent | (rk << 17); rr[e] = act ? r : 1u;          // (the rank: at most TPOS / 8 starts per tile)
                 LL[e] = cand ? L : 0u;
                 XX[e] = P.window(HP + p);
                 // the cell of the C newest symbols as they stand: what it says about depths <= L does not depend on
                 // the older ones, and nothing deeper is asked when L <= C
                 hc[e] = *(const u32x2*)((const uint8_t*)a.hot + (code_n(XX[e], Cn) << 3));   // (32-bit offset)
-            }
+            )
             wave_sync();                                                 // (the queue's memory is free from here on)
             PH(2);
             // 2. top levels: how many keys end here, the value of the shallowest, whether the walk goes deeper
             uint32_t n_go = 0, gomask = 0, tvany = 0;
             uint32_t tvm[NE];
 #pragma unroll
-            for (int e = 0; e < NE; e++) {
+            for (int e = 0; e < NE; e++) tvm[e] = 0;
+            PPM_SLOTS(e,
                 const uint32_t hw = hc[e].x, hx = hc[e].y, L = LL[e];
                 const uint32_t m = hw & cmask & ((1u << (L < 16u ? L : 16u)) - 1u);
                 cn[e] = (uint32_t)__popc(m);
@@ -943,7 +946,7 @@ __global__ void __launch_bounds__(ACX_PPM_BLOCK) k_ppm_stream(const acx_ppm_args
                 va[e] = (int32_t)hx; vb[e] = 0;                          // (the shallowest key's value, unless the word holds the id)
                 tvm[e] = ((cn[e] >= 2u ? 1u : 0u) | ((cn[e] == 1u ? 1u : 0u) & has_id)) ? m : 0u;
                 tvany |= tvm[e];
-            }
+            )
             // values that the cell does not hold: its second word is the id, or a second key ends here
             if (__any(tvany != 0u)) {
 #pragma unroll
@@ -966,14 +969,13 @@ __global__ void __launch_bounds__(ACX_PPM_BLOCK) k_ppm_stream(const acx_ppm_args
             for (uint32_t d0 = 0; d0 < n_deep; d0 += 64u) {
                 {
                     uint32_t rnk = d_base - d0;                          // (unsigned: ranks below d0 wrap far beyond 64)
-#pragma unroll
-                    for (int e = 0; e < NE; e++) {
+                    PPM_SLOTS(e,
                         const uint32_t g = (gomask >> e) & 1u;
                         const uint32_t slot = (g != 0u && rnk < 64u) ? rnk : 64u;       // (slot 64: nobody reads it)
                         u32x2 v; v.x = (HP + (pp[e] & 0x7FFFu)) | (LL[e] << 12); v.y = (uint32_t)hc[e].y;
                         *(u32x2*)(dq + 2 * slot) = v;
                         rnk += g;
-                    }
+                    )
                 }
                 wave_sync();
                 {
@@ -1011,8 +1013,7 @@ __global__ void __launch_bounds__(ACX_PPM_BLOCK) k_ppm_stream(const acx_ppm_args
                 wave_sync();
                 {
                     uint32_t rnk = d_base - d0;
-#pragma unroll
-                    for (int e = 0; e < NE; e++) {
+                    PPM_SLOTS(e,
                         const uint32_t g = (gomask >> e) & 1u;
                         const bool mine = g != 0u && rnk < 64u;
                         const uint32_t slot = mine ? rnk : 64u;
@@ -1023,7 +1024,7 @@ __global__ void __launch_bounds__(ACX_PPM_BLOCK) k_ppm_stream(const acx_ppm_args
                         vb[e] = c0 ? (int32_t)dv.y : (c1 ? (int32_t)dv.x : vb[e]);
                         cn[e] += c2;
                         rnk += g;
-                    }
+                    )
                 }
                 wave_sync();
             }
@@ -1034,10 +1035,13 @@ __global__ void __launch_bounds__(ACX_PPM_BLOCK) k_ppm_stream(const acx_ppm_args
             static_assert(NE % 2 == 0, "slots are placed in pairs");
 #pragma unroll
             for (int e = 0; e < NE; e += 2) {
-                uint32_t t;
-                const uint32_t x2 = wave_excl_scan(cn[e] | (cn[e + 1] << 16), t);
-                ex[e] = rt + (x2 & 0xFFFFu); rt += t & 0xFFFFu;
-                ex[e + 1] = rt + (x2 >> 16); rt += t >> 16;
+                ex[e] = rt; ex[e + 1] = rt;
+                if (e == 0 || (uint32_t)e < k) {
+                    uint32_t t;
+                    const uint32_t x2 = wave_excl_scan(cn[e] | (cn[e + 1] << 16), t);
+                    ex[e] = rt + (x2 & 0xFFFFu); rt += t & 0xFFFFu;
+                    ex[e + 1] = rt + (x2 >> 16); rt += t >> 16;
+                }
             }
             if (rt && !dead) {
                 if (g_used + rt + 1u > g_size) {                       // this round (and the spare slot behind it) does not fit the current grant: open the next one
@@ -1070,14 +1074,11 @@ __global__ void __launch_bounds__(ACX_PPM_BLOCK) k_ppm_stream(const acx_ppm_args
                 for (int e = 0; e < NE; e++) startany |= rr[e] == 0u ? 1u : 0u;       // (no entry: rr = 1)
                 if (__any(startany != 0u) || a.index_base) {
                     const uint32_t dump = (uint32_t)a.n_hay;             // hay_local[n_hay]: spare
-#pragma unroll
-                    for (int e = 0; e < NE; e++) {
-                        uint32_t r, rk;
-                        where(pp[e] & 0x7FFFu, r, rk);
-                        const uint32_t hh = OFFS ? hbase + rk : h_tile + rk;
+                    PPM_SLOTS(e,
+                        const uint32_t hh = (OFFS ? hbase : h_tile) + (pp[e] >> 17);      // (the rank that step 1 found)
                         a.hay_local[rr[e] == 0u ? hh : dump] = (int32_t)(run_off + ex[e]);   // the records in front of this haystack
                         if (a.index_base) rr[e] += cn[e] ? (uint32_t)a.index_base[hh] : 0u;
-                    }
+                    )
                 }
             }
             // 6. records, longest key of a position first.  Slot rt of the round (one past its last record; the grant has
@@ -1086,13 +1087,12 @@ __global__ void __launch_bounds__(ACX_PPM_BLOCK) k_ppm_stream(const acx_ppm_args
             uint8_t* const out8 = (uint8_t*)(a.scratch + g_base + g_used);
             uint2* const out = (uint2*)out8;
             if (wr) {
-#pragma unroll
-                for (int e = 0; e < NE; e++) {
-                    const uint32_t c = cn[e], oe = ex[e] + c - 1u, idx = rr[e];
+                PPM_SLOTS(e,
+                    const uint32_t c = cn[e]; const uint32_t oe = ex[e] + c - 1u; const uint32_t idx = rr[e];
                     *(uint2*)(out8 + ((c ? oe : rt) << 3)) = make_uint2(idx, (uint32_t)va[e]);
                     *(uint2*)(out8 + ((c > 1u ? oe - 1u : rt) << 3)) = make_uint2(idx, (uint32_t)vb[e]);
                     slow |= (c > 2u ? 1u : 0u) << e;
-                }
+                )
                 while (__any(slow != 0u)) {                              // rare: one slot per lane and pass, from the 32-byte cell
                     if (slow) {
                         const uint32_t se = (uint32_t)__ffs(slow) - 1u;
@@ -1115,6 +1115,7 @@ __global__ void __launch_bounds__(ACX_PPM_BLOCK) k_ppm_stream(const acx_ppm_args
             wave_sync();
             PH(5);
         };
+#undef PPM_SLOTS
 
         // (one call site of the round: its code exists once)
         uint32_t seg_lo = 0;

@@ -79,6 +79,24 @@ int acx_trie_add_word(acx_trie_t* t, const uint8_t* key, size_t len, int64_t val
     return ACX_OK;
 }
 
+int acx_trie_add_words(acx_trie_t* t, const uint8_t* keys, const int64_t* key_off, const int64_t* values, int64_t n,
+                       int value_mode, int64_t* n_new) {
+    if (!t || !key_off || n < 0 || (!keys && n && key_off[n] > key_off[0])) return acx_fail(ACX_E_INVAL, "acx_trie_add_words: bad argument");
+    if (!values && value_mode != 1 && value_mode != 2) return acx_fail(ACX_E_INVAL, "acx_trie_add_words: values == NULL needs value_mode 1 or 2");
+    int64_t fresh = 0;
+    for (int64_t i = 0; i < n; i++) {
+        if (key_off[i + 1] < key_off[i]) return acx_fail(ACX_E_INVAL, "acx_trie_add_words: offsets not monotone at %lld", (long long)i);
+        const size_t len = (size_t)(key_off[i + 1] - key_off[i]);
+        const int64_t v = values ? values[i] : (value_mode == 1 ? t->count + 1 : (int64_t)len);
+        int is_new = 0;
+        const int rc = acx_trie_add_word(t, keys + key_off[i], len, v, &is_new);
+        if (rc) { if (n_new) *n_new = fresh; return rc; }
+        fresh += is_new;
+    }
+    if (n_new) *n_new = fresh;
+    return ACX_OK;
+}
+
 static int32_t find_node(const acx_trie* t, const uint8_t* key, size_t len) {
     if (t->kind == ACX_KIND_EMPTY) return -1;
     int32_t node = 0;

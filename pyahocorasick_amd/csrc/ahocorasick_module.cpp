@@ -41,10 +41,35 @@ struct AutomatonObject {
     int store;
     int key_type;
     PyObject* values;          // list: value id -> object (STORE_ANY only)
-    acx_image_t* image;        // device image, valid for image_version
+    struct ImageRef* image;    // device image, valid for image_version; shared with the scans in flight
     int64_t image_version;
-    acx_result_t* result;      // reusable device / pinned buffers
+    std::vector<acx_result_t*>* results;   // idle result objects (device / pinned buffers), reused by the next scan
     std::vector<Py_ssize_t>* free_slots;   // STORE_ANY: slots of `values` freed by remove_word / pop, reused by add_word
+};
+
+// A scan runs WITHOUT the GIL: other Python threads may meanwhile change the automaton, which replaces
+// the device image.  The image a scan uses is therefore counted: it is freed by whoever drops the last use.  Every
+// scan has a result object of its own (taken from the automaton's idle list, handed back when its records have been
+// copied out), so two threads scanning one automaton share nothing but the immutable image.  All counters and lists
+// are touched with the GIL held.
+struct ImageRef { acx_image_t* img; int users; bool dead; };
+inline void image_drop(ImageRef* r) { if (r && r->users == 0 && r->dead) { acx_image_free(r->img); delete r; } }
+inline void image_retire(AutomatonObject* a) {
+    if (!a->image) return;
+    a->image->dead = true;
+    image_drop(a->image);
+    a->image = nullptr;
+}
+struct ScanLease {                 // what one scan holds until its caller has copied the records out
+    AutomatonObject* a = nullptr; ImageRef* ref = nullptr; acx_result_t* res = nullptr;
+    void done() {
+        if (ref) { ref->users--; image_drop(ref); ref = nullptr; }
+        if (res) {
+            if (a->results && a->results->size() < 4) a->results->push_back(res); else acx_result_free(res);
+            res = nullptr;
+        }
+    }
+    ~ScanLease() { done(); }
 };
 
 PyObject* set_acx_error(int rc) {
@@ -243,28 +268,42 @@ bool parse_start_end(PyObject* args, Py_ssize_t i0, Py_ssize_t i1, Py_ssize_t lo
 bool gpu_sync(AutomatonObject* a) {
     const int64_t v = acx_trie_version(a->trie);
     if (a->image && a->image_version == v) return true;
-    if (a->image) { acx_image_free(a->image); a->image = nullptr; }
+    image_retire(a);
     void* blob = nullptr; size_t nbytes = 0;
-    int rc = acx_flatten(a->trie, &blob, &nbytes);
+    int rc = acx_flatten(a->trie, &blob, &nbytes);                // (reads the host trie: the GIL stays held)
     if (rc) { set_acx_error(rc); return false; }
-    // the GIL stays held, here and around the scan: the image and the result buffers belong to this
-    // Automaton object and the reference never releases it either (sharing an automaton between
-    // threads is safe there: src/Automaton.c holds the GIL for the whole of every call)
-    rc = acx_image_upload(blob, nbytes, &a->image);
+    acx_image_t* img = nullptr;
+    rc = acx_image_upload(blob, nbytes, &img);
     acx_blob_free(blob);
     if (rc) { set_acx_error(rc); return false; }
+    a->image = new (std::nothrow) ImageRef{img, 0, false};
+    if (!a->image) { acx_image_free(img); PyErr_NoMemory(); return false; }
     a->image_version = v;
     return true;
 }
 
-// one GPU scan of n haystacks given as (data, offsets); results stay in a->result
+// one GPU scan of n haystacks given as (data, offsets).  The GIL is released around H2D, kernels and D2H; the
+// records stay valid until lease->done() (or its destructor).  `data` must not be a buffer that another Python
+// thread can free meanwhile: the callers pass memory of objects they hold a reference to, or their own copies.
 bool run_scan(AutomatonObject* a, int mode, const uint8_t* data, const int64_t* off, int64_t n,
               const int32_t* init_state, const int32_t* index_base,
-              const int64_t** moff, const acx_match_t** m, const int32_t** fin) {
+              const int64_t** moff, const acx_match_t** m, const int32_t** fin, ScanLease* lease) {
     if (!gpu_sync(a)) return false;
-    int rc = acx_scan_host(a->image, mode, data, off, n, init_state, index_base, &a->result);
-    if (!rc) rc = acx_result_fetch_host(a->result, moff, m, fin);
-    if (rc) { set_acx_error(rc); return false; }
+    lease->a = a; lease->ref = a->image; lease->ref->users++;
+    if (a->results && !a->results->empty()) { lease->res = a->results->back(); a->results->pop_back(); }
+    acx_image_t* const img = lease->ref->img;
+    int rc;
+    char err[512];
+    err[0] = 0;
+    Py_BEGIN_ALLOW_THREADS
+    rc = acx_scan_host(img, mode, data, off, n, init_state, index_base, &lease->res);
+    if (!rc) rc = acx_result_fetch_host(lease->res, moff, m, fin);
+    if (rc) { strncpy(err, acx_last_error(), sizeof err - 1); err[sizeof err - 1] = 0; }     // (the message is thread-local: keep it across the switch)
+    Py_END_ALLOW_THREADS
+    if (rc) {
+        if (rc == ACX_E_NOMEM) PyErr_NoMemory(); else PyErr_SetString(PyExc_RuntimeError, err);
+        return false;
+    }
     return true;
 }
 
@@ -293,7 +332,8 @@ bool check_store_key(int store, int key_type) {
 AutomatonObject* automaton_alloc(PyTypeObject* type, int store, int key_type) {
     AutomatonObject* a = (AutomatonObject*)type->tp_alloc(type, 0);
     if (!a) return nullptr;
-    a->trie = nullptr; a->values = nullptr; a->image = nullptr; a->result = nullptr; a->image_version = -1;
+    a->trie = nullptr; a->values = nullptr; a->image = nullptr; a->image_version = -1;
+    a->results = new (std::nothrow) std::vector<acx_result_t*>();
     a->free_slots = new (std::nothrow) std::vector<Py_ssize_t>();
     a->store = store; a->key_type = key_type;
     return a;
@@ -375,8 +415,8 @@ PyObject* automaton_new(PyTypeObject* type, PyObject* args, PyObject*) {
 }
 
 void automaton_dealloc(AutomatonObject* a) {
-    if (a->image) acx_image_free(a->image);
-    if (a->result) acx_result_free(a->result);
+    image_retire(a);
+    if (a->results) { for (acx_result_t* r : *a->results) acx_result_free(r); delete a->results; }
     if (a->trie) acx_trie_free(a->trie);
     Py_XDECREF(a->values);
     delete a->free_slots;
@@ -426,6 +466,37 @@ PyObject* automaton_add_word(AutomatonObject* a, PyObject* args) {
     }
     if (is_new) Py_RETURN_TRUE;
     Py_RETURN_FALSE;
+}
+
+// add_words(keys[, values]) -> number of new keys.  Not in the reference (an extension, like iter_batch): add_word for
+// every (key, value) pair in order, one Python call for the lot — a million signatures cost seconds of interpreter
+// time otherwise.
+PyObject* automaton_add_words(AutomatonObject* a, PyObject* args) {
+    PyObject* keys; PyObject* values = nullptr;
+    if (!PyArg_ParseTuple(args, "O|O", &keys, &values)) return nullptr;
+    if (values == Py_None) values = nullptr;
+    PyObject* kf = PySequence_Fast(keys, "add_words() takes a sequence of keys");
+    if (!kf) return nullptr;
+    PyObject* vf = values ? PySequence_Fast(values, "add_words(): values must be a sequence") : nullptr;
+    if (values && !vf) { Py_DECREF(kf); return nullptr; }
+    const Py_ssize_t n = PySequence_Fast_GET_SIZE(kf);
+    if (vf && PySequence_Fast_GET_SIZE(vf) != n) {
+        Py_DECREF(kf); Py_DECREF(vf);
+        PyErr_SetString(PyExc_ValueError, "add_words(): as many values as keys");
+        return nullptr;
+    }
+    Py_ssize_t fresh = 0;
+    for (Py_ssize_t i = 0; i < n; i++) {
+        PyObject* pair = vf ? PyTuple_Pack(2, PySequence_Fast_GET_ITEM(kf, i), PySequence_Fast_GET_ITEM(vf, i))
+                            : PyTuple_Pack(1, PySequence_Fast_GET_ITEM(kf, i));
+        PyObject* r = pair ? automaton_add_word(a, pair) : nullptr;
+        Py_XDECREF(pair);
+        if (!r) { Py_DECREF(kf); Py_XDECREF(vf); return nullptr; }
+        fresh += r == Py_True;
+        Py_DECREF(r);
+    }
+    Py_DECREF(kf); Py_XDECREF(vf);
+    return PyLong_FromSsize_t(fresh);
 }
 
 bool lookup(AutomatonObject* a, PyObject* keyobj, int* found, int64_t* value) {
@@ -524,7 +595,7 @@ PyObject* automaton_clear(AutomatonObject* a, PyObject*) {
     acx_trie_clear(a->trie);
     if (a->values) { if (PyList_SetSlice(a->values, 0, PyList_GET_SIZE(a->values), nullptr) < 0) return nullptr; }
     if (a->free_slots) a->free_slots->clear();
-    if (a->image) { acx_image_free(a->image); a->image = nullptr; }
+    image_retire(a);
     Py_RETURN_NONE;
 }
 
@@ -591,7 +662,8 @@ bool scan_text(AutomatonObject* a, int mode, const Text& t, Py_ssize_t start, Py
     const int64_t* moff; const acx_match_t* m; const int32_t* fin;
     int32_t init = state_io ? *state_io : 0;
     // (the root needs no init_state array: such a scan may take the position-parallel kernels)
-    if (!run_scan(a, mode, scan_src, off, 1, (state_io && init != 0) ? &init : nullptr, nullptr, &moff, &m, &fin)) return false;
+    ScanLease lease;
+    if (!run_scan(a, mode, scan_src, off, 1, (state_io && init != 0) ? &init : nullptr, nullptr, &moff, &m, &fin, &lease)) return false;
     out->assign(m, m + moff[1]);
     for (auto& r : *out) {
         int32_t byte_off = ignore_ws ? remap[(size_t)r.end_index] : r.end_index;
@@ -599,6 +671,7 @@ bool scan_text(AutomatonObject* a, int mode, const Text& t, Py_ssize_t start, Py
         r.end_index = (int32_t)(start + letter + index_shift);
     }
     if (state_io && fin) *state_io = fin[0];
+    lease.done();
     return true;
 }
 
@@ -777,7 +850,8 @@ PyObject* automaton_iter_batch(AutomatonObject* a, PyObject* args, PyObject* kw)
     for (Py_ssize_t i = 0; i < n; i++) memcpy(data.data() + off[(size_t)i], texts[(size_t)i].data, (size_t)texts[(size_t)i].nbytes);
     Py_DECREF(fast);
     const int64_t* moff; const acx_match_t* m0; const int32_t* fin;
-    if (!run_scan(a, is_long ? ACX_SCAN_LONG : ACX_SCAN_ALL, data.data(), off.data(), n, nullptr, nullptr, &moff, &m0, &fin))
+    ScanLease lease;                                              // (its destructor hands the buffers back on every return path)
+    if (!run_scan(a, is_long ? ACX_SCAN_LONG : ACX_SCAN_ALL, data.data(), off.data(), n, nullptr, nullptr, &moff, &m0, &fin, &lease))
         return nullptr;
     std::vector<acx_match_t> conv;                                // unicode build: byte indices -> letters
     const acx_match_t* m = m0;
@@ -1058,6 +1132,7 @@ PyObject* automaton_tp_iter(PyObject* a) { return automaton_items_create((Automa
 
 PyMethodDef automaton_methods[] = {
     {"add_word", (PyCFunction)automaton_add_word, METH_VARARGS, "add_word(key, [value]) -> bool"},
+    {"add_words", (PyCFunction)automaton_add_words, METH_VARARGS, "add_words(keys, [values]) -> number of new keys (extension: add_word for every pair)"},
     {"exists", (PyCFunction)automaton_exists, METH_VARARGS, "exists(key) -> bool"},
     {"get", (PyCFunction)automaton_get, METH_VARARGS, "get(key[, default])"},
     {"longest_prefix", (PyCFunction)automaton_longest_prefix, METH_VARARGS, "longest_prefix(key) -> int"},

@@ -207,3 +207,57 @@ def test_store_any_value_slots_are_reused(ahocorasick):
         for i in range(20):
             assert M.pop(b"k%d" % i) == (round_, i)
     assert len(M._values) <= 20
+
+
+def test_dropin_add_words(ahocorasick):
+    m = ahocorasick
+    A, B = m.Automaton(m.STORE_INTS), m.Automaton(m.STORE_INTS)
+    keys = [b"he", b"her", b"hers", b"she", b"he", b""]
+    n_new = sum(bool(A.add_word(k, i)) for i, k in enumerate(keys))
+    assert B.add_words(keys, list(range(len(keys)))) == n_new == 4
+    assert sorted(A.items()) == sorted(B.items())
+    D = m.Automaton()
+    assert D.add_words([b"a", b"b"], [("x", 1), None]) == 2 and D.get(b"a") == ("x", 1)
+    with pytest.raises(ValueError):
+        B.add_words([b"q"], [1, 2])
+
+
+@pytest.mark.gpu
+def test_dropin_scans_release_the_gil_and_threads_share_an_automaton(ahocorasick):
+    """scans run without the GIL: several threads scanning ONE automaton at once — each with a result
+    object of its own, all on the same immutable device image — get the reference's answers, and a thread that
+    changes the automaton meanwhile (new image) makes the old iterators stale, not wrong"""
+    import threading
+    m = ahocorasick
+    A = m.Automaton(m.STORE_INTS)
+    for i, w in enumerate([b"he", b"her", b"hers", b"she"]):
+        A.add_word(w, i)
+    A.make_automaton()
+    hay = b"_sherhershe_" * 2000
+    want = list(A.iter(hay))
+    assert len(want) == 8 * 2000
+    errs, counts = [], []
+
+    def worker():
+        try:
+            for _ in range(30):
+                got = list(A.iter(hay))
+                assert got == want
+                B_ = A.iter_batch([hay[:1200], hay[:24]])
+                assert len(B_[1]) == 16
+            counts.append(1)
+        except Exception as ex:                        # noqa: BLE001
+            errs.append(repr(ex))
+
+    ts = [threading.Thread(target=worker) for _ in range(6)]
+    [t.start() for t in ts]
+    [t.join() for t in ts]
+    assert not errs and len(counts) == 6, errs
+    it = A.iter(hay)
+    first = next(it)
+    A.add_word(b"rhe", 9)                             # the automaton changes under a live iterator
+    with pytest.raises(ValueError):
+        next(it)
+    assert first == want[0]
+    A.make_automaton()
+    assert len(list(A.iter(hay))) > len(want)

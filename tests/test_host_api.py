@@ -174,3 +174,23 @@ def test_save_image_round_trip(tmp_path):
     B.make_automaton()
     with pytest.raises(ValueError):
         B.save_image(str(tmp_path / "no.acx"))
+
+
+def test_add_words_equals_add_word_in_a_loop():
+    """acx_trie_add_words / Automaton.add_words (an extension: one call for many keys) == add_word per pair, in order"""
+    import random
+    import pyahocorasick_amd as acx
+    rng = random.Random(4)
+    keys = [bytes(rng.choice(b"abc") for _ in range(rng.randint(0, 7))) for _ in range(400)]     # duplicates and empty keys included
+    for store, vals in ((acx.STORE_INTS, [rng.randint(-2**40, 2**40) for _ in keys]), (acx.STORE_INTS, None), (acx.STORE_LENGTH, None)):
+        A, B = acx.Automaton(store), acx.Automaton(store)
+        n_new = 0
+        for i, k in enumerate(keys):
+            n_new += bool(A.add_word(k, vals[i]) if vals is not None else A.add_word(k))
+        assert B.add_words(keys, vals) == n_new
+        assert len(A) == len(B)
+        assert sorted(A.items()) == sorted(B.items())
+        A.make_automaton(); B.make_automaton()
+        assert A.flat_image_bytes() == B.flat_image_bytes()
+    C_ = acx.Automaton()                                               # STORE_ANY: objects
+    assert C_.add_words([b"x", b"xy", b"x"], ["a", "b", "c"]) == 2 and C_.get(b"x") == "c"

@@ -64,8 +64,7 @@ def main():
     t_gen = time.time() - t0
     t1 = time.time()
     A = acx.Automaton(acx.STORE_INTS)
-    for i, k in enumerate(keys):
-        A.add_word(k, i)
+    A.add_words(keys, range(len(keys)))
     t_add = time.time() - t1; t1 = time.time()
     A.make_automaton()
     t_make = time.time() - t1; t1 = time.time()

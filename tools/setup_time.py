@@ -20,9 +20,13 @@ else:
 print("generate keys   %.2f s" % (time.perf_counter() - t), flush=True)
 A = acx.Automaton(acx.STORE_INTS)
 t = time.perf_counter()
-for i, k in enumerate(keys):
-    A.add_word(k, i)
-print("add_word        %.2f s" % (time.perf_counter() - t), flush=True)
+if "--loop" in sys.argv:                  # the reference's way: one Python call per key
+    for i, k in enumerate(keys):
+        A.add_word(k, i)
+    print("add_word loop   %.2f s" % (time.perf_counter() - t), flush=True)
+else:
+    A.add_words(keys, range(len(keys)))
+    print("add_words       %.2f s" % (time.perf_counter() - t), flush=True)
 t = time.perf_counter()
 A.make_automaton()
 print("make_automaton  %.2f s" % (time.perf_counter() - t), flush=True)
