@@ -745,6 +745,7 @@ static int scan_ppm(acx_image_t* img, const acx_scan_params* p, acx_result* r, h
         ga.hay_local = r->hay_local.p; ga.match_off = r->match_off.p; ga.n_hay = p->n_hay; ga.stride = p->stride;
         ga.off = chunked ? p->dev_off : nullptr;
         ga.tile_pos = tpos; ga.tpw = (stream_tiles + n_waves - 1) / n_waves;
+        ga.stride_magic = pa.stride_magic; ga.index_base = chunked ? nullptr : p->dev_index_base;
     }
 
     acx_ppm_compact_args& ca = r->pend_ca;            // (the general kernel: per-tile counts, scan, compact)

@@ -154,8 +154,10 @@ struct acx_ppm_gather_args {       // k_ppm_stream results -> final place
     const uint32_t* wave_desc; const int64_t* wave_off; int64_t n_waves;
     const uint2* scratch; uint2* matches; int64_t capacity;
     const int32_t* hay_local; int64_t* match_off; int64_t n_hay; int64_t stride;
-    const int64_t* off;            // offsets batch (else nullptr: fixed stride)
+    const int64_t* off;            // offsets batch (else nullptr: fixed stride — records carry global positions)
     int64_t tile_pos, tpw;         // positions per tile, tiles per wave
+    uint64_t stride_magic;         // fixed stride: ceil(2^64 / stride) (0 for stride 1)
+    const int32_t* index_base;     // fixed stride: added to every index of haystack h (nullable)
 };
 #define ACX_PPM_DESC_WORDS 40
 hipError_t acx_launch_ppm_first_h(const int64_t* off, int64_t n_hay, int64_t n_tiles, int64_t tile_pos, int64_t* first_h, hipStream_t s);

@@ -530,6 +530,11 @@ __global__ void __launch_bounds__(ACX_PPM_BLOCK) k_ppm_stream(const acx_ppm_args
     constexpr uint32_t OW = OWN / 32;                                  // ... in words
     constexpr uint32_t LPS = 256 / PPL;                                // lanes of a sub-step (256 positions)
     static_assert(OWN >= 32 && DPL >= 4, "tiles of 1024 or 2048 positions");
+    // Fixed-stride batches: a record carries the GLOBAL position of its match; k_ppm_gather, which moves every record
+    // anyway and is bound by memory, turns it into the index inside its haystack and finds the record offset of every
+    // haystack from the positions.  Offset batches: haystack starts travel through the queue as entries of their own
+    // (the exclusive record count in front of one IS the record offset of its haystack), records carry the final index.
+    constexpr bool STARTQ = OFFS;
     const int lane = threadIdx.x & 63;
     const int wid = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));   // (wave-uniform, and the compiler is told so)
     Ppm<SB, POW2, false> P(a);
@@ -853,16 +858,9 @@ __global__ void __launch_bounds__(ACX_PPM_BLOCK) k_ppm_stream(const acx_ppm_args
             }
         }
         PH(0);                                                           // stage + filter
-        // haystack starts among the lane's positions
+        // haystack starts among the lane's positions (offset batches)
         uint32_t sw = 0;
-        if (OFFS) sw = PPL == 32 ? sbits[lane] : ((const uint16_t*)sbits)[lane];
-        else {
-            uint32_t r;
-            (void)divmod(r_tile + PPL * (uint32_t)lane, r);
-            uint32_t o = r ? stride - r : 0u;                           // (stride >= 8: PPL / 8 starts at most)
-#pragma unroll
-            for (int k = 0; k < (int)PPL / 8; k++) { sw |= o < PPL ? 1u << (o & 31u) : 0u; o += stride; }
-        }
+        if (STARTQ) sw = PPL == 32 ? sbits[lane] : ((const uint16_t*)sbits)[lane];
         {
             const uint32_t lp = PPL * (uint32_t)lane;
             const uint32_t nv = npos > lp ? (npos - lp < PPL ? npos - lp : PPL) : 0u;
@@ -916,7 +914,8 @@ __global__ void __launch_bounds__(ACX_PPM_BLOCK) k_ppm_stream(const acx_ppm_args
                 where(p, r, rk);
                 if (OFFS && hbase == 0xFFFFFFFFu && rk == 0u) cand = false;          // (a byte in front of off[0]: belongs to no haystack)
                 const uint32_t L = r + 1 < LL[e] ? r + 1 : LL[e];
-                pp[e] = ent | (rk << 17); rr[e] = act ? r : 1u;          // (the rank: at most TPOS / 8 starts per tile)
+                pp[e] = STARTQ ? ent | (rk << 17) : ent;                 // (the rank: at most TPOS / 8 starts per tile)
+                rr[e] = STARTQ ? (act ? r : 1u) : e0 + p;                // offset batches: the index in the haystack; else the global position
                 LL[e] = cand ? L : 0u;
                 XX[e] = P.window(HP + p);
                 // the cell of the C newest symbols as they stand: what it says about depths <= L does not depend on
@@ -944,7 +943,7 @@ __global__ void __launch_bounds__(ACX_PPM_BLOCK) k_ppm_stream(const acx_ppm_args
                 } else { has_id = hw >> 31; g = has_id & (L > Cn ? 1u : 0u); }
                 gomask |= g << e; n_go += g;
                 va[e] = (int32_t)hx; vb[e] = 0;                          // (the shallowest key's value, unless the word holds the id)
-                tvm[e] = ((cn[e] >= 2u ? 1u : 0u) | ((cn[e] == 1u ? 1u : 0u) & has_id)) ? m : 0u;
+                tvm[e] = cn[e] + has_id >= 2u ? m : 0u;                  // (a second key, or one key and the word holds the id)
                 tvany |= tvm[e];
             )
             // values that the cell does not hold: its second word is the id, or a second key ends here
@@ -1013,18 +1012,29 @@ __global__ void __launch_bounds__(ACX_PPM_BLOCK) k_ppm_stream(const acx_ppm_args
                 wave_sync();
                 {
                     uint32_t rnk = d_base - d0;
+                    uint32_t found = 0;                                  // slots whose walk found keys: their values are fetched below (rare)
                     PPM_SLOTS(e,
                         const uint32_t g = (gomask >> e) & 1u;
                         const bool mine = g != 0u && rnk < 64u;
-                        const uint32_t slot = mine ? rnk : 64u;
-                        const u32x2 dv = *(const u32x2*)(dq + 2 * slot);
-                        const uint32_t c2 = mine ? (uint32_t)dcnt[slot] : 0u;
-                        const bool c0 = mine && cn[e] == 0u, c1 = mine && cn[e] == 1u;
-                        va[e] = c0 ? (int32_t)dv.x : va[e];
-                        vb[e] = c0 ? (int32_t)dv.y : (c1 ? (int32_t)dv.x : vb[e]);
-                        cn[e] += c2;
+                        const uint32_t c2 = mine ? (uint32_t)dcnt[mine ? rnk : 64u] : 0u;
+                        found |= (c2 ? 1u : 0u) << e;
+                        cn[e] += c2 << 16;                               // (kept apart until the values are in place)
                         rnk += g;
                     )
+                    if (__any(found != 0u)) {
+                        uint32_t rnk2 = d_base - d0;
+                        PPM_SLOTS(e,
+                            const uint32_t g = (gomask >> e) & 1u;
+                            if ((found >> e) & 1u) {
+                                const u32x2 dv = *(const u32x2*)(dq + 2 * rnk2);
+                                const uint32_t ct = cn[e] & 0xFFFFu;
+                                if (ct == 0u) { va[e] = (int32_t)dv.x; vb[e] = (int32_t)dv.y; } else if (ct == 1u) vb[e] = (int32_t)dv.x;
+                            }
+                            rnk2 += g;
+                        )
+                    }
+#pragma unroll
+                    for (int e = 0; e < NE; e++) cn[e] = (cn[e] & 0xFFFFu) + (cn[e] >> 16);
                 }
                 wave_sync();
             }
@@ -1068,7 +1078,7 @@ __global__ void __launch_bounds__(ACX_PPM_BLOCK) k_ppm_stream(const acx_ppm_args
 #endif
             // 5. the record offsets of the haystacks that start here (and the caller's index bases).  Stores are not
             // predicated: a lane with nothing to say writes to a spare element (divergent branches cost more than that)
-            {
+            if (STARTQ) {
                 uint32_t startany = 0;
 #pragma unroll
                 for (int e = 0; e < NE; e++) startany |= rr[e] == 0u ? 1u : 0u;       // (no entry: rr = 1)
@@ -1087,12 +1097,18 @@ __global__ void __launch_bounds__(ACX_PPM_BLOCK) k_ppm_stream(const acx_ppm_args
             uint8_t* const out8 = (uint8_t*)(a.scratch + g_base + g_used);
             uint2* const out = (uint2*)out8;
             if (wr) {
+                uint32_t two = 0;                                        // slots with a second record (rare with long keys)
                 PPM_SLOTS(e,
-                    const uint32_t c = cn[e]; const uint32_t oe = ex[e] + c - 1u; const uint32_t idx = rr[e];
-                    *(uint2*)(out8 + ((c ? oe : rt) << 3)) = make_uint2(idx, (uint32_t)va[e]);
-                    *(uint2*)(out8 + ((c > 1u ? oe - 1u : rt) << 3)) = make_uint2(idx, (uint32_t)vb[e]);
+                    const uint32_t c = cn[e]; const uint32_t oe = ex[e] + c - 1u;
+                    *(uint2*)(out8 + ((c ? oe : rt) << 3)) = make_uint2(rr[e], (uint32_t)va[e]);
+                    two |= (c > 1u ? 1u : 0u) << e;
                     slow |= (c > 2u ? 1u : 0u) << e;
                 )
+                if (__any(two != 0u)) {
+                    PPM_SLOTS(e,
+                        if ((two >> e) & 1u) *(uint2*)(out8 + ((ex[e] + cn[e] - 2u) << 3)) = make_uint2(rr[e], (uint32_t)vb[e]);
+                    )
+                }
                 while (__any(slow != 0u)) {                              // rare: one slot per lane and pass, from the 32-byte cell
                     if (slow) {
                         const uint32_t se = (uint32_t)__ffs(slow) - 1u;
@@ -1238,12 +1254,90 @@ __global__ void __launch_bounds__(256) k_ppm_gather(const acx_ppm_gather_args c)
         }
     }
     const int64_t n_threads = (int64_t)gridDim.x * 256;
-    const int tile_shift = 63 - __clzll((unsigned long long)c.tile_pos);       // (tiles are 512, 1024 or 2048 positions; the batch is below 4 GiB)
+    const int tile_shift = 63 - __clzll((unsigned long long)c.tile_pos);       // (tiles are 1024 or 2048 positions; the batch is below 4 GiB)
     const uint32_t tpw = (uint32_t)c.tpw;
     for (int64_t h = (int64_t)blockIdx.x * 256 + threadIdx.x; h <= c.n_hay; h += n_threads) {
         if (h == c.n_hay) c.match_off[h] = total;
-        else c.match_off[h] = c.wave_off[(uint32_t)((c.off ? c.off[h] : h * c.stride) >> tile_shift) / tpw] + c.hay_local[h];
+        else c.match_off[h] = c.wave_off[(uint32_t)(c.off[h] >> tile_shift) / tpw] + c.hay_local[h];
     }
+}
+
+// The same for fixed-stride batches, whose records carry the GLOBAL position of their match: the index inside the
+// haystack is position - h * stride (+ the caller's index base), and the record offset of haystack h is the number of
+// records in front of position h * stride.  A wave of k_ppm_stream covers the positions [A, B) = its run of tiles, so its
+// block here knows every haystack that starts in there: those in front of its first record, those between two records
+// of different haystacks (the thread of the later record fills the gap), those behind its last record.
+__global__ void __launch_bounds__(256) k_ppm_gather_pos(const acx_ppm_gather_args c) {
+    const int64_t total = c.wave_off[c.n_waves];
+    const bool fits = total <= c.capacity;
+    const uint32_t stride = (uint32_t)c.stride;
+    const uint64_t H = (uint64_t)c.n_hay * stride;
+    const int lane = threadIdx.x & 63;
+    // positions of one wave lie within tpw * tile_pos of its first: the haystack of a position is a 32-bit multiply-high
+    // away (exact while (offset in its haystack + distance) * stride < 2^32), else the 64-bit magic
+    const uint64_t span = (uint64_t)c.tpw * (uint64_t)c.tile_pos;
+    const bool small = (span + stride) * (uint64_t)stride < ((uint64_t)1 << 32);
+    const uint32_t m32 = small ? (uint32_t)((((uint64_t)1 << 32) + stride - 1) / stride) : 0u;
+    for (int64_t w = blockIdx.x; w < c.n_waves; w += gridDim.x) {
+        const uint32_t* d = c.wave_desc + (size_t)w * PPM_DESC_WORDS;
+        const uint32_t ng = d[1], count = d[0];
+        uint64_t A = (uint64_t)w * span, B = A + span;
+        if (A > H) A = H;
+        if (B > H) B = H;
+        const int64_t hA = (int64_t)((A + stride - 1) / stride), hB = (int64_t)((B + stride - 1) / stride);   // haystacks that start in [A, B): hA .. hB - 1
+        const int64_t h0 = (int64_t)(A / stride);                      // haystack of position A
+        const uint32_t rA = (uint32_t)(A - (uint64_t)h0 * stride), A32 = (uint32_t)A;
+        // haystack (relative to h0) and index of a position of this wave
+        auto locate = [&](uint32_t gpos, uint32_t& idx) -> uint32_t {
+            if (small) { const uint32_t y = rA + (gpos - A32), q = __umulhi(y, m32); idx = y - q * stride; return q; }
+            uint32_t rem; const uint32_t hh = div_magic(gpos, c.stride_magic, stride, rem); idx = rem; return (uint32_t)((int64_t)hh - h0);
+        };
+        const int64_t base = c.wave_off[w];
+        u32x2* dst = (u32x2*)(c.matches + base);
+        uint32_t li = 0;                                               // records of this wave in front of the current grant
+        uint32_t q_last = (uint32_t)(hA - 1 - h0);                     // haystack (relative) of the last record so far; none: the one in front of the first start
+        for (uint32_t g = 0; g < ng && fits; g++) {
+            const u32x2* src = (const u32x2*)(c.scratch + d[2 + g]);
+            const uint32_t n = d[18 + g];
+            // two records per access where the destination allows 16-byte stores (the source only needs dword alignment)
+            const uint32_t head = (n && (((uintptr_t)(dst + li) >> 3) & 1u)) ? 1u : 0u;
+            const uint32_t pairs = (n - head) >> 1, tailn = (n - head) & 1u;
+            const u32x4a* src2 = (const u32x4a*)(src + head);
+            u32x4* dst2 = (u32x4*)(dst + li + head);
+            auto emit = [&](uint32_t k, u32x2 rec, uint32_t q_prev) -> u32x2 {      // record k of the grant; q_prev: haystack of the record before it
+                uint32_t idx;
+                const uint32_t q = locate(rec.x, idx);
+                for (uint32_t qq = q_prev + 1; (int32_t)(qq - q) <= 0; qq++) c.match_off[h0 + (int64_t)(int32_t)qq] = base + li + k;   // haystacks that start between the two records
+                u32x2 o; o.x = idx + (c.index_base ? (uint32_t)c.index_base[h0 + (int64_t)(int32_t)q] : 0u); o.y = rec.y;
+                return o;
+            };
+            auto q_of = [&](uint32_t k) -> uint32_t { uint32_t t; return locate(src[k].x, t); };
+            if (head && threadIdx.x == 0) __builtin_nontemporal_store(emit(0, __builtin_nontemporal_load(src), q_last), dst + li);
+            for (uint32_t k0 = 0; k0 < pairs; k0 += 256) {
+                const uint32_t k = k0 + threadIdx.x;
+                if (k < pairs) {
+                    const u32x4a v = src2[k];
+                    const uint32_t r = head + 2 * k;                   // index of the pair's first record in the grant
+                    u32x2 r0; r0.x = v.x; r0.y = v.y;
+                    u32x2 r1; r1.x = v.z; r1.y = v.w;
+                    const uint32_t qp = r ? q_of(r - 1) : q_last;      // (the neighbour's second record: an L2 hit)
+                    uint32_t t0;
+                    const uint32_t q0 = locate(r0.x, t0);
+                    const u32x2 o0 = emit(r, r0, qp), o1 = emit(r + 1, r1, q0);
+                    u32x4 o; o.x = o0.x; o.y = o0.y; o.z = o1.x; o.w = o1.y;
+                    __builtin_nontemporal_store(o, dst2 + k);
+                }
+            }
+            if (tailn && threadIdx.x == 255) __builtin_nontemporal_store(emit(n - 1, __builtin_nontemporal_load(src + n - 1), n > 1 ? q_of(n - 2) : q_last), dst + li + n - 1);
+            if (n) q_last = q_of(n - 1);
+            li += n;
+        }
+        (void)lane;
+        // haystacks behind the last record (all of them, when the wave has none or nothing fits)
+        const int64_t h_last = fits ? h0 + (int64_t)(int32_t)q_last : hA - 1;
+        for (int64_t hh = h_last + 1 + threadIdx.x; hh < hB; hh += 256) c.match_off[hh] = base + (fits ? count : 0u);
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) c.match_off[c.n_hay] = total;
 }
 
 // records of every tile -> their final place; STRIDE scans: match_off[] from the tile offsets
@@ -1360,7 +1454,8 @@ hipError_t acx_launch_ppm_gather(const uint32_t* wave_desc, int64_t n_waves, int
     if (blocks < hb) blocks = hb;
     const int64_t cap = (int64_t)num_cus() * 32;
     if (blocks > cap) blocks = cap;
-    hipLaunchKernelGGL(k_ppm_gather, dim3((unsigned)blocks), dim3(256), 0, s, c);
+    if (c.off) hipLaunchKernelGGL(k_ppm_gather, dim3((unsigned)blocks), dim3(256), 0, s, c);
+    else hipLaunchKernelGGL(k_ppm_gather_pos, dim3((unsigned)(n_waves < cap ? n_waves : cap)), dim3(256), 0, s, c);
     return hipGetLastError();
 }
 
