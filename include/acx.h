@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define ACX_ABI_VERSION 2
+#define ACX_ABI_VERSION 3          /* 3: acx_scan_params.dev_skip, acx_scan_host_ctx, acx_trie_add_words */
 
 typedef enum acx_status {
     ACX_OK            =  0,
@@ -243,6 +243,14 @@ typedef struct acx_scan_params {
                                   again on the general kernels when the result completes: slower, never wrong.
                                   acx_scan_host derives it from the host offsets. */
     int32_t  reserved0;
+    const int32_t* dev_skip;   /* ACX_SCAN_ALL, optional int32[n_hay]: the first dev_skip[h] bytes of haystack h are CONTEXT —
+                                  the tail of what a stream delivered before (at most longest_word - 1 bytes matter).
+                                  Matches that end inside it are not reported, and end_index counts from the first
+                                  byte behind it (then dev_index_base is added).  This is how a stream continues on the
+                                  position-parallel kernels: what AutomatonSearchIter.set(chunk, reset=False) does with
+                                  a carried state (src/AutomatonSearchIter.c:303-368) follows from the previous
+                                  longest_word - 1 bytes alone, so the caller keeps those instead of a state id and
+                                  no dense table is needed.  Not for ACX_SCAN_LONG (its restarts need the state). */
 } acx_scan_params;
 /* Return as soon as the kernels are queued on `stream`.  The result completes (wait for THIS
  * scan's completion event — later scans queued on the same stream keep running —, total read,
@@ -293,6 +301,13 @@ void acx_result_free(acx_result_t* r);
 int  acx_scan_host(acx_image_t* img, int mode, const uint8_t* hay, const int64_t* off, int64_t n_hay,
                    const int32_t* init_state, const int32_t* index_base,
                    acx_result_t** result);
+/* ACX_SCAN_ALL over streams: haystack h is scanned with the context bytes ctx[ctx_off[h] .. ctx_off[h+1]) in front of it
+ * (dev_skip above); the library stages context and chunk side by side, the caller copies nothing.  ctx == NULL: as
+ * acx_scan_host without states.  No final states are computed (the next chunk's context is the caller's: the last
+ * longest_word - 1 bytes of context + chunk). */
+int  acx_scan_host_ctx(acx_image_t* img, const uint8_t* hay, const int64_t* off, int64_t n_hay,
+                       const uint8_t* ctx, const int64_t* ctx_off, const int32_t* index_base,
+                       acx_result_t** result);
 
 /* device helpers used by bindings that have no HIP runtime of their own */
 int  acx_device_count(int* n);

@@ -41,6 +41,7 @@ class ScanParams(C.Structure):
         ("want_final_state", C.c_int32), ("timing", C.c_int32),
         ("variant", C.c_int32), ("flags", C.c_int32),
         ("min_hay_len", C.c_int32), ("reserved0", C.c_int32),
+        ("dev_skip", C.c_void_p),
     ]
 
 
@@ -102,6 +103,7 @@ SIGNATURES = {
     "acx_result_timing": (C.c_int, [_P] + [C.POINTER(C.c_float)] * 4),
     "acx_result_free": (None, [_P]),
     "acx_scan_host": (C.c_int, [_P, C.c_int, _P, _P, C.c_int64, _P, _P, _PP]),
+    "acx_scan_host_ctx": (C.c_int, [_P, _P, _P, C.c_int64, _P, _P, _P, _PP]),
     "acx_device_count": (C.c_int, [C.POINTER(C.c_int)]),
     "acx_device_set": (C.c_int, [C.c_int]),
     "acx_dev_malloc": (C.c_int, [_PP, C.c_size_t]),
@@ -145,8 +147,8 @@ def lib():
                               "`python -m pyahocorasick_amd.build --force`)" % (LIB_PATH, name))
         fn.restype = res
         fn.argtypes = args
-    if l.acx_abi_version() != 2:
-        raise ImportError("pyahocorasick_amd: libacx ABI version %d, binding expects 2" % l.acx_abi_version())
+    if l.acx_abi_version() != 3:
+        raise ImportError("pyahocorasick_amd: libacx ABI version %d, binding expects 3" % l.acx_abi_version())
     _lib = l
     return l
 

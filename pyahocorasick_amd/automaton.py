@@ -262,6 +262,9 @@ class Automaton:
     def _version(self):
         return lib().acx_trie_version(self._trie)
 
+    def _longest_word(self):
+        return int(lib().acx_trie_longest_word(self._trie))
+
     def __len__(self):
         return lib().acx_trie_num_keys(self._trie)
 
@@ -429,10 +432,13 @@ class Automaton:
             f.write(self.flat_image_bytes())
 
     # ---- batch scan (NEW: the reference scans one haystack per iterator) ---------------
-    def scan_batch(self, data, offsets, mode=ACX_SCAN_ALL, init_state=None, index_base=None):
+    def scan_batch(self, data, offsets, mode=ACX_SCAN_ALL, init_state=None, index_base=None, context=None):
         """Scan haystacks data[offsets[k]:offsets[k+1]] on the GPU; returns a BatchResult.
 
         data: bytes-like; offsets: int64[n+1] with offsets[0] == 0.
+        context (ACX_SCAN_ALL): (bytes-like, int64[n+1]) — the bytes a stream delivered in front of every haystack
+        (the last longest_word - 1 matter): matches may begin in there, none that ends in there is reported
+        (acx_scan_host_ctx); this is how iter().set() continues without a state.
         """
         if self.kind != AHOCORASICK:
             raise AttributeError("Not an Aho-Corasick automaton yet: call add_word to add some keys and call "
@@ -449,15 +455,29 @@ class Automaton:
         # ctypes drops the GIL inside every libacx call, and the image and the result buffers belong to this
         # Automaton: one scan (image refresh, kernels, fetch) at a time per object.  The reference holds the
         # GIL for the whole of every call, so sharing an automaton between threads is safe there too.
+        ctx = None
+        if context is not None:
+            if mode != ACX_SCAN_ALL or init is not None:
+                raise ValueError("context is for ACX_SCAN_ALL without carried states")
+            cbuf = np.frombuffer(context[0], dtype=np.uint8) if not isinstance(context[0], np.ndarray) else np.ascontiguousarray(context[0], dtype=np.uint8)
+            coff = np.ascontiguousarray(context[1], dtype=np.int64)
+            if coff.shape != (n + 1,) or coff[0] != 0 or coff[-1] > cbuf.size:
+                raise ValueError("bad context offsets")
+            ctx = (cbuf, coff)
         with self._lock:
-            return self._scan_locked(buf, off, n, mode, init, base)
+            return self._scan_locked(buf, off, n, mode, init, base, ctx)
 
-    def _scan_locked(self, buf, off, n, mode, init, base):
+    def _scan_locked(self, buf, off, n, mode, init, base, ctx=None):
         img = self._ensure_image()
-        check(lib().acx_scan_host(img.handle, mode, buf.ctypes.data if buf.size else None, off.ctypes.data, n,
-                                  init.ctypes.data if init is not None else None,
-                                  base.ctypes.data if base is not None else None,
-                                  C.byref(self._result)))
+        if ctx is not None:
+            check(lib().acx_scan_host_ctx(img.handle, buf.ctypes.data if buf.size else None, off.ctypes.data, n,
+                                          ctx[0].ctypes.data if ctx[0].size else C.c_void_p(1), ctx[1].ctypes.data,
+                                          base.ctypes.data if base is not None else None, C.byref(self._result)))
+        else:
+            check(lib().acx_scan_host(img.handle, mode, buf.ctypes.data if buf.size else None, off.ctypes.data, n,
+                                      init.ctypes.data if init is not None else None,
+                                      base.ctypes.data if base is not None else None,
+                                      C.byref(self._result)))
         p_off, p_m, p_f = C.c_void_p(), C.c_void_p(), C.c_void_p()
         check(lib().acx_result_fetch_host(self._result, C.byref(p_off), C.byref(p_m), C.byref(p_f)))
         total = lib().acx_result_num_matches(self._result)
@@ -623,21 +643,35 @@ class AutomatonSearchIter:
         self._version = automaton._version
         self._ws = ignore_white_space
         self._state = 0
+        self._ctx = b""                  # iter: what the stream delivered before this chunk (its last longest_word - 1 letters)
         self._shift = 0
         self._load(string, start, end)
 
-    def _scan(self, string, start, end, state, shift):
+    def _letters(self, string, start, end):
+        """the letters of string[start:end] that touch the automaton (ignore_white_space skips the others without
+        touching the state, src/AutomatonSearchIter.c:269-274) and where each came from"""
         chunk = string[start:end]
-        remap = None
-        if self._ws:
-            # the reference skips white-space letters without touching the state
-            # (src/AutomatonSearchIter.c:269-274): scan the compacted bytes, map indices back
-            arr = np.frombuffer(chunk, dtype=np.uint8)
-            remap = np.flatnonzero(~_WS[arr])
-            chunk = arr[remap].tobytes()
-        res = self._a.scan_batch(chunk, [0, len(chunk)], ACX_SCAN_LONG if self._long else ACX_SCAN_ALL,
-                                 init_state=[state] if state else None,      # (the root needs none: such a scan may take the position-parallel kernels)
-                                 index_base=[0 if remap is not None else start + shift])
+        if not self._ws:
+            return chunk, None
+        arr = np.frombuffer(chunk, dtype=np.uint8)
+        remap = np.flatnonzero(~_WS[arr])
+        return arr[remap].tobytes(), remap
+
+    def _tail(self, ctx, walked):
+        keep = max(0, self._a._longest_word() - 1)
+        t = ctx + walked
+        return t[len(t) - keep:] if keep and len(t) > keep else (t if keep else b"")
+
+    def _scan(self, string, start, end, state, shift):
+        chunk, remap = self._letters(string, start, end)
+        if self._long:
+            res = self._a.scan_batch(chunk, [0, len(chunk)], ACX_SCAN_LONG, init_state=[state] if state else None,
+                                     index_base=[0 if remap is not None else start + shift])
+        else:
+            # iter continues a stream from the bytes before it, not from a state: every match that ends in this chunk
+            # depends on the previous longest_word - 1 letters at most (the position-parallel kernels take it)
+            res = self._a.scan_batch(chunk, [0, len(chunk)], ACX_SCAN_ALL, context=(self._ctx, [0, len(self._ctx)]),
+                                     index_base=[0 if remap is not None else start + shift])
         if remap is not None and res.num_matches():
             res.end_index = (remap[res.end_index] + (start + shift)).astype(np.int32)
         return res.tolists()[0], (int(res.final_state[0]) if res.final_state is not None else 0)
@@ -674,18 +708,19 @@ class AutomatonSearchIter:
             raise TypeError("bytes expected")
         if reset:
             self._state = 0
+            self._ctx = b""
             self._shift = 0
         else:
-            if not self._exhausted and self._version == self._a._version:
-                # set() before StopIteration (the chunk was scanned eagerly, the reference has only walked up to the
-                # last match it returned): iter_long is at the root after every match (src/AutomatonSearchIterLong.c:
-                # 101-110); iter holds the state after the last yielded position, found by scanning that prefix of
-                # the old chunk again
+            # What the reference has walked of the old chunk: all of it after StopIteration, else up to the last match it
+            # returned.  iter: those letters, behind the old context, are the new context.  iter_long: it is at the root
+            # after every match (src/AutomatonSearchIterLong.c:101-110), or where the exhausted walk ended.
+            if self._version == self._a._version:
+                upto = self._end if self._exhausted else max(self._ref_index + 1, self._start)
                 if self._long:
-                    self._state = 0 if self._ref_index >= self._start else self._state0   # (nothing returned yet: untouched)
+                    if not self._exhausted:
+                        self._state = 0 if self._ref_index >= self._start else self._state0   # (nothing returned yet: untouched)
                 else:
-                    upto = max(self._ref_index + 1, self._start)
-                    _, self._state = self._scan(self._src, self._start, upto, self._state0, 0)
+                    self._ctx = self._tail(self._ctx, self._letters(self._src, self._start, upto)[0])
             self._shift += self._ref_index if self._ref_index >= 0 else 0   # :344-352
         self._load(string, 0, len(string))
 

@@ -401,7 +401,11 @@ struct acx_result {
     PinBuf<int32_t> h_final;
     PinBuf<int64_t> h_total;
     // staging used only by acx_scan_host
-    DevBuf<uint8_t> in_hay; DevBuf<int64_t> in_off; DevBuf<int32_t> in_init, in_base;
+    DevBuf<uint8_t> in_hay; DevBuf<int64_t> in_off; DevBuf<int32_t> in_init, in_base, in_skip;
+    PinBuf<uint8_t> h_stage;                    // acx_scan_host_ctx: context and chunk of every haystack side by side
+    // dev_skip on the kernel families that do not know it: the context's records are dropped after the scan
+    const int32_t* skip_after = nullptr; const int32_t* skip_base = nullptr;
+    DevBuf<int32_t> skip_kept; DevBuf<int64_t> skip_off; DevBuf<uint2> matches2;
     int64_t n_hay = 0;
     int64_t total = 0;
     bool has_final = false;
@@ -423,7 +427,8 @@ struct acx_result {
         nck.release(); ck_first.release(); ck_match_off.release(); ck.release();
         scratch.release(); scr_off.release(); ppm_ctl.release(); hay_local.release(); wave_desc.release();
         events.release(); matches.release(); h_off.release(); h_matches.release(); h_final.release(); h_total.release();
-        in_hay.release(); in_off.release(); in_init.release(); in_base.release();
+        in_hay.release(); in_off.release(); in_init.release(); in_base.release(); in_skip.release(); h_stage.release();
+        skip_kept.release(); skip_off.release(); matches2.release();
         for (auto& e : ev) if (e) (void)hipEventDestroy(e);
         if (done) (void)hipEventDestroy(done);
         if (ev_scan) (void)hipEventDestroy(ev_scan);
@@ -433,6 +438,31 @@ struct acx_result {
 
 static int ppm_enqueue(acx_result* r, acx_image* img, const acx_chunk_args* ca, const acx_walk_args* tail, hipStream_t s);
 static int ppm_size_pool(acx_result* r, size_t records);
+
+// dev_skip after a scan on kernels that do not know it (the serial walks, k_ppm_scan): drop the records of every
+// haystack's context (a prefix of its records) and rebase the rest; the result's buffers are swapped for the new ones
+static int skip_compact(acx_result* r) {
+    if (!r->skip_after) return ACX_OK;
+    const int32_t* skip = r->skip_after;
+    r->skip_after = nullptr;
+    const size_t n = (size_t)r->n_hay;
+    hipStream_t s = r->stream;
+    int rc;
+    if ((rc = r->skip_kept.ensure(n + 1))) return rc;
+    if ((rc = r->skip_off.ensure(n + 1))) return rc;
+    if ((rc = r->matches2.ensure((size_t)r->total + 1))) return rc;
+    if ((rc = r->partials.ensure((size_t)acx_scan_num_partials((int64_t)n) + 2))) return rc;
+    HIP_TRY(acx_launch_skip_count(r->match_off.p, r->matches.p, skip, r->skip_base, (int64_t)n, r->skip_kept.p, s));
+    HIP_TRY(acx_launch_scan(r->skip_kept.p, (int64_t)n, r->skip_off.p, r->partials.p, s));
+    HIP_TRY(acx_launch_skip_move(r->match_off.p, r->matches.p, skip, r->skip_kept.p, r->skip_off.p, (int64_t)n, r->matches2.p, s));
+    int64_t total = 0;
+    HIP_TRY(hipMemcpyAsync(&total, r->skip_off.p + n, sizeof total, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    std::swap(r->matches.p, r->matches2.p); std::swap(r->matches.cap, r->matches2.cap);
+    std::swap(r->match_off.p, r->skip_off.p); std::swap(r->match_off.cap, r->skip_off.cap);
+    r->total = total;
+    return ACX_OK;
+}
 
 // position-parallel scan: the record pool ran out (grow it and scan again) or the match buffer
 // is too small (grow it and copy again: the pool is intact)
@@ -480,7 +510,7 @@ static int ppm_complete(acx_result* r) {
             HIP_TRY(hipEventElapsedTime(&r->t_total, r->ev[0], r->ev[3]));
         }
     }
-    return ACX_OK;
+    return skip_compact(r);
 }
 
 // Finish a scan whose kernels are queued: wait, read the total, and if the speculative expand did
@@ -517,7 +547,7 @@ static int result_complete(acx_result* r) {
             r->t_total = r->t_walk + r->t_scan + r->t_expand;
         }
     }
-    return ACX_OK;
+    return skip_compact(r);
 }
 
 extern "C" int acx_result_wait(acx_result_t* r) {
@@ -673,6 +703,7 @@ static int scan_ppm(acx_image_t* img, const acx_scan_params* p, acx_result* r, h
     pa.stride_magic = p->stride > 1 ? ~0ull / (uint64_t)p->stride + 1 : 0;           // ceil(2^64 / stride) (stride is no power of two, or the +1 is still right)
     if (p->stride > 1 && (p->stride & (p->stride - 1)) == 0) pa.stride_magic = ((uint64_t)1 << 63) / (uint64_t)p->stride * 2;
     pa.index_base = chunked ? nullptr : p->dev_index_base;
+    pa.skip = plan == 2 ? p->dev_skip : nullptr;
     pa.ck = chunked ? r->ck.p : nullptr; pa.n_items_dev = chunked ? r->ck_first.p + p->n_hay : nullptr;
     pa.n_items = n_items;
     pa.cls = img->cls; pa.g = img->ppm_g; pa.cells = img->ppm_cells; pa.top_val = img->ppm_top_val;
@@ -745,7 +776,7 @@ static int scan_ppm(acx_image_t* img, const acx_scan_params* p, acx_result* r, h
         ga.hay_local = r->hay_local.p; ga.match_off = r->match_off.p; ga.n_hay = p->n_hay; ga.stride = p->stride;
         ga.off = chunked ? p->dev_off : nullptr;
         ga.tile_pos = tpos; ga.tpw = (stream_tiles + n_waves - 1) / n_waves;
-        ga.stride_magic = pa.stride_magic; ga.index_base = chunked ? nullptr : p->dev_index_base;
+        ga.stride_magic = pa.stride_magic; ga.index_base = chunked ? nullptr : p->dev_index_base; ga.skip = chunked ? nullptr : p->dev_skip;
     }
 
     acx_ppm_compact_args& ca = r->pend_ca;            // (the general kernel: per-tile counts, scan, compact)
@@ -792,6 +823,8 @@ extern "C" int acx_scan_batch(acx_image_t* img, const acx_scan_params* p, acx_re
         if (p->stride < 0 || p->stride > INT32_MAX) return acx_fail(ACX_E_INVAL, "acx_scan_batch: stride out of range");
         if (p->n_hay * p->stride > p->hay_capacity) return acx_fail(ACX_E_INVAL, "acx_scan_batch: n_hay*stride exceeds hay_capacity");
     }
+    if (p->dev_skip && (p->mode != ACX_SCAN_ALL || p->dev_init_state))
+        return acx_fail(ACX_E_INVAL, "acx_scan_batch: dev_skip is for ACX_SCAN_ALL without carried states (the context replaces them)");
     if (p->hay_capacity > ACX_MAX_LAUNCH_BYTES)
         return acx_fail(ACX_E_UNSUPPORTED, "acx_scan_batch: %lld haystack bytes in one call; split the batch into calls of <= %lld bytes",
                         (long long)p->hay_capacity, (long long)ACX_MAX_LAUNCH_BYTES);
@@ -805,6 +838,7 @@ extern "C" int acx_scan_batch(acx_image_t* img, const acx_scan_params* p, acx_re
     }
     if (r->pending) { int rcw = result_complete(r); if (rcw) return rcw; }     // still in flight on its old stream
     r->stream = s; r->n_hay = p->n_hay; r->total = 0; r->host_valid = false;
+    r->skip_after = nullptr; r->skip_base = p->dev_index_base;
     r->has_final = p->want_final_state != 0; r->timed = p->timing != 0; r->timed_all = p->timing == 1;
 
     // position-parallel kernels: ACX_SCAN_ALL on an image that carries the structures, no carried-in state
@@ -812,8 +846,10 @@ extern "C" int acx_scan_batch(acx_image_t* img, const acx_scan_params* p, acx_re
     if (p->mode == ACX_SCAN_ALL && img->ppm_g && !p->dev_init_state && p->n_hay > 0 && !((p->variant >> 23) & 1) &&
         (p->dev_off || p->stride > 0)) {
         const int plan = ppm_plan(img, p);
+        if (plan == 1) r->skip_after = p->dev_skip;                 // (k_ppm_scan does not know dev_skip: its records are dropped afterwards)
         if (plan) return scan_ppm(img, p, r, s, plan);
     }
+    r->skip_after = p->dev_skip;                                      // (neither do the serial walks)
 
     const size_t n = (size_t)p->n_hay;
     int rc;
@@ -969,7 +1005,7 @@ extern "C" int acx_result_timing(acx_result_t* r, float* walk_ms, float* scan_ms
 
 // one group of haystacks that fits a launch: H2D, scan; `off` starts at 0
 static int scan_host_once(acx_image_t* img, int mode, const uint8_t* hay, const int64_t* off, int64_t n_hay,
-                          const int32_t* init_state, const int32_t* index_base, acx_result_t** result) {
+                          const int32_t* init_state, const int32_t* index_base, acx_result_t** result, int want_final) {
     acx_result* r = *result;
     const int64_t total_bytes = off[n_hay];
     int rc;
@@ -991,9 +1027,67 @@ static int scan_host_once(acx_image_t* img, int mode, const uint8_t* hay, const 
     p.dev_hay = r->in_hay.p; p.hay_capacity = total_bytes; p.dev_off = r->in_off.p; p.stride = 0; p.n_hay = n_hay;
     p.dev_init_state = init_state ? r->in_init.p : nullptr;
     p.dev_index_base = index_base ? r->in_base.p : nullptr;
-    p.want_final_state = 1;
+    p.want_final_state = want_final;
     int64_t shortest = INT32_MAX;
     for (int64_t h = 0; h < n_hay && shortest >= 8; h++) if (off[h + 1] - off[h] < shortest) shortest = off[h + 1] - off[h];
+    p.min_hay_len = n_hay > 0 ? (int32_t)shortest : 0;
+    return acx_scan_batch(img, &p, result, nullptr);
+}
+
+static int scan_host_impl(acx_image_t* img, int mode, const uint8_t* hay, const int64_t* off, int64_t n_hay,
+                          const int32_t* init_state, const int32_t* index_base, acx_result_t** result, int want_final);
+
+// streams: context and chunk of every haystack staged side by side; the context's records are never reported
+extern "C" int acx_scan_host_ctx(acx_image_t* img, const uint8_t* hay, const int64_t* off, int64_t n_hay,
+                                 const uint8_t* ctx, const int64_t* ctx_off, const int32_t* index_base, acx_result_t** result) {
+    if (!img || !off || !result || n_hay < 0) return acx_fail(ACX_E_INVAL, "acx_scan_host_ctx: bad argument");
+    if (!ctx || !ctx_off) return scan_host_impl(img, ACX_SCAN_ALL, hay, off, n_hay, nullptr, index_base, result, 0);
+    if (off[0] != 0 || ctx_off[0] != 0) return acx_fail(ACX_E_INVAL, "acx_scan_host_ctx: off[0] and ctx_off[0] must be 0");
+    int64_t total = 0, shortest = INT32_MAX;
+    for (int64_t h = 0; h < n_hay; h++) {
+        const int64_t l = off[h + 1] - off[h], c = ctx_off[h + 1] - ctx_off[h];
+        if (l < 0 || c < 0 || l + c > INT32_MAX) return acx_fail(ACX_E_INVAL, "acx_scan_host_ctx: bad lengths at haystack %lld", (long long)h);
+        total += l + c;
+        if (l + c < shortest) shortest = l + c;
+    }
+    if (total > ACX_MAX_LAUNCH_BYTES) return acx_fail(ACX_E_UNSUPPORTED, "acx_scan_host_ctx: %lld bytes in one call; split the batch", (long long)total);
+    acx_result* r = *result;
+    if (!r) {
+        r = new (std::nothrow) acx_result();
+        if (!r) return acx_fail(ACX_E_NOMEM, "acx_scan_host_ctx: out of memory");
+        *result = r;
+    }
+    if (r->pending) { int rcw = result_complete(r); if (rcw) return rcw; }
+    int rc;
+    if ((rc = r->h_stage.ensure((size_t)total + 64))) return rc;
+    if ((rc = r->h_off.ensure((size_t)n_hay + 1))) return rc;           // (reused as staging for the new offsets; fetch_host rewrites it)
+    if ((rc = r->h_final.ensure((size_t)n_hay + 1))) return rc;         // (staging for the context lengths)
+    int64_t at = 0;
+    for (int64_t h = 0; h < n_hay; h++) {
+        const int64_t l = off[h + 1] - off[h], c = ctx_off[h + 1] - ctx_off[h];
+        r->h_off.p[h] = at;
+        r->h_final.p[h] = (int32_t)c;
+        if (c) memcpy(r->h_stage.p + at, ctx + ctx_off[h], (size_t)c);
+        if (l) memcpy(r->h_stage.p + at + c, hay + off[h], (size_t)l);
+        at += l + c;
+    }
+    r->h_off.p[n_hay] = at;
+    if ((rc = r->in_hay.ensure((size_t)total + 64))) return rc;
+    if ((rc = r->in_off.ensure((size_t)n_hay + 1))) return rc;
+    if ((rc = r->in_skip.ensure((size_t)n_hay + 1))) return rc;
+    if (total) HIP_TRY(hipMemcpy(r->in_hay.p, r->h_stage.p, (size_t)total, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(r->in_off.p, r->h_off.p, ((size_t)n_hay + 1) * sizeof(int64_t), hipMemcpyHostToDevice));
+    if (n_hay) HIP_TRY(hipMemcpy(r->in_skip.p, r->h_final.p, (size_t)n_hay * 4, hipMemcpyHostToDevice));
+    if (index_base) {
+        if ((rc = r->in_base.ensure((size_t)n_hay + 1))) return rc;
+        if (n_hay) HIP_TRY(hipMemcpy(r->in_base.p, index_base, (size_t)n_hay * 4, hipMemcpyHostToDevice));
+    }
+    acx_scan_params p;
+    memset(&p, 0, sizeof p);
+    p.struct_bytes = sizeof p; p.mode = ACX_SCAN_ALL;
+    p.dev_hay = r->in_hay.p; p.hay_capacity = total; p.dev_off = r->in_off.p; p.stride = 0; p.n_hay = n_hay;
+    p.dev_index_base = index_base ? r->in_base.p : nullptr;
+    p.dev_skip = r->in_skip.p;
     p.min_hay_len = n_hay > 0 ? (int32_t)shortest : 0;
     return acx_scan_batch(img, &p, result, nullptr);
 }
@@ -1005,6 +1099,13 @@ static int64_t max_launch_bytes() {
 
 extern "C" int acx_scan_host(acx_image_t* img, int mode, const uint8_t* hay, const int64_t* off, int64_t n_hay,
                              const int32_t* init_state, const int32_t* index_base, acx_result_t** result) {
+    return scan_host_impl(img, mode, hay, off, n_hay, init_state, index_base, result, 1);
+}
+
+// want_final = 0: no final states (an image with the position-parallel structures then never builds its dense table
+// for ACX_SCAN_ALL: acx_scan_host_ctx, what the iterators and find_all call)
+static int scan_host_impl(acx_image_t* img, int mode, const uint8_t* hay, const int64_t* off, int64_t n_hay,
+                          const int32_t* init_state, const int32_t* index_base, acx_result_t** result, int want_final) {
     if (!img || !off || !result || n_hay < 0) return acx_fail(ACX_E_INVAL, "acx_scan_host: bad argument");
     if (off[0] != 0) return acx_fail(ACX_E_INVAL, "acx_scan_host: off[0] must be 0");
     for (int64_t h = 0; h < n_hay; h++) {
@@ -1020,7 +1121,7 @@ extern "C" int acx_scan_host(acx_image_t* img, int mode, const uint8_t* hay, con
         *result = r;
     }
     const int64_t limit = max_launch_bytes();
-    if (total_bytes <= limit) return scan_host_once(img, mode, hay, off, n_hay, init_state, index_base, result);
+    if (total_bytes <= limit) return scan_host_once(img, mode, hay, off, n_hay, init_state, index_base, result, want_final);
 
     // More than one launch can stage (8 B of event scratch per haystack byte): scan groups of whole
     // haystacks one after the other and assemble the host-side result; the device-side accessors then
@@ -1042,7 +1143,7 @@ extern "C" int acx_scan_host(acx_image_t* img, int mode, const uint8_t* hay, con
             if (goff[(size_t)gn] > ACX_MAX_LAUNCH_BYTES)
                 return acx_fail(ACX_E_UNSUPPORTED, "acx_scan_host: haystack %lld alone exceeds one launch", (long long)g0);
             rc = scan_host_once(img, mode, hay + off[g0], goff.data(), gn, init_state ? init_state + g0 : nullptr,
-                                index_base ? index_base + g0 : nullptr, result);
+                                index_base ? index_base + g0 : nullptr, result, want_final);
             if (rc) return rc;
             const int64_t* moff; const acx_match_t* m; const int32_t* fin;
             if ((rc = acx_result_fetch_host(r, &moff, &m, &fin))) return rc;

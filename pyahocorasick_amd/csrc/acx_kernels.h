@@ -107,6 +107,7 @@ struct acx_ppm_args {
     const uint8_t* hay; int64_t hay_cap;
     int64_t stride; int64_t n_hay; uint64_t stride_magic;    // ceil(2^64 / stride); 0 for stride 1
     const int32_t* index_base;                               // nullable (fixed-stride batches)
+    const int32_t* skip;                                     // nullable: context bytes in front of every haystack (acx_scan_params.dev_skip)
     const acx_chunk_desc* ck; const int64_t* n_items_dev;
     int64_t n_items;                                         // tiles of a fixed-stride batch
     // image
@@ -158,6 +159,7 @@ struct acx_ppm_gather_args {       // k_ppm_stream results -> final place
     int64_t tile_pos, tpw;         // positions per tile, tiles per wave
     uint64_t stride_magic;         // fixed stride: ceil(2^64 / stride) (0 for stride 1)
     const int32_t* index_base;     // fixed stride: added to every index of haystack h (nullable)
+    const int32_t* skip;           // fixed stride: context bytes of haystack h, taken off every index (nullable)
 };
 #define ACX_PPM_DESC_WORDS 40
 hipError_t acx_launch_ppm_first_h(const int64_t* off, int64_t n_hay, int64_t n_tiles, int64_t tile_pos, int64_t* first_h, hipStream_t s);
@@ -169,6 +171,13 @@ int64_t acx_ppm_grid_blocks(const acx_ppm_lds& lds, int64_t n_items_bound, uint3
 // state after a haystack = the state after its last longest_word bytes walked from the root
 hipError_t acx_launch_tail_state(const acx_walk_args& a, int32_t longest, hipStream_t s);
 int acx_num_cus();
+// dev_skip for the kernel families that do not know it (serial walks, k_ppm_scan): the records of the context — a prefix
+// of every haystack's records, they are sorted by end_index — are dropped and the rest rebased.  kept[h] and new offsets
+// come from k_skip_count + scan, then k_skip_move copies into `dst`.
+hipError_t acx_launch_skip_count(const int64_t* match_off, const uint2* matches, const int32_t* skip, const int32_t* index_base,
+                                 int64_t n_hay, int32_t* kept, hipStream_t s);
+hipError_t acx_launch_skip_move(const int64_t* match_off, const uint2* matches, const int32_t* skip, const int32_t* kept,
+                                const int64_t* new_off, int64_t n_hay, uint2* dst, hipStream_t s);
 // build the dense transition table in HBM from the sparse form (acx_build.hip)
 hipError_t acx_launch_build_table(uint32_t* table, const int32_t* fail, const uint32_t* edge_off, const uint8_t* edge_cls,
                                   const uint32_t* edge_dst, const uint32_t* tflags, const uint32_t* lvl_first_host,

@@ -900,6 +900,17 @@ __global__ void __launch_bounds__(ACX_PPM_BLOCK) k_ppm_stream(const acx_ppm_args
                     if (lo2 < LL[e]) LL[e] = lo2;
                 )
             }
+            // 0b. streams (acx_scan_params.dev_skip): an entry inside the context of its haystack ends no reported match
+            if (a.skip) {
+                PPM_SLOTS(e,
+                    const uint32_t qi = 64u * (uint32_t)e + (uint32_t)lane;
+                    uint32_t r; uint32_t rk;
+                    where(qi < n ? (uint32_t)queue[qi] & 0x7FFFu : 0u, r, rk);
+                    uint32_t hh = (OFFS ? hbase : h_tile) + rk;
+                    if (OFFS && hh == 0xFFFFFFFFu) hh = 0;
+                    if (r < (uint32_t)a.skip[hh]) LL[e] = 0;
+                )
+            }
             // 1. where the entries sit, their windows, the requests for their hot cells.  Straight-line over all NE slots
             // (a slot beyond the queue's end works on position 0 with L = 0, which matches nothing): the LDS reads and
             // the gathers of the slots overlap.
@@ -1082,12 +1093,13 @@ __global__ void __launch_bounds__(ACX_PPM_BLOCK) k_ppm_stream(const acx_ppm_args
                 uint32_t startany = 0;
 #pragma unroll
                 for (int e = 0; e < NE; e++) startany |= rr[e] == 0u ? 1u : 0u;       // (no entry: rr = 1)
-                if (__any(startany != 0u) || a.index_base) {
+                if (__any(startany != 0u) || a.index_base || a.skip) {
                     const uint32_t dump = (uint32_t)a.n_hay;             // hay_local[n_hay]: spare
                     PPM_SLOTS(e,
                         const uint32_t hh = (OFFS ? hbase : h_tile) + (pp[e] >> 17);      // (the rank that step 1 found)
                         a.hay_local[rr[e] == 0u ? hh : dump] = (int32_t)(run_off + ex[e]);   // the records in front of this haystack
                         if (a.index_base) rr[e] += cn[e] ? (uint32_t)a.index_base[hh] : 0u;
+                        if (a.skip) rr[e] -= cn[e] ? (uint32_t)a.skip[hh] : 0u;
                     )
                 }
             }
@@ -1308,7 +1320,8 @@ __global__ void __launch_bounds__(256) k_ppm_gather_pos(const acx_ppm_gather_arg
                 uint32_t idx;
                 const uint32_t q = locate(rec.x, idx);
                 for (uint32_t qq = q_prev + 1; (int32_t)(qq - q) <= 0; qq++) c.match_off[h0 + (int64_t)(int32_t)qq] = base + li + k;   // haystacks that start between the two records
-                u32x2 o; o.x = idx + (c.index_base ? (uint32_t)c.index_base[h0 + (int64_t)(int32_t)q] : 0u); o.y = rec.y;
+                u32x2 o; o.y = rec.y;
+                o.x = idx + (c.index_base ? (uint32_t)c.index_base[h0 + (int64_t)(int32_t)q] : 0u) - (c.skip ? (uint32_t)c.skip[h0 + (int64_t)(int32_t)q] : 0u);
                 return o;
             };
             auto q_of = [&](uint32_t k) -> uint32_t { uint32_t t; return locate(src[k].x, t); };
@@ -1363,6 +1376,31 @@ __global__ void __launch_bounds__(256) k_ppm_compact(const acx_ppm_compact_args 
             if (h == c.n_hay) c.match_off[h] = total;
             else c.match_off[h] = c.item_off[(h * c.stride) / PPM_TILE] + c.hay_local[h];
         }
+    }
+}
+
+// dev_skip for kernels that do not know it: the records of haystack h are sorted by end index, those of its context
+// (end index below index_base[h] + skip[h]) are a prefix
+__global__ void __launch_bounds__(256) k_skip_count(const int64_t* match_off, const uint2* matches, const int32_t* skip, const int32_t* index_base,
+                                                    int64_t n_hay, int32_t* kept) {
+    const int64_t n_threads = (int64_t)gridDim.x * 256;
+    for (int64_t h = (int64_t)blockIdx.x * 256 + threadIdx.x; h < n_hay; h += n_threads) {
+        const int64_t lo0 = match_off[h], hi0 = match_off[h + 1];
+        const int32_t lim = skip[h] + (index_base ? index_base[h] : 0);
+        int64_t lo = lo0, hi = hi0;                                      // first record with end_index >= lim
+        while (lo < hi) { const int64_t mid = (lo + hi) >> 1; if ((int32_t)matches[mid].x >= lim) hi = mid; else lo = mid + 1; }
+        kept[h] = (int32_t)(hi0 - lo);
+    }
+}
+__global__ void __launch_bounds__(256) k_skip_move(const int64_t* match_off, const uint2* matches, const int32_t* skip, const int32_t* kept,
+                                                   const int64_t* new_off, int64_t n_hay, uint2* dst) {
+    const int sub = threadIdx.x & 15;
+    const int64_t n_groups = (int64_t)gridDim.x * 16;
+    for (int64_t h = (int64_t)blockIdx.x * 16 + (threadIdx.x >> 4); h < n_hay; h += n_groups) {
+        const int32_t n = kept[h], sk = skip[h];
+        const uint2* src = matches + (match_off[h + 1] - n);
+        uint2* d = dst + new_off[h];
+        for (int32_t k = sub; k < n; k += 16) { uint2 r = src[k]; r.x -= (uint32_t)sk; d[k] = r; }
     }
 }
 
@@ -1437,6 +1475,25 @@ hipError_t acx_launch_ppm_scan(const acx_ppm_args& a, int64_t n_items_bound, hip
     if (a.sym_bits == 8) PPM_CASE(8);
 #undef PPM_CASE
     return hipErrorInvalidValue;
+}
+
+hipError_t acx_launch_skip_count(const int64_t* match_off, const uint2* matches, const int32_t* skip, const int32_t* index_base,
+                                 int64_t n_hay, int32_t* kept, hipStream_t s) {
+    int64_t blocks = (n_hay + 255) / 256;
+    const int64_t cap = (int64_t)num_cus() * 16;
+    if (blocks > cap) blocks = cap;
+    if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(k_skip_count, dim3((unsigned)blocks), dim3(256), 0, s, match_off, matches, skip, index_base, n_hay, kept);
+    return hipGetLastError();
+}
+hipError_t acx_launch_skip_move(const int64_t* match_off, const uint2* matches, const int32_t* skip, const int32_t* kept,
+                                const int64_t* new_off, int64_t n_hay, uint2* dst, hipStream_t s) {
+    int64_t blocks = (n_hay + 15) / 16;
+    const int64_t cap = (int64_t)num_cus() * 32;
+    if (blocks > cap) blocks = cap;
+    if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(k_skip_move, dim3((unsigned)blocks), dim3(256), 0, s, match_off, matches, skip, kept, new_off, n_hay, dst);
+    return hipGetLastError();
 }
 
 hipError_t acx_launch_ppm_first_h(const int64_t* off, int64_t n_hay, int64_t n_tiles, int64_t tile_pos, int64_t* first_h, hipStream_t s) {

@@ -285,9 +285,12 @@ bool gpu_sync(AutomatonObject* a) {
 // one GPU scan of n haystacks given as (data, offsets).  The GIL is released around H2D, kernels and D2H; the
 // records stay valid until lease->done() (or its destructor).  `data` must not be a buffer that another Python
 // thread can free meanwhile: the callers pass memory of objects they hold a reference to, or their own copies.
+// ctx != nullptr (ACX_SCAN_ALL, one haystack): the bytes a stream delivered before `data` — matches may begin in there,
+// none that ends in there is reported (acx_scan_host_ctx).  ACX_SCAN_ALL asks for no final states either way.
 bool run_scan(AutomatonObject* a, int mode, const uint8_t* data, const int64_t* off, int64_t n,
               const int32_t* init_state, const int32_t* index_base,
-              const int64_t** moff, const acx_match_t** m, const int32_t** fin, ScanLease* lease) {
+              const int64_t** moff, const acx_match_t** m, const int32_t** fin, ScanLease* lease,
+              const uint8_t* ctx = nullptr, int64_t ctx_len = 0) {
     if (!gpu_sync(a)) return false;
     lease->a = a; lease->ref = a->image; lease->ref->users++;
     if (a->results && !a->results->empty()) { lease->res = a->results->back(); a->results->pop_back(); }
@@ -295,8 +298,12 @@ bool run_scan(AutomatonObject* a, int mode, const uint8_t* data, const int64_t* 
     int rc;
     char err[512];
     err[0] = 0;
+    const int64_t ctx_off[2] = {0, ctx_len};
+    static const uint8_t no_ctx = 0;
     Py_BEGIN_ALLOW_THREADS
-    rc = acx_scan_host(img, mode, data, off, n, init_state, index_base, &lease->res);
+    if (mode == ACX_SCAN_ALL && !init_state)
+        rc = acx_scan_host_ctx(img, data, off, n, ctx ? ctx : (n == 1 ? &no_ctx : nullptr), n == 1 ? ctx_off : nullptr, index_base, &lease->res);
+    else rc = acx_scan_host(img, mode, data, off, n, init_state, index_base, &lease->res);
     if (!rc) rc = acx_result_fetch_host(lease->res, moff, m, fin);
     if (rc) { strncpy(err, acx_last_error(), sizeof err - 1); err[sizeof err - 1] = 0; }     // (the message is thread-local: keep it across the switch)
     Py_END_ALLOW_THREADS
@@ -617,7 +624,8 @@ struct SearchIterObject {
     int64_t version;
     std::vector<acx_match_t>* pending;
     size_t pos;
-    int32_t state;          // carried across set() (ACX_SCAN_ALL only)
+    int32_t state;          // iter_long: carried across set()
+    std::vector<uint8_t>* ctx;   // iter: what the stream delivered before the current chunk (its last longest_word - 1 letters)
     Py_ssize_t shift;
     Py_ssize_t ref_index;   // the reference's iter->index, for set()'s shift arithmetic
     Py_ssize_t end;
@@ -639,8 +647,11 @@ inline bool is_cspace(uint8_t b) { return b == ' ' || (b >= '\t' && b <= '\r'); 
 // Scan letters [start, end) of `t`; matches come back with end_index in LETTERS of the whole
 // string plus `index_shift`.  ignore_ws: white-space letters are skipped without touching the state
 // (src/AutomatonSearchIter.c:269-274).  state_io: automaton state carried in and out (iter.set()).
+// ctx (ACX_SCAN_ALL): the letters the stream delivered before this slice (iter().set()): the scan continues from them,
+// not from a state.
 bool scan_text(AutomatonObject* a, int mode, const Text& t, Py_ssize_t start, Py_ssize_t end, bool ignore_ws,
-               int32_t* state_io, Py_ssize_t index_shift, std::vector<acx_match_t>* out) {
+               int32_t* state_io, Py_ssize_t index_shift, std::vector<acx_match_t>* out,
+               const std::vector<uint8_t>* ctx = nullptr) {
     const Py_ssize_t bs = char_to_byte(t, start), be = char_to_byte(t, end);
     const uint8_t* src = t.data + bs;
     const Py_ssize_t nb = be - bs;
@@ -663,7 +674,8 @@ bool scan_text(AutomatonObject* a, int mode, const Text& t, Py_ssize_t start, Py
     int32_t init = state_io ? *state_io : 0;
     // (the root needs no init_state array: such a scan may take the position-parallel kernels)
     ScanLease lease;
-    if (!run_scan(a, mode, scan_src, off, 1, (state_io && init != 0) ? &init : nullptr, nullptr, &moff, &m, &fin, &lease)) return false;
+    if (!run_scan(a, mode, scan_src, off, 1, (state_io && init != 0) ? &init : nullptr, nullptr, &moff, &m, &fin, &lease,
+                  ctx && !ctx->empty() ? ctx->data() : nullptr, ctx ? (int64_t)ctx->size() : 0)) return false;
     out->assign(m, m + moff[1]);
     for (auto& r : *out) {
         int32_t byte_off = ignore_ws ? remap[(size_t)r.end_index] : r.end_index;
@@ -673,6 +685,17 @@ bool scan_text(AutomatonObject* a, int mode, const Text& t, Py_ssize_t start, Py
     if (state_io && fin) *state_io = fin[0];
     lease.done();
     return true;
+}
+
+// the context after the letters [start, upto) of `t` have been walked behind `ctx`: their bytes (white space left out
+// when the iterator ignores it: it does not touch the state, src/AutomatonSearchIter.c:269-274), the last
+// longest_word - 1 of the lot
+void ctx_advance(AutomatonObject* a, std::vector<uint8_t>* ctx, const Text& t, Py_ssize_t start, Py_ssize_t upto, bool ignore_ws) {
+    const Py_ssize_t bs = char_to_byte(t, start), be = char_to_byte(t, upto);
+    for (Py_ssize_t i = bs; i < be; i++) if (!ignore_ws || !is_cspace(t.data[i])) ctx->push_back(t.data[i]);
+    const int64_t lw = acx_trie_longest_word(a->trie);
+    const size_t keep = lw > 1 ? (size_t)(lw - 1) : 0;
+    if (ctx->size() > keep) ctx->erase(ctx->begin(), ctx->end() - (std::ptrdiff_t)keep);
 }
 
 // A chunk is scanned when its first match is asked for, not when iter() / set() hands it over: the reference walks
@@ -694,7 +717,7 @@ bool iter_ensure_loaded(SearchIterObject* it) {
     if (!get_text(it->src, &t, true, it->automaton->key_type)) return false;
     Py_ssize_t end = it->end > t.nchars ? t.nchars : it->end;
     if (!scan_text(it->automaton, it->is_long ? ACX_SCAN_LONG : ACX_SCAN_ALL, t, it->start, end, it->ignore_ws,
-                   &it->state, it->shift, it->pending)) return false;
+                   it->is_long ? &it->state : nullptr, it->shift, it->pending, it->is_long ? nullptr : it->ctx)) return false;
     it->pos = 0; it->loaded = true;
     return true;
 }
@@ -705,6 +728,7 @@ PyObject* search_iter_create(AutomatonObject* a, PyObject* srcobj, const Text& t
     it->automaton = a; Py_INCREF(a);
     it->version = acx_trie_version(a->trie);
     it->pending = new std::vector<acx_match_t>();
+    it->ctx = new std::vector<uint8_t>();
     it->pos = 0; it->state = 0; it->shift = 0; it->ref_index = -1; it->end = 0; it->ignore_ws = ws; it->is_long = is_long;
     Py_INCREF(srcobj); it->src = srcobj; it->start = 0; it->state0 = 0; it->exhausted = false; it->loaded = false;
     if (!iter_load(it, t, start, end)) { Py_DECREF(it); return nullptr; }
@@ -715,6 +739,7 @@ void search_iter_dealloc(SearchIterObject* it) {
     Py_XDECREF(it->automaton);
     Py_XDECREF(it->src);
     delete it->pending;
+    delete it->ctx;
     PyObject_Del(it);
 }
 
@@ -737,23 +762,22 @@ PyObject* search_iter_set(SearchIterObject* it, PyObject* args) {  // src/Automa
     if (!PyArg_ParseTuple(args, "O|p", &s, &reset)) return nullptr;
     Text t;
     if (!get_text(s, &t, true, it->automaton->key_type)) return nullptr;
-    if (reset) { it->state = 0; it->shift = 0; }
+    if (reset) { it->state = 0; it->shift = 0; it->ctx->clear(); }
     else {
-        if (!it->loaded) it->state = it->state0;                   // nothing of the old chunk was asked for: the reference has not moved
-        else if (!it->exhausted && it->version == acx_trie_version(it->automaton->trie)) {
-            // set() before StopIteration.  iter_long: the reference is at the root after every match it returned
-            // (src/AutomatonSearchIterLong.c:101-110).  iter: it holds the state after the last yielded position:
-            // scan that prefix of the old chunk again (the whole chunk was scanned eagerly, so it->state is the
-            // state at the chunk's END, which is not what the reference continues from)
-            if (it->is_long) it->state = it->ref_index >= it->start ? 0 : it->state0;      // (nothing returned yet: untouched)
-            else if (it->src) {
+        // What the reference has walked of the old chunk: all of it after StopIteration, else up to the last match it
+        // returned (nothing, when no match was asked for).  iter: those letters go behind the old context; no scan.
+        // iter_long: it is at the root after every match it returned (src/AutomatonSearchIterLong.c:101-110), where it
+        // was before the chunk when it returned none, and where the walk ended after StopIteration.
+        if (it->version == acx_trie_version(it->automaton->trie)) {
+            if (it->is_long) {
+                if (!it->loaded) it->state = it->state0;
+                else if (!it->exhausted) it->state = it->ref_index >= it->start ? 0 : it->state0;
+            } else if (it->src) {
                 Text old;
                 if (!get_text(it->src, &old, true, it->automaton->key_type)) return nullptr;
-                std::vector<acx_match_t> drop;
-                int32_t st = it->state0;
-                const Py_ssize_t upto = it->ref_index + 1 > it->start ? it->ref_index + 1 : it->start;
-                if (!scan_text(it->automaton, ACX_SCAN_ALL, old, it->start, upto, it->ignore_ws, &st, 0, &drop)) return nullptr;
-                it->state = st;
+                Py_ssize_t upto = it->exhausted ? it->end : (it->ref_index + 1 > it->start ? it->ref_index + 1 : it->start);
+                if (upto > old.nchars) upto = old.nchars;
+                ctx_advance(it->automaton, it->ctx, old, it->start, upto, it->ignore_ws);
             }
         }
         it->shift += it->ref_index >= 0 ? it->ref_index : 0;

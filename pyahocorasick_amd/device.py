@@ -152,7 +152,7 @@ class Scanner:
 
     def scan(self, dev_hay, hay_capacity, n_hay, dev_off=None, stride=0, mode=ACX_SCAN_ALL,
              dev_init_state=None, dev_index_base=None, want_final_state=False, timing=False,
-             variant=0, stream=None, asynchronous=False, min_hay_len=0):
+             variant=0, stream=None, asynchronous=False, min_hay_len=0, dev_skip=None):
         """All pointer arguments are raw device addresses (int / c_void_p / None).
         asynchronous=True: return as soon as the kernels are queued on `stream` (returns None);
         `wait()`, `num_matches()`, `fetch()` complete the scan."""
@@ -170,6 +170,7 @@ class Scanner:
         p.timing = 2 if (timing == 2 and timing is not True) else (1 if timing else 0)   # 2: events around the walk only
         p.variant = int(variant)
         p.min_hay_len = int(min_hay_len)
+        p.dev_skip = _addr(dev_skip)                 # streams: context bytes in front of every haystack (include/acx.h)
         p.flags = ACX_SCAN_ASYNC if asynchronous else 0
         check(lib().acx_scan_batch(self.image.handle, C.byref(p), C.byref(self._res), _addr(stream)))
         self.n_hay = int(n_hay)

@@ -28,7 +28,7 @@ def test_header_functions_all_exported_and_bound():
 
 def test_library_loads_and_reports_abi():
     l = _lib.lib()
-    assert l.acx_abi_version() == 2
+    assert l.acx_abi_version() == 3
 
 
 def test_struct_layout_matches_header(tmp_path):

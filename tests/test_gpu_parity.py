@@ -820,3 +820,43 @@ def test_image_broadcast_over_rccl_single_rank():
     finally:
         rccl.ncclCommDestroy.argtypes = [C.c_void_p]
         rccl.ncclCommDestroy(comm)
+
+
+def test_dev_skip_streams_on_every_kernel_family():
+    """acx_scan_params.dev_skip: the first skip[h] bytes of haystack h are context (the tail of what a stream delivered
+    before): matches that end in there are not reported, indices count from behind them.  A stream cut into chunks, every
+    chunk scanned with the longest_word - 1 bytes before it as context, gives what one scan of the whole stream gives —
+    on the stream kernel (offsets and fixed stride), the general position-parallel kernel and the serial walks."""
+    rng = np.random.default_rng(17)
+    for alpha_b, kmax in ((b"ACGT", 12), (b"abcdefghijklmnop", 9), (bytes(range(256)), 6)):
+        alpha = np.frombuffer(alpha_b, dtype=np.uint8)
+        keys = list({bytes(alpha[rng.integers(0, len(alpha), size=int(k))]) for k in rng.integers(2, kmax + 1, size=300)})
+        A, O = build_pair(keys)
+        img = Image.from_automaton(A)
+        halo = max(len(k) for k in keys) - 1
+        n_streams, chunk = 700, 96
+        streams = np.ascontiguousarray(alpha[rng.integers(0, len(alpha), size=(n_streams, 3 * chunk))])
+        for i in range(0, n_streams, 3):                                 # keys across the cuts
+            k = np.frombuffer(keys[int(rng.integers(0, len(keys)))], dtype=np.uint8)
+            cut = chunk * int(rng.integers(1, 3))
+            o = cut - int(rng.integers(0, len(k)))
+            streams[i, o:o + len(k)] = k
+        want = [O.iter(streams[i].tobytes()) for i in range(n_streams)]
+        for variant in (0, (1 << 24) | (1 << 28), 1 << 23):
+            for layout in ("offsets", "stride"):
+                got = [[] for _ in range(n_streams)]
+                for c in range(3):
+                    ctx = halo if c else 0
+                    lo = c * chunk - ctx
+                    part = np.ascontiguousarray(streams[:, lo:(c + 1) * chunk])
+                    L = part.shape[1]
+                    d_hay = DeviceBuffer.from_numpy(part.reshape(-1), pad=64)
+                    d_skip = DeviceBuffer.from_numpy(np.full(n_streams, ctx, dtype=np.int32))
+                    d_base = DeviceBuffer.from_numpy(np.full(n_streams, c * chunk, dtype=np.int32))
+                    sc = Scanner(img)
+                    kw = dict(dev_off=DeviceBuffer.from_numpy(np.arange(n_streams + 1, dtype=np.int64) * L), min_hay_len=L) if layout == "offsets" else dict(stride=L)
+                    sc.scan(d_hay, part.size, n_streams, dev_skip=d_skip, dev_index_base=d_base, variant=variant, **kw)
+                    moff, e, v, _ = sc.fetch()
+                    for i in range(n_streams):
+                        got[i] += list(zip(e[moff[i]:moff[i + 1]].tolist(), v[moff[i]:moff[i + 1]].tolist()))
+                assert got == want, (alpha_b[:4], variant, layout)
