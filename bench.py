@@ -262,7 +262,7 @@ def main():
     # a batch = (device bytes, capacity, n haystacks, device offsets or None, stride, host copy for batch 0)
     strong = args.scaling == "strong" and world > 1
     B = max(1, args.batches)
-    batches, host0 = [], None
+    batches, host0, e2e0 = [], None, None
     t0 = time.perf_counter()
     for b in range(B):
         seed = 1 + b + (0 if strong else 16 * rank)
@@ -275,6 +275,7 @@ def main():
             flat, off = reads.reshape(-1), None
             if b == 0:
                 host0 = [reads[i].tobytes() for i in range(n)]
+                e2e0 = (np.ascontiguousarray(flat), np.arange(n + 1, dtype=np.int64) * L)
         elif args.workload == "c3":
             nbytes = args.batch_mb << 20
             flat = np.concatenate([W.text_corpus(vocab, min(64 << 20, nbytes - o), seed=4 + 64 * seed + o // (64 << 20))
@@ -285,12 +286,14 @@ def main():
             n, L, off = 1, 0, np.array([0, len(flat)], dtype=np.int64)
             if b == 0:
                 host0 = [flat[i:i + (1 << 16)].tobytes() for i in range(0, min(len(flat), 32 << 20), 1 << 16)]
+                e2e0 = (np.ascontiguousarray(flat), off)
         else:
             flat, off = W.packet_payloads(keys, args.batch_mb << 20, seed=6 + seed)
             n, L = len(off) - 1, 0
             if b == 0:
                 m = int(np.searchsorted(off, 32 << 20))
                 host0 = [flat[off[i]:off[i + 1]].tobytes() for i in range(m)]
+                e2e0 = (np.ascontiguousarray(flat), off)
         d_hay = torch.empty(len(flat) + 64, dtype=torch.uint8, device=dev)
         d_hay[: len(flat)].copy_(torch.from_numpy(np.ascontiguousarray(flat)))
         d_off = torch.from_numpy(off).to(dev) if off is not None else None
@@ -450,6 +453,24 @@ def main():
             },
             "setup": {"build_flatten_s": round(t_build, 3), "broadcast_upload_s": round(t_bcast, 3), "stage_batches_s": round(t_stage, 3)},
         }
+        if world == 1 and e2e0 is not None and args.mode == "iter":
+            # PCIe-inclusive (SURVEY §8d "also report end-to-end"): host buffers in, offsets and records back in host
+            # memory — acx_scan_host_ctx + acx_result_fetch_host, what Automaton.iter / find_all / iter_batch call.
+            # Never `value`.  (On this box H2D and D2H do not overlap: profiles/r3_pcie_probe.txt.)
+            import ctypes as C
+            res_e2e = C.c_void_p()
+            hflat, hoff = e2e0
+            best = None
+            for _ in range(4):
+                t0 = time.perf_counter()
+                _lib.check(_lib.lib().acx_scan_host_ctx(image.handle, hflat.ctypes.data, hoff.ctypes.data, len(hoff) - 1, None, None, None, C.byref(res_e2e)))
+                p1, p2, p3 = C.c_void_p(), C.c_void_p(), C.c_void_p()
+                _lib.check(_lib.lib().acx_result_fetch_host(res_e2e, C.byref(p1), C.byref(p2), C.byref(p3)))
+                dt_e = time.perf_counter() - t0
+                best = dt_e if best is None or dt_e < best else best
+            out["end_to_end_GBps"] = hflat.size / best / 1e9
+            out["end_to_end_ms"] = best * 1e3
+            _lib.lib().acx_result_free(res_e2e)
         if world == 1 and args.cpu_sample_reads != 0 and host0:
             sample = host0 if not args.cpu_sample_reads else host0[: args.cpu_sample_reads]
             out["cpu_baseline"] = cpu_baseline(keys, sample, args.mode)

@@ -1009,27 +1009,39 @@ static int scan_host_once(acx_image_t* img, int mode, const uint8_t* hay, const 
     acx_result* r = *result;
     const int64_t total_bytes = off[n_hay];
     int rc;
+    // one pass over the offsets: the shortest haystack (what the stream kernel is promised), and whether they are all
+    // equally long — then the batch is a fixed-stride one: no offsets travel, and the scan takes the faster layout
+    int64_t shortest = INT32_MAX;
+    bool uniform = n_hay > 0;
+    const int64_t L0 = n_hay > 0 ? off[1] - off[0] : 0;
+    for (int64_t h = 0; h < n_hay; h++) {
+        const int64_t l = off[h + 1] - off[h];
+        if (l < shortest) shortest = l;
+        uniform = uniform && l == L0;
+    }
+    const bool as_stride = uniform && L0 > 0 && L0 <= INT32_MAX;
     if ((rc = r->in_hay.ensure((size_t)total_bytes + 64))) return rc;
-    if ((rc = r->in_off.ensure((size_t)n_hay + 1))) return rc;
-    if (total_bytes) HIP_TRY(hipMemcpy(r->in_hay.p, hay, (size_t)total_bytes, hipMemcpyHostToDevice));
-    HIP_TRY(hipMemcpy(r->in_off.p, off, ((size_t)n_hay + 1) * sizeof(int64_t), hipMemcpyHostToDevice));
+    if (total_bytes) HIP_TRY(hipMemcpyAsync(r->in_hay.p, hay, (size_t)total_bytes, hipMemcpyHostToDevice, nullptr));
+    if (!as_stride) {
+        if ((rc = r->in_off.ensure((size_t)n_hay + 1))) return rc;
+        HIP_TRY(hipMemcpyAsync(r->in_off.p, off, ((size_t)n_hay + 1) * sizeof(int64_t), hipMemcpyHostToDevice, nullptr));
+    }
     if (init_state) {
         if ((rc = r->in_init.ensure((size_t)n_hay + 1))) return rc;
-        if (n_hay) HIP_TRY(hipMemcpy(r->in_init.p, init_state, (size_t)n_hay * 4, hipMemcpyHostToDevice));
+        if (n_hay) HIP_TRY(hipMemcpyAsync(r->in_init.p, init_state, (size_t)n_hay * 4, hipMemcpyHostToDevice, nullptr));
     }
     if (index_base) {
         if ((rc = r->in_base.ensure((size_t)n_hay + 1))) return rc;
-        if (n_hay) HIP_TRY(hipMemcpy(r->in_base.p, index_base, (size_t)n_hay * 4, hipMemcpyHostToDevice));
+        if (n_hay) HIP_TRY(hipMemcpyAsync(r->in_base.p, index_base, (size_t)n_hay * 4, hipMemcpyHostToDevice, nullptr));
     }
     acx_scan_params p;
     memset(&p, 0, sizeof p);
     p.struct_bytes = sizeof p; p.mode = mode;
-    p.dev_hay = r->in_hay.p; p.hay_capacity = total_bytes; p.dev_off = r->in_off.p; p.stride = 0; p.n_hay = n_hay;
+    p.dev_hay = r->in_hay.p; p.hay_capacity = total_bytes; p.n_hay = n_hay;
+    if (as_stride) { p.dev_off = nullptr; p.stride = L0; } else { p.dev_off = r->in_off.p; p.stride = 0; }
     p.dev_init_state = init_state ? r->in_init.p : nullptr;
     p.dev_index_base = index_base ? r->in_base.p : nullptr;
     p.want_final_state = want_final;
-    int64_t shortest = INT32_MAX;
-    for (int64_t h = 0; h < n_hay && shortest >= 8; h++) if (off[h + 1] - off[h] < shortest) shortest = off[h + 1] - off[h];
     p.min_hay_len = n_hay > 0 ? (int32_t)shortest : 0;
     return acx_scan_batch(img, &p, result, nullptr);
 }
@@ -1108,9 +1120,11 @@ static int scan_host_impl(acx_image_t* img, int mode, const uint8_t* hay, const 
                           const int32_t* init_state, const int32_t* index_base, acx_result_t** result, int want_final) {
     if (!img || !off || !result || n_hay < 0) return acx_fail(ACX_E_INVAL, "acx_scan_host: bad argument");
     if (off[0] != 0) return acx_fail(ACX_E_INVAL, "acx_scan_host: off[0] must be 0");
-    for (int64_t h = 0; h < n_hay; h++) {
-        if (off[h + 1] < off[h]) return acx_fail(ACX_E_INVAL, "acx_scan_host: offsets not monotone at %lld", (long long)h);
-        if (off[h + 1] - off[h] > INT32_MAX) return acx_fail(ACX_E_INVAL, "acx_scan_host: haystack %lld longer than INT_MAX", (long long)h);
+    {   // (one branch-free pass: a batch of a million reads spends as long here as in its scan kernel otherwise)
+        int64_t lo = 0, hi = 0;
+        for (int64_t h = 0; h < n_hay; h++) { const int64_t l = off[h + 1] - off[h]; lo = l < lo ? l : lo; hi = l > hi ? l : hi; }
+        if (lo < 0) return acx_fail(ACX_E_INVAL, "acx_scan_host: offsets not monotone");
+        if (hi > INT32_MAX) return acx_fail(ACX_E_INVAL, "acx_scan_host: a haystack longer than INT_MAX");
     }
     const int64_t total_bytes = off[n_hay];
     if (total_bytes > 0 && !hay) return acx_fail(ACX_E_INVAL, "acx_scan_host: hay is NULL");
