@@ -178,7 +178,7 @@ static int image_resolve(acx_image* img, const uint32_t* lvl_host) {
     // The blob carries only the sparse form.  An image that has the position-parallel structures builds the dense
     // table on first use by a serial walk (iter_long, carried-in states, final states): 34.8 GB and most of the
     // set-up time for the 1M-signature dictionary, which an ACX_SCAN_ALL-only user never needs.
-    if (img->ppm_g && !getenv("ACX_EAGER_TABLE")) {
+    if (img->ppm_g && !acx_tune_env("ACX_EAGER_TABLE")) {
         if (lvl_host) img->lvl_host.assign(lvl_host, lvl_host + (size_t)img->h.n_levels + 1);
         return ACX_OK;
     }
@@ -586,7 +586,14 @@ static int ppm_enqueue(acx_result* r, acx_image* img, const acx_chunk_args* ca, 
     hipStream_t g = s;                                 // where the rest of this scan is queued
     if (r->ppm_stream) {
         if (r->use_side) {
-            if (!r->side) HIP_TRY(hipStreamCreateWithFlags(&r->side, hipStreamNonBlocking));
+            if (!r->side) {
+                // the lowest priority: the copy fills the CUs that the scan kernels of the caller's stream leave idle, it
+                // must not take a CU before them (a scan block needs a whole CU: LDS and registers)
+                int lo_pri = 0, hi_pri = 0;
+                if (acx_tune_env("ACX_SIDE_DEFAULT_PRIORITY") || hipDeviceGetStreamPriorityRange(&lo_pri, &hi_pri) != hipSuccess || lo_pri == hi_pri)
+                    HIP_TRY(hipStreamCreateWithFlags(&r->side, hipStreamNonBlocking));
+                else HIP_TRY(hipStreamCreateWithPriority(&r->side, hipStreamNonBlocking, lo_pri));
+            }
             if (!r->ev_scan) HIP_TRY(hipEventCreateWithFlags(&r->ev_scan, hipEventDisableTiming));
             HIP_TRY(hipEventRecord(r->ev_scan, s));
             HIP_TRY(hipStreamWaitEvent(r->side, r->ev_scan, 0));
@@ -634,7 +641,7 @@ static uint32_t ppm_halo_pos(const acx_ppm_header& ph) {         // whole words 
 // better (a tile's candidates are worked off before the next one is staged).
 static uint32_t ppm_stream_nsub(const acx_ppm_header& ph, uint32_t halo_pos, bool offs) {
     const uint32_t gw = ph.g_global ? 0u : ph.g_words;
-    static const uint32_t forced = [] { const char* v = getenv("ACX_PPM_NSUB"); const int x = v ? atoi(v) : 0; return (x == 4 || x == 8) ? (uint32_t)x : 0u; }();   // tuning hook
+    static const uint32_t forced = [] { const char* v = acx_tune_env("ACX_PPM_NSUB"); const int x = v ? atoi(v) : 0; return (x == 4 || x == 8) ? (uint32_t)x : 0u; }();   // tuning hook
     // (8-bit symbols with the filter in LDS and no second-level filter: 2048-position tiles measured slower than 1024,
     //  203 vs 218 GB/s — too many candidates per tile for the queue; with the second level: 353 vs 340)
     const uint32_t top = forced ? forced : ((ph.sym_bits == 8 && !ph.g_global && !ph.F2) ? 4u : 8u);
@@ -718,9 +725,9 @@ static int scan_ppm(acx_image_t* img, const acx_scan_params* p, acx_result* r, h
     pa.heads = r->ppm_ctl.p; pa.overflow = (int32_t*)(r->ppm_ctl.p + 8); pa.short_hay = (int32_t*)(r->ppm_ctl.p + 9);
     pa.hay_local = chunked ? nullptr : r->hay_local.p;
     pa.dbg = 0;
-    if (const char* e = getenv("ACX_PPM_DBG")) pa.dbg = (uint32_t)atoi(e);
+    if (const char* e = acx_tune_env("ACX_PPM_DBG")) pa.dbg = (uint32_t)atoi(e);
     static unsigned long long* g_phase = nullptr;
-    if (getenv("ACX_PPM_PHASES")) {
+    if (acx_tune_env("ACX_PPM_PHASES")) {
         if (!g_phase) { if (hipMalloc((void**)&g_phase, 64) != hipSuccess) g_phase = nullptr; }
         if (g_phase) {
             unsigned long long hph[8];
@@ -751,8 +758,8 @@ static int scan_ppm(acx_image_t* img, const acx_scan_params* p, acx_result* r, h
         pa.m24 = (!chunked && p->stride < 2048) ? (uint32_t)(((1u << 23) + (uint32_t)p->stride - 1) / (uint32_t)p->stride) : 0u;
         // An asynchronous scan finishes on a side stream.  Leaving CUs free for that copy while the NEXT batch is
         // scanned did not pay (config 2, 4 / 8 / 16 CUs: 364 / 363 / 355 GB/s against 375 with none): hook only.
-        if ((p->flags & ACX_SCAN_ASYNC) && !getenv("ACX_NO_SIDE_STREAM")) {
-            static const int env_res = [] { const char* v = getenv("ACX_PPM_RESERVE_CUS"); return v ? atoi(v) : 0; }();
+        if ((p->flags & ACX_SCAN_ASYNC) && !acx_tune_env("ACX_NO_SIDE_STREAM")) {
+            static const int env_res = [] { const char* v = acx_tune_env("ACX_PPM_RESERVE_CUS"); return v ? atoi(v) : 0; }();
             pa.reserve_cus = env_res > 0 ? (uint32_t)env_res : 0u;
         }
         const int64_t blocks = acx_ppm_grid_blocks(pa.lds, stream_tiles, pa.reserve_cus);
@@ -805,7 +812,7 @@ static int scan_ppm(acx_image_t* img, const acx_scan_params* p, acx_result* r, h
         wa.final_state = r->final_state.p;
     }
     r->pend_img = img; r->pend_params = *p;
-    r->use_side = (p->flags & ACX_SCAN_ASYNC) != 0 && r->ppm_stream && !getenv("ACX_NO_SIDE_STREAM");
+    r->use_side = (p->flags & ACX_SCAN_ASYNC) != 0 && r->ppm_stream && !acx_tune_env("ACX_NO_SIDE_STREAM");
     if ((rc = ppm_enqueue(r, img, r->ppm_chunk ? &r->pend_cka : nullptr, r->has_final ? &r->pend_tail : nullptr, s))) return rc;
     r->pending = true; r->ppm = true;
     if (p->flags & ACX_SCAN_ASYNC) return ACX_OK;

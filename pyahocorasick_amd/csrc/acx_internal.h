@@ -14,4 +14,18 @@ uint64_t acx_fnv1a64(const uint8_t* p, size_t n);
 int acx_blob_check_header(const acx_blob_header* h, size_t nbytes);
 }
 
+
+/* Tuning hooks (A/B switches, size caps of the builders, launch shapes) exist in builds made with -DACX_TUNING only:
+ * the default library reads ACX_HOST_THREADS, ACX_FLATTEN_TABLE, ACX_FORCE_WIDE_LAYOUT, ACX_NO_ITOP, ACX_NO_PPM,
+ * ACX_MAX_LAUNCH_BYTES (layouts and limits the tests exercise) and the two *_TIMING switches, nothing else. */
+#include <stdlib.h>
+static inline const char* acx_tune_env(const char* name) {
+#ifdef ACX_TUNING
+    return getenv(name);
+#else
+    (void)name;
+    return (const char*)0;
+#endif
+}
+
 #endif

@@ -24,6 +24,7 @@
 // reads, every 64-B sector is consumed completely), so the per-byte VMEM budget goes to
 // the table gathers, which are what bounds the kernel (L2 transaction rate).
 #include "acx_kernels.h"
+#include "acx_internal.h"
 #include <cstdlib>
 #include "acx_blob.h"
 
@@ -1233,7 +1234,7 @@ hipError_t acx_launch_walk_long(const acx_walk_args& a, int variant, hipStream_t
     if (a.n_hay <= 0) return hipSuccess;
     // rows of the shallowest states in LDS (variant bit 21: without, A/B): 76 KiB of them, two 1024-thread blocks per
     // CU; config 5: 0.873 -> 0.774 ms.  Only for batches that fill the chip.
-    static const uint32_t budget_kb = [] { const char* v = getenv("ACX_LONG_TOP_KB"); const int x = v ? atoi(v) : 0; return (x >= 4 && x <= 156) ? (uint32_t)x : 76u; }();   // tuning hook (76: two blocks per CU; 24 .. 150 KiB measured within 4 %)
+    static const uint32_t budget_kb = [] { const char* v = acx_tune_env("ACX_LONG_TOP_KB"); const int x = v ? atoi(v) : 0; return (x >= 4 && x <= 156) ? (uint32_t)x : 76u; }();   // tuning hook (76: two blocks per CU; 24 .. 150 KiB measured within 4 %)
     const uint32_t budget = budget_kb * 1024u;
     uint32_t n_top = a.row_bytes ? budget / a.row_bytes : 0u;
     if (n_top > a.n_states) n_top = a.n_states;
@@ -1347,8 +1348,8 @@ hipError_t acx_launch_walk_itop(const acx_walk_args& a, const acx_chunk_desc* ck
     int bpc_env = 0;
     int threads = ACX_ITOP_BLOCK;
     // occupancy experiments (tools/itop_sweep.sh); read once per process
-    static const int env_bpc = [] { const char* v = getenv("ACX_ITOP_BPC"); const int x = v ? atoi(v) : 0; return x >= 1 && x <= 8 ? x : 0; }();
-    static const int env_threads = [] { const char* v = getenv("ACX_ITOP_THREADS"); const int x = v ? atoi(v) : 0; return (x == 256 || x == 512 || x == 768) ? x : 0; }();
+    static const int env_bpc = [] { const char* v = acx_tune_env("ACX_ITOP_BPC"); const int x = v ? atoi(v) : 0; return x >= 1 && x <= 8 ? x : 0; }();
+    static const int env_threads = [] { const char* v = acx_tune_env("ACX_ITOP_THREADS"); const int x = v ? atoi(v) : 0; return (x == 256 || x == 512 || x == 768) ? x : 0; }();
     bpc_env = env_bpc;
     if (env_threads) threads = env_threads;
     const size_t lds_bytes = (size_t)((itop_words + 3) & ~3u) * 4 + 1024;

@@ -8,6 +8,7 @@
 // first.  A key is a suffix of text[..e] iff the reversed key is a path from the root of the
 // reversed trie along text[e], text[e-1], ...  That walk needs no state from position e-1.
 #include "acx_trie_impl.h"
+#include "acx_internal.h"
 #include "acx_ppm_layout.h"
 
 #include <algorithm>
@@ -169,7 +170,7 @@ int acx_ppm_build(const acx_trie* t, const uint8_t* cls, uint32_t n_classes, boo
         uint8_t symof[256];
         uint32_t sym_arith = 0, sym_lut = 0;
         for (int b = 0; b < 256; b++) symof[b] = (has_other && cls[b] == 0) ? 0xFFu : (uint8_t)(cls[b] - ho);
-        if (sigma == 4 && !getenv("ACX_PPM_NO_ARITH")) {
+        if (sigma == 4 && !acx_tune_env("ACX_PPM_NO_ARITH")) {
             for (uint32_t sh = 0; sh <= 6 && !sym_arith; sh++) {
                 uint32_t seen = 0, lut = 0;
                 for (int b = 0; b < 256; b++) if (symof[b] != 0xFFu) { seen |= 1u << ((b >> sh) & 3); lut |= (uint32_t)b << (8 * ((b >> sh) & 3)); }
@@ -205,7 +206,7 @@ int acx_ppm_build(const acx_trie* t, const uint8_t* cls, uint32_t n_classes, boo
         auto ipow = [&](uint32_t e) -> uint64_t { uint64_t p = 1; for (uint32_t i = 0; i < e; i++) { p *= sigma; if (p > ((uint64_t)1 << 40)) break; } return p; };
         uint32_t C = 0;
         uint32_t cell_bits = 18;                                        // cells: 32 bytes each, at most 2^cell_bits of them
-        if (const char* e = getenv("ACX_PPM_CELL_BITS")) { const int v = atoi(e); if (v >= 4 && v <= 22) cell_bits = (uint32_t)v; }   // tuning hook
+        if (const char* e = acx_tune_env("ACX_PPM_CELL_BITS")) { const int v = atoi(e); if (v >= 4 && v <= 22) cell_bits = (uint32_t)v; }   // tuning hook
         const uint32_t c_cap = h.sym_bits == 2 ? 12u : 16u;            // (the hot cell: eowmask beside the child bits)
         while (C + 1 <= (uint32_t)max_depth && C + 1 <= max_syms && C + 1 <= c_cap && ipow(C + 1) <= ((uint64_t)1 << cell_bits)) C++;
         if (C == 0) return ACX_OK;
@@ -217,10 +218,10 @@ int acx_ppm_build(const acx_trie* t, const uint8_t* cls, uint32_t n_classes, boo
         else if (h.sym_bits == 8 && C + 1 <= (uint32_t)max_depth && C + 1 <= max_syms && ipow(C + 1) <= ((uint64_t)1 << 27)) {
             // one level below the cells does not fit LDS (wide alphabets: 256^3 bits = 2 MB) but it is what tells most
             // positions apart from key ends: keep it in global memory (L2 resident), the stream kernel reads it there
-            const char* gg = getenv("ACX_PPM_GLOBAL_FILTER");
+            const char* gg = acx_tune_env("ACX_PPM_GLOBAL_FILTER");
             if (!(gg && gg[0] == '0')) { F = C + 1; h.g_global = 1; }
         }
-        if (const char* e = getenv("ACX_PPM_MAX_F")) { const uint32_t v = (uint32_t)atoi(e); if (v >= 1 && v < F) { F = v; if (C > F) C = F; } }   // tuning hook
+        if (const char* e = acx_tune_env("ACX_PPM_MAX_F")) { const uint32_t v = (uint32_t)atoi(e); if (v >= 1 && v < F) { F = v; if (C > F) C = F; } }   // tuning hook
         if (!h.g_global && ipow(F) > gbits_cap) return ACX_OK;           // (F == C and even that does not fit: no image)
         h.C = C; h.F = F;
         // Second-level filter: the same question with more symbols, in global memory (L2 resident), asked only for the
@@ -231,7 +232,7 @@ int acx_ppm_build(const acx_trie* t, const uint8_t* cls, uint32_t n_classes, boo
         uint32_t F2 = 0;
         {
             uint32_t g2_bits = 25;
-            const char* e = getenv("ACX_PPM_G2_BITS");                   // tuning hook: 0 none, 10..27 the size cap
+            const char* e = acx_tune_env("ACX_PPM_G2_BITS");                   // tuning hook: 0 none, 10..27 the size cap
             if (e) { const int v = atoi(e); g2_bits = (v >= 10 && v <= 27) ? (uint32_t)v : 0u; }
             // (the kernel extends the code of F = max_syms symbols by older ones: only where the window caps F)
             if (g2_bits && !h.g_global && F == max_syms) {
@@ -314,7 +315,7 @@ int acx_ppm_build(const acx_trie* t, const uint8_t* cls, uint32_t n_classes, boo
         h.n_deep = n_rows; h.n_chain = n_single;
         const uint64_t row_bytes = (uint64_t)(n_rows + 1) * sigma * 16;
         uint64_t cap = (uint64_t)6 << 30;
-        if (const char* e = getenv("ACX_PPM_MAX_DEEP_BYTES")) { const long long v = atoll(e); if (v > 0) cap = (uint64_t)v; }
+        if (const char* e = acx_tune_env("ACX_PPM_MAX_DEEP_BYTES")) { const long long v = atoll(e); if (v > 0) cap = (uint64_t)v; }
         if (row_bytes > cap || n_rows >= 0x7FFFFFFFu || n_single >= 0x7FFFFFFFu) return ACX_OK;
 
         // layout

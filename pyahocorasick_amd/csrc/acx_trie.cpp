@@ -14,6 +14,7 @@
 //     root (the only node that is routinely wide);
 //   * BFS order is recorded by make_automaton and reused as the state numbering.
 #include "acx_trie_impl.h"
+#include "acx_internal.h"
 
 #include <algorithm>
 #include <cstdlib>
@@ -361,7 +362,7 @@ int acx_flatten(const acx_trie_t* t, void** blob_out, size_t* nbytes_out) {
                    itop_b * (itop_D + 2) <= 24 && n + ((size_t)2 << (itop_b * (itop_D + 1))) < ((size_t)1 << ACX_STATE_BITS_NARROW) &&
                    (itop_b * (itop_D + 1) < 5 || itop_cost(itop_D + 1) <= budget_words))
                 itop_D++;
-            if (const char* cap = getenv("ACX_ITOP_MAX_D")) { const int v = atoi(cap); if (v > 0 && (uint32_t)v < itop_D) itop_D = (uint32_t)v; }   // tuning hook
+            if (const char* cap = acx_tune_env("ACX_ITOP_MAX_D")) { const int v = atoi(cap); if (v > 0 && (uint32_t)v < itop_D) itop_D = (uint32_t)v; }   // tuning hook
             if (itop_b * itop_D < 5) itop_D = 0;      // a trie this small does not need it (ND4 needs whole words)
         }
         if (itop_D > 0) {
