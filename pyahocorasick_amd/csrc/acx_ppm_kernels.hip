@@ -489,7 +489,7 @@ __global__ void __launch_bounds__(ACX_PPM_BLOCK) k_ppm_scan(const acx_ppm_args a
 //     streams to their final place.  The exclusive prefix of an entry that is a haystack start IS the record offset
 //     of its haystack.
 // ---------------------------------------------------------------------------------------------------
-#define PPM_QCAP 384u              // queue entries (uint16): 64 x NE, NE = 6 — a round takes them all
+#define PPM_QCAP_MAX 384u          // queue entries (uint16) the LDS layout has room for: 64 x NE, NE <= 6 — a round takes them all
 #define PPM_DESC_WORDS 40u         // per wave: total, n_grants, 16 x base, 16 x count (+ pad)
 #define PPM_MAX_GRANTS 16u
 
@@ -672,7 +672,8 @@ __global__ void __launch_bounds__(ACX_PPM_BLOCK) k_ppm_stream(const acx_ppm_args
     uint32_t g_base = 0, g_size = 0, g_used = 0, ng = 0;               // current grant of the pool
     bool dead = false;                                                 // pool or grant list exhausted: keep counting, stop writing
     uint32_t qcount = 0;
-    static_assert(64 * NE == PPM_QCAP, "a round takes the whole queue");
+    constexpr uint32_t PPM_QCAP = 64u * NE;                            // a round takes the whole queue
+    static_assert(PPM_QCAP <= PPM_QCAP_MAX && PPM_QCAP >= 256u, "a sub-step (256 positions) fits the empty queue");
     const uint32_t Cn = a.C;
     const uint32_t cmask = (1u << Cn) - 1u;                            // (C <= 16)
     const uint32_t longest = a.longest;
@@ -1444,13 +1445,16 @@ hipError_t acx_launch_ppm_scan(const acx_ppm_args& a, int64_t n_items_bound, hip
     };
     if (a.fast) {
         const bool offs = a.off != nullptr, p2 = a.pow2 != 0, ar = a.sym_arith != 0 && a.sym_bits == 2 && p2;
-        constexpr int NE = ACX_PPM_NE;
-#define PPM_S5(SB, N, P2, GG, AR) do { if (offs) return launch(k_ppm_stream<SB, N, P2, true, GG, AR, false, NE>); \
-            if (a.m24) return launch(k_ppm_stream<SB, N, P2, false, GG, AR, true, NE>); return launch(k_ppm_stream<SB, N, P2, false, GG, AR, false, NE>); } while (0)
+        // entries per lane and round: 6 where the filter lets many positions through (2- and 4-bit symbols: short keys over
+        // few letters), 4 with 8-bit symbols (a tile of text or packets holds a few dozen entries; the slot arrays of 6
+        // spilled registers there: 17-24 VGPRs, 80-96 bytes of scratch per lane)
+#define PPM_NE(SB) ((SB) == 8 ? 4 : ACX_PPM_NE)
+#define PPM_S5(SB, N, P2, GG, AR) do { if (offs) return launch(k_ppm_stream<SB, N, P2, true, GG, AR, false, PPM_NE(SB)>); \
+            if (a.m24) return launch(k_ppm_stream<SB, N, P2, false, GG, AR, true, PPM_NE(SB)>); return launch(k_ppm_stream<SB, N, P2, false, GG, AR, false, PPM_NE(SB)>); } while (0)
 #define PPM_S(SB, N, GG) do { if (p2) PPM_S5(SB, N, true, GG, false); PPM_S5(SB, N, false, GG, false); } while (0)
         if (a.nsub != 8 && a.nsub != 4) return hipErrorInvalidValue;
 #ifdef ACX_PPM_DEV      /* development builds: the config-2 kernel only (compile time) */
-        if (a.sym_bits == 2 && a.nsub == 8 && ar && !offs && a.m24) return launch(k_ppm_stream<2, 8, true, false, false, true, true, NE>);
+        if (a.sym_bits == 2 && a.nsub == 8 && ar && !offs && a.m24) return launch(k_ppm_stream<2, 8, true, false, false, true, true, ACX_PPM_NE>);
         return hipErrorInvalidValue;
 #else
         if (a.sym_bits == 8) {
@@ -1464,6 +1468,7 @@ hipError_t acx_launch_ppm_scan(const acx_ppm_args& a, int64_t n_items_bound, hip
 #endif
 #undef PPM_S
 #undef PPM_S5
+#undef PPM_NE
     }
 #define PPM_CASE(SB) \
     do { \
