@@ -69,7 +69,7 @@ int build_trie(const std::vector<RawNode>& raw, bool values_by_position, int64_t
         std::vector<uint8_t> linked(n, 0);
         for (size_t k = 0; k < n; k++) {
             Node& nd = t->nodes[k];
-            nd.value = 0; nd.first_child = -1; nd.next_sibling = -1; nd.fail = -1; nd.letter = 0; nd.eow = raw[k].eow ? 1 : 0; nd.pad = 0;
+            nd.value = 0; nd.first_child = -1; nd.next_sibling = -1; nd.fail = -1; nd.letter = 0; nd.eow = raw[k].eow ? 1 : 0; nd.wide = 0;
         }
         depth[0] = 0;
         int64_t eow_seen = 0, longest = 0;

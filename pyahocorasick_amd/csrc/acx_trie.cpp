@@ -41,6 +41,7 @@ void acx_trie_clear(acx_trie_t* t) {
     if (!t) return;
     // automaton_clear, src/Automaton.c:405-416
     t->nodes.clear(); t->nodes.shrink_to_fit();
+    t->wide_index.clear();
     t->bfs.clear(); t->bfs.shrink_to_fit();
     t->level_first.clear();
     for (auto& c : t->root_child) c = -1;
