@@ -463,7 +463,7 @@ def main():
             best = None
             for _ in range(4):
                 t0 = time.perf_counter()
-                _lib.check(_lib.lib().acx_scan_host_ctx(image.handle, hflat.ctypes.data, hoff.ctypes.data, len(hoff) - 1, None, None, None, C.byref(res_e2e)))
+                _lib.check(_lib.lib().acx_scan_host_ctx(image.handle, hflat.ctypes.data, hoff.ctypes.data, len(hoff) - 1, None, None, None, 0, C.byref(res_e2e)))
                 p1, p2, p3 = C.c_void_p(), C.c_void_p(), C.c_void_p()
                 _lib.check(_lib.lib().acx_result_fetch_host(res_e2e, C.byref(p1), C.byref(p2), C.byref(p3)))
                 dt_e = time.perf_counter() - t0

@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define ACX_ABI_VERSION 3          /* 3: acx_scan_params.dev_skip, acx_scan_host_ctx, acx_trie_add_words */
+#define ACX_ABI_VERSION 3          /* 3: acx_scan_params.dev_skip, acx_scan_host_ctx, acx_trie_add_words, ACX_SCAN_SKIP_WS */
 
 typedef enum acx_status {
     ACX_OK            =  0,
@@ -235,7 +235,7 @@ typedef struct acx_scan_params {
     int32_t  timing;           /* 1 => record HIP events around each kernel; 2 => around the walk only
                                   (an event between two kernels costs a few microseconds of idle GPU) */
     int32_t  variant;          /* 0 = default; >0 selects an alternative kernel (bench/tuning) */
-    int32_t  flags;            /* ACX_SCAN_ASYNC or 0 */
+    int32_t  flags;            /* ACX_SCAN_ASYNC | ACX_SCAN_SKIP_WS or 0 */
     int32_t  min_hay_len;      /* offsets batches: a lower bound on the haystack lengths that the caller vouches for
                                   (0 = unknown).  With >= 8 the position-parallel stream kernel takes the batch (it
                                   keeps room for one haystack start per eight positions of a tile).  A batch that breaks
@@ -261,7 +261,14 @@ typedef struct acx_scan_params {
  * An asynchronous scan is complete when acx_result_wait (or an accessor) returns — NOT when `stream` has
  * drained: the library queues the final copy of the records on a stream of the result's own, so that it
  * overlaps the next scan kernel that the caller queues on `stream`. */
-enum { ACX_SCAN_ASYNC = 1 };
+enum { ACX_SCAN_ASYNC = 1,
+/* White space never touches the automaton: AutomatonSearchIter with ignore_white_space=True steps over every letter
+ * that iswspace() accepts without changing its state, and reports end indices of the original string
+ * (src/AutomatonSearchIter.c:269-274).  Over the letters of a bytes build that is 0x09..0x0D and 0x20.  On the device:
+ * the batch is compacted (white space out, the original position of every kept byte remembered), the compacted batch is
+ * scanned by the same kernels as any other batch, and the end indices of the records are mapped back — end_index,
+ * dev_skip and dev_index_base all count bytes of the batch as the caller gave it.  Batches below 4 GiB. */
+       ACX_SCAN_SKIP_WS = 2 };
 
 typedef struct acx_result acx_result_t;
 
@@ -307,6 +314,7 @@ int  acx_scan_host(acx_image_t* img, int mode, const uint8_t* hay, const int64_t
  * longest_word - 1 bytes of context + chunk). */
 int  acx_scan_host_ctx(acx_image_t* img, const uint8_t* hay, const int64_t* off, int64_t n_hay,
                        const uint8_t* ctx, const int64_t* ctx_off, const int32_t* index_base,
+                       int32_t flags /* ACX_SCAN_SKIP_WS or 0: iter(..., ignore_white_space=True) */,
                        acx_result_t** result);
 
 /* device helpers used by bindings that have no HIP runtime of their own */

@@ -15,6 +15,7 @@ ACX_E_INVAL, ACX_E_NOMEM, ACX_E_STATE, ACX_E_HIP = -1, -2, -3, -4
 ACX_E_UNSUPPORTED, ACX_E_FORMAT, ACX_E_NODEVICE = -5, -6, -7
 ACX_SCAN_ALL, ACX_SCAN_LONG = 0, 1
 ACX_SCAN_ASYNC = 1
+ACX_SCAN_SKIP_WS = 2        # white space (0x09..0x0D, 0x20) never touches the automaton; indices stay those of the original bytes
 ACX_BLOB_HEADER_BYTES = 256
 
 
@@ -103,7 +104,7 @@ SIGNATURES = {
     "acx_result_timing": (C.c_int, [_P] + [C.POINTER(C.c_float)] * 4),
     "acx_result_free": (None, [_P]),
     "acx_scan_host": (C.c_int, [_P, C.c_int, _P, _P, C.c_int64, _P, _P, _PP]),
-    "acx_scan_host_ctx": (C.c_int, [_P, _P, _P, C.c_int64, _P, _P, _P, _PP]),
+    "acx_scan_host_ctx": (C.c_int, [_P, _P, _P, C.c_int64, _P, _P, _P, C.c_int32, _PP]),
     "acx_device_count": (C.c_int, [C.POINTER(C.c_int)]),
     "acx_device_set": (C.c_int, [C.c_int]),
     "acx_dev_malloc": (C.c_int, [_PP, C.c_size_t]),

@@ -23,7 +23,7 @@ import threading
 import numpy as np
 
 from . import _lib
-from ._lib import ACX_SCAN_ALL, ACX_SCAN_LONG, AcxError, lib, check
+from ._lib import ACX_SCAN_ALL, ACX_SCAN_LONG, ACX_SCAN_SKIP_WS, AcxError, lib, check
 
 # constants of the reference module, src/pyahocorasick.c:113-134, src/Automaton.h:16-41
 EMPTY, TRIE, AHOCORASICK = 0, 1, 2
@@ -432,13 +432,15 @@ class Automaton:
             f.write(self.flat_image_bytes())
 
     # ---- batch scan (NEW: the reference scans one haystack per iterator) ---------------
-    def scan_batch(self, data, offsets, mode=ACX_SCAN_ALL, init_state=None, index_base=None, context=None):
+    def scan_batch(self, data, offsets, mode=ACX_SCAN_ALL, init_state=None, index_base=None, context=None, skip_white_space=False):
         """Scan haystacks data[offsets[k]:offsets[k+1]] on the GPU; returns a BatchResult.
 
         data: bytes-like; offsets: int64[n+1] with offsets[0] == 0.
         context (ACX_SCAN_ALL): (bytes-like, int64[n+1]) — the bytes a stream delivered in front of every haystack
         (the last longest_word - 1 matter): matches may begin in there, none that ends in there is reported
         (acx_scan_host_ctx); this is how iter().set() continues without a state.
+        skip_white_space (ACX_SCAN_ALL): iter(..., ignore_white_space=True) for the whole batch — the device takes the
+        white space out before the scan and maps the end indices back (ACX_SCAN_SKIP_WS).
         """
         if self.kind != AHOCORASICK:
             raise AttributeError("Not an Aho-Corasick automaton yet: call add_word to add some keys and call "
@@ -455,7 +457,11 @@ class Automaton:
         # ctypes drops the GIL inside every libacx call, and the image and the result buffers belong to this
         # Automaton: one scan (image refresh, kernels, fetch) at a time per object.  The reference holds the
         # GIL for the whole of every call, so sharing an automaton between threads is safe there too.
+        if skip_white_space and (mode != ACX_SCAN_ALL or init is not None):
+            raise ValueError("skip_white_space is for ACX_SCAN_ALL without carried states")
         ctx = None
+        if context is None and skip_white_space:
+            context = (b"", np.zeros(n + 1, dtype=np.int64))
         if context is not None:
             if mode != ACX_SCAN_ALL or init is not None:
                 raise ValueError("context is for ACX_SCAN_ALL without carried states")
@@ -465,14 +471,14 @@ class Automaton:
                 raise ValueError("bad context offsets")
             ctx = (cbuf, coff)
         with self._lock:
-            return self._scan_locked(buf, off, n, mode, init, base, ctx)
+            return self._scan_locked(buf, off, n, mode, init, base, ctx, ACX_SCAN_SKIP_WS if skip_white_space else 0)
 
-    def _scan_locked(self, buf, off, n, mode, init, base, ctx=None):
+    def _scan_locked(self, buf, off, n, mode, init, base, ctx=None, flags=0):
         img = self._ensure_image()
         if ctx is not None:
             check(lib().acx_scan_host_ctx(img.handle, buf.ctypes.data if buf.size else None, off.ctypes.data, n,
                                           ctx[0].ctypes.data if ctx[0].size else C.c_void_p(1), ctx[1].ctypes.data,
-                                          base.ctypes.data if base is not None else None, C.byref(self._result)))
+                                          base.ctypes.data if base is not None else None, flags, C.byref(self._result)))
         else:
             check(lib().acx_scan_host(img.handle, mode, buf.ctypes.data if buf.size else None, off.ctypes.data, n,
                                       init.ctypes.data if init is not None else None,
@@ -663,17 +669,16 @@ class AutomatonSearchIter:
         return t[len(t) - keep:] if keep and len(t) > keep else (t if keep else b"")
 
     def _scan(self, string, start, end, state, shift):
-        chunk, remap = self._letters(string, start, end)
+        chunk = string[start:end]
         if self._long:
             res = self._a.scan_batch(chunk, [0, len(chunk)], ACX_SCAN_LONG, init_state=[state] if state else None,
-                                     index_base=[0 if remap is not None else start + shift])
+                                     index_base=[start + shift])
         else:
             # iter continues a stream from the bytes before it, not from a state: every match that ends in this chunk
-            # depends on the previous longest_word - 1 letters at most (the position-parallel kernels take it)
+            # depends on the previous longest_word - 1 letters at most (the position-parallel kernels take it).
+            # ignore_white_space: the device skips the white space and reports indices of the original bytes.
             res = self._a.scan_batch(chunk, [0, len(chunk)], ACX_SCAN_ALL, context=(self._ctx, [0, len(self._ctx)]),
-                                     index_base=[0 if remap is not None else start + shift])
-        if remap is not None and res.num_matches():
-            res.end_index = (remap[res.end_index] + (start + shift)).astype(np.int32)
+                                     index_base=[start + shift], skip_white_space=self._ws)
         return res.tolists()[0], (int(res.final_state[0]) if res.final_state is not None else 0)
 
     def _load(self, string, start, end):

@@ -390,10 +390,13 @@ struct acx_result {
     acx_ppm_args pend_pa; acx_ppm_compact_args pend_ca; int64_t pend_items = 0;
     const int32_t* pend_counts = nullptr; int64_t* pend_item_off = nullptr;
     acx_chunk_args pend_cka; acx_walk_args pend_tail; bool ppm_chunk = false, ppm_tail = false;
-    bool ppm_stream = false; acx_ppm_gather_args pend_ga; DevBuf<uint32_t> wave_desc;
+    bool ppm_stream = false; acx_ppm_gather_args pend_ga; DevBuf<uint32_t> wave_desc, wave_aux;
     // ACX_SCAN_ASYNC scans: the gather (memory bound) runs on a stream of the result's own, so that the next
     // scan kernel (instruction bound) of another result on the caller's stream overlaps it
     bool use_side = false; hipStream_t side = nullptr; hipEvent_t ev_scan = nullptr;
+    bool ctl_zero = false;      // ppm_ctl is known to be all zero (the gather of the last fixed-stride stream scan cleaned up)
+    bool ppm_self = false;      // the pending stream scan is a fixed-stride one: block sums, totals and clean-up in k_ppm_gather_pos
+    int bs_parity = 0;          // which half of wave_aux the next such scan sums into
     acx_image* pend_img = nullptr;
     acx_scan_params pend_params;                // the scan as it was asked for (a stream scan that must be issued again)
     PinBuf<int64_t> h_off;
@@ -406,6 +409,10 @@ struct acx_result {
     // dev_skip on the kernel families that do not know it: the context's records are dropped after the scan
     const int32_t* skip_after = nullptr; const int32_t* skip_base = nullptr;
     DevBuf<int32_t> skip_kept; DevBuf<int64_t> skip_off; DevBuf<uint2> matches2;
+    // ACX_SCAN_SKIP_WS: the compacted batch that was scanned, and the batch as the caller gave it (for the way back)
+    bool ws_active = false;
+    DevBuf<uint8_t> ws_hay; DevBuf<uint32_t> ws_map; DevBuf<int32_t> ws_cnt, ws_skip; DevBuf<int64_t> ws_tile_off, ws_off, ws_partials;
+    const int64_t* ws_o_off = nullptr; int64_t ws_o_stride = 0; const int32_t* ws_o_skip = nullptr; const int32_t* ws_o_base = nullptr;
     int64_t n_hay = 0;
     int64_t total = 0;
     bool has_final = false;
@@ -425,10 +432,11 @@ struct acx_result {
         if (pending) (void)hipStreamSynchronize(stream);
         counts.release(); nev.release(); final_state.release(); match_off.release(); partials.release();
         nck.release(); ck_first.release(); ck_match_off.release(); ck.release();
-        scratch.release(); scr_off.release(); ppm_ctl.release(); hay_local.release(); wave_desc.release();
+        scratch.release(); scr_off.release(); ppm_ctl.release(); hay_local.release(); wave_desc.release(); wave_aux.release();
         events.release(); matches.release(); h_off.release(); h_matches.release(); h_final.release(); h_total.release();
         in_hay.release(); in_off.release(); in_init.release(); in_base.release(); in_skip.release(); h_stage.release();
         skip_kept.release(); skip_off.release(); matches2.release();
+        ws_hay.release(); ws_map.release(); ws_cnt.release(); ws_skip.release(); ws_tile_off.release(); ws_off.release(); ws_partials.release();
         for (auto& e : ev) if (e) (void)hipEventDestroy(e);
         if (done) (void)hipEventDestroy(done);
         if (ev_scan) (void)hipEventDestroy(ev_scan);
@@ -438,6 +446,7 @@ struct acx_result {
 
 static int ppm_enqueue(acx_result* r, acx_image* img, const acx_chunk_args* ca, const acx_walk_args* tail, hipStream_t s);
 static int ppm_size_pool(acx_result* r, size_t records);
+static int scan_batch_inner(acx_image_t* img, const acx_scan_params* p, acx_result_t** result, void* stream_v);
 
 // dev_skip after a scan on kernels that do not know it (the serial walks, k_ppm_scan): drop the records of every
 // haystack's context (a prefix of its records) and rebase the rest; the result's buffers are swapped for the new ones
@@ -464,6 +473,26 @@ static int skip_compact(acx_result* r) {
     return ACX_OK;
 }
 
+// ACX_SCAN_SKIP_WS, last step of a scan: the records hold end indices of the compacted batch; send them back to the
+// positions of the batch the caller gave (context off, the caller's base on)
+static int ws_remap(acx_result* r) {
+    if (!r->ws_active) return ACX_OK;
+    r->ws_active = false;
+    if (r->total <= 0) return ACX_OK;
+    acx_ws_remap_args a;
+    a.matches = r->matches.p; a.match_off = r->match_off.p; a.n_hay = r->n_hay; a.total = r->total;
+    a.off = r->ws_o_off; a.stride = r->ws_o_stride; a.skip = r->ws_o_skip; a.index_base = r->ws_o_base;
+    a.c_off = r->ws_off.p; a.c_skip = r->ws_o_skip ? r->ws_skip.p : nullptr; a.map = r->ws_map.p;
+    HIP_TRY(acx_launch_ws_remap(a, r->stream));
+    HIP_TRY(hipStreamSynchronize(r->stream));
+    return ACX_OK;
+}
+
+static int finish_records(acx_result* r) {
+    const int rc = skip_compact(r);
+    return rc ? rc : ws_remap(r);
+}
+
 // position-parallel scan: the record pool ran out (grow it and scan again) or the match buffer
 // is too small (grow it and copy again: the pool is intact)
 static int ppm_complete(acx_result* r) {
@@ -477,7 +506,7 @@ static int ppm_complete(acx_result* r) {
             acx_scan_params p = r->pend_params;
             p.min_hay_len = 0; p.flags &= ~(int32_t)ACX_SCAN_ASYNC;
             acx_result* self = r;
-            return acx_scan_batch(r->pend_img, &p, &self, (void*)s);
+            return scan_batch_inner(r->pend_img, &p, &self, (void*)s);
         }
         r->total = r->h_total.p[0];
         const bool overflow = (int32_t)r->h_total.p[1] != 0;
@@ -510,7 +539,7 @@ static int ppm_complete(acx_result* r) {
             HIP_TRY(hipEventElapsedTime(&r->t_total, r->ev[0], r->ev[3]));
         }
     }
-    return skip_compact(r);
+    return finish_records(r);
 }
 
 // Finish a scan whose kernels are queued: wait, read the total, and if the speculative expand did
@@ -547,7 +576,7 @@ static int result_complete(acx_result* r) {
             r->t_total = r->t_walk + r->t_scan + r->t_expand;
         }
     }
-    return skip_compact(r);
+    return finish_records(r);
 }
 
 extern "C" int acx_result_wait(acx_result_t* r) {
@@ -571,7 +600,16 @@ static const int64_t ACX_MAX_LAUNCH_BYTES = (int64_t)4 << 30;   // event staging
 static int ppm_enqueue(acx_result* r, acx_image* img, const acx_chunk_args* ca, const acx_walk_args* tail, hipStream_t s) {
     const acx_ppm_args& pa = r->pend_pa;
     const int64_t ni = r->pend_items;
-    HIP_TRY(hipMemsetAsync(r->ppm_ctl.p, 0, 16 * sizeof(unsigned long long), s));
+    // (a stream scan leaves the control words zeroed behind it: only the first one, and one after another kernel family, clears them)
+    const bool self = r->ppm_stream && r->ppm_self;
+    if (!(self && r->ctl_zero)) HIP_TRY(hipMemsetAsync(r->ppm_ctl.p, 0, 16 * sizeof(unsigned long long), s));
+    r->ctl_zero = self;
+    if (self) {                                         // this scan's block sums (zeroed by the gather of the scan before), the next scan's
+        r->pend_pa.block_sum = r->wave_aux.p + (size_t)r->bs_parity * ACX_PPM_MAX_BLOCKS;
+        r->pend_ga.block_sum = r->pend_pa.block_sum;
+        r->bs_parity ^= 1;
+        r->pend_ga.block_sum_next = r->wave_aux.p + (size_t)r->bs_parity * ACX_PPM_MAX_BLOCKS;
+    }
     if (ca) {
         HIP_TRY(hipMemsetAsync(r->counts.p, 0, ((size_t)ni + 1) * sizeof(int32_t), s));   // tiles beyond the real chunk count read as empty
         HIP_TRY(acx_launch_chunk_count(*ca, s));
@@ -600,7 +638,7 @@ static int ppm_enqueue(acx_result* r, acx_image* img, const acx_chunk_args* ca, 
             g = r->side;
         }
         if (r->timed_all) HIP_TRY(hipEventRecord(r->ev[2], g));
-        HIP_TRY(acx_launch_ppm_gather(pa.wave_desc, r->pend_ga.n_waves, r->pend_item_off, r->pend_ga, g));
+        HIP_TRY(acx_launch_ppm_gather(r->pend_pa.wave_desc, r->pend_ga.n_waves, r->pend_item_off, r->pend_ga, g));
     } else {
         HIP_TRY(acx_launch_scan(r->pend_counts, ni, r->pend_item_off, r->partials.p, s));
         if (r->timed_all) HIP_TRY(hipEventRecord(r->ev[2], s));
@@ -609,9 +647,11 @@ static int ppm_enqueue(acx_result* r, acx_image* img, const acx_chunk_args* ca, 
     }
     if (r->timed_all) HIP_TRY(hipEventRecord(r->ev[3], g));
     r->h_total.p[1] = 0; r->h_total.p[2] = 0;
-    HIP_TRY(hipMemcpyAsync(r->h_total.p, r->pend_item_off + (r->ppm_stream ? r->pend_ga.n_waves : ni), sizeof(int64_t), hipMemcpyDeviceToHost, g));
-    HIP_TRY(hipMemcpyAsync(r->h_total.p + 1, r->ppm_ctl.p + 8, sizeof(int32_t), hipMemcpyDeviceToHost, g));
-    HIP_TRY(hipMemcpyAsync(r->h_total.p + 2, r->ppm_ctl.p + 9, sizeof(int32_t), hipMemcpyDeviceToHost, g));
+    if (!self) {                                        // (k_ppm_gather_pos writes total and flags into h_total itself)
+        HIP_TRY(hipMemcpyAsync(r->h_total.p, r->pend_item_off + (r->ppm_stream ? r->pend_ga.n_waves : ni), sizeof(int64_t), hipMemcpyDeviceToHost, g));
+        HIP_TRY(hipMemcpyAsync(r->h_total.p + 1, r->ppm_ctl.p + 8, sizeof(int32_t), hipMemcpyDeviceToHost, g));
+        HIP_TRY(hipMemcpyAsync(r->h_total.p + 2, r->ppm_ctl.p + 9, sizeof(int32_t), hipMemcpyDeviceToHost, g));
+    }
     if (!r->done) HIP_TRY(hipEventCreateWithFlags(&r->done, hipEventDisableTiming));
     HIP_TRY(hipEventRecord(r->done, g));
     return ACX_OK;
@@ -677,6 +717,13 @@ static int ppm_plan(const acx_image* img, const acx_scan_params* p) {
 
 extern "C" int acx_scan_plan(const acx_image_t* img, const acx_scan_params* p) {
     if (!img || !p || p->struct_bytes != sizeof(acx_scan_params)) return -1;
+    if (p->flags & ACX_SCAN_SKIP_WS) {                      // what scan_batch_ws hands to the kernels: offsets, aligned, a promise of 8 at most
+        acx_scan_params q = *p;
+        q.dev_hay = nullptr; q.hay_capacity = p->dev_off ? p->hay_capacity : p->n_hay * p->stride;
+        q.dev_off = (const int64_t*)(uintptr_t)8; q.stride = 0;
+        q.min_hay_len = (p->dev_off ? p->min_hay_len : (int32_t)(p->stride > INT32_MAX ? INT32_MAX : p->stride)) >= 8 ? 8 : 0;
+        return ppm_plan(img, &q);
+    }
     return ppm_plan(img, p);
 }
 
@@ -768,6 +815,18 @@ static int scan_ppm(acx_image_t* img, const acx_scan_params* p, acx_result* r, h
         if ((rc = r->ck_match_off.ensure((size_t)n_waves + 1))) return rc;
         if ((rc = r->hay_local.ensure(n + 1))) return rc;
         pa.wave_desc = r->wave_desc.p;
+        pa.block_sum = nullptr;
+        if (!chunked) {
+            // fixed stride: block sums instead of a prefix-sum launch, totals and clean-up by k_ppm_gather_pos (acx_kernels.h);
+            // two sets of sums: the gather of one scan zeroes the set of the result's next scan
+            if (blocks > ACX_PPM_MAX_BLOCKS) return acx_fail(ACX_E_UNSUPPORTED, "position-parallel scan: %lld blocks", (long long)blocks);
+            if (r->wave_aux.cap < 2 * ACX_PPM_MAX_BLOCKS) {
+                if ((rc = r->wave_aux.ensure(2 * ACX_PPM_MAX_BLOCKS))) return rc;
+                HIP_TRY(hipMemset(r->wave_aux.p, 0, 2 * ACX_PPM_MAX_BLOCKS * sizeof(uint32_t)));
+                r->bs_parity = 0;
+            }
+            if ((rc = r->h_total.ensure(4))) return rc;
+        }
         pa.hay_local = r->hay_local.p;
         pa.n_items = stream_tiles;
         pa.ck = nullptr; pa.n_items_dev = nullptr;
@@ -784,6 +843,12 @@ static int scan_ppm(acx_image_t* img, const acx_scan_params* p, acx_result* r, h
         ga.off = chunked ? p->dev_off : nullptr;
         ga.tile_pos = tpos; ga.tpw = (stream_tiles + n_waves - 1) / n_waves;
         ga.stride_magic = pa.stride_magic; ga.index_base = chunked ? nullptr : p->dev_index_base; ga.skip = chunked ? nullptr : p->dev_skip;
+        if (!chunked) {
+            void* dp = nullptr;
+            HIP_TRY(hipHostGetDevicePointer(&dp, r->h_total.p, 0));
+            ga.host_words = (long long*)dp; ga.ctl = r->ppm_ctl.p;
+        }
+        r->ppm_self = !chunked;
     }
 
     acx_ppm_compact_args& ca = r->pend_ca;            // (the general kernel: per-tile counts, scan, compact)
@@ -819,7 +884,7 @@ static int scan_ppm(acx_image_t* img, const acx_scan_params* p, acx_result* r, h
     return result_complete(r);
 }
 
-extern "C" int acx_scan_batch(acx_image_t* img, const acx_scan_params* p, acx_result_t** result, void* stream_v) {
+static int scan_batch_inner(acx_image_t* img, const acx_scan_params* p, acx_result_t** result, void* stream_v) {
     if (!img || !p || !result) return acx_fail(ACX_E_INVAL, "acx_scan_batch: NULL argument");
     if (p->struct_bytes != sizeof(acx_scan_params))
         return acx_fail(ACX_E_INVAL, "acx_scan_batch: params.struct_bytes = %u, library expects %zu", p->struct_bytes, sizeof(acx_scan_params));
@@ -967,6 +1032,63 @@ extern "C" int acx_scan_batch(acx_image_t* img, const acx_scan_params* p, acx_re
     return result_complete(r);
 }
 
+// ACX_SCAN_SKIP_WS: compact the batch (acx_ws.hip), scan the compacted one, map the records back when the scan completes
+static int scan_batch_ws(acx_image_t* img, const acx_scan_params* p, acx_result* r, hipStream_t s) {
+    const int64_t total = p->dev_off ? p->hay_capacity : p->n_hay * p->stride;
+    if (!p->dev_off && (p->stride < 0 || p->n_hay * p->stride > p->hay_capacity)) return acx_fail(ACX_E_INVAL, "acx_scan_batch: n_hay*stride exceeds hay_capacity");
+    if (total > 0xFFFFFFFFll) return acx_fail(ACX_E_UNSUPPORTED, "acx_scan_batch: ACX_SCAN_SKIP_WS takes batches below 4 GiB");
+    if (total > 0 && !p->dev_hay) return acx_fail(ACX_E_INVAL, "acx_scan_batch: dev_hay is NULL");
+    const size_t n = (size_t)p->n_hay;
+    const int64_t nt = acx_ws_num_tiles(total);
+    int rc;
+    if ((rc = r->ws_hay.ensure((size_t)total + 64))) return rc;
+    if ((rc = r->ws_map.ensure((size_t)total + 1))) return rc;
+    if ((rc = r->ws_cnt.ensure((size_t)nt + 1))) return rc;
+    if ((rc = r->ws_tile_off.ensure((size_t)nt + 2))) return rc;
+    if ((rc = r->ws_partials.ensure((size_t)acx_scan_num_partials(nt) + 2))) return rc;
+    if ((rc = r->ws_off.ensure(n + 2))) return rc;
+    if (p->dev_skip && (rc = r->ws_skip.ensure(n + 1))) return rc;
+    if (nt > 0) {
+        HIP_TRY(acx_launch_ws_count(p->dev_hay, total, r->ws_cnt.p, s));
+        HIP_TRY(acx_launch_scan(r->ws_cnt.p, nt, r->ws_tile_off.p, r->ws_partials.p, s));
+        HIP_TRY(acx_launch_ws_move(p->dev_hay, total, r->ws_tile_off.p, r->ws_hay.p, r->ws_map.p, s));
+    } else HIP_TRY(hipMemsetAsync(r->ws_tile_off.p, 0, sizeof(int64_t), s));
+    HIP_TRY(acx_launch_ws_offsets(p->dev_off, p->stride, p->n_hay, p->dev_skip, r->ws_map.p, r->ws_tile_off.p + nt, r->ws_off.p,
+                                  p->dev_skip ? r->ws_skip.p : nullptr, s));
+    r->ws_o_off = p->dev_off; r->ws_o_stride = p->stride; r->ws_o_skip = p->dev_skip; r->ws_o_base = p->dev_index_base;
+    acx_scan_params q = *p;
+    q.flags &= ~(int32_t)ACX_SCAN_SKIP_WS;
+    q.dev_hay = r->ws_hay.p; q.hay_capacity = total; q.dev_off = r->ws_off.p; q.stride = 0;
+    q.dev_index_base = nullptr; q.dev_skip = p->dev_skip ? r->ws_skip.p : nullptr;
+    // what is left of a haystack may be shorter than what the caller promised for the whole of it; the stream kernel
+    // notices a broken promise and the batch is scanned again on the general kernels (acx.h), so the promise stays
+    q.min_hay_len = (p->dev_off ? p->min_hay_len : (p->stride > INT32_MAX ? INT32_MAX : (int32_t)p->stride)) >= 8 ? 8 : 0;
+    r->ws_active = true;
+    acx_result* self = r;
+    rc = scan_batch_inner(img, &q, &self, (void*)s);
+    if (rc) r->ws_active = false;
+    return rc;
+}
+
+extern "C" int acx_scan_batch(acx_image_t* img, const acx_scan_params* p, acx_result_t** result, void* stream_v) {
+    if (!img || !p || !result) return acx_fail(ACX_E_INVAL, "acx_scan_batch: NULL argument");
+    if (p->struct_bytes != sizeof(acx_scan_params))
+        return acx_fail(ACX_E_INVAL, "acx_scan_batch: params.struct_bytes = %u, library expects %zu", p->struct_bytes, sizeof(acx_scan_params));
+    if (*result && (*result)->pending) { int rcw = result_complete(*result); if (rcw) return rcw; }     // still in flight on its old stream
+    if (*result) (*result)->ws_active = false;
+    if (!(p->flags & ACX_SCAN_SKIP_WS) || p->n_hay <= 0) return scan_batch_inner(img, p, result, stream_v);
+    if (p->n_hay < 0 || p->hay_capacity < 0) return acx_fail(ACX_E_INVAL, "acx_scan_batch: negative size");
+    if (p->hay_capacity > ACX_MAX_LAUNCH_BYTES)
+        return acx_fail(ACX_E_UNSUPPORTED, "acx_scan_batch: %lld haystack bytes in one call; split the batch into calls of <= %lld bytes",
+                        (long long)p->hay_capacity, (long long)ACX_MAX_LAUNCH_BYTES);
+    if (!*result) {
+        *result = new (std::nothrow) acx_result();
+        if (!*result) return acx_fail(ACX_E_NOMEM, "acx_scan_batch: out of memory");
+    }
+    (*result)->stream = (hipStream_t)stream_v;
+    return scan_batch_ws(img, p, *result, (hipStream_t)stream_v);
+}
+
 extern "C" int64_t acx_result_num_matches(acx_result_t* r) { return (r && result_complete(r) == ACX_OK) ? r->total : 0; }
 extern "C" const int64_t* acx_result_offsets_dev(acx_result_t* r) { return (r && result_complete(r) == ACX_OK) ? r->match_off.p : nullptr; }
 extern "C" const acx_match_t* acx_result_matches_dev(acx_result_t* r) {
@@ -1012,7 +1134,7 @@ extern "C" int acx_result_timing(acx_result_t* r, float* walk_ms, float* scan_ms
 
 // one group of haystacks that fits a launch: H2D, scan; `off` starts at 0
 static int scan_host_once(acx_image_t* img, int mode, const uint8_t* hay, const int64_t* off, int64_t n_hay,
-                          const int32_t* init_state, const int32_t* index_base, acx_result_t** result, int want_final) {
+                          const int32_t* init_state, const int32_t* index_base, acx_result_t** result, int want_final, int32_t flags) {
     acx_result* r = *result;
     const int64_t total_bytes = off[n_hay];
     int rc;
@@ -1050,17 +1172,20 @@ static int scan_host_once(acx_image_t* img, int mode, const uint8_t* hay, const 
     p.dev_index_base = index_base ? r->in_base.p : nullptr;
     p.want_final_state = want_final;
     p.min_hay_len = n_hay > 0 ? (int32_t)shortest : 0;
+    p.flags = flags;
     return acx_scan_batch(img, &p, result, nullptr);
 }
 
 static int scan_host_impl(acx_image_t* img, int mode, const uint8_t* hay, const int64_t* off, int64_t n_hay,
-                          const int32_t* init_state, const int32_t* index_base, acx_result_t** result, int want_final);
+                          const int32_t* init_state, const int32_t* index_base, acx_result_t** result, int want_final, int32_t flags);
 
 // streams: context and chunk of every haystack staged side by side; the context's records are never reported
 extern "C" int acx_scan_host_ctx(acx_image_t* img, const uint8_t* hay, const int64_t* off, int64_t n_hay,
-                                 const uint8_t* ctx, const int64_t* ctx_off, const int32_t* index_base, acx_result_t** result) {
+                                 const uint8_t* ctx, const int64_t* ctx_off, const int32_t* index_base, int32_t flags,
+                                 acx_result_t** result) {
     if (!img || !off || !result || n_hay < 0) return acx_fail(ACX_E_INVAL, "acx_scan_host_ctx: bad argument");
-    if (!ctx || !ctx_off) return scan_host_impl(img, ACX_SCAN_ALL, hay, off, n_hay, nullptr, index_base, result, 0);
+    if (flags & ~(int32_t)ACX_SCAN_SKIP_WS) return acx_fail(ACX_E_INVAL, "acx_scan_host_ctx: flags = %d (ACX_SCAN_SKIP_WS or 0)", flags);
+    if (!ctx || !ctx_off) return scan_host_impl(img, ACX_SCAN_ALL, hay, off, n_hay, nullptr, index_base, result, 0, flags);
     if (off[0] != 0 || ctx_off[0] != 0) return acx_fail(ACX_E_INVAL, "acx_scan_host_ctx: off[0] and ctx_off[0] must be 0");
     int64_t total = 0, shortest = INT32_MAX;
     for (int64_t h = 0; h < n_hay; h++) {
@@ -1108,6 +1233,7 @@ extern "C" int acx_scan_host_ctx(acx_image_t* img, const uint8_t* hay, const int
     p.dev_index_base = index_base ? r->in_base.p : nullptr;
     p.dev_skip = r->in_skip.p;
     p.min_hay_len = n_hay > 0 ? (int32_t)shortest : 0;
+    p.flags = flags;
     return acx_scan_batch(img, &p, result, nullptr);
 }
 
@@ -1118,13 +1244,13 @@ static int64_t max_launch_bytes() {
 
 extern "C" int acx_scan_host(acx_image_t* img, int mode, const uint8_t* hay, const int64_t* off, int64_t n_hay,
                              const int32_t* init_state, const int32_t* index_base, acx_result_t** result) {
-    return scan_host_impl(img, mode, hay, off, n_hay, init_state, index_base, result, 1);
+    return scan_host_impl(img, mode, hay, off, n_hay, init_state, index_base, result, 1, 0);
 }
 
 // want_final = 0: no final states (an image with the position-parallel structures then never builds its dense table
 // for ACX_SCAN_ALL: acx_scan_host_ctx, what the iterators and find_all call)
 static int scan_host_impl(acx_image_t* img, int mode, const uint8_t* hay, const int64_t* off, int64_t n_hay,
-                          const int32_t* init_state, const int32_t* index_base, acx_result_t** result, int want_final) {
+                          const int32_t* init_state, const int32_t* index_base, acx_result_t** result, int want_final, int32_t flags) {
     if (!img || !off || !result || n_hay < 0) return acx_fail(ACX_E_INVAL, "acx_scan_host: bad argument");
     if (off[0] != 0) return acx_fail(ACX_E_INVAL, "acx_scan_host: off[0] must be 0");
     {   // (one branch-free pass: a batch of a million reads spends as long here as in its scan kernel otherwise)
@@ -1141,8 +1267,9 @@ static int scan_host_impl(acx_image_t* img, int mode, const uint8_t* hay, const 
         if (!r) return acx_fail(ACX_E_NOMEM, "acx_scan_host: out of memory");
         *result = r;
     }
-    const int64_t limit = max_launch_bytes();
-    if (total_bytes <= limit) return scan_host_once(img, mode, hay, off, n_hay, init_state, index_base, result, want_final);
+    int64_t limit = max_launch_bytes();
+    if ((flags & ACX_SCAN_SKIP_WS) && limit > 0xFFFFFFFFll) limit = 0xFFFFFFFFll;     // (positions of the compacted batch's map are 32-bit)
+    if (total_bytes <= limit) return scan_host_once(img, mode, hay, off, n_hay, init_state, index_base, result, want_final, flags);
 
     // More than one launch can stage (8 B of event scratch per haystack byte): scan groups of whole
     // haystacks one after the other and assemble the host-side result; the device-side accessors then
@@ -1164,7 +1291,7 @@ static int scan_host_impl(acx_image_t* img, int mode, const uint8_t* hay, const 
             if (goff[(size_t)gn] > ACX_MAX_LAUNCH_BYTES)
                 return acx_fail(ACX_E_UNSUPPORTED, "acx_scan_host: haystack %lld alone exceeds one launch", (long long)g0);
             rc = scan_host_once(img, mode, hay + off[g0], goff.data(), gn, init_state ? init_state + g0 : nullptr,
-                                index_base ? index_base + g0 : nullptr, result, want_final);
+                                index_base ? index_base + g0 : nullptr, result, want_final, flags);
             if (rc) return rc;
             const int64_t* moff; const acx_match_t* m; const int32_t* fin;
             if ((rc = acx_result_fetch_host(r, &moff, &m, &fin))) return rc;

@@ -141,6 +141,7 @@ struct acx_ppm_args {
     int32_t*  overflow;      // set when a sub-pool ran out: the host grows the pool and scans again
     unsigned long long* phase_out;   // development builds: 8 clock sums over all waves (stage+filter, push, -, fetch, tops, deep, place+records, rest)
     int32_t*  short_hay;     // k_ppm_stream on an offsets batch: set when a tile holds more haystack starts than min_hay_len >= 8 allows
+    uint32_t* block_sum;     // fixed-stride stream scans: += the records of every wave of block b (zero before the scan); NULL: not kept
     int32_t*  hay_local;     // fixed-stride batches: tile-local record offset of every haystack start
 };
 struct acx_ppm_compact_args {
@@ -151,8 +152,12 @@ struct acx_ppm_compact_args {
     // fixed-stride batches: match_off[h] = item_off[h * stride / TILE] + hay_local[h]
     const int32_t* hay_local; int64_t* match_off; int64_t n_hay; int64_t stride;
 };
+#define ACX_PPM_MAX_BLOCKS 1024     // blocks of one k_ppm_stream launch at most (one or two per CU)
 struct acx_ppm_gather_args {       // k_ppm_stream results -> final place
     const uint32_t* wave_desc; const int64_t* wave_off; int64_t n_waves;
+    // k_ppm_gather_pos: the block sums of this scan, those of the result's next scan (zeroed here), the control words
+    // (flags read, then zeroed here) and the host's pinned words (total, overflow, short_hay)
+    const uint32_t* block_sum; uint32_t* block_sum_next; unsigned long long* ctl; long long* host_words;
     const uint2* scratch; uint2* matches; int64_t capacity;
     const int32_t* hay_local; int64_t* match_off; int64_t n_hay; int64_t stride;
     const int64_t* off;            // offsets batch (else nullptr: fixed stride — records carry global positions)
@@ -178,6 +183,20 @@ hipError_t acx_launch_skip_count(const int64_t* match_off, const uint2* matches,
                                  int64_t n_hay, int32_t* kept, hipStream_t s);
 hipError_t acx_launch_skip_move(const int64_t* match_off, const uint2* matches, const int32_t* skip, const int32_t* kept,
                                 const int64_t* new_off, int64_t n_hay, uint2* dst, hipStream_t s);
+// ACX_SCAN_SKIP_WS (acx_ws.hip): white space out of the haystack buffer before the scan (tile counts -> scan ->
+// compacted bytes + the original position of each -> offsets and context lengths of the compacted batch), and the end
+// indices of the records back to original positions afterwards
+struct acx_ws_remap_args {
+    uint2* matches; const int64_t* match_off; int64_t n_hay; int64_t total;
+    const int64_t* off; int64_t stride; const int32_t* skip; const int32_t* index_base;     // the batch as the caller gave it
+    const int64_t* c_off; const int32_t* c_skip; const uint32_t* map;                       // the compacted batch
+};
+int64_t acx_ws_num_tiles(int64_t total);
+hipError_t acx_launch_ws_count(const uint8_t* hay, int64_t total, int32_t* tile_count, hipStream_t s);
+hipError_t acx_launch_ws_move(const uint8_t* hay, int64_t total, const int64_t* tile_off, uint8_t* out_hay, uint32_t* out_map, hipStream_t s);
+hipError_t acx_launch_ws_offsets(const int64_t* off, int64_t stride, int64_t n_hay, const int32_t* skip, const uint32_t* map,
+                                 const int64_t* n_kept, int64_t* c_off, int32_t* c_skip, hipStream_t s);
+hipError_t acx_launch_ws_remap(const acx_ws_remap_args& a, hipStream_t s);
 // build the dense transition table in HBM from the sparse form (acx_build.hip)
 hipError_t acx_launch_build_table(uint32_t* table, const int32_t* fail, const uint32_t* edge_off, const uint8_t* edge_cls,
                                   const uint32_t* edge_dst, const uint32_t* tflags, const uint32_t* lvl_first_host,

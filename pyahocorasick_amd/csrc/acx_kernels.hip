@@ -961,6 +961,92 @@ __global__ void __launch_bounds__(TOP ? 1024 : ACX_BLOCK) k_walk_long(const acx_
     }
 }
 
+// The same state machine in select form.  The branchy form above costs 138 wave-instructions a step (rocprofv3: 147 M
+// VALU + 176 M scalar per 2.34 M wave-steps of config 5): every lane of a wave stands in another arm of it, each arm is
+// an exec-mask region, and the SIMDs issue instructions 3/4 of the kernel's time.  Here a step is straight-line code:
+//     byte    the lane's current 16 haystack bytes sit in LDS (a byte read instead of a four-way register select)
+//     entry   rows of the shallowest states from LDS, read by every lane at a clamped address; the table gather only
+//             for the lanes that stand deeper
+//     emit  = (no edge and a match is remembered) or (the target's fail node ends a key and the target does not) or
+//             (the haystack is over and a match is remembered)
+//     state = emit ? root : target;  index = (emit ? last_index : index) + 1
+// (a transition to the root carries neither EOW nor FAILEOW, so the root needs no test of its own).  The regions that
+// stay are the reload of the 16-byte block and the store of an event.  Four steps per test of the loop condition: a
+// lane that is finished idles through them.  Needs hay_cap >= 16 (a block at the end of the buffer is loaded from
+// 16 bytes before its end and read at an offset).
+template <int SB, bool TOP>
+__global__ void __launch_bounds__(TOP ? 1024 : ACX_BLOCK) k_walk_long_sel(const acx_walk_args a, uint32_t n_top) {
+    __shared__ uint32_t s_cls4[256];
+    __shared__ uint4 s_blk[TOP ? 1024 : ACX_BLOCK];
+    extern __shared__ __attribute__((aligned(16))) uint32_t s_top[];
+    if (threadIdx.x < 256) s_cls4[threadIdx.x] = (uint32_t)a.cls[threadIdx.x] * 4u;
+    if (TOP) for (uint32_t i = threadIdx.x; i < n_top * (a.row_bytes >> 2); i += blockDim.x) s_top[i] = a.table[i];
+    __syncthreads();
+
+    const int64_t n_threads = (int64_t)gridDim.x * blockDim.x;
+    const uint8_t* table_bytes = (const uint8_t*)a.table;
+    const uint8_t* last16 = a.hay + a.hay_cap - 16;
+    const uint8_t* my_blk = (const uint8_t*)&s_blk[threadIdx.x];
+    constexpr uint32_t MASK = ACX_ENTRY_STATE_MASK(SB), EDGE = ACX_ENTRY_EDGE(SB), EOW = ACX_ENTRY_EOW(SB), FEOW = ACX_ENTRY_FAILEOW(SB);
+    const uint32_t top_last = TOP ? n_top - 1u : 0u;
+
+    for (int64_t h = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; h < a.n_hay; h += n_threads) {
+        int64_t b, e;
+        if (a.off) { b = a.off[h]; e = a.off[h + 1]; }
+        else       { b = h * a.stride; e = b + a.stride; }
+        const int len = (int)(e - b);
+        const uint8_t* p = a.hay + b;
+        uint2* ev = a.events + (a.ev_shift ? (b >> a.ev_shift) + h : b);
+        uint2* const ev0 = ev;
+        const uint32_t base = a.index_base ? (uint32_t)a.index_base[h] : 0u;
+        uint32_t state = a.init_state ? (uint32_t)a.init_state[h] : 0u;
+        if (state >= a.n_states) state = 0u;
+        int index = 0, last_index = -1;
+        uint32_t last_state = 0;
+        int blk = -1;
+        uint32_t adj = 0;                                     // where byte 0 of the current block sits in the lane's LDS slot
+        const int last = len > 0 ? len - 1 : 0;
+        while (index < len || last_index >= 0) {
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const bool in = index < len;
+                const int ix = index < last ? index : last;      // (a lane whose haystack is over reads a valid byte and ignores it)
+                const int nb = ix >> 4;
+                if (nb != blk) {
+                    blk = nb;
+                    const uint8_t* q = p + (int64_t)nb * 16;
+                    const uint8_t* q2 = q > last16 ? last16 : q;
+                    adj = (uint32_t)(q - q2);
+                    s_blk[threadIdx.x] = *(const uint4*)q2;   // (unaligned 16-byte loads are fine on gfx9)
+                }
+                const uint32_t c4 = s_cls4[my_blk[((uint32_t)ix & 15u) + adj]];
+                uint32_t en;
+                if (TOP) {
+                    const uint32_t st = state < top_last ? state : top_last;
+                    en = *(const uint32_t*)((const uint8_t*)s_top + (st * a.row_bytes + c4));
+                    if (state > top_last) en = load_entry<SB>(table_bytes, state, a.row_bytes, c4);
+                } else en = load_entry<SB>(table_bytes, state, a.row_bytes, c4);
+                const uint32_t next = en & MASK;
+                const bool have = last_index >= 0;
+                const bool emit_a = in && have && (en & EDGE) == 0u;
+                const bool go = in && !emit_a;
+                const bool setl = go && (en & (EOW | FEOW)) != 0u;
+                const bool emit = emit_a || (go && (en & (EOW | FEOW)) == FEOW) || (!in && have);
+                last_state = setl ? next : last_state;
+                last_index = setl ? index : last_index;
+                if (emit) *ev++ = make_uint2(base + (uint32_t)last_index, last_state);
+                state = emit ? 0u : (in ? next : state);
+                index = (emit ? last_index : index) + 1;
+                last_index = emit ? -1 : last_index;
+            }
+        }
+        const int32_t n = (int32_t)(ev - ev0);
+        a.counts[h] = n;
+        a.nev[h] = n;
+        if (a.final_state) a.final_state[h] = (int32_t)(state & MASK);
+    }
+}
+
 // final_state of every haystack from its last `longest` bytes (position-parallel scans keep no
 // state): the state reached from the root over a window is the longest suffix of the window that
 // is a trie node, and no node is longer than the longest key.
@@ -1248,10 +1334,19 @@ hipError_t acx_launch_walk_long(const acx_walk_args& a, int variant, hipStream_t
             hipLaunchKernelGGL(kernel, dim3((unsigned)cus * bpc), dim3(1024), lds, s, a, n_top);
             return hipGetLastError();
         };
-        if (a.state_bits == ACX_STATE_BITS_WIDE) return launch(k_walk_long<ACX_STATE_BITS_WIDE, true>);
-        return launch(k_walk_long<ACX_STATE_BITS_NARROW, true>);
+        if (((variant >> 22) & 1) || a.hay_cap < 16) {                           // (A/B: the branchy form)
+            if (a.state_bits == ACX_STATE_BITS_WIDE) return launch(k_walk_long<ACX_STATE_BITS_WIDE, true>);
+            return launch(k_walk_long<ACX_STATE_BITS_NARROW, true>);
+        }
+        if (a.state_bits == ACX_STATE_BITS_WIDE) return launch(k_walk_long_sel<ACX_STATE_BITS_WIDE, true>);
+        return launch(k_walk_long_sel<ACX_STATE_BITS_NARROW, true>);
     }
     const int grid = grid_for_waves((a.n_hay + ACX_WAVE - 1) / ACX_WAVE);
+    if (!((variant >> 22) & 1) && a.hay_cap >= 16) {
+        if (a.state_bits == ACX_STATE_BITS_WIDE) hipLaunchKernelGGL((k_walk_long_sel<ACX_STATE_BITS_WIDE, false>), dim3(grid), dim3(ACX_BLOCK), 0, s, a, 0u);
+        else                                     hipLaunchKernelGGL((k_walk_long_sel<ACX_STATE_BITS_NARROW, false>), dim3(grid), dim3(ACX_BLOCK), 0, s, a, 0u);
+        return hipGetLastError();
+    }
     if (a.state_bits == ACX_STATE_BITS_WIDE) hipLaunchKernelGGL((k_walk_long<ACX_STATE_BITS_WIDE, false>), dim3(grid), dim3(ACX_BLOCK), 0, s, a, 0u);
     else                                     hipLaunchKernelGGL((k_walk_long<ACX_STATE_BITS_NARROW, false>), dim3(grid), dim3(ACX_BLOCK), 0, s, a, 0u);
     return hipGetLastError();

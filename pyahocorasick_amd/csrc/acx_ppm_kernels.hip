@@ -750,6 +750,9 @@ __global__ void __launch_bounds__(ACX_PPM_BLOCK) k_ppm_stream(const acx_ppm_args
                 const uint32_t wv = (uint32_t)lane < BW ? sbits[lane] : 0u;
                 uint32_t tot;
                 const uint32_t before = wave_excl_scan((uint32_t)__popc(wv), tot);
+                // two starts at one position — an empty haystack, which the contract excludes as well — would count as
+                // one: the ranks of everything behind it would be off by one.  Same answer: say so, the host scans again.
+                if (tot != m && lane == 0) *a.short_hay = 1;
                 uint32_t last = wv ? 32u * lane + (31 - __clz(wv)) + 1 : 0u;
 #pragma unroll
                 for (int d = 1; d < 64; d <<= 1) { const uint32_t t = __shfl_up(last, d, 64); if (lane >= d && t > last) last = t; }
@@ -1199,7 +1202,12 @@ __global__ void __launch_bounds__(ACX_PPM_BLOCK) k_ppm_stream(const acx_ppm_args
         }
         wave_sync();
     }
-    if (lane == 0) { desc[0] = run_off; desc[1] = ng; if (ng) desc[18 + ng - 1] = g_used; }
+    if (lane == 0) {
+        desc[0] = run_off; desc[1] = ng; if (ng) desc[18 + ng - 1] = g_used;
+        // fixed-stride batches: the records of the 16 waves of this block, summed where k_ppm_gather_pos finds them (no
+        // launch for a prefix sum over the waves: every block of the gather adds up the 256 block sums in front of its wave)
+        if (a.block_sum && run_off) __hip_atomic_fetch_add(a.block_sum + blockIdx.x, run_off, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
 #ifdef ACX_PPM_PHASES
     PH(7);
     if (lane == 0 && a.phase_out) for (int i = 0; i < 8; i++) atomicAdd(a.phase_out + i, ph[i]);
@@ -1281,7 +1289,29 @@ __global__ void __launch_bounds__(256) k_ppm_gather(const acx_ppm_gather_args c)
 // block here knows every haystack that starts in there: those in front of its first record, those between two records
 // of different haystacks (the thread of the later record fills the gap), those behind its last record.
 __global__ void __launch_bounds__(256) k_ppm_gather_pos(const acx_ppm_gather_args c) {
-    const int64_t total = c.wave_off[c.n_waves];
+    __shared__ uint32_t s_red[4];
+    const int n_blocks = (int)(c.n_waves / ACX_PPM_WAVES);
+    // sum over the block (the records of one scan are fewer than 2^32: the pool addresses them with 32 bits)
+    auto block_add = [&](uint32_t x) -> uint32_t {
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) x += __shfl_xor(x, d, 64);
+        __syncthreads();
+        if ((threadIdx.x & 63) == 0) s_red[threadIdx.x >> 6] = x;
+        __syncthreads();
+        return s_red[0] + s_red[1] + s_red[2] + s_red[3];
+    };
+    uint32_t total32 = 0;
+#pragma unroll 1
+    for (int b = threadIdx.x; b < n_blocks; b += 256) total32 += c.block_sum[b];
+    const int64_t total = (int64_t)block_add(total32);
+    if (blockIdx.x == 0) {
+        // what the host reads when this result completes (its pinned words), the control words and the block sums of the
+        // result's NEXT scan back to zero: no copies behind this kernel, no memset in front of the next scan kernel
+        if (threadIdx.x == 0) { c.host_words[0] = total; c.host_words[1] = ((const int32_t*)(c.ctl + 8))[0]; c.host_words[2] = ((const int32_t*)(c.ctl + 9))[0]; }
+        __syncthreads();
+        if (threadIdx.x < 16) c.ctl[threadIdx.x] = 0ull;
+        for (int b = threadIdx.x; b < ACX_PPM_MAX_BLOCKS; b += 256) c.block_sum_next[b] = 0u;
+    }
     const bool fits = total <= c.capacity;
     const uint32_t stride = (uint32_t)c.stride;
     const uint64_t H = (uint64_t)c.n_hay * stride;
@@ -1305,7 +1335,12 @@ __global__ void __launch_bounds__(256) k_ppm_gather_pos(const acx_ppm_gather_arg
             if (small) { const uint32_t y = rA + (gpos - A32), q = __umulhi(y, m32); idx = y - q * stride; return q; }
             uint32_t rem; const uint32_t hh = div_magic(gpos, c.stride_magic, stride, rem); idx = rem; return (uint32_t)((int64_t)hh - h0);
         };
-        const int64_t base = c.wave_off[w];
+        uint32_t part = 0;                                             // records of the waves in front of w: whole blocks, then the waves of its own
+        const int wb = (int)(w / ACX_PPM_WAVES);
+#pragma unroll 1
+        for (int b = threadIdx.x; b < wb; b += 256) part += c.block_sum[b];
+        if (threadIdx.x < (int)(w % ACX_PPM_WAVES)) part += c.wave_desc[((size_t)wb * ACX_PPM_WAVES + threadIdx.x) * PPM_DESC_WORDS];
+        const int64_t base = (int64_t)block_add(part);
         u32x2* dst = (u32x2*)(c.matches + base);
         uint32_t li = 0;                                               // records of this wave in front of the current grant
         uint32_t q_last = (uint32_t)(hA - 1 - h0);                     // haystack (relative) of the last record so far; none: the one in front of the first start
@@ -1510,7 +1545,7 @@ hipError_t acx_launch_ppm_first_h(const int64_t* off, int64_t n_hay, int64_t n_t
 }
 
 hipError_t acx_launch_ppm_gather(const uint32_t* wave_desc, int64_t n_waves, int64_t* wave_off, const acx_ppm_gather_args& c, hipStream_t s) {
-    hipLaunchKernelGGL(k_ppm_wave_scan, dim3(1), dim3(1024), 0, s, wave_desc, n_waves, wave_off);
+    if (c.off) hipLaunchKernelGGL(k_ppm_wave_scan, dim3(1), dim3(1024), 0, s, wave_desc, n_waves, wave_off);
     int64_t blocks = n_waves;
     const int64_t hb = (c.n_hay + 256) / 256;
     if (blocks < hb) blocks = hb;

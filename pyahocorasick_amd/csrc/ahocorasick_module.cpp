@@ -290,7 +290,7 @@ bool gpu_sync(AutomatonObject* a) {
 bool run_scan(AutomatonObject* a, int mode, const uint8_t* data, const int64_t* off, int64_t n,
               const int32_t* init_state, const int32_t* index_base,
               const int64_t** moff, const acx_match_t** m, const int32_t** fin, ScanLease* lease,
-              const uint8_t* ctx = nullptr, int64_t ctx_len = 0) {
+              const uint8_t* ctx = nullptr, int64_t ctx_len = 0, int32_t flags = 0) {
     if (!gpu_sync(a)) return false;
     lease->a = a; lease->ref = a->image; lease->ref->users++;
     if (a->results && !a->results->empty()) { lease->res = a->results->back(); a->results->pop_back(); }
@@ -302,7 +302,7 @@ bool run_scan(AutomatonObject* a, int mode, const uint8_t* data, const int64_t* 
     static const uint8_t no_ctx = 0;
     Py_BEGIN_ALLOW_THREADS
     if (mode == ACX_SCAN_ALL && !init_state)
-        rc = acx_scan_host_ctx(img, data, off, n, ctx ? ctx : (n == 1 ? &no_ctx : nullptr), n == 1 ? ctx_off : nullptr, index_base, &lease->res);
+        rc = acx_scan_host_ctx(img, data, off, n, ctx ? ctx : (n == 1 ? &no_ctx : nullptr), n == 1 ? ctx_off : nullptr, index_base, flags, &lease->res);
     else rc = acx_scan_host(img, mode, data, off, n, init_state, index_base, &lease->res);
     if (!rc) rc = acx_result_fetch_host(lease->res, moff, m, fin);
     if (rc) { strncpy(err, acx_last_error(), sizeof err - 1); err[sizeof err - 1] = 0; }     // (the message is thread-local: keep it across the switch)
@@ -655,15 +655,8 @@ bool scan_text(AutomatonObject* a, int mode, const Text& t, Py_ssize_t start, Py
     const Py_ssize_t bs = char_to_byte(t, start), be = char_to_byte(t, end);
     const uint8_t* src = t.data + bs;
     const Py_ssize_t nb = be - bs;
-    std::vector<uint8_t> compact;
-    std::vector<int32_t> remap;                                   // compacted byte -> byte of the slice
     int64_t off[2] = {0, (int64_t)nb};
-    const uint8_t* scan_src = src;
-    if (ignore_ws) {
-        for (Py_ssize_t i = 0; i < nb; i++)
-            if (!is_cspace(src[i])) { compact.push_back(src[i]); remap.push_back((int32_t)i); }
-        scan_src = compact.data(); off[1] = (int64_t)compact.size();
-    }
+    // ignore_ws: the device takes the white space out and maps the end indices back (ACX_SCAN_SKIP_WS)
     std::vector<int32_t> cob;                                     // letter (relative to `start`) of each byte of the slice
     if (!t.ascii()) {
         cob.resize((size_t)nb);
@@ -674,11 +667,12 @@ bool scan_text(AutomatonObject* a, int mode, const Text& t, Py_ssize_t start, Py
     int32_t init = state_io ? *state_io : 0;
     // (the root needs no init_state array: such a scan may take the position-parallel kernels)
     ScanLease lease;
-    if (!run_scan(a, mode, scan_src, off, 1, (state_io && init != 0) ? &init : nullptr, nullptr, &moff, &m, &fin, &lease,
-                  ctx && !ctx->empty() ? ctx->data() : nullptr, ctx ? (int64_t)ctx->size() : 0)) return false;
+    if (!run_scan(a, mode, src, off, 1, (state_io && init != 0) ? &init : nullptr, nullptr, &moff, &m, &fin, &lease,
+                  ctx && !ctx->empty() ? ctx->data() : nullptr, ctx ? (int64_t)ctx->size() : 0,
+                  (ignore_ws && mode == ACX_SCAN_ALL) ? ACX_SCAN_SKIP_WS : 0)) return false;
     out->assign(m, m + moff[1]);
     for (auto& r : *out) {
-        int32_t byte_off = ignore_ws ? remap[(size_t)r.end_index] : r.end_index;
+        const int32_t byte_off = r.end_index;
         const int32_t letter = t.ascii() ? byte_off : cob[(size_t)byte_off];
         r.end_index = (int32_t)(start + letter + index_shift);
     }

@@ -8,7 +8,7 @@ import ctypes as C
 
 import numpy as np
 
-from ._lib import ACX_SCAN_ALL, ACX_SCAN_ASYNC, ACX_BLOB_HEADER_BYTES, ScanParams, check, lib
+from ._lib import ACX_SCAN_ALL, ACX_SCAN_ASYNC, ACX_SCAN_SKIP_WS, ACX_BLOB_HEADER_BYTES, ScanParams, check, lib
 
 
 class DeviceBuffer:
@@ -152,10 +152,12 @@ class Scanner:
 
     def scan(self, dev_hay, hay_capacity, n_hay, dev_off=None, stride=0, mode=ACX_SCAN_ALL,
              dev_init_state=None, dev_index_base=None, want_final_state=False, timing=False,
-             variant=0, stream=None, asynchronous=False, min_hay_len=0, dev_skip=None):
+             variant=0, stream=None, asynchronous=False, min_hay_len=0, dev_skip=None, skip_white_space=False):
         """All pointer arguments are raw device addresses (int / c_void_p / None).
         asynchronous=True: return as soon as the kernels are queued on `stream` (returns None);
-        `wait()`, `num_matches()`, `fetch()` complete the scan."""
+        `wait()`, `num_matches()`, `fetch()` complete the scan.
+        skip_white_space=True: ACX_SCAN_SKIP_WS — white space never touches the automaton, indices stay those of the
+        bytes given (iter(..., ignore_white_space=True) for a whole batch)."""
         p = ScanParams()
         p.struct_bytes = C.sizeof(ScanParams)
         p.mode = mode
@@ -171,7 +173,7 @@ class Scanner:
         p.variant = int(variant)
         p.min_hay_len = int(min_hay_len)
         p.dev_skip = _addr(dev_skip)                 # streams: context bytes in front of every haystack (include/acx.h)
-        p.flags = ACX_SCAN_ASYNC if asynchronous else 0
+        p.flags = (ACX_SCAN_ASYNC if asynchronous else 0) | (ACX_SCAN_SKIP_WS if skip_white_space else 0)
         check(lib().acx_scan_batch(self.image.handle, C.byref(p), C.byref(self._res), _addr(stream)))
         self.n_hay = int(n_hay)
         return None if asynchronous else lib().acx_result_num_matches(self._res)

@@ -49,6 +49,11 @@ def test_min_hay_len_promise_broken_is_detected_and_rescanned():
     flat = np.ascontiguousarray(alpha[rng.integers(0, 4, size=int(off[-1]))])
     img = _check(A, O, flat, off, min_hay_len=8)
     assert img.ppm_kernel(stride=0, has_offsets=True, variant=0, min_hay_len=8, dev_hay=0, n_hay=len(lens)) == "stream"
+    # (a') a few EMPTY haystacks: two starts at one position, nowhere near too many per tile — noticed as well
+    lens = [200] * 20 + [0] + [200] * 20 + [0, 0] + [5] + [200] * 20 + [0]
+    off = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+    flat = np.ascontiguousarray(alpha[rng.integers(0, 4, size=int(off[-1]))])
+    _check(A, O, flat, off, min_hay_len=8)
     # (b) thousands of 3-byte haystacks, still promising 8: more starts in a tile than the kernel has room for;
     # it raises its flag and the result comes from a second scan on the general kernels
     lens = [3] * 5000 + [300] * 20 + [1] * 3000 + [0] * 10 + [2] * 999

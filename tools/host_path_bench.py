@@ -43,7 +43,7 @@ def main():
     tx = []
     for _ in range(5):
         t0 = time.perf_counter()
-        check(lib().acx_scan_host_ctx(img.handle, data.ctypes.data, off.ctypes.data, n_reads, None, None, None, C.byref(A._result)))
+        check(lib().acx_scan_host_ctx(img.handle, data.ctypes.data, off.ctypes.data, n_reads, None, None, None, 0, C.byref(A._result)))
         p_off, p_m, p_f = C.c_void_p(), C.c_void_p(), C.c_void_p()
         check(lib().acx_result_fetch_host(A._result, C.byref(p_off), C.byref(p_m), C.byref(p_f)))
         tx.append(time.perf_counter() - t0)
