@@ -630,7 +630,7 @@ static int ppm_enqueue(acx_result* r, acx_image* img, const acx_chunk_args* ca, 
                 int lo_pri = 0, hi_pri = 0;
                 if (acx_tune_env("ACX_SIDE_DEFAULT_PRIORITY") || hipDeviceGetStreamPriorityRange(&lo_pri, &hi_pri) != hipSuccess || lo_pri == hi_pri)
                     HIP_TRY(hipStreamCreateWithFlags(&r->side, hipStreamNonBlocking));
-                else HIP_TRY(hipStreamCreateWithPriority(&r->side, hipStreamNonBlocking, lo_pri));
+                else HIP_TRY(hipStreamCreateWithPriority(&r->side, hipStreamNonBlocking, acx_tune_env("ACX_SIDE_HIGH_PRIORITY") ? hi_pri : lo_pri));
             }
             if (!r->ev_scan) HIP_TRY(hipEventCreateWithFlags(&r->ev_scan, hipEventDisableTiming));
             HIP_TRY(hipEventRecord(r->ev_scan, s));

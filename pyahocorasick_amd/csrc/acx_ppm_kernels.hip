@@ -891,12 +891,18 @@ __global__ void __launch_bounds__(ACX_PPM_BLOCK) k_ppm_stream(const acx_ppm_args
             const uint32_t k = (n + 63u) >> 6;                           // slots that hold entries
             uint32_t pp[NE], XX[NE], rr[NE], LL[NE], cn[NE];
             u32x2 hc[NE];
-            int32_t va[NE], vb[NE];
+            int32_t va[NE];
+            // the second value of an entry (two keys end at one position: 0.6 % of the matching positions of config 2): one
+            // per lane and round in registers, with the slot it belongs to; a lane that meets a second such entry in one
+            // round sends it through the general enumeration below.  (Six registers of second values, one per slot, are
+            // what kept this kernel above 112 registers: k_ppm_gather_pos then finds no room beside it on a CU.)
+            int32_t vb1 = 0; uint32_t vbe = NE;
+            auto set_vb = [&](uint32_t e, int32_t v) { if (vbe == (uint32_t)NE) { vb1 = v; vbe = e; } };
             // 0. bytes of no key around (rare): the symbols that exist going back from every entry.  Done apart from the
             // slots below, which must stay one basic block: a branch between two of them, even one that never diverges,
             // keeps the scheduler from overlapping their LDS reads.
 #pragma unroll
-            for (int e = 0; e < NE; e++) { LL[e] = longest; pp[e] = 0x18000u; XX[e] = 0; rr[e] = 1; cn[e] = 0; va[e] = 0; vb[e] = 0; hc[e].x = 0; hc[e].y = 0; }
+            for (int e = 0; e < NE; e++) { LL[e] = longest; pp[e] = 0x18000u; XX[e] = 0; rr[e] = 1; cn[e] = 0; va[e] = 0; hc[e].x = 0; hc[e].y = 0; }
             if (use_other) {
                 PPM_SLOTS(e,
                     const uint32_t qi = 64u * (uint32_t)e + (uint32_t)lane;
@@ -957,7 +963,7 @@ __global__ void __launch_bounds__(ACX_PPM_BLOCK) k_ppm_stream(const acx_ppm_args
                     g = (L > Cn ? 1u : 0u) & (kk | gk) & 1u;
                 } else { has_id = hw >> 31; g = has_id & (L > Cn ? 1u : 0u); }
                 gomask |= g << e; n_go += g;
-                va[e] = (int32_t)hx; vb[e] = 0;                          // (the shallowest key's value, unless the word holds the id)
+                va[e] = (int32_t)hx;                                     // (the shallowest key's value, unless the word holds the id)
                 tvm[e] = cn[e] + has_id >= 2u ? m : 0u;                  // (a second key, or one key and the word holds the id)
                 tvany |= tvm[e];
             )
@@ -968,7 +974,7 @@ __global__ void __launch_bounds__(ACX_PPM_BLOCK) k_ppm_stream(const acx_ppm_args
                     if (tvm[e]) {
                         const uint32_t d1 = (uint32_t)__ffs(tvm[e]), m2 = tvm[e] & (tvm[e] - 1u);
                         va[e] = a.top_val[s_tb[d1] + code_n(XX[e], d1)];
-                        if (m2) { const uint32_t d2 = (uint32_t)__ffs(m2); vb[e] = a.top_val[s_tb[d2] + code_n(XX[e], d2)]; }
+                        if (m2) { const uint32_t d2 = (uint32_t)__ffs(m2); set_vb((uint32_t)e, a.top_val[s_tb[d2] + code_n(XX[e], d2)]); }
                     }
                 }
             }
@@ -1043,7 +1049,7 @@ __global__ void __launch_bounds__(ACX_PPM_BLOCK) k_ppm_stream(const acx_ppm_args
                             if ((found >> e) & 1u) {
                                 const u32x2 dv = *(const u32x2*)(dq + 2 * rnk2);
                                 const uint32_t ct = cn[e] & 0xFFFFu;
-                                if (ct == 0u) { va[e] = (int32_t)dv.x; vb[e] = (int32_t)dv.y; } else if (ct == 1u) vb[e] = (int32_t)dv.x;
+                                if (ct == 0u) { va[e] = (int32_t)dv.x; if ((cn[e] >> 16) > 1u) set_vb((uint32_t)e, (int32_t)dv.y); } else if (ct == 1u) set_vb((uint32_t)e, (int32_t)dv.x);
                             }
                             rnk2 += g;
                         )
@@ -1109,7 +1115,7 @@ __global__ void __launch_bounds__(ACX_PPM_BLOCK) k_ppm_stream(const acx_ppm_args
             }
             // 6. records, longest key of a position first.  Slot rt of the round (one past its last record; the grant has
             // the room) takes the stores of the lanes that have no first / second record.
-            uint32_t slow = 0;                                           // slots with more than two records: the general enumeration
+            uint32_t slow = 0, slow1 = 0;                                // slots with more than two records (slow1: or two, the second not in vb1): the general enumeration
             uint8_t* const out8 = (uint8_t*)(a.scratch + g_base + g_used);
             uint2* const out = (uint2*)out8;
             if (wr) {
@@ -1117,27 +1123,32 @@ __global__ void __launch_bounds__(ACX_PPM_BLOCK) k_ppm_stream(const acx_ppm_args
                 PPM_SLOTS(e,
                     const uint32_t c = cn[e]; const uint32_t oe = ex[e] + c - 1u;
                     *(uint2*)(out8 + ((c ? oe : rt) << 3)) = make_uint2(rr[e], (uint32_t)va[e]);
-                    two |= (c > 1u ? 1u : 0u) << e;
+                    const uint32_t mine = vbe == (uint32_t)e ? 1u : 0u;
+                    two |= ((c > 1u ? 1u : 0u) & mine) << e;
+                    slow1 |= ((c > 1u ? 1u : 0u) & (mine ^ 1u)) << e;
                     slow |= (c > 2u ? 1u : 0u) << e;
                 )
                 if (__any(two != 0u)) {
                     PPM_SLOTS(e,
-                        if ((two >> e) & 1u) *(uint2*)(out8 + ((ex[e] + cn[e] - 2u) << 3)) = make_uint2(rr[e], (uint32_t)vb[e]);
+                        if ((two >> e) & 1u) *(uint2*)(out8 + ((ex[e] + cn[e] - 2u) << 3)) = make_uint2(rr[e], (uint32_t)vb1);
                     )
                 }
+                slow |= slow1;
                 while (__any(slow != 0u)) {                              // rare: one slot per lane and pass, from the 32-byte cell
                     if (slow) {
                         const uint32_t se = (uint32_t)__ffs(slow) - 1u;
                         slow &= slow - 1u;
+                        const uint32_t from = (slow1 >> se) & 1u ? 1u : 2u;
                         typename Ppm<SB, POW2, false>::Ent E;
                         uint32_t oe = 0;
                         E.p = 0; E.X = 0; E.L = 0; E.idx = 0;
 #pragma unroll
-                        for (int e = 0; e < NE; e++) if (se == (uint32_t)e) { E.p = pp[e] & 0x7FFFu; E.X = XX[e]; E.L = LL[e]; E.idx = rr[e]; oe = ex[e] + cn[e] - 1; }
+                        for (int e = 0; e < NE; e++) if (se == (uint32_t)e) { E.p = pp[e] & 0x7FFFu; E.L = LL[e]; E.idx = rr[e]; oe = ex[e] + cn[e] - 1; }
+                        E.X = P.window(HP + E.p);                        // (read again: the windows of the round need not stay in registers for this)
                         const u32x4* cell = (const u32x4*)((const uint8_t*)a.cells + (code_n(E.X, Cn) << 5));
                         E.c0 = cell[0]; E.c1 = cell[1];
                         const uint32_t idx = E.idx;
-                        P.matches(E, 2u, 0xFFFFFFFFu, [&](uint32_t kk2, int32_t v) { out[oe - kk2] = make_uint2(idx, (uint32_t)v); });
+                        P.matches(E, from, 0xFFFFFFFFu, [&](uint32_t kk2, int32_t v) { out[oe - kk2] = make_uint2(idx, (uint32_t)v); });
                     }
                 }
             }
