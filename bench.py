@@ -405,7 +405,7 @@ def main():
         used_ppm = args.mode == "iter" and image.ppm_kernel(stride=L0, has_offsets=d_off0 is not None, variant=args.variant, min_hay_len=shortest0,
                                                               dev_hay=d_hay.data_ptr(), n_hay=n0)
         if args.mode != "iter":
-            walk_kernel, walk_bytes = "k_walk_long", H + 12 * Nh
+            walk_kernel, walk_bytes = "k_walk_long_sel", H + 12 * Nh
         elif used_ppm == "stream":
             # the scan kernel reads the haystack, writes every record (to the pool) and one offset per haystack
             walk_kernel, walk_bytes = "k_ppm_stream", H + 8 * M + (4 if d_off0 is None else 12) * Nh

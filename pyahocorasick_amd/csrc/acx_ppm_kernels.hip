@@ -1123,12 +1123,12 @@ __global__ void __launch_bounds__(ACX_PPM_BLOCK) k_ppm_stream(const acx_ppm_args
                 PPM_SLOTS(e,
                     const uint32_t c = cn[e]; const uint32_t oe = ex[e] + c - 1u;
                     *(uint2*)(out8 + ((c ? oe : rt) << 3)) = make_uint2(rr[e], (uint32_t)va[e]);
-                    const uint32_t mine = vbe == (uint32_t)e ? 1u : 0u;
-                    two |= ((c > 1u ? 1u : 0u) & mine) << e;
-                    slow1 |= ((c > 1u ? 1u : 0u) & (mine ^ 1u)) << e;
+                    two |= (c > 1u ? 1u : 0u) << e;
                     slow |= (c > 2u ? 1u : 0u) << e;
                 )
                 if (__any(two != 0u)) {
+                    const uint32_t mine = vbe < (uint32_t)NE ? 1u << vbe : 0u;   // the slot whose second value vb1 holds
+                    slow1 = two & ~mine; two &= mine;
                     PPM_SLOTS(e,
                         if ((two >> e) & 1u) *(uint2*)(out8 + ((ex[e] + cn[e] - 2u) << 3)) = make_uint2(rr[e], (uint32_t)vb1);
                     )

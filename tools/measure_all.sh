@@ -10,7 +10,7 @@ CFGS=${@:-c2 c5 c3 c4}
 for CFG in $CFGS; do
   case $CFG in
     c2) BARGS="--steps 20 --warmup 4"; MARGS=""; KEY=c2_iter; KERNEL=k_ppm_stream;;
-    c5) BARGS="--mode iter_long --steps 20 --warmup 4 --cpu-sample-reads 200000"; MARGS="--mode iter_long"; KEY=c2_iter_long; KERNEL=k_walk_long;;
+    c5) BARGS="--mode iter_long --steps 20 --warmup 4 --cpu-sample-reads 200000"; MARGS="--mode iter_long"; KEY=c2_iter_long; KERNEL=k_walk_long_sel;;
     c3) BARGS="--workload c3 --steps 12 --warmup 4"; MARGS="--alphabet text --bytes 536870912"; KEY=c3_iter; KERNEL=k_ppm_stream;;
     c4) BARGS="--workload c4 --steps 12 --warmup 4"; MARGS="--alphabet snort --keys 1000000 --bytes 536870912"; KEY=c4_iter; KERNEL=k_ppm_stream;;
   esac
