@@ -71,3 +71,39 @@ def test_min_hay_len_promise_broken_is_detected_and_rescanned():
     moff, e, v, _ = sc.fetch()
     mo, oe, ov = O.batch(flat.tobytes(), off, 0)
     assert np.array_equal(moff, mo) and np.array_equal(e, oe) and np.array_equal(v, ov)
+
+
+def test_one_scanner_through_batches_of_every_shape():
+    """What a result object carries from one scan to the next — control words that the gather of a fixed-stride scan
+    zeroes, block sums kept in two alternating sets, buffers that grow — survives any order of batch shapes: fixed
+    stride small and large (a record pool that overflows and is issued again), offsets, a broken promise, other kernel
+    families in between, asynchronous and not."""
+    rng = np.random.default_rng(77)
+    alpha = np.frombuffer(b"ACGT", dtype=np.uint8)
+    keys = list({bytes(alpha[rng.integers(0, 4, size=int(k))]) for k in rng.integers(3, 12, size=500)})
+    A, O = build_pair(keys)
+    img = Image.from_automaton(A)
+    sc = Scanner(img)
+    shapes = [("stride", 300, 120), ("stride", 60000, 150), ("offsets", 500, 0), ("stride", 40, 64), ("stride", 200000, 100),
+              ("broken", 800, 0), ("stride", 5000, 33), ("serial", 700, 90), ("general", 900, 80), ("stride", 60000, 150),
+              ("stride", 1, 4096), ("offsets", 3000, 0), ("stride", 70000, 151)]
+    for i, (kind, n, L) in enumerate(shapes):
+        asynchronous = i % 2 == 1
+        if kind in ("stride", "serial", "general"):
+            flat = np.ascontiguousarray(alpha[rng.integers(0, 4, size=n * L)])
+            off = np.arange(n + 1, dtype=np.int64) * L
+            variant = {"stride": 0, "serial": 1 << 23, "general": (1 << 24) | (1 << 28)}[kind]
+            d_hay = DeviceBuffer.from_numpy(flat, pad=64)
+            sc.scan(d_hay, len(flat), n, stride=L, variant=variant, asynchronous=asynchronous)
+        else:
+            lens = rng.integers(8, 300, size=n)
+            if kind == "broken":
+                lens[::7] = 0
+            off = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+            flat = np.ascontiguousarray(alpha[rng.integers(0, 4, size=int(off[-1]))])
+            d_hay = DeviceBuffer.from_numpy(flat, pad=64)
+            d_off = DeviceBuffer.from_numpy(off)
+            sc.scan(d_hay, len(flat), n, dev_off=d_off, min_hay_len=8, asynchronous=asynchronous)
+        moff, e, v, _ = sc.fetch()
+        mo, oe, ov = O.batch(flat.tobytes(), off, 0)
+        assert np.array_equal(moff, mo) and np.array_equal(e, oe) and np.array_equal(v, ov), (i, kind, n, L)
