@@ -18,6 +18,8 @@
 #include <cstring>
 #include <new>
 #include <atomic>
+#include <exception>
+#include <mutex>
 #include <thread>
 #include <vector>
 
@@ -26,6 +28,23 @@ static_assert(sizeof(acx_ppm_header) == 256, "acx_ppm_header must be exactly 256
 namespace {
 
 inline size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
+
+// Threads that must not take the process down: what a job throws (std::bad_alloc, in practice) is caught on its thread
+// and thrown again on the caller's, after every thread has been joined (emplace_back itself may throw, too).
+struct Gang {
+    std::vector<std::thread> th;
+    std::mutex mu;
+    std::exception_ptr first;
+    template <class F> void guarded(F&& f) noexcept {
+        try { f(); } catch (...) { std::lock_guard<std::mutex> g(mu); if (!first) first = std::current_exception(); }
+    }
+    template <class F> void spawn(F f) {
+        try { th.emplace_back([this, f]() mutable { guarded(f); }); }
+        catch (...) { std::lock_guard<std::mutex> g(mu); if (!first) first = std::current_exception(); }
+    }
+    void join() { for (auto& x : th) x.join(); th.clear(); if (first) { std::exception_ptr e = first; first = nullptr; std::rethrow_exception(e); } }
+    ~Gang() { for (auto& x : th) if (x.joinable()) x.join(); }
+};
 
 // The trie of the REVERSED keys of `t`, built in one pass over the sorted reversed keys (a key shares a prefix
 // with its predecessor: pop to that depth, append the rest).  Children come out in ascending letter order and are
@@ -69,10 +88,10 @@ int build_reversed(const acx_trie* t, acx_trie* rev, std::vector<int32_t>* depth
         {
             size_t T = acx_host_threads();
             if (t->nodes.size() < 200000 || T > tops.size()) T = t->nodes.size() < 200000 ? 1 : tops.size();
-            std::vector<std::thread> th;
-            for (size_t k = 1; k < T; k++) th.emplace_back(worker);
-            worker();
-            for (auto& x : th) x.join();
+            Gang gang;
+            for (size_t k = 1; k < T; k++) gang.spawn([&] { worker(); });
+            gang.guarded(worker);
+            gang.join();
         }
         size_t total = 0, nkeys = 0;
         for (const Part& P : parts) { total += P.buf.size(); nkeys += P.val.size(); }
@@ -100,18 +119,18 @@ int build_reversed(const acx_trie* t, acx_trie* rev, std::vector<int32_t>* depth
         std::vector<size_t> cut(runs + 1);
         for (size_t r = 0; r <= runs; r++) cut[r] = nk * r / runs;
         {
-            std::vector<std::thread> th;
-            for (size_t r = 1; r < runs; r++) th.emplace_back([&, r] { std::sort(idx.begin() + cut[r], idx.begin() + cut[r + 1], less); });
-            std::sort(idx.begin() + cut[0], idx.begin() + cut[1], less);
-            for (auto& x : th) x.join();
+            Gang gang;
+            for (size_t r = 1; r < runs; r++) gang.spawn([&, r] { std::sort(idx.begin() + cut[r], idx.begin() + cut[r + 1], less); });
+            gang.guarded([&] { std::sort(idx.begin() + cut[0], idx.begin() + cut[1], less); });
+            gang.join();
         }
         for (size_t w = 1; w < runs; w *= 2) {
-            std::vector<std::thread> th;
+            Gang gang;
             for (size_t r = 0; r + w < runs; r += 2 * w) {
                 const size_t a = cut[r], m = cut[r + w], e = cut[r + 2 * w < runs ? r + 2 * w : runs];
-                th.emplace_back([&, a, m, e] { std::inplace_merge(idx.begin() + a, idx.begin() + m, idx.begin() + e, less); });
+                gang.spawn([&, a, m, e] { std::inplace_merge(idx.begin() + a, idx.begin() + m, idx.begin() + e, less); });
             }
-            for (auto& x : th) x.join();
+            gang.join();
         }
     }
     // 3. build
@@ -444,5 +463,7 @@ int acx_ppm_build(const acx_trie* t, const uint8_t* cls, uint32_t n_classes, boo
         return ACX_OK;
     } catch (const std::bad_alloc&) {
         return acx_fail(ACX_E_NOMEM, "acx_ppm_build: out of memory");
+    } catch (const std::exception& e) {                             // (a thread that could not be started, ...)
+        return acx_fail(ACX_E_NOMEM, "acx_ppm_build: %s", e.what());
     }
 }
