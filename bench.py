@@ -69,6 +69,9 @@ def parse():
                     help="bracket the dominant kernel by HIP events in every N-th timed step (0: in none).  Two event records cost "
                          "the stream about 19 us of idle time per step they are in (config 2: 442 GB/s with events in every step, "
                          "468 in every fourth, 472 in none)")
+    ap.add_argument("--no-e2e", action="store_true",
+                    help="skip the host-to-host leg (end_to_end_GBps): it scans the batch in groups, whose short launches would mix into "
+                         "the per-kernel averages of a rocprofv3 --stats run of this command")
     ap.add_argument("--cpu-sample-reads", type=int, default=None,
                     help="haystacks timed on the CPU baseline legs (default: the whole first batch; 0 disables)")
     ap.add_argument("--verify", action="store_true", help="check the first batch's GPU output against the oracle (all records)")
@@ -465,7 +468,7 @@ def main():
             },
             "setup": {"build_flatten_s": round(t_build, 3), "broadcast_upload_s": round(t_bcast, 3), "stage_batches_s": round(t_stage, 3)},
         }
-        if world == 1 and e2e0 is not None and args.mode == "iter":
+        if world == 1 and e2e0 is not None and args.mode == "iter" and not args.no_e2e:
             # PCIe-inclusive (SURVEY §8d "also report end-to-end"): host buffers in, offsets and records back in host
             # memory — acx_scan_host_ctx + acx_result_fetch_host, what Automaton.iter / find_all / iter_batch call.
             # Never `value`.  (On this box H2D and D2H do not overlap: profiles/r3_pcie_probe.txt.)

@@ -302,8 +302,9 @@ void acx_result_free(acx_result_t* r);
  *    This is what a CPython binding for Automaton.iter()/find_all() on a large haystack,
  *    or a new Automaton.iter_batch(), calls.  PCIe-inclusive by construction.
  *    A batch larger than one launch can stage (4 GiB of haystack) is scanned in groups of whole
- *    haystacks; acx_result_fetch_host returns the assembled result (the *_dev accessors then only
- *    see the last group).
+ *    haystacks; a large batch of equally long haystacks is scanned as a pipeline of groups whose records are written
+ *    straight into the result's pinned host buffers while the next group is uploaded.  Either way the result of these
+ *    entry points is what acx_result_fetch_host returns; the *_dev accessors are for acx_scan_batch.
  * ---------------------------------------------------------------------------------- */
 int  acx_scan_host(acx_image_t* img, int mode, const uint8_t* hay, const int64_t* off, int64_t n_hay,
                    const int32_t* init_state, const int32_t* index_base,

@@ -11,7 +11,9 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <atomic>
 #include <mutex>
+#include <thread>
 #include <new>
 #include <vector>
 
@@ -395,6 +397,10 @@ struct acx_result {
     // scan kernel (instruction bound) of another result on the caller's stream overlaps it
     bool use_side = false; hipStream_t side = nullptr; hipEvent_t ev_scan = nullptr;
     bool ctl_zero = false;      // ppm_ctl is known to be all zero (the gather of the last fixed-stride stream scan cleaned up)
+    // acx_scan_host, pipelined (scan_host_pipelined): the gather of a fixed-stride stream scan writes records and offsets
+    // straight into the result's pinned host buffers (device-mapped pointers) instead of r->matches / r->match_off
+    uint2* ext_matches = nullptr; int64_t ext_capacity = 0; int64_t* ext_match_off = nullptr;
+    hipStream_t copy_stream = nullptr;
     bool ppm_self = false;      // the pending stream scan is a fixed-stride one: block sums, totals and clean-up in k_ppm_gather_pos
     int bs_parity = 0;          // which half of wave_aux the next such scan sums into
     acx_image* pend_img = nullptr;
@@ -441,11 +447,13 @@ struct acx_result {
         if (done) (void)hipEventDestroy(done);
         if (ev_scan) (void)hipEventDestroy(ev_scan);
         if (side) (void)hipStreamDestroy(side);
+        if (copy_stream) (void)hipStreamDestroy(copy_stream);
     }
 };
 
 static int ppm_enqueue(acx_result* r, acx_image* img, const acx_chunk_args* ca, const acx_walk_args* tail, hipStream_t s);
 static int ppm_size_pool(acx_result* r, size_t records);
+enum { ACX_HOST_RETRY = 1 };            // internal: the pipelined host scan could not be used; scan_host_once takes the staged path
 static int scan_batch_inner(acx_image_t* img, const acx_scan_params* p, acx_result_t** result, void* stream_v);
 
 // dev_skip after a scan on kernels that do not know it (the serial walks, k_ppm_scan): drop the records of every
@@ -510,11 +518,13 @@ static int ppm_complete(acx_result* r) {
         }
         r->total = r->h_total.p[0];
         const bool overflow = (int32_t)r->h_total.p[1] != 0;
-        const bool small = r->total > (int64_t)r->matches.cap;
+        const bool ext = r->ppm_stream && r->ppm_self && r->ext_matches;
+        const bool small = r->total > (ext ? r->ext_capacity : (int64_t)r->matches.cap);
         if (!overflow && !small) break;
+        if (ext && small && !overflow) return ACX_HOST_RETRY;          // (the caller's buffer: it falls back to the staged path)
         if (attempt >= 4) return acx_fail(ACX_E_NOMEM, "position-parallel scan: record pool still too small after %d attempts", attempt);
         int rc;
-        if (small) {
+        if (small && !ext) {
             if ((rc = r->matches.ensure((size_t)r->total))) return rc;
             r->pend_ca.matches = r->matches.p; r->pend_ca.capacity = (int64_t)r->matches.cap;
             r->pend_ga.matches = r->matches.p; r->pend_ga.capacity = (int64_t)r->matches.cap;
@@ -839,7 +849,8 @@ static int scan_ppm(acx_image_t* img, const acx_scan_params* p, acx_result* r, h
         memset(&ga, 0, sizeof ga);
         ga.wave_desc = r->wave_desc.p; ga.wave_off = r->ck_match_off.p; ga.n_waves = n_waves;
         ga.matches = r->matches.p; ga.capacity = (int64_t)r->matches.cap;
-        ga.hay_local = r->hay_local.p; ga.match_off = r->match_off.p; ga.n_hay = p->n_hay; ga.stride = p->stride;
+        ga.hay_local = r->hay_local.p; ga.match_off = r->match_off.p;
+        if (!chunked && r->ext_matches) { ga.matches = r->ext_matches; ga.capacity = r->ext_capacity; ga.match_off = r->ext_match_off; } ga.n_hay = p->n_hay; ga.stride = p->stride;
         ga.off = chunked ? p->dev_off : nullptr;
         ga.tile_pos = tpos; ga.tpw = (stream_tiles + n_waves - 1) / n_waves;
         ga.stride_magic = pa.stride_magic; ga.index_base = chunked ? nullptr : p->dev_index_base; ga.skip = chunked ? nullptr : p->dev_skip;
@@ -1132,6 +1143,87 @@ extern "C" int acx_result_timing(acx_result_t* r, float* walk_ms, float* scan_ms
     return ACX_OK;
 }
 
+// A fixed-stride batch, host to host, as a pipeline of groups of haystacks: the copy engine uploads group k + 1 while
+// group k is scanned and its gather writes records and offsets STRAIGHT into the result's pinned host buffers (the
+// kernel stores go over PCIe themselves).  Why this shape: on this box two copies in opposite directions crawl (15 GB/s
+// each way), a kernel that writes pinned host memory beside an upload does not (43 GB/s each way;
+// profiles/r3_pcie_probe.txt).  Returns ACX_HOST_RETRY when it does not apply (not the stream kernel's batch, or the
+// records outgrew the host buffer: the staged path grows it); the result is then untouched as far as callers see.
+static int scan_host_pipelined(acx_image_t* img, const uint8_t* hay, int64_t n_hay, int64_t L, const int32_t* index_base,
+                               acx_result* r, int32_t flags) {
+    const int64_t total_bytes = n_hay * L;
+    if (flags || total_bytes < ((int64_t)16 << 20) || n_hay < 4096) return ACX_HOST_RETRY;
+    int G = (int)(total_bytes >> 25);                                  // groups of about 32 MB
+    G = G < 2 ? 2 : (G > 8 ? 8 : G);
+    int rc;
+    if ((rc = r->in_hay.ensure((size_t)total_bytes + 64))) return rc;
+    {
+        acx_scan_params q;
+        memset(&q, 0, sizeof q);
+        q.struct_bytes = sizeof q; q.mode = ACX_SCAN_ALL; q.dev_hay = r->in_hay.p; q.hay_capacity = total_bytes / G; q.stride = L; q.n_hay = n_hay / G;
+        if (ppm_plan(img, &q) != 2) return ACX_HOST_RETRY;
+    }
+    if (r->pending) { int rcw = result_complete(r); if (rcw) return rcw; }
+    if ((rc = r->h_off.ensure((size_t)n_hay + 2))) return rc;
+    {   // room for the records: what earlier calls needed, or one per eight bytes
+        const size_t want = (size_t)(total_bytes / 8) + 1024;
+        if (r->h_matches.cap < want && (rc = r->h_matches.ensure(want))) return rc;
+    }
+    if (index_base) {
+        if ((rc = r->in_base.ensure((size_t)n_hay + 1))) return rc;
+        HIP_TRY(hipMemcpy(r->in_base.p, index_base, (size_t)n_hay * 4, hipMemcpyHostToDevice));
+    }
+    if (!r->copy_stream) HIP_TRY(hipStreamCreateWithFlags(&r->copy_stream, hipStreamNonBlocking));
+    void* d_m = nullptr; void* d_o = nullptr;
+    HIP_TRY(hipHostGetDevicePointer(&d_m, r->h_matches.p, 0));
+    HIP_TRY(hipHostGetDevicePointer(&d_o, r->h_off.p, 0));
+    auto first = [&](int g) { return g >= G ? n_hay : (n_hay * g / G) & ~(int64_t)15; };   // (a group starts 16-byte aligned: 16 haystacks of any length)
+    // The uploads run on a thread of their own: the caller's buffer is pageable, and a copy from pageable memory keeps
+    // the calling thread until it is done — queued from this thread they would all be over before the first scan starts.
+    std::atomic<int> uploaded{0}, up_err{0};
+    int dev_id = 0;
+    HIP_TRY(hipGetDevice(&dev_id));
+    std::thread uploader([&] {
+        if (hipSetDevice(dev_id) != hipSuccess) { up_err.store(1); return; }
+        for (int g = 0; g < G; g++) {
+            const int64_t h0 = first(g), h1 = first(g + 1);
+            hipError_t e = hipMemcpyAsync(r->in_hay.p + h0 * L, hay + h0 * L, (size_t)((h1 - h0) * L), hipMemcpyHostToDevice, r->copy_stream);
+            if (e == hipSuccess) e = hipStreamSynchronize(r->copy_stream);
+            if (e != hipSuccess) { up_err.store(1); return; }
+            uploaded.store(g + 1, std::memory_order_release);
+        }
+    });
+    struct Joiner { std::thread& t; ~Joiner() { if (t.joinable()) t.join(); } } joiner{uploader};
+    int64_t done = 0;
+    int out = ACX_OK;
+    for (int g = 0; g < G && out == ACX_OK; g++) {
+        const int64_t h0 = first(g), h1 = first(g + 1);
+        while (uploaded.load(std::memory_order_acquire) <= g && !up_err.load()) std::this_thread::yield();
+        if (up_err.load()) { out = acx_fail(ACX_E_HIP, "acx_scan_host: the upload of a group failed"); break; }
+        acx_scan_params q;
+        memset(&q, 0, sizeof q);
+        q.struct_bytes = sizeof q; q.mode = ACX_SCAN_ALL;
+        q.dev_hay = r->in_hay.p + h0 * L; q.hay_capacity = (h1 - h0) * L; q.stride = L; q.n_hay = h1 - h0;
+        q.dev_index_base = index_base ? r->in_base.p + h0 : nullptr;
+        r->ext_matches = (uint2*)d_m + done; r->ext_capacity = (int64_t)r->h_matches.cap - done; r->ext_match_off = (int64_t*)d_o + h0;
+        acx_result* self = r;
+        out = scan_batch_inner(img, &q, &self, nullptr);              // (synchronous: the gather has written when it returns)
+        if (out == ACX_OK && !(r->ppm_stream && r->ppm_self)) out = ACX_HOST_RETRY;      // (not the kernels this path is for)
+        if (out != ACX_OK) break;
+        if (done) for (int64_t h = h0; h < h1; h++) r->h_off.p[h] += done;               // the group's offsets count from its first record
+        done += r->total;
+    }
+    r->ext_matches = nullptr; r->ext_capacity = 0; r->ext_match_off = nullptr;
+    uploader.join();                                                   // (the uploads read the caller's buffer)
+    if (out != ACX_OK) {
+        if (out == ACX_HOST_RETRY) (void)r->h_matches.ensure(r->h_matches.cap * 2);     // the staged path would need it as well
+        return out;
+    }
+    r->h_off.p[n_hay] = done;
+    r->n_hay = n_hay; r->total = done; r->has_final = false; r->host_valid = true;
+    return ACX_OK;
+}
+
 // one group of haystacks that fits a launch: H2D, scan; `off` starts at 0
 static int scan_host_once(acx_image_t* img, int mode, const uint8_t* hay, const int64_t* off, int64_t n_hay,
                           const int32_t* init_state, const int32_t* index_base, acx_result_t** result, int want_final, int32_t flags) {
@@ -1149,6 +1241,10 @@ static int scan_host_once(acx_image_t* img, int mode, const uint8_t* hay, const 
         uniform = uniform && l == L0;
     }
     const bool as_stride = uniform && L0 > 0 && L0 <= INT32_MAX;
+    if (as_stride && mode == ACX_SCAN_ALL && !init_state && !want_final) {
+        rc = scan_host_pipelined(img, hay, n_hay, L0, index_base, r, flags);
+        if (rc != ACX_HOST_RETRY) return rc;
+    }
     if ((rc = r->in_hay.ensure((size_t)total_bytes + 64))) return rc;
     if (total_bytes) HIP_TRY(hipMemcpyAsync(r->in_hay.p, hay, (size_t)total_bytes, hipMemcpyHostToDevice, nullptr));
     if (!as_stride) {

@@ -860,3 +860,31 @@ def test_dev_skip_streams_on_every_kernel_family():
                     for i in range(n_streams):
                         got[i] += list(zip(e[moff[i]:moff[i + 1]].tolist(), v[moff[i]:moff[i + 1]].tolist()))
                 assert got == want, (alpha_b[:4], variant, layout)
+
+
+def test_host_to_host_pipeline_of_groups_equals_the_oracle():
+    """acx_scan_host on a large batch of equally long haystacks: groups of haystacks whose records the gather writes
+    straight into the result's pinned host buffers while the next group is uploaded (scan_host_pipelined).  Every offset
+    and record against the oracle, with and without index bases, on a batch whose groups do not divide evenly; then a
+    batch whose records outgrow the host buffer's first estimate (the staged path takes over) and a small one (staged)."""
+    rng = np.random.default_rng(99)
+    alpha = np.frombuffer(b"ACGT", dtype=np.uint8)
+    keys = list({bytes(alpha[rng.integers(0, 4, size=int(k))]) for k in rng.integers(6, 14, size=3000)})
+    A, O = build_pair(keys)
+    for n, L, use_base in ((300_007, 150, False), (200_001, 100, True), (5000, 150, False)):
+        flat = np.ascontiguousarray(alpha[rng.integers(0, 4, size=n * L)])
+        off = np.arange(n + 1, dtype=np.int64) * L
+        base = rng.integers(0, 1 << 20, size=n).astype(np.int32) if use_base else None
+        res = A.scan_batch(flat, off, index_base=base)
+        mo, oe, ov = O.batch(flat.tobytes(), off, 0)
+        if use_base:
+            oe = oe + np.repeat(base, np.diff(mo)).astype(np.int32)
+        assert np.array_equal(res.offsets, mo) and np.array_equal(res.end_index, oe) and np.array_equal(res.value, ov), (n, L)
+    # dense matches: short keys everywhere -> far more than one record per eight bytes
+    A2, O2 = build_pair([b"A", b"C", b"AC", b"CA", b"G", b"GT", b"T"])
+    n, L = 200_000, 100
+    flat = np.ascontiguousarray(alpha[rng.integers(0, 4, size=n * L)])
+    off = np.arange(n + 1, dtype=np.int64) * L
+    res = A2.scan_batch(flat, off)
+    mo, oe, ov = O2.batch(flat.tobytes(), off, 0)
+    assert np.array_equal(res.offsets, mo) and np.array_equal(res.end_index, oe) and np.array_equal(res.value, ov)

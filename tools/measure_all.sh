@@ -35,9 +35,9 @@ except Exception as e:
     print("no bench line:", e); print(open("$OUT/${T}_bench.err").read()[-1500:])
 PY
   echo "== $CFG: rocprofv3 --kernel-trace --stats"
-  cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats -d $OUT/${T}_prof -o stats -- python $R/bench.py $BARGS --cpu-sample-reads 0 > $OUT/${T}_prof_bench.json 2> $OUT/${T}_prof.err; echo "rocprof rc=$?"
+  cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats -d $OUT/${T}_prof -o stats -- python $R/bench.py $BARGS --cpu-sample-reads 0 --no-e2e > $OUT/${T}_prof_bench.json 2> $OUT/${T}_prof.err; echo "rocprof rc=$?"
   cd $R
-  python tools/rocpd_summary.py $(find $OUT/${T}_prof -name "*.db" | head -1) $OUT/${T}_kernel_stats "rocprofv3 --kernel-trace --stats -- python bench.py $BARGS --cpu-sample-reads 0" > /dev/null 2>&1 && head -8 $OUT/${T}_kernel_stats.md
+  python tools/rocpd_summary.py $(find $OUT/${T}_prof -name "*.db" | head -1) $OUT/${T}_kernel_stats "rocprofv3 --kernel-trace --stats -- python bench.py $BARGS --cpu-sample-reads 0 --no-e2e" > /dev/null 2>&1 && head -8 $OUT/${T}_kernel_stats.md
   rm -rf $OUT/${T}_prof
 done
 cp profiles/traffic.json $OUT/${TAG}_traffic.json
