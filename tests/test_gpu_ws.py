@@ -163,3 +163,28 @@ def test_iterators_of_both_host_sides_ignore_white_space(ahocorasick):
             it.set(text[cut:nxt])
             got += list(it)
         assert got == O.iter(text, ignore_ws=True)
+
+
+def test_reference_white_space_fixtures_on_both_host_sides(ahocorasick):
+    """tests/golden/ref_ws.json (written by the reference, tests/golden/make_ws_golden.py): iter(..., ignore_white_space=True)
+    on whole strings and slices, and a stream continued with iter().set(chunk) — drop-in extension and ctypes mirror"""
+    import pyahocorasick_amd as acx
+    from helpers import expected_pairs, load_json
+    for c in load_json("ref_ws.json")["cases"]:
+        keys = [bytes.fromhex(k) for k in c["keys_hex"]]
+        for mod in (ahocorasick, acx):
+            A = mod.Automaton()
+            for i, k in enumerate(keys):
+                A.add_word(k, i)
+            A.make_automaton()
+            for h in c["hays"]:
+                hay = bytes.fromhex(h["hay_hex"])
+                assert list(A.iter(hay, ignore_white_space=True)) == expected_pairs(h["iter_ws"]), c["id"]
+                assert list(A.iter(hay)) == expected_pairs(h["iter"]), c["id"]
+                if "slice" in h:
+                    s = h["slice"]
+                    assert list(A.iter(hay, s["start"], s["end"], ignore_white_space=True)) == expected_pairs(s["iter_ws"]), c["id"]
+            it = A.iter(b"", ignore_white_space=True)
+            for chunk_hex, exp in zip(c["stream"]["chunks_hex"], c["stream"]["iter_ws_set"]):
+                it.set(bytes.fromhex(chunk_hex))
+                assert list(it) == expected_pairs(exp), c["id"]

@@ -281,3 +281,29 @@ def test_itop_flags_of_the_flat_image():
         assert bool(flags & 1) == (complete + 2 >= D), (D, complete, flags)
         both.add(flags & 1)
     assert both == {0, 1}
+
+
+# ----------------------------------------------------------------------------------------
+# ignore_white_space: fixtures written by the reference (tests/golden/make_ws_golden.py)
+# ----------------------------------------------------------------------------------------
+WS_CASES = load_json("ref_ws.json")["cases"]
+
+
+@pytest.mark.parametrize("c", WS_CASES, ids=[c["id"] for c in WS_CASES])
+def test_oracle_ignore_white_space_matches_reference_fixtures(c):
+    keys = [bytes.fromhex(k) for k in c["keys_hex"]]
+    O = _oracle_from(keys, list(range(len(keys))))
+    for h in c["hays"]:
+        hay = bytes.fromhex(h["hay_hex"])
+        assert O.iter(hay, ignore_ws=True) == expected_pairs(h["iter_ws"])
+        assert O.iter(hay) == expected_pairs(h["iter"])
+        if "slice" in h:
+            s = h["slice"]
+            assert O.iter(hay, s["start"], s["end"], ignore_ws=True) == expected_pairs(s["iter_ws"])
+    # the stream: state and shift carried across set(chunk), src/AutomatonSearchIter.c:303-368
+    state, shift = 0, 0
+    for chunk_hex, exp in zip(c["stream"]["chunks_hex"], c["stream"]["iter_ws_set"]):
+        chunk = bytes.fromhex(chunk_hex)
+        e, v, state = O.iter_arrays(chunk, 0, len(chunk), ignore_ws=True, state=state, shift=shift)
+        assert list(zip(e.tolist(), v.tolist())) == expected_pairs(exp)
+        shift += len(chunk)
