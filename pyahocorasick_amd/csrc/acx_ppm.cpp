@@ -50,6 +50,9 @@ struct Gang {
 // with its predecessor: pop to that depth, append the rest).  Children come out in ascending letter order and are
 // linked in O(1); acx_trie_add_word would walk sibling lists, which are 256 long at the top of a signature trie.
 int build_reversed(const acx_trie* t, acx_trie* rev, std::vector<int32_t>* depth_out) {
+    const bool timing_ = getenv("ACX_PPM_TIMING") != nullptr;
+    auto t0_ = std::chrono::steady_clock::now();
+    auto lap_ = [&](const char* what) { if (timing_) { auto t1 = std::chrono::steady_clock::now(); fprintf(stderr, "[build_reversed] %s: %.3f s\n", what, std::chrono::duration<double>(t1 - t0_).count()); t0_ = t1; } };
     // 1. collect: DFS with an explicit stack; every key reversed into one buffer
     std::vector<uint8_t> buf;
     std::vector<uint64_t> koff;                 // key k = buf[koff[k] .. koff[k+1])
@@ -103,6 +106,7 @@ int build_reversed(const acx_trie* t, acx_trie* rev, std::vector<int32_t>* depth
         }
     }
     const size_t nk = kval.size();
+    lap_("collect");
     // 2. sort the reversed keys
     std::vector<uint32_t> idx(nk);
     for (size_t i = 0; i < nk; i++) idx[i] = (uint32_t)i;
@@ -133,39 +137,119 @@ int build_reversed(const acx_trie* t, acx_trie* rev, std::vector<int32_t>* depth
             gang.join();
         }
     }
-    // 3. build
-    rev->nodes.clear();
-    rev->nodes.reserve(buf.size() / 2 + 16);
-    rev->new_node(0);
-    std::vector<int32_t>& depth = *depth_out;   // per node; the arena comes out in pre-order (a parent before its children)
-    depth.clear(); depth.reserve(buf.size() / 2 + 16);
-    depth.push_back(0);
-    std::vector<int32_t> last_child;            // per node: its most recent child (siblings are appended in order)
-    last_child.push_back(-1);
-    std::vector<int32_t> stack;                 // stack[d] = node at depth d on the current key's path
-    stack.push_back(0);
-    const uint8_t* prev = nullptr; size_t prev_len = 0;
-    for (size_t q = 0; q < nk; q++) {
-        const uint8_t* key = b + koff[idx[q]];
-        const size_t len = (size_t)(koff[idx[q] + 1] - koff[idx[q]]);
-        size_t lcp = 0;
-        const size_t m = len < prev_len ? len : prev_len;
-        while (lcp < m && key[lcp] == prev[lcp]) lcp++;
-        stack.resize(lcp + 1);
-        for (size_t d = lcp; d < len; d++) {
-            const int32_t parent = stack[d];
-            const int32_t c = rev->new_node(key[d]);
-            depth.push_back((int32_t)d + 1);
-            last_child.push_back(-1);
-            if (last_child[parent] < 0) rev->nodes[parent].first_child = c; else rev->nodes[last_child[parent]].next_sibling = c;
-            last_child[parent] = c;
-            if (parent == 0) rev->root_child[key[d]] = c;
-            stack.push_back(c);
+    lap_("sort");
+    // 3. build.  The subtrie below every child of the root is built on its own (the sorted keys of one first letter are one
+    // contiguous run), in an arena of its own, by the host threads; the arenas are then laid end to end in letter order,
+    // which is exactly the arena a single pass over all keys would produce (nodes in pre-order, a parent before its
+    // children): the same numbering, the same image, byte for byte.  (One pass took 0.8 s of the 6 s set-up of the
+    // million-signature dictionary: 33 M nodes, first touched by one thread.)
+    std::vector<int32_t>& depth = *depth_out;   // per node
+    struct Sub { std::vector<Node> nodes; std::vector<int32_t> depth; size_t lo = 0, hi = 0; };
+    std::vector<Sub> subs(256);
+    {
+        size_t q = 0;
+        for (int c = 0; c < 256; c++) {            // (no key is empty: the trie stores none)
+            subs[c].lo = q;
+            while (q < nk && b[koff[idx[q]]] == (uint8_t)c) q++;
+            subs[c].hi = q;
         }
-        Node& nd = rev->nodes[stack[len]];
-        nd.eow = 1; nd.value = kval[idx[q]];
-        prev = key; prev_len = len;
+        if (q != nk) return acx_fail(ACX_E_FORMAT, "acx_ppm_build: reversed keys out of order");
     }
+    auto build_sub = [&](Sub& S, uint8_t letter) {
+        size_t bytes = 0;
+        for (size_t q = S.lo; q < S.hi; q++) bytes += (size_t)(koff[idx[q] + 1] - koff[idx[q]]);
+        S.nodes.reserve(bytes); S.depth.reserve(bytes);      // (an upper bound: every byte of every key a node)
+        std::vector<int32_t> last_child;        // per local node: its most recent child (siblings are appended in order)
+        std::vector<int32_t> stack;             // stack[d - 1] = local node at depth d on the current key's path
+        auto new_local = [&](uint8_t l, int32_t d) -> int32_t {
+            Node n;
+            n.value = 0; n.first_child = -1; n.next_sibling = -1; n.fail = -1; n.letter = l; n.eow = 0; n.wide = 0;
+            S.nodes.push_back(n); S.depth.push_back(d); last_child.push_back(-1);
+            return (int32_t)S.nodes.size() - 1;
+        };
+        stack.push_back(new_local(letter, 1));
+        const uint8_t* prev = nullptr; size_t prev_len = 0;
+        for (size_t q = S.lo; q < S.hi; q++) {
+            const uint8_t* key = b + koff[idx[q]];
+            const size_t len = (size_t)(koff[idx[q] + 1] - koff[idx[q]]);
+            size_t lcp = 1;                         // (the first letter is the sub's own)
+            const size_t m = len < prev_len ? len : prev_len;
+            while (lcp < m && key[lcp] == prev[lcp]) lcp++;
+            stack.resize(lcp);
+            for (size_t d = lcp; d < len; d++) {
+                const int32_t parent = stack[d - 1];
+                const int32_t c = new_local(key[d], (int32_t)d + 1);
+                if (last_child[parent] < 0) S.nodes[parent].first_child = c; else S.nodes[last_child[parent]].next_sibling = c;
+                last_child[parent] = c;
+                stack.push_back(c);
+            }
+            Node& nd = S.nodes[stack[len - 1]];
+            nd.eow = 1; nd.value = kval[idx[q]];
+            prev = key; prev_len = len;
+        }
+    };
+    {
+        std::atomic<int> next{0};
+        auto worker = [&] { for (int c = next.fetch_add(1); c < 256; c = next.fetch_add(1)) if (subs[c].hi > subs[c].lo) build_sub(subs[c], (uint8_t)c); };
+        size_t T = acx_host_threads();
+        if (nk < 20000) T = 1;
+        Gang gang;
+        for (size_t k = 1; k < T; k++) gang.spawn([&] { worker(); });
+        // Meanwhile this thread makes the final arena (an upper bound of it: every byte of every key a node): zero-filling
+        // close to a gigabyte of fresh pages is the one serial piece left, so it runs beside the builders.
+        gang.guarded([&] {
+            if (T > 1) { rev->nodes.clear(); rev->nodes.resize(buf.size() + 1); depth.clear(); depth.resize(buf.size() + 1); }
+            worker();
+        });
+        gang.join();
+    }
+    lap_("subtries (and the arena)");
+    // the arenas end to end: local index i of sub c becomes first[c] + i
+    std::vector<int64_t> first(257);
+    first[0] = 1;
+    for (int c = 0; c < 256; c++) first[c + 1] = first[c] + (int64_t)subs[c].nodes.size();
+    if (first[256] > (int64_t)INT32_MAX) return acx_fail(ACX_E_UNSUPPORTED, "acx_ppm_build: more than 2^31 nodes");
+    if (rev->nodes.size() < (size_t)first[256]) rev->nodes.clear();     // (not pre-sized above: one thread)
+    rev->nodes.resize((size_t)first[256]);
+    if (depth.size() < (size_t)first[256]) depth.clear();
+    depth.resize((size_t)first[256]);
+    {
+        Node root;
+        root.value = 0; root.first_child = -1; root.next_sibling = -1; root.fail = -1; root.letter = 0; root.eow = 0; root.wide = 0;
+        int prev_c = -1;
+        for (int c = 0; c < 256; c++) {
+            if (subs[c].nodes.empty()) continue;
+            rev->root_child[c] = (int32_t)first[c];
+            if (prev_c < 0) root.first_child = (int32_t)first[c];
+            else subs[prev_c].nodes[0].next_sibling = (int32_t)(first[c] - first[prev_c]);      // (local to prev_c's arena: rebased with the rest below)
+            prev_c = c;
+        }
+        rev->nodes[0] = root; depth[0] = 0;
+        std::atomic<int> next{0};
+        auto worker = [&] {
+            for (int c = next.fetch_add(1); c < 256; c = next.fetch_add(1)) {
+                Sub& S = subs[c];
+                const int32_t off = (int32_t)first[c];
+                Node* dst = rev->nodes.data() + off;
+                for (size_t i = 0; i < S.nodes.size(); i++) {
+                    Node n = S.nodes[i];
+                    if (n.first_child >= 0) n.first_child += off;
+                    if (n.next_sibling >= 0) n.next_sibling += off;
+                    dst[i] = n;
+                }
+                if (!S.depth.empty()) memcpy(depth.data() + off, S.depth.data(), S.depth.size() * sizeof(int32_t));
+                std::vector<Node>().swap(S.nodes); std::vector<int32_t>().swap(S.depth);
+            }
+        };
+        size_t T = acx_host_threads();
+        if (nk < 20000) T = 1;
+        Gang gang;
+        for (size_t k = 1; k < T; k++) gang.spawn([&] { worker(); });
+        gang.guarded(worker);
+        gang.join();
+    }
+    rev->live_nodes = first[256];
+    lap_("arenas end to end");
     rev->kind = ACX_KIND_TRIE;
     rev->count = (int64_t)nk;
     rev->longest_word = t->longest_word;
