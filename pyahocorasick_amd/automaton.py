@@ -318,17 +318,22 @@ class Automaton:
     def add_words(self, keys, values=None):
         """Many keys in one call (not in the reference): the same as add_word(k, v) for every pair in order, without
         a Python call per key — one acx_trie_add_words for STORE_INTS / STORE_LENGTH.  Returns how many keys were new."""
-        keys = [self._key(k) for k in keys]
+        keys = keys if isinstance(keys, list) else list(keys)
+        if not all(map(bytes.__instancecheck__, keys)):
+            raise TypeError("bytes expected")
         if self._store == STORE_ANY:
             if values is None:
                 raise ValueError("A value object is required as second argument.")
             return sum(1 for k, v in zip(keys, values) if self.add_word(k, v))
         off = np.zeros(len(keys) + 1, dtype=np.int64)
-        np.cumsum([len(k) for k in keys], out=off[1:])
+        np.cumsum(np.fromiter(map(len, keys), dtype=np.int64, count=len(keys)), out=off[1:])
         buf = np.frombuffer(b"".join(keys), dtype=np.uint8) if off[-1] else np.zeros(1, dtype=np.uint8)
         vals = None
         if self._store == STORE_INTS and values is not None:
-            vals = np.array([((int(v) + (1 << 63)) % (1 << 64)) - (1 << 63) for v in values], dtype=np.int64)
+            try:                                # (a range, an array, a list of ints that fit 64 bits: no Python arithmetic per value)
+                vals = np.ascontiguousarray(values if isinstance(values, np.ndarray) else np.fromiter(values, dtype=np.int64), dtype=np.int64)
+            except (OverflowError, TypeError, ValueError):
+                vals = np.array([((int(v) + (1 << 63)) % (1 << 64)) - (1 << 63) for v in values], dtype=np.int64)   # wraps like the reference's C long
             if len(vals) != len(keys):
                 raise ValueError("add_words: %d keys, %d values" % (len(keys), len(vals)))
         n_new = C.c_int64(0)
