@@ -356,13 +356,26 @@ int acx_ppm_build(const acx_trie* t, const uint8_t* cls, uint32_t n_classes, boo
         std::vector<uint32_t> code(n, 0);
         std::vector<uint32_t> nkids(n, 0);
         uint32_t min_len = 0xFFFFFFFFu;
-        for (size_t i = 0; i < order.size(); i++) {
-            const int32_t u = order[i];
-            const Node& nd = rev.nodes[u];
-            if (nd.eow && (uint32_t)depth[u] < min_len) min_len = (uint32_t)depth[u];
-            for (int32_t c = nd.first_child; c >= 0; c = rev.nodes[c].next_sibling) {
-                nkids[u]++;
-                if ((uint32_t)depth[u] < (F2 > F ? F2 : F)) code[c] = code[u] * sigma + (uint32_t)symof[rev.nodes[c].letter];
+        {   // children per node and the shortest key: every node on its own, on the host threads
+            std::mutex mu;
+            parallel_range(0, n, [&](size_t a, size_t b2) {
+                uint32_t ml = 0xFFFFFFFFu;
+                for (size_t u = a; u < b2; u++) {
+                    const Node& nd = rev.nodes[u];
+                    if (nd.eow && (uint32_t)depth[u] < ml) ml = (uint32_t)depth[u];
+                    uint32_t k = 0;
+                    for (int32_t c = nd.first_child; c >= 0; c = rev.nodes[c].next_sibling) k++;
+                    nkids[u] = k;
+                }
+                std::lock_guard<std::mutex> g(mu);
+                if (ml < min_len) min_len = ml;
+            });
+        }
+        {   // codes: a child's from its parent's, parents first (the arena's order); only the top levels have any
+            const uint32_t lim = F2 > F ? F2 : F;
+            for (size_t u = 0; u < n; u++) {
+                if ((uint32_t)depth[u] >= lim) continue;
+                for (int32_t c = rev.nodes[u].first_child; c >= 0; c = rev.nodes[c].next_sibling) code[c] = code[u] * sigma + (uint32_t)symof[rev.nodes[c].letter];
             }
         }
         h.min_len = min_len;
