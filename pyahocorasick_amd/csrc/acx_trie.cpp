@@ -301,7 +301,15 @@ int acx_flatten(const acx_trie_t* t, void** blob_out, size_t* nbytes_out) {
 
     // 1. byte classes: class 0 = bytes used by no key (they all lead to the root)
     bool used[256] = {false};
-    for (size_t i = 1; i < n; i++) used[t->nodes[t->bfs[i]].letter] = true;
+    {
+        std::mutex mu;
+        parallel_range(1, n, [&](size_t a, size_t b2) {
+            bool mine[256] = {false};
+            for (size_t i = a; i < b2; i++) mine[t->nodes[t->bfs[i]].letter] = true;
+            std::lock_guard<std::mutex> g(mu);
+            for (int b = 0; b < 256; b++) used[b] = used[b] || mine[b];
+        });
+    }
     uint8_t cls[256];
     unsigned n_used = 0;
     for (int b = 0; b < 256; b++) n_used += used[b];
