@@ -86,6 +86,11 @@ int acx_trie_add_words(acx_trie_t* t, const uint8_t* keys, const int64_t* key_of
     if (!t || !key_off || n < 0 || (!keys && n && key_off[n] > key_off[0])) return acx_fail(ACX_E_INVAL, "acx_trie_add_words: bad argument");
     if (!values && value_mode != 1 && value_mode != 2) return acx_fail(ACX_E_INVAL, "acx_trie_add_words: values == NULL needs value_mode 1 or 2");
     int64_t fresh = 0;
+    if (n > 0 && key_off[n] > key_off[0]) {
+        // room for every node these keys can add (one per byte at most): the arena does not move while they go in — a
+        // million signatures are 800 MB of nodes, which doubling would copy twice over.  Address space only until used.
+        try { t->nodes.reserve(t->nodes.size() + (size_t)(key_off[n] - key_off[0]) + 1); } catch (const std::bad_alloc&) {}
+    }
     for (int64_t i = 0; i < n; i++) {
         if (key_off[i + 1] < key_off[i]) return acx_fail(ACX_E_INVAL, "acx_trie_add_words: offsets not monotone at %lld", (long long)i);
         const size_t len = (size_t)(key_off[i + 1] - key_off[i]);
