@@ -76,7 +76,7 @@
 #define ACX_ITOP_FLAG_TFLAGS_ID 2u
 
 #define ACX_BLOB_MAGIC        0x31424F4C42584341ull   /* "ACXBLOB1" */
-#define ACX_BLOB_VERSION      2u          /* 2: the checksum below, the "PPM3" section (hot cells, symbol table) */
+#define ACX_BLOB_VERSION      3u          /* 3: the "PPM4" section (PPM3 + hot4 / cid for four-letter alphabets); 2: the checksum below, "PPM3" */
 #define ACX_BLOB_HEADER_BYTES 256u
 #define ACX_BLOB_ALIGN        256u
 
@@ -185,6 +185,15 @@ typedef struct acx_blob_header {
  *            (s1 * 4 + s2) exists — the walk goes deeper iff one of the two bits of the next two symbols is set;
  *            (bits 12..31) != 0 iff the node has children.  Wider symbols: bit 31 = the node has children.
  *       [1]  the node has children: its deep id (as cell[1]); else the value of the shallowest key of eowmask (else 0).
+ *   hot4[code_C] (global, 8 bytes; sym_bits == 2 and C + 2 <= 16 only — off_hot4 = 0: absent) and cid[code_C] (4 bytes):
+ *       the hot cell as k_ppm_stream4 (four-letter alphabets, fixed stride) reads it.  A position that ends a key — most
+ *       candidates that are no false alarm — needs the VALUE of its shallowest key, not the id of the depth-C node:
+ *       [0]  bits 0..C-1  eowmask; bits 16..31  go[s1 * 4 + s2]: the child s1 of the depth-C node is a key or its
+ *            grandchild (s1, s2) exists — the walk goes deeper iff the bit of the next two symbols is set (a leaf is a
+ *            key: bits 16..31 != 0 iff the node has children)
+ *       [1]  eowmask != 0: the value of its shallowest key; else the deep id of the depth-C node (0: none)
+ *       cid[code_C] = the deep id of the depth-C node (0: absent or childless): read by the walks that go deeper from a
+ *       cell whose second word holds a value.
  *   G2[code_F2] (global, L2 resident, at most 2^25 bits; optional): the same question as G asked with F2 > F symbols,
  *       put to the positions that passed G before they become candidates: set iff the depth-F2 node exists or a key
  *       shorter than F2 ends here.  For alphabets whose filter passes many positions that end no key (text: a 32-bit
@@ -200,7 +209,7 @@ typedef struct acx_blob_header {
  *   node it ends on if that node has children.
  * All section offsets are relative to the start of the acx_ppm_header.
  */
-#define ACX_PPM_MAGIC 0x334D5050u   /* "PPM3" */
+#define ACX_PPM_MAGIC 0x344D5050u   /* "PPM4" */
 #define ACX_PPM_MAX_C 20
 #define ACX_PPM_TILE  256           /* end positions per wave and tile */
 typedef struct acx_ppm_header {
@@ -227,7 +236,9 @@ typedef struct acx_ppm_header {
     uint64_t off_hot;        /* uint32 [2 * K^C]: the 8-byte hot cells (stream kernel) */
     uint32_t top_base[ACX_PPM_MAX_C + 2];
     uint64_t off_chains;     /* singles */
-    uint8_t  reserved[256 - 144 - 4 * (ACX_PPM_MAX_C + 2)];
+    uint64_t off_hot4;       /* uint32 [2 * K^C]: hot cells of k_ppm_stream4 (0: absent) */
+    uint64_t off_cid;        /* uint32 [K^C]: deep id of every depth-C node (with off_hot4) */
+    uint8_t  reserved[256 - 160 - 4 * (ACX_PPM_MAX_C + 2)];
 } acx_ppm_header;
 
 #endif

@@ -98,6 +98,8 @@ struct acx_image {
     const uint32_t* ppm_hot = nullptr;         // 8-byte hot cells (stream kernel)
     const uint8_t*  ppm_symtab = nullptr;      // byte -> symbol, 0xFF = a byte of no key
     const uint32_t* ppm_chains = nullptr;
+    const uint32_t* ppm_hot4 = nullptr;        // hot cells and depth-C ids of k_ppm_stream4 (four-letter alphabets; nullptr: absent)
+    const uint32_t* ppm_cid = nullptr;
 };
 
 // The steady-state step of the itop walk uses 32-bit offsets: table and cells from the lower of
@@ -145,7 +147,8 @@ static int image_resolve(acx_image* img, const uint32_t* lvl_host) {
                  inside(ph.off_g, (uint64_t)ph.g_words * 4) && (ph.F2 == 0 || inside(ph.off_g2, (uint64_t)ph.g2_words * 4)) &&
                  inside(ph.off_symtab, 256) && inside(ph.off_cells, nC * 32) && inside(ph.off_hot, nC * 8) &&
                  inside(ph.off_top_val, (uint64_t)ph.n_top * 4) && inside(ph.off_kids, ((uint64_t)ph.n_deep + 1) * ph.K * 16) &&
-                 inside(ph.off_chains, ((uint64_t)ph.n_chain + 1) * 16);
+                 inside(ph.off_chains, ((uint64_t)ph.n_chain + 1) * 16) &&
+                 ((ph.off_hot4 == 0 && ph.off_cid == 0) || (ph.sym_bits == 2 && inside(ph.off_hot4, (nC + 1) * 8) && inside(ph.off_cid, (nC + 1) * 4)));
             uint64_t tbase = 0;
             for (uint32_t d = 0; ok && d <= ph.C; d++) { ok = ph.top_base[d] == tbase; tbase += pw(ph.K, d); }
             ok = ok && ph.n_top == tbase && (ph.sym_arith == 0 || (ph.K == 4 && ph.sym_arith <= 7));
@@ -160,6 +163,8 @@ static int image_resolve(acx_image* img, const uint32_t* lvl_host) {
         img->ppm_hot = (const uint32_t*)(sec + ph.off_hot);
         img->ppm_symtab = sec + ph.off_symtab;
         img->ppm_chains = (const uint32_t*)(sec + ph.off_chains);
+        img->ppm_hot4 = ph.off_hot4 ? (const uint32_t*)(sec + ph.off_hot4) : nullptr;
+        img->ppm_cid = ph.off_cid ? (const uint32_t*)(sec + ph.off_cid) : nullptr;
         if (!ph.g_global && acx_ppm_lds_layout(ph.g_words, ph.sym_bits, ph.longest).total_words * 4 > ACX_PPM_LDS_BYTES) img->ppm_g = nullptr;
     }
     img->out_off = (const uint32_t*)(img->dev + img->h.off_out_off);
@@ -772,6 +777,7 @@ static int scan_ppm(acx_image_t* img, const acx_scan_params* p, acx_result* r, h
     pa.n_items = n_items;
     pa.cls = img->cls; pa.g = img->ppm_g; pa.cells = img->ppm_cells; pa.top_val = img->ppm_top_val;
     pa.kids = img->ppm_kids; pa.chains = img->ppm_chains; pa.n_branch = ph.n_deep;
+    pa.hot4 = ((p->variant >> 19) & 1) ? nullptr : img->ppm_hot4; pa.cid = img->ppm_cid;        // (variant bit 19: the general stream kernel instead of k_ppm_stream4, A/B)
     pa.hot = img->ppm_hot; pa.symtab = img->ppm_symtab; pa.sym_arith = ph.sym_arith; pa.sym_lut = ph.sym_lut;
     pa.K = ph.K; pa.sym_bits = ph.sym_bits; pa.pow2 = ph.pow2; pa.C = ph.C; pa.F = ph.F; pa.g_words = ph.g_words;
     pa.g2 = ((p->variant >> 20) & 1) ? nullptr : img->ppm_g2; pa.F2 = pa.g2 ? ph.F2 : 0u;      // (variant bit 20: without the second-level filter, A/B)

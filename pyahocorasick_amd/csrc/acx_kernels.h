@@ -114,6 +114,7 @@ struct acx_ppm_args {
     const uint8_t* cls; const uint32_t* g; const uint32_t* cells; const int32_t* top_val;
     const uint32_t* kids; const uint32_t* chains; uint32_t n_branch;
     const uint32_t* hot;     // k_ppm_stream: 8-byte hot cells
+    const uint32_t* hot4; const uint32_t* cid;   // k_ppm_stream4: its hot cells and the ids of the depth-C nodes (include/acx_blob.h; nullptr: absent or not wanted)
     const uint8_t* symtab;   // byte -> symbol, 0xFF = a byte of no key
     uint32_t sym_arith, sym_lut;   // K == 4: symbol = (byte >> (sym_arith - 1)) & 3, sym_lut = the four key bytes (0: table only)
     uint32_t K, sym_bits, pow2, C, F, g_words, has_other, longest, min_len;
@@ -170,6 +171,9 @@ struct acx_ppm_gather_args {       // k_ppm_stream results -> final place
 hipError_t acx_launch_ppm_first_h(const int64_t* off, int64_t n_hay, int64_t n_tiles, int64_t tile_pos, int64_t* first_h, hipStream_t s);
 hipError_t acx_launch_ppm_gather(const uint32_t* wave_desc, int64_t n_waves, int64_t* wave_off, const acx_ppm_gather_args& c, hipStream_t s);
 hipError_t acx_launch_ppm_scan(const acx_ppm_args& a, int64_t n_items_bound, hipStream_t s);
+// k_ppm_stream4 (acx_ppm_stream4.hip): fixed-stride batches over four-letter alphabets; eligible() says whether it takes the scan
+bool acx_ppm_stream4_eligible(const acx_ppm_args& a);
+hipError_t acx_launch_ppm_stream4(const acx_ppm_args& a, int64_t blocks, hipStream_t s);
 hipError_t acx_launch_ppm_compact(const acx_ppm_compact_args& c, int64_t n_items_bound, hipStream_t s);
 int64_t acx_ppm_grid_blocks(const acx_ppm_lds& lds, int64_t n_items_bound, uint32_t reserve_cus = 0);   // blocks of a k_ppm_scan launch
 // final_state of an ACX_SCAN_ALL scan when the matches came from the position-parallel kernels: the

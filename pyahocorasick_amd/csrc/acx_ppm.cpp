@@ -442,6 +442,10 @@ int acx_ppm_build(const acx_trie* t, const uint8_t* cls, uint32_t n_classes, boo
         h.off_symtab = off;   off = align256(off + 256);
         h.off_cells = off;    off = align256(off + (size_t)nC * 32);
         h.off_hot = off;      off = align256(off + (size_t)nC * 8);
+        if (h.sym_bits == 2) {                                          // four-letter alphabets: the cells k_ppm_stream4 reads (one spare cell behind them, all zero)
+            h.off_hot4 = off; off = align256(off + ((size_t)nC + 1) * 8);
+            h.off_cid = off;  off = align256(off + ((size_t)nC + 1) * 4);
+        }
         h.off_top_val = off;  off = align256(off + (size_t)h.n_top * 4);
         h.off_kids = off;     off = align256(off + (size_t)row_bytes);
         h.off_chains = off;   off = align256(off + ((size_t)n_single + 1) * 16);
@@ -451,6 +455,8 @@ int acx_ppm_build(const acx_trie* t, const uint8_t* cls, uint32_t n_classes, boo
         uint32_t* G = (uint32_t*)(sec + h.off_g);
         uint32_t* cells = (uint32_t*)(sec + h.off_cells);
         uint32_t* hot = (uint32_t*)(sec + h.off_hot);
+        uint32_t* hot4 = h.off_hot4 ? (uint32_t*)(sec + h.off_hot4) : nullptr;
+        uint32_t* cid = h.off_cid ? (uint32_t*)(sec + h.off_cid) : nullptr;
         memcpy(sec + h.off_symtab, symof, 256);
         int32_t* top_val = (int32_t*)(sec + h.off_top_val);
         uint32_t* rows = (uint32_t*)(sec + h.off_kids);
@@ -550,6 +556,13 @@ int acx_ppm_build(const acx_trie* t, const uint8_t* cls, uint32_t n_classes, boo
                     else hw |= 0x80000000u;
                 }
                 hot[cc * 2] = hw; hot[cc * 2 + 1] = hx;
+            }
+            if (hot4) {                                                  // include/acx_blob.h "hot4": the value where a key ends, the id elsewhere
+                uint32_t go = 0;
+                if (cell[1]) for (uint32_t t4 = 0; t4 < 16; t4++) if (((cell[2] >> (4 + (t4 >> 2))) | (cell[2] >> (8 + t4))) & 1u) go |= 1u << t4;
+                hot4[cc * 2] = mask | go << 16;
+                hot4[cc * 2 + 1] = mask ? cell[3] : cell[1];
+                cid[cc] = cell[1];
             }
             if (F == C) { if (cell[0] | cell[1]) G[cc >> 5] |= 1u << (cc & 31); }
             else if (cell[0]) for (uint32_t s = 0; s < sigma; s++) { const uint64_t x = cc * sigma + s; G[x >> 5] |= 1u << (x & 31); }

@@ -1,0 +1,501 @@
+// acx_ppm_stream4.hip — k_ppm_stream4: the position-parallel `iter` scan (automaton_search_iter_next,
+// src/AutomatonSearchIter.c:243-300; what it reports at a position: automaton_build_output, :157-197) for the
+// batch shape BASELINE.json's config 2 names: haystacks of one fixed length (a stride below 2048) over a FOUR-LETTER
+// alphabet that a shift tells apart (ACGT: symbol = (byte >> 1) & 3), image with C = 9, F = 10 (any dictionary of
+// 2-bit symbols with keys of ten letters or more) and keys of at most 33 letters.  Everything else stays with
+// k_ppm_stream (acx_ppm_kernels.hip), which this kernel is a specialisation of: the same tiles, the same queue and
+// rounds, the same record streams, grants and block sums (k_ppm_gather_pos moves its records as it moves those of
+// k_ppm_stream).  What is different, and why (profiles/r4_*): the kernel is bound by instruction issue — every
+// instruction of every kind costs its SIMD an issue slot — so
+//   * the geometry is constant: C, F, the halo, the LDS layout (2 KiB per wave, so that an LDS address is an OR) and
+//     the tile size are compile-time numbers, the kernel reads a dozen arguments instead of fifty (no SGPR spills);
+//   * the hot cell is `hot4` (include/acx_blob.h): its second word is the VALUE of the shallowest key that ends here —
+//     what nearly every candidate that is no false alarm needs — and the id of the depth-C node only where no key
+//     ends; one 16-bit field says "go deeper" for the next two symbols.  The top level of a slot is a dozen
+//     instructions (k_ppm_stream: thirty, and a second gather for a third of the matching positions);
+//   * a queue entry is the position + 33, the number its window, its offset in the haystack and its global position
+//     are all one add away from;
+//   * the haystack of a tile is staged by straight-line code (whole tiles: two 16-byte loads per lane, no bounds
+//     checks; the last tile of a batch: a copy of the loop body that checks).
+// Integer only, no MFMA: there is no contraction on this path.
+#include "acx_kernels.h"
+#include "acx_ppm_layout.h"
+
+#define PPM_GRANT 1024u            // records a wave takes from the scratch pool at a time (as k_ppm_stream)
+#define PPM_MAX_GRANTS 16u
+#define PPM_DESC_WORDS 40u         // per wave: total, n_grants, 16 x base, 16 x count (+ pad)
+
+#include "acx_ppm_device.h"
+
+namespace {
+
+constexpr uint32_t S4_C = 9, S4_F = 10;                // symbols of a hot cell's code, of the filter's
+constexpr uint32_t S4_HP = 32;                         // halo: staged positions in front of a tile (>= longest - 1)
+constexpr uint32_t S4_TPOS = 2048;                     // positions per tile: 32 per lane
+constexpr int      S4_NE = 6;                          // queue entries per lane and round
+constexpr uint32_t S4_QCAP = 64u * S4_NE;
+constexpr uint32_t S4_G_BYTES = 4u << (2 * S4_F - 5);  // the filter bitmap: 4^F bits = 128 KiB, at LDS address 0
+constexpr uint32_t S4_WAVE_BYTES = 2048;               // LDS of one wave: a power of two (an address inside it is an OR away)
+// byte offsets inside a wave's LDS
+constexpr uint32_t S4_SYM = 0;                         // words 0, 1: pad; 2, 3: halo (32 positions); 4 .. 131: the tile; 132: pad
+constexpr uint32_t S4_OBITS = 544;                     // word 0: halo, 1 .. 64: tile (one bit per staged position: a byte of no key), 65: spare
+constexpr uint32_t S4_QUEUE = 816;                     // 384 uint16 entries; the hand-over of the deeper walks lives in the same memory
+static_assert(S4_QUEUE + 2 * S4_QCAP + 16 <= S4_WAVE_BYTES && S4_G_BYTES + 16 * S4_WAVE_BYTES <= ACX_PPM_LDS_BYTES, "LDS plan");
+
+__device__ __forceinline__ uint32_t top_base4(uint32_t d) { return 0x55555555u & ((1u << (2u * d)) - 1u); }   // (4^d - 1) / 3: top_base[d] of a four-symbol image
+
+template <bool DUMMY>
+__global__ void __launch_bounds__(ACX_PPM_BLOCK) k_ppm_stream4(const acx_ppm_args a) {
+    extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
+    {
+        const u32x4* g4 = (const u32x4*)a.g;
+        u32x4* s4 = (u32x4*)smem;
+#pragma unroll
+        for (uint32_t i = 0; i < S4_G_BYTES / 16 / ACX_PPM_BLOCK; i++) s4[threadIdx.x + i * ACX_PPM_BLOCK] = g4[threadIdx.x + i * ACX_PPM_BLOCK];
+    }
+    __syncthreads();
+
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t wid = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    uint8_t* const lds = (uint8_t*)smem;
+    const uint32_t wbase = S4_G_BYTES + wid * S4_WAVE_BYTES;          // this wave's LDS, as a byte address
+    uint32_t* const sym = (uint32_t*)(lds + wbase + S4_SYM);
+    uint32_t* const sym_tile = sym + 4;
+    uint32_t* const obits = (uint32_t*)(lds + wbase + S4_OBITS);
+    uint32_t* const obits_tile = obits + 1;
+    uint16_t* const queue = (uint16_t*)(lds + wbase + S4_QUEUE);
+    Ppm<2, true, false> P(a);                                          // windows and symbols for the walks below the cells and for the rare general enumeration
+    P.s_g = smem; P.s_map = nullptr; P.s_sym = sym + 1;
+    P.T.q0 = S4_HP; P.T.halo = 0; P.T.idx_first = 0; P.T.ndw = 0; P.T.abase = nullptr; P.T.e0 = 0; P.T.npos = 0; P.has_other = 0;
+    for (uint32_t i = lane; i < 134; i += 64) sym[i] = 0;
+    for (uint32_t i = lane; i < 66; i += 64) obits[i] = 0;
+
+    // the batch: H bytes, cut into tiles; a wave takes a contiguous run of them (k_ppm_gather_pos counts on exactly this cut)
+    const uint32_t stride = (uint32_t)a.stride, m24 = a.m24;
+    const uint32_t H = (uint32_t)(a.n_hay * a.stride - 1) + 1u;       // (the launcher checks the size)
+    const int64_t n_tiles = ((int64_t)H + S4_TPOS - 1) / S4_TPOS;
+    const int64_t n_waves = (int64_t)gridDim.x * ACX_PPM_WAVES;
+    const int64_t tpw = (n_tiles + n_waves - 1) / n_waves;
+    const int64_t wave_id = (int64_t)blockIdx.x * ACX_PPM_WAVES + wid;
+    const int64_t t_begin = wave_id * tpw;
+    const int64_t t_end = t_begin + tpw < n_tiles ? t_begin + tpw : n_tiles;
+    uint32_t* const desc = a.wave_desc + (size_t)wave_id * PPM_DESC_WORDS;
+    const uint32_t pool_x = blockIdx.x % a.n_pools;
+    const uint32_t step_q = S4_TPOS / stride, step_r = S4_TPOS % stride;
+    wave_sync();
+    if (t_begin >= t_end || (uint64_t)t_begin * S4_TPOS >= H) { if (lane == 0) { desc[0] = 0; desc[1] = 0; } return; }
+
+    const uint32_t ar_shift = a.sym_arith - 1u, ar_lut = a.sym_lut;
+    // which of the four bytes of a dword are none of the four letters (rare path)
+    auto nib_of = [&](uint32_t w) -> uint32_t {
+        const uint32_t x = (w >> ar_shift) & 0x03030303u;
+        const uint32_t d = __builtin_amdgcn_perm(0u, ar_lut, x) ^ w;
+        return ((d & 0xFFu) ? 1u : 0u) | ((d & 0xFF00u) ? 2u : 0u) | ((d & 0xFF0000u) ? 4u : 0u) | ((d >> 24) ? 8u : 0u);
+    };
+    // symbols that exist going back from staged position q when bytes of no key are around (as k_ppm_stream)
+    auto other_limit = [&](uint32_t q) -> uint32_t {
+        uint32_t w = q >> 5;
+        uint32_t m = obits[w] & (0xFFFFFFFFu >> (31u - (q & 31u)));
+        while (m == 0u && w > 0u) m = obits[--w];
+        const uint32_t last = m ? 32u * w + (31u - (uint32_t)__clz(m)) + 1u : 0u;
+        return q + 1 - last;
+    };
+
+    // ---- prologue: the halo of the run's first tile ---------------------------------------------------
+    uint32_t e0 = (uint32_t)(t_begin * S4_TPOS);
+    uint32_t any_prev = 0;
+    if (e0 > 0) {                                                      // (a multiple of 2048: 32 bytes in front of it exist)
+        uint32_t nib = 0;
+        if (lane < S4_HP / 4) {
+            const uint32_t w = *(const uint32_t*)(a.hay + (e0 - S4_HP) + 4u * lane);
+            const uint32_t x = (w >> ar_shift) & 0x03030303u;
+            ((uint8_t*)(sym + 2))[lane] = (uint8_t)((x * 0x01041040u) >> 24);
+            nib = nib_of(w);
+            if (nib) atomicOr(&obits[0], nib << (4u * lane));
+        }
+        if (__any(nib != 0)) any_prev = 1;
+    }
+    uint32_t h_tile, r_tile;
+    { uint32_t rr0; h_tile = div_magic(e0, a.stride_magic, stride, rr0); r_tile = (uint32_t)__builtin_amdgcn_readfirstlane((int)rr0); h_tile = (uint32_t)__builtin_amdgcn_readfirstlane((int)h_tile); }
+    (void)h_tile;
+
+    // a lane's 32 bytes of a tile (read once: they need not stay in the caches)
+    uint32_t wnext[8];
+    auto load_lane_full = [&](uint32_t b) {
+        const u32x4a v0 = __builtin_nontemporal_load((const u32x4a*)(a.hay + b));
+        const u32x4a v1 = __builtin_nontemporal_load((const u32x4a*)(a.hay + b + 16u));
+        wnext[0] = v0.x; wnext[1] = v0.y; wnext[2] = v0.z; wnext[3] = v0.w; wnext[4] = v1.x; wnext[5] = v1.y; wnext[6] = v1.z; wnext[7] = v1.w;
+    };
+    auto load_lane = [&](uint32_t b) {                                 // the tile may end inside the buffer's last bytes
+        if ((int64_t)b + 32 <= a.hay_cap) load_lane_full(b);
+        else {
+#pragma unroll
+            for (int j = 0; j < 8; j++) wnext[j] = (int64_t)b + 4 * j + 4 <= a.hay_cap ? *(const uint32_t*)(a.hay + b + 4u * j) : load_dw_tail(a.hay, a.hay_cap, b + 4u * j);
+        }
+    };
+    // (a tile whose 2048 bytes lie inside the buffer: no checks)
+    const int64_t cap = a.hay_cap;
+    if ((int64_t)e0 + S4_TPOS <= cap) load_lane_full(e0 + 32u * lane); else load_lane(e0 + 32u * lane);
+
+    // the wave's record stream
+    uint32_t run_off = 0;                                              // records so far
+    uint32_t g_base = 0, g_size = 0, g_used = 0, ng = 0;               // current grant of the pool
+    bool dead = false;                                                 // pool or grant list exhausted: keep counting, stop writing
+    const uint32_t longest = a.longest;
+    const uint32_t wbase_v = wbase;                                    // (kept in a VGPR: an operand of the window's address)
+    const uint32_t qaddr = wbase + S4_QUEUE + 2u * lane;               // this lane's entry of slot 0
+    const uint32_t nm24 = 0u - m24;
+
+    for (int64_t tile = t_begin; tile < t_end; tile++) {
+        if (e0 >= H) break;
+        const uint32_t left = H - e0;
+        const uint32_t npos = left < S4_TPOS ? left : S4_TPOS;
+        // ---- stage: bytes -> 2-bit symbols; the next tile's bytes are requested ----------------------------
+        uint32_t W0, W1, W2, anyo = 0;
+        {
+            uint32_t diff = 0, pr[8];
+#pragma unroll
+            for (int j = 0; j < 8; j++) {
+                const uint32_t w = wnext[j];
+                const uint32_t x = (w >> ar_shift) & 0x03030303u;
+                diff |= __builtin_amdgcn_perm(0u, ar_lut, x) ^ w;        // the letters permuted by the symbols give the bytes back iff all four are letters
+                pr[j] = x * 0x01041040u;                                  // one multiply gathers the four 2-bit fields into the top byte
+            }
+            W1 = __builtin_amdgcn_perm(pr[1], pr[0], 0x0c0c0703u) | __builtin_amdgcn_perm(pr[3], pr[2], 0x07030c0cu);
+            W2 = __builtin_amdgcn_perm(pr[5], pr[4], 0x0c0c0703u) | __builtin_amdgcn_perm(pr[7], pr[6], 0x07030c0cu);
+            if (__any(diff != 0u)) {                                    // some byte of the tile is none of the four letters
+#pragma unroll
+                for (int j = 0; j < 8; j++) anyo |= nib_of(wnext[j]) << (4 * j);
+            }
+        }
+        { u32x2 v; v.x = W1; v.y = W2; *(u32x2*)(sym_tile + 2u * lane) = v; }
+        if (tile + 1 < t_end) { if ((int64_t)e0 + 2 * S4_TPOS <= cap) load_lane_full(e0 + S4_TPOS + 32u * lane); else load_lane(e0 + S4_TPOS + 32u * lane); }
+        const uint32_t any_cur = __any(anyo != 0) ? 1u : 0u;
+        const uint32_t use_other = any_cur | any_prev;
+        if (use_other) obits_tile[lane] = anyo;
+        wave_sync();
+        W0 = sym_tile[(int)(2u * lane) - 1];
+
+        // ---- filter: every lane asks the bitmap about its own 32 positions, windows in registers (as k_ppm_stream) -------
+        uint32_t pw;
+        {
+            constexpr uint32_t FB = 2 * S4_F, ush = 32u - FB, amask = ((1u << (FB - 5u)) - 1u) << 2;
+            uint32_t U[5];
+            U[0] = __builtin_amdgcn_alignbit(W1, W0, ush); U[1] = __builtin_amdgcn_alignbit(W2, W1, ush); U[2] = W2 >> ush; U[3] = 0; U[4] = 0;
+            uint32_t acc = 0;
+#pragma unroll
+            for (int i0 = 0; i0 < 32; i0 += 16) {
+                uint32_t gw[16], bs[16];
+#pragma unroll
+                for (int i = 0; i < 16; i++) {
+                    const uint32_t b = 2u * (uint32_t)(i0 + i + 1), k = b >> 5, sh = b & 31u;
+                    bs[i] = sh ? __builtin_amdgcn_alignbit(U[k + 1], U[k], sh) : U[k];
+                    const uint32_t A = (bs[i] >> 3) & amask;
+                    gw[i] = *(const uint32_t*)((const uint8_t*)smem + A);
+                }
+#pragma unroll
+                for (int i = 0; i < 16; i++) acc = __builtin_amdgcn_alignbit(gw[i] >> (bs[i] & 31u), acc, 1u);
+            }
+            pw = acc;
+        }
+        if (use_other | (npos < S4_TPOS ? 1u : 0u)) {
+            const uint32_t lp = 32u * lane;
+            const uint32_t nv = npos > lp ? (npos - lp < 32u ? npos - lp : 32u) : 0u;
+            pw &= (nv >= 32u ? 0xFFFFFFFFu : (1u << nv) - 1u) & ~anyo;      // (a byte of no key ends no key)
+        }
+        // ---- candidates -> the queue, in position order; a round works them off -------------------------------
+        uint32_t x_tot;
+        const uint32_t x_ex = wave_excl_scan((uint32_t)__popc(pw), x_tot);
+        const uint32_t cx1 = r_tile - 32u;                              // entry + cx1 = 1 + (offset of the tile's first byte in its haystack + position)
+        const uint32_t cg = e0 - 33u;                                   // entry + cg = the global position
+
+        // ---- a round: every entry of the queue (n <= 384, in position order).  Lane l owns entries l, 64 + l, ..; slots are
+        // worked in pairs, a pair beyond the queue's end is skipped; the two slots of a pair are one basic block (as k_ppm_stream)
+#define S4_SLOTS(e, ...) _Pragma("unroll") for (int g_ = 0; g_ < S4_NE; g_ += 2) { if (g_ == 0 || (uint32_t)g_ < k) { _Pragma("unroll") for (int e = g_; e < g_ + 2; e++) { __VA_ARGS__ } } }
+        auto do_round = [&](const uint32_t n) {
+            const uint32_t k = (n + 63u) >> 6;                           // slots that hold entries
+            uint32_t pp[S4_NE], XX[S4_NE], rr[S4_NE], LL[S4_NE], cn[S4_NE];
+            u32x2 hc[S4_NE];
+            int32_t va[S4_NE];
+            int32_t vb1 = 0; uint32_t vbe = S4_NE;                      // one second value per lane and round, with the slot it belongs to (as k_ppm_stream)
+            auto set_vb = [&](uint32_t e, int32_t v) { if (vbe == (uint32_t)S4_NE) { vb1 = v; vbe = e; } };
+#pragma unroll
+            for (int e = 0; e < S4_NE; e++) { LL[e] = longest; pp[e] = S4_HP + 1u; XX[e] = 0; rr[e] = 0; cn[e] = 0; va[e] = 0; hc[e].x = 0; hc[e].y = 0; }
+            if (use_other) {                                            // bytes of no key around (rare): the symbols that exist going back from every entry
+                S4_SLOTS(e,
+                    const uint32_t qi = 64u * (uint32_t)e + lane;
+                    const uint32_t lo2 = other_limit(qi < n ? (uint32_t)queue[qi] - 1u : S4_HP);
+                    if (lo2 < LL[e]) LL[e] = lo2;
+                )
+            }
+            // 1. where the entries sit, their windows, the requests for their hot cells.  Straight-line over the slots: their
+            // LDS reads and gathers overlap.  A slot beyond the queue's end reads the spare cell (all zero: nothing ends
+            // there, nothing goes deeper).
+            S4_SLOTS(e,
+                const uint32_t qi = 64u * (uint32_t)e + lane;
+                const uint32_t ent = *(const uint16_t*)(lds + qaddr + 128u * (uint32_t)e);      // position + 33
+                // 1 + the offset in its haystack = x1 - stride * floor((x1 - 1) / stride), the quotient by a 24-bit multiply
+                // (exact while x1 - 1 < stride + 2048)
+                const uint32_t x1 = ent + cx1;
+                const uint32_t q = ((uint32_t)__umul24(x1, m24) + nm24) >> 23;
+                const uint32_t L0 = x1 - (uint32_t)__umul24(q, stride);
+                LL[e] = L0 < LL[e] ? L0 : LL[e];
+                pp[e] = ent;
+                rr[e] = ent + cg;
+                // the 32 bits of symbols that end with the entry's position: words (ent >> 4) + 1 and + 2 of the symbol array
+                const uint32_t* ws = (const uint32_t*)(lds + (((ent >> 2) & 0x7FCu) | wbase_v));
+                XX[e] = __builtin_amdgcn_alignbit(ws[2], ws[1], ent << 1);
+                const uint32_t off = (XX[e] >> (32u - 2u * S4_C - 3u)) & ((8u << (2u * S4_C)) - 8u);
+                hc[e] = *(const u32x2*)((const uint8_t*)a.hot4 + (qi < n ? off : (8u << (2u * S4_C))));
+            )
+            wave_sync();                                                 // (the queue's memory is free from here on)
+            // 2. top levels: how many keys end here (the cell holds the value of the shallowest), whether the walk goes deeper
+            uint32_t n_go = 0, gomask = 0, cmax = 0;
+            S4_SLOTS(e,
+                const uint32_t hw = hc[e].x, L = LL[e];
+                const uint32_t Lc = L < S4_C ? L : S4_C;
+                const uint32_t m = hw & ((1u << Lc) - 1u);
+                cn[e] = (uint32_t)__popc(m);
+                // the walk below the cell: bit 16 + (next two symbols) — asked whatever L is: a walk that runs out of symbols ends at once
+                const uint32_t t16 = __builtin_amdgcn_ubfe(XX[e], 32u - 2u * (S4_C + 2u), 4u) | 16u;
+                const uint32_t g = __builtin_amdgcn_ubfe(hw, t16, 1u);
+                gomask |= g << e; n_go += g;
+                va[e] = (int32_t)hc[e].y;
+                cmax = cn[e] > cmax ? cn[e] : cmax;
+            )
+            if (__any(cmax > 1u)) {                                     // a second key within the cell's levels (0.6 % of the matching positions of config 2)
+#pragma unroll
+                for (int e = 0; e < S4_NE; e++) {
+                    if (cn[e] > 1u) {
+                        const uint32_t L = LL[e], Lc = L < S4_C ? L : S4_C;
+                        const uint32_t m = hc[e].x & ((1u << Lc) - 1u), m2 = m & (m - 1u);
+                        const uint32_t d2 = (uint32_t)__ffs(m2);
+                        set_vb((uint32_t)e, a.top_val[top_base4(d2) + (XX[e] >> (32u - 2u * d2))]);
+                    }
+                }
+            }
+            // 3. deeper levels: the entries that go on, 64 at a time, one per lane; one 16-byte record per step, selects instead
+            // of branches (as k_ppm_stream).  The hand-over: {entry | L << 12 | eowmask << 20, second word of the cell}.
+            uint32_t n_deep;
+            const uint32_t d_base = wave_excl_scan(n_go, n_deep);
+            uint32_t* const dq = (uint32_t*)queue;                       // [0..127] hand-over, then {first, second value}; [128..129] the dump slot; then 64 counts
+            uint16_t* const dcnt = (uint16_t*)(dq + 130);
+            for (uint32_t d0 = 0; d0 < n_deep; d0 += 64u) {
+                {
+                    uint32_t rnk = d_base - d0;                          // (unsigned: ranks below d0 wrap far beyond 64)
+                    S4_SLOTS(e,
+                        const uint32_t g = (gomask >> e) & 1u;
+                        const uint32_t slot = (g != 0u && rnk < 64u) ? rnk : 64u;       // (slot 64: nobody reads it)
+                        u32x2 v; v.x = pp[e] | (LL[e] << 12) | (hc[e].x << 20); v.y = hc[e].y;
+                        *(u32x2*)(dq + 2 * slot) = v;
+                        rnk += g;
+                    )
+                }
+                wave_sync();
+                {
+                    bool go = d0 + lane < n_deep;
+                    const uint32_t pk = go ? dq[2 * lane] : S4_HP + 1u;
+                    uint32_t did = go ? dq[2 * lane + 1] : 0u;
+                    const uint32_t wpq = (pk & 0xFFFu) - 1u, wL = (pk >> 12) & 63u;
+                    if (go && (pk >> 20)) did = a.cid[P.window(wpq) >> (32u - 2u * S4_C)];     // the cell's second word is a value: the id comes from cid[]
+                    uint32_t dd = S4_C, wc = 0;
+                    int32_t wa = 0, wb = 0;
+                    uint32_t s1 = P.sym_at(wpq - S4_C);
+                    go = go && did != 0u;
+                    for (;;) {
+                        const uint32_t single = did >> 31, first = single ^ 1u;
+                        uint32_t off = single ? a.single_off + (did << 4) : a.row_off + ((did + s1) << 4);   // (bit 31 shifts out; a row's id is a record index)
+                        off = go ? off : a.row_off;
+                        const u32x4 rec = *(const u32x4*)(a.deep_base + off);
+                        const uint32_t g = go ? 1u : 0u;
+                        const uint32_t len = rec.y & 0xFFu;
+                        const uint32_t dn = dd + first + len;
+                        const uint32_t wq = go ? wpq - dd - first : S4_HP;      // (a walker that is done reads a harmless window)
+                        const uint32_t diff = (P.window(wq) ^ rec.x) >> ((0u - 2u * len) & 31u);
+                        const uint32_t ok = g & (rec.y >> 9) & (wL >= dn ? 1u : 0u) & ((len == 0u ? 1u : 0u) | (diff == 0u ? 1u : 0u));
+                        const uint32_t hit = ok & (rec.y >> 8) & 1u;
+                        wa = (hit & (wc == 0u ? 1u : 0u)) ? (int32_t)rec.z : wa;
+                        wb = (hit & (wc == 1u ? 1u : 0u)) ? (int32_t)rec.z : wb;
+                        wc += hit;
+                        dd = dn;
+                        did = rec.w;
+                        const uint32_t g2 = ok & 1u & (rec.w != 0u ? 1u : 0u) & ((rec.w >> 31) | (wL > dn ? 1u : 0u));
+                        go = g2 != 0u;
+                        if (!__any(go)) break;
+                        s1 = go ? P.sym_at(wpq - dd) : 0u;
+                    }
+                    dq[2 * lane] = (uint32_t)wa; dq[2 * lane + 1] = (uint32_t)wb; dcnt[lane] = (uint16_t)wc;
+                }
+                wave_sync();
+                {
+                    uint32_t rnk = d_base - d0;
+                    uint32_t found = 0;                                  // slots whose walk found keys: their values are fetched below
+                    S4_SLOTS(e,
+                        const uint32_t g = (gomask >> e) & 1u;
+                        const bool mine = g != 0u && rnk < 64u;
+                        const uint32_t c2 = mine ? (uint32_t)dcnt[mine ? rnk : 64u] : 0u;
+                        found |= (c2 ? 1u : 0u) << e;
+                        cn[e] += c2 << 16;                               // (kept apart until the values are in place)
+                        rnk += g;
+                    )
+                    if (__any(found != 0u)) {
+                        uint32_t rnk2 = d_base - d0;
+                        S4_SLOTS(e,
+                            const uint32_t g = (gomask >> e) & 1u;
+                            if ((found >> e) & 1u) {
+                                const u32x2 dv = *(const u32x2*)(dq + 2 * rnk2);
+                                const uint32_t ct = cn[e] & 0xFFFFu;
+                                if (ct == 0u) { va[e] = (int32_t)dv.x; if ((cn[e] >> 16) > 1u) set_vb((uint32_t)e, (int32_t)dv.y); } else if (ct == 1u) set_vb((uint32_t)e, (int32_t)dv.x);
+                            }
+                            rnk2 += g;
+                        )
+                    }
+#pragma unroll
+                    for (int e = 0; e < S4_NE; e++) cn[e] = (cn[e] & 0xFFFFu) + (cn[e] >> 16);
+                }
+                wave_sync();
+            }
+            // 4. place: entry e * 64 + lane; the records of a slot follow those of the slots below it (two slots per prefix
+            // sum, 16 bits each: a slot has at most 64 x longest < 65536 records)
+            uint32_t ex[S4_NE], rt = 0;
+#pragma unroll
+            for (int e = 0; e < S4_NE; e += 2) {
+                ex[e] = rt; ex[e + 1] = rt;
+                if (e == 0 || (uint32_t)e < k) {
+                    uint32_t t;
+                    const uint32_t x2 = wave_excl_scan(cn[e] | (cn[e + 1] << 16), t);
+                    ex[e] = rt + (x2 & 0xFFFFu); rt += t & 0xFFFFu;
+                    ex[e + 1] = rt + (x2 >> 16); rt += t >> 16;
+                }
+            }
+            if (rt && !dead) {
+                if (g_used + rt + 1u > g_size) {                       // this round (and the spare slot behind it) does not fit the current grant: open the next one
+                    if (ng == PPM_MAX_GRANTS) dead = true;
+                    else {
+                        uint32_t need = PPM_GRANT << (ng < 10 ? ng : 10);
+                        if (need < rt + 1u) need = rt + 1u;
+                        unsigned long long oo = 0;
+                        if (lane == 0) oo = atomicAdd(a.heads + pool_x, (unsigned long long)need);
+                        oo = __shfl(oo, 0, 64);
+                        if (oo + need > a.pool_records) dead = true;
+                        else {
+                            if (lane == 0) { if (ng) desc[18 + ng - 1] = g_used; desc[2 + ng] = (uint32_t)((unsigned long long)pool_x * a.pool_records + oo); }
+                            g_base = (uint32_t)((unsigned long long)pool_x * a.pool_records + oo); g_size = need; g_used = 0; ng++;
+                        }
+                    }
+                    if (dead && lane == 0) *a.overflow = 1;
+                }
+            }
+            const bool wr = rt && !dead;
+            // 5. records, longest key of a position first.  Slot rt of the round (one past its last record; the grant has the
+            // room) takes the stores of the lanes that have no first / second record.
+            uint32_t slow = 0, slow1 = 0;                                // slots with more than two records (slow1: or two, the second not in vb1): the general enumeration
+            uint8_t* const out8 = (uint8_t*)(a.scratch + g_base + g_used);
+            uint2* const out = (uint2*)out8;
+            if (wr) {
+                uint32_t two = 0;
+                S4_SLOTS(e,
+                    const uint32_t c = cn[e]; const uint32_t oe = ex[e] + c - 1u;
+                    *(uint2*)(out8 + ((c ? oe : rt) << 3)) = make_uint2(rr[e], (uint32_t)va[e]);
+                    two |= (c > 1u ? 1u : 0u) << e;
+                    slow |= (c > 2u ? 1u : 0u) << e;
+                )
+                if (__any(two != 0u)) {
+                    const uint32_t mine = vbe < (uint32_t)S4_NE ? 1u << vbe : 0u;   // the slot whose second value vb1 holds
+                    slow1 = two & ~mine; two &= mine;
+                    S4_SLOTS(e,
+                        if ((two >> e) & 1u) *(uint2*)(out8 + ((ex[e] + cn[e] - 2u) << 3)) = make_uint2(rr[e], (uint32_t)vb1);
+                    )
+                }
+                slow |= slow1;
+                while (__any(slow != 0u)) {                              // rare: one slot per lane and pass, from the 32-byte cell
+                    if (slow) {
+                        const uint32_t se = (uint32_t)__ffs(slow) - 1u;
+                        slow &= slow - 1u;
+                        const uint32_t from = (slow1 >> se) & 1u ? 1u : 2u;
+                        typename Ppm<2, true, false>::Ent E;
+                        uint32_t oe = 0;
+                        E.p = 0; E.X = 0; E.L = 0; E.idx = 0;
+#pragma unroll
+                        for (int e = 0; e < S4_NE; e++) if (se == (uint32_t)e) { E.p = pp[e] - (S4_HP + 1u); E.L = LL[e]; E.idx = rr[e]; oe = ex[e] + cn[e] - 1; }
+                        E.X = P.window(S4_HP + E.p);
+                        const u32x4* cell = (const u32x4*)((const uint8_t*)a.cells + ((E.X >> (32u - 2u * S4_C)) << 5));
+                        E.c0 = cell[0]; E.c1 = cell[1];
+                        const uint32_t idx = E.idx;
+                        P.matches(E, from, 0xFFFFFFFFu, [&](uint32_t kk2, int32_t v) { out[oe - kk2] = make_uint2(idx, (uint32_t)v); });
+                    }
+                }
+            }
+            if (rt && !dead) g_used += rt;
+            run_off += rt;
+            wave_sync();
+        };
+#undef S4_SLOTS
+
+        // (one call site of the round: its code exists once.)  Everything at once when the queue has the room (the usual
+        // case), else eight lanes (256 positions, at most 256 entries) at a time with a round whenever the next eight do not fit.
+        uint32_t seg_lo = 0, qcount = 0;
+        for (;;) {
+            if (seg_lo < 64u) {
+                const uint32_t ex_lo = seg_lo ? (uint32_t)__builtin_amdgcn_readlane((int)x_ex, (int)seg_lo) : 0u;
+                uint32_t seg_hi = 64u, n_seg = x_tot - ex_lo;
+                if (n_seg > S4_QCAP - qcount) { seg_hi = seg_lo + 8u; n_seg = (seg_hi < 64u ? (uint32_t)__builtin_amdgcn_readlane((int)x_ex, (int)seg_hi) : x_tot) - ex_lo; }
+                if (n_seg <= S4_QCAP - qcount) {                         // (else: a round first — 256 entries fit the empty queue)
+                    uint32_t w = (lane >= seg_lo && lane < seg_hi) ? pw : 0u;
+                    uint32_t ja = wbase + S4_QUEUE + 2u * (qcount + (x_ex - ex_lo));
+                    const uint32_t lp = 32u * lane + S4_HP + 1u;
+                    while (w) {
+                        const uint32_t b = (uint32_t)__builtin_ctz(w);
+                        w &= w - 1u;
+                        *(uint16_t*)(lds + ja) = (uint16_t)(lp + b);
+                        ja += 2u;
+                    }
+                    qcount += n_seg;
+                    seg_lo = seg_hi;
+                    wave_sync();
+                    if (seg_lo < 64u) continue;
+                }
+            }
+            if (qcount) { do_round(qcount); qcount = 0; }               // (the queue is full, or the symbols of this tile are about to move)
+            if (seg_lo >= 64u) break;
+        }
+
+        // ---- the tail of this tile is the halo of the next ----------------------------------------------
+        {
+            uint32_t t = 0, tn = 0;
+            if (lane < 2u) t = sym[130u + lane];
+            if (use_other && lane == 0u) tn = obits[64];
+            wave_sync();
+            if (lane < 2u) sym[2u + lane] = t;
+            if (use_other && lane == 0u) obits[0] = tn;
+        }
+        any_prev = any_cur;
+        e0 += S4_TPOS;
+        r_tile += step_r; h_tile += step_q;
+        if (r_tile >= stride) { r_tile -= stride; h_tile++; }
+        wave_sync();
+    }
+    if (lane == 0) {
+        desc[0] = run_off; desc[1] = ng; if (ng) desc[18 + ng - 1] = g_used;
+        // the records of the 16 waves of this block, summed where k_ppm_gather_pos finds them (relaxed: no fences, see k_ppm_stream)
+        if (a.block_sum && run_off) __hip_atomic_fetch_add(a.block_sum + blockIdx.x, run_off, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+
+}  // namespace
+
+// Does k_ppm_stream4 take this scan?  (acx_ppm_args as scan_ppm filled them for the stream kernels.)
+bool acx_ppm_stream4_eligible(const acx_ppm_args& a) {
+    return a.fast && a.hot4 && a.cid && !a.off && !a.skip && a.m24 && a.stride >= 8 && a.stride < 2048 &&
+           a.sym_bits == 2 && a.pow2 && a.sym_arith != 0 && a.K == 4 && !a.g_global && !a.F2 && a.nsub == 8 &&
+           a.C == S4_C && a.F == S4_F && a.halo_pos == S4_HP && a.longest <= S4_HP + 1u && a.g_words * 4u == S4_G_BYTES;
+}
+
+hipError_t acx_launch_ppm_stream4(const acx_ppm_args& a, int64_t blocks, hipStream_t s) {
+    const size_t lds_bytes = S4_G_BYTES + 16u * S4_WAVE_BYTES;
+    auto kernel = k_ppm_stream4<false>;
+    hipError_t e = hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(kernel, dim3((unsigned)blocks), dim3(ACX_PPM_BLOCK), lds_bytes, s, a);
+    return hipGetLastError();
+}

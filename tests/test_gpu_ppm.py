@@ -17,6 +17,7 @@ pytestmark = pytest.mark.gpu
 
 SERIAL = 1 << 23          # serial walk kernels instead of the position-parallel ones
 GENERAL = (1 << 24) | (1 << 28)   # k_ppm_scan (any batch; bit 28: even where the serial walks would be chosen) instead of k_ppm_stream
+STREAM_ANY = (1 << 19) | (1 << 28)  # k_ppm_stream (every alphabet) where k_ppm_stream4 (four letters, fixed stride) would take the scan
 
 
 def _ppm_fields(blob):
@@ -41,8 +42,10 @@ def _three_way(A, O, data, off, stride=None, index_base=None, want_final=True):
     shortest = int(np.diff(np.asarray(off)).min()) if n else 0
     # offsets entry twice: with the caller's lower bound on the haystack lengths (>= 8: the stream kernel) and without
     entries = [dict(dev_off=d_off), dict(dev_off=d_off, min_hay_len=shortest)] + ([dict(stride=stride)] if stride else [])
-    for variant in (1 << 28, GENERAL, SERIAL):
+    for variant in (1 << 28, STREAM_ANY, GENERAL, SERIAL):
         for kw in entries:
+            if variant == STREAM_ANY and "stride" not in kw:
+                continue                                  # (k_ppm_stream4 takes fixed-stride batches only: nothing to tell apart)
             sc = Scanner(img)
             sc.scan(d_hay, len(data), n, dev_index_base=d_base, want_final_state=want_final, variant=variant, **kw)
             moff, e, v, fin = sc.fetch()
