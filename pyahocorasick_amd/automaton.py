@@ -315,12 +315,17 @@ class Automaton:
         check(lib().acx_trie_add_word(self._trie, key, len(key), v, C.byref(is_new)))
         return bool(is_new.value)
 
+    @_locked
     def add_words(self, keys, values=None):
         """Many keys in one call (not in the reference): the same as add_word(k, v) for every pair in order, without
         a Python call per key — one acx_trie_add_words for STORE_INTS / STORE_LENGTH.  Returns how many keys were new."""
         keys = keys if isinstance(keys, list) else list(keys)
         if not all(map(bytes.__instancecheck__, keys)):
             raise TypeError("bytes expected")
+        if values is not None and not isinstance(values, (np.ndarray, range)):
+            values = values if isinstance(values, list) else list(values)   # (a generator is read once; what fails below must not leave it half consumed)
+        if values is not None and len(values) != len(keys):
+            raise ValueError("add_words: %d keys, %d values" % (len(keys), len(values)))
         if self._store == STORE_ANY:
             if values is None:
                 raise ValueError("A value object is required as second argument.")

@@ -1296,6 +1296,7 @@ extern "C" int acx_scan_host_ctx(acx_image_t* img, const uint8_t* hay, const int
         total += l + c;
         if (l + c < shortest) shortest = l + c;
     }
+    if (off[n_hay] > 0 && !hay) return acx_fail(ACX_E_INVAL, "acx_scan_host_ctx: hay is NULL");
     if (total > ACX_MAX_LAUNCH_BYTES) return acx_fail(ACX_E_UNSUPPORTED, "acx_scan_host_ctx: %lld bytes in one call; split the batch", (long long)total);
     acx_result* r = *result;
     if (!r) {

@@ -27,6 +27,17 @@
 
 #include "acx_ppm_device.h"
 
+// development builds: -DACX_S4_EXP=<bits> switches parts off FOR TIMING ONLY (results are wrong): 1 hot cells from one
+// line (no L2 latency), 2 no deeper walks, 4 no record stores, 8 no rounds, 16 no queue
+#ifndef ACX_S4_EXP
+#define ACX_S4_EXP 0
+#endif
+#ifdef ACX_S4_MARK
+#define S4_MARK(x) asm volatile("; MARK " #x)
+#else
+#define S4_MARK(x) do { } while (0)
+#endif
+
 namespace {
 
 constexpr uint32_t S4_C = 9, S4_F = 10;                // symbols of a hot cell's code, of the filter's
@@ -150,6 +161,7 @@ __global__ void __launch_bounds__(ACX_PPM_BLOCK) k_ppm_stream4(const acx_ppm_arg
         if (e0 >= H) break;
         const uint32_t left = H - e0;
         const uint32_t npos = left < S4_TPOS ? left : S4_TPOS;
+        S4_MARK(M_STAGE);
         // ---- stage: bytes -> 2-bit symbols; the next tile's bytes are requested ----------------------------
         uint32_t W0, W1, W2, anyo = 0;
         {
@@ -176,6 +188,7 @@ __global__ void __launch_bounds__(ACX_PPM_BLOCK) k_ppm_stream4(const acx_ppm_arg
         wave_sync();
         W0 = sym_tile[(int)(2u * lane) - 1];
 
+        S4_MARK(M_FILTER);
         // ---- filter: every lane asks the bitmap about its own 32 positions, windows in registers (as k_ppm_stream) -------
         uint32_t pw;
         {
@@ -198,11 +211,13 @@ __global__ void __launch_bounds__(ACX_PPM_BLOCK) k_ppm_stream4(const acx_ppm_arg
             }
             pw = acc;
         }
+        S4_MARK(M_VALID);
         if (use_other | (npos < S4_TPOS ? 1u : 0u)) {
             const uint32_t lp = 32u * lane;
             const uint32_t nv = npos > lp ? (npos - lp < 32u ? npos - lp : 32u) : 0u;
             pw &= (nv >= 32u ? 0xFFFFFFFFu : (1u << nv) - 1u) & ~anyo;      // (a byte of no key ends no key)
         }
+        S4_MARK(M_PREFIX);
         // ---- candidates -> the queue, in position order; a round works them off -------------------------------
         uint32_t x_tot;
         const uint32_t x_ex = wave_excl_scan((uint32_t)__popc(pw), x_tot);
@@ -228,6 +243,7 @@ __global__ void __launch_bounds__(ACX_PPM_BLOCK) k_ppm_stream4(const acx_ppm_arg
                     if (lo2 < LL[e]) LL[e] = lo2;
                 )
             }
+            S4_MARK(M_FETCH);
             // 1. where the entries sit, their windows, the requests for their hot cells.  Straight-line over the slots: their
             // LDS reads and gathers overlap.  A slot beyond the queue's end reads the spare cell (all zero: nothing ends
             // there, nothing goes deeper).
@@ -246,9 +262,10 @@ __global__ void __launch_bounds__(ACX_PPM_BLOCK) k_ppm_stream4(const acx_ppm_arg
                 const uint32_t* ws = (const uint32_t*)(lds + (((ent >> 2) & 0x7FCu) | wbase_v));
                 XX[e] = __builtin_amdgcn_alignbit(ws[2], ws[1], ent << 1);
                 const uint32_t off = (XX[e] >> (32u - 2u * S4_C - 3u)) & ((8u << (2u * S4_C)) - 8u);
-                hc[e] = *(const u32x2*)((const uint8_t*)a.hot4 + (qi < n ? off : (8u << (2u * S4_C))));
+                hc[e] = *(const u32x2*)((const uint8_t*)a.hot4 + ((ACX_S4_EXP & 1) ? ((qi < n ? off : 0u) & 56u) : (qi < n ? off : (8u << (2u * S4_C)))));
             )
             wave_sync();                                                 // (the queue's memory is free from here on)
+            S4_MARK(M_TOP);
             // 2. top levels: how many keys end here (the cell holds the value of the shallowest), whether the walk goes deeper
             uint32_t n_go = 0, gomask = 0, cmax = 0;
             S4_SLOTS(e,
@@ -263,6 +280,7 @@ __global__ void __launch_bounds__(ACX_PPM_BLOCK) k_ppm_stream4(const acx_ppm_arg
                 va[e] = (int32_t)hc[e].y;
                 cmax = cn[e] > cmax ? cn[e] : cmax;
             )
+            S4_MARK(M_SECOND);
             if (__any(cmax > 1u)) {                                     // a second key within the cell's levels (0.6 % of the matching positions of config 2)
 #pragma unroll
                 for (int e = 0; e < S4_NE; e++) {
@@ -274,10 +292,12 @@ __global__ void __launch_bounds__(ACX_PPM_BLOCK) k_ppm_stream4(const acx_ppm_arg
                     }
                 }
             }
+            S4_MARK(M_DEEP);
             // 3. deeper levels: the entries that go on, 64 at a time, one per lane; one 16-byte record per step, selects instead
             // of branches (as k_ppm_stream).  The hand-over: {entry | L << 12 | eowmask << 20, second word of the cell}.
             uint32_t n_deep;
             const uint32_t d_base = wave_excl_scan(n_go, n_deep);
+            if (ACX_S4_EXP & 2) n_deep = 0;
             uint32_t* const dq = (uint32_t*)queue;                       // [0..127] hand-over, then {first, second value}; [128..129] the dump slot; then 64 counts
             uint16_t* const dcnt = (uint16_t*)(dq + 130);
             for (uint32_t d0 = 0; d0 < n_deep; d0 += 64u) {
@@ -355,6 +375,7 @@ __global__ void __launch_bounds__(ACX_PPM_BLOCK) k_ppm_stream4(const acx_ppm_arg
                 }
                 wave_sync();
             }
+            S4_MARK(M_PLACE);
             // 4. place: entry e * 64 + lane; the records of a slot follow those of the slots below it (two slots per prefix
             // sum, 16 bits each: a slot has at most 64 x longest < 65536 records)
             uint32_t ex[S4_NE], rt = 0;
@@ -386,7 +407,8 @@ __global__ void __launch_bounds__(ACX_PPM_BLOCK) k_ppm_stream4(const acx_ppm_arg
                     if (dead && lane == 0) *a.overflow = 1;
                 }
             }
-            const bool wr = rt && !dead;
+            const bool wr = rt && !dead && !(ACX_S4_EXP & 4);
+            S4_MARK(M_REC);
             // 5. records, longest key of a position first.  Slot rt of the round (one past its last record; the grant has the
             // room) takes the stores of the lanes that have no first / second record.
             uint32_t slow = 0, slow1 = 0;                                // slots with more than two records (slow1: or two, the second not in vb1): the general enumeration
@@ -432,6 +454,7 @@ __global__ void __launch_bounds__(ACX_PPM_BLOCK) k_ppm_stream4(const acx_ppm_arg
         };
 #undef S4_SLOTS
 
+        S4_MARK(M_PUSH);
         // (one call site of the round: its code exists once.)  Everything at once when the queue has the room (the usual
         // case), else eight lanes (256 positions, at most 256 entries) at a time with a round whenever the next eight do not fit.
         uint32_t seg_lo = 0, qcount = 0;
@@ -442,6 +465,7 @@ __global__ void __launch_bounds__(ACX_PPM_BLOCK) k_ppm_stream4(const acx_ppm_arg
                 if (n_seg > S4_QCAP - qcount) { seg_hi = seg_lo + 8u; n_seg = (seg_hi < 64u ? (uint32_t)__builtin_amdgcn_readlane((int)x_ex, (int)seg_hi) : x_tot) - ex_lo; }
                 if (n_seg <= S4_QCAP - qcount) {                         // (else: a round first — 256 entries fit the empty queue)
                     uint32_t w = (lane >= seg_lo && lane < seg_hi) ? pw : 0u;
+                    if (ACX_S4_EXP & 16) w = 0;
                     uint32_t ja = wbase + S4_QUEUE + 2u * (qcount + (x_ex - ex_lo));
                     const uint32_t lp = 32u * lane + S4_HP + 1u;
                     while (w) {
@@ -456,10 +480,12 @@ __global__ void __launch_bounds__(ACX_PPM_BLOCK) k_ppm_stream4(const acx_ppm_arg
                     if (seg_lo < 64u) continue;
                 }
             }
-            if (qcount) { do_round(qcount); qcount = 0; }               // (the queue is full, or the symbols of this tile are about to move)
+            if (qcount && !(ACX_S4_EXP & 8)) do_round(qcount);
+            qcount = 0;               // (the queue is full, or the symbols of this tile are about to move)
             if (seg_lo >= 64u) break;
         }
 
+        S4_MARK(M_TAIL);
         // ---- the tail of this tile is the halo of the next ----------------------------------------------
         {
             uint32_t t = 0, tn = 0;

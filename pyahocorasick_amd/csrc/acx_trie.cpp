@@ -89,7 +89,10 @@ int acx_trie_add_words(acx_trie_t* t, const uint8_t* keys, const int64_t* key_of
     if (n > 0 && key_off[n] > key_off[0]) {
         // room for every node these keys can add (one per byte at most): the arena does not move while they go in — a
         // million signatures are 800 MB of nodes, which doubling would copy twice over.  Address space only until used.
-        try { t->nodes.reserve(t->nodes.size() + (size_t)(key_off[n] - key_off[0]) + 1); } catch (const std::bad_alloc&) {}
+        // (only when they do not fit what is there, and then at least twice the capacity: many small batches must not
+        //  copy the arena once per call — reserve() allocates exactly what it is asked for)
+        const size_t need = t->nodes.size() + (size_t)(key_off[n] - key_off[0]) + 1, have = t->nodes.capacity();
+        if (need > have) { try { t->nodes.reserve(need > 2 * have ? need : 2 * have); } catch (const std::bad_alloc&) {} }
     }
     for (int64_t i = 0; i < n; i++) {
         if (key_off[i + 1] < key_off[i]) return acx_fail(ACX_E_INVAL, "acx_trie_add_words: offsets not monotone at %lld", (long long)i);

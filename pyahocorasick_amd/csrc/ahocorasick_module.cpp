@@ -638,6 +638,16 @@ struct SearchIterObject {
     int32_t state0;         // state before this chunk
     bool exhausted;         // StopIteration seen: the reference has walked the whole chunk
     bool loaded;            // the chunk has been scanned (lazily: at the first next(), as the reference walks nothing in iter())
+    bool busy;              // a scan of this iterator is running without the GIL: next() / set() from another thread raise
+};
+
+// The scan behind next() runs without the GIL and holds pointers into the iterator's source and context; a second
+// thread that calls next() or set() on the SAME iterator meanwhile would free or move them.  The reference holds the
+// GIL throughout (sharing an iterator is memory-safe there); here re-entry raises, as it does for a generator.
+struct IterBusy {
+    SearchIterObject* it; bool ok;
+    explicit IterBusy(SearchIterObject* i) : it(i), ok(!i->busy) { if (ok) it->busy = true; else PyErr_SetString(PyExc_ValueError, "iterator already executing"); }
+    ~IterBusy() { if (ok) it->busy = false; }
 };
 
 extern PyTypeObject SearchIterType;
@@ -724,7 +734,7 @@ PyObject* search_iter_create(AutomatonObject* a, PyObject* srcobj, const Text& t
     it->pending = new std::vector<acx_match_t>();
     it->ctx = new std::vector<uint8_t>();
     it->pos = 0; it->state = 0; it->shift = 0; it->ref_index = -1; it->end = 0; it->ignore_ws = ws; it->is_long = is_long;
-    Py_INCREF(srcobj); it->src = srcobj; it->start = 0; it->state0 = 0; it->exhausted = false; it->loaded = false;
+    Py_INCREF(srcobj); it->src = srcobj; it->start = 0; it->state0 = 0; it->exhausted = false; it->loaded = false; it->busy = false;
     if (!iter_load(it, t, start, end)) { Py_DECREF(it); return nullptr; }
     return (PyObject*)it;
 }
@@ -744,7 +754,10 @@ PyObject* search_iter_next(SearchIterObject* it) {
         PyErr_SetString(PyExc_ValueError, "underlaying automaton has changed, iterator is not valid anymore");
         return nullptr;
     }
-    if (!iter_ensure_loaded(it)) return nullptr;
+    {
+        IterBusy guard(it);
+        if (!guard.ok || !iter_ensure_loaded(it)) return nullptr;
+    }
     if (it->pos >= it->pending->size()) { it->ref_index = it->end; it->exhausted = true; return nullptr; }   // StopIteration
     const acx_match_t r = (*it->pending)[it->pos++];
     it->ref_index = (Py_ssize_t)r.end_index - it->shift;
@@ -756,6 +769,8 @@ PyObject* search_iter_set(SearchIterObject* it, PyObject* args) {  // src/Automa
     if (!PyArg_ParseTuple(args, "O|p", &s, &reset)) return nullptr;
     Text t;
     if (!get_text(s, &t, true, it->automaton->key_type)) return nullptr;
+    IterBusy guard(it);
+    if (!guard.ok) return nullptr;
     if (reset) { it->state = 0; it->shift = 0; it->ctx->clear(); }
     else {
         // What the reference has walked of the old chunk: all of it after StopIteration, else up to the last match it

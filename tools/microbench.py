@@ -39,7 +39,11 @@ def main():
     ap.add_argument("--layout", default="stride", choices=["stride", "offsets", "one"],
                     help="stride: fixed-length reads (direct path); offsets: same reads through a device "
                          "offsets array (chunked path); one: the whole buffer as ONE haystack (chunk+halo)")
+    ap.add_argument("--lib", default=None, help="another build of libacx.so (development variants): loaded instead of the one in the package")
     args = ap.parse_args()
+    if args.lib:
+        from pyahocorasick_amd import _lib
+        _lib.LIB_PATH = os.path.abspath(args.lib)
 
     t0 = time.time()
     pre_off = None
