@@ -44,14 +44,15 @@ constexpr uint32_t S4_C = 9, S4_F = 10;                // symbols of a hot cell'
 constexpr uint32_t S4_HP = 32;                         // halo: staged positions in front of a tile (>= longest - 1)
 constexpr uint32_t S4_TPOS = 2048;                     // positions per tile: 32 per lane
 constexpr int      S4_NE = 6;                          // queue entries per lane and round
-constexpr uint32_t S4_QCAP = 64u * S4_NE;
+constexpr uint32_t S4_QCAP = 352;                      // entries of a round (the queue's memory; the last slot is half used)
 constexpr uint32_t S4_G_BYTES = 4u << (2 * S4_F - 5);  // the filter bitmap: 4^F bits = 128 KiB, at LDS address 0
-constexpr uint32_t S4_WAVE_BYTES = 2048;               // LDS of one wave: a power of two (an address inside it is an OR away)
-// byte offsets inside a wave's LDS
-constexpr uint32_t S4_SYM = 0;                         // words 0, 1: pad; 2, 3: halo (32 positions); 4 .. 131: the tile; 132: pad
-constexpr uint32_t S4_OBITS = 544;                     // word 0: halo, 1 .. 64: tile (one bit per staged position: a byte of no key), 65: spare
-constexpr uint32_t S4_QUEUE = 816;                     // 384 uint16 entries; the hand-over of the deeper walks lives in the same memory
-static_assert(S4_QUEUE + 2 * S4_QCAP + 16 <= S4_WAVE_BYTES && S4_G_BYTES + 16 * S4_WAVE_BYTES <= ACX_PPM_LDS_BYTES, "LDS plan");
+constexpr uint32_t S4_WAVE_BYTES = 2048;               // LDS of one wave
+// byte offsets inside a wave's LDS.  Two symbol buffers: the round that is worked on may belong to the tile before the
+// one whose candidates are being fetched.  A buffer: words 0, 1: pad; 2, 3: halo (32 positions); 4 .. 131: the tile; 132: pad
+constexpr uint32_t S4_SYMB = 536;                      // bytes of one symbol buffer
+constexpr uint32_t S4_OBITS = 2 * S4_SYMB;             // word 0: halo, 1 .. 64: tile (one bit per staged position: a byte of no key), 65: spare
+constexpr uint32_t S4_QUEUE = S4_OBITS + 264;          // 352 uint16 entries; the hand-over of the deeper walks lives in the same memory
+static_assert(S4_QUEUE % 8 == 0 && S4_QUEUE + 2 * S4_QCAP <= S4_WAVE_BYTES && 648 <= 2 * S4_QCAP && S4_G_BYTES + 16 * S4_WAVE_BYTES <= ACX_PPM_LDS_BYTES, "LDS plan");
 
 __device__ __forceinline__ uint32_t top_base4(uint32_t d) { return 0x55555555u & ((1u << (2u * d)) - 1u); }   // (4^d - 1) / 3: top_base[d] of a four-symbol image
 
@@ -70,33 +71,29 @@ __global__ void __launch_bounds__(ACX_PPM_BLOCK) k_ppm_stream4(const acx_ppm_arg
     const uint32_t wid = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     uint8_t* const lds = (uint8_t*)smem;
     const uint32_t wbase = S4_G_BYTES + wid * S4_WAVE_BYTES;          // this wave's LDS, as a byte address
-    uint32_t* const sym = (uint32_t*)(lds + wbase + S4_SYM);
-    uint32_t* const sym_tile = sym + 4;
     uint32_t* const obits = (uint32_t*)(lds + wbase + S4_OBITS);
     uint32_t* const obits_tile = obits + 1;
     uint16_t* const queue = (uint16_t*)(lds + wbase + S4_QUEUE);
     Ppm<2, true, false> P(a);                                          // windows and symbols for the walks below the cells and for the rare general enumeration
-    P.s_g = smem; P.s_map = nullptr; P.s_sym = sym + 1;
+    P.s_g = smem; P.s_map = nullptr; P.s_sym = (uint32_t*)(lds + wbase) + 1;
     P.T.q0 = S4_HP; P.T.halo = 0; P.T.idx_first = 0; P.T.ndw = 0; P.T.abase = nullptr; P.T.e0 = 0; P.T.npos = 0; P.has_other = 0;
-    for (uint32_t i = lane; i < 134; i += 64) sym[i] = 0;
-    for (uint32_t i = lane; i < 66; i += 64) obits[i] = 0;
+    for (uint32_t i = lane; i < (S4_OBITS + 264) / 4; i += 64) ((uint32_t*)(lds + wbase))[i] = 0;
 
     // the batch: H bytes, cut into tiles; a wave takes a contiguous run of them (k_ppm_gather_pos counts on exactly this cut)
     const uint32_t stride = (uint32_t)a.stride, m24 = a.m24;
     const uint32_t H = (uint32_t)(a.n_hay * a.stride - 1) + 1u;       // (the launcher checks the size)
-    const int64_t n_tiles = ((int64_t)H + S4_TPOS - 1) / S4_TPOS;
-    const int64_t n_waves = (int64_t)gridDim.x * ACX_PPM_WAVES;
-    const int64_t tpw = (n_tiles + n_waves - 1) / n_waves;
-    const int64_t wave_id = (int64_t)blockIdx.x * ACX_PPM_WAVES + wid;
-    const int64_t t_begin = wave_id * tpw;
-    const int64_t t_end = t_begin + tpw < n_tiles ? t_begin + tpw : n_tiles;
+    const uint32_t n_tiles = (uint32_t)(((int64_t)H + S4_TPOS - 1) / S4_TPOS);
+    const uint32_t n_waves = gridDim.x * ACX_PPM_WAVES;
+    const uint32_t tpw = (n_tiles + n_waves - 1) / n_waves;
+    const uint32_t wave_id = blockIdx.x * ACX_PPM_WAVES + wid;
+    const uint64_t t_begin = (uint64_t)wave_id * tpw;
     uint32_t* const desc = a.wave_desc + (size_t)wave_id * PPM_DESC_WORDS;
-    const uint32_t pool_x = blockIdx.x % a.n_pools;
-    const uint32_t step_q = S4_TPOS / stride, step_r = S4_TPOS % stride;
     wave_sync();
-    if (t_begin >= t_end || (uint64_t)t_begin * S4_TPOS >= H) { if (lane == 0) { desc[0] = 0; desc[1] = 0; } return; }
+    if (t_begin >= n_tiles) { if (lane == 0) { desc[0] = 0; desc[1] = 0; } return; }
+    uint32_t tiles_left = n_tiles - (uint32_t)t_begin < tpw ? n_tiles - (uint32_t)t_begin : tpw;
 
-    const uint32_t ar_shift = a.sym_arith - 1u, ar_lut = a.sym_lut;
+    uint32_t ar_shift = a.sym_arith - 1u, ar_lut = a.sym_lut;
+    asm volatile("" : "+s"(ar_shift), "+s"(ar_lut));                  // (kept in registers: the stage reads them for every dword)
     // which of the four bytes of a dword are none of the four letters (rare path)
     auto nib_of = [&](uint32_t w) -> uint32_t {
         const uint32_t x = (w >> ar_shift) & 0x03030303u;
@@ -113,22 +110,22 @@ __global__ void __launch_bounds__(ACX_PPM_BLOCK) k_ppm_stream4(const acx_ppm_arg
     };
 
     // ---- prologue: the halo of the run's first tile ---------------------------------------------------
-    uint32_t e0 = (uint32_t)(t_begin * S4_TPOS);
+    uint32_t e0 = (uint32_t)t_begin * S4_TPOS;
     uint32_t any_prev = 0;
     if (e0 > 0) {                                                      // (a multiple of 2048: 32 bytes in front of it exist)
         uint32_t nib = 0;
         if (lane < S4_HP / 4) {
             const uint32_t w = *(const uint32_t*)(a.hay + (e0 - S4_HP) + 4u * lane);
             const uint32_t x = (w >> ar_shift) & 0x03030303u;
-            ((uint8_t*)(sym + 2))[lane] = (uint8_t)((x * 0x01041040u) >> 24);
+            ((uint8_t*)(lds + wbase + 8))[lane] = (uint8_t)((x * 0x01041040u) >> 24);     // (the halo words of buffer 0)
             nib = nib_of(w);
             if (nib) atomicOr(&obits[0], nib << (4u * lane));
         }
         if (__any(nib != 0)) any_prev = 1;
     }
-    uint32_t h_tile, r_tile;
-    { uint32_t rr0; h_tile = div_magic(e0, a.stride_magic, stride, rr0); r_tile = (uint32_t)__builtin_amdgcn_readfirstlane((int)rr0); h_tile = (uint32_t)__builtin_amdgcn_readfirstlane((int)h_tile); }
-    (void)h_tile;
+    uint32_t r_tile;
+    { uint32_t rr0; (void)div_magic(e0, a.stride_magic, stride, rr0); r_tile = (uint32_t)__builtin_amdgcn_readfirstlane((int)rr0); }
+    const uint32_t step_r = S4_TPOS % stride;
 
     // a lane's 32 bytes of a tile (read once: they need not stay in the caches)
     uint32_t wnext[8];
@@ -145,139 +142,194 @@ __global__ void __launch_bounds__(ACX_PPM_BLOCK) k_ppm_stream4(const acx_ppm_arg
         }
     };
     // (a tile whose 2048 bytes lie inside the buffer: no checks)
-    const int64_t cap = a.hay_cap;
-    if ((int64_t)e0 + S4_TPOS <= cap) load_lane_full(e0 + 32u * lane); else load_lane(e0 + 32u * lane);
+    const uint32_t full_end = a.hay_cap >= (int64_t)S4_TPOS ? (uint32_t)((a.hay_cap < 0xFFFFFFFFll ? a.hay_cap : 0xFFFFFFFFll) - S4_TPOS) : 0u;
+    const bool any_full = a.hay_cap >= (int64_t)S4_TPOS;
+    auto load_tile = [&](uint32_t e) { if (any_full && e <= full_end) load_lane_full(e + 32u * lane); else load_lane(e + 32u * lane); };
+    load_tile(e0);
 
     // the wave's record stream
     uint32_t run_off = 0;                                              // records so far
     uint32_t g_base = 0, g_size = 0, g_used = 0, ng = 0;               // current grant of the pool
     bool dead = false;                                                 // pool or grant list exhausted: keep counting, stop writing
+    const uint32_t pool_x = blockIdx.x % a.n_pools;
     const uint32_t longest = a.longest;
-    const uint32_t wbase_v = wbase;                                    // (kept in a VGPR: an operand of the window's address)
     const uint32_t qaddr = wbase + S4_QUEUE + 2u * lane;               // this lane's entry of slot 0
     const uint32_t nm24 = 0u - m24;
 
-    for (int64_t tile = t_begin; tile < t_end; tile++) {
-        if (e0 >= H) break;
-        const uint32_t left = H - e0;
-        const uint32_t npos = left < S4_TPOS ? left : S4_TPOS;
-        S4_MARK(M_STAGE);
-        // ---- stage: bytes -> 2-bit symbols; the next tile's bytes are requested ----------------------------
-        uint32_t W0, W1, W2, anyo = 0;
-        {
-            uint32_t diff = 0, pr[8];
+    // ---- the pipeline -----------------------------------------------------------------------------------
+    // A ROUND is at most 352 candidates of one tile (all of them, unless the tile holds more).  Every trip of the loop
+    //   stages the next tile if the one before it has handed over all its candidates (symbols -> the OTHER symbol buffer,
+    //     the filter, the prefix sum of the pass words),
+    //   pushes the candidates of the next round into the queue and FETCHES: where they sit, their windows, the requests
+    //     for their hot cells — into the registers of set N,
+    //   works off the round fetched one trip earlier (set O): top levels, deeper walks, placement, records.
+    // The gathers of a round are in flight while the round before it is worked off and the next tile is staged: the
+    // CU's address unit serves them (about one lane per ns and CU, profiles/r4_*) beside the instruction stream instead
+    // of in front of it.
+    uint32_t cur = 0;                                                  // symbol buffer of the tile whose candidates are being fetched
+    bool tile_ok = true, need_stage = true;
+    uint32_t pw = 0, x_ex = 0, x_tot = 0, seg_lo = 0, use_other = 0, any_cur = 0;
+    u32x2 hcO[S4_NE], hcN[S4_NE];
+    uint32_t ppO[S4_NE], ppN[S4_NE];                                   // entry (position + 33) | symbols that exist << 12 | (16 + the next two symbols) << 18
+    uint32_t nO = 0, nN = 0, cgO = 0, cgN = 0, symO = wbase, symN = wbase;
+    bool haveO = false;
 #pragma unroll
-            for (int j = 0; j < 8; j++) {
-                const uint32_t w = wnext[j];
-                const uint32_t x = (w >> ar_shift) & 0x03030303u;
-                diff |= __builtin_amdgcn_perm(0u, ar_lut, x) ^ w;        // the letters permuted by the symbols give the bytes back iff all four are letters
-                pr[j] = x * 0x01041040u;                                  // one multiply gathers the four 2-bit fields into the top byte
-            }
-            W1 = __builtin_amdgcn_perm(pr[1], pr[0], 0x0c0c0703u) | __builtin_amdgcn_perm(pr[3], pr[2], 0x07030c0cu);
-            W2 = __builtin_amdgcn_perm(pr[5], pr[4], 0x0c0c0703u) | __builtin_amdgcn_perm(pr[7], pr[6], 0x07030c0cu);
-            if (__any(diff != 0u)) {                                    // some byte of the tile is none of the four letters
-#pragma unroll
-                for (int j = 0; j < 8; j++) anyo |= nib_of(wnext[j]) << (4 * j);
-            }
-        }
-        { u32x2 v; v.x = W1; v.y = W2; *(u32x2*)(sym_tile + 2u * lane) = v; }
-        if (tile + 1 < t_end) { if ((int64_t)e0 + 2 * S4_TPOS <= cap) load_lane_full(e0 + S4_TPOS + 32u * lane); else load_lane(e0 + S4_TPOS + 32u * lane); }
-        const uint32_t any_cur = __any(anyo != 0) ? 1u : 0u;
-        const uint32_t use_other = any_cur | any_prev;
-        if (use_other) obits_tile[lane] = anyo;
-        wave_sync();
-        W0 = sym_tile[(int)(2u * lane) - 1];
+    for (int e = 0; e < S4_NE; e++) { hcO[e].x = 0; hcO[e].y = 0; ppO[e] = 0; hcN[e].x = 0; hcN[e].y = 0; ppN[e] = 0; }
 
-        S4_MARK(M_FILTER);
-        // ---- filter: every lane asks the bitmap about its own 32 positions, windows in registers (as k_ppm_stream) -------
-        uint32_t pw;
-        {
-            constexpr uint32_t FB = 2 * S4_F, ush = 32u - FB, amask = ((1u << (FB - 5u)) - 1u) << 2;
-            uint32_t U[5];
-            U[0] = __builtin_amdgcn_alignbit(W1, W0, ush); U[1] = __builtin_amdgcn_alignbit(W2, W1, ush); U[2] = W2 >> ush; U[3] = 0; U[4] = 0;
-            uint32_t acc = 0;
-#pragma unroll
-            for (int i0 = 0; i0 < 32; i0 += 16) {
-                uint32_t gw[16], bs[16];
-#pragma unroll
-                for (int i = 0; i < 16; i++) {
-                    const uint32_t b = 2u * (uint32_t)(i0 + i + 1), k = b >> 5, sh = b & 31u;
-                    bs[i] = sh ? __builtin_amdgcn_alignbit(U[k + 1], U[k], sh) : U[k];
-                    const uint32_t A = (bs[i] >> 3) & amask;
-                    gw[i] = *(const uint32_t*)((const uint8_t*)smem + A);
-                }
-#pragma unroll
-                for (int i = 0; i < 16; i++) acc = __builtin_amdgcn_alignbit(gw[i] >> (bs[i] & 31u), acc, 1u);
-            }
-            pw = acc;
-        }
-        S4_MARK(M_VALID);
-        if (use_other | (npos < S4_TPOS ? 1u : 0u)) {
-            const uint32_t lp = 32u * lane;
-            const uint32_t nv = npos > lp ? (npos - lp < 32u ? npos - lp : 32u) : 0u;
-            pw &= (nv >= 32u ? 0xFFFFFFFFu : (1u << nv) - 1u) & ~anyo;      // (a byte of no key ends no key)
-        }
-        S4_MARK(M_PREFIX);
-        // ---- candidates -> the queue, in position order; a round works them off -------------------------------
-        uint32_t x_tot;
-        const uint32_t x_ex = wave_excl_scan((uint32_t)__popc(pw), x_tot);
-        const uint32_t cx1 = r_tile - 32u;                              // entry + cx1 = 1 + (offset of the tile's first byte in its haystack + position)
-        const uint32_t cg = e0 - 33u;                                   // entry + cg = the global position
-
-        // ---- a round: every entry of the queue (n <= 384, in position order).  Lane l owns entries l, 64 + l, ..; slots are
-        // worked in pairs, a pair beyond the queue's end is skipped; the two slots of a pair are one basic block (as k_ppm_stream)
 #define S4_SLOTS(e, ...) _Pragma("unroll") for (int g_ = 0; g_ < S4_NE; g_ += 2) { if (g_ == 0 || (uint32_t)g_ < k) { _Pragma("unroll") for (int e = g_; e < g_ + 2; e++) { __VA_ARGS__ } } }
-        auto do_round = [&](const uint32_t n) {
+    for (;;) {
+        // ---- stage the tile at e0: bytes -> 2-bit symbols (buffer `cur`), the filter, the prefix sum ------------------
+        if (tile_ok && need_stage) {
+            S4_MARK(M_STAGE);
+            uint32_t* const sym_tile = (uint32_t*)(lds + wbase + cur * S4_SYMB) + 4;
+            const uint32_t left = H - e0;
+            const uint32_t npos = left < S4_TPOS ? left : S4_TPOS;
+            uint32_t W0, W1, W2, anyo = 0;
+            {
+                uint32_t diff = 0, pr[8];
+#pragma unroll
+                for (int j = 0; j < 8; j++) {
+                    const uint32_t w = wnext[j];
+                    const uint32_t x = (w >> ar_shift) & 0x03030303u;
+                    diff |= __builtin_amdgcn_perm(0u, ar_lut, x) ^ w;    // the letters permuted by the symbols give the bytes back iff all four are letters
+                    pr[j] = x * 0x01041040u;                              // one multiply gathers the four 2-bit fields into the top byte
+                }
+                W1 = __builtin_amdgcn_perm(pr[1], pr[0], 0x0c0c0703u) | __builtin_amdgcn_perm(pr[3], pr[2], 0x07030c0cu);
+                W2 = __builtin_amdgcn_perm(pr[5], pr[4], 0x0c0c0703u) | __builtin_amdgcn_perm(pr[7], pr[6], 0x07030c0cu);
+                if (__any(diff != 0u)) {                                // some byte of the tile is none of the four letters
+#pragma unroll
+                    for (int j = 0; j < 8; j++) anyo |= nib_of(wnext[j]) << (4 * j);
+                }
+            }
+            { u32x2 v; v.x = W1; v.y = W2; *(u32x2*)(sym_tile + 2u * lane) = v; }
+            if (tiles_left > 1) load_tile(e0 + S4_TPOS);                 // the next tile's bytes: requested a whole trip ahead
+            any_cur = __any(anyo != 0) ? 1u : 0u;
+            use_other = any_cur | any_prev;
+            if (use_other) obits_tile[lane] = anyo;
+            wave_sync();
+            W0 = sym_tile[(int)(2u * lane) - 1];
+            S4_MARK(M_FILTER);
+            // the filter: every lane asks the bitmap about its own 32 positions, windows in registers (as k_ppm_stream)
+            {
+                constexpr uint32_t FB = 2 * S4_F, ush = 32u - FB, amask = ((1u << (FB - 5u)) - 1u) << 2;
+                uint32_t U[5];
+                U[0] = __builtin_amdgcn_alignbit(W1, W0, ush); U[1] = __builtin_amdgcn_alignbit(W2, W1, ush); U[2] = W2 >> ush; U[3] = 0; U[4] = 0;
+                uint32_t acc = 0;
+#pragma unroll
+                for (int i0 = 0; i0 < 32; i0 += 16) {
+                    uint32_t gw[16], bs[16];
+#pragma unroll
+                    for (int i = 0; i < 16; i++) {
+                        const uint32_t b = 2u * (uint32_t)(i0 + i + 1), k = b >> 5, sh = b & 31u;
+                        bs[i] = sh ? __builtin_amdgcn_alignbit(U[k + 1], U[k], sh) : U[k];
+                        const uint32_t A = (bs[i] >> 3) & amask;
+                        gw[i] = *(const uint32_t*)((const uint8_t*)smem + A);
+                    }
+#pragma unroll
+                    for (int i = 0; i < 16; i++) acc = __builtin_amdgcn_alignbit(gw[i] >> (bs[i] & 31u), acc, 1u);
+                }
+                pw = acc;
+            }
+            if (use_other | (npos < S4_TPOS ? 1u : 0u)) {
+                const uint32_t lp = 32u * lane;
+                const uint32_t nv = npos > lp ? (npos - lp < 32u ? npos - lp : 32u) : 0u;
+                pw &= (nv >= 32u ? 0xFFFFFFFFu : (1u << nv) - 1u) & ~anyo;  // (a byte of no key ends no key)
+            }
+            S4_MARK(M_PREFIX);
+            x_ex = wave_excl_scan((uint32_t)__popc(pw), x_tot);
+            if (ACX_S4_EXP & 16) x_tot = 0;
+            seg_lo = 0; need_stage = false;
+        }
+
+        // ---- the next round of this tile: its candidates -> the queue, in position order; fetch --------------------------
+        bool haveN = false;
+        if (tile_ok) {
+            if (x_tot == 0u) seg_lo = 64u;
+            else {
+                S4_MARK(M_PUSH);
+                const uint32_t ex_lo = seg_lo ? (uint32_t)__builtin_amdgcn_readlane((int)x_ex, (int)seg_lo) : 0u;
+                uint32_t seg_hi = 64u, n = x_tot - ex_lo;
+                if (n > S4_QCAP) { seg_hi = seg_lo + 8u; n = (seg_hi < 64u ? (uint32_t)__builtin_amdgcn_readlane((int)x_ex, (int)seg_hi) : x_tot) - ex_lo; }   // (eight lanes: 256 positions)
+                {
+                    uint32_t w = (lane >= seg_lo && lane < seg_hi) ? pw : 0u;
+                    uint32_t ja = wbase + S4_QUEUE + 2u * (x_ex - ex_lo);
+                    const uint32_t lp = 32u * lane + S4_HP + 1u;
+                    while (w) {
+                        const uint32_t b = (uint32_t)__builtin_ctz(w);
+                        w &= w - 1u;
+                        *(uint16_t*)(lds + ja) = (uint16_t)(lp + b);
+                        ja += 2u;
+                    }
+                }
+                seg_lo = seg_hi;
+                wave_sync();
+                if (n && !(ACX_S4_EXP & 8)) {
+                    S4_MARK(M_FETCH);
+                    // where the entries sit, their windows, the requests for their hot cells.  Straight-line over the slots (lane l
+                    // owns entries l, 64 + l, ..; slots are worked in pairs, a pair beyond the queue's end is skipped): their LDS
+                    // reads and gathers overlap.  A slot beyond the queue's end asks the spare cell (all zero: nothing ends
+                    // there, nothing goes deeper).
+                    const uint32_t k = (n + 63u) >> 6;
+                    const uint32_t cx1 = r_tile - 32u;                  // entry + cx1 = 1 + (offset of the tile's first byte in its haystack + position)
+                    const uint32_t sbase = wbase + cur * S4_SYMB;
+                    uint32_t LL[S4_NE];
+#pragma unroll
+                    for (int e = 0; e < S4_NE; e++) { LL[e] = longest; hcN[e].x = 0; hcN[e].y = 0; ppN[e] = S4_HP + 1u; }
+                    if (use_other) {                                    // bytes of no key around (rare): the symbols that exist going back from every entry
+                        S4_SLOTS(e,
+                            const uint32_t qi = 64u * (uint32_t)e + lane;
+                            const uint32_t lo2 = other_limit(qi < n ? (uint32_t)queue[qi] - 1u : S4_HP);
+                            if (lo2 < LL[e]) LL[e] = lo2;
+                        )
+                    }
+                    S4_SLOTS(e,
+                        const uint32_t qi = 64u * (uint32_t)e + lane;
+                        const uint32_t ent = *(const uint16_t*)(lds + qaddr + 128u * (uint32_t)e);      // position + 33
+                        // 1 + the offset in its haystack = x1 - stride * floor((x1 - 1) / stride), the quotient by a 24-bit multiply
+                        // (exact while x1 - 1 < stride + 2048)
+                        const uint32_t x1 = ent + cx1;
+                        const uint32_t q = ((uint32_t)__umul24(x1, m24) + nm24) >> 23;
+                        const uint32_t L0 = x1 - (uint32_t)__umul24(q, stride);
+                        const uint32_t L = L0 < LL[e] ? L0 : LL[e];
+                        // the 32 bits of symbols that end with the entry's position: words (ent >> 4) + 1 and + 2 of the symbol buffer
+                        const uint32_t* ws = (const uint32_t*)(lds + (((ent >> 2) & 0x7FCu) + sbase));
+                        const uint32_t X = __builtin_amdgcn_alignbit(ws[2], ws[1], ent << 1);
+                        const uint32_t off = (X >> (32u - 2u * S4_C - 3u)) & ((8u << (2u * S4_C)) - 8u);
+                        hcN[e] = *(const u32x2*)((const uint8_t*)a.hot4 + ((ACX_S4_EXP & 1) ? ((qi < n ? off : 0u) & 56u) : (qi < n ? off : (8u << (2u * S4_C)))));
+                        const uint32_t t5 = __builtin_amdgcn_ubfe(X, 32u - 2u * (S4_C + 2u), 4u) | 16u;     // 16 + the next two symbols: the cell's "go deeper" bit
+                        ppN[e] = ent | (L << 12) | (t5 << 18);
+                    )
+                    wave_sync();                                         // (the queue's memory is free from here on)
+                    nN = n; cgN = e0 - 33u; symN = sbase; haveN = true;
+                }
+            }
+        }
+
+        // ---- the round fetched one trip earlier: top levels, deeper walks, placement, records ------------------------------
+        if (haveO) {
+            S4_MARK(M_TOP);
+            const uint32_t n = nO, cg = cgO;
             const uint32_t k = (n + 63u) >> 6;                           // slots that hold entries
-            uint32_t pp[S4_NE], XX[S4_NE], rr[S4_NE], LL[S4_NE], cn[S4_NE];
-            u32x2 hc[S4_NE];
+            P.s_sym = (uint32_t*)(lds + symO) + 1;
+            uint32_t cn[S4_NE], rr[S4_NE];
             int32_t va[S4_NE];
             int32_t vb1 = 0; uint32_t vbe = S4_NE;                      // one second value per lane and round, with the slot it belongs to (as k_ppm_stream)
             auto set_vb = [&](uint32_t e, int32_t v) { if (vbe == (uint32_t)S4_NE) { vb1 = v; vbe = e; } };
 #pragma unroll
-            for (int e = 0; e < S4_NE; e++) { LL[e] = longest; pp[e] = S4_HP + 1u; XX[e] = 0; rr[e] = 0; cn[e] = 0; va[e] = 0; hc[e].x = 0; hc[e].y = 0; }
-            if (use_other) {                                            // bytes of no key around (rare): the symbols that exist going back from every entry
-                S4_SLOTS(e,
-                    const uint32_t qi = 64u * (uint32_t)e + lane;
-                    const uint32_t lo2 = other_limit(qi < n ? (uint32_t)queue[qi] - 1u : S4_HP);
-                    if (lo2 < LL[e]) LL[e] = lo2;
-                )
-            }
-            S4_MARK(M_FETCH);
-            // 1. where the entries sit, their windows, the requests for their hot cells.  Straight-line over the slots: their
-            // LDS reads and gathers overlap.  A slot beyond the queue's end reads the spare cell (all zero: nothing ends
-            // there, nothing goes deeper).
-            S4_SLOTS(e,
-                const uint32_t qi = 64u * (uint32_t)e + lane;
-                const uint32_t ent = *(const uint16_t*)(lds + qaddr + 128u * (uint32_t)e);      // position + 33
-                // 1 + the offset in its haystack = x1 - stride * floor((x1 - 1) / stride), the quotient by a 24-bit multiply
-                // (exact while x1 - 1 < stride + 2048)
-                const uint32_t x1 = ent + cx1;
-                const uint32_t q = ((uint32_t)__umul24(x1, m24) + nm24) >> 23;
-                const uint32_t L0 = x1 - (uint32_t)__umul24(q, stride);
-                LL[e] = L0 < LL[e] ? L0 : LL[e];
-                pp[e] = ent;
-                rr[e] = ent + cg;
-                // the 32 bits of symbols that end with the entry's position: words (ent >> 4) + 1 and + 2 of the symbol array
-                const uint32_t* ws = (const uint32_t*)(lds + (((ent >> 2) & 0x7FCu) | wbase_v));
-                XX[e] = __builtin_amdgcn_alignbit(ws[2], ws[1], ent << 1);
-                const uint32_t off = (XX[e] >> (32u - 2u * S4_C - 3u)) & ((8u << (2u * S4_C)) - 8u);
-                hc[e] = *(const u32x2*)((const uint8_t*)a.hot4 + ((ACX_S4_EXP & 1) ? ((qi < n ? off : 0u) & 56u) : (qi < n ? off : (8u << (2u * S4_C)))));
-            )
-            wave_sync();                                                 // (the queue's memory is free from here on)
-            S4_MARK(M_TOP);
-            // 2. top levels: how many keys end here (the cell holds the value of the shallowest), whether the walk goes deeper
+            for (int e = 0; e < S4_NE; e++) { cn[e] = 0; rr[e] = 0; va[e] = 0; }
+            // top levels: how many keys end here (the cell holds the value of the shallowest), whether the walk goes deeper
             uint32_t n_go = 0, gomask = 0, cmax = 0;
             S4_SLOTS(e,
-                const uint32_t hw = hc[e].x, L = LL[e];
+                const uint32_t hw = hcO[e].x, pk = ppO[e];
+                const uint32_t L = __builtin_amdgcn_ubfe(pk, 12u, 6u);
                 const uint32_t Lc = L < S4_C ? L : S4_C;
                 const uint32_t m = hw & ((1u << Lc) - 1u);
                 cn[e] = (uint32_t)__popc(m);
                 // the walk below the cell: bit 16 + (next two symbols) — asked whatever L is: a walk that runs out of symbols ends at once
-                const uint32_t t16 = __builtin_amdgcn_ubfe(XX[e], 32u - 2u * (S4_C + 2u), 4u) | 16u;
-                const uint32_t g = __builtin_amdgcn_ubfe(hw, t16, 1u);
+                const uint32_t g = __builtin_amdgcn_ubfe(hw, pk >> 18, 1u);
                 gomask |= g << e; n_go += g;
-                va[e] = (int32_t)hc[e].y;
+                va[e] = (int32_t)hcO[e].y;
+                rr[e] = (pk & 0xFFFu) + cg;                              // the global position
                 cmax = cn[e] > cmax ? cn[e] : cmax;
             )
             S4_MARK(M_SECOND);
@@ -285,19 +337,20 @@ __global__ void __launch_bounds__(ACX_PPM_BLOCK) k_ppm_stream4(const acx_ppm_arg
 #pragma unroll
                 for (int e = 0; e < S4_NE; e++) {
                     if (cn[e] > 1u) {
-                        const uint32_t L = LL[e], Lc = L < S4_C ? L : S4_C;
-                        const uint32_t m = hc[e].x & ((1u << Lc) - 1u), m2 = m & (m - 1u);
+                        const uint32_t L = __builtin_amdgcn_ubfe(ppO[e], 12u, 6u), Lc = L < S4_C ? L : S4_C;
+                        const uint32_t m = hcO[e].x & ((1u << Lc) - 1u), m2 = m & (m - 1u);
                         const uint32_t d2 = (uint32_t)__ffs(m2);
-                        set_vb((uint32_t)e, a.top_val[top_base4(d2) + (XX[e] >> (32u - 2u * d2))]);
+                        const uint32_t X = P.window((ppO[e] & 0xFFFu) - 1u);
+                        set_vb((uint32_t)e, a.top_val[top_base4(d2) + (X >> (32u - 2u * d2))]);
                     }
                 }
             }
             S4_MARK(M_DEEP);
-            // 3. deeper levels: the entries that go on, 64 at a time, one per lane; one 16-byte record per step, selects instead
-            // of branches (as k_ppm_stream).  The hand-over: {entry | L << 12 | eowmask << 20, second word of the cell}.
+            // deeper levels: the entries that go on, 64 at a time, one per lane; one 16-byte record per step, selects instead of
+            // branches (as k_ppm_stream).  The hand-over: {entry | L << 12 | .. | eowmask << 23, second word of the cell}.
             uint32_t n_deep;
             const uint32_t d_base = wave_excl_scan(n_go, n_deep);
-            if (ACX_S4_EXP & 2) n_deep = 0;
+            if (ACX_S4_EXP & 3) n_deep = 0;
             uint32_t* const dq = (uint32_t*)queue;                       // [0..127] hand-over, then {first, second value}; [128..129] the dump slot; then 64 counts
             uint16_t* const dcnt = (uint16_t*)(dq + 130);
             for (uint32_t d0 = 0; d0 < n_deep; d0 += 64u) {
@@ -306,7 +359,7 @@ __global__ void __launch_bounds__(ACX_PPM_BLOCK) k_ppm_stream4(const acx_ppm_arg
                     S4_SLOTS(e,
                         const uint32_t g = (gomask >> e) & 1u;
                         const uint32_t slot = (g != 0u && rnk < 64u) ? rnk : 64u;       // (slot 64: nobody reads it)
-                        u32x2 v; v.x = pp[e] | (LL[e] << 12) | (hc[e].x << 20); v.y = hc[e].y;
+                        u32x2 v; v.x = (ppO[e] & 0x7FFFFFu) | (hcO[e].x << 23); v.y = hcO[e].y;
                         *(u32x2*)(dq + 2 * slot) = v;
                         rnk += g;
                     )
@@ -317,7 +370,7 @@ __global__ void __launch_bounds__(ACX_PPM_BLOCK) k_ppm_stream4(const acx_ppm_arg
                     const uint32_t pk = go ? dq[2 * lane] : S4_HP + 1u;
                     uint32_t did = go ? dq[2 * lane + 1] : 0u;
                     const uint32_t wpq = (pk & 0xFFFu) - 1u, wL = (pk >> 12) & 63u;
-                    if (go && (pk >> 20)) did = a.cid[P.window(wpq) >> (32u - 2u * S4_C)];     // the cell's second word is a value: the id comes from cid[]
+                    if (go && (pk >> 23)) did = a.cid[P.window(wpq) >> (32u - 2u * S4_C)];     // the cell's second word is a value: the id comes from cid[]
                     uint32_t dd = S4_C, wc = 0;
                     int32_t wa = 0, wb = 0;
                     uint32_t s1 = P.sym_at(wpq - S4_C);
@@ -376,7 +429,7 @@ __global__ void __launch_bounds__(ACX_PPM_BLOCK) k_ppm_stream4(const acx_ppm_arg
                 wave_sync();
             }
             S4_MARK(M_PLACE);
-            // 4. place: entry e * 64 + lane; the records of a slot follow those of the slots below it (two slots per prefix
+            // place: entry e * 64 + lane; the records of a slot follow those of the slots below it (two slots per prefix
             // sum, 16 bits each: a slot has at most 64 x longest < 65536 records)
             uint32_t ex[S4_NE], rt = 0;
 #pragma unroll
@@ -409,7 +462,7 @@ __global__ void __launch_bounds__(ACX_PPM_BLOCK) k_ppm_stream4(const acx_ppm_arg
             }
             const bool wr = rt && !dead && !(ACX_S4_EXP & 4);
             S4_MARK(M_REC);
-            // 5. records, longest key of a position first.  Slot rt of the round (one past its last record; the grant has the
+            // records, longest key of a position first.  Slot rt of the round (one past its last record; the grant has the
             // room) takes the stores of the lanes that have no first / second record.
             uint32_t slow = 0, slow1 = 0;                                // slots with more than two records (slow1: or two, the second not in vb1): the general enumeration
             uint8_t* const out8 = (uint8_t*)(a.scratch + g_base + g_used);
@@ -439,7 +492,7 @@ __global__ void __launch_bounds__(ACX_PPM_BLOCK) k_ppm_stream4(const acx_ppm_arg
                         uint32_t oe = 0;
                         E.p = 0; E.X = 0; E.L = 0; E.idx = 0;
 #pragma unroll
-                        for (int e = 0; e < S4_NE; e++) if (se == (uint32_t)e) { E.p = pp[e] - (S4_HP + 1u); E.L = LL[e]; E.idx = rr[e]; oe = ex[e] + cn[e] - 1; }
+                        for (int e = 0; e < S4_NE; e++) if (se == (uint32_t)e) { E.p = (ppO[e] & 0xFFFu) - (S4_HP + 1u); E.L = __builtin_amdgcn_ubfe(ppO[e], 12u, 6u); E.idx = rr[e]; oe = ex[e] + cn[e] - 1; }
                         E.X = P.window(S4_HP + E.p);
                         const u32x4* cell = (const u32x4*)((const uint8_t*)a.cells + ((E.X >> (32u - 2u * S4_C)) << 5));
                         E.c0 = cell[0]; E.c1 = cell[1];
@@ -451,57 +504,34 @@ __global__ void __launch_bounds__(ACX_PPM_BLOCK) k_ppm_stream4(const acx_ppm_arg
             if (rt && !dead) g_used += rt;
             run_off += rt;
             wave_sync();
-        };
-#undef S4_SLOTS
-
-        S4_MARK(M_PUSH);
-        // (one call site of the round: its code exists once.)  Everything at once when the queue has the room (the usual
-        // case), else eight lanes (256 positions, at most 256 entries) at a time with a round whenever the next eight do not fit.
-        uint32_t seg_lo = 0, qcount = 0;
-        for (;;) {
-            if (seg_lo < 64u) {
-                const uint32_t ex_lo = seg_lo ? (uint32_t)__builtin_amdgcn_readlane((int)x_ex, (int)seg_lo) : 0u;
-                uint32_t seg_hi = 64u, n_seg = x_tot - ex_lo;
-                if (n_seg > S4_QCAP - qcount) { seg_hi = seg_lo + 8u; n_seg = (seg_hi < 64u ? (uint32_t)__builtin_amdgcn_readlane((int)x_ex, (int)seg_hi) : x_tot) - ex_lo; }
-                if (n_seg <= S4_QCAP - qcount) {                         // (else: a round first — 256 entries fit the empty queue)
-                    uint32_t w = (lane >= seg_lo && lane < seg_hi) ? pw : 0u;
-                    if (ACX_S4_EXP & 16) w = 0;
-                    uint32_t ja = wbase + S4_QUEUE + 2u * (qcount + (x_ex - ex_lo));
-                    const uint32_t lp = 32u * lane + S4_HP + 1u;
-                    while (w) {
-                        const uint32_t b = (uint32_t)__builtin_ctz(w);
-                        w &= w - 1u;
-                        *(uint16_t*)(lds + ja) = (uint16_t)(lp + b);
-                        ja += 2u;
-                    }
-                    qcount += n_seg;
-                    seg_lo = seg_hi;
-                    wave_sync();
-                    if (seg_lo < 64u) continue;
-                }
-            }
-            if (qcount && !(ACX_S4_EXP & 8)) do_round(qcount);
-            qcount = 0;               // (the queue is full, or the symbols of this tile are about to move)
-            if (seg_lo >= 64u) break;
         }
 
+        // ---- set N becomes set O; a tile that has handed over all its candidates makes room for the next ---------------------
         S4_MARK(M_TAIL);
-        // ---- the tail of this tile is the halo of the next ----------------------------------------------
-        {
-            uint32_t t = 0, tn = 0;
-            if (lane < 2u) t = sym[130u + lane];
-            if (use_other && lane == 0u) tn = obits[64];
+#pragma unroll
+        for (int e = 0; e < S4_NE; e++) { hcO[e] = hcN[e]; ppO[e] = ppN[e]; }
+        nO = nN; cgO = cgN; symO = symN; haveO = haveN;
+        if (tile_ok && seg_lo >= 64u) {
+            // the tail of this tile is the halo of the next (which is staged into the other buffer)
+            const uint32_t* const sc = (const uint32_t*)(lds + wbase + cur * S4_SYMB);
+            uint32_t* const sn = (uint32_t*)(lds + wbase + (cur ^ 1u) * S4_SYMB);
+            if (lane < 2u) sn[2u + lane] = sc[130u + lane];
+            if (use_other && lane == 0u) obits[0] = obits[64];
+            any_prev = any_cur;
+            e0 += S4_TPOS;
+            r_tile += step_r;
+            if (r_tile >= stride) r_tile -= stride;
+            cur ^= 1u;
+            tiles_left--;
+            tile_ok = tiles_left != 0u && e0 < H;
+            need_stage = tile_ok;
             wave_sync();
-            if (lane < 2u) sym[2u + lane] = t;
-            if (use_other && lane == 0u) obits[0] = tn;
         }
-        any_prev = any_cur;
-        e0 += S4_TPOS;
-        r_tile += step_r; h_tile += step_q;
-        if (r_tile >= stride) { r_tile -= stride; h_tile++; }
-        wave_sync();
+        if (!tile_ok && !haveO) break;
     }
+#undef S4_SLOTS
     if (lane == 0) {
+        if (ACX_S4_EXP & 5) { run_off = 0; ng = 0; }                   // (timing-only builds: nothing for the gather to move)
         desc[0] = run_off; desc[1] = ng; if (ng) desc[18 + ng - 1] = g_used;
         // the records of the 16 waves of this block, summed where k_ppm_gather_pos finds them (relaxed: no fences, see k_ppm_stream)
         if (a.block_sum && run_off) __hip_atomic_fetch_add(a.block_sum + blockIdx.x, run_off, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
