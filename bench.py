@@ -75,6 +75,7 @@ def parse():
     ap.add_argument("--cpu-sample-reads", type=int, default=None,
                     help="haystacks timed on the CPU baseline legs (default: the whole first batch; 0 disables)")
     ap.add_argument("--verify", action="store_true", help="check the first batch's GPU output against the oracle (all records)")
+    ap.add_argument("--lib", default=None, help="another build of libacx.so (development A/B, tools/build_variant.sh) instead of the package's")
     ap.add_argument("--launch-check", action="store_true",
                     help="start the ranks (gloo, no GPU), agree on the world size, print {\"n_gpus\": N, \"launch_check\": true} and exit: "
                          "tests/test_parallel_cpu.py runs the self-launch path of --gpus N with it")
@@ -236,6 +237,8 @@ def main():
 
     import pyahocorasick_amd as acx
     from pyahocorasick_amd import _lib
+    if args.lib:
+        _lib.LIB_PATH = os.path.abspath(args.lib)
     from pyahocorasick_amd.device import Scanner
     from pyahocorasick_amd.parallel import broadcast_image, halo_shard, shard_range
     from pyahocorasick_amd import workloads as W

@@ -795,7 +795,7 @@ static int scan_ppm(acx_image_t* img, const acx_scan_params* p, acx_result* r, h
         if (g_phase) {
             unsigned long long hph[8];
             if (hipMemcpy(hph, g_phase, 64, hipMemcpyDeviceToHost) == hipSuccess && hph[7])
-                fprintf(stderr, "[phases of the previous scan, clocks summed over waves] stage+filter %llu push %llu fetch %llu tops %llu deep %llu place+records %llu rest %llu\n", hph[0], hph[1], hph[2], hph[3], hph[4], hph[5], hph[7]);
+                fprintf(stderr, "[phases of the previous scan, clock ticks summed over waves] %llu %llu %llu %llu %llu %llu %llu %llu (k_ppm_stream: stage+filter, push, fetch, tops, deep, place+records, -, rest; k_ppm_stream4: top+deep, convert, push+fetch, place+records, stage, -, -, loop)\n", hph[0], hph[1], hph[2], hph[3], hph[4], hph[5], hph[6], hph[7]);
             (void)hipMemset(g_phase, 0, 64);
         }
     }

@@ -297,6 +297,7 @@ __global__ void __launch_bounds__(ACX_PPM_BLOCK) k_ppm_scan(const acx_ppm_args a
 #define PPM_QCAP_MAX 384u          // queue entries (uint16) the LDS layout has room for: 64 x NE, NE <= 6 — a round takes them all
 #define PPM_DESC_WORDS 40u         // per wave: total, n_grants, 16 x base, 16 x count (+ pad)
 #define PPM_MAX_GRANTS 16u
+#define PPM_GPOS_THREADS 64        // k_ppm_gather_pos: one wave per block, no LDS
 
 // OFFS:  the batch is given by a device offsets array instead of a fixed stride (ragged packets, one long
 //        haystack).  Contract: off[0] = 0 and no haystack shorter than 8 bytes (acx_scan_params.min_hay_len), as with a
@@ -1104,29 +1105,30 @@ __global__ void __launch_bounds__(256) k_ppm_gather(const acx_ppm_gather_args c)
 // records in front of position h * stride.  A wave of k_ppm_stream covers the positions [A, B) = its run of tiles, so its
 // block here knows every haystack that starts in there: those in front of its first record, those between two records
 // of different haystacks (the thread of the later record fills the gap), those behind its last record.
-__global__ void __launch_bounds__(256) k_ppm_gather_pos(const acx_ppm_gather_args c) {
-    __shared__ uint32_t s_red[4];
+__global__ void __launch_bounds__(PPM_GPOS_THREADS) k_ppm_gather_pos(const acx_ppm_gather_args c) {
+    // One WAVE per block and no LDS: the scan kernel of the NEXT batch, beside which this kernel runs, may hold every byte of
+    // a CU's LDS (k_ppm_stream4 does), and a block that asks for any — 16 bytes for a reduction — then finds no CU to start on.
+    constexpr int GT = PPM_GPOS_THREADS;
+    static_assert(GT == 64, "the sums below are wave sums");
     const int n_blocks = (int)(c.n_waves / ACX_PPM_WAVES);
     // sum over the block (the records of one scan are fewer than 2^32: the pool addresses them with 32 bits)
     auto block_add = [&](uint32_t x) -> uint32_t {
 #pragma unroll
         for (int d = 32; d >= 1; d >>= 1) x += __shfl_xor(x, d, 64);
-        __syncthreads();
-        if ((threadIdx.x & 63) == 0) s_red[threadIdx.x >> 6] = x;
-        __syncthreads();
-        return s_red[0] + s_red[1] + s_red[2] + s_red[3];
+        return x;
     };
     uint32_t total32 = 0;
 #pragma unroll 1
-    for (int b = threadIdx.x; b < n_blocks; b += 256) total32 += c.block_sum[b];
+    for (int b = threadIdx.x; b < n_blocks; b += GT) total32 += c.block_sum[b];
     const int64_t total = (int64_t)block_add(total32);
     if (blockIdx.x == 0) {
         // what the host reads when this result completes (its pinned words), the control words and the block sums of the
         // result's NEXT scan back to zero: no copies behind this kernel, no memset in front of the next scan kernel
-        if (threadIdx.x == 0) { c.host_words[0] = total; c.host_words[1] = ((const int32_t*)(c.ctl + 8))[0]; c.host_words[2] = ((const int32_t*)(c.ctl + 9))[0]; }
-        __syncthreads();
-        if (threadIdx.x < 16) c.ctl[threadIdx.x] = 0ull;
-        for (int b = threadIdx.x; b < ACX_PPM_MAX_BLOCKS; b += 256) c.block_sum_next[b] = 0u;
+        uint32_t f1 = 0, f2 = 0;
+        if (threadIdx.x == 0) { f1 = (uint32_t)((const int32_t*)(c.ctl + 8))[0]; f2 = (uint32_t)((const int32_t*)(c.ctl + 9))[0]; c.host_words[0] = total; c.host_words[1] = (int32_t)f1; c.host_words[2] = (int32_t)f2; }
+        const uint32_t seen = (uint32_t)__shfl((int)(f1 | f2 | 0x100u), 0, 64);      // (a value that depends on the flags lane 0 read: the stores below wait for its loads)
+        if (seen && threadIdx.x < 16) c.ctl[threadIdx.x] = 0ull;
+        for (int b = threadIdx.x; b < ACX_PPM_MAX_BLOCKS; b += GT) c.block_sum_next[b] = 0u;
     }
     const bool fits = total <= c.capacity;
     const uint32_t stride = (uint32_t)c.stride;
@@ -1154,7 +1156,7 @@ __global__ void __launch_bounds__(256) k_ppm_gather_pos(const acx_ppm_gather_arg
         uint32_t part = 0;                                             // records of the waves in front of w: whole blocks, then the waves of its own
         const int wb = (int)(w / ACX_PPM_WAVES);
 #pragma unroll 1
-        for (int b = threadIdx.x; b < wb; b += 256) part += c.block_sum[b];
+        for (int b = threadIdx.x; b < wb; b += GT) part += c.block_sum[b];
         if (threadIdx.x < (int)(w % ACX_PPM_WAVES)) part += c.wave_desc[((size_t)wb * ACX_PPM_WAVES + threadIdx.x) * PPM_DESC_WORDS];
         const int64_t base = (int64_t)block_add(part);
         u32x2* dst = (u32x2*)(c.matches + base);
@@ -1178,7 +1180,7 @@ __global__ void __launch_bounds__(256) k_ppm_gather_pos(const acx_ppm_gather_arg
             };
             auto q_of = [&](uint32_t k) -> uint32_t { uint32_t t; return locate(src[k].x, t); };
             if (head && threadIdx.x == 0) __builtin_nontemporal_store(emit(0, __builtin_nontemporal_load(src), q_last), dst + li);
-            for (uint32_t k0 = 0; k0 < pairs; k0 += 256) {
+            for (uint32_t k0 = 0; k0 < pairs; k0 += GT) {
                 const uint32_t k = k0 + threadIdx.x;
                 if (k < pairs) {
                     const u32x4a v = src2[k];
@@ -1193,14 +1195,14 @@ __global__ void __launch_bounds__(256) k_ppm_gather_pos(const acx_ppm_gather_arg
                     __builtin_nontemporal_store(o, dst2 + k);
                 }
             }
-            if (tailn && threadIdx.x == 255) __builtin_nontemporal_store(emit(n - 1, __builtin_nontemporal_load(src + n - 1), n > 1 ? q_of(n - 2) : q_last), dst + li + n - 1);
+            if (tailn && threadIdx.x == GT - 1) __builtin_nontemporal_store(emit(n - 1, __builtin_nontemporal_load(src + n - 1), n > 1 ? q_of(n - 2) : q_last), dst + li + n - 1);
             if (n) q_last = q_of(n - 1);
             li += n;
         }
         (void)lane;
         // haystacks behind the last record (all of them, when the wave has none or nothing fits)
         const int64_t h_last = fits ? h0 + (int64_t)(int32_t)q_last : hA - 1;
-        for (int64_t hh = h_last + 1 + threadIdx.x; hh < hB; hh += 256) c.match_off[hh] = base + (fits ? count : 0u);
+        for (int64_t hh = h_last + 1 + threadIdx.x; hh < hB; hh += GT) c.match_off[hh] = base + (fits ? count : 0u);
     }
     if (blockIdx.x == 0 && threadIdx.x == 0) c.match_off[c.n_hay] = total;
 }
@@ -1369,7 +1371,7 @@ hipError_t acx_launch_ppm_gather(const uint32_t* wave_desc, int64_t n_waves, int
     const int64_t cap = (int64_t)num_cus() * 32;
     if (blocks > cap) blocks = cap;
     if (c.off) hipLaunchKernelGGL(k_ppm_gather, dim3((unsigned)blocks), dim3(256), 0, s, c);
-    else hipLaunchKernelGGL(k_ppm_gather_pos, dim3((unsigned)(n_waves < cap ? n_waves : cap)), dim3(256), 0, s, c);
+    else { const int64_t cap4 = 4 * cap; hipLaunchKernelGGL(k_ppm_gather_pos, dim3((unsigned)(n_waves < cap4 ? n_waves : cap4)), dim3(PPM_GPOS_THREADS), 0, s, c); }
     return hipGetLastError();
 }
 

@@ -32,6 +32,13 @@
 #ifndef ACX_S4_EXP
 #define ACX_S4_EXP 0
 #endif
+// -DACX_S4_PHASES: every wave adds up the clock ticks (s_memtime, 100 MHz) it spends in the five steps of a trip of the loop
+// (acx_ppm_args.phase_out: 8 sums over all waves; read and printed by scan_ppm under ACX_PPM_PHASES in -DACX_TUNING builds)
+#ifdef ACX_S4_PHASES
+#define S4_PH(i) do { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); ph[i] += t_ - tph; tph = t_; } while (0)
+#else
+#define S4_PH(i) do { } while (0)
+#endif
 #ifdef ACX_S4_MARK
 #define S4_MARK(x) asm volatile("; MARK " #x)
 #else
@@ -53,6 +60,15 @@ constexpr uint32_t S4_SYMB = 536;                      // bytes of one symbol bu
 constexpr uint32_t S4_OBITS = 2 * S4_SYMB;             // word 0: halo, 1 .. 64: tile (one bit per staged position: a byte of no key), 65: spare
 constexpr uint32_t S4_QUEUE = S4_OBITS + 264;          // 352 uint16 entries; the hand-over of the deeper walks lives in the same memory
 static_assert(S4_QUEUE % 8 == 0 && S4_QUEUE + 2 * S4_QCAP <= S4_WAVE_BYTES && 648 <= 2 * S4_QCAP && S4_G_BYTES + 16 * S4_WAVE_BYTES <= ACX_PPM_LDS_BYTES, "LDS plan");
+
+// LDS by byte address (the kernel's dynamic LDS starts at address 0: it has no static LDS).  A generic pointer built from
+// `smem` costs an add of the array's base — zero, but a link-time zero the compiler does not fold — per access: one
+// instruction per probe of the filter.
+typedef __attribute__((address_space(3))) uint32_t lds_u32_t;
+typedef __attribute__((address_space(3))) uint16_t lds_u16_t;
+__device__ __forceinline__ uint32_t lds_rd32(uint32_t byte_addr) { return *(const lds_u32_t*)byte_addr; }
+__device__ __forceinline__ uint32_t lds_rd16(uint32_t byte_addr) { return *(const lds_u16_t*)byte_addr; }
+__device__ __forceinline__ void lds_wr16(uint32_t byte_addr, uint32_t v) { *(lds_u16_t*)byte_addr = (uint16_t)v; }
 
 __device__ __forceinline__ uint32_t top_base4(uint32_t d) { return 0x55555555u & ((1u << (2u * d)) - 1u); }   // (4^d - 1) / 3: top_base[d] of a four-symbol image
 
@@ -158,165 +174,114 @@ __global__ void __launch_bounds__(ACX_PPM_BLOCK) k_ppm_stream4(const acx_ppm_arg
 
     // ---- the pipeline -----------------------------------------------------------------------------------
     // A ROUND is at most 352 candidates of one tile (all of them, unless the tile holds more).  Every trip of the loop
-    //   stages the next tile if the one before it has handed over all its candidates (symbols -> the OTHER symbol buffer,
-    //     the filter, the prefix sum of the pass words),
-    //   pushes the candidates of the next round into the queue and FETCHES: where they sit, their windows, the requests
-    //     for their hot cells — into the registers of set N,
-    //   works off the round fetched one trip earlier (set O): top levels, deeper walks, placement, records.
-    // The gathers of a round are in flight while the round before it is worked off and the next tile is staged: the
-    // CU's address unit serves them (about one lane per ns and CU, profiles/r4_*) beside the instruction stream instead
-    // of in front of it.
+    //   1. works off the first half of the round fetched one trip earlier (set O): top levels, deeper walks — every load
+    //      that is waited for lies here;
+    //   2. turns the bytes of the next tile into symbols (registers only) when this trip hands over the last candidates
+    //      of the current one, and requests the bytes of the tile after that;
+    //   3. pushes the candidates of the next round into the queue and FETCHES: where they sit, their windows, the
+    //      requests for their hot cells — into the registers of set N;
+    //   4. finishes set O: placement, records (stores);
+    //   5. stages the next tile: symbols -> the OTHER symbol buffer, the filter, the prefix sum of the pass words.
+    // Loads return in order: a wait for a later load is a wait for the hot cells too.  So nothing between 3 and the next
+    // trip's 1 waits for a load: the gathers of a round are in flight while the address unit of the CU serves them
+    // (about one lane per ns and CU, profiles/r4_*) and the wave does steps 4 and 5.
     uint32_t cur = 0;                                                  // symbol buffer of the tile whose candidates are being fetched
-    bool tile_ok = true, need_stage = true;
+    bool tile_ok = true;
     uint32_t pw = 0, x_ex = 0, x_tot = 0, seg_lo = 0, use_other = 0, any_cur = 0;
-    u32x2 hcO[S4_NE], hcN[S4_NE];
-    uint32_t ppO[S4_NE], ppN[S4_NE];                                   // entry (position + 33) | symbols that exist << 12 | (16 + the next two symbols) << 18
+    uint32_t Wc1 = 0, Wc2 = 0, anyo_c = 0;                             // the symbols of the tile that is being staged, which of its bytes occur in no key
+    // ONE set of slot registers: step 1 is the last reader of a round's hot cells, step 3 loads the next round's into the
+    // same registers (a second set would have to be copied into the first, and a copy of a loaded register is a wait)
+    u32x2 hcO[S4_NE];
+    uint32_t ppO[S4_NE], ppK[S4_NE];                                   // entry (position + 33) | symbols that exist << 12 | (16 + the next two symbols) << 18; ppK: set O's, kept across the fetch
     uint32_t nO = 0, nN = 0, cgO = 0, cgN = 0, symO = wbase, symN = wbase;
     bool haveO = false;
 #pragma unroll
-    for (int e = 0; e < S4_NE; e++) { hcO[e].x = 0; hcO[e].y = 0; ppO[e] = 0; hcN[e].x = 0; hcN[e].y = 0; ppN[e] = 0; }
+    for (int e = 0; e < S4_NE; e++) { hcO[e].x = 0; hcO[e].y = 0; ppO[e] = 0; ppK[e] = 0; }
 
+    // bytes of the tile in wnext -> symbols (registers); the bytes of the tile at e_next are requested
+    auto convert = [&](bool more, uint32_t e_next) {
+        S4_MARK(M_STAGE);
+        uint32_t diff = 0, pr[8];
+        anyo_c = 0;
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            const uint32_t w = wnext[j];
+            const uint32_t x = (w >> ar_shift) & 0x03030303u;
+            diff |= __builtin_amdgcn_perm(0u, ar_lut, x) ^ w;            // the letters permuted by the symbols give the bytes back iff all four are letters
+            pr[j] = x * 0x01041040u;                                      // one multiply gathers the four 2-bit fields into the top byte
+        }
+        Wc1 = __builtin_amdgcn_perm(pr[1], pr[0], 0x0c0c0703u) | __builtin_amdgcn_perm(pr[3], pr[2], 0x07030c0cu);
+        Wc2 = __builtin_amdgcn_perm(pr[5], pr[4], 0x0c0c0703u) | __builtin_amdgcn_perm(pr[7], pr[6], 0x07030c0cu);
+        if (__any(diff != 0u)) {                                        // some byte of the tile is none of the four letters
+#pragma unroll
+            for (int j = 0; j < 8; j++) anyo_c |= nib_of(wnext[j]) << (4 * j);
+        }
+        if (more) load_tile(e_next);
+    };
+    // the tile at e0 (its symbols in Wc1, Wc2): symbols -> buffer `cur`, the filter, the prefix sum
+    auto stage_rest = [&]() {
+        uint32_t* const sym_tile = (uint32_t*)(lds + wbase + cur * S4_SYMB) + 4;
+        const uint32_t left = H - e0;
+        const uint32_t npos = left < S4_TPOS ? left : S4_TPOS;
+        const uint32_t W1 = Wc1, W2 = Wc2, anyo = anyo_c;
+        { u32x2 v; v.x = W1; v.y = W2; *(u32x2*)(sym_tile + 2u * lane) = v; }
+        any_cur = __any(anyo != 0) ? 1u : 0u;
+        use_other = any_cur | any_prev;
+        if (use_other) obits_tile[lane] = anyo;
+        wave_sync();
+        const uint32_t W0 = sym_tile[(int)(2u * lane) - 1];
+        S4_MARK(M_FILTER);
+        // the filter: every lane asks the bitmap about its own 32 positions, windows in registers (as k_ppm_stream)
+        {
+            constexpr uint32_t FB = 2 * S4_F, ush = 32u - FB, amask = ((1u << (FB - 5u)) - 1u) << 2;
+            uint32_t U[5];
+            U[0] = __builtin_amdgcn_alignbit(W1, W0, ush); U[1] = __builtin_amdgcn_alignbit(W2, W1, ush); U[2] = W2 >> ush; U[3] = 0; U[4] = 0;
+            uint32_t acc = 0;
+#pragma unroll
+            for (int i0 = 0; i0 < 32; i0 += 16) {
+                uint32_t gw[16], bs[16];
+#pragma unroll
+                for (int i = 0; i < 16; i++) {
+                    const uint32_t b = 2u * (uint32_t)(i0 + i + 1), k = b >> 5, sh = b & 31u;
+                    bs[i] = sh ? __builtin_amdgcn_alignbit(U[k + 1], U[k], sh) : U[k];
+                    const uint32_t A = (bs[i] >> 3) & amask;
+                    gw[i] = lds_rd32(A);
+                }
+#pragma unroll
+                for (int i = 0; i < 16; i++) acc = __builtin_amdgcn_alignbit(gw[i] >> (bs[i] & 31u), acc, 1u);
+            }
+            pw = acc;
+        }
+        if (use_other | (npos < S4_TPOS ? 1u : 0u)) {
+            const uint32_t lp = 32u * lane;
+            const uint32_t nv = npos > lp ? (npos - lp < 32u ? npos - lp : 32u) : 0u;
+            pw &= (nv >= 32u ? 0xFFFFFFFFu : (1u << nv) - 1u) & ~anyo;      // (a byte of no key ends no key)
+        }
+        S4_MARK(M_PREFIX);
+        x_ex = wave_excl_scan((uint32_t)__popc(pw), x_tot);
+        if (ACX_S4_EXP & 16) x_tot = 0;
+        seg_lo = 0;
+    };
+    convert(tiles_left > 1, e0 + S4_TPOS);
+    stage_rest();
+
+#ifdef ACX_S4_PHASES
+    unsigned long long ph[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tph = __builtin_amdgcn_s_memtime();
+#endif
 #define S4_SLOTS(e, ...) _Pragma("unroll") for (int g_ = 0; g_ < S4_NE; g_ += 2) { if (g_ == 0 || (uint32_t)g_ < k) { _Pragma("unroll") for (int e = g_; e < g_ + 2; e++) { __VA_ARGS__ } } }
     for (;;) {
-        // ---- stage the tile at e0: bytes -> 2-bit symbols (buffer `cur`), the filter, the prefix sum ------------------
-        if (tile_ok && need_stage) {
-            S4_MARK(M_STAGE);
-            uint32_t* const sym_tile = (uint32_t*)(lds + wbase + cur * S4_SYMB) + 4;
-            const uint32_t left = H - e0;
-            const uint32_t npos = left < S4_TPOS ? left : S4_TPOS;
-            uint32_t W0, W1, W2, anyo = 0;
-            {
-                uint32_t diff = 0, pr[8];
+        S4_PH(7);
+        // ---- 1. the round fetched one trip earlier: top levels, deeper walks -----------------------------------------------
+        const uint32_t k = (nO + 63u) >> 6;                              // slots of set O that hold entries
+        uint32_t cn[S4_NE];
+        int32_t va[S4_NE];
+        int32_t vb1 = 0; uint32_t vbe = S4_NE;                          // one second value per lane and round, with the slot it belongs to (as k_ppm_stream)
+        auto set_vb = [&](uint32_t e, int32_t v) { if (vbe == (uint32_t)S4_NE) { vb1 = v; vbe = e; } };
 #pragma unroll
-                for (int j = 0; j < 8; j++) {
-                    const uint32_t w = wnext[j];
-                    const uint32_t x = (w >> ar_shift) & 0x03030303u;
-                    diff |= __builtin_amdgcn_perm(0u, ar_lut, x) ^ w;    // the letters permuted by the symbols give the bytes back iff all four are letters
-                    pr[j] = x * 0x01041040u;                              // one multiply gathers the four 2-bit fields into the top byte
-                }
-                W1 = __builtin_amdgcn_perm(pr[1], pr[0], 0x0c0c0703u) | __builtin_amdgcn_perm(pr[3], pr[2], 0x07030c0cu);
-                W2 = __builtin_amdgcn_perm(pr[5], pr[4], 0x0c0c0703u) | __builtin_amdgcn_perm(pr[7], pr[6], 0x07030c0cu);
-                if (__any(diff != 0u)) {                                // some byte of the tile is none of the four letters
-#pragma unroll
-                    for (int j = 0; j < 8; j++) anyo |= nib_of(wnext[j]) << (4 * j);
-                }
-            }
-            { u32x2 v; v.x = W1; v.y = W2; *(u32x2*)(sym_tile + 2u * lane) = v; }
-            if (tiles_left > 1) load_tile(e0 + S4_TPOS);                 // the next tile's bytes: requested a whole trip ahead
-            any_cur = __any(anyo != 0) ? 1u : 0u;
-            use_other = any_cur | any_prev;
-            if (use_other) obits_tile[lane] = anyo;
-            wave_sync();
-            W0 = sym_tile[(int)(2u * lane) - 1];
-            S4_MARK(M_FILTER);
-            // the filter: every lane asks the bitmap about its own 32 positions, windows in registers (as k_ppm_stream)
-            {
-                constexpr uint32_t FB = 2 * S4_F, ush = 32u - FB, amask = ((1u << (FB - 5u)) - 1u) << 2;
-                uint32_t U[5];
-                U[0] = __builtin_amdgcn_alignbit(W1, W0, ush); U[1] = __builtin_amdgcn_alignbit(W2, W1, ush); U[2] = W2 >> ush; U[3] = 0; U[4] = 0;
-                uint32_t acc = 0;
-#pragma unroll
-                for (int i0 = 0; i0 < 32; i0 += 16) {
-                    uint32_t gw[16], bs[16];
-#pragma unroll
-                    for (int i = 0; i < 16; i++) {
-                        const uint32_t b = 2u * (uint32_t)(i0 + i + 1), k = b >> 5, sh = b & 31u;
-                        bs[i] = sh ? __builtin_amdgcn_alignbit(U[k + 1], U[k], sh) : U[k];
-                        const uint32_t A = (bs[i] >> 3) & amask;
-                        gw[i] = *(const uint32_t*)((const uint8_t*)smem + A);
-                    }
-#pragma unroll
-                    for (int i = 0; i < 16; i++) acc = __builtin_amdgcn_alignbit(gw[i] >> (bs[i] & 31u), acc, 1u);
-                }
-                pw = acc;
-            }
-            if (use_other | (npos < S4_TPOS ? 1u : 0u)) {
-                const uint32_t lp = 32u * lane;
-                const uint32_t nv = npos > lp ? (npos - lp < 32u ? npos - lp : 32u) : 0u;
-                pw &= (nv >= 32u ? 0xFFFFFFFFu : (1u << nv) - 1u) & ~anyo;  // (a byte of no key ends no key)
-            }
-            S4_MARK(M_PREFIX);
-            x_ex = wave_excl_scan((uint32_t)__popc(pw), x_tot);
-            if (ACX_S4_EXP & 16) x_tot = 0;
-            seg_lo = 0; need_stage = false;
-        }
-
-        // ---- the next round of this tile: its candidates -> the queue, in position order; fetch --------------------------
-        bool haveN = false;
-        if (tile_ok) {
-            if (x_tot == 0u) seg_lo = 64u;
-            else {
-                S4_MARK(M_PUSH);
-                const uint32_t ex_lo = seg_lo ? (uint32_t)__builtin_amdgcn_readlane((int)x_ex, (int)seg_lo) : 0u;
-                uint32_t seg_hi = 64u, n = x_tot - ex_lo;
-                if (n > S4_QCAP) { seg_hi = seg_lo + 8u; n = (seg_hi < 64u ? (uint32_t)__builtin_amdgcn_readlane((int)x_ex, (int)seg_hi) : x_tot) - ex_lo; }   // (eight lanes: 256 positions)
-                {
-                    uint32_t w = (lane >= seg_lo && lane < seg_hi) ? pw : 0u;
-                    uint32_t ja = wbase + S4_QUEUE + 2u * (x_ex - ex_lo);
-                    const uint32_t lp = 32u * lane + S4_HP + 1u;
-                    while (w) {
-                        const uint32_t b = (uint32_t)__builtin_ctz(w);
-                        w &= w - 1u;
-                        *(uint16_t*)(lds + ja) = (uint16_t)(lp + b);
-                        ja += 2u;
-                    }
-                }
-                seg_lo = seg_hi;
-                wave_sync();
-                if (n && !(ACX_S4_EXP & 8)) {
-                    S4_MARK(M_FETCH);
-                    // where the entries sit, their windows, the requests for their hot cells.  Straight-line over the slots (lane l
-                    // owns entries l, 64 + l, ..; slots are worked in pairs, a pair beyond the queue's end is skipped): their LDS
-                    // reads and gathers overlap.  A slot beyond the queue's end asks the spare cell (all zero: nothing ends
-                    // there, nothing goes deeper).
-                    const uint32_t k = (n + 63u) >> 6;
-                    const uint32_t cx1 = r_tile - 32u;                  // entry + cx1 = 1 + (offset of the tile's first byte in its haystack + position)
-                    const uint32_t sbase = wbase + cur * S4_SYMB;
-                    uint32_t LL[S4_NE];
-#pragma unroll
-                    for (int e = 0; e < S4_NE; e++) { LL[e] = longest; hcN[e].x = 0; hcN[e].y = 0; ppN[e] = S4_HP + 1u; }
-                    if (use_other) {                                    // bytes of no key around (rare): the symbols that exist going back from every entry
-                        S4_SLOTS(e,
-                            const uint32_t qi = 64u * (uint32_t)e + lane;
-                            const uint32_t lo2 = other_limit(qi < n ? (uint32_t)queue[qi] - 1u : S4_HP);
-                            if (lo2 < LL[e]) LL[e] = lo2;
-                        )
-                    }
-                    S4_SLOTS(e,
-                        const uint32_t qi = 64u * (uint32_t)e + lane;
-                        const uint32_t ent = *(const uint16_t*)(lds + qaddr + 128u * (uint32_t)e);      // position + 33
-                        // 1 + the offset in its haystack = x1 - stride * floor((x1 - 1) / stride), the quotient by a 24-bit multiply
-                        // (exact while x1 - 1 < stride + 2048)
-                        const uint32_t x1 = ent + cx1;
-                        const uint32_t q = ((uint32_t)__umul24(x1, m24) + nm24) >> 23;
-                        const uint32_t L0 = x1 - (uint32_t)__umul24(q, stride);
-                        const uint32_t L = L0 < LL[e] ? L0 : LL[e];
-                        // the 32 bits of symbols that end with the entry's position: words (ent >> 4) + 1 and + 2 of the symbol buffer
-                        const uint32_t* ws = (const uint32_t*)(lds + (((ent >> 2) & 0x7FCu) + sbase));
-                        const uint32_t X = __builtin_amdgcn_alignbit(ws[2], ws[1], ent << 1);
-                        const uint32_t off = (X >> (32u - 2u * S4_C - 3u)) & ((8u << (2u * S4_C)) - 8u);
-                        hcN[e] = *(const u32x2*)((const uint8_t*)a.hot4 + ((ACX_S4_EXP & 1) ? ((qi < n ? off : 0u) & 56u) : (qi < n ? off : (8u << (2u * S4_C)))));
-                        const uint32_t t5 = __builtin_amdgcn_ubfe(X, 32u - 2u * (S4_C + 2u), 4u) | 16u;     // 16 + the next two symbols: the cell's "go deeper" bit
-                        ppN[e] = ent | (L << 12) | (t5 << 18);
-                    )
-                    wave_sync();                                         // (the queue's memory is free from here on)
-                    nN = n; cgN = e0 - 33u; symN = sbase; haveN = true;
-                }
-            }
-        }
-
-        // ---- the round fetched one trip earlier: top levels, deeper walks, placement, records ------------------------------
+        for (int e = 0; e < S4_NE; e++) { cn[e] = 0; va[e] = 0; }
         if (haveO) {
-            S4_MARK(M_TOP);
-            const uint32_t n = nO, cg = cgO;
-            const uint32_t k = (n + 63u) >> 6;                           // slots that hold entries
             P.s_sym = (uint32_t*)(lds + symO) + 1;
-            uint32_t cn[S4_NE], rr[S4_NE];
-            int32_t va[S4_NE];
-            int32_t vb1 = 0; uint32_t vbe = S4_NE;                      // one second value per lane and round, with the slot it belongs to (as k_ppm_stream)
-            auto set_vb = [&](uint32_t e, int32_t v) { if (vbe == (uint32_t)S4_NE) { vb1 = v; vbe = e; } };
-#pragma unroll
-            for (int e = 0; e < S4_NE; e++) { cn[e] = 0; rr[e] = 0; va[e] = 0; }
+            S4_MARK(M_TOP);
             // top levels: how many keys end here (the cell holds the value of the shallowest), whether the walk goes deeper
             uint32_t n_go = 0, gomask = 0, cmax = 0;
             S4_SLOTS(e,
@@ -329,7 +294,6 @@ __global__ void __launch_bounds__(ACX_PPM_BLOCK) k_ppm_stream4(const acx_ppm_arg
                 const uint32_t g = __builtin_amdgcn_ubfe(hw, pk >> 18, 1u);
                 gomask |= g << e; n_go += g;
                 va[e] = (int32_t)hcO[e].y;
-                rr[e] = (pk & 0xFFFu) + cg;                              // the global position
                 cmax = cn[e] > cmax ? cn[e] : cmax;
             )
             S4_MARK(M_SECOND);
@@ -428,6 +392,85 @@ __global__ void __launch_bounds__(ACX_PPM_BLOCK) k_ppm_stream4(const acx_ppm_arg
                 }
                 wave_sync();
             }
+        }
+
+        S4_PH(0);
+        // ---- 2. this trip hands over the last candidates of the current tile: the next tile's bytes -> symbols ------------------
+        const uint32_t ex_lo = (tile_ok && seg_lo) ? (uint32_t)__builtin_amdgcn_readlane((int)x_ex, (int)seg_lo) : 0u;
+        const bool will_adv = tile_ok && x_tot - ex_lo <= S4_QCAP;
+        const bool st = will_adv && tiles_left > 1u && e0 + S4_TPOS < H;
+        if (st) convert(tiles_left > 2u, e0 + 2u * S4_TPOS);
+
+#pragma unroll
+        for (int e = 0; e < S4_NE; e++) ppK[e] = ppO[e];
+        S4_PH(1);
+        // ---- 3. the next round of this tile: its candidates -> the queue, in position order; fetch -------------------------------
+        bool haveN = false;
+        if (tile_ok && x_tot != 0u) {
+            S4_MARK(M_PUSH);
+            uint32_t seg_hi = 64u, n = x_tot - ex_lo;
+            if (n > S4_QCAP) { seg_hi = seg_lo + 8u; n = (seg_hi < 64u ? (uint32_t)__builtin_amdgcn_readlane((int)x_ex, (int)seg_hi) : x_tot) - ex_lo; }   // (eight lanes: 256 positions)
+            {
+                uint32_t w = (lane >= seg_lo && lane < seg_hi) ? pw : 0u;
+                uint32_t ja = wbase + S4_QUEUE + 2u * (x_ex - ex_lo);
+                const uint32_t lp = 32u * lane + S4_HP + 1u;
+                while (w) {
+                    const uint32_t b = (uint32_t)__builtin_ctz(w);
+                    w &= w - 1u;
+                    lds_wr16(ja, lp + b);
+                    ja += 2u;
+                }
+            }
+            seg_lo = seg_hi;
+            wave_sync();
+            if (n && !(ACX_S4_EXP & 8)) {
+                S4_MARK(M_FETCH);
+                // where the entries sit, their windows, the requests for their hot cells.  Straight-line over the slots (lane l
+                // owns entries l, 64 + l, ..; slots are worked in pairs, a pair beyond the queue's end is skipped): their LDS
+                // reads and gathers overlap.  A slot beyond the queue's end asks the spare cell (all zero: nothing ends
+                // there, nothing goes deeper).
+                const uint32_t k = (n + 63u) >> 6;                   // (slots of set N: shadows the count of set O)
+                const uint32_t cx1 = r_tile - 32u;                  // entry + cx1 = 1 + (offset of the tile's first byte in its haystack + position)
+                const uint32_t sbase = wbase + cur * S4_SYMB;
+                uint32_t LL[S4_NE];
+#pragma unroll
+                for (int e = 0; e < S4_NE; e++) LL[e] = longest;           // (slots beyond the round's last keep what they held: nobody reads them)
+                if (use_other) {                                    // bytes of no key around (rare): the symbols that exist going back from every entry
+                    S4_SLOTS(e,
+                        const uint32_t qi = 64u * (uint32_t)e + lane;
+                        const uint32_t lo2 = other_limit(qi < n ? (uint32_t)queue[qi] - 1u : S4_HP);
+                        if (lo2 < LL[e]) LL[e] = lo2;
+                    )
+                }
+                S4_SLOTS(e,
+                    const uint32_t qi = 64u * (uint32_t)e + lane;
+                    const uint32_t ent = lds_rd16(qaddr + 128u * (uint32_t)e);      // position + 33
+                    // 1 + the offset in its haystack = x1 - stride * floor((x1 - 1) / stride), the quotient by a 24-bit multiply
+                    // (exact while x1 - 1 < stride + 2048)
+                    const uint32_t x1 = ent + cx1;
+                    const uint32_t q = ((uint32_t)__umul24(x1, m24) + nm24) >> 23;
+                    const uint32_t L0 = x1 - (uint32_t)__umul24(q, stride);
+                    const uint32_t L = L0 < LL[e] ? L0 : LL[e];
+                    // the 32 bits of symbols that end with the entry's position: words (ent >> 4) + 1 and + 2 of the symbol buffer
+                    const uint32_t wa = ((ent >> 2) & 0x7FCu) + sbase;
+                    const uint32_t X = __builtin_amdgcn_alignbit(lds_rd32(wa + 8u), lds_rd32(wa + 4u), ent << 1);
+                    const uint32_t off = (X >> (32u - 2u * S4_C - 3u)) & ((8u << (2u * S4_C)) - 8u);
+                    hcO[e] = *(const u32x2*)((const uint8_t*)a.hot4 + ((ACX_S4_EXP & 1) ? ((qi < n ? off : 0u) & 56u) : (qi < n ? off : (8u << (2u * S4_C)))));
+                    const uint32_t t5 = __builtin_amdgcn_ubfe(X, 32u - 2u * (S4_C + 2u), 4u) | 16u;     // 16 + the next two symbols: the cell's "go deeper" bit
+                    ppO[e] = ent | (L << 12) | (t5 << 18);
+                )
+                wave_sync();                                         // (the queue's memory is free from here on)
+                nN = n; cgN = e0 - 33u; symN = sbase; haveN = true;
+            }
+        }
+
+        S4_PH(2);
+        // ---- 4. set O: placement, records ------------------------------------------------------------------------------------
+        if (haveO) {
+            const uint32_t cg = cgO;
+            uint32_t rr[S4_NE];
+#pragma unroll
+            for (int e = 0; e < S4_NE; e++) rr[e] = (ppK[e] & 0xFFFu) + cg;   // the global positions
             S4_MARK(M_PLACE);
             // place: entry e * 64 + lane; the records of a slot follow those of the slots below it (two slots per prefix
             // sum, 16 bits each: a slot has at most 64 x longest < 65536 records)
@@ -471,7 +514,11 @@ __global__ void __launch_bounds__(ACX_PPM_BLOCK) k_ppm_stream4(const acx_ppm_arg
                 uint32_t two = 0;
                 S4_SLOTS(e,
                     const uint32_t c = cn[e]; const uint32_t oe = ex[e] + c - 1u;
+#ifdef ACX_S4_PRED_STORES
+                    if (c) *(uint2*)(out8 + (oe << 3)) = make_uint2(rr[e], (uint32_t)va[e]);
+#else
                     *(uint2*)(out8 + ((c ? oe : rt) << 3)) = make_uint2(rr[e], (uint32_t)va[e]);
+#endif
                     two |= (c > 1u ? 1u : 0u) << e;
                     slow |= (c > 2u ? 1u : 0u) << e;
                 )
@@ -492,7 +539,7 @@ __global__ void __launch_bounds__(ACX_PPM_BLOCK) k_ppm_stream4(const acx_ppm_arg
                         uint32_t oe = 0;
                         E.p = 0; E.X = 0; E.L = 0; E.idx = 0;
 #pragma unroll
-                        for (int e = 0; e < S4_NE; e++) if (se == (uint32_t)e) { E.p = (ppO[e] & 0xFFFu) - (S4_HP + 1u); E.L = __builtin_amdgcn_ubfe(ppO[e], 12u, 6u); E.idx = rr[e]; oe = ex[e] + cn[e] - 1; }
+                        for (int e = 0; e < S4_NE; e++) if (se == (uint32_t)e) { E.p = (ppK[e] & 0xFFFu) - (S4_HP + 1u); E.L = __builtin_amdgcn_ubfe(ppK[e], 12u, 6u); E.idx = rr[e]; oe = ex[e] + cn[e] - 1; }
                         E.X = P.window(S4_HP + E.p);
                         const u32x4* cell = (const u32x4*)((const uint8_t*)a.cells + ((E.X >> (32u - 2u * S4_C)) << 5));
                         E.c0 = cell[0]; E.c1 = cell[1];
@@ -504,14 +551,14 @@ __global__ void __launch_bounds__(ACX_PPM_BLOCK) k_ppm_stream4(const acx_ppm_arg
             if (rt && !dead) g_used += rt;
             run_off += rt;
             wave_sync();
+
         }
 
-        // ---- set N becomes set O; a tile that has handed over all its candidates makes room for the next ---------------------
+        S4_PH(3);
+        // ---- the round that was fetched is the next trip's set O; a tile that has handed over all its candidates makes room for the next ---------------------
         S4_MARK(M_TAIL);
-#pragma unroll
-        for (int e = 0; e < S4_NE; e++) { hcO[e] = hcN[e]; ppO[e] = ppN[e]; }
         nO = nN; cgO = cgN; symO = symN; haveO = haveN;
-        if (tile_ok && seg_lo >= 64u) {
+        if (will_adv) {
             // the tail of this tile is the halo of the next (which is staged into the other buffer)
             const uint32_t* const sc = (const uint32_t*)(lds + wbase + cur * S4_SYMB);
             uint32_t* const sn = (uint32_t*)(lds + wbase + (cur ^ 1u) * S4_SYMB);
@@ -523,13 +570,18 @@ __global__ void __launch_bounds__(ACX_PPM_BLOCK) k_ppm_stream4(const acx_ppm_arg
             if (r_tile >= stride) r_tile -= stride;
             cur ^= 1u;
             tiles_left--;
-            tile_ok = tiles_left != 0u && e0 < H;
-            need_stage = tile_ok;
+            tile_ok = st;
             wave_sync();
+            // ---- 5. stage the next tile ------------------------------------------------------------------------------------
+            if (st) stage_rest();
         }
+        S4_PH(4);
         if (!tile_ok && !haveO) break;
     }
 #undef S4_SLOTS
+#ifdef ACX_S4_PHASES
+    if (lane == 0 && a.phase_out) for (int i = 0; i < 8; i++) atomicAdd(a.phase_out + i, ph[i]);
+#endif
     if (lane == 0) {
         if (ACX_S4_EXP & 5) { run_off = 0; ng = 0; }                   // (timing-only builds: nothing for the gather to move)
         desc[0] = run_off; desc[1] = ng; if (ng) desc[18 + ng - 1] = g_used;
