@@ -17,9 +17,13 @@ haystack bytes of a step come from HBM, not from a cache that the previous step 
                                every step scans a different quarter of it as ONE haystack
     --workload c4              config-4 shape on one GPU: Snort-style byte signatures (--keys, default
                                1,000,000), ragged packets 64..1500 B
-    --scaling strong           N > 1: ONE fixed corpus (c2: the read batches, c3: the text) is cut into
-                               N contiguous shards (text: with a longest_word-1 halo); default "weak":
-                               every rank scans its own batches of the full size
+    --scaling strong           N > 1: ONE fixed corpus (c2: the read batches, c3: the text, c4: the packets) is cut
+                               into N contiguous shards (reads by count, packets by BYTES, text with a
+                               longest_word-1 halo); default "weak": every rank scans its own batches of the full size
+    --configs all|none         N = 1, default workload only: after the headline measurement the other named
+                               single-GPU configurations are measured in the same run and reported under
+                               "configs": c5 (iter_long, same automaton and batches), c3 and c4 (two batches each) —
+                               each with value, ms_per_step, roofline and a sample-limited cpu_baseline
 
 N > 1: one process per GPU; rank 0 builds + flattens the automaton and the flat image is replicated
 with ONE RCCL broadcast; no data-path collective; time = max over ranks, value = all ranks' bytes /
@@ -44,7 +48,15 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md
-KERNEL_SOURCES = ("acx_kernels.hip", "acx_ppm_kernels.hip", "acx_kernels.h", "acx_ppm_layout.h", "acx_capi.hip")
+# the sources a dominant kernel is made of: a PMC traffic figure (profiles/traffic.json) is tied to their hash
+KERNEL_SOURCES = {
+    "k_ppm_stream4": ("acx_ppm_stream4.hip", "acx_ppm_device.h", "acx_ppm_layout.h", "acx_kernels.h"),
+    "k_ppm_stream": ("acx_ppm_kernels.hip", "acx_ppm_device.h", "acx_ppm_layout.h", "acx_kernels.h"),
+    "k_ppm_scan": ("acx_ppm_kernels.hip", "acx_ppm_device.h", "acx_ppm_layout.h", "acx_kernels.h"),
+    "k_walk_long_sel": ("acx_kernels.hip", "acx_kernels.h"),
+    "k_walk_itop": ("acx_kernels.hip", "acx_kernels.h"),
+    "k_walk_all": ("acx_kernels.hip", "acx_kernels.h"),
+}
 
 
 def parse():
@@ -75,6 +87,8 @@ def parse():
     ap.add_argument("--cpu-sample-reads", type=int, default=None,
                     help="haystacks timed on the CPU baseline legs (default: the whole first batch; 0 disables)")
     ap.add_argument("--verify", action="store_true", help="check the first batch's GPU output against the oracle (all records)")
+    ap.add_argument("--configs", choices=["all", "none"], default=None,
+                    help="the other named single-GPU configurations in the same run (default: all for the default command on one GPU)")
     ap.add_argument("--lib", default=None, help="another build of libacx.so (development A/B, tools/build_variant.sh) instead of the package's")
     ap.add_argument("--launch-check", action="store_true",
                     help="start the ranks (gloo, no GPU), agree on the world size, print {\"n_gpus\": N, \"launch_check\": true} and exit: "
@@ -123,9 +137,9 @@ def launch_check(args):
         print(json.dumps({"n_gpus": seen, "launch_check": True}), flush=True)
 
 
-def kernel_source_hash():
+def kernel_source_hash(kernel):
     h = hashlib.sha256()
-    for name in KERNEL_SOURCES:
+    for name in KERNEL_SOURCES.get(kernel, ()):
         with open(os.path.join(ROOT, "pyahocorasick_amd", "csrc", name), "rb") as f:
             h.update(f.read())
     return h.hexdigest()[:16]
@@ -203,6 +217,272 @@ def cpu_baseline(keys, hays, mode):
                       "1 core, then %d forked workers (automaton inherited copy-on-write, contiguous shares)" % (len(hays), nbytes / 1e6, mode, workers)}
 
 
+WORKLOAD_NAMES = {
+    "c2": "config2: %d ACGT keys 8-32 B, %d x %d B reads per batch",
+    "c3": "config3 shape: %d multi-word text keys, %d MiB of text per batch scanned as ONE haystack",
+    "c4": "config4 shape: %d Snort-style byte signatures 4-128 B, %d MiB of packets 64-1500 B per batch",
+}
+
+
+def build_keys(workload, n_keys):
+    from pyahocorasick_amd import workloads as W
+    vocab = None
+    if workload == "c2":
+        keys = W.dna_keys(n_keys, seed=0)
+    elif workload == "c3":
+        vocab = W.text_vocab(1_000_000 if n_keys >= 100_000 else 10 * n_keys, seed=2)
+        keys = W.text_keys(vocab, n_keys, seed=3)
+    else:
+        keys = W.snort_signatures(n_keys, seed=5)
+    return keys, vocab
+
+
+def strong_shard(workload, data, off, rank, world, longest):
+    """--scaling strong: rank `rank`'s contiguous share of ONE corpus that every rank generated identically.
+    c2: `data` is uint8[n_reads, L], cut by count; c4: packets (data, off), cut so that the shares are balanced by BYTES
+    (SURVEY §8e); c3: one text, shares of equal length plus longest - 1 bytes of left halo (exact for iter).
+    Returns (data, off) of the share (off: None / rebased to 0 / [0, len])."""
+    from pyahocorasick_amd.parallel import halo_shard, shard_range, shard_range_by_bytes
+    if workload == "c2":
+        lo, hi = shard_range(len(data), rank, world)
+        return data[lo:hi], None
+    if workload == "c4":
+        lo, hi = shard_range_by_bytes(off, rank, world)
+        return data[off[lo]:off[hi]], off[lo:hi + 1] - off[lo]
+    s0, lo, hi = halo_shard(len(data), rank, world, longest)
+    return data[s0:hi], np.array([0, hi - s0], dtype=np.int64)
+
+
+def make_batches(torch, dev, workload, keys, vocab, n_batches, reads, read_len, batch_mb, rank, world, strong):
+    """this rank's batches, resident in HBM: [(device bytes, capacity, n haystacks, device offsets or None, stride, shortest)],
+    the haystacks of batch 0 for the CPU baseline, batch 0 as (bytes, offsets) for the host-to-host leg, bytes of the whole
+    corpus of one step over all ranks"""
+    from pyahocorasick_amd import workloads as W
+    longest = max(len(k) for k in keys)
+    batches, host0, e2e0, corpus_bytes = [], None, None, []
+    for b in range(n_batches):
+        seed = 1 + b + (0 if strong else 16 * rank)          # strong: every rank generates the SAME corpus and keeps its shard
+        if workload == "c2":
+            r = W.dna_reads(keys, reads, read_len, seed=seed)
+            corpus_bytes.append(r.size)
+            if strong:
+                r, _ = strong_shard("c2", r, None, rank, world, longest)
+            n, L = r.shape
+            flat, off = r.reshape(-1), None
+            if b == 0:
+                host0 = [r[i].tobytes() for i in range(n)]
+                e2e0 = (np.ascontiguousarray(flat), np.arange(n + 1, dtype=np.int64) * L)
+        elif workload == "c3":
+            nbytes = batch_mb << 20
+            flat = np.concatenate([W.text_corpus(vocab, min(64 << 20, nbytes - o), seed=4 + 64 * seed + o // (64 << 20))
+                                   for o in range(0, nbytes, 64 << 20)])
+            corpus_bytes.append(len(flat))
+            if strong:            # one corpus, contiguous shards, longest_word-1 bytes of left halo (exact for iter)
+                flat, _ = strong_shard("c3", flat, None, rank, world, longest)
+            n, L, off = 1, 0, np.array([0, len(flat)], dtype=np.int64)
+            if b == 0:
+                host0 = [flat[i:i + (1 << 16)].tobytes() for i in range(0, min(len(flat), 32 << 20), 1 << 16)]
+                e2e0 = (np.ascontiguousarray(flat), off)
+        else:
+            flat, off = W.packet_payloads(keys, batch_mb << 20, seed=6 + seed)
+            corpus_bytes.append(len(flat))
+            if strong:            # packets are independent haystacks of unequal length: contiguous shards balanced by BYTES (SURVEY §8e)
+                flat, off = strong_shard("c4", flat, off, rank, world, longest)
+            n, L = len(off) - 1, 0
+            if b == 0:
+                m = int(np.searchsorted(off, 32 << 20))
+                host0 = [flat[off[i]:off[i + 1]].tobytes() for i in range(m)]
+                e2e0 = (np.ascontiguousarray(flat), off)
+        d_hay = torch.empty(len(flat) + 64, dtype=torch.uint8, device=dev)
+        d_hay[: len(flat)].copy_(torch.from_numpy(np.ascontiguousarray(flat)))
+        d_off = torch.from_numpy(np.ascontiguousarray(off)).to(dev) if off is not None else None
+        # offsets batches: the shortest haystack, which the caller of acx_scan_batch vouches for (min_hay_len)
+        shortest = int(np.diff(off).min()) if off is not None and len(off) > 1 else 0
+        batches.append((d_hay, len(flat), n, d_off, L, shortest))
+    torch.cuda.synchronize()
+    return batches, host0, e2e0, corpus_bytes
+
+
+def measure(torch, dist, dev, image, batches, mode, steps, warmup, P, event_every, variant):
+    """K timed steps rotating over the batches (barrier + synchronize on both sides, max over ranks by the caller).  Every
+    collected step's record count is compared with the count of the same batch in the untimed pre-pass."""
+    from pyahocorasick_amd.device import Scanner
+    B = len(batches)
+    scs = [Scanner(image) for _ in range(P)]
+    stream = torch.cuda.current_stream().cuda_stream
+
+    def step(k, timing=False):
+        d_hay, cap, n, d_off, L, shortest = batches[k % B]
+        return scs[k % P].scan(d_hay.data_ptr(), cap, n, dev_off=d_off.data_ptr() if d_off is not None else None,
+                               stride=L, mode=mode, timing=timing, variant=variant, stream=stream, asynchronous=P > 1,
+                               min_hay_len=shortest)
+
+    for k in range(max(warmup, P, B)):                    # every batch scanned at least once before timing
+        step(k)
+    for x in scs:
+        x.wait()
+    # per-kernel times (HIP events around every kernel of a step) from separate passes over every batch
+    pre = {"walk": [], "scan": [], "expand": [], "total": []}
+    matches_per_batch = []
+    for k in range(B):
+        step(k, timing=True)
+        scs[k % P].wait()
+        t = scs[k % P].timing_ms()
+        for key in pre:
+            pre[key].append(t[key])
+        matches_per_batch.append(scs[k % P].num_matches())
+    pre = {k: float(np.mean(v)) for k, v in pre.items()}
+    # the synchronous step (pipeline depth 1: scan and gather one after the other, the host waits for each)
+    sync_ms = None
+    if P > 1:
+        ssc = Scanner(image)
+        d_hay, cap, n, d_off, L, shortest = batches[0]
+        ts = []
+        for _ in range(5):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            ssc.scan(d_hay.data_ptr(), cap, n, dev_off=d_off.data_ptr() if d_off is not None else None, stride=L, mode=mode,
+                     variant=variant, stream=stream, asynchronous=False, min_hay_len=shortest)
+            ts.append(time.perf_counter() - t0)
+        sync_ms = float(np.median(ts[1:])) * 1e3
+        del ssc
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    # ---- the timed region: K steps, rotating over the batches; the dominant kernel of every N-th step is bracketed
+    #      by HIP events on the stream it runs on (timing = 2: an event between two kernels costs ~5 us of idle GPU)
+    walk_ms, timed, owner = [], {}, {}
+
+    def collect(x):
+        x.wait()
+        k = owner.pop(id(x))
+        got = x.num_matches()
+        if got != matches_per_batch[k % B]:                # a dropped, racing or repeated step would show here
+            raise SystemExit("bench: step %d reports %d matches, the pre-pass of its batch %d" % (k, got, matches_per_batch[k % B]))
+        if timed.pop(id(x), False):
+            walk_ms.append(x.timing_ms()["walk"])
+
+    barrier()
+    t0 = time.perf_counter()
+    for k in range(steps):
+        if k >= P:
+            collect(scs[k % P])
+        ev = event_every > 0 and k % event_every == 0
+        timed[id(scs[k % P])] = ev
+        owner[id(scs[k % P])] = k
+        step(k, timing=2 if ev else False)
+    for k in range(max(0, steps - P), steps):
+        collect(scs[k % P])                                # every step complete: totals read and checked, records in HBM
+    torch.cuda.synchronize()
+    dt_rank = time.perf_counter() - t0
+    barrier()
+    dt = time.perf_counter() - t0
+    return {"dt": dt, "dt_rank": dt_rank, "walk_ms": walk_ms, "pre": pre, "matches_per_batch": matches_per_batch, "sync_ms": sync_ms,
+            "bytes_rank": sum(batches[k % B][1] for k in range(steps)), "matches_rank": sum(matches_per_batch[k % B] for k in range(steps)),
+            "scanner": scs[0], "stream": stream}
+
+
+def roofline_entry(image, batches, m, mode_name, workload, variant, steps, event_every):
+    """the dominant kernel against the HBM roofline: algorithmic bytes per launch / its average duration (HIP events inside the
+    timed region), PMC traffic from profiles/traffic.json when it was measured on these kernel sources"""
+    B = len(batches)
+    d_hay, cap0, n0, d_off0, L0, shortest0 = batches[0]
+    H = m["bytes_rank"] / steps                              # haystack bytes per rank per step (mean over the rotation)
+    M = m["matches_rank"] / steps
+    Nh = float(np.mean([batches[k % B][2] for k in range(steps)]))
+    A_bytes = H + 8 * M + 12 * Nh                            # SURVEY.md §8(d): H + 8*M + 12*N
+    pre = m["pre"]
+    walk = float(np.mean(m["walk_ms"])) if m["walk_ms"] else pre["walk"]
+    used_ppm = mode_name == "iter" and image.ppm_kernel(stride=L0, has_offsets=d_off0 is not None, variant=variant, min_hay_len=shortest0,
+                                                          dev_hay=d_hay.data_ptr(), n_hay=n0)
+    if mode_name != "iter":
+        walk_kernel, walk_bytes = "k_walk_long_sel", H + 12 * Nh
+    elif used_ppm in ("stream", "stream4"):
+        # the scan kernel reads the haystack, writes every record (to the pool) and one offset per haystack
+        walk_kernel, walk_bytes = ("k_ppm_stream4" if used_ppm == "stream4" else "k_ppm_stream"), H + 8 * M + (4 if d_off0 is None else 12) * Nh
+    elif used_ppm == "scan":
+        walk_kernel, walk_bytes = "k_ppm_scan", H + 8 * M + 8 * (H / 256)
+    else:
+        walk_kernel, walk_bytes = ("k_walk_itop" if image.itop_depth > 0 and not (variant >> 16) & 1 else "k_walk_all"), H + 12 * Nh
+    traffic_raw = traffic_corr = None
+    traffic_note = "profiles/traffic.json absent"
+    tpath = os.path.join(ROOT, "profiles", "traffic.json")
+    src_hash = kernel_source_hash(walk_kernel)
+    if os.path.exists(tpath):
+        try:
+            ent = json.load(open(tpath)).get("%s_%s" % (workload, mode_name))
+            if not ent:
+                traffic_note = "no PMC entry for this workload"
+            elif ent.get("kernel") != walk_kernel:
+                traffic_note = "PMC entry is for kernel %s" % ent.get("kernel")
+            elif ent.get("kernel_source_sha") != src_hash:
+                traffic_note = "PMC entry is for other sources of %s (%s, now %s): refused" % (walk_kernel, ent.get("kernel_source_sha"), src_hash)
+            else:
+                traffic_raw = ent["fetch_bytes_raw"] + ent["write_bytes"]
+                traffic_corr = ent["fetch_bytes_x2_gfx950"] + ent["write_bytes"]
+                traffic_note = ent.get("note", "")
+        except Exception as ex:                             # noqa: BLE001
+            traffic_note = "unreadable: %s" % ex
+    gpu_ms = walk + pre["scan"] + pre["expand"]
+    return {
+        "bound": "hbm", "kernel": walk_kernel,
+        "achieved": walk_bytes / (walk * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+        "frac": walk_bytes / (walk * 1e-3) / 1e9 / HBM_PEAK_GBS,
+        "algorithmic_bytes": walk_bytes, "kernel_avg_ms": round(walk, 4),
+        # HIP events around the kernel, on its stream, inside the timed region: in every N-th step (an event
+        # pair costs the stream ~19 us of idle time in the step it is in)
+        "kernel_events": {"every_nth_step": event_every, "samples": len(m["walk_ms"])},
+        # HBM bytes of the dominant kernel per launch from the PMC passes (FETCH_SIZE + WRITE_SIZE): `traffic` is the figure
+        # corrected as /opt/skills/guides/MI355X_MICROARCH.md prescribes for gfx950 (FETCH_SIZE x 2: it tallies 128-B requests
+        # at 64 B; an upper bound where the requests are narrow gathers), `traffic_raw` the counters as they read
+        "traffic": traffic_corr, "traffic_raw": traffic_raw, "traffic_corrected": traffic_corr,
+        "traffic_note": traffic_note, "kernel_source_sha": src_hash,
+        # the whole batch scan (scan kernel + prefix sum + gather), A = H + 8*M + 12*N
+        "pipeline": {"algorithmic_bytes": A_bytes, "gpu_ms": round(gpu_ms, 4),
+                     "achieved": A_bytes / (gpu_ms * 1e-3) / 1e9, "frac": A_bytes / (gpu_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                     "kernel_ms": {"walk": round(walk, 4), "scan": round(pre["scan"], 4), "expand": round(pre["expand"], 4)}},
+    }
+
+
+def other_config(torch, dev, acx, name, workload, mode_name, keys, vocab, image, batches, host0, args, n_keys, batch_mb, cpu_sample):
+    """one of the other named single-GPU configurations, measured like the headline (fewer batches and steps)"""
+    from pyahocorasick_amd.device import Image
+    t0 = time.perf_counter()
+    t_build = None
+    if image is None:
+        A = acx.Automaton(acx.STORE_INTS)
+        A.add_words(keys, range(len(keys)))
+        A.make_automaton()
+        image = Image.from_automaton(A)
+        torch.cuda.synchronize()
+        t_build = time.perf_counter() - t0
+        del A
+    t0 = time.perf_counter()
+    if batches is None:
+        batches, host0, _, _ = make_batches(torch, dev, workload, keys, vocab, 2, args.reads, args.read_len, batch_mb, 0, 1, False)
+    t_stage = time.perf_counter() - t0
+    mode = acx.ACX_SCAN_ALL if mode_name == "iter" else acx.ACX_SCAN_LONG
+    steps = max(8, min(args.steps, 20))
+    m = measure(torch, None, dev, image, batches, mode, steps, 2, max(1, args.pipeline), args.event_every, 0)
+    out = {
+        "value": m["bytes_rank"] / m["dt"] / 1e9, "unit": "GB/s", "ms_per_step": m["dt"] / steps * 1e3, "steps": steps,
+        "ms_per_step_synchronous": m["sync_ms"],
+        "matches_per_step": m["matches_rank"] / steps,
+        "workload": (WORKLOAD_NAMES[workload] % ((n_keys, args.reads, args.read_len) if workload == "c2" else (n_keys, batch_mb)))
+                    + ", Automaton.%s; %d distinct batches rotated (%.0f MB resident)" % (mode_name, len(batches), sum(b[1] for b in batches) / 1e6),
+        "states": int(image.num_states), "image_mb": round(image.nbytes / 1e6, 1),
+        "roofline": roofline_entry(image, batches, m, mode_name, workload, 0, steps, args.event_every),
+        "setup": {"build_flatten_upload_s": None if t_build is None else round(t_build, 3), "stage_batches_s": round(t_stage, 3)},
+    }
+    if cpu_sample and host0:
+        out["cpu_baseline"] = cpu_baseline(keys, host0[:cpu_sample], mode_name)
+    del m
+    return out
+
+
 def main():
     args = parse()
     self_launch(args)                                      # --gpus N > 1 outside torch.distributed.run: N ranks are started here
@@ -239,22 +519,12 @@ def main():
     from pyahocorasick_amd import _lib
     if args.lib:
         _lib.LIB_PATH = os.path.abspath(args.lib)
-    from pyahocorasick_amd.device import Scanner
-    from pyahocorasick_amd.parallel import broadcast_image, halo_shard, shard_range
-    from pyahocorasick_amd import workloads as W
+    from pyahocorasick_amd.parallel import broadcast_image
     _lib.check(_lib.lib().acx_device_set(local_rank))
 
     # ---- dictionary: built on rank 0 (CPU), replicated by one RCCL broadcast ---------------------
     n_keys = args.keys or (1_000_000 if args.workload == "c4" else 100_000)
-    vocab = None
-    if args.workload == "c2":
-        keys = W.dna_keys(n_keys, seed=0)
-    elif args.workload == "c3":
-        vocab = W.text_vocab(1_000_000 if n_keys >= 100_000 else 10 * n_keys, seed=2)
-        keys = W.text_keys(vocab, n_keys, seed=3)
-    else:
-        keys = W.snort_signatures(n_keys, seed=5)
-    longest = max(len(k) for k in keys)
+    keys, vocab = build_keys(args.workload, n_keys)
     t0 = time.perf_counter()
     blob = None
     if rank == 0:
@@ -262,116 +532,25 @@ def main():
         A.add_words(keys, range(len(keys)))                 # (one call: 1 M signatures cost seconds of interpreter time otherwise)
         A.make_automaton()
         blob = A.flat_image_bytes()
+        del A
     t_build = time.perf_counter() - t0
     t0 = time.perf_counter()
     image, image_tensor = broadcast_image(blob, src=0, device=dev)
     torch.cuda.synchronize()
     t_bcast = time.perf_counter() - t0
+    del blob
 
-    # ---- this rank's batches, resident in HBM ---------------------------------------------------------
-    # a batch = (device bytes, capacity, n haystacks, device offsets or None, stride, host copy for batch 0)
     strong = args.scaling == "strong" and world > 1
     B = max(1, args.batches)
-    batches, host0, e2e0 = [], None, None
     t0 = time.perf_counter()
-    for b in range(B):
-        seed = 1 + b + (0 if strong else 16 * rank)
-        if args.workload == "c2":
-            reads = W.dna_reads(keys, args.reads, args.read_len, seed=seed)
-            if strong:
-                lo, hi = shard_range(len(reads), rank, world)
-                reads = reads[lo:hi]
-            n, L = reads.shape
-            flat, off = reads.reshape(-1), None
-            if b == 0:
-                host0 = [reads[i].tobytes() for i in range(n)]
-                e2e0 = (np.ascontiguousarray(flat), np.arange(n + 1, dtype=np.int64) * L)
-        elif args.workload == "c3":
-            nbytes = args.batch_mb << 20
-            flat = np.concatenate([W.text_corpus(vocab, min(64 << 20, nbytes - o), seed=4 + 64 * seed + o // (64 << 20))
-                                   for o in range(0, nbytes, 64 << 20)])
-            if strong:            # one corpus, contiguous shards, longest_word-1 bytes of left halo (exact for iter)
-                s0, lo, hi = halo_shard(len(flat), rank, world, longest)
-                flat = flat[s0:hi]
-            n, L, off = 1, 0, np.array([0, len(flat)], dtype=np.int64)
-            if b == 0:
-                host0 = [flat[i:i + (1 << 16)].tobytes() for i in range(0, min(len(flat), 32 << 20), 1 << 16)]
-                e2e0 = (np.ascontiguousarray(flat), off)
-        else:
-            flat, off = W.packet_payloads(keys, args.batch_mb << 20, seed=6 + seed)
-            n, L = len(off) - 1, 0
-            if b == 0:
-                m = int(np.searchsorted(off, 32 << 20))
-                host0 = [flat[off[i]:off[i + 1]].tobytes() for i in range(m)]
-                e2e0 = (np.ascontiguousarray(flat), off)
-        d_hay = torch.empty(len(flat) + 64, dtype=torch.uint8, device=dev)
-        d_hay[: len(flat)].copy_(torch.from_numpy(np.ascontiguousarray(flat)))
-        d_off = torch.from_numpy(off).to(dev) if off is not None else None
-        # offsets batches: the shortest haystack, which the caller of acx_scan_batch vouches for (min_hay_len)
-        shortest = int(np.diff(off).min()) if off is not None else 0
-        batches.append((d_hay, len(flat), n, d_off, L, shortest))
-    torch.cuda.synchronize()
+    batches, host0, e2e0, corpus_bytes = make_batches(torch, dev, args.workload, keys, vocab, B, args.reads, args.read_len, args.batch_mb,
+                                                      rank, world, strong)
     t_stage = time.perf_counter() - t0
     mode = acx.ACX_SCAN_ALL if args.mode == "iter" else acx.ACX_SCAN_LONG
     P = max(1, args.pipeline)
-    scs = [Scanner(image) for _ in range(P)]
-    stream = torch.cuda.current_stream().cuda_stream
-
-    def step(k, timing=False):
-        d_hay, cap, n, d_off, L, shortest = batches[k % B]
-        return scs[k % P].scan(d_hay.data_ptr(), cap, n, dev_off=d_off.data_ptr() if d_off is not None else None,
-                               stride=L, mode=mode, timing=timing, variant=args.variant, stream=stream, asynchronous=P > 1,
-                               min_hay_len=shortest)
-
-    for k in range(max(args.warmup, P, B)):               # every batch scanned at least once before timing
-        step(k)
-    for x in scs:
-        x.wait()
-    # per-kernel times (HIP events around every kernel of a step) from separate passes over every batch
-    pre = {"walk": [], "scan": [], "expand": [], "total": []}
-    matches_per_batch = []
-    for k in range(B):
-        step(k, timing=True)
-        scs[k % P].wait()
-        t = scs[k % P].timing_ms()
-        for key in pre:
-            pre[key].append(t[key])
-        matches_per_batch.append(scs[k % P].num_matches())
-    pre = {k: float(np.mean(v)) for k, v in pre.items()}
-
-    def barrier():
-        if dist is not None:
-            dist.barrier()
-        torch.cuda.synchronize()
-
-    # ---- the timed region: K steps, rotating over the batches; the dominant kernel of every step is bracketed
-    #      by HIP events on the stream it runs on (timing = 2: an event between two kernels costs ~5 us of idle GPU)
-    walk_ms = []
-
-    timed = {}
-
-    def collect(x):
-        x.wait()
-        if timed.pop(id(x), False):
-            walk_ms.append(x.timing_ms()["walk"])
-
-    barrier()
-    t0 = time.perf_counter()
-    for k in range(args.steps):
-        if k >= P:
-            collect(scs[k % P])
-        ev = args.event_every > 0 and k % args.event_every == 0
-        timed[id(scs[k % P])] = ev
-        step(k, timing=2 if ev else False)
-    for k in range(max(0, args.steps - P), args.steps):
-        collect(scs[k % P])                                # every step complete: totals read, records in HBM
-    torch.cuda.synchronize()
-    dt_rank = time.perf_counter() - t0
-    barrier()
-    dt = time.perf_counter() - t0
-    bytes_rank = sum(batches[k % B][1] for k in range(args.steps))
-    matches_rank = sum(matches_per_batch[k % B] for k in range(args.steps))
-    per_rank = [bytes_rank / dt_rank / 1e9]
+    m = measure(torch, dist, dev, image, batches, mode, args.steps, args.warmup, P, args.event_every, args.variant)
+    dt, bytes_rank, matches_rank = m["dt"], m["bytes_rank"], m["matches_rank"]
+    per_rank = [bytes_rank / m["dt_rank"] / 1e9]
     if dist is not None:
         tt = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -393,52 +572,19 @@ def main():
             O.add_word(k, i)
         O.make_automaton()
         d_hay, cap, n, d_off, L, shortest = batches[0]
-        scs[0].scan(d_hay.data_ptr(), cap, n, dev_off=d_off.data_ptr() if d_off is not None else None, stride=L, mode=mode, stream=stream, min_hay_len=shortest)
-        off_g, e, v, _ = scs[0].fetch()
+        sc0 = m["scanner"]
+        sc0.scan(d_hay.data_ptr(), cap, n, dev_off=d_off.data_ptr() if d_off is not None else None, stride=L, mode=mode, stream=m["stream"], min_hay_len=shortest)
+        off_g, e, v, _ = sc0.fetch()
         data = d_hay[:cap].cpu().numpy().tobytes()
         offs = np.arange(n + 1, dtype=np.int64) * L if d_off is None else d_off.cpu().numpy()
         mo, oe, ov = O.batch_records(data, offs, 0)
         assert np.array_equal(off_g, mo) and np.array_equal(e, oe) and np.array_equal(v, ov), "GPU result differs from the oracle"
 
     if rank == 0:
-        d_hay, cap0, n0, d_off0, L0, shortest0 = batches[0]
         ms_step = dt / args.steps * 1e3
-        H = bytes_rank / args.steps                        # haystack bytes per rank per step (mean over the rotation)
-        M = matches_rank / args.steps
-        Nh = float(np.mean([batches[k % B][2] for k in range(args.steps)]))
-        A_bytes = H + 8 * M + 12 * Nh                      # H + 8*M + 12*N
-        walk = float(np.mean(walk_ms)) if walk_ms else pre["walk"]
-        used_ppm = args.mode == "iter" and image.ppm_kernel(stride=L0, has_offsets=d_off0 is not None, variant=args.variant, min_hay_len=shortest0,
-                                                              dev_hay=d_hay.data_ptr(), n_hay=n0)
-        if args.mode != "iter":
-            walk_kernel, walk_bytes = "k_walk_long_sel", H + 12 * Nh
-        elif used_ppm == "stream":
-            # the scan kernel reads the haystack, writes every record (to the pool) and one offset per haystack
-            walk_kernel, walk_bytes = "k_ppm_stream", H + 8 * M + (4 if d_off0 is None else 12) * Nh
-        elif used_ppm == "scan":
-            walk_kernel, walk_bytes = "k_ppm_scan", H + 8 * M + 8 * (H / 256)
-        else:
-            walk_kernel, walk_bytes = ("k_walk_itop" if image.itop_depth > 0 and not (args.variant >> 16) & 1 else "k_walk_all"), H + 12 * Nh
-        traffic, traffic_note = None, "profiles/traffic.json absent"
-        tpath = os.path.join(ROOT, "profiles", "traffic.json")
-        src_hash = kernel_source_hash()
-        if os.path.exists(tpath):
-            try:
-                tj = json.load(open(tpath))
-                ent = tj.get("%s_%s" % (args.workload, args.mode))
-                if not ent:
-                    traffic_note = "no PMC entry for this workload"
-                elif ent.get("kernel_source_sha") != src_hash:
-                    traffic_note = "PMC entry is for other kernel sources (%s, now %s): refused" % (ent.get("kernel_source_sha"), src_hash)
-                elif ent.get("kernel") != walk_kernel:
-                    traffic_note = "PMC entry is for kernel %s" % ent.get("kernel")
-                else:
-                    traffic, traffic_note = ent["hbm_bytes_dominant_kernel"], ent.get("note", "")
-            except Exception as ex:                       # noqa: BLE001
-                traffic_note = "unreadable: %s" % ex
-        names = {"c2": "config2: %d ACGT keys 8-32 B, %d x %d B reads per batch" % (n_keys, args.reads, args.read_len),
-                 "c3": "config3 shape: %d multi-word text keys, %d MiB of text per batch scanned as ONE haystack" % (n_keys, args.batch_mb),
-                 "c4": "config4 shape: %d Snort-style byte signatures 4-128 B, %d MiB of packets 64-1500 B per batch" % (n_keys, args.batch_mb)}
+        wname = WORKLOAD_NAMES[args.workload] % ((n_keys, args.reads, args.read_len) if args.workload == "c2" else (n_keys, args.batch_mb))
+        # bytes of the corpus one step covers over all ranks: strong scaling cuts ONE corpus (bytes_total / step stays what one
+        # GPU scans alone, plus the halos of a text shard), weak scaling gives every rank its own
         out = {
             "metric": "GB/s haystack scanned, 100k-pattern automaton" if args.workload != "c4" else "GB/s haystack scanned, %d-signature automaton" % n_keys,
             "value": bytes_all / dt / 1e9,
@@ -448,27 +594,16 @@ def main():
             "vs_baseline": None, "dtype": "u8", "data": "synthetic",
             "matches_per_s": matches_all / dt,
             "matches_per_step": matches_all / args.steps / world,
+            "bytes_total": bytes_all, "bytes_per_step_all_ranks": bytes_all / args.steps,
+            "corpus_bytes_per_batch": int(np.mean(corpus_bytes)),
+            "ms_per_step_synchronous": m["sync_ms"],
             "per_rank_GBps": {"min": min(per_rank), "max": max(per_rank)},
-            "config": {"workload": names[args.workload] + ", Automaton.%s; %d distinct batches rotated (%.0f MB resident per GPU)"
+            "config": {"workload": wname + ", Automaton.%s; %d distinct batches rotated (%.0f MB resident per GPU)"
                                    % (args.mode, B, sum(b[1] for b in batches) / 1e6),
                        "states": int(image.num_states), "classes": int(image.num_classes),
                        "image_mb": round(image.nbytes / 1e6, 1), "variant": args.variant, "pipeline_depth": P,
                        "parallelism": "replicated automaton (1 RCCL broadcast), haystacks sharded x%d (%s)" % (world, "strong" if strong else "weak")},
-            "roofline": {
-                "bound": "hbm", "kernel": walk_kernel,
-                "achieved": walk_bytes / (walk * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": walk_bytes / (walk * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                "algorithmic_bytes": walk_bytes, "kernel_avg_ms": round(walk, 4),
-                # HIP events around the kernel, on its stream, inside the timed region: in every N-th step (an event
-                # pair costs the stream ~19 us of idle time in the step it is in)
-                "kernel_events": {"every_nth_step": args.event_every, "samples": len(walk_ms)},
-                "traffic": traffic, "traffic_note": traffic_note, "kernel_source_sha": src_hash,
-                # the whole batch scan (scan kernel + prefix sum + gather), A = H + 8*M + 12*N
-                "pipeline": {"algorithmic_bytes": A_bytes, "gpu_ms": round(walk + pre["scan"] + pre["expand"], 4),
-                             "achieved": A_bytes / ((walk + pre["scan"] + pre["expand"]) * 1e-3) / 1e9,
-                             "frac": A_bytes / ((walk + pre["scan"] + pre["expand"]) * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                             "kernel_ms": {"walk": round(walk, 4), "scan": round(pre["scan"], 4), "expand": round(pre["expand"], 4)}},
-            },
+            "roofline": roofline_entry(image, batches, m, args.mode, args.workload, args.variant, args.steps, args.event_every),
             "setup": {"build_flatten_s": round(t_build, 3), "broadcast_upload_s": round(t_bcast, 3), "stage_batches_s": round(t_stage, 3)},
         }
         if world == 1 and e2e0 is not None and args.mode == "iter" and not args.no_e2e:
@@ -492,6 +627,29 @@ def main():
         if world == 1 and args.cpu_sample_reads != 0 and host0:
             sample = host0 if not args.cpu_sample_reads else host0[: args.cpu_sample_reads]
             out["cpu_baseline"] = cpu_baseline(keys, sample, args.mode)
+        # ---- the other named single-GPU configurations, in the same run (driver-timed: BENCH_rNN.json carries them) ----
+        want = args.configs or ("all" if (world == 1 and args.workload == "c2" and args.mode == "iter" and args.variant == 0 and not args.keys) else "none")
+        if want == "all" and world == 1:
+            cfgs = {}
+            cpu_on = args.cpu_sample_reads != 0
+            try:
+                cfgs["c5_iter_long"] = other_config(torch, dev, acx, "c5_iter_long", "c2", "iter_long", keys, None, image, batches, host0, args,
+                                                    n_keys, args.batch_mb, 200_000 if cpu_on else 0)
+            except SystemExit as ex:                          # (a failed sub-configuration must not take the headline line with it)
+                cfgs["c5_iter_long"] = {"error": str(ex)}
+            del m, batches, host0, e2e0
+            image.free()
+            del image, image_tensor
+            torch.cuda.empty_cache()
+            for name, wl, nk in (("c3", "c3", 100_000), ("c4", "c4", 1_000_000)):
+                try:
+                    k2, v2 = build_keys(wl, nk)
+                    cfgs[name] = other_config(torch, dev, acx, name, wl, "iter", k2, v2, None, None, None, args, nk, 512, 100_000 if cpu_on else 0)
+                    del k2, v2
+                except (SystemExit, Exception) as ex:        # noqa: BLE001
+                    cfgs[name] = {"error": "%s: %s" % (type(ex).__name__, ex)}
+                torch.cuda.empty_cache()
+            out["configs"] = cfgs
         os.write(json_fd, (json.dumps(out) + "\n").encode())
     if dist is not None:
         dist.barrier()

@@ -278,8 +278,8 @@ typedef struct acx_result acx_result_t;
 int  acx_scan_batch(acx_image_t* img, const acx_scan_params* p, acx_result_t** result, void* stream);
 /* Which kernels acx_scan_batch would run for these parameters (nothing is launched): 0 = the serial walks
  * (one lane per haystack or chunk: k_walk_itop / k_walk_all / k_walk_chunks / k_walk_long), 1 = the general
- * position-parallel kernel k_ppm_scan, 2 = the position-parallel stream kernel k_ppm_stream; -1 on bad
- * arguments.  bench.py names the dominant kernel of its roofline entry with it. */
+ * position-parallel kernel k_ppm_scan, 2 = the position-parallel stream kernel k_ppm_stream, 3 = its
+ * specialisation for fixed-length haystacks over a four-letter alphabet, k_ppm_stream4; -1 on bad arguments.  bench.py names the dominant kernel of its roofline entry with it. */
 int  acx_scan_plan(const acx_image_t* img, const acx_scan_params* p);
 int  acx_result_wait(acx_result_t* r);
 

@@ -730,6 +730,16 @@ static int ppm_plan(const acx_image* img, const acx_scan_params* p) {
     return 0;
 }
 
+// k_ppm_stream4 instead of k_ppm_stream (plan 2): what acx_ppm_stream4_eligible asks of the arguments scan_ppm fills, asked of
+// the image and the parameters (keep the two in step)
+static bool ppm_plan_stream4(const acx_image* img, const acx_scan_params* p) {
+    const acx_ppm_header& ph = img->ppm;
+    return img->ppm_hot4 && img->ppm_cid && !((p->variant >> 19) & 1) && !p->dev_off && !p->dev_skip && p->stride >= 8 && p->stride < 2048 &&
+           ph.sym_bits == 2 && ph.pow2 && ph.sym_arith != 0 && ph.K == 4 && !ph.g_global && (!ph.F2 || ((p->variant >> 20) & 1)) &&
+           ph.C == 9 && ph.F == 10 && ppm_halo_pos(ph) == 32 && ph.longest <= 33 && ph.g_words * 4u == (128u << 10) &&
+           ppm_stream_nsub(ph, 32, false) == 8;
+}
+
 extern "C" int acx_scan_plan(const acx_image_t* img, const acx_scan_params* p) {
     if (!img || !p || p->struct_bytes != sizeof(acx_scan_params)) return -1;
     if (p->flags & ACX_SCAN_SKIP_WS) {                      // what scan_batch_ws hands to the kernels: offsets, aligned, a promise of 8 at most
@@ -739,7 +749,8 @@ extern "C" int acx_scan_plan(const acx_image_t* img, const acx_scan_params* p) {
         q.min_hay_len = (p->dev_off ? p->min_hay_len : (int32_t)(p->stride > INT32_MAX ? INT32_MAX : p->stride)) >= 8 ? 8 : 0;
         return ppm_plan(img, &q);
     }
-    return ppm_plan(img, p);
+    const int plan = ppm_plan(img, p);
+    return plan == 2 && ppm_plan_stream4(img, p) ? 3 : plan;
 }
 
 static int scan_ppm(acx_image_t* img, const acx_scan_params* p, acx_result* r, hipStream_t s, int plan) {

@@ -109,7 +109,7 @@ class Image:
 
     def ppm_kernel(self, stride=0, has_offsets=False, variant=0, dev_hay=0x1000, n_hay=1, min_hay_len=0):
         """which kernel family an ACX_SCAN_ALL scan of such a batch takes (acx_scan_plan): None = the serial
-        walks, "scan" = k_ppm_scan, "stream" = k_ppm_stream"""
+        walks, "scan" = k_ppm_scan, "stream" = k_ppm_stream, "stream4" = k_ppm_stream4 (four letters, fixed stride)"""
         p = ScanParams()
         p.struct_bytes = C.sizeof(ScanParams)
         p.mode = ACX_SCAN_ALL
@@ -120,7 +120,7 @@ class Image:
         p.n_hay = n_hay
         p.variant = int(variant)
         p.min_hay_len = int(min_hay_len)
-        return {0: None, 1: "scan", 2: "stream"}.get(lib().acx_scan_plan(self.handle, C.byref(p)))
+        return {0: None, 1: "scan", 2: "stream", 3: "stream4"}.get(lib().acx_scan_plan(self.handle, C.byref(p)))
 
     def download_table(self):
         """the dense transition table the scans read, as uint32[n_states, n_classes] (tests/tools)"""

@@ -53,6 +53,32 @@ def test_halo_shard_ranges():
             assert all(lo - s0 == min(lo, 31) for s0, lo, hi in cuts)
 
 
+def test_bench_strong_scaling_shards_are_disjoint_and_cover_the_corpus():
+    """`bench.py --scaling strong`: every rank generates the same corpus and keeps its share — packets (config 4) cut so
+    that the shares are balanced by BYTES, reads by count, text with a halo.  Shares laid end to end are the corpus."""
+    sys.path.insert(0, os.path.dirname(HERE))
+    import bench
+    from pyahocorasick_amd import workloads as W
+    sigs = W.snort_signatures(2000, seed=5)
+    data, off = W.packet_payloads(sigs, 4 << 20, seed=7)
+    for world in (1, 2, 3, 8):
+        parts = [bench.strong_shard("c4", data, off, r, world, 128) for r in range(world)]
+        assert all(o[0] == 0 and o[-1] == len(d) and np.all(np.diff(o) > 0) for d, o in parts)
+        assert np.array_equal(np.concatenate([d for d, _ in parts]), data)                       # disjoint, in order, complete
+        assert np.array_equal(np.concatenate([[0]] + [o[1:] + sum(len(x[0]) for x in parts[:i]) for i, (_, o) in enumerate(parts)]), off)
+        sizes = [len(d) for d, _ in parts]
+        assert max(sizes) - min(sizes) <= 2 * 1500, sizes                                          # balanced by bytes (a packet is at most 1500)
+    reads = W.dna_reads(W.dna_keys(50, seed=0), 1001, 150, seed=1)
+    for world in (2, 8):
+        parts = [bench.strong_shard("c2", reads, None, r, world, 32)[0] for r in range(world)]
+        assert np.array_equal(np.concatenate(parts), reads)
+    text = np.frombuffer(bytes(range(256)) * 40, dtype=np.uint8)
+    for world in (2, 8):
+        parts = [bench.strong_shard("c3", text, None, r, world, 32) for r in range(world)]
+        own = [d[(0 if r == 0 else 31):] for r, (d, _) in enumerate(parts)]                       # without its halo a share is the rank's own range
+        assert np.array_equal(np.concatenate(own), text) and all(o[-1] == len(d) for d, o in parts)
+
+
 def test_bench_gpus_n_launches_its_own_ranks():
     """`python bench.py --gpus 2` with no WORLD_SIZE in the environment must start 2 ranks itself (the driver's 8-GPU
     run is launched exactly like that).  --launch-check stops after the ranks have met (gloo, no GPU)."""

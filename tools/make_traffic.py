@@ -25,7 +25,7 @@ def main(summary, key, kernel, note=""):
     out = json.load(open(path)) if os.path.exists(path) else {}
     out = {k: v for k, v in out.items() if isinstance(v, dict) and "kernel_source_sha" in v}     # drop entries of older formats
     out[key] = {
-        "kernel": kernel, "kernel_source_sha": kernel_source_hash(),
+        "kernel": kernel, "kernel_source_sha": kernel_source_hash(kernel),
         "hbm_bytes_dominant_kernel": d["fetch_bytes_raw"] + d["write_bytes"],
         "fetch_bytes_raw": d["fetch_bytes_raw"], "fetch_bytes_x2_gfx950": d["fetch_bytes_x2_gfx950"], "write_bytes": d["write_bytes"],
         "l2_requests": d.get("l2_requests"), "l2_hit_rate": d.get("l2_hit_rate"), "ea_rdreq": d.get("TCC_EA0_RDREQ_sum"),
