@@ -18,6 +18,7 @@ without a GPU, iter()/iter_long()/find_all()/iter_batch() raise.
 """
 import ctypes as C
 import functools
+import os
 import threading
 
 import numpy as np
@@ -120,7 +121,28 @@ def _locked(fn):
     return wrapper
 
 
+def _extension():
+    """the CPython extension `ahocorasick` (dropin/, bytes build): the product's host side"""
+    import importlib.util
+    from .build import dropin_path
+    path = dropin_path()
+    if not os.path.exists(path):
+        raise ImportError("pyahocorasick_amd: %s is missing; build it with `python -m pyahocorasick_amd.build`" % path)
+    spec = importlib.util.spec_from_file_location("ahocorasick", path)
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
 class Automaton:
+    def __new__(cls, *args):
+        # KEY_SEQUENCE (src/utils.c:238-289: keys and haystacks are tuples of integers) lives in ONE place, the extension:
+        # this class hands such automata to it (the numpy-level batch methods below are for byte automata)
+        kt = args[3] if len(args) == 7 else (args[1] if len(args) >= 2 and isinstance(args[0], int) and isinstance(args[1], int) else KEY_STRING)
+        if kt == KEY_SEQUENCE and (len(args) == 7 or args[0] in (STORE_INTS, STORE_LENGTH, STORE_ANY)):
+            return _extension().Automaton(*args)
+        return super().__new__(cls)
+
     def __init__(self, *args):
         """Automaton([store, [key_type]]) — or the 7-tuple of `__reduce__`
         (bytes_list, kind, store, key_type, count, longest_word, values), which is how pickles of
@@ -148,8 +170,6 @@ class Automaton:
             raise ValueError("store value must be one of ahocorasick.STORE_LENGTH, STORE_INTS or STORE_ANY")
         if key_type not in (KEY_STRING, KEY_SEQUENCE):
             raise ValueError("key_type must have value KEY_STRING or KEY_SEQUENCE")
-        if key_type == KEY_SEQUENCE:
-            raise NotImplementedError("KEY_SEQUENCE automata are not byte automata; outside the GPU path (SURVEY §8f N4)")
         self._store = store
         self._key_type = key_type
         self._values = [] if store == STORE_ANY else None   # STORE_ANY: value id -> object

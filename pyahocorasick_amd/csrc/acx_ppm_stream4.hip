@@ -247,6 +247,11 @@ __global__ void __launch_bounds__(ACX_PPM_BLOCK) k_ppm_stream4(const acx_ppm_arg
                     const uint32_t A = (bs[i] >> 3) & amask;
                     gw[i] = lds_rd32(A);
                 }
+                // ONE wait for the sixteen reads: all of them are operands of the (empty) statement below, so the compiler waits
+                // for the last before it and for none after it (a wait per read is an instruction per read, and every
+                // instruction is an issue slot)
+                asm volatile("" : "+v"(gw[0]), "+v"(gw[1]), "+v"(gw[2]), "+v"(gw[3]), "+v"(gw[4]), "+v"(gw[5]), "+v"(gw[6]), "+v"(gw[7]),
+                                  "+v"(gw[8]), "+v"(gw[9]), "+v"(gw[10]), "+v"(gw[11]), "+v"(gw[12]), "+v"(gw[13]), "+v"(gw[14]), "+v"(gw[15]));
 #pragma unroll
                 for (int i = 0; i < 16; i++) acc = __builtin_amdgcn_alignbit(gw[i] >> (bs[i] & 31u), acc, 1u);
             }

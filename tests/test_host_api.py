@@ -194,3 +194,17 @@ def test_add_words_equals_add_word_in_a_loop():
         assert A.flat_image_bytes() == B.flat_image_bytes()
     C_ = acx.Automaton()                                               # STORE_ANY: objects
     assert C_.add_words([b"x", b"xy", b"x"], ["a", "b", "c"]) == 2 and C_.get(b"x") == "c"
+
+
+def test_key_sequence_automata_come_from_the_extension():
+    """pyahocorasick_amd.Automaton(store, KEY_SEQUENCE) is the extension's Automaton (src/utils.c:238-289: keys are tuples
+    of integers): one implementation of that flavour, and the ctypes mirror does not refuse it"""
+    A = acx.Automaton(acx.STORE_INTS, acx.KEY_SEQUENCE)
+    assert type(A).__module__ == "ahocorasick"
+    assert A.add_word((1, 2, 3), 7) and A.add_word((2, 3), 9) and not A.add_word((1, 2, 3), 8)
+    assert A.get((1, 2, 3)) == 8 and A.exists((2, 3)) and not A.exists((3,)) and len(A) == 2
+    assert A.longest_prefix((1, 2, 9)) == 2
+    with pytest.raises(ValueError):
+        A.add_word((1, -2), 1)
+    B = acx.Automaton(acx.STORE_INTS, acx.KEY_STRING)
+    assert type(B) is acx.Automaton
