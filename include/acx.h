@@ -152,6 +152,14 @@ int acx_trie_to_ref_savefile(const acx_trie_t* t, int store, int key_type, int l
  *    Replaces the pointer graph of src/trienode.h:19-42 as the thing the scan reads.
  * ---------------------------------------------------------------------------------- */
 int  acx_flatten(const acx_trie_t* t, void** blob, size_t* nbytes);   /* malloc'd */
+/* The same with layout options (0 = what acx_flatten chooses): the image is valid whatever is asked for, only laid out
+ * otherwise — the test-suite walks every layout on small automata with them. */
+enum { ACX_FLATTEN_NO_PPM       = 1,    /* no position-parallel section: ACX_SCAN_ALL takes the serial walk kernels */
+       ACX_FLATTEN_WIDE         = 2,    /* the wide entry layout (27-bit states) although the narrow one would fit */
+       ACX_FLATTEN_NO_ITOP      = 4,    /* no implicit top-of-trie structures */
+       ACX_FLATTEN_TABLE_HOST   = 8,    /* the dense table is built on the host and travels in the blob */
+       ACX_FLATTEN_TABLE_DEVICE = 16 }; /* the blob carries the sparse form only: the table is built in HBM (default above 64 MiB) */
+int  acx_flatten_ex(const acx_trie_t* t, uint32_t flags, void** blob, size_t* nbytes);
 void acx_blob_free(void* blob);
 int  acx_blob_validate(const void* blob, size_t nbytes);             /* host blob */
 
@@ -309,6 +317,9 @@ void acx_result_free(acx_result_t* r);
 int  acx_scan_host(acx_image_t* img, int mode, const uint8_t* hay, const int64_t* off, int64_t n_hay,
                    const int32_t* init_state, const int32_t* index_base,
                    acx_result_t** result);
+/* acx_scan_host / acx_scan_host_ctx scan a batch larger than this many bytes in groups of haystacks, one launch each, and
+ * assemble one result (default, and 0: 4 GiB — what one launch stages).  Process-wide. */
+void acx_set_host_group_bytes(int64_t bytes);
 /* ACX_SCAN_ALL over streams: haystack h is scanned with the context bytes ctx[ctx_off[h] .. ctx_off[h+1]) in front of it
  * (dev_skip above); the library stages context and chunk side by side, the caller copies nothing.  ctx == NULL: as
  * acx_scan_host without states.  No final states are computed (the next chunk's context is the caller's: the last

@@ -17,6 +17,8 @@ ACX_SCAN_ALL, ACX_SCAN_LONG = 0, 1
 ACX_SCAN_ASYNC = 1
 ACX_SCAN_SKIP_WS = 2        # white space (0x09..0x0D, 0x20) never touches the automaton; indices stay those of the original bytes
 ACX_BLOB_HEADER_BYTES = 256
+# layout options of acx_flatten_ex (include/acx.h)
+ACX_FLATTEN_NO_PPM, ACX_FLATTEN_WIDE, ACX_FLATTEN_NO_ITOP, ACX_FLATTEN_TABLE_HOST, ACX_FLATTEN_TABLE_DEVICE = 1, 2, 4, 8, 16
 
 
 class AcxError(RuntimeError):
@@ -81,6 +83,8 @@ SIGNATURES = {
     "acx_trie_to_ref_savefile": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t), _PP,
                                            C.POINTER(C.c_size_t)]),
     "acx_flatten": (C.c_int, [_P, _PP, C.POINTER(C.c_size_t)]),
+    "acx_flatten_ex": (C.c_int, [_P, C.c_uint32, _PP, C.POINTER(C.c_size_t)]),
+    "acx_set_host_group_bytes": (None, [C.c_int64]),
     "acx_blob_free": (None, [_P]),
     "acx_blob_validate": (C.c_int, [_P, C.c_size_t]),
     "acx_image_upload": (C.c_int, [_P, C.c_size_t, _PP]),

@@ -55,10 +55,11 @@ def _parse_start_end(args, lo, hi):
 class _DeviceImage:
     """The flat automaton uploaded to HBM, tagged with the trie version it was built from."""
 
-    def __init__(self, trie, version):
+    def __init__(self, trie, version, flags=0):
         blob = C.c_void_p()
         nbytes = C.c_size_t()
-        check(lib().acx_flatten(trie, C.byref(blob), C.byref(nbytes)))
+        check(lib().acx_flatten_ex(trie, flags, C.byref(blob), C.byref(nbytes)))
+        self.flags = flags
         self.handle = C.c_void_p()
         try:
             check(lib().acx_image_upload(blob, nbytes.value, C.byref(self.handle)))
@@ -149,6 +150,7 @@ class Automaton:
         this class AND of the reference's bytes build are loaded (src/Automaton.c:97-181)."""
         self._trie = C.c_void_p()
         self._image = None
+        self.flatten_flags = 0                               # layout options of the flat image (acx_flatten_ex, ACX_FLATTEN_*): 0 = the library's choice
         self._result = C.c_void_p()                          # reusable device/pinned buffers
         self._lock = threading.RLock()
         self._free_slots = []                                # STORE_ANY: value slots freed by remove_word / pop
@@ -437,16 +439,17 @@ class Automaton:
 
     def _ensure_image(self):
         v = self._version
-        if self._image is None or self._image.version != v:
+        if self._image is None or self._image.version != v or self._image.flags != self.flatten_flags:
             self._drop_image()                      # invalidated by version (SURVEY §7 "Invalidation")
-            self._image = _DeviceImage(self._trie, v)
+            self._image = _DeviceImage(self._trie, v, self.flatten_flags)
         return self._image
 
-    def flat_image_bytes(self):
-        """The flat image (include/acx_blob.h) as bytes — what a single RCCL broadcast replicates."""
+    def flat_image_bytes(self, flags=None):
+        """The flat image (include/acx_blob.h) as bytes — what a single RCCL broadcast replicates.  flags: layout options
+        of acx_flatten_ex (ACX_FLATTEN_*; default: this automaton's `flatten_flags`)."""
         blob = C.c_void_p()
         nbytes = C.c_size_t()
-        check(lib().acx_flatten(self._trie, C.byref(blob), C.byref(nbytes)))
+        check(lib().acx_flatten_ex(self._trie, self.flatten_flags if flags is None else flags, C.byref(blob), C.byref(nbytes)))
         try:
             return bytes((C.c_char * nbytes.value).from_address(blob.value))   # (string_at takes a C int)
         finally:

@@ -798,8 +798,10 @@ static int scan_ppm(acx_image_t* img, const acx_scan_params* p, acx_result* r, h
     pa.counts = r->counts.p; pa.scr_off = r->scr_off.p;
     pa.heads = r->ppm_ctl.p; pa.overflow = (int32_t*)(r->ppm_ctl.p + 8); pa.short_hay = (int32_t*)(r->ppm_ctl.p + 9);
     pa.hay_local = chunked ? nullptr : r->hay_local.p;
+#ifdef ACX_PPM_DEV
     pa.dbg = 0;
     if (const char* e = acx_tune_env("ACX_PPM_DBG")) pa.dbg = (uint32_t)atoi(e);
+#endif
     static unsigned long long* g_phase = nullptr;
     if (acx_tune_env("ACX_PPM_PHASES")) {
         if (!g_phase) { if (hipMalloc((void**)&g_phase, 64) != hipSuccess) g_phase = nullptr; }
@@ -1351,9 +1353,11 @@ extern "C" int acx_scan_host_ctx(acx_image_t* img, const uint8_t* hay, const int
     return acx_scan_batch(img, &p, result, nullptr);
 }
 
+static std::atomic<int64_t> g_host_group_bytes{0};
+extern "C" void acx_set_host_group_bytes(int64_t bytes) { g_host_group_bytes.store(bytes > 0 ? bytes : 0); }
 static int64_t max_launch_bytes() {
-    if (const char* v = getenv("ACX_MAX_LAUNCH_BYTES")) { const long long x = atoll(v); if (x > 0) return (int64_t)x; }   // test hook
-    return ACX_MAX_LAUNCH_BYTES;
+    const int64_t x = g_host_group_bytes.load();
+    return x > 0 && x < ACX_MAX_LAUNCH_BYTES ? x : ACX_MAX_LAUNCH_BYTES;
 }
 
 extern "C" int acx_scan_host(acx_image_t* img, int mode, const uint8_t* hay, const int64_t* off, int64_t n_hay,

@@ -121,7 +121,9 @@ struct acx_ppm_args {
     uint32_t top_base[ACX_PPM_MAX_C + 2];
     acx_ppm_lds lds;
     uint32_t fast;           // 1: k_ppm_stream (fixed stride >= 4, aligned buffer, bit-field codes, halo_pos <= 256)
-    uint32_t dbg;            // tuning only (variant bits 25..27): 1 = no exact phase, 2 = no emit, 4 = no filter
+#ifdef ACX_PPM_DEV
+    uint32_t dbg;            // development builds only (k_ppm_stream's phase switches: 2 = no record writes, 4 = no rounds, 8 = no queue, 16 = no filter)
+#endif
     uint32_t nsub;           // k_ppm_stream: sub-steps of 256 positions per tile (4 or 8)
     uint32_t m24;            // k_ppm_stream: ceil(2^23 / stride) for strides below 2048 (a 24-bit multiply divides), else 0
     const int64_t* off; const int64_t* first_h;    // k_ppm_stream on an offsets batch: offsets, first haystack at or after every tile

@@ -50,7 +50,7 @@ struct Gang {
 // with its predecessor: pop to that depth, append the rest).  Children come out in ascending letter order and are
 // linked in O(1); acx_trie_add_word would walk sibling lists, which are 256 long at the top of a signature trie.
 int build_reversed(const acx_trie* t, acx_trie* rev, std::vector<int32_t>* depth_out) {
-    const bool timing_ = getenv("ACX_PPM_TIMING") != nullptr;
+    const bool timing_ = acx_tune_env("ACX_PPM_TIMING") != nullptr;
     auto t0_ = std::chrono::steady_clock::now();
     auto lap_ = [&](const char* what) { if (timing_) { auto t1 = std::chrono::steady_clock::now(); fprintf(stderr, "[build_reversed] %s: %.3f s\n", what, std::chrono::duration<double>(t1 - t0_).count()); t0_ = t1; } };
     // 1. collect: DFS with an explicit stack; every key reversed into one buffer
@@ -262,8 +262,6 @@ int build_reversed(const acx_trie* t, acx_trie* rev, std::vector<int32_t>* depth
 // too large): the scan then uses the serial walk kernels.  *out is malloc'd.
 int acx_ppm_build(const acx_trie* t, const uint8_t* cls, uint32_t n_classes, bool has_other, uint8_t** out, size_t* nbytes) {
     *out = nullptr; *nbytes = 0;
-    const char* off_env = getenv("ACX_NO_PPM");
-    if (off_env && off_env[0] == '1') return ACX_OK;
     if (t->count <= 0 || t->longest_word <= 0 || t->longest_word > (int64_t)ACX_PPM_MAX_LONGEST) return ACX_OK;
     try {
         const uint32_t sigma = has_other ? n_classes - 1 : 256u;        // symbols = bytes that occur in keys
@@ -282,7 +280,7 @@ int acx_ppm_build(const acx_trie* t, const uint8_t* cls, uint32_t n_classes, boo
             if (sym_arith) for (int b = 0; b < 256; b++) if (symof[b] != 0xFFu) symof[b] = (uint8_t)((b >> (sym_arith - 1)) & 3);
         }
 
-        const bool timing = getenv("ACX_PPM_TIMING") != nullptr;
+        const bool timing = acx_tune_env("ACX_PPM_TIMING") != nullptr;
         auto t0 = std::chrono::steady_clock::now();
         auto lap = [&](const char* what) { if (timing) { auto t1 = std::chrono::steady_clock::now(); fprintf(stderr, "[acx_ppm_build] %s: %.3f s\n", what, std::chrono::duration<double>(t1 - t0).count()); t0 = t1; } };
         acx_trie rev;

@@ -290,11 +290,14 @@ uint64_t acx_fnv1a64(const uint8_t* p, size_t n) {
     return h;
 }
 
-int acx_flatten(const acx_trie_t* t, void** blob_out, size_t* nbytes_out) {
+int acx_flatten(const acx_trie_t* t, void** blob_out, size_t* nbytes_out) { return acx_flatten_ex(t, 0u, blob_out, nbytes_out); }
+
+int acx_flatten_ex(const acx_trie_t* t, uint32_t flags, void** blob_out, size_t* nbytes_out) {
     if (!t || !blob_out || !nbytes_out) return acx_fail(ACX_E_INVAL, "acx_flatten: NULL argument");
+    if ((flags & ACX_FLATTEN_TABLE_HOST) && (flags & ACX_FLATTEN_TABLE_DEVICE)) return acx_fail(ACX_E_INVAL, "acx_flatten_ex: the table is built on the host or on the device");
     if (t->kind != ACX_KIND_AHOCORASICK)
         return acx_fail(ACX_E_STATE, "acx_flatten: not an Aho-Corasick automaton yet: call make_automaton first");
-    const bool timing = getenv("ACX_FLATTEN_TIMING") != nullptr;
+    const bool timing = acx_tune_env("ACX_FLATTEN_TIMING") != nullptr;
     struct timespec lap_t0; clock_gettime(CLOCK_MONOTONIC, &lap_t0);
     auto lap = [&](const char* what) {
         if (!timing) return;
@@ -326,12 +329,11 @@ int acx_flatten(const acx_trie_t* t, void** blob_out, size_t* nbytes_out) {
     else { K = n_used + 1; unsigned k = 1; for (int b = 0; b < 256; b++) cls[b] = used[b] ? (uint8_t)k++ : 0; }
 
     // narrow layout whenever it fits: 24-bit states and 32-bit byte offsets into the table
-    // (ACX_FORCE_WIDE_LAYOUT=1 forces the wide layout on small automata: test hook)
-    const char* force_wide = getenv("ACX_FORCE_WIDE_LAYOUT");
+    // (ACX_FLATTEN_WIDE asks for the wide layout on small automata)
     auto narrow_fits = [&](size_t rows) -> bool {
         return rows < ((size_t)1 << ACX_STATE_BITS_NARROW) && rows * (size_t)K * 4 < ((size_t)1 << 32);
     };
-    const uint32_t SB = (narrow_fits(n) && !(force_wide && force_wide[0] == '1')) ? ACX_STATE_BITS_NARROW : ACX_STATE_BITS_WIDE;
+    const uint32_t SB = (narrow_fits(n) && !(flags & ACX_FLATTEN_WIDE)) ? ACX_STATE_BITS_NARROW : ACX_STATE_BITS_WIDE;
     const uint32_t ESC = ACX_ENTRY_CNT_ESCAPE(SB);
 
     // 1b. state numbering and the implicit top-of-trie (include/acx_blob.h "itop").
@@ -360,8 +362,7 @@ int acx_flatten(const acx_trie_t* t, void** blob_out, size_t* nbytes_out) {
         for (int32_t d = 0; d <= max_depth; d++)
             parallel_range((size_t)lvl[d], (size_t)lvl[d + 1], [&](size_t a, size_t b) { for (size_t i = a; i < b; i++) adepth[order[i]] = d; });
         const size_t budget_words = (size_t)156 * 1024 / 4;          // of the CU's 160 KiB of LDS (+1 KiB class map)
-        const char* no_itop = getenv("ACX_NO_ITOP");
-        if (SB == ACX_STATE_BITS_NARROW && sigma <= 16 && !(no_itop && no_itop[0] == '1')) {
+        if (SB == ACX_STATE_BITS_NARROW && sigma <= 16 && !(flags & ACX_FLATTEN_NO_ITOP)) {
             // complete levels: every k-gram over the key alphabet is a node (the warm-up path needs
             // no probe there).  dense levels: at least 95 % of them are.  In the steady state the
             // automaton is hardly ever shallower than the last dense level, so with D <= dense + 2
@@ -438,7 +439,7 @@ int acx_flatten(const acx_trie_t* t, void** blob_out, size_t* nbytes_out) {
     uint8_t* ppm = nullptr;
     size_t ppm_bytes = 0;
     {
-        const int rcp = acx_ppm_build(t, cls, K, has_other, &ppm, &ppm_bytes);
+        const int rcp = (flags & ACX_FLATTEN_NO_PPM) ? ACX_OK : acx_ppm_build(t, cls, K, has_other, &ppm, &ppm_bytes);
         if (rcp) return rcp;
     }
     struct PpmFree { uint8_t* p; ~PpmFree() { free(p); } } ppm_guard{ppm};
@@ -449,13 +450,12 @@ int acx_flatten(const acx_trie_t* t, void** blob_out, size_t* nbytes_out) {
     memset(&h, 0, sizeof h);
     // Where is the dense table built?  On the host (it is then part of the blob) or on the device
     // from the sparse edge lists (the blob is ~K x smaller; acx_image_upload/adopt run the build
-    // kernels).  ACX_FLATTEN_TABLE=host|device overrides; default: device once it exceeds 64 MiB.
+    // kernels).  ACX_FLATTEN_TABLE_HOST / _DEVICE override; default: device once it exceeds 64 MiB.
     const size_t table_entries = n * (size_t)K;
     const uint32_t itop_cell_bytes = itop_D ? (sigma <= 4 ? 4u : 8u) : 0u;
-    const char* tbl_env = getenv("ACX_FLATTEN_TABLE");
     bool table_in_blob = table_entries * 4 < ((size_t)64 << 20);
-    if (tbl_env && !strcmp(tbl_env, "host")) table_in_blob = true;
-    if (tbl_env && !strcmp(tbl_env, "device")) table_in_blob = false;
+    if (flags & ACX_FLATTEN_TABLE_HOST) table_in_blob = true;
+    if (flags & ACX_FLATTEN_TABLE_DEVICE) table_in_blob = false;
     const uint32_t n_levels = (uint32_t)t->level_first.size() - 1;
     const size_t n_edges = n - 1;
 

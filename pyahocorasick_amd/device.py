@@ -62,10 +62,10 @@ class Image:
         return cls(h)
 
     @classmethod
-    def from_automaton(cls, automaton):
+    def from_automaton(cls, automaton, flags=None):
         """flatten + upload without routing the (possibly tens of GB) blob through Python bytes"""
         blob, nbytes, h = C.c_void_p(), C.c_size_t(), C.c_void_p()
-        check(lib().acx_flatten(automaton._trie, C.byref(blob), C.byref(nbytes)))
+        check(lib().acx_flatten_ex(automaton._trie, automaton.flatten_flags if flags is None else flags, C.byref(blob), C.byref(nbytes)))
         try:
             check(lib().acx_image_upload(blob, nbytes.value, C.byref(h)))
         finally:

@@ -405,18 +405,19 @@ def test_iter_long_rows_in_lds_vs_plain_vs_oracle():
         assert all(np.array_equal(x, y) for x, y in zip(outs[0], outs[1]))
 
 
-def test_wide_layout_on_gpu(monkeypatch):
+def test_wide_layout_on_gpu():
     """27-bit states, 64-bit table addressing, 2-bit counts (escape from 3 outputs on):
-    same fixtures, layout forced on small automata"""
-    monkeypatch.setenv("ACX_FORCE_WIDE_LAYOUT", "1")
+    same fixtures, layout asked for on small automata (ACX_FLATTEN_WIDE)"""
     for c in RANDOM["cases"][::3]:
         keys, values = _case_values(c)
         A, _ = build_pair(keys, values, c["store"])
+        A.flatten_flags = acx.ACX_FLATTEN_WIDE
         hays = [bytes.fromhex(h["hay_hex"]) for h in c["hays"]]
         assert A.iter_batch(hays) == [expected_pairs(h["iter"]) for h in c["hays"]]
         assert A.iter_batch(hays, long=True) == [expected_pairs(h["iter_long"]) for h in c["hays"]]
     keys, reads = dna_workload(3000, 3000, 150, seed=5)
     A, O = build_pair(keys)
+    A.flatten_flags = acx.ACX_FLATTEN_WIDE
     n, L = reads.shape
     off = np.arange(n + 1, dtype=np.int64) * L
     img = Image.from_automaton(A)
@@ -503,23 +504,18 @@ def test_blob_without_itop_flags_walks_with_plain_kernels():
         assert np.array_equal(moff, mo) and np.array_equal(e, oe) and np.array_equal(v, ov)
 
 
-def test_device_built_table_equals_host_built(monkeypatch):
-    """blobs without a table section (ACX_FLATTEN_TABLE=device): the table is built in HBM level by
+def test_device_built_table_equals_host_built():
+    """blobs without a table section (ACX_FLATTEN_TABLE_DEVICE): the table is built in HBM level by
     level from the sparse form and must equal the host-built one bit for bit; scans agree too"""
     import struct
     rng = np.random.default_rng(44)
     for alpha, wide in ((b"ACGT", False), (bytes(range(256)), False), (b"abcdefghij ", True)):
         a = np.frombuffer(alpha, dtype=np.uint8)
         keys = list({bytes(rng.choice(a, size=int(n)).tobytes()) for n in rng.integers(1, 30, size=3000)})
-        if wide:
-            monkeypatch.setenv("ACX_FORCE_WIDE_LAYOUT", "1")
         A, O = build_pair(keys)
-        monkeypatch.setenv("ACX_FLATTEN_TABLE", "host")
-        blob_h = A.flat_image_bytes()
-        monkeypatch.setenv("ACX_FLATTEN_TABLE", "device")
-        blob_d = A.flat_image_bytes()
-        monkeypatch.delenv("ACX_FLATTEN_TABLE")
-        monkeypatch.delenv("ACX_FORCE_WIDE_LAYOUT", raising=False)
+        lay = acx.ACX_FLATTEN_WIDE if wide else 0
+        blob_h = A.flat_image_bytes(lay | acx.ACX_FLATTEN_TABLE_HOST)
+        blob_d = A.flat_image_bytes(lay | acx.ACX_FLATTEN_TABLE_DEVICE)
         n, K = struct.unpack_from("<II", blob_h, 24)
         off_table, = struct.unpack_from("<Q", blob_h, 72)
         assert struct.unpack_from("<I", blob_d, 216)[0] == 0 and struct.unpack_from("<I", blob_h, 216)[0] == 1
@@ -700,7 +696,7 @@ def test_asynchronous_scans_complete_lazily():
     assert np.array_equal(moff, m8) and np.array_equal(e, e8) and np.array_equal(v, v8)
 
 
-def test_host_scan_splits_batches_that_exceed_one_launch(monkeypatch):
+def test_host_scan_splits_batches_that_exceed_one_launch():
     """acx_scan_host scans groups of whole haystacks when the batch is larger than one launch can
     stage (4 GiB; the limit is lowered here through the test hook) and assembles one result"""
     keys, reads = dna_workload(2000, 3000, 150, seed=31)
@@ -708,11 +704,15 @@ def test_host_scan_splits_batches_that_exceed_one_launch(monkeypatch):
     hays = [r.tobytes() for r in reads] + [b"", reads[0].tobytes() * 40]
     want = [O.iter(h) for h in hays]
     assert A.iter_batch(hays) == want                                   # one launch
-    monkeypatch.setenv("ACX_MAX_LAUNCH_BYTES", "20000")                 # ~130 haystacks per group, one group of 1
-    assert A.iter_batch(hays) == want
-    assert A.iter_batch(hays, long=True) == [O.iter_long(h) for h in hays]
-    monkeypatch.setenv("ACX_MAX_LAUNCH_BYTES", "1")                     # every haystack its own launch
-    assert A.iter_batch(hays[:50]) == want[:50]
+    from pyahocorasick_amd import _lib
+    try:
+        _lib.lib().acx_set_host_group_bytes(20000)                      # ~130 haystacks per group, one group of 1
+        assert A.iter_batch(hays) == want
+        assert A.iter_batch(hays, long=True) == [O.iter_long(h) for h in hays]
+        _lib.lib().acx_set_host_group_bytes(1)                          # every haystack its own launch
+        assert A.iter_batch(hays[:50]) == want[:50]
+    finally:
+        _lib.lib().acx_set_host_group_bytes(0)
 
 
 def test_iterator_set_semantics_vs_reference():

@@ -11,6 +11,8 @@ import random
 
 import pytest
 
+import pyahocorasick_amd as acx
+
 from helpers import build_pair, expected_pairs, i32, load_json
 from oracle import orc
 
@@ -167,17 +169,16 @@ def test_int_truncation_matches_reference_probe():
     assert i32(2**40 + 5) == 5
 
 
-def test_wide_layout_flat_walk(monkeypatch):
+def test_wide_layout_flat_walk():
     """the 27-bit-state / 2-bit-count entry layout used for automata beyond 2^24 states or a
     4 GiB table, forced here on small automata"""
     import struct
-    monkeypatch.setenv("ACX_FORCE_WIDE_LAYOUT", "1")
     rng = random.Random(13)
     for trial in range(25):
         alpha = rng.choice([b"ab", b"ACGT", bytes([0x61, 0x80, 0xFF, 0x00]), bytes(range(256))])
         keys = list({bytes(rng.choice(alpha) for _ in range(rng.randint(1, 9))) for _ in range(rng.randint(1, 60))})
         A, O = build_pair(keys, [rng.randint(-2**40, 2**40) for _ in keys])
-        blob = A.flat_image_bytes()
+        blob = A.flat_image_bytes(acx.ACX_FLATTEN_WIDE)
         assert struct.unpack_from("<I", blob, 136)[0] == 27
         for _ in range(6):
             hay = bytes(rng.choice(alpha) for _ in range(rng.randint(0, 200)))
@@ -187,17 +188,17 @@ def test_wide_layout_flat_walk(monkeypatch):
     # counts >= 3 take the escape path in this layout
     keys = [b"a" * n for n in range(1, 9)]
     A, O = build_pair(keys)
-    blob = A.flat_image_bytes()
+    blob = A.flat_image_bytes(acx.ACX_FLATTEN_WIDE)
     got, _ = orc.flat_iter(blob, b"a" * 20)
     assert got == O.iter(b"a" * 20)
 
 
-def test_implicit_top_of_trie_structures(monkeypatch):
+def test_implicit_top_of_trie_structures():
     """itop (include/acx_blob.h): the ND4 table + entries + level-D row copies let shallow states
     be walked without table rows.  flat_walk.c:flat_iter_itop is the CPU restatement of
     k_walk_itop and cross-checks every step against the explicit table."""
     import struct
-    monkeypatch.setenv("ACX_FLATTEN_TABLE", "host")      # the CPU walkers read the table from the blob
+    HOST = acx.ACX_FLATTEN_TABLE_HOST                       # the CPU walkers read the table from the blob
     rng = random.Random(17)
     alphabets = [b"ab", b"ACGT", b"ACGTN", bytes([0x61, 0x80, 0xFF, 0x00]), b"0123456789", b"abcdefghijklmnop",
                  b"abcdefghijklmnopqrstuvwxyz ", bytes(range(256)), b"0123456789abcdef", b"xyz"]
@@ -207,7 +208,7 @@ def test_implicit_top_of_trie_structures(monkeypatch):
         hay_alpha = alpha + (b"#" if len(alpha) < 256 and trial % 3 == 0 else b"")   # bytes outside the key alphabet
         keys = list({bytes(rng.choice(alpha) for _ in range(rng.randint(1, 12))) for _ in range(rng.randint(1, 400))})
         A, O = build_pair(keys, [rng.randint(-2**40, 2**40) for _ in keys])
-        blob = A.flat_image_bytes()
+        blob = A.flat_image_bytes(HOST)
         D = struct.unpack_from("<I", blob, 140)[0]
         cell_bytes = struct.unpack_from("<I", blob, 220)[0]
         sigma = len(set(b"".join(keys)))

@@ -85,11 +85,12 @@ def test_ppm_walk_dna_dictionary_deep_rows():
         assert orc.ppm_iter(blob, hay) == O.iter(hay)
 
 
-def test_ppm_absent_when_disabled(monkeypatch):
-    monkeypatch.setenv("ACX_NO_PPM", "1")
+def test_ppm_absent_when_not_asked_for():
+    import pyahocorasick_amd as acx
     A, O = build_pair([b"he", b"she"])
-    assert _ppm_header(A.flat_image_bytes()) is None
-    assert orc.ppm_iter(A.flat_image_bytes(), b"ushers") is None
+    assert _ppm_header(A.flat_image_bytes(acx.ACX_FLATTEN_NO_PPM)) is None
+    assert orc.ppm_iter(A.flat_image_bytes(acx.ACX_FLATTEN_NO_PPM), b"ushers") is None
+    assert _ppm_header(A.flat_image_bytes()) is not None
 
 
 def test_arithmetic_symbol_map_for_four_letter_alphabets():
