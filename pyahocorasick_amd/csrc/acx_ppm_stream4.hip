@@ -302,17 +302,23 @@ __global__ void __launch_bounds__(ACX_PPM_BLOCK) k_ppm_stream4(const acx_ppm_arg
                 cmax = cn[e] > cmax ? cn[e] : cmax;
             )
             S4_MARK(M_SECOND);
-            if (__any(cmax > 1u)) {                                     // a second key within the cell's levels (0.6 % of the matching positions of config 2)
+            // a second key within the cell's levels (0.6 % of the matching positions of config 2): the value of the first such
+            // slot of the lane is REQUESTED here and looked at behind the deeper walks — a wait here would be one more
+            // round trip to the L2 in the chain of every round
+            uint32_t vbte = S4_NE, vbt_at = 0;
+            int32_t vbt = 0;
+            if (__any(cmax > 1u)) {
 #pragma unroll
                 for (int e = 0; e < S4_NE; e++) {
-                    if (cn[e] > 1u) {
+                    if (cn[e] > 1u && vbte == (uint32_t)S4_NE) {
                         const uint32_t L = __builtin_amdgcn_ubfe(ppO[e], 12u, 6u), Lc = L < S4_C ? L : S4_C;
                         const uint32_t m = hcO[e].x & ((1u << Lc) - 1u), m2 = m & (m - 1u);
                         const uint32_t d2 = (uint32_t)__ffs(m2);
                         const uint32_t X = P.window((ppO[e] & 0xFFFu) - 1u);
-                        set_vb((uint32_t)e, a.top_val[top_base4(d2) + (X >> (32u - 2u * d2))]);
+                        vbte = (uint32_t)e; vbt_at = top_base4(d2) + (X >> (32u - 2u * d2));
                     }
                 }
+                if (vbte < (uint32_t)S4_NE) vbt = a.top_val[vbt_at];
             }
             S4_MARK(M_DEEP);
             // deeper levels: the entries that go on, 64 at a time, one per lane; one 16-byte record per step, selects instead of
@@ -339,11 +345,17 @@ __global__ void __launch_bounds__(ACX_PPM_BLOCK) k_ppm_stream4(const acx_ppm_arg
                     const uint32_t pk = go ? dq[2 * lane] : S4_HP + 1u;
                     uint32_t did = go ? dq[2 * lane + 1] : 0u;
                     const uint32_t wpq = (pk & 0xFFFu) - 1u, wL = (pk >> 12) & 63u;
-                    if (go && (pk >> 23)) did = a.cid[P.window(wpq) >> (32u - 2u * S4_C)];     // the cell's second word is a value: the id comes from cid[]
+                    // the cell's second word is a value (a key ends within the cell's levels as well: one walker in twelve): the id comes
+                    // from cid[] — requested here, looked at when the others have taken their first step (their record gather is
+                    // issued behind this load and waited for first: no round trip of its own)
+                    const bool pend = go && (pk >> 23) != 0u;
+                    uint32_t cidv = 0;
+                    if (pend) cidv = a.cid[P.window(wpq) >> (32u - 2u * S4_C)];
                     uint32_t dd = S4_C, wc = 0;
                     int32_t wa = 0, wb = 0;
                     uint32_t s1 = P.sym_at(wpq - S4_C);
-                    go = go && did != 0u;
+                    go = go && !pend && did != 0u;
+                    bool first_step = true;
                     for (;;) {
                         const uint32_t single = did >> 31, first = single ^ 1u;
                         uint32_t off = single ? a.single_off + (did << 4) : a.row_off + ((did + s1) << 4);   // (bit 31 shifts out; a row's id is a record index)
@@ -363,6 +375,10 @@ __global__ void __launch_bounds__(ACX_PPM_BLOCK) k_ppm_stream4(const acx_ppm_arg
                         did = rec.w;
                         const uint32_t g2 = ok & 1u & (rec.w != 0u ? 1u : 0u) & ((rec.w >> 31) | (wL > dn ? 1u : 0u));
                         go = g2 != 0u;
+                        if (first_step) {                                // (wave-uniform) the walkers whose id has arrived meanwhile join
+                            first_step = false;
+                            if (pend) { dd = S4_C; did = cidv; go = cidv != 0u; }
+                        }
                         if (!__any(go)) break;
                         s1 = go ? P.sym_at(wpq - dd) : 0u;
                     }
@@ -370,33 +386,29 @@ __global__ void __launch_bounds__(ACX_PPM_BLOCK) k_ppm_stream4(const acx_ppm_arg
                 }
                 wave_sync();
                 {
+                    // what the walks found: the count and both values of every slot's walker in one pass (no second look at the
+                    // hand-over's memory, no branches: selects)
                     uint32_t rnk = d_base - d0;
-                    uint32_t found = 0;                                  // slots whose walk found keys: their values are fetched below
                     S4_SLOTS(e,
                         const uint32_t g = (gomask >> e) & 1u;
                         const bool mine = g != 0u && rnk < 64u;
-                        const uint32_t c2 = mine ? (uint32_t)dcnt[mine ? rnk : 64u] : 0u;
-                        found |= (c2 ? 1u : 0u) << e;
-                        cn[e] += c2 << 16;                               // (kept apart until the values are in place)
+                        const uint32_t ix = mine ? rnk : 64u;
+                        const uint32_t c2 = mine ? (uint32_t)dcnt[ix] : 0u;
+                        const u32x2 dv = *(const u32x2*)(dq + 2 * ix);
+                        const uint32_t ct = cn[e];
+                        va[e] = (c2 != 0u && ct == 0u) ? (int32_t)dv.x : va[e];
+                        // the second value of the position: the walk's first behind ONE key of the cell, its second behind none
+                        const bool has2 = (ct == 0u && c2 > 1u) || (ct == 1u && c2 != 0u);
+                        const bool take = has2 && vbe == (uint32_t)S4_NE;
+                        vb1 = take ? (ct == 0u ? (int32_t)dv.y : (int32_t)dv.x) : vb1;
+                        vbe = take ? (uint32_t)e : vbe;
+                        cn[e] = ct + c2;
                         rnk += g;
                     )
-                    if (__any(found != 0u)) {
-                        uint32_t rnk2 = d_base - d0;
-                        S4_SLOTS(e,
-                            const uint32_t g = (gomask >> e) & 1u;
-                            if ((found >> e) & 1u) {
-                                const u32x2 dv = *(const u32x2*)(dq + 2 * rnk2);
-                                const uint32_t ct = cn[e] & 0xFFFFu;
-                                if (ct == 0u) { va[e] = (int32_t)dv.x; if ((cn[e] >> 16) > 1u) set_vb((uint32_t)e, (int32_t)dv.y); } else if (ct == 1u) set_vb((uint32_t)e, (int32_t)dv.x);
-                            }
-                            rnk2 += g;
-                        )
-                    }
-#pragma unroll
-                    for (int e = 0; e < S4_NE; e++) cn[e] = (cn[e] & 0xFFFFu) + (cn[e] >> 16);
                 }
                 wave_sync();
             }
+            if (vbte < (uint32_t)S4_NE) set_vb(vbte, vbt);
         }
 
         S4_PH(0);
@@ -479,16 +491,27 @@ __global__ void __launch_bounds__(ACX_PPM_BLOCK) k_ppm_stream4(const acx_ppm_arg
             S4_MARK(M_PLACE);
             // place: entry e * 64 + lane; the records of a slot follow those of the slots below it (two slots per prefix
             // sum, 16 bits each: a slot has at most 64 x longest < 65536 records)
+            // (the three prefix sums are independent: their steps are interleaved, one chain of six dependent DPP adds instead of
+            //  three; slots beyond the round's last count nothing)
             uint32_t ex[S4_NE], rt = 0;
-#pragma unroll
-            for (int e = 0; e < S4_NE; e += 2) {
-                ex[e] = rt; ex[e + 1] = rt;
-                if (e == 0 || (uint32_t)e < k) {
-                    uint32_t t;
-                    const uint32_t x2 = wave_excl_scan(cn[e] | (cn[e + 1] << 16), t);
-                    ex[e] = rt + (x2 & 0xFFFFu); rt += t & 0xFFFFu;
-                    ex[e + 1] = rt + (x2 >> 16); rt += t >> 16;
-                }
+            {
+                static_assert(S4_NE == 6, "three pairs of slots");
+                const uint32_t v0 = cn[0] | (cn[1] << 16), v1 = cn[2] | (cn[3] << 16), v2 = cn[4] | (cn[5] << 16);
+                uint32_t x0 = v0, x1 = v1, x2 = v2;
+#define S4_DPP3(ctrl, rmask) do { \
+                    const uint32_t a0_ = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x0, ctrl, rmask, 0xF, false); \
+                    const uint32_t a1_ = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x1, ctrl, rmask, 0xF, false); \
+                    const uint32_t a2_ = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x2, ctrl, rmask, 0xF, false); \
+                    x0 += a0_; x1 += a1_; x2 += a2_; } while (0)
+                S4_DPP3(0x111, 0xF); S4_DPP3(0x112, 0xF); S4_DPP3(0x114, 0xF); S4_DPP3(0x118, 0xF);     // row_shr 1, 2, 4, 8
+                S4_DPP3(0x142, 0xA); S4_DPP3(0x143, 0xC);                                               // row_bcast 15 -> rows 1, 3; 31 -> rows 2, 3
+#undef S4_DPP3
+                const uint32_t t0 = (uint32_t)__builtin_amdgcn_readlane((int)x0, 63), t1 = (uint32_t)__builtin_amdgcn_readlane((int)x1, 63),
+                               t2 = (uint32_t)__builtin_amdgcn_readlane((int)x2, 63);
+                x0 -= v0; x1 -= v1; x2 -= v2;
+                ex[0] = rt + (x0 & 0xFFFFu); rt += t0 & 0xFFFFu; ex[1] = rt + (x0 >> 16); rt += t0 >> 16;
+                ex[2] = rt + (x1 & 0xFFFFu); rt += t1 & 0xFFFFu; ex[3] = rt + (x1 >> 16); rt += t1 >> 16;
+                ex[4] = rt + (x2 & 0xFFFFu); rt += t2 & 0xFFFFu; ex[5] = rt + (x2 >> 16); rt += t2 >> 16;
             }
             if (rt && !dead) {
                 if (g_used + rt + 1u > g_size) {                       // this round (and the spare slot behind it) does not fit the current grant: open the next one
