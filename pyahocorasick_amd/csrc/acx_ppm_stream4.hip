@@ -174,17 +174,20 @@ __global__ void __launch_bounds__(ACX_PPM_BLOCK) k_ppm_stream4(const acx_ppm_arg
 
     // ---- the pipeline -----------------------------------------------------------------------------------
     // A ROUND is at most 352 candidates of one tile (all of them, unless the tile holds more).  Every trip of the loop
-    //   1. works off the first half of the round fetched one trip earlier (set O): top levels, deeper walks — every load
-    //      that is waited for lies here;
-    //   2. turns the bytes of the next tile into symbols (registers only) when this trip hands over the last candidates
+    //   1. works off the round fetched one trip earlier (set O): top levels, deeper walks — every load that is waited for
+    //      lies here;
+    //   2. finishes it: placement, records (stores);
+    //   3. turns the bytes of the next tile into symbols (registers only) when this trip hands over the last candidates
     //      of the current one, and requests the bytes of the tile after that;
-    //   3. pushes the candidates of the next round into the queue and FETCHES: where they sit, their windows, the
-    //      requests for their hot cells — into the registers of set N;
-    //   4. finishes set O: placement, records (stores);
+    //   4. pushes the candidates of the next round into the queue and FETCHES: where they sit, their windows, the
+    //      requests for their hot cells — into the same slot registers;
     //   5. stages the next tile: symbols -> the OTHER symbol buffer, the filter, the prefix sum of the pass words.
-    // Loads return in order: a wait for a later load is a wait for the hot cells too.  So nothing between 3 and the next
+    // Loads return in order: a wait for a later load is a wait for the hot cells too.  So nothing between 4 and the next
     // trip's 1 waits for a load: the gathers of a round are in flight while the address unit of the CU serves them
-    // (about one lane per ns and CU, profiles/r4_*) and the wave does steps 4 and 5.
+    // (about one lane per ns and CU, profiles/r4_*) and the wave does step 5.  What a wave's time per round is made of
+    // is the chain of its DEPENDENT round trips to the L2 (profiles/r4_experiments.md): every one taken out of the chain —
+    // a value requested early and looked at late, an id that rides behind another gather — made the kernel faster,
+    // instructions taken out did not.
     uint32_t cur = 0;                                                  // symbol buffer of the tile whose candidates are being fetched
     bool tile_ok = true;
     uint32_t pw = 0, x_ex = 0, x_tot = 0, seg_lo = 0, use_other = 0, any_cur = 0;
@@ -192,11 +195,11 @@ __global__ void __launch_bounds__(ACX_PPM_BLOCK) k_ppm_stream4(const acx_ppm_arg
     // ONE set of slot registers: step 1 is the last reader of a round's hot cells, step 3 loads the next round's into the
     // same registers (a second set would have to be copied into the first, and a copy of a loaded register is a wait)
     u32x2 hcO[S4_NE];
-    uint32_t ppO[S4_NE], ppK[S4_NE];                                   // entry (position + 33) | symbols that exist << 12 | (16 + the next two symbols) << 18; ppK: set O's, kept across the fetch
+    uint32_t ppO[S4_NE];                                               // entry (position + 33) | symbols that exist << 12 | (16 + the next two symbols) << 18
     uint32_t nO = 0, nN = 0, cgO = 0, cgN = 0, symO = wbase, symN = wbase;
     bool haveO = false;
 #pragma unroll
-    for (int e = 0; e < S4_NE; e++) { hcO[e].x = 0; hcO[e].y = 0; ppO[e] = 0; ppK[e] = 0; }
+    for (int e = 0; e < S4_NE; e++) { hcO[e].x = 0; hcO[e].y = 0; ppO[e] = 0; }
 
     // bytes of the tile in wnext -> symbols (registers); the bytes of the tile at e_next are requested
     auto convert = [&](bool more, uint32_t e_next) {
@@ -412,82 +415,12 @@ __global__ void __launch_bounds__(ACX_PPM_BLOCK) k_ppm_stream4(const acx_ppm_arg
         }
 
         S4_PH(0);
-        // ---- 2. this trip hands over the last candidates of the current tile: the next tile's bytes -> symbols ------------------
-        const uint32_t ex_lo = (tile_ok && seg_lo) ? (uint32_t)__builtin_amdgcn_readlane((int)x_ex, (int)seg_lo) : 0u;
-        const bool will_adv = tile_ok && x_tot - ex_lo <= S4_QCAP;
-        const bool st = will_adv && tiles_left > 1u && e0 + S4_TPOS < H;
-        if (st) convert(tiles_left > 2u, e0 + 2u * S4_TPOS);
-
-#pragma unroll
-        for (int e = 0; e < S4_NE; e++) ppK[e] = ppO[e];
-        S4_PH(1);
-        // ---- 3. the next round of this tile: its candidates -> the queue, in position order; fetch -------------------------------
-        bool haveN = false;
-        if (tile_ok && x_tot != 0u) {
-            S4_MARK(M_PUSH);
-            uint32_t seg_hi = 64u, n = x_tot - ex_lo;
-            if (n > S4_QCAP) { seg_hi = seg_lo + 8u; n = (seg_hi < 64u ? (uint32_t)__builtin_amdgcn_readlane((int)x_ex, (int)seg_hi) : x_tot) - ex_lo; }   // (eight lanes: 256 positions)
-            {
-                uint32_t w = (lane >= seg_lo && lane < seg_hi) ? pw : 0u;
-                uint32_t ja = wbase + S4_QUEUE + 2u * (x_ex - ex_lo);
-                const uint32_t lp = 32u * lane + S4_HP + 1u;
-                while (w) {
-                    const uint32_t b = (uint32_t)__builtin_ctz(w);
-                    w &= w - 1u;
-                    lds_wr16(ja, lp + b);
-                    ja += 2u;
-                }
-            }
-            seg_lo = seg_hi;
-            wave_sync();
-            if (n && !(ACX_S4_EXP & 8)) {
-                S4_MARK(M_FETCH);
-                // where the entries sit, their windows, the requests for their hot cells.  Straight-line over the slots (lane l
-                // owns entries l, 64 + l, ..; slots are worked in pairs, a pair beyond the queue's end is skipped): their LDS
-                // reads and gathers overlap.  A slot beyond the queue's end asks the spare cell (all zero: nothing ends
-                // there, nothing goes deeper).
-                const uint32_t k = (n + 63u) >> 6;                   // (slots of set N: shadows the count of set O)
-                const uint32_t cx1 = r_tile - 32u;                  // entry + cx1 = 1 + (offset of the tile's first byte in its haystack + position)
-                const uint32_t sbase = wbase + cur * S4_SYMB;
-                uint32_t LL[S4_NE];
-#pragma unroll
-                for (int e = 0; e < S4_NE; e++) LL[e] = longest;           // (slots beyond the round's last keep what they held: nobody reads them)
-                if (use_other) {                                    // bytes of no key around (rare): the symbols that exist going back from every entry
-                    S4_SLOTS(e,
-                        const uint32_t qi = 64u * (uint32_t)e + lane;
-                        const uint32_t lo2 = other_limit(qi < n ? (uint32_t)queue[qi] - 1u : S4_HP);
-                        if (lo2 < LL[e]) LL[e] = lo2;
-                    )
-                }
-                S4_SLOTS(e,
-                    const uint32_t qi = 64u * (uint32_t)e + lane;
-                    const uint32_t ent = lds_rd16(qaddr + 128u * (uint32_t)e);      // position + 33
-                    // 1 + the offset in its haystack = x1 - stride * floor((x1 - 1) / stride), the quotient by a 24-bit multiply
-                    // (exact while x1 - 1 < stride + 2048)
-                    const uint32_t x1 = ent + cx1;
-                    const uint32_t q = ((uint32_t)__umul24(x1, m24) + nm24) >> 23;
-                    const uint32_t L0 = x1 - (uint32_t)__umul24(q, stride);
-                    const uint32_t L = L0 < LL[e] ? L0 : LL[e];
-                    // the 32 bits of symbols that end with the entry's position: words (ent >> 4) + 1 and + 2 of the symbol buffer
-                    const uint32_t wa = ((ent >> 2) & 0x7FCu) + sbase;
-                    const uint32_t X = __builtin_amdgcn_alignbit(lds_rd32(wa + 8u), lds_rd32(wa + 4u), ent << 1);
-                    const uint32_t off = (X >> (32u - 2u * S4_C - 3u)) & ((8u << (2u * S4_C)) - 8u);
-                    hcO[e] = *(const u32x2*)((const uint8_t*)a.hot4 + ((ACX_S4_EXP & 1) ? ((qi < n ? off : 0u) & 56u) : (qi < n ? off : (8u << (2u * S4_C)))));
-                    const uint32_t t5 = __builtin_amdgcn_ubfe(X, 32u - 2u * (S4_C + 2u), 4u) | 16u;     // 16 + the next two symbols: the cell's "go deeper" bit
-                    ppO[e] = ent | (L << 12) | (t5 << 18);
-                )
-                wave_sync();                                         // (the queue's memory is free from here on)
-                nN = n; cgN = e0 - 33u; symN = sbase; haveN = true;
-            }
-        }
-
-        S4_PH(2);
-        // ---- 4. set O: placement, records ------------------------------------------------------------------------------------
+        // ---- 2. set O: placement, records ------------------------------------------------------------------------------------
         if (haveO) {
             const uint32_t cg = cgO;
             uint32_t rr[S4_NE];
 #pragma unroll
-            for (int e = 0; e < S4_NE; e++) rr[e] = (ppK[e] & 0xFFFu) + cg;   // the global positions
+            for (int e = 0; e < S4_NE; e++) rr[e] = (ppO[e] & 0xFFFu) + cg;   // the global positions
             S4_MARK(M_PLACE);
             // place: entry e * 64 + lane; the records of a slot follow those of the slots below it (two slots per prefix
             // sum, 16 bits each: a slot has at most 64 x longest < 65536 records)
@@ -567,7 +500,7 @@ __global__ void __launch_bounds__(ACX_PPM_BLOCK) k_ppm_stream4(const acx_ppm_arg
                         uint32_t oe = 0;
                         E.p = 0; E.X = 0; E.L = 0; E.idx = 0;
 #pragma unroll
-                        for (int e = 0; e < S4_NE; e++) if (se == (uint32_t)e) { E.p = (ppK[e] & 0xFFFu) - (S4_HP + 1u); E.L = __builtin_amdgcn_ubfe(ppK[e], 12u, 6u); E.idx = rr[e]; oe = ex[e] + cn[e] - 1; }
+                        for (int e = 0; e < S4_NE; e++) if (se == (uint32_t)e) { E.p = (ppO[e] & 0xFFFu) - (S4_HP + 1u); E.L = __builtin_amdgcn_ubfe(ppO[e], 12u, 6u); E.idx = rr[e]; oe = ex[e] + cn[e] - 1; }
                         E.X = P.window(S4_HP + E.p);
                         const u32x4* cell = (const u32x4*)((const uint8_t*)a.cells + ((E.X >> (32u - 2u * S4_C)) << 5));
                         E.c0 = cell[0]; E.c1 = cell[1];
@@ -580,6 +513,73 @@ __global__ void __launch_bounds__(ACX_PPM_BLOCK) k_ppm_stream4(const acx_ppm_arg
             run_off += rt;
             wave_sync();
 
+        }
+
+        // ---- 3. this trip hands over the last candidates of the current tile: the next tile's bytes -> symbols ------------------
+        const uint32_t ex_lo = (tile_ok && seg_lo) ? (uint32_t)__builtin_amdgcn_readlane((int)x_ex, (int)seg_lo) : 0u;
+        const bool will_adv = tile_ok && x_tot - ex_lo <= S4_QCAP;
+        const bool st = will_adv && tiles_left > 1u && e0 + S4_TPOS < H;
+        if (st) convert(tiles_left > 2u, e0 + 2u * S4_TPOS);
+
+        S4_PH(1);
+        // ---- 4. the next round of this tile: its candidates -> the queue, in position order; fetch -------------------------------
+        bool haveN = false;
+        if (tile_ok && x_tot != 0u) {
+            S4_MARK(M_PUSH);
+            uint32_t seg_hi = 64u, n = x_tot - ex_lo;
+            if (n > S4_QCAP) { seg_hi = seg_lo + 8u; n = (seg_hi < 64u ? (uint32_t)__builtin_amdgcn_readlane((int)x_ex, (int)seg_hi) : x_tot) - ex_lo; }   // (eight lanes: 256 positions)
+            {
+                uint32_t w = (lane >= seg_lo && lane < seg_hi) ? pw : 0u;
+                uint32_t ja = wbase + S4_QUEUE + 2u * (x_ex - ex_lo);
+                const uint32_t lp = 32u * lane + S4_HP + 1u;
+                while (w) {
+                    const uint32_t b = (uint32_t)__builtin_ctz(w);
+                    w &= w - 1u;
+                    lds_wr16(ja, lp + b);
+                    ja += 2u;
+                }
+            }
+            seg_lo = seg_hi;
+            wave_sync();
+            if (n && !(ACX_S4_EXP & 8)) {
+                S4_MARK(M_FETCH);
+                // where the entries sit, their windows, the requests for their hot cells.  Straight-line over the slots (lane l
+                // owns entries l, 64 + l, ..; slots are worked in pairs, a pair beyond the queue's end is skipped): their LDS
+                // reads and gathers overlap.  A slot beyond the queue's end asks the spare cell (all zero: nothing ends
+                // there, nothing goes deeper).
+                const uint32_t k = (n + 63u) >> 6;                   // (slots of set N: shadows the count of set O)
+                const uint32_t cx1 = r_tile - 32u;                  // entry + cx1 = 1 + (offset of the tile's first byte in its haystack + position)
+                const uint32_t sbase = wbase + cur * S4_SYMB;
+                uint32_t LL[S4_NE];
+#pragma unroll
+                for (int e = 0; e < S4_NE; e++) LL[e] = longest;           // (slots beyond the round's last keep what they held: nobody reads them)
+                if (use_other) {                                    // bytes of no key around (rare): the symbols that exist going back from every entry
+                    S4_SLOTS(e,
+                        const uint32_t qi = 64u * (uint32_t)e + lane;
+                        const uint32_t lo2 = other_limit(qi < n ? (uint32_t)queue[qi] - 1u : S4_HP);
+                        if (lo2 < LL[e]) LL[e] = lo2;
+                    )
+                }
+                S4_SLOTS(e,
+                    const uint32_t qi = 64u * (uint32_t)e + lane;
+                    const uint32_t ent = lds_rd16(qaddr + 128u * (uint32_t)e);      // position + 33
+                    // 1 + the offset in its haystack = x1 - stride * floor((x1 - 1) / stride), the quotient by a 24-bit multiply
+                    // (exact while x1 - 1 < stride + 2048)
+                    const uint32_t x1 = ent + cx1;
+                    const uint32_t q = ((uint32_t)__umul24(x1, m24) + nm24) >> 23;
+                    const uint32_t L0 = x1 - (uint32_t)__umul24(q, stride);
+                    const uint32_t L = L0 < LL[e] ? L0 : LL[e];
+                    // the 32 bits of symbols that end with the entry's position: words (ent >> 4) + 1 and + 2 of the symbol buffer
+                    const uint32_t wa = ((ent >> 2) & 0x7FCu) + sbase;
+                    const uint32_t X = __builtin_amdgcn_alignbit(lds_rd32(wa + 8u), lds_rd32(wa + 4u), ent << 1);
+                    const uint32_t off = (X >> (32u - 2u * S4_C - 3u)) & ((8u << (2u * S4_C)) - 8u);
+                    hcO[e] = *(const u32x2*)((const uint8_t*)a.hot4 + ((ACX_S4_EXP & 1) ? ((qi < n ? off : 0u) & 56u) : (qi < n ? off : (8u << (2u * S4_C)))));
+                    const uint32_t t5 = __builtin_amdgcn_ubfe(X, 32u - 2u * (S4_C + 2u), 4u) | 16u;     // 16 + the next two symbols: the cell's "go deeper" bit
+                    ppO[e] = ent | (L << 12) | (t5 << 18);
+                )
+                wave_sync();                                         // (the queue's memory is free from here on)
+                nN = n; cgN = e0 - 33u; symN = sbase; haveN = true;
+            }
         }
 
         S4_PH(3);
