@@ -51,15 +51,20 @@ constexpr uint32_t S4_C = 9, S4_F = 10;                // symbols of a hot cell'
 constexpr uint32_t S4_HP = 32;                         // halo: staged positions in front of a tile (>= longest - 1)
 constexpr uint32_t S4_TPOS = 2048;                     // positions per tile: 32 per lane
 constexpr int      S4_NE = 6;                          // queue entries per lane and round
-constexpr uint32_t S4_QCAP = 352;                      // entries of a round (the queue's memory; the last slot is half used)
+constexpr uint32_t S4_QCAP = 64u * S4_NE;              // entries of a round
 constexpr uint32_t S4_G_BYTES = 4u << (2 * S4_F - 5);  // the filter bitmap: 4^F bits = 128 KiB, at LDS address 0
 constexpr uint32_t S4_WAVE_BYTES = 2048;               // LDS of one wave
 // byte offsets inside a wave's LDS.  Two symbol buffers: the round that is worked on may belong to the tile before the
 // one whose candidates are being fetched.  A buffer: words 0, 1: pad; 2, 3: halo (32 positions); 4 .. 131: the tile; 132: pad
-constexpr uint32_t S4_SYMB = 536;                      // bytes of one symbol buffer
-constexpr uint32_t S4_OBITS = 2 * S4_SYMB;             // word 0: halo, 1 .. 64: tile (one bit per staged position: a byte of no key), 65: spare
-constexpr uint32_t S4_QUEUE = S4_OBITS + 264;          // 352 uint16 entries; the hand-over of the deeper walks lives in the same memory
-static_assert(S4_QUEUE % 8 == 0 && S4_QUEUE + 2 * S4_QCAP <= S4_WAVE_BYTES && 648 <= 2 * S4_QCAP && S4_G_BYTES + 16 * S4_WAVE_BYTES <= ACX_PPM_LDS_BYTES, "LDS plan");
+constexpr uint32_t S4_SYMB = 528;                      // bytes from one symbol buffer to the next (word 0 of the second, never read, is word 132 of the first, read for nothing)
+constexpr uint32_t S4_QUEUE = 1064;                    // uint16 entries; the hand-over of the deeper walks lives in the same memory
+// one bit per staged position: a byte of no key (word 0: halo, 1 .. 64: tile).  At the END of the wave's LDS: a tile without
+// such bytes around (the usual one) does not look at them, and its queue may grow into them — 384 entries, a whole round;
+// with them the queue ends where they begin (362 entries: a tile that holds more takes two rounds)
+constexpr uint32_t S4_OBITS = S4_WAVE_BYTES - 260;
+constexpr uint32_t S4_QCAP_OTHER = (S4_OBITS - S4_QUEUE) / 2;
+static_assert(S4_QUEUE % 8 == 0 && S4_QUEUE >= S4_SYMB + 133 * 4 && S4_QUEUE + 2 * S4_QCAP <= S4_WAVE_BYTES && S4_QUEUE + 648 <= S4_OBITS &&
+              S4_QCAP_OTHER >= 256 && S4_G_BYTES + 16 * S4_WAVE_BYTES <= ACX_PPM_LDS_BYTES, "LDS plan");
 
 // LDS by byte address (the kernel's dynamic LDS starts at address 0: it has no static LDS).  A generic pointer built from
 // `smem` costs an add of the array's base — zero, but a link-time zero the compiler does not fold — per access: one
@@ -93,7 +98,7 @@ __global__ void __launch_bounds__(ACX_PPM_BLOCK) k_ppm_stream4(const acx_ppm_arg
     Ppm<2, true, false> P(a);                                          // windows and symbols for the walks below the cells and for the rare general enumeration
     P.s_g = smem; P.s_map = nullptr; P.s_sym = (uint32_t*)(lds + wbase) + 1;
     P.T.q0 = S4_HP; P.T.halo = 0; P.T.idx_first = 0; P.T.ndw = 0; P.T.abase = nullptr; P.T.e0 = 0; P.T.npos = 0; P.has_other = 0;
-    for (uint32_t i = lane; i < (S4_OBITS + 264) / 4; i += 64) ((uint32_t*)(lds + wbase))[i] = 0;
+    for (uint32_t i = lane; i < S4_WAVE_BYTES / 4; i += 64) ((uint32_t*)(lds + wbase))[i] = 0;
 
     // the batch: H bytes, cut into tiles; a wave takes a contiguous run of them (k_ppm_gather_pos counts on exactly this cut)
     const uint32_t stride = (uint32_t)a.stride, m24 = a.m24;
@@ -230,7 +235,10 @@ __global__ void __launch_bounds__(ACX_PPM_BLOCK) k_ppm_stream4(const acx_ppm_arg
         { u32x2 v; v.x = W1; v.y = W2; *(u32x2*)(sym_tile + 2u * lane) = v; }
         any_cur = __any(anyo != 0) ? 1u : 0u;
         use_other = any_cur | any_prev;
-        if (use_other) obits_tile[lane] = anyo;
+        if (use_other) {
+            obits_tile[lane] = anyo;
+            if (!any_prev && lane == 0) obits[0] = 0;                    // (the tile before left no such bits, and a queue may have been there)
+        }
         wave_sync();
         const uint32_t W0 = sym_tile[(int)(2u * lane) - 1];
         S4_MARK(M_FILTER);
@@ -517,7 +525,8 @@ __global__ void __launch_bounds__(ACX_PPM_BLOCK) k_ppm_stream4(const acx_ppm_arg
 
         // ---- 3. this trip hands over the last candidates of the current tile: the next tile's bytes -> symbols ------------------
         const uint32_t ex_lo = (tile_ok && seg_lo) ? (uint32_t)__builtin_amdgcn_readlane((int)x_ex, (int)seg_lo) : 0u;
-        const bool will_adv = tile_ok && x_tot - ex_lo <= S4_QCAP;
+        const uint32_t qcap = use_other ? S4_QCAP_OTHER : S4_QCAP;
+        const bool will_adv = tile_ok && x_tot - ex_lo <= qcap;
         const bool st = will_adv && tiles_left > 1u && e0 + S4_TPOS < H;
         if (st) convert(tiles_left > 2u, e0 + 2u * S4_TPOS);
 
@@ -527,7 +536,7 @@ __global__ void __launch_bounds__(ACX_PPM_BLOCK) k_ppm_stream4(const acx_ppm_arg
         if (tile_ok && x_tot != 0u) {
             S4_MARK(M_PUSH);
             uint32_t seg_hi = 64u, n = x_tot - ex_lo;
-            if (n > S4_QCAP) { seg_hi = seg_lo + 8u; n = (seg_hi < 64u ? (uint32_t)__builtin_amdgcn_readlane((int)x_ex, (int)seg_hi) : x_tot) - ex_lo; }   // (eight lanes: 256 positions)
+            if (n > qcap) { seg_hi = seg_lo + 8u; n = (seg_hi < 64u ? (uint32_t)__builtin_amdgcn_readlane((int)x_ex, (int)seg_hi) : x_tot) - ex_lo; }   // (eight lanes: 256 positions)
             {
                 uint32_t w = (lane >= seg_lo && lane < seg_hi) ? pw : 0u;
                 uint32_t ja = wbase + S4_QUEUE + 2u * (x_ex - ex_lo);
