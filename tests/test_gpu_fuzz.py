@@ -26,6 +26,18 @@ def test_fuzz_slice_fixed_seed():
     assert matches > 0
 
 
+def test_fuzz_stream4_slice_fixed_seed():
+    """tools/fuzz_stream4.py: the batches k_ppm_stream4 takes (four-letter alphabets, fixed strides, keys of up to 33 letters;
+    bytes of no key, nested keys, dense dictionaries, runs of tiles per wave, index_base) against the oracle and k_ppm_stream;
+    every case checks that the plan names k_ppm_stream4"""
+    import fuzz_stream4
+    rng = np.random.default_rng(424242)
+    matches = 0
+    for trial in range(24):                                          # ~ 20 s on an MI355X
+        matches += fuzz_stream4.one_case(rng, trial)
+    assert matches > 0
+
+
 def _check(A, O, flat, off, **kw):
     img = Image.from_automaton(A)
     sc = Scanner(img)
