@@ -194,6 +194,7 @@ typedef struct acx_blob_header {
  *       [1]  eowmask != 0: the value of its shallowest key; else the deep id of the depth-C node (0: none)
  *       cid[code_C] = the deep id of the depth-C node (0: absent or childless): read by the walks that go deeper from a
  *       cell whose second word holds a value.
+ *   gh (optional, g_global images): a hashed copy of G for LDS, see ACX_PPM_GH_* below.
  *   G2[code_F2] (global, L2 resident, at most 2^25 bits; optional): the same question as G asked with F2 > F symbols,
  *       put to the positions that passed G before they become candidates: set iff the depth-F2 node exists or a key
  *       shorter than F2 ends here.  For alphabets whose filter passes many positions that end no key (text: a 32-bit
@@ -211,6 +212,15 @@ typedef struct acx_blob_header {
  */
 #define ACX_PPM_MAGIC 0x344D5050u   /* "PPM4" */
 #define ACX_PPM_MAX_C 20
+/* gh: a filter that lives in global memory (g_global: 2^24 bits for three 8-bit symbols) costs one L2 request per position.
+ * gh is a hashed copy of it that LDS can hold: bit acx_ppm_gh_index(code_F) is set for every code whose bit of G is set, so a
+ * position whose bit of gh is clear is rejected without asking G (no false negatives); the others ask G as before.  Written
+ * only when it rejects enough (the builder measures: at most 3 of 4 random codes pass). */
+#define ACX_PPM_GH_BITS  (3u << 18)   /* 96 KiB: what the staging of 8-bit symbols leaves of a CU's LDS */
+#define ACX_PPM_GH_WORDS (ACX_PPM_GH_BITS / 32u)
+#define ACX_PPM_GH_MUL   0x9E3779B1u
+/* index of a code in gh: the high word of (code * MUL mod 2^32) * BITS */
+#define ACX_PPM_GH_INDEX(code) ((uint32_t)(((uint64_t)(uint32_t)((uint32_t)(code) * ACX_PPM_GH_MUL) * ACX_PPM_GH_BITS) >> 32))
 #define ACX_PPM_TILE  256           /* end positions per wave and tile */
 typedef struct acx_ppm_header {
     uint32_t magic;
@@ -238,7 +248,7 @@ typedef struct acx_ppm_header {
     uint64_t off_chains;     /* singles */
     uint64_t off_hot4;       /* uint32 [2 * K^C]: hot cells of k_ppm_stream4 (0: absent) */
     uint64_t off_cid;        /* uint32 [K^C]: deep id of every depth-C node (with off_hot4) */
-    uint8_t  reserved[256 - 160 - 4 * (ACX_PPM_MAX_C + 2)];
+    uint64_t off_gh;         /* uint32 [ACX_PPM_GH_WORDS]: hashed copy of a global filter for LDS (g_global images; 0: absent) */
 } acx_ppm_header;
 
 #endif

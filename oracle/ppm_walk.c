@@ -10,6 +10,7 @@
  * of the reversed trie; matches come out shortest first and are reversed.
  */
 #include <stdint.h>
+#include <stdlib.h>
 #include <string.h>
 #include "acx_blob.h"
 
@@ -40,7 +41,7 @@ int64_t ppm_iter_fill(const uint8_t* blob, const uint8_t* hay, int64_t len, int3
     int64_t last_other = -1;            /* last position holding a byte no key contains */
     static int32_t mv[PPM_MAX_MATCH];
     for (int64_t e = 0; e < len; e++) {
-        if (symtab[hay[e]] == 0xFFu) { last_other = e; continue; }
+        if (h.has_other && symtab[hay[e]] == 0xFFu) { last_other = e; continue; }   /* (all 256 bytes in keys: symbol 255 is a symbol, as in the kernels) */
         int64_t L = e - last_other;     /* symbols available going back from e */
         if (L > (int64_t)h.longest) L = h.longest;
         /* codes of the newest d symbols, zero beyond L */
@@ -166,6 +167,19 @@ int64_t ppm_check_hot(const uint8_t* blob) {
             if (!ok) bad++;
         }
     } else if (h.off_hot4 || h.off_cid) bad++;
+    /* gh: the hashed copy of a global filter (include/acx_blob.h ACX_PPM_GH_*) is exactly the image of G under the hash */
+    if (h.off_gh) {
+        if (!h.g_global) return -5;
+        const uint32_t* G = (const uint32_t*)(sec + h.off_g);
+        const uint32_t* gh = (const uint32_t*)(sec + h.off_gh);
+        uint32_t* want = (uint32_t*)calloc(ACX_PPM_GH_WORDS, 4);
+        if (!want) return -6;
+        for (uint32_t w = 0; w < h.g_words; w++)
+            for (uint32_t b = 0; b < 32; b++)
+                if ((G[w] >> b) & 1u) { const uint32_t ix = ACX_PPM_GH_INDEX(w * 32u + b); want[ix >> 5] |= 1u << (ix & 31); }
+        for (uint32_t w = 0; w < ACX_PPM_GH_WORDS; w++) if (want[w] != gh[w]) bad++;
+        free(want);
+    }
     /* the arithmetic symbol map, where the image has one */
     const uint8_t* symtab = sec + h.off_symtab;
     if (h.sym_arith) {

@@ -100,6 +100,7 @@ struct acx_image {
     const uint32_t* ppm_chains = nullptr;
     const uint32_t* ppm_hot4 = nullptr;        // hot cells and depth-C ids of k_ppm_stream4 (four-letter alphabets; nullptr: absent)
     const uint32_t* ppm_cid = nullptr;
+    const uint32_t* ppm_gh = nullptr;          // hashed copy of a global filter for LDS (nullptr: absent)
 };
 
 // The steady-state step of the itop walk uses 32-bit offsets: table and cells from the lower of
@@ -148,6 +149,7 @@ static int image_resolve(acx_image* img, const uint32_t* lvl_host) {
                  inside(ph.off_symtab, 256) && inside(ph.off_cells, nC * 32) && inside(ph.off_hot, nC * 8) &&
                  inside(ph.off_top_val, (uint64_t)ph.n_top * 4) && inside(ph.off_kids, ((uint64_t)ph.n_deep + 1) * ph.K * 16) &&
                  inside(ph.off_chains, ((uint64_t)ph.n_chain + 1) * 16) &&
+                 (ph.off_gh == 0 || (ph.g_global && inside(ph.off_gh, (uint64_t)ACX_PPM_GH_WORDS * 4))) &&
                  ((ph.off_hot4 == 0 && ph.off_cid == 0) || (ph.sym_bits == 2 && inside(ph.off_hot4, (nC + 1) * 8) && inside(ph.off_cid, (nC + 1) * 4)));
             uint64_t tbase = 0;
             for (uint32_t d = 0; ok && d <= ph.C; d++) { ok = ph.top_base[d] == tbase; tbase += pw(ph.K, d); }
@@ -165,6 +167,7 @@ static int image_resolve(acx_image* img, const uint32_t* lvl_host) {
         img->ppm_chains = (const uint32_t*)(sec + ph.off_chains);
         img->ppm_hot4 = ph.off_hot4 ? (const uint32_t*)(sec + ph.off_hot4) : nullptr;
         img->ppm_cid = ph.off_cid ? (const uint32_t*)(sec + ph.off_cid) : nullptr;
+        img->ppm_gh = ph.off_gh ? (const uint32_t*)(sec + ph.off_gh) : nullptr;
         if (!ph.g_global && acx_ppm_lds_layout(ph.g_words, ph.sym_bits, ph.longest).total_words * 4 > ACX_PPM_LDS_BYTES) img->ppm_g = nullptr;
     }
     img->out_off = (const uint32_t*)(img->dev + img->h.off_out_off);
@@ -694,8 +697,8 @@ static uint32_t ppm_halo_pos(const acx_ppm_header& ph) {         // whole words 
 }
 // sub-steps of 256 positions per tile: the most that fit LDS for this image (0: none).  Larger tiles fill the rounds
 // better (a tile's candidates are worked off before the next one is staged).
-static uint32_t ppm_stream_nsub(const acx_ppm_header& ph, uint32_t halo_pos, bool offs) {
-    const uint32_t gw = ph.g_global ? 0u : ph.g_words;
+static uint32_t ppm_stream_nsub(const acx_ppm_header& ph, uint32_t halo_pos, bool offs, bool with_gh = false) {
+    const uint32_t gw = ph.g_global ? (with_gh ? ACX_PPM_GH_WORDS : 0u) : ph.g_words;
     static const uint32_t forced = [] { const char* v = acx_tune_env("ACX_PPM_NSUB"); const int x = v ? atoi(v) : 0; return (x == 4 || x == 8) ? (uint32_t)x : 0u; }();   // tuning hook
     // (8-bit symbols with the filter in LDS and no second-level filter: 2048-position tiles measured slower than 1024,
     //  203 vs 218 GB/s — too many candidates per tile for the queue; with the second level: 353 vs 340)
@@ -825,7 +828,9 @@ static int scan_ppm(acx_image_t* img, const acx_scan_params* p, acx_result* r, h
     if (pa.fast) {
         pa.nsub = ppm_stream_nsub(ph, pa.halo_pos, chunked);
         pa.g_global = ph.g_global;
-        pa.lds = acx_ppm_stream_layout(ph.g_global ? 0u : ph.g_words, ph.sym_bits, pa.halo_pos, pa.nsub, chunked);
+        // a hashed copy of a global filter goes into LDS when it fits beside the staging at the same tile size (variant bit 18: without, A/B)
+        pa.gh = (ph.g_global && img->ppm_gh && !((p->variant >> 18) & 1) && ppm_stream_nsub(ph, pa.halo_pos, chunked, true) == pa.nsub) ? img->ppm_gh : nullptr;
+        pa.lds = acx_ppm_stream_layout(ph.g_global ? (pa.gh ? ACX_PPM_GH_WORDS : 0u) : ph.g_words, ph.sym_bits, pa.halo_pos, pa.nsub, chunked);
     }
     if (pa.fast) {
         const int64_t tpos = (int64_t)pa.nsub * 256;

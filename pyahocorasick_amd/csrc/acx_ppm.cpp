@@ -444,6 +444,7 @@ int acx_ppm_build(const acx_trie* t, const uint8_t* cls, uint32_t n_classes, boo
             h.off_hot4 = off; off = align256(off + ((size_t)nC + 1) * 8);
             h.off_cid = off;  off = align256(off + ((size_t)nC + 1) * 4);
         }
+        if (h.g_global) { h.off_gh = off; off = align256(off + (size_t)ACX_PPM_GH_WORDS * 4); }       // (dropped again below when it rejects too little)
         h.off_top_val = off;  off = align256(off + (size_t)h.n_top * 4);
         h.off_kids = off;     off = align256(off + (size_t)row_bytes);
         h.off_chains = off;   off = align256(off + ((size_t)n_single + 1) * 16);
@@ -566,6 +567,28 @@ int acx_ppm_build(const acx_trie* t, const uint8_t* cls, uint32_t n_classes, boo
             else if (cell[0]) for (uint32_t s = 0; s < sigma; s++) { const uint64_t x = cc * sigma + s; G[x >> 5] |= 1u << (x & 31); }
         }
         lap("cells + filter");
+        if (h.off_gh) {                                                 // include/acx_blob.h "gh": the hashed copy of a global filter
+            uint32_t* gh = (uint32_t*)(sec + h.off_gh);
+            uint64_t n_set = 0;
+            for (uint32_t w = 0; w < h.g_words; w++) {
+                uint32_t m = G[w];
+                while (m) {
+                    const uint32_t code = w * 32u + (uint32_t)__builtin_ctz(m);
+                    m &= m - 1;
+                    const uint32_t ix = ACX_PPM_GH_INDEX(code);
+                    gh[ix >> 5] |= 1u << (ix & 31);
+                    n_set++;
+                }
+            }
+            uint64_t occ = 0;
+            for (uint32_t w = 0; w < ACX_PPM_GH_WORDS; w++) occ += (uint64_t)__builtin_popcount(gh[w]);
+            if (occ * 4 > (uint64_t)ACX_PPM_GH_BITS * 3) {              // more than 3 of 4 random codes would pass: not worth a probe
+                memset(gh, 0, (size_t)ACX_PPM_GH_WORDS * 4);
+                h.off_gh = 0;                                            // (the section stays in the blob, unused: offsets behind it are set)
+            }
+            (void)n_set;
+            lap("hashed filter for LDS");
+        }
         memcpy(sec, &h, sizeof h);
         *out = sec; *nbytes = off;
         return ACX_OK;

@@ -316,6 +316,7 @@ __global__ void __launch_bounds__(ACX_PPM_BLOCK) k_ppm_stream(const acx_ppm_args
     extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
     static_assert(!ARITH || (SB == 2 && POW2), "arithmetic symbols: four letters");
     if (!GG) for (uint32_t i = threadIdx.x; i < a.g_words; i += blockDim.x) smem[a.lds.g_off + i] = a.g[i];
+    if (GG && a.gh) for (uint32_t i = threadIdx.x; i < ACX_PPM_GH_WORDS; i += blockDim.x) smem[a.lds.g_off + i] = a.gh[i];    // the hashed copy of the global filter
     if (threadIdx.x < 256) {
         // a byte of no key: 0xFF with 8-bit symbols (staged as symbol 0 by convert), 0x80 with narrower ones — its
         // symbol bits are 0 then, which keeps every staged field below K (the filter reads windows unmasked)
@@ -610,6 +611,31 @@ __global__ void __launch_bounds__(ACX_PPM_BLOCK) k_ppm_stream(const acx_ppm_args
             for (int k = 0; k < (int)OW; k++) U[k] = __builtin_amdgcn_alignbit(W[k + 1], W[k], ush);
             U[OW] = W[OW] >> ush; U[OW + 1] = 0; U[OW + 2] = 0;
             uint32_t acc = 0;
+            if (GG && a.gh) {
+                // The filter lives in global memory: one L2 request per position, and the L2s take about 260 G of them a second
+                // over the chip — what bounds a scan of a million signatures (profiles/r3_c4_*).  gh (include/acx_blob.h) is a
+                // hashed copy of it in LDS with no false negatives: a position it rejects asks G for a word that every
+                // rejected lane of the instruction asks for (one request), the others ask for their own as before.
+                const uint32_t cmask = FB >= 32u ? 0xFFFFFFFFu : (1u << FB) - 1u;
+#pragma unroll
+                for (int i0 = 0; i0 < (int)PPL; i0 += 16) {
+                    uint32_t gw[16], bs[16], hb[16];
+#pragma unroll
+                    for (int i = 0; i < 16; i++) {
+                        const uint32_t b = SB * (uint32_t)(i0 + i + 1), k = b >> 5, sh = b & 31u;
+                        bs[i] = sh ? __builtin_amdgcn_alignbit(U[k + 1], U[k], sh) : U[k];
+                        const uint32_t ix = __umulhi((bs[i] & cmask) * ACX_PPM_GH_MUL, ACX_PPM_GH_BITS);
+                        hb[i] = (smem[a.lds.g_off + (ix >> 5)] >> (ix & 31u)) & 1u;
+                    }
+#pragma unroll
+                    for (int i = 0; i < 16; i++) {
+                        const uint32_t A = hb[i] ? (bs[i] >> 3) & amask : 0u;
+                        gw[i] = *(const uint32_t*)((const uint8_t*)a.g + A);
+                    }
+#pragma unroll
+                    for (int i = 0; i < 16; i++) acc = __builtin_amdgcn_alignbit((gw[i] >> (bs[i] & 31u)) & hb[i], acc, 1u);
+                }
+            } else {
 #pragma unroll
             for (int i0 = 0; i0 < (int)PPL; i0 += 16) {                // (16 probes in flight at a time: registers)
                 uint32_t gw[16], bs[16];
@@ -622,6 +648,7 @@ __global__ void __launch_bounds__(ACX_PPM_BLOCK) k_ppm_stream(const acx_ppm_args
                 }
 #pragma unroll
                 for (int i = 0; i < 16; i++) acc = __builtin_amdgcn_alignbit(gw[i] >> (bs[i] & 31u), acc, 1u);
+            }
             }
             pw = PPL == 32 ? acc : acc >> (32 - PPL);
         } else {

@@ -85,6 +85,25 @@ def test_ppm_walk_dna_dictionary_deep_rows():
         assert orc.ppm_iter(blob, hay) == O.iter(hay)
 
 
+def test_hashed_copy_of_a_global_filter():
+    """all 256 byte values in keys of three bytes and more: the filter (three 8-bit symbols, 2 MiB) lives in global memory and
+    the image carries a hashed copy of it for LDS (include/acx_blob.h "gh") — ppm_check_hot pins it as exactly the image of
+    the bitmap under the hash (no false negatives); a dictionary that fills it (the copy would reject nothing) gets none"""
+    rng = random.Random(77)
+    for shortest, want_gh in ((3, True), (1, False)):            # (one-byte keys: every position ends a key, the bitmap is full)
+        keys = list({bytes(rng.randrange(256) for _ in range(rng.randint(shortest, 9))) for _ in range(4000)})
+        A, O = build_pair(keys, list(range(len(keys))))
+        blob = A.flat_image_bytes()
+        off_ppm = struct.unpack_from("<Q", blob, 248)[0]
+        magic, K, sb, pow2, C, F, g_global = struct.unpack_from("<7I", blob, off_ppm)
+        assert (K, sb, C, F, g_global) == (256, 8, 2, 3, 1)
+        assert (struct.unpack_from("<Q", blob, off_ppm + 256 - 8)[0] != 0) == want_gh
+        assert orc.ppm_check_hot(blob) == 0
+        for _ in range(5):
+            hay = bytes(rng.randrange(256) for _ in range(400))
+            assert orc.ppm_iter(blob, hay) == O.iter(hay)
+
+
 def test_ppm_absent_when_not_asked_for():
     import pyahocorasick_amd as acx
     A, O = build_pair([b"he", b"she"])
