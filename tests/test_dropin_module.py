@@ -261,3 +261,40 @@ def test_dropin_scans_release_the_gil_and_threads_share_an_automaton(ahocorasick
     assert first == want[0]
     A.make_automaton()
     assert len(list(A.iter(hay))) > len(want)
+
+
+@pytest.mark.gpu
+def test_dropin_iterator_refuses_a_second_thread_while_its_scan_runs(ahocorasick):
+    """the scan behind next() runs without the GIL and holds pointers into the iterator's source: a second thread that calls
+    next() on the SAME iterator meanwhile gets ValueError("iterator already executing"), as a generator would give (the
+    reference holds the GIL throughout, src/AutomatonSearchIter.c:243-300)"""
+    import threading
+    m = ahocorasick
+    A = m.Automaton(m.STORE_INTS)
+    for i, w in enumerate([b"he", b"her", b"hers", b"she"]):
+        A.add_word(w, i)
+    A.make_automaton()
+    hay = b"_sherhershe_" * 4_000_000                       # 48 MB: the first next() uploads and scans for tens of milliseconds
+    want = list(A.iter(b"_sherhershe_"))
+    refused = 0
+    for attempt in range(5):
+        it = A.iter(hay)
+        start = threading.Barrier(2)
+        got, errs = [], []
+
+        def one():
+            start.wait()
+            try:
+                got.append(next(it))
+            except ValueError as ex:
+                errs.append(str(ex))
+
+        ts = [threading.Thread(target=one) for _ in range(2)]
+        [t.start() for t in ts]
+        [t.join() for t in ts]
+        assert all("already executing" in e for e in errs), errs
+        assert sorted(got) == sorted(want[:len(got)]) and len(got) + len(errs) == 2      # whoever got through got the stream's next items
+        refused += len(errs)
+        if refused:
+            break
+    assert refused >= 1
