@@ -365,22 +365,27 @@ def measure(torch, dist, dev, image, batches, mode, steps, warmup, P, event_ever
         if timed.pop(id(x), False):
             walk_ms.append(x.timing_ms()["walk"])
 
+    marks = []                                             # host clock after every collected step: a stall shows as ONE long interval
     barrier()
     t0 = time.perf_counter()
     for k in range(steps):
         if k >= P:
             collect(scs[k % P])
+            marks.append(time.perf_counter())
         ev = event_every > 0 and k % event_every == 0
         timed[id(scs[k % P])] = ev
         owner[id(scs[k % P])] = k
         step(k, timing=2 if ev else False)
     for k in range(max(0, steps - P), steps):
         collect(scs[k % P])                                # every step complete: totals read and checked, records in HBM
+        marks.append(time.perf_counter())
     torch.cuda.synchronize()
     dt_rank = time.perf_counter() - t0
     barrier()
     dt = time.perf_counter() - t0
-    return {"dt": dt, "dt_rank": dt_rank, "walk_ms": walk_ms, "pre": pre, "matches_per_batch": matches_per_batch, "sync_ms": sync_ms,
+    gaps = np.diff(np.array([t0] + marks)) * 1e3
+    step_ms = {"median": round(float(np.median(gaps)), 4), "max": round(float(gaps.max()), 4), "argmax": int(gaps.argmax())}
+    return {"dt": dt, "dt_rank": dt_rank, "walk_ms": walk_ms, "pre": pre, "step_ms": step_ms, "matches_per_batch": matches_per_batch, "sync_ms": sync_ms,
             "bytes_rank": sum(batches[k % B][1] for k in range(steps)), "matches_rank": sum(matches_per_batch[k % B] for k in range(steps)),
             "scanner": scs[0], "stream": stream}
 
@@ -469,7 +474,7 @@ def other_config(torch, dev, acx, name, workload, mode_name, keys, vocab, image,
     m = measure(torch, None, dev, image, batches, mode, steps, 2, max(1, args.pipeline), args.event_every, 0)
     out = {
         "value": m["bytes_rank"] / m["dt"] / 1e9, "unit": "GB/s", "ms_per_step": m["dt"] / steps * 1e3, "steps": steps,
-        "ms_per_step_synchronous": m["sync_ms"],
+        "ms_per_step_synchronous": m["sync_ms"], "step_ms_host_intervals": m["step_ms"],
         "matches_per_step": m["matches_rank"] / steps,
         "workload": (WORKLOAD_NAMES[workload] % ((n_keys, args.reads, args.read_len) if workload == "c2" else (n_keys, batch_mb)))
                     + ", Automaton.%s; %d distinct batches rotated (%.0f MB resident)" % (mode_name, len(batches), sum(b[1] for b in batches) / 1e6),
@@ -596,7 +601,7 @@ def main():
             "matches_per_step": matches_all / args.steps / world,
             "bytes_total": bytes_all, "bytes_per_step_all_ranks": bytes_all / args.steps,
             "corpus_bytes_per_batch": int(np.mean(corpus_bytes)),
-            "ms_per_step_synchronous": m["sync_ms"],
+            "ms_per_step_synchronous": m["sync_ms"], "step_ms_host_intervals": m["step_ms"],
             "per_rank_GBps": {"min": min(per_rank), "max": max(per_rank)},
             "config": {"workload": wname + ", Automaton.%s; %d distinct batches rotated (%.0f MB resident per GPU)"
                                    % (args.mode, B, sum(b[1] for b in batches) / 1e6),
