@@ -407,7 +407,7 @@ struct acx_result {
     bool ctl_zero = false;      // ppm_ctl is known to be all zero (the gather of the last fixed-stride stream scan cleaned up)
     // acx_scan_host, pipelined (scan_host_pipelined): the gather of a fixed-stride stream scan writes records and offsets
     // straight into the result's pinned host buffers (device-mapped pointers) instead of r->matches / r->match_off
-    uint2* ext_matches = nullptr; int64_t ext_capacity = 0; int64_t* ext_match_off = nullptr;
+    uint2* ext_matches = nullptr; int64_t ext_capacity = 0; int64_t* ext_match_off = nullptr; int64_t ext_off_base = 0;
     hipStream_t copy_stream = nullptr;
     bool ppm_self = false;      // the pending stream scan is a fixed-stride one: block sums, totals and clean-up in k_ppm_gather_pos
     int bs_parity = 0;          // which half of wave_aux the next such scan sums into
@@ -874,7 +874,8 @@ static int scan_ppm(acx_image_t* img, const acx_scan_params* p, acx_result* r, h
         ga.wave_desc = r->wave_desc.p; ga.wave_off = r->ck_match_off.p; ga.n_waves = n_waves;
         ga.matches = r->matches.p; ga.capacity = (int64_t)r->matches.cap;
         ga.hay_local = r->hay_local.p; ga.match_off = r->match_off.p;
-        if (!chunked && r->ext_matches) { ga.matches = r->ext_matches; ga.capacity = r->ext_capacity; ga.match_off = r->ext_match_off; } ga.n_hay = p->n_hay; ga.stride = p->stride;
+        if (!chunked && r->ext_matches) { ga.matches = r->ext_matches; ga.capacity = r->ext_capacity; ga.match_off = r->ext_match_off; ga.off_base = r->ext_off_base; }
+        ga.n_hay = p->n_hay; ga.stride = p->stride;
         ga.off = chunked ? p->dev_off : nullptr;
         ga.tile_pos = tpos; ga.tpw = (stream_tiles + n_waves - 1) / n_waves;
         ga.stride_magic = pa.stride_magic; ga.index_base = chunked ? nullptr : p->dev_index_base; ga.skip = chunked ? nullptr : p->dev_skip;
@@ -1173,12 +1174,27 @@ extern "C" int acx_result_timing(acx_result_t* r, float* walk_ms, float* scan_ms
 // each way), a kernel that writes pinned host memory beside an upload does not (43 GB/s each way;
 // profiles/r3_pcie_probe.txt).  Returns ACX_HOST_RETRY when it does not apply (not the stream kernel's batch, or the
 // records outgrew the host buffer: the staged path grows it); the result is then untouched as far as callers see.
+#ifdef ACX_HOST_TRACE             // development builds: where a host-to-host call spends its time (stderr)
+#include <chrono>
+static double host_now_ms() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+static double g_host_t0 = 0;
+#define HOST_MARK(...) do { fprintf(stderr, "[host %8.3f] ", host_now_ms() - g_host_t0); fprintf(stderr, __VA_ARGS__); fputc('\n', stderr); } while (0)
+#else
+#define HOST_MARK(...) do { } while (0)
+#endif
+
+// `verify`: the caller's offsets when they have only been SAMPLED so far (scan_host_impl): every one of them is compared
+// with h * L while the first group travels, and a batch that turns out not to be equally spaced goes back untouched.
 static int scan_host_pipelined(acx_image_t* img, const uint8_t* hay, int64_t n_hay, int64_t L, const int32_t* index_base,
-                               acx_result* r, int32_t flags) {
+                               acx_result* r, int32_t flags, const int64_t* verify) {
     const int64_t total_bytes = n_hay * L;
     if (flags || total_bytes < ((int64_t)16 << 20) || n_hay < 4096) return ACX_HOST_RETRY;
-    int G = (int)(total_bytes >> 25);                                  // groups of about 32 MB
-    G = G < 2 ? 2 : (G > 8 ? 8 : G);
+    // Groups: the uploads are the bottleneck (they run back to back on the copy engine), every scan + gather hides behind the
+    // next group's upload, and what does not hide is the LAST group's scan + gather: many small groups make that tail short,
+    // few large ones keep the number of waits down.  About 16 MB each, 2 .. 12.
+    int G = (int)(total_bytes >> 24);
+    G = G < 2 ? 2 : (G > 12 ? 12 : G);
+    if (const char* e = acx_tune_env("ACX_HOST_GROUPS")) { const int v = atoi(e); if (v >= 1 && v <= 64) G = v; }   // tuning hook
     int rc;
     if ((rc = r->in_hay.ensure((size_t)total_bytes + 64))) return rc;
     {
@@ -1198,26 +1214,36 @@ static int scan_host_pipelined(acx_image_t* img, const uint8_t* hay, int64_t n_h
         HIP_TRY(hipMemcpy(r->in_base.p, index_base, (size_t)n_hay * 4, hipMemcpyHostToDevice));
     }
     if (!r->copy_stream) HIP_TRY(hipStreamCreateWithFlags(&r->copy_stream, hipStreamNonBlocking));
+    HOST_MARK("pipelined: %d groups, buffers ready", G);
     void* d_m = nullptr; void* d_o = nullptr;
     HIP_TRY(hipHostGetDevicePointer(&d_m, r->h_matches.p, 0));
     HIP_TRY(hipHostGetDevicePointer(&d_o, r->h_off.p, 0));
     auto first = [&](int g) { return g >= G ? n_hay : (n_hay * g / G) & ~(int64_t)15; };   // (a group starts 16-byte aligned: 16 haystacks of any length)
     // The uploads run on a thread of their own: the caller's buffer is pageable, and a copy from pageable memory keeps
     // the calling thread until it is done — queued from this thread they would all be over before the first scan starts.
-    std::atomic<int> uploaded{0}, up_err{0};
+    std::atomic<int> uploaded{0}, up_err{0}, up_stop{0};
     int dev_id = 0;
     HIP_TRY(hipGetDevice(&dev_id));
     std::thread uploader([&] {
         if (hipSetDevice(dev_id) != hipSuccess) { up_err.store(1); return; }
-        for (int g = 0; g < G; g++) {
+        for (int g = 0; g < G && !up_stop.load(std::memory_order_relaxed); g++) {
             const int64_t h0 = first(g), h1 = first(g + 1);
             hipError_t e = hipMemcpyAsync(r->in_hay.p + h0 * L, hay + h0 * L, (size_t)((h1 - h0) * L), hipMemcpyHostToDevice, r->copy_stream);
             if (e == hipSuccess) e = hipStreamSynchronize(r->copy_stream);
             if (e != hipSuccess) { up_err.store(1); return; }
+            HOST_MARK("  upload %d done", g);
             uploaded.store(g + 1, std::memory_order_release);
         }
     });
     struct Joiner { std::thread& t; ~Joiner() { if (t.joinable()) t.join(); } } joiner{uploader};
+    if (verify) {
+        // (one pass the compiler can vectorise, hidden behind the first upload; a million offsets took 1.2 ms of every call
+        //  when two scalar passes looked at them before anything was sent)
+        uint64_t bad = 0;
+        for (int64_t h = 0; h < n_hay; h++) bad |= (uint64_t)((verify[h + 1] - verify[h]) ^ L);
+        HOST_MARK("  offsets verified (%s)", bad ? "NOT equally spaced" : "equally spaced");
+        if (bad) { up_stop.store(1); uploader.join(); return ACX_HOST_RETRY; }
+    }
     int64_t done = 0;
     int out = ACX_OK;
     for (int g = 0; g < G && out == ACX_OK; g++) {
@@ -1230,14 +1256,17 @@ static int scan_host_pipelined(acx_image_t* img, const uint8_t* hay, int64_t n_h
         q.dev_hay = r->in_hay.p + h0 * L; q.hay_capacity = (h1 - h0) * L; q.stride = L; q.n_hay = h1 - h0;
         q.dev_index_base = index_base ? r->in_base.p + h0 : nullptr;
         r->ext_matches = (uint2*)d_m + done; r->ext_capacity = (int64_t)r->h_matches.cap - done; r->ext_match_off = (int64_t*)d_o + h0;
+        r->ext_off_base = done;                                        // (the gather writes offsets that count from the batch's first record)
         acx_result* self = r;
+        HOST_MARK("  scan %d issued", g);
         out = scan_batch_inner(img, &q, &self, nullptr);              // (synchronous: the gather has written when it returns)
+        HOST_MARK("  scan %d complete (%lld records)", g, (long long)r->total);
         if (out == ACX_OK && !(r->ppm_stream && r->ppm_self)) out = ACX_HOST_RETRY;      // (not the kernels this path is for)
         if (out != ACX_OK) break;
-        if (done) for (int64_t h = h0; h < h1; h++) r->h_off.p[h] += done;               // the group's offsets count from its first record
         done += r->total;
     }
-    r->ext_matches = nullptr; r->ext_capacity = 0; r->ext_match_off = nullptr;
+    r->ext_matches = nullptr; r->ext_capacity = 0; r->ext_match_off = nullptr; r->ext_off_base = 0;
+    if (out != ACX_OK) up_stop.store(1);
     uploader.join();                                                   // (the uploads read the caller's buffer)
     if (out != ACX_OK) {
         if (out == ACX_HOST_RETRY) (void)r->h_matches.ensure(r->h_matches.cap * 2);     // the staged path would need it as well
@@ -1245,6 +1274,7 @@ static int scan_host_pipelined(acx_image_t* img, const uint8_t* hay, int64_t n_h
     }
     r->h_off.p[n_hay] = done;
     r->n_hay = n_hay; r->total = done; r->has_final = false; r->host_valid = true;
+    HOST_MARK("pipelined: done");
     return ACX_OK;
 }
 
@@ -1265,8 +1295,9 @@ static int scan_host_once(acx_image_t* img, int mode, const uint8_t* hay, const 
         uniform = uniform && l == L0;
     }
     const bool as_stride = uniform && L0 > 0 && L0 <= INT32_MAX;
+    HOST_MARK("offsets looked at twice");
     if (as_stride && mode == ACX_SCAN_ALL && !init_state && !want_final) {
-        rc = scan_host_pipelined(img, hay, n_hay, L0, index_base, r, flags);
+        rc = scan_host_pipelined(img, hay, n_hay, L0, index_base, r, flags, nullptr);
         if (rc != ACX_HOST_RETRY) return rc;
     }
     if ((rc = r->in_hay.ensure((size_t)total_bytes + 64))) return rc;
@@ -1376,6 +1407,27 @@ static int scan_host_impl(acx_image_t* img, int mode, const uint8_t* hay, const 
                           const int32_t* init_state, const int32_t* index_base, acx_result_t** result, int want_final, int32_t flags) {
     if (!img || !off || !result || n_hay < 0) return acx_fail(ACX_E_INVAL, "acx_scan_host: bad argument");
     if (off[0] != 0) return acx_fail(ACX_E_INVAL, "acx_scan_host: off[0] must be 0");
+#ifdef ACX_HOST_TRACE
+    g_host_t0 = host_now_ms();
+#endif
+    HOST_MARK("scan_host_impl: %lld haystacks", (long long)n_hay);
+    // A large batch whose offsets LOOK equally spaced (both ends and a few in between) goes to the pipeline of groups at
+    // once: it compares every offset while the first group is on its way, and hands the batch back if one differs.
+    if (mode == ACX_SCAN_ALL && !init_state && !want_final && !flags && n_hay >= 4096 && hay) {
+        const int64_t L0 = off[1] - off[0];
+        bool looks = L0 > 0 && L0 <= INT32_MAX && off[n_hay] == n_hay * L0 && off[n_hay] <= max_launch_bytes();
+        for (int64_t k = 1; k < 16 && looks; k++) { const int64_t h = n_hay / 16 * k; looks = off[h] == h * L0; }
+        if (looks) {
+            acx_result* r0 = *result;
+            if (!r0) {
+                r0 = new (std::nothrow) acx_result();
+                if (!r0) return acx_fail(ACX_E_NOMEM, "acx_scan_host: out of memory");
+                *result = r0;
+            }
+            const int rc0 = scan_host_pipelined(img, hay, n_hay, L0, index_base, r0, flags, off);
+            if (rc0 != ACX_HOST_RETRY) return rc0;
+        }
+    }
     {   // (one branch-free pass: a batch of a million reads spends as long here as in its scan kernel otherwise)
         int64_t lo = 0, hi = 0;
         for (int64_t h = 0; h < n_hay; h++) { const int64_t l = off[h + 1] - off[h]; lo = l < lo ? l : lo; hi = l > hi ? l : hi; }

@@ -169,6 +169,7 @@ struct acx_ppm_gather_args {       // k_ppm_stream results -> final place
     uint64_t stride_magic;         // fixed stride: ceil(2^64 / stride) (0 for stride 1)
     const int32_t* index_base;     // fixed stride: added to every index of haystack h (nullable)
     const int32_t* skip;           // fixed stride: context bytes of haystack h, taken off every index (nullable)
+    int64_t off_base;              // k_ppm_gather_pos: added to every offset written (the records of the groups in front: acx_scan_host's pipeline)
 };
 #define ACX_PPM_DESC_WORDS 40
 hipError_t acx_launch_ppm_first_h(const int64_t* off, int64_t n_hay, int64_t n_tiles, int64_t tile_pos, int64_t* first_h, hipStream_t s);

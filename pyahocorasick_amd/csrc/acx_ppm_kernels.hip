@@ -1200,7 +1200,7 @@ __global__ void __launch_bounds__(PPM_GPOS_THREADS) k_ppm_gather_pos(const acx_p
             auto emit = [&](uint32_t k, u32x2 rec, uint32_t q_prev) -> u32x2 {      // record k of the grant; q_prev: haystack of the record before it
                 uint32_t idx;
                 const uint32_t q = locate(rec.x, idx);
-                for (uint32_t qq = q_prev + 1; (int32_t)(qq - q) <= 0; qq++) c.match_off[h0 + (int64_t)(int32_t)qq] = base + li + k;   // haystacks that start between the two records
+                for (uint32_t qq = q_prev + 1; (int32_t)(qq - q) <= 0; qq++) c.match_off[h0 + (int64_t)(int32_t)qq] = c.off_base + base + li + k;   // haystacks that start between the two records
                 u32x2 o; o.y = rec.y;
                 o.x = idx + (c.index_base ? (uint32_t)c.index_base[h0 + (int64_t)(int32_t)q] : 0u) - (c.skip ? (uint32_t)c.skip[h0 + (int64_t)(int32_t)q] : 0u);
                 return o;
@@ -1229,9 +1229,9 @@ __global__ void __launch_bounds__(PPM_GPOS_THREADS) k_ppm_gather_pos(const acx_p
         (void)lane;
         // haystacks behind the last record (all of them, when the wave has none or nothing fits)
         const int64_t h_last = fits ? h0 + (int64_t)(int32_t)q_last : hA - 1;
-        for (int64_t hh = h_last + 1 + threadIdx.x; hh < hB; hh += GT) c.match_off[hh] = base + (fits ? count : 0u);
+        for (int64_t hh = h_last + 1 + threadIdx.x; hh < hB; hh += GT) c.match_off[hh] = c.off_base + base + (fits ? count : 0u);
     }
-    if (blockIdx.x == 0 && threadIdx.x == 0) c.match_off[c.n_hay] = total;
+    if (blockIdx.x == 0 && threadIdx.x == 0) c.match_off[c.n_hay] = c.off_base + total;
 }
 
 // records of every tile -> their final place; STRIDE scans: match_off[] from the tile offsets

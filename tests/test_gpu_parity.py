@@ -888,3 +888,30 @@ def test_host_to_host_pipeline_of_groups_equals_the_oracle():
     res = A2.scan_batch(flat, off)
     mo, oe, ov = O2.batch(flat.tobytes(), off, 0)
     assert np.array_equal(res.offsets, mo) and np.array_equal(res.end_index, oe) and np.array_equal(res.value, ov)
+
+
+def test_host_batch_that_only_looks_equally_spaced_takes_the_general_path():
+    """acx_scan_host_ctx starts its pipeline of groups on offsets it has SAMPLED (both ends and 15 in between) and compares
+    all of them while the first group is uploaded.  Batches whose sampled offsets are those of equally long haystacks while
+    some haystacks in between are a byte longer and their neighbours a byte shorter must come back exactly as from the
+    general path: every offset and record against the oracle, and again after a truly uniform batch went through the same
+    result object's buffers."""
+    rng = np.random.default_rng(1234)
+    alpha = np.frombuffer(b"ACGT", dtype=np.uint8)
+    keys = list({bytes(alpha[rng.integers(0, 4, size=int(k))]) for k in rng.integers(6, 14, size=3000)})
+    A, O = build_pair(keys)
+    n, L = 160_000, 120                                               # 19.2 MB: above the pipeline's threshold
+    flat = np.ascontiguousarray(alpha[rng.integers(0, 4, size=n * L)])
+    uniform = np.arange(n + 1, dtype=np.int64) * L
+    for moved in ([7], [n // 16 * 3 + 1, n // 2 + 5, n - 2], list(range(1, n, 9973))):
+        off = uniform.copy()
+        for h in moved:
+            if h % (n // 16):                                         # (never one of the sampled offsets)
+                off[h] += 1                                           # haystack h - 1 one byte longer, haystack h one shorter
+        assert off[-1] == n * L and all(off[n // 16 * k] == n // 16 * k * L for k in range(1, 16))
+        res = A.scan_batch(flat, off)
+        mo, oe, ov = O.batch(flat.tobytes(), off, 0)
+        assert np.array_equal(res.offsets, mo) and np.array_equal(res.end_index, oe) and np.array_equal(res.value, ov), moved[:3]
+    res = A.scan_batch(flat, uniform)
+    mo, oe, ov = O.batch(flat.tobytes(), uniform, 0)
+    assert np.array_equal(res.offsets, mo) and np.array_equal(res.end_index, oe) and np.array_equal(res.value, ov)
