@@ -216,7 +216,9 @@ typedef struct acx_blob_header {
  * gh is a hashed copy of it that LDS can hold: bit acx_ppm_gh_index(code_F) is set for every code whose bit of G is set, so a
  * position whose bit of gh is clear is rejected without asking G (no false negatives); the others ask G as before.  Written
  * only when it rejects enough (the builder measures: at most 3 of 4 random codes pass). */
-#define ACX_PPM_GH_BITS  (3u << 18)   /* 96 KiB: what the staging of 8-bit symbols leaves of a CU's LDS */
+#ifndef ACX_PPM_GH_BITS               /* (development builds try other sizes: tools/build_variant.sh -DACX_PPM_GH_BITS=...) */
+#define ACX_PPM_GH_BITS  (15u << 16)  /* 120 KiB: what the staging of 1024-position tiles of 8-bit symbols (halo up to 256) leaves of a CU's LDS */
+#endif
 #define ACX_PPM_GH_WORDS (ACX_PPM_GH_BITS / 32u)
 #define ACX_PPM_GH_MUL   0x9E3779B1u
 /* index of a code in gh: the high word of (code * MUL mod 2^32) * BITS */

@@ -828,8 +828,15 @@ static int scan_ppm(acx_image_t* img, const acx_scan_params* p, acx_result* r, h
     if (pa.fast) {
         pa.nsub = ppm_stream_nsub(ph, pa.halo_pos, chunked);
         pa.g_global = ph.g_global;
-        // a hashed copy of a global filter goes into LDS when it fits beside the staging at the same tile size (variant bit 18: without, A/B)
-        pa.gh = (ph.g_global && img->ppm_gh && !((p->variant >> 18) & 1) && ppm_stream_nsub(ph, pa.halo_pos, chunked, true) == pa.nsub) ? img->ppm_gh : nullptr;
+        // A hashed copy of a global filter goes into LDS whenever a tile size exists beside which it fits (variant bit 18:
+        // without, A/B) — also when that means tiles of 1024 positions instead of 2048: config 4 (a million signatures) 239
+        // GB/s with a 96 KiB copy beside tiles of 2048, 251 with the same copy beside tiles of 1024, 268 with 122 KiB beside
+        // tiles of 1024 (profiles/experiments/README.md).
+        pa.gh = nullptr;
+        if (ph.g_global && img->ppm_gh && !((p->variant >> 18) & 1)) {
+            const uint32_t ns = ppm_stream_nsub(ph, pa.halo_pos, chunked, true);
+            if (ns) { pa.nsub = ns; pa.gh = img->ppm_gh; }
+        }
         pa.lds = acx_ppm_stream_layout(ph.g_global ? (pa.gh ? ACX_PPM_GH_WORDS : 0u) : ph.g_words, ph.sym_bits, pa.halo_pos, pa.nsub, chunked);
     }
     if (pa.fast) {

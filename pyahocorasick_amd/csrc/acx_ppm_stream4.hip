@@ -71,9 +71,12 @@ static_assert(S4_QUEUE % 8 == 0 && S4_QUEUE >= S4_SYMB + 133 * 4 && S4_QUEUE + 2
 // instruction per probe of the filter.
 typedef __attribute__((address_space(3))) uint32_t lds_u32_t;
 typedef __attribute__((address_space(3))) uint16_t lds_u16_t;
+#pragma clang diagnostic push
+#pragma clang diagnostic ignored "-Wint-to-pointer-cast"     // (the HOST pass sees 64-bit pointers here; LDS pointers of the device are 32 bits)
 __device__ __forceinline__ uint32_t lds_rd32(uint32_t byte_addr) { return *(const lds_u32_t*)byte_addr; }
 __device__ __forceinline__ uint32_t lds_rd16(uint32_t byte_addr) { return *(const lds_u16_t*)byte_addr; }
 __device__ __forceinline__ void lds_wr16(uint32_t byte_addr, uint32_t v) { *(lds_u16_t*)byte_addr = (uint16_t)v; }
+#pragma clang diagnostic pop
 
 __device__ __forceinline__ uint32_t top_base4(uint32_t d) { return 0x55555555u & ((1u << (2u * d)) - 1u); }   // (4^d - 1) / 3: top_base[d] of a four-symbol image
 
