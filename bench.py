@@ -73,6 +73,10 @@ def parse():
     ap.add_argument("--mode", choices=["iter", "iter_long"], default="iter")
     ap.add_argument("--scaling", choices=["weak", "strong"], default="weak")
     ap.add_argument("--variant", type=int, default=0)
+    ap.add_argument("--scan-streams", type=int, default=2,
+                    help="streams the scans of consecutive steps alternate over (default 2: the blocks of step k + 1 start on the CUs that "
+                         "step k's finished blocks leave — one block of the scan kernel fills a CU's LDS, so the kernels share the chip only "
+                         "at that seam; 1: one stream, every scan kernel starts when the one before has drained: 500 instead of 530 GB/s)")
     ap.add_argument("--pipeline", type=int, default=2,
                     help="result objects kept in flight per GPU (ACX_SCAN_ASYNC): the host queues step i+1 and reads "
                          "the counters of step i-1 while step i runs; on ONE stream the kernels of consecutive steps "
@@ -303,6 +307,9 @@ def make_batches(torch, dev, workload, keys, vocab, n_batches, reads, read_len, 
     return batches, host0, e2e0, corpus_bytes
 
 
+SCAN_STREAMS = 2
+
+
 def measure(torch, dist, dev, image, batches, mode, steps, warmup, P, event_every, variant):
     """K timed steps rotating over the batches (barrier + synchronize on both sides, max over ranks by the caller).  Every
     collected step's record count is compared with the count of the same batch in the untimed pre-pass."""
@@ -310,11 +317,17 @@ def measure(torch, dist, dev, image, batches, mode, steps, warmup, P, event_ever
     B = len(batches)
     scs = [Scanner(image) for _ in range(P)]
     stream = torch.cuda.current_stream().cuda_stream
+    # (iter_long's walk kernel is many small blocks: two of them share every CU for their whole length and each other's L2 —
+    #  168 instead of 171 GB/s — so only the position-parallel scans alternate)
+    from pyahocorasick_amd import ACX_SCAN_ALL
+    n_streams = min(SCAN_STREAMS, P) if mode == ACX_SCAN_ALL else 1
+    extra = [torch.cuda.Stream() for _ in range(max(0, n_streams - 1))]
+    streams = [stream] + [x.cuda_stream for x in extra]     # slot k % P scans on stream (k % P) % len(streams)
 
     def step(k, timing=False):
         d_hay, cap, n, d_off, L, shortest = batches[k % B]
         return scs[k % P].scan(d_hay.data_ptr(), cap, n, dev_off=d_off.data_ptr() if d_off is not None else None,
-                               stride=L, mode=mode, timing=timing, variant=variant, stream=stream, asynchronous=P > 1,
+                               stride=L, mode=mode, timing=timing, variant=variant, stream=streams[(k % P) % len(streams)], asynchronous=P > 1,
                                min_hay_len=shortest)
 
     for k in range(max(warmup, P, B)):                    # every batch scanned at least once before timing
@@ -345,7 +358,8 @@ def measure(torch, dist, dev, image, batches, mode, steps, warmup, P, event_ever
                      variant=variant, stream=stream, asynchronous=False, min_hay_len=shortest)
             ts.append(time.perf_counter() - t0)
         sync_ms = float(np.median(ts[1:])) * 1e3
-        del ssc
+        # (ssc stays alive until the caller drops the returned dict: freeing its buffers — 8 B of event scratch per haystack
+        #  byte in iter_long mode, gigabytes — right in front of the timed region hands the driver unmapping work to do)
 
     def barrier():
         if dist is not None:
@@ -387,7 +401,7 @@ def measure(torch, dist, dev, image, batches, mode, steps, warmup, P, event_ever
     step_ms = {"median": round(float(np.median(gaps)), 4), "max": round(float(gaps.max()), 4), "argmax": int(gaps.argmax())}
     return {"dt": dt, "dt_rank": dt_rank, "walk_ms": walk_ms, "pre": pre, "step_ms": step_ms, "matches_per_batch": matches_per_batch, "sync_ms": sync_ms,
             "bytes_rank": sum(batches[k % B][1] for k in range(steps)), "matches_rank": sum(matches_per_batch[k % B] for k in range(steps)),
-            "scanner": scs[0], "stream": stream}
+            "scanner": scs[0], "stream": stream, "keepalive": (ssc if P > 1 else None, extra), "scan_streams": len(streams)}
 
 
 def roofline_entry(image, batches, m, mode_name, workload, variant, steps, event_every):
@@ -440,6 +454,10 @@ def roofline_entry(image, batches, m, mode_name, workload, variant, steps, event
         # HIP events around the kernel, on its stream, inside the timed region: in every N-th step (an event
         # pair costs the stream ~19 us of idle time in the step it is in)
         "kernel_events": {"every_nth_step": event_every, "samples": len(m["walk_ms"])},
+        # with two scan streams the launch of step k + 1 begins while the last blocks of step k still run: a launch's duration
+        # then covers CUs it shares at both seams (it can exceed ms_per_step); kernel_alone_ms is the same kernel in the
+        # pre-pass, where every step is waited for before the next is issued
+        "launches_overlap": m["scan_streams"] > 1, "kernel_alone_ms": round(pre["walk"], 4),
         # HBM bytes of the dominant kernel per launch from the PMC passes (FETCH_SIZE + WRITE_SIZE): `traffic` is the figure
         # corrected as /opt/skills/guides/MI355X_MICROARCH.md prescribes for gfx950 (FETCH_SIZE x 2: it tallies 128-B requests
         # at 64 B; an upper bound where the requests are narrow gathers), `traffic_raw` the counters as they read
@@ -474,7 +492,7 @@ def other_config(torch, dev, acx, name, workload, mode_name, keys, vocab, image,
     m = measure(torch, None, dev, image, batches, mode, steps, 2, max(1, args.pipeline), args.event_every, 0)
     out = {
         "value": m["bytes_rank"] / m["dt"] / 1e9, "unit": "GB/s", "ms_per_step": m["dt"] / steps * 1e3, "steps": steps,
-        "ms_per_step_synchronous": m["sync_ms"], "step_ms_host_intervals": m["step_ms"],
+        "ms_per_step_synchronous": m["sync_ms"], "step_ms_host_intervals": m["step_ms"], "scan_streams": m["scan_streams"],
         "matches_per_step": m["matches_rank"] / steps,
         "workload": (WORKLOAD_NAMES[workload] % ((n_keys, args.reads, args.read_len) if workload == "c2" else (n_keys, batch_mb)))
                     + ", Automaton.%s; %d distinct batches rotated (%.0f MB resident)" % (mode_name, len(batches), sum(b[1] for b in batches) / 1e6),
@@ -553,6 +571,8 @@ def main():
     t_stage = time.perf_counter() - t0
     mode = acx.ACX_SCAN_ALL if args.mode == "iter" else acx.ACX_SCAN_LONG
     P = max(1, args.pipeline)
+    global SCAN_STREAMS
+    SCAN_STREAMS = max(1, args.scan_streams)
     m = measure(torch, dist, dev, image, batches, mode, args.steps, args.warmup, P, args.event_every, args.variant)
     dt, bytes_rank, matches_rank = m["dt"], m["bytes_rank"], m["matches_rank"]
     per_rank = [bytes_rank / m["dt_rank"] / 1e9]
@@ -606,7 +626,7 @@ def main():
             "config": {"workload": wname + ", Automaton.%s; %d distinct batches rotated (%.0f MB resident per GPU)"
                                    % (args.mode, B, sum(b[1] for b in batches) / 1e6),
                        "states": int(image.num_states), "classes": int(image.num_classes),
-                       "image_mb": round(image.nbytes / 1e6, 1), "variant": args.variant, "pipeline_depth": P,
+                       "image_mb": round(image.nbytes / 1e6, 1), "variant": args.variant, "pipeline_depth": P, "scan_streams": m["scan_streams"],
                        "parallelism": "replicated automaton (1 RCCL broadcast), haystacks sharded x%d (%s)" % (world, "strong" if strong else "weak")},
             "roofline": roofline_entry(image, batches, m, args.mode, args.workload, args.variant, args.steps, args.event_every),
             "setup": {"build_flatten_s": round(t_build, 3), "broadcast_upload_s": round(t_bcast, 3), "stage_batches_s": round(t_stage, 3)},
