@@ -16,6 +16,8 @@
 #include <thread>
 #include <new>
 #include <vector>
+#include <algorithm>
+#include <cmath>
 
 // ------------------------------------------------------------------------------------
 // errors
@@ -815,6 +817,43 @@ static int scan_ppm(acx_image_t* img, const acx_scan_params* p, acx_result* r, h
             (void)hipMemset(g_phase, 0, 64);
         }
     }
+#ifdef ACX_S4_WAVETIME
+    {   // development: start and end of every wave of the previous k_ppm_stream4 launch (100 MHz ticks)
+        static unsigned long long* g_wt = nullptr;
+        static std::vector<unsigned long long> h_wt;
+        const size_t W = 8 + 2 * 4096;
+        if (!g_wt) { if (hipMalloc((void**)&g_wt, W * 8) != hipSuccess) g_wt = nullptr; else (void)hipMemset(g_wt, 0, W * 8); }
+        if (g_wt) {
+            h_wt.resize(W);
+            if (hipMemcpy(h_wt.data(), g_wt, W * 8, hipMemcpyDeviceToHost) == hipSuccess && h_wt[8 + 1]) {
+                unsigned long long t0 = ~0ull, t1 = 0; double sum_end = 0, sum_busy = 0; int n = 0;
+                for (int w = 0; w < 4096; w++) { const unsigned long long b = h_wt[8 + 2 * w], e = h_wt[8 + 2 * w + 1]; if (!e) continue; if (b < t0) t0 = b; if (e > t1) t1 = e; n++; }
+                std::vector<double> ends, blk_end(256, 0.0), starts;
+                for (int w = 0; w < 4096; w++) { const unsigned long long b = h_wt[8 + 2 * w], e = h_wt[8 + 2 * w + 1]; if (!e) continue;
+                    const double en = (double)(e - t0) / 100.0, st = (double)(b - t0) / 100.0; ends.push_back(en); starts.push_back(st); sum_end += en; sum_busy += en - st; if (en > blk_end[w / 16]) blk_end[w / 16] = en; }
+                std::sort(ends.begin(), ends.end()); std::sort(starts.begin(), starts.end()); std::sort(blk_end.begin(), blk_end.end());
+                fprintf(stderr, "[wave times of the previous k_ppm_stream4 launch, us from the first wave's start] waves %d  start p50 %.1f max %.1f | end min %.1f p10 %.1f p50 %.1f p90 %.1f p99 %.1f max %.1f mean %.1f | busy mean %.1f | block end min %.1f p50 %.1f max %.1f\n",
+                        n, starts[starts.size() / 2], starts.back(), ends.front(), ends[ends.size() / 10], ends[ends.size() / 2], ends[ends.size() * 9 / 10], ends[ends.size() * 99 / 100], ends.back(), sum_end / n, sum_busy / n,
+                        blk_end.front(), blk_end[128], blk_end.back());
+                {   // where the spread comes from: by wave slot of the block, by XCD (block % 8), between and within blocks
+                    double by_wid[16] = {0}, by_xcd[8] = {0}; int n_wid[16] = {0}, n_xcd[8] = {0};
+                    std::vector<double> bmean(256, 0.0); std::vector<int> bn(256, 0);
+                    for (int w = 0; w < 4096; w++) { const unsigned long long e = h_wt[8 + 2 * w + 1]; if (!e) continue; const double en = (double)(e - t0) / 100.0;
+                        by_wid[w % 16] += en; n_wid[w % 16]++; by_xcd[(w / 16) % 8] += en; n_xcd[(w / 16) % 8]++; bmean[w / 16] += en; bn[w / 16]++; }
+                    fprintf(stderr, "  mean end by wave slot:"); for (int i = 0; i < 16; i++) fprintf(stderr, " %.0f", by_wid[i] / (n_wid[i] ? n_wid[i] : 1));
+                    fprintf(stderr, "\n  mean end by XCD:"); for (int i = 0; i < 8; i++) fprintf(stderr, " %.0f", by_xcd[i] / (n_xcd[i] ? n_xcd[i] : 1));
+                    double gm = 0; int gb = 0; for (int b = 0; b < 256; b++) if (bn[b]) { bmean[b] /= bn[b]; gm += bmean[b]; gb++; } gm /= gb ? gb : 1;
+                    double vb = 0, vw = 0; int nw = 0;
+                    for (int b = 0; b < 256; b++) if (bn[b]) vb += (bmean[b] - gm) * (bmean[b] - gm);
+                    for (int w = 0; w < 4096; w++) { const unsigned long long e = h_wt[8 + 2 * w + 1]; if (!e) continue; const double en = (double)(e - t0) / 100.0; vw += (en - bmean[w / 16]) * (en - bmean[w / 16]); nw++; }
+                    fprintf(stderr, "\n  sd of block means %.1f us, sd within blocks %.1f us\n", sqrt(vb / (gb ? gb : 1)), sqrt(vw / (nw ? nw : 1)));
+                }
+            }
+            (void)hipMemset(g_wt, 0, W * 8);
+        }
+        g_phase = g_wt;
+    }
+#endif
     pa.phase_out = g_phase;                      // development builds (-DACX_PPM_DEV): phase switches, timing only
     pa.halo_pos = ppm_halo_pos(ph);
     pa.fast = plan == 2;
@@ -885,6 +924,14 @@ static int scan_ppm(acx_image_t* img, const acx_scan_params* p, acx_result* r, h
         ga.n_hay = p->n_hay; ga.stride = p->stride;
         ga.off = chunked ? p->dev_off : nullptr;
         ga.tile_pos = tpos; ga.tpw = (stream_tiles + n_waves - 1) / n_waves;
+        // fixed stride: unequal runs for the waves of a block (acx_ppm_layout.h; variant bit 17: equal runs, A/B)
+        pa.share_a = pa.share_b = 0;
+        if (!chunked && !((p->variant >> 17) & 1) && ga.tpw >= 8 && ga.tpw < 100000) {
+            uint32_t pa_ = 160, pb_ = 55;                               // per mille of tpw
+            if (const char* e = acx_tune_env("ACX_S4_SHARE")) { int x = 0, y = 0; if (sscanf(e, "%d,%d", &x, &y) == 2 && x >= 0 && y >= 0 && x < 900 && y <= x) { pa_ = (uint32_t)x; pb_ = (uint32_t)y; } }   // tuning hook
+            pa.share_a = (uint32_t)((ga.tpw * pa_ + 500) / 1000); pa.share_b = (uint32_t)((ga.tpw * pb_ + 500) / 1000);
+        }
+        ga.share_a = pa.share_a; ga.share_b = pa.share_b;
         ga.stride_magic = pa.stride_magic; ga.index_base = chunked ? nullptr : p->dev_index_base; ga.skip = chunked ? nullptr : p->dev_skip;
         if (!chunked) {
             void* dp = nullptr;

@@ -126,6 +126,7 @@ struct acx_ppm_args {
     uint32_t dbg;            // development builds only (k_ppm_stream's phase switches: 2 = no record writes, 4 = no rounds, 8 = no queue, 16 = no filter)
 #endif
     uint32_t nsub;           // k_ppm_stream: sub-steps of 256 positions per tile (4 or 8)
+    uint32_t share_a, share_b;   // k_ppm_stream4: the unequal runs of a block's waves (acx_ppm_slot_first_tile; 0, 0: equal)
     uint32_t m24;            // k_ppm_stream: ceil(2^23 / stride) for strides below 2048 (a 24-bit multiply divides), else 0
     const int64_t* off; const int64_t* first_h;    // k_ppm_stream on an offsets batch: offsets, first haystack at or after every tile
     uint32_t g_global;       // the filter bitmap is read from global memory (not copied to LDS)
@@ -170,6 +171,7 @@ struct acx_ppm_gather_args {       // k_ppm_stream results -> final place
     const int32_t* index_base;     // fixed stride: added to every index of haystack h (nullable)
     const int32_t* skip;           // fixed stride: context bytes of haystack h, taken off every index (nullable)
     int64_t off_base;              // k_ppm_gather_pos: added to every offset written (the records of the groups in front: acx_scan_host's pipeline)
+    uint32_t share_a, share_b;     // k_ppm_gather_pos: the runs of the scan kernel's waves (acx_ppm_slot_first_tile)
 };
 #define ACX_PPM_DESC_WORDS 40
 hipError_t acx_launch_ppm_first_h(const int64_t* off, int64_t n_hay, int64_t n_tiles, int64_t tile_pos, int64_t* first_h, hipStream_t s);

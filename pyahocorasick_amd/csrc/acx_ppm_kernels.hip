@@ -371,8 +371,12 @@ __global__ void __launch_bounds__(ACX_PPM_BLOCK) k_ppm_stream(const acx_ppm_args
     const int64_t n_waves = (int64_t)gridDim.x * ACX_PPM_WAVES;
     const int64_t tpw = (n_tiles + n_waves - 1) / n_waves;            // tiles per wave: a contiguous run
     const int64_t wave_id = (int64_t)blockIdx.x * ACX_PPM_WAVES + wid;
-    const int64_t t_begin = wave_id * tpw;
-    const int64_t t_end = t_begin + tpw < n_tiles ? t_begin + tpw : n_tiles;
+    // (fixed stride: the waves of a block may take unequal runs — acx_ppm_slot_first_tile, acx_ppm_layout.h; k_ppm_gather_pos
+    //  is told the same shares.  Offset batches: equal runs, k_ppm_gather finds a tile's wave by a division.)
+    const int64_t blk_first = (int64_t)blockIdx.x * ACX_PPM_WAVES * tpw;
+    const int64_t t_begin = OFFS ? wave_id * tpw : blk_first + acx_ppm_slot_first_tile((uint32_t)wid, (uint32_t)tpw, a.share_a, a.share_b);
+    const int64_t t_stop = OFFS ? t_begin + tpw : blk_first + acx_ppm_slot_first_tile((uint32_t)wid + 1u, (uint32_t)tpw, a.share_a, a.share_b);
+    const int64_t t_end = t_stop < n_tiles ? t_stop : n_tiles;
     uint32_t* const desc = a.wave_desc + (size_t)wave_id * PPM_DESC_WORDS;
     const uint32_t pool_x = blockIdx.x % a.n_pools;
     const uint32_t step_q = OFFS ? 0u : TPOS / stride, step_r = OFFS ? 0u : TPOS % stride;
@@ -1163,13 +1167,17 @@ __global__ void __launch_bounds__(PPM_GPOS_THREADS) k_ppm_gather_pos(const acx_p
     const int lane = threadIdx.x & 63;
     // positions of one wave lie within tpw * tile_pos of its first: the haystack of a position is a 32-bit multiply-high
     // away (exact while (offset in its haystack + distance) * stride < 2^32), else the 64-bit magic
-    const uint64_t span = (uint64_t)c.tpw * (uint64_t)c.tile_pos;
+    const uint64_t span = ((uint64_t)c.tpw + c.share_a) * (uint64_t)c.tile_pos;       // (the longest run of a wave)
     const bool small = (span + stride) * (uint64_t)stride < ((uint64_t)1 << 32);
     const uint32_t m32 = small ? (uint32_t)((((uint64_t)1 << 32) + stride - 1) / stride) : 0u;
     for (int64_t w = blockIdx.x; w < c.n_waves; w += gridDim.x) {
         const uint32_t* d = c.wave_desc + (size_t)w * PPM_DESC_WORDS;
         const uint32_t ng = d[1], count = d[0];
-        uint64_t A = (uint64_t)w * span, B = A + span;
+        // the run of wave w of the scan kernel (acx_ppm_slot_first_tile: the waves of a block take unequal runs)
+        const uint64_t blk_first = (uint64_t)(w / ACX_PPM_WAVES) * ACX_PPM_WAVES * (uint64_t)c.tpw;
+        const uint32_t slot = (uint32_t)(w % ACX_PPM_WAVES);
+        uint64_t A = (blk_first + acx_ppm_slot_first_tile(slot, (uint32_t)c.tpw, c.share_a, c.share_b)) * (uint64_t)c.tile_pos;
+        uint64_t B = (blk_first + acx_ppm_slot_first_tile(slot + 1u, (uint32_t)c.tpw, c.share_a, c.share_b)) * (uint64_t)c.tile_pos;
         if (A > H) A = H;
         if (B > H) B = H;
         const int64_t hA = (int64_t)((A + stride - 1) / stride), hB = (int64_t)((B + stride - 1) / stride);   // haystacks that start in [A, B): hA .. hB - 1

@@ -45,6 +45,23 @@ static inline acx_ppm_lds acx_ppm_lds_layout(uint32_t g_words, uint32_t sym_bits
 }
 
 
+// The tiles of a block, 16 tpw of them, over its 16 waves.  Equal runs end unequally: the four waves of a SIMD do not run
+// equally fast (the issue arbiter prefers the older wave — profiles/r4_wave_end_times.txt: with 18 tiles each the oldest
+// wave of every SIMD ends after 205 us, the next after 217, 232, 247), and a SIMD whose first waves are gone hides less
+// latency for the rest: the kernel's last 40 us run on half-empty SIMDs.  So wave slot i — the (i / 4)-th oldest wave of
+// SIMD i % 4 — takes tpw + d tiles, d = +a, +b, -b, -a for i / 4 = 0 .. 3 (a = b = 0: equal runs).  First tile of slot
+// `slot` (0 .. 16) within its block:
+#if defined(__HIPCC__)
+__host__ __device__
+#endif
+static inline uint32_t acx_ppm_slot_first_tile(uint32_t slot, uint32_t tpw, uint32_t a, uint32_t b) {
+    const uint32_t g = slot >> 2, r = slot & 3u;
+    const uint32_t t0 = tpw + a, t1 = tpw + b, t2 = tpw - b, t3 = tpw - a;
+    const uint32_t before = g == 0 ? 0u : g == 1 ? 4u * t0 : g == 2 ? 4u * (t0 + t1) : g == 3 ? 4u * (t0 + t1 + t2) : 16u * tpw;
+    const uint32_t own = g == 0 ? t0 : g == 1 ? t1 : g == 2 ? t2 : t3;
+    return before + r * own;                                            // (slot 16: g = 4, r = 0 -> 16 tpw)
+}
+
 // k_ppm_stream: tiles of nsub x 256 positions, halo of halo_pos positions (a multiple of 32) carried in LDS, a ring
 // queue.  oth: one bit per staged position (a byte of no key); cnt: the start tables of offsets batches.
 static inline acx_ppm_lds acx_ppm_stream_layout(uint32_t g_words, uint32_t sym_bits, uint32_t halo_pos, uint32_t nsub, int offs) {

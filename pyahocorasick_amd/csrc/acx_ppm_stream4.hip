@@ -110,11 +110,17 @@ __global__ void __launch_bounds__(ACX_PPM_BLOCK) k_ppm_stream4(const acx_ppm_arg
     const uint32_t n_waves = gridDim.x * ACX_PPM_WAVES;
     const uint32_t tpw = (n_tiles + n_waves - 1) / n_waves;
     const uint32_t wave_id = blockIdx.x * ACX_PPM_WAVES + wid;
-    const uint64_t t_begin = (uint64_t)wave_id * tpw;
+#ifdef ACX_S4_WAVETIME             // development: when every wave starts and ends (100 MHz clock; phase_out: 2 x 4096 words), printed by scan_ppm
+    const unsigned long long wt0 = __builtin_amdgcn_s_memrealtime();
+#endif
+    // (unequal runs: acx_ppm_slot_first_tile, acx_ppm_layout.h)
+    const uint32_t blk_first = blockIdx.x * ACX_PPM_WAVES * tpw;
+    const uint64_t t_begin = (uint64_t)blk_first + acx_ppm_slot_first_tile((uint32_t)wid, tpw, a.share_a, a.share_b);
+    const uint32_t t_run = acx_ppm_slot_first_tile((uint32_t)wid + 1u, tpw, a.share_a, a.share_b) - acx_ppm_slot_first_tile((uint32_t)wid, tpw, a.share_a, a.share_b);
     uint32_t* const desc = a.wave_desc + (size_t)wave_id * PPM_DESC_WORDS;
     wave_sync();
     if (t_begin >= n_tiles) { if (lane == 0) { desc[0] = 0; desc[1] = 0; } return; }
-    uint32_t tiles_left = n_tiles - (uint32_t)t_begin < tpw ? n_tiles - (uint32_t)t_begin : tpw;
+    uint32_t tiles_left = n_tiles - (uint32_t)t_begin < t_run ? n_tiles - (uint32_t)t_begin : t_run;
 
     uint32_t ar_shift = a.sym_arith - 1u, ar_lut = a.sym_lut;
     asm volatile("" : "+s"(ar_shift), "+s"(ar_lut));                  // (kept in registers: the stage reads them for every dword)
@@ -621,6 +627,9 @@ __global__ void __launch_bounds__(ACX_PPM_BLOCK) k_ppm_stream4(const acx_ppm_arg
 #undef S4_SLOTS
 #ifdef ACX_S4_PHASES
     if (lane == 0 && a.phase_out) for (int i = 0; i < 8; i++) atomicAdd(a.phase_out + i, ph[i]);
+#endif
+#ifdef ACX_S4_WAVETIME
+    if (lane == 0 && a.phase_out && wave_id < 4096u) { a.phase_out[8 + 2 * wave_id] = wt0; a.phase_out[8 + 2 * wave_id + 1] = __builtin_amdgcn_s_memrealtime(); }
 #endif
     if (lane == 0) {
         if (ACX_S4_EXP & 5) { run_off = 0; ng = 0; }                   // (timing-only builds: nothing for the gather to move)
