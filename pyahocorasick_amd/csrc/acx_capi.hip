@@ -924,9 +924,9 @@ static int scan_ppm(acx_image_t* img, const acx_scan_params* p, acx_result* r, h
         ga.n_hay = p->n_hay; ga.stride = p->stride;
         ga.off = chunked ? p->dev_off : nullptr;
         ga.tile_pos = tpos; ga.tpw = (stream_tiles + n_waves - 1) / n_waves;
-        // fixed stride: unequal runs for the waves of a block (acx_ppm_layout.h; variant bit 17: equal runs, A/B)
+        // unequal runs for the waves of a block (acx_ppm_layout.h; variant bit 17: equal runs, A/B)
         pa.share_a = pa.share_b = 0;
-        if (!chunked && !((p->variant >> 17) & 1) && ga.tpw >= 8 && ga.tpw < 100000) {
+        if (!((p->variant >> 17) & 1) && ga.tpw >= 8 && ga.tpw < 100000) {
             uint32_t pa_ = 160, pb_ = 55;                               // per mille of tpw
             if (const char* e = acx_tune_env("ACX_S4_SHARE")) { int x = 0, y = 0; if (sscanf(e, "%d,%d", &x, &y) == 2 && x >= 0 && y >= 0 && x < 900 && y <= x) { pa_ = (uint32_t)x; pb_ = (uint32_t)y; } }   // tuning hook
             pa.share_a = (uint32_t)((ga.tpw * pa_ + 500) / 1000); pa.share_b = (uint32_t)((ga.tpw * pb_ + 500) / 1000);

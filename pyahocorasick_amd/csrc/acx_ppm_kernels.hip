@@ -371,11 +371,11 @@ __global__ void __launch_bounds__(ACX_PPM_BLOCK) k_ppm_stream(const acx_ppm_args
     const int64_t n_waves = (int64_t)gridDim.x * ACX_PPM_WAVES;
     const int64_t tpw = (n_tiles + n_waves - 1) / n_waves;            // tiles per wave: a contiguous run
     const int64_t wave_id = (int64_t)blockIdx.x * ACX_PPM_WAVES + wid;
-    // (fixed stride: the waves of a block may take unequal runs — acx_ppm_slot_first_tile, acx_ppm_layout.h; k_ppm_gather_pos
-    //  is told the same shares.  Offset batches: equal runs, k_ppm_gather finds a tile's wave by a division.)
+    // (the waves of a block may take unequal runs — acx_ppm_slot_first_tile, acx_ppm_layout.h; the gather kernels are told the
+    //  same shares)
     const int64_t blk_first = (int64_t)blockIdx.x * ACX_PPM_WAVES * tpw;
-    const int64_t t_begin = OFFS ? wave_id * tpw : blk_first + acx_ppm_slot_first_tile((uint32_t)wid, (uint32_t)tpw, a.share_a, a.share_b);
-    const int64_t t_stop = OFFS ? t_begin + tpw : blk_first + acx_ppm_slot_first_tile((uint32_t)wid + 1u, (uint32_t)tpw, a.share_a, a.share_b);
+    const int64_t t_begin = blk_first + acx_ppm_slot_first_tile((uint32_t)wid, (uint32_t)tpw, a.share_a, a.share_b);
+    const int64_t t_stop = blk_first + acx_ppm_slot_first_tile((uint32_t)wid + 1u, (uint32_t)tpw, a.share_a, a.share_b);
     const int64_t t_end = t_stop < n_tiles ? t_stop : n_tiles;
     uint32_t* const desc = a.wave_desc + (size_t)wave_id * PPM_DESC_WORDS;
     const uint32_t pool_x = blockIdx.x % a.n_pools;
@@ -1127,7 +1127,11 @@ __global__ void __launch_bounds__(256) k_ppm_gather(const acx_ppm_gather_args c)
     const uint32_t tpw = (uint32_t)c.tpw;
     for (int64_t h = (int64_t)blockIdx.x * 256 + threadIdx.x; h <= c.n_hay; h += n_threads) {
         if (h == c.n_hay) c.match_off[h] = total;
-        else c.match_off[h] = c.wave_off[(uint32_t)(c.off[h] >> tile_shift) / tpw] + c.hay_local[h];
+        else {
+            const uint32_t tile = (uint32_t)(c.off[h] >> tile_shift), per_block = ACX_PPM_WAVES * tpw;      // the wave whose run holds the haystack's first byte
+            const uint32_t blk = tile / per_block;
+            c.match_off[h] = c.wave_off[blk * ACX_PPM_WAVES + acx_ppm_tile_slot(tile - blk * per_block, tpw, c.share_a, c.share_b)] + c.hay_local[h];
+        }
     }
 }
 

@@ -62,6 +62,21 @@ static inline uint32_t acx_ppm_slot_first_tile(uint32_t slot, uint32_t tpw, uint
     return before + r * own;                                            // (slot 16: g = 4, r = 0 -> 16 tpw)
 }
 
+// the inverse: which slot of its block holds tile t (0 .. 16 tpw - 1, counted from the block's first tile)
+#if defined(__HIPCC__)
+__host__ __device__
+#endif
+static inline uint32_t acx_ppm_tile_slot(uint32_t t, uint32_t tpw, uint32_t a, uint32_t b) {
+    const uint32_t t0 = tpw + a, t1 = tpw + b, t2 = tpw - b, t3 = tpw - a;
+    if (t < 4u * t0) return t / t0;
+    t -= 4u * t0;
+    if (t < 4u * t1) return 4u + t / t1;
+    t -= 4u * t1;
+    if (t < 4u * t2) return 8u + t / t2;
+    t -= 4u * t2;
+    return 12u + t / t3;
+}
+
 // k_ppm_stream: tiles of nsub x 256 positions, halo of halo_pos positions (a multiple of 32) carried in LDS, a ring
 // queue.  oth: one bit per staged position (a byte of no key); cnt: the start tables of offsets batches.
 static inline acx_ppm_lds acx_ppm_stream_layout(uint32_t g_words, uint32_t sym_bits, uint32_t halo_pos, uint32_t nsub, int offs) {
