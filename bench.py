@@ -418,7 +418,14 @@ def roofline_entry(image, batches, m, mode_name, workload, variant, steps, event
     used_ppm = mode_name == "iter" and image.ppm_kernel(stride=L0, has_offsets=d_off0 is not None, variant=variant, min_hay_len=shortest0,
                                                           dev_hay=d_hay.data_ptr(), n_hay=n0)
     if mode_name != "iter":
-        walk_kernel, walk_bytes = "k_walk_long_sel", H + 12 * Nh
+        # iter_long: the position-parallel scan over the dictionary of acx_long.cpp where it applies (the scan kernel is the
+        # dominant one; the sweep over its records is `expand` in kernel_ms), else the serial walk.  Algorithmic bytes of the
+        # task either way: the haystack in, one offset per haystack out (the records are in the pipeline figure below).
+        from pyahocorasick_amd import ACX_SCAN_LONG
+        long_ppm = image.ppm_kernel(stride=L0, has_offsets=d_off0 is not None, variant=variant, min_hay_len=shortest0,
+                                    dev_hay=d_hay.data_ptr(), n_hay=n0, mode=ACX_SCAN_LONG)
+        walk_kernel = {"stream4": "k_ppm_stream4", "stream": "k_ppm_stream", "scan": "k_ppm_scan"}.get(long_ppm, "k_walk_long_sel")
+        walk_bytes = H + 12 * Nh
     elif used_ppm in ("stream", "stream4"):
         # the scan kernel reads the haystack, writes every record (to the pool) and one offset per haystack
         walk_kernel, walk_bytes = ("k_ppm_stream4" if used_ppm == "stream4" else "k_ppm_stream"), H + 8 * M + (4 if d_off0 is None else 12) * Nh

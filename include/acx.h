@@ -163,6 +163,17 @@ int  acx_flatten_ex(const acx_trie_t* t, uint32_t flags, void** blob, size_t* nb
 void acx_blob_free(void* blob);
 int  acx_blob_validate(const void* blob, size_t nbytes);             /* host blob */
 
+/* The dictionary that ACX_SCAN_LONG scans position-parallel (acx_long.cpp): iter_long — automaton_search_iter_long_next,
+ * src/AutomatonSearchIterLong.c:89-153, a serial state machine — only ever reports nodes that end a key (E) or whose fail
+ * node does while they do not (FE), and whether it stops at one depends on the next LONGER path of the trie that ends
+ * with it (U: the nodes whose fail node is an E or FE node).  A trie of exactly these node strings, each with the value
+ * index | length << 24 | kind << 30  (kind 0 U, 1 E, 2 FE; real_vals[index] = what iter_long reports for the node),
+ * finalised.  ACX_SCAN_ALL over it gives, per haystack, the records a single sweep turns into iter_long's output; the
+ * device side builds it from an image on the first ACX_SCAN_LONG scan.  *n = 0 (and no trie) when the form does not apply:
+ * a node deeper than 63 letters, 2^24 nodes or more.  Host only; the trie is the caller's (acx_trie_free), real_vals is
+ * malloc'd (acx_blob_free). */
+int  acx_blob_long_trie(const void* blob, size_t nbytes, acx_trie_t** out_trie, int32_t** real_vals, int64_t* n, int32_t* longest);
+
 typedef struct acx_image acx_image_t;
 /* copy a host blob to the current HIP device */
 int  acx_image_upload(const void* blob, size_t nbytes, acx_image_t** out);
@@ -287,7 +298,10 @@ int  acx_scan_batch(acx_image_t* img, const acx_scan_params* p, acx_result_t** r
 /* Which kernels acx_scan_batch would run for these parameters (nothing is launched): 0 = the serial walks
  * (one lane per haystack or chunk: k_walk_itop / k_walk_all / k_walk_chunks / k_walk_long), 1 = the general
  * position-parallel kernel k_ppm_scan, 2 = the position-parallel stream kernel k_ppm_stream, 3 = its
- * specialisation for fixed-length haystacks over a four-letter alphabet, k_ppm_stream4; -1 on bad arguments.  bench.py names the dominant kernel of its roofline entry with it. */
+ * specialisation for fixed-length haystacks over a four-letter alphabet, k_ppm_stream4; -1 on bad arguments.  ACX_SCAN_LONG:
+ * 10 + that number for the scan over the dictionary of acx_blob_long_trie when iter_long takes the position-parallel form
+ * (the call builds that dictionary's image if it does not exist yet), 0 for the serial walk k_walk_long_sel.  bench.py
+ * names the dominant kernel of its roofline entry with it. */
 int  acx_scan_plan(const acx_image_t* img, const acx_scan_params* p);
 int  acx_result_wait(acx_result_t* r);
 

@@ -86,6 +86,7 @@ SIGNATURES = {
     "acx_flatten_ex": (C.c_int, [_P, C.c_uint32, _PP, C.POINTER(C.c_size_t)]),
     "acx_set_host_group_bytes": (None, [C.c_int64]),
     "acx_blob_free": (None, [_P]),
+    "acx_blob_long_trie": (C.c_int, [_P, C.c_size_t, _PP, _PP, C.POINTER(C.c_int64), C.POINTER(C.c_int32)]),
     "acx_blob_validate": (C.c_int, [_P, C.c_size_t]),
     "acx_image_upload": (C.c_int, [_P, C.c_size_t, _PP]),
     "acx_image_adopt": (C.c_int, [_P, C.c_size_t, _P, _PP]),

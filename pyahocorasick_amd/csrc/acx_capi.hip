@@ -103,6 +103,13 @@ struct acx_image {
     const uint32_t* ppm_hot4 = nullptr;        // hot cells and depth-C ids of k_ppm_stream4 (four-letter alphabets; nullptr: absent)
     const uint32_t* ppm_cid = nullptr;
     const uint32_t* ppm_gh = nullptr;          // hashed copy of a global filter for LDS (nullptr: absent)
+    // ACX_SCAN_LONG position-parallel (acx_long.cpp): a second image, over the dictionary D = E + FE + U of this one, built on
+    // the first such scan; long_state 0: not tried yet, 1: there, -1: does not apply (the serial walk stays)
+    std::mutex long_mu;
+    int long_state = 0;
+    acx_image* long_img = nullptr;
+    int32_t* long_real = nullptr;              // device: what iter_long reports for dictionary entry i
+    uint32_t long_longest = 0;
 };
 
 // The steady-state step of the itop walk uses 32-bit offsets: table and cells from the lower of
@@ -346,6 +353,8 @@ extern "C" void acx_image_free(acx_image_t* img) {
     if (!img) return;
     if (img->owns && img->dev) (void)hipFree(img->dev);
     if (img->built_table) (void)hipFree(img->built_table);
+    if (img->long_img) acx_image_free(img->long_img);
+    if (img->long_real) (void)hipFree(img->long_real);
     delete img;
 }
 extern "C" int64_t acx_image_num_states(const acx_image_t* img) { return img ? img->h.n_states : 0; }
@@ -410,6 +419,7 @@ struct acx_result {
     // acx_scan_host, pipelined (scan_host_pipelined): the gather of a fixed-stride stream scan writes records and offsets
     // straight into the result's pinned host buffers (device-mapped pointers) instead of r->matches / r->match_off
     uint2* ext_matches = nullptr; int64_t ext_capacity = 0; int64_t* ext_match_off = nullptr; int64_t ext_off_base = 0;
+    acx_result* long_inner = nullptr;           // ACX_SCAN_LONG position-parallel: the result of the scan over the dictionary D
     hipStream_t copy_stream = nullptr;
     bool ppm_self = false;      // the pending stream scan is a fixed-stride one: block sums, totals and clean-up in k_ppm_gather_pos
     int bs_parity = 0;          // which half of wave_aux the next such scan sums into
@@ -458,6 +468,7 @@ struct acx_result {
         if (ev_scan) (void)hipEventDestroy(ev_scan);
         if (side) (void)hipStreamDestroy(side);
         if (copy_stream) (void)hipStreamDestroy(copy_stream);
+        delete long_inner;
     }
 };
 
@@ -745,6 +756,7 @@ static bool ppm_plan_stream4(const acx_image* img, const acx_scan_params* p) {
            ppm_stream_nsub(ph, 32, false) == 8;
 }
 
+static acx_image* image_long(acx_image* img);
 extern "C" int acx_scan_plan(const acx_image_t* img, const acx_scan_params* p) {
     if (!img || !p || p->struct_bytes != sizeof(acx_scan_params)) return -1;
     if (p->flags & ACX_SCAN_SKIP_WS) {                      // what scan_batch_ws hands to the kernels: offsets, aligned, a promise of 8 at most
@@ -753,6 +765,15 @@ extern "C" int acx_scan_plan(const acx_image_t* img, const acx_scan_params* p) {
         q.dev_off = (const int64_t*)(uintptr_t)8; q.stride = 0;
         q.min_hay_len = (p->dev_off ? p->min_hay_len : (int32_t)(p->stride > INT32_MAX ? INT32_MAX : p->stride)) >= 8 ? 8 : 0;
         return ppm_plan(img, &q);
+    }
+    if (p->mode == ACX_SCAN_LONG) {                         // 10 + the plan of the scan over the dictionary D (builds D's image on first use)
+        if (p->dev_init_state || p->want_final_state || p->n_hay <= 0 || ((p->variant >> 25) & 1) || !(p->dev_off || p->stride > 0)) return 0;
+        acx_image* li = image_long(const_cast<acx_image_t*>(img));
+        if (!li) return 0;
+        acx_scan_params q = *p;
+        q.mode = ACX_SCAN_ALL; q.want_final_state = 0; q.dev_skip = nullptr;
+        const int lp = ppm_plan(li, &q);
+        return lp ? 10 + (lp == 2 && ppm_plan_stream4(li, &q) ? 3 : lp) : 0;
     }
     const int plan = ppm_plan(img, p);
     return plan == 2 && ppm_plan_stream4(img, p) ? 3 : plan;
@@ -974,6 +995,78 @@ static int scan_ppm(acx_image_t* img, const acx_scan_params* p, acx_result* r, h
     return result_complete(r);
 }
 
+// ---- ACX_SCAN_LONG, position-parallel (acx_long.cpp, acx_long.hip) ---------------------------------------------------------
+// The image over the dictionary D of `img`, built on first use: the blob comes back from the device (the sparse form of the
+// transitions, fail links and key flags are all in it), acx_blob_long_trie makes the trie of D, flatten + upload as for any
+// automaton.  nullptr: the form does not apply (no position-parallel section, nodes deeper than 63, D has no such section).
+static acx_image* image_long(acx_image* img) {
+    std::lock_guard<std::mutex> g(img->long_mu);
+    if (img->long_state) return img->long_state > 0 ? img->long_img : nullptr;
+    img->long_state = -1;
+    if (!img->ppm_g || !img->dev) return nullptr;
+    acx_trie_t* t = nullptr; int32_t* real = nullptr; int64_t n = 0; int32_t longest = 0;
+    {
+        std::vector<uint8_t> host;
+        try { host.resize(img->nbytes); } catch (const std::bad_alloc&) { return nullptr; }
+        if (hipMemcpy(host.data(), img->dev, img->nbytes, hipMemcpyDeviceToHost) != hipSuccess) return nullptr;
+        if (acx_blob_long_trie(host.data(), img->nbytes, &t, &real, &n, &longest) != ACX_OK || n == 0 || !t) return nullptr;
+    }
+    void* blob2 = nullptr; size_t nb2 = 0;
+    int rc = acx_flatten_ex(t, ACX_FLATTEN_NO_ITOP | ACX_FLATTEN_TABLE_DEVICE, &blob2, &nb2);
+    acx_trie_free(t);
+    acx_image* li = nullptr;
+    if (!rc) { rc = acx_image_upload(blob2, nb2, &li); acx_blob_free(blob2); }
+    if (rc || !li || !li->ppm_g) { if (li) acx_image_free(li); free(real); return nullptr; }
+    li->long_state = -1;                                              // (no dictionary of the dictionary)
+    int32_t* d_real = nullptr;
+    if (hipMalloc((void**)&d_real, (size_t)n * 4) != hipSuccess || hipMemcpy(d_real, real, (size_t)n * 4, hipMemcpyHostToDevice) != hipSuccess) {
+        if (d_real) (void)hipFree(d_real);
+        acx_image_free(li); free(real); return nullptr;
+    }
+    free(real);
+    img->long_img = li; img->long_real = d_real; img->long_longest = (uint32_t)longest; img->long_state = 1;
+    return li;
+}
+
+enum { ACX_LONG_FALLBACK = 2 };         // internal: not this batch (the serial walk takes it)
+// the scan over D (any position-parallel plan), then one sweep per haystack over its records, a prefix sum, a move
+static int scan_long_ppm(acx_image* img, acx_image* li, const acx_scan_params* p, acx_result* r, hipStream_t s) {
+    acx_scan_params q = *p;
+    q.mode = ACX_SCAN_ALL; q.flags &= ~(int32_t)ACX_SCAN_ASYNC; q.want_final_state = 0; q.dev_skip = nullptr; q.dev_init_state = nullptr;
+    if (!ppm_plan(li, &q)) return ACX_LONG_FALLBACK;
+    if (!r->long_inner) { r->long_inner = new (std::nothrow) acx_result(); if (!r->long_inner) return acx_fail(ACX_E_NOMEM, "acx_scan_batch: out of memory"); }
+    acx_result* in = r->long_inner;
+    int rc = scan_batch_inner(li, &q, &in, (void*)s);
+    if (rc) return rc;
+    if (in->pending && (rc = result_complete(in))) return rc;
+    const size_t n = (size_t)p->n_hay;
+    if ((rc = r->counts.ensure(n + 1))) return rc;
+    if ((rc = r->match_off.ensure(n + 1))) return rc;
+    if ((rc = r->partials.ensure((size_t)acx_scan_num_partials((int64_t)n) + 2))) return rc;
+    if (r->timed) for (auto& e : r->ev) if (!e) HIP_TRY(hipEventCreate(&e));
+    if (r->timed) HIP_TRY(hipEventRecord(r->ev[2], s));
+    acx_long_args la;
+    la.rec = in->matches.p; la.off = in->match_off.p; la.n_hay = p->n_hay; la.index_base = p->dev_index_base;
+    la.longest = img->long_longest; la.counts = r->counts.p;
+    if ((rc = r->matches.ensure((size_t)in->total + 1))) return rc;     // (no more records than the scan over D found)
+    HIP_TRY(acx_launch_long_sweep(la, s));
+    HIP_TRY(acx_launch_scan(r->counts.p, (int64_t)n, r->match_off.p, r->partials.p, s));
+    HIP_TRY(acx_launch_long_move(in->matches.p, in->match_off.p, r->match_off.p, (int64_t)n, img->long_real, r->matches.p, s));
+    if (r->timed) HIP_TRY(hipEventRecord(r->ev[3], s));
+    int64_t total = 0;
+    HIP_TRY(hipMemcpyAsync(&total, r->match_off.p + n, sizeof total, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    r->total = total; r->has_final = false; r->pending = false; r->ppm = false;
+    if (r->timed) {
+        float t_in_walk = 0, t_in_scan = 0, t_in_exp = 0, t_in_total = 0, t_sweep = 0;
+        if (acx_result_timing(in, &t_in_walk, &t_in_scan, &t_in_exp, &t_in_total) != ACX_OK) { t_in_walk = t_in_total = 0; }
+        HIP_TRY(hipEventElapsedTime(&t_sweep, r->ev[2], r->ev[3]));
+        r->t_walk = t_in_walk; r->t_scan = t_in_total > t_in_walk ? t_in_total - t_in_walk : 0.f; r->t_expand = t_sweep;
+        r->t_total = (t_in_total > 0 ? t_in_total : t_in_walk) + t_sweep;
+    }
+    return ACX_OK;
+}
+
 static int scan_batch_inner(acx_image_t* img, const acx_scan_params* p, acx_result_t** result, void* stream_v) {
     if (!img || !p || !result) return acx_fail(ACX_E_INVAL, "acx_scan_batch: NULL argument");
     if (p->struct_bytes != sizeof(acx_scan_params))
@@ -1010,6 +1103,12 @@ static int scan_batch_inner(acx_image_t* img, const acx_scan_params* p, acx_resu
         const int plan = ppm_plan(img, p);
         if (plan == 1) r->skip_after = p->dev_skip;                 // (k_ppm_scan does not know dev_skip: its records are dropped afterwards)
         if (plan) return scan_ppm(img, p, r, s, plan);
+    }
+    // iter_long as a position-parallel scan over the dictionary of acx_long.cpp + one sweep (variant bit 25: the serial walk, A/B)
+    if (p->mode == ACX_SCAN_LONG && !p->dev_init_state && !p->want_final_state && p->n_hay > 0 && !((p->variant >> 25) & 1) &&
+        (p->dev_off || p->stride > 0) && !(p->flags & ACX_SCAN_SKIP_WS)) {
+        acx_image* li = image_long(img);
+        if (li) { const int rcl = scan_long_ppm(img, li, p, r, s); if (rcl != ACX_LONG_FALLBACK) return rcl; }
     }
     r->skip_after = p->dev_skip;                                      // (neither do the serial walks)
 

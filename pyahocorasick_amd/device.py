@@ -107,12 +107,13 @@ class Image:
     def itop_depth(self):
         return lib().acx_image_itop_depth(self.handle)
 
-    def ppm_kernel(self, stride=0, has_offsets=False, variant=0, dev_hay=0x1000, n_hay=1, min_hay_len=0):
-        """which kernel family an ACX_SCAN_ALL scan of such a batch takes (acx_scan_plan): None = the serial
-        walks, "scan" = k_ppm_scan, "stream" = k_ppm_stream, "stream4" = k_ppm_stream4 (four letters, fixed stride)"""
+    def ppm_kernel(self, stride=0, has_offsets=False, variant=0, dev_hay=0x1000, n_hay=1, min_hay_len=0, mode=ACX_SCAN_ALL):
+        """which kernel family a scan of such a batch takes (acx_scan_plan): None = the serial walks, "scan" = k_ppm_scan,
+        "stream" = k_ppm_stream, "stream4" = k_ppm_stream4 (four letters, fixed stride); mode ACX_SCAN_LONG: the family that
+        scans the dictionary of the position-parallel iter_long (acx_long.cpp), None = the serial walk"""
         p = ScanParams()
         p.struct_bytes = C.sizeof(ScanParams)
-        p.mode = ACX_SCAN_ALL
+        p.mode = mode
         p.dev_hay = dev_hay
         p.hay_capacity = max(1, int(stride)) * n_hay
         p.dev_off = 0x1000 if has_offsets else None
@@ -120,7 +121,7 @@ class Image:
         p.n_hay = n_hay
         p.variant = int(variant)
         p.min_hay_len = int(min_hay_len)
-        return {0: None, 1: "scan", 2: "stream", 3: "stream4"}.get(lib().acx_scan_plan(self.handle, C.byref(p)))
+        return {0: None, 1: "scan", 2: "stream", 3: "stream4", 11: "scan", 12: "stream", 13: "stream4"}.get(lib().acx_scan_plan(self.handle, C.byref(p)))
 
     def download_table(self):
         """the dense transition table the scans read, as uint32[n_states, n_classes] (tests/tools)"""

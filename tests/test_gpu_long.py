@@ -1,0 +1,104 @@
+"""GPU: ACX_SCAN_LONG as a position-parallel scan over the dictionary D = E + FE + U (acx_long.cpp) + one sweep per haystack
+(acx_long.hip), three ways: the new path (the scan plan says so: the test refuses to pass on the serial walk), the serial
+walk k_walk_long_sel (variant bit 25) and the oracle (oracle/ac_oracle.c orc_iter_long).  Bit-exact records and offsets."""
+import numpy as np
+import pytest
+
+import pyahocorasick_amd as acx
+from pyahocorasick_amd.device import DeviceBuffer, Image, Scanner
+from helpers import build_pair, dna_workload
+
+pytestmark = pytest.mark.gpu
+
+SERIAL = 1 << 25
+
+
+def _three_way(A, O, flat, off=None, n=None, L=None, base=None, expect_plan=True):
+    img = Image.from_automaton(A)
+    d_hay = DeviceBuffer.from_numpy(flat, pad=64)
+    if off is None:
+        host_off = np.arange(n + 1, dtype=np.int64) * L
+        kw = dict(stride=L)
+    else:
+        host_off = np.asarray(off, dtype=np.int64)
+        n = len(host_off) - 1
+        d_off = DeviceBuffer.from_numpy(host_off)
+        kw = dict(dev_off=d_off, min_hay_len=int(np.diff(host_off).min()) if n else 0)
+    d_base = DeviceBuffer.from_numpy(base) if base is not None else None
+    plan = img.ppm_kernel(stride=kw.get("stride", 0), has_offsets=off is not None, dev_hay=d_hay.ptr.value, n_hay=n,
+                          min_hay_len=kw.get("min_hay_len", 0), mode=acx.ACX_SCAN_LONG)
+    if expect_plan:
+        assert plan is not None, "iter_long did not take the position-parallel form"
+    mo, oe, ov = O.batch(flat.tobytes(), host_off, 1)
+    if base is not None:
+        oe = oe + np.repeat(base, np.diff(mo)).astype(np.int32)
+    for variant in (0, SERIAL):
+        sc = Scanner(img)
+        sc.scan(d_hay, len(flat), n, mode=acx.ACX_SCAN_LONG, dev_index_base=d_base, variant=variant, **kw)
+        moff, e, v, _ = sc.fetch()
+        assert np.array_equal(moff, mo) and np.array_equal(e, oe) and np.array_equal(v, ov), (variant, plan)
+    return plan
+
+
+def test_reference_examples_and_nested_keys():
+    for keys, text in (([b"he", b"her", b"hers", b"she"], b"_sherhershe_ shers hehehers he"),
+                       ([b"abcd", b"bc"], b"abc xbc abcd abcabcd bcbc"),
+                       ([b"abcde", b"bcd", b"c"], b"abc abcd abcde abcdx ccc"),
+                       ([b"a", b"ab", b"bab", b"ba"], b"abab babab bbaabb aaaa")):
+        A, O = build_pair(keys, list(range(7, 7 + len(keys))))
+        hays = text.split(b" ") * 40                                    # many short haystacks, unequal lengths: an offsets batch
+        flat = np.frombuffer(b"".join(hays), dtype=np.uint8)
+        off = np.concatenate([[0], np.cumsum([len(h) for h in hays])])
+        _three_way(A, O, flat, off=off, expect_plan=False)              # (haystacks below 8 bytes: whatever kernels take them)
+        one = np.frombuffer(text * 300, dtype=np.uint8)                 # one long haystack
+        _three_way(A, O, one, off=[0, len(one)], expect_plan=False)
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_random_dictionaries_fixed_stride_and_offsets(seed):
+    rng = np.random.default_rng(500 + seed)
+    alpha = np.frombuffer([b"ACGT", b"ab", b"abcdefghijklmnopqrstuvwxyz ", bytes(range(256))][seed % 4], dtype=np.uint8)
+    n_keys = int(rng.choice([30, 300, 3000]))
+    kmax = int(rng.choice([6, 12, 30]))
+    keys = list({bytes(rng.choice(alpha, size=int(k))) for k in rng.integers(1 if seed % 2 else 3, kmax + 1, size=n_keys)})
+    long_key = bytes(rng.choice(alpha, size=20))
+    keys = list(dict.fromkeys(keys + [long_key, long_key[:9], long_key[3:12], long_key[5:], long_key[7:9]]))
+    vals = [int(x) for x in rng.integers(-2**31, 2**31, size=len(keys))]
+    A, O = build_pair(keys, vals)
+    n, L = 3000, int(rng.choice([24, 100, 151]))
+    reads = alpha[rng.integers(0, len(alpha), size=(n, L))]
+    for i in range(0, n, 3):                                            # plant keys, some of them back to back
+        k = np.frombuffer(keys[int(rng.integers(0, len(keys)))], dtype=np.uint8)
+        if len(k) <= L:
+            o = int(rng.integers(0, L - len(k) + 1)); reads[i, o:o + len(k)] = k
+    reads[1, :20] = np.frombuffer(long_key, dtype=np.uint8)
+    flat = np.ascontiguousarray(reads.reshape(-1))
+    base = rng.integers(0, 1 << 20, size=n).astype(np.int32) if seed % 2 else None
+    _three_way(A, O, flat, n=n, L=L, base=base)
+    cuts = np.sort(rng.choice(np.arange(8, len(flat) - 8), size=500, replace=False))
+    cuts = cuts[np.diff(np.concatenate([[0], cuts])) >= 8]
+    off = np.concatenate([[0], cuts, [len(flat)]]).astype(np.int64)
+    if off[-1] - off[-2] < 8:
+        off = np.delete(off, -2)
+    _three_way(A, O, flat, off=off)
+
+
+def test_config5_shape_against_the_serial_walk():
+    """100 k ACGT keys, 150-byte reads: the plan must be stream4 over the dictionary; every record equal to the serial walk's
+    on 200 k reads, and to the oracle's on a sample"""
+    keys, reads = dna_workload(100_000, 200_000, 150, seed=11)
+    A, O = build_pair(keys)
+    img = Image.from_automaton(A)
+    n, L = reads.shape
+    flat = np.ascontiguousarray(reads.reshape(-1))
+    d_hay = DeviceBuffer.from_numpy(flat, pad=64)
+    assert img.ppm_kernel(stride=L, dev_hay=d_hay.ptr.value, n_hay=n, mode=acx.ACX_SCAN_LONG) == "stream4"
+    got = []
+    for variant in (0, SERIAL):
+        sc = Scanner(img)
+        sc.scan(d_hay, n * L, n, stride=L, mode=acx.ACX_SCAN_LONG, variant=variant)
+        got.append(sc.fetch()[:3])
+    assert all(np.array_equal(a, b) for a, b in zip(got[0], got[1]))
+    m = 3000
+    mo, oe, ov = O.batch(flat[: m * L].tobytes(), np.arange(m + 1, dtype=np.int64) * L, 1)
+    assert np.array_equal(got[0][0][: m + 1], mo) and np.array_equal(got[0][1][: mo[-1]], oe) and np.array_equal(got[0][2][: mo[-1]], ov)

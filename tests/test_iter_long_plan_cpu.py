@@ -186,3 +186,153 @@ def test_plan_on_random_dictionaries(seed):
     hays = [bytes(rng.choice(list(alpha), size=int(rng.integers(0, 80))).astype(np.uint8)) for _ in range(30)]
     hays += [long_key * 3, long_key[:9] + long_key, b""]
     _check(keys, hays)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# The same through the product's host code: acx_blob_long_trie (acx_long.cpp) builds the dictionary D = E + FE + U from a flat
+# image; the ORACLE's iter over D stands in for the position-parallel scan (records per haystack, position ascending,
+# longest first); sweep_records below is the sweep with its loops spelled out, sweep_records_lockstep the form k_long_sweep
+# (acx_long.hip) runs.
+def long_dictionary(A):
+    """-> (keys, packed values, real values, longest) of the dictionary the device scans for iter_long; None when the form does not apply"""
+    import ctypes as C
+    from pyahocorasick_amd._lib import check, lib
+    blob = A.flat_image_bytes()
+    trie, real, n, longest = C.c_void_p(), C.c_void_p(), C.c_int64(), C.c_int32()
+    check(lib().acx_blob_long_trie(blob, len(blob), C.byref(trie), C.byref(real), C.byref(n), C.byref(longest)))
+    if n.value == 0:
+        return None
+    try:
+        kb, ko, kv, kn = C.c_void_p(), C.POINTER(C.c_int64)(), C.POINTER(C.c_int64)(), C.c_int64()
+        check(lib().acx_trie_items(trie, None, 0, None, 0, 2, 0, C.byref(kb), C.byref(ko), C.byref(kv), C.byref(kn)))
+        assert kn.value == n.value
+        off = [ko[i] for i in range(kn.value + 1)]
+        raw = C.string_at(kb.value, off[-1]) if off[-1] else b""
+        keys = [raw[off[i]:off[i + 1]] for i in range(kn.value)]
+        vals = [kv[i] for i in range(kn.value)]
+        reals = list((C.c_int32 * n.value).from_address(real.value))
+        for p in (kb, C.cast(ko, C.c_void_p), C.cast(kv, C.c_void_p)):
+            lib().acx_blob_free(p)
+        return keys, vals, reals, longest.value
+    finally:
+        lib().acx_trie_free(trie)
+        lib().acx_blob_free(real)
+
+
+def sweep_records(ends, vals, reals, longest, base=0):
+    """k_long_sweep for one haystack: records (end, packed value) in scan order -> [(end, value)]"""
+    out, r, k, n = [], base, 0, len(ends)
+    while k < n:
+        e, v = ends[k], vals[k] & 0xFFFFFFFF
+        kind, ln = v >> 30, (v >> 24) & 63
+        fires = False
+        if kind:
+            lup = ((vals[k - 1] & 0xFFFFFFFF) >> 24) & 63 if k > 0 and ends[k - 1] == e else 0
+            fires = e - ln + 1 >= r and (lup == 0 or e - lup + 1 < r)
+        if not fires:
+            k += 1
+            continue
+        if kind == 2:
+            out.append((e, reals[v & 0xFFFFFF])); r = e + 1
+        else:
+            p, last, done = e - ln + 1, (e, reals[v & 0xFFFFFF]), False
+            j = k + 1
+            while j < n and ends[j] <= p + longest - 1:
+                v2 = vals[j] & 0xFFFFFFFF
+                k2, l2 = v2 >> 30, (v2 >> 24) & 63
+                if k2 and ends[j] - l2 + 1 == p:
+                    if k2 == 2:
+                        out.append((ends[j], reals[v2 & 0xFFFFFF])); r = ends[j] + 1; done = True
+                        break
+                    last = (ends[j], reals[v2 & 0xFFFFFF])
+                j += 1
+            if not done:
+                out.append(last); r = last[0] + 1
+        while k < n and ends[k] < r:
+            k += 1
+    return out
+
+
+def sweep_records_lockstep(ends, vals, reals, longest, base=0):
+    """the same sweep in the form k_long_sweep runs it (acx_long.hip sweep_one, statement by statement): ONE record per trip
+    of the loop — looking for a stop, or following a path; after a report the records behind the reported one are read again"""
+    out, r, k, n = [], base, 0, len(ends)
+    prev_e, prev_len = None, 0
+    path, p, last, k_last = False, 0, None, 0
+    reach = longest - 1
+    while True:
+        if k >= n:
+            if not path:
+                break
+            out.append((last[0], reals[last[1]])); r = last[0] + 1; k = k_last + 1; path = False; prev_e = None
+            continue
+        e, v = ends[k], vals[k] & 0xFFFFFFFF
+        kind, ln, idx = v >> 30, (v >> 24) & 63, v & 0xFFFFFF
+        if path:
+            if e > p + reach:
+                out.append((last[0], reals[last[1]])); r = last[0] + 1; k = k_last + 1; path = False; prev_e = None
+                continue
+            if kind and e - ln + 1 == p:
+                if kind == 2:
+                    out.append((e, reals[idx])); r = e + 1; path = False; prev_e, prev_len = e, ln
+                else:
+                    last, k_last = (e, idx), k
+            k += 1
+            continue
+        fires = e >= r and kind != 0 and e - ln + 1 >= r and (prev_e != e or e - prev_len + 1 < r)
+        prev_e, prev_len = e, ln
+        if fires:
+            if kind == 2:
+                out.append((e, reals[idx])); r = e + 1
+            else:
+                p, last, k_last, path = e - ln + 1, (e, idx), k, True
+        k += 1
+    return out
+
+
+def _check_product_dictionary(keys, hays, values=None):
+    from helpers import build_pair
+    keys = list(dict.fromkeys(keys))
+    values = list(range(1000, 1000 + len(keys))) if values is None else values
+    A, O = build_pair(keys, values)
+    D = long_dictionary(A)
+    assert D is not None
+    dkeys, dvals, reals, longest = D
+    assert longest == max(len(k) for k in dkeys) and len(set(dkeys)) == len(dkeys)
+    OD = orc.Oracle()
+    for k, v in zip(dkeys, dvals):
+        OD.add_word(k, v)
+    OD.make_automaton()
+    for h in hays:
+        recs = OD.iter(h)
+        got = sweep_records([e for e, _ in recs], [v for _, v in recs], reals, longest)
+        assert got == O.iter_long(h), (keys, h)
+        assert sweep_records_lockstep([e for e, _ in recs], [v for _, v in recs], reals, longest) == got, (keys, h)
+        got = sweep_records([e + 77 for e, _ in recs], [v for _, v in recs], reals, longest, base=77)      # index_base
+        assert got == [(e + 77, v) for e, v in O.iter_long(h)], (keys, h)
+
+
+def test_product_dictionary_on_the_reference_examples():
+    _check_product_dictionary([b"he", b"her", b"hers", b"she"], [b"_sherhershe_", b"shers", b"hehehers", b"", b"h", b"sh"])
+    _check_product_dictionary([b"abcd", b"bc"], [b"abc", b"xbc", b"abcd", b"abcabcd", b"bcbc"])
+    _check_product_dictionary([b"abcde", b"bcd", b"c"], [b"abc", b"abcd", b"abcde", b"abcdx", b"ccc"])
+    _check_product_dictionary([b"a", b"ab", b"bab", b"ba"], [b"abab", b"babab", b"bbaabb", b"aaaa"])
+
+
+@pytest.mark.parametrize("seed", range(8))
+def test_product_dictionary_on_random_dictionaries(seed):
+    rng = np.random.default_rng(100 + seed)
+    alpha = [b"ab", b"abc", b"ACGT", bytes(range(60, 90))][seed % 4]
+    n_keys = int(rng.integers(2, 60))
+    keys = [bytes(rng.choice(list(alpha), size=int(rng.integers(1, 12))).astype(np.uint8)) for _ in range(n_keys)]
+    long_key = bytes(rng.choice(list(alpha), size=14).astype(np.uint8))
+    keys += [long_key, long_key[:6], long_key[2:7], long_key[3:], long_key[4:5]]
+    hays = [bytes(rng.choice(list(alpha) + [33], size=int(rng.integers(0, 120))).astype(np.uint8)) for _ in range(40)]
+    hays += [long_key * 3, long_key[:9] + long_key, b""]
+    _check_product_dictionary(keys, hays, values=[int(x) for x in rng.integers(-2**31, 2**31, size=len(dict.fromkeys(keys)))])
+
+
+def test_dictionary_does_not_apply_to_keys_longer_than_63():
+    from helpers import build_pair
+    A, _ = build_pair([b"a" * 70, b"b"])
+    assert long_dictionary(A) is None
