@@ -46,42 +46,44 @@ struct LdsRecs {
 // one in front ends before r, so it cannot end where the current one ends.
 template <typename R>
 __device__ __forceinline__ uint32_t sweep_one(R rec, uint32_t n, int32_t r, int32_t reach) {
+    // Straight-line: every condition a 0 / 1 word, combined with & and | (a short-circuit && is an exec-mask region and a
+    // branch each — the first version of this loop was 80 basic blocks), one LDS read and one predicated write per trip.
     uint32_t k = 0, w = 0;                                             // the record to read, the next slot to write
     int32_t prev_e = INT32_MIN; uint32_t prev_len = 0;
-    bool path = false;                                                 // following a path
+    uint32_t path = 0;                                                 // 1: following a path
     int32_t p = 0; uint32_t last_e = 0, last_i = 0, k_last = 0;
+    if (n == 0u) return 0u;
     for (;;) {
-        if (k >= n) {
-            if (!path) break;
-            rec2_t out; out.x = last_e; out.y = last_i; rec.put(w++, out);          // (w <= k_last: never ahead of a record still to be read)
-            r = (int32_t)last_e + 1; k = k_last + 1; path = false; prev_e = INT32_MIN;
-            continue;
-        }
-        const rec2_t x = rec.get(k);
+        const uint32_t eor = k >= n ? 1u : 0u;                         // behind the last record
+        if (eor & (path ^ 1u)) break;
+        const rec2_t x = rec.get(eor ? n - 1u : k);
         const int32_t e = (int32_t)x.x;
         const uint32_t kind = x.y >> 30, len = (x.y >> 24) & 63u, idx = x.y & 0xFFFFFFu;
-        if (path) {
-            if (e > p + reach) {
-                rec2_t out; out.x = last_e; out.y = last_i; rec.put(w++, out);
-                r = (int32_t)last_e + 1; k = k_last + 1; path = false; prev_e = INT32_MIN;
-                continue;
-            }
-            if (kind != 0u && e - (int32_t)len + 1 == p) {
-                if (kind == 2u) {
-                    rec2_t out; out.x = (uint32_t)e; out.y = idx; rec.put(w++, out);
-                    r = e + 1; path = false; prev_e = e; prev_len = len;
-                } else { last_e = (uint32_t)e; last_i = idx; k_last = k; }
-            }
-            k++;
-            continue;
-        }
-        const bool fires = e >= r && kind != 0u && e - (int32_t)len + 1 >= r && (prev_e != e || e - (int32_t)prev_len + 1 < r);
-        prev_e = e; prev_len = len;
-        if (fires) {
-            if (kind == 2u) { rec2_t out; out.x = (uint32_t)e; out.y = idx; rec.put(w++, out); r = e + 1; }
-            else { p = e - (int32_t)len + 1; last_e = (uint32_t)e; last_i = idx; k_last = k; path = true; }
-        }
-        k++;
+        const int32_t start = e - (int32_t)len + 1;
+        const uint32_t is_fe = kind == 2u ? 1u : 0u, is_ev = kind != 0u ? 1u : 0u;
+        // following a path: its end (the remembered record is reported, the records behind it are read again), a record of the path
+        const uint32_t p_end = path & (eor | (e > p + reach ? 1u : 0u));
+        const uint32_t p_hit = path & (p_end ^ 1u) & is_ev & (start == p ? 1u : 0u);
+        const uint32_t p_fe = p_hit & is_fe, p_e = p_hit & (is_fe ^ 1u);
+        // looking for a stop
+        const uint32_t s_act = (path ^ 1u) & (eor ^ 1u);
+        const uint32_t longer_in = (prev_e == e ? 1u : 0u) & (e - (int32_t)prev_len + 1 >= r ? 1u : 0u);    // a longer path ends here and starts at or behind r
+        const uint32_t fires = s_act & is_ev & (start >= r ? 1u : 0u) & (longer_in ^ 1u);                     // (start >= r implies e >= r)
+        const uint32_t s_fe = fires & is_fe, s_e = fires & (is_fe ^ 1u);
+        const uint32_t emit = p_end | p_fe | s_fe;
+        rec2_t out; out.x = p_end ? last_e : (uint32_t)e; out.y = p_end ? last_i : idx;
+        if (emit) rec.put(w, out);                                      // (w <= the record being read or remembered: never ahead of one still to be read)
+        w += emit;
+        r = emit ? (int32_t)out.x + 1 : r;
+        const uint32_t keep = p_e | s_e;                                // remember this record
+        last_e = keep ? (uint32_t)e : last_e; last_i = keep ? idx : last_i;
+        const uint32_t k_next = p_end ? k_last + 1u : k + 1u;
+        k_last = keep ? k : k_last;
+        p = s_e ? start : p;
+        const uint32_t seen = s_act | p_fe;                             // this record is the one "in front" of the next
+        prev_e = p_end ? INT32_MIN : (seen ? e : prev_e); prev_len = seen ? len : prev_len;
+        path = (path & (p_end ^ 1u) & (p_fe ^ 1u)) | s_e;
+        k = k_next;
     }
     return w;
 }

@@ -255,38 +255,50 @@ def sweep_records(ends, vals, reals, longest, base=0):
 
 def sweep_records_lockstep(ends, vals, reals, longest, base=0):
     """the same sweep in the form k_long_sweep runs it (acx_long.hip sweep_one, statement by statement): ONE record per trip
-    of the loop — looking for a stop, or following a path; after a report the records behind the reported one are read again"""
-    out, r, k, n = [], base, 0, len(ends)
-    prev_e, prev_len = None, 0
-    path, p, last, k_last = False, 0, None, 0
+    of the loop, every condition a 0 / 1 word — looking for a stop, or following a path; after a report at the end of a path
+    the records behind the reported one are read again"""
+    INT_MIN = -(1 << 31)
+    out, r, k, w, n = [], base, 0, 0, len(ends)
+    prev_e, prev_len = INT_MIN, 0
+    path, p, last_e, last_i, k_last = 0, 0, 0, 0, 0
     reach = longest - 1
+    if n == 0:
+        return out
     while True:
-        if k >= n:
-            if not path:
-                break
-            out.append((last[0], reals[last[1]])); r = last[0] + 1; k = k_last + 1; path = False; prev_e = None
-            continue
-        e, v = ends[k], vals[k] & 0xFFFFFFFF
+        eor = 1 if k >= n else 0
+        if eor & (path ^ 1):
+            break
+        kk = n - 1 if eor else k
+        e, v = ends[kk], vals[kk] & 0xFFFFFFFF
         kind, ln, idx = v >> 30, (v >> 24) & 63, v & 0xFFFFFF
-        if path:
-            if e > p + reach:
-                out.append((last[0], reals[last[1]])); r = last[0] + 1; k = k_last + 1; path = False; prev_e = None
-                continue
-            if kind and e - ln + 1 == p:
-                if kind == 2:
-                    out.append((e, reals[idx])); r = e + 1; path = False; prev_e, prev_len = e, ln
-                else:
-                    last, k_last = (e, idx), k
-            k += 1
-            continue
-        fires = e >= r and kind != 0 and e - ln + 1 >= r and (prev_e != e or e - prev_len + 1 < r)
-        prev_e, prev_len = e, ln
-        if fires:
-            if kind == 2:
-                out.append((e, reals[idx])); r = e + 1
-            else:
-                p, last, k_last, path = e - ln + 1, (e, idx), k, True
-        k += 1
+        start = e - ln + 1
+        is_fe, is_ev = int(kind == 2), int(kind != 0)
+        p_end = path & (eor | int(e > p + reach))
+        p_hit = path & (p_end ^ 1) & is_ev & int(start == p)
+        p_fe, p_e = p_hit & is_fe, p_hit & (is_fe ^ 1)
+        s_act = (path ^ 1) & (eor ^ 1)
+        longer_in = int(prev_e == e) & int(e - prev_len + 1 >= r)
+        fires = s_act & is_ev & int(start >= r) & (longer_in ^ 1)
+        s_fe, s_e = fires & is_fe, fires & (is_fe ^ 1)
+        emit = p_end | p_fe | s_fe
+        ox, oy = (last_e, last_i) if p_end else (e, idx)
+        if emit:
+            out.append((ox, reals[oy])); assert w <= kk
+        w += emit
+        r = ox + 1 if emit else r
+        keep = p_e | s_e
+        if keep:
+            last_e, last_i = e, idx
+        k_next = k_last + 1 if p_end else k + 1
+        if keep:
+            k_last = k
+        if s_e:
+            p = start
+        seen = s_act | p_fe
+        prev_e = INT_MIN if p_end else (e if seen else prev_e)
+        prev_len = ln if seen else prev_len
+        path = (path & (p_end ^ 1) & (p_fe ^ 1)) | s_e
+        k = k_next
     return out
 
 
