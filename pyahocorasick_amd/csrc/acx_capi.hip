@@ -1064,7 +1064,7 @@ static int scan_long_ppm(acx_image* img, acx_image* li, const acx_scan_params* p
         r->t_walk = t_in_walk; r->t_scan = t_in_total > t_in_walk ? t_in_total - t_in_walk : 0.f; r->t_expand = t_sweep;
         r->t_total = (t_in_total > 0 ? t_in_total : t_in_walk) + t_sweep;
     }
-    return ACX_OK;
+    return finish_records(r);                                         // (ACX_SCAN_SKIP_WS: the indices go back to the batch the caller gave)
 }
 
 static int scan_batch_inner(acx_image_t* img, const acx_scan_params* p, acx_result_t** result, void* stream_v) {
