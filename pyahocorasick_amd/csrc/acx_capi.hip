@@ -5,6 +5,7 @@
 // entry point fails with ACX_E_NODEVICE / ACX_E_HIP.
 #include "acx_internal.h"
 #include "acx_kernels.h"
+#include "acx_long.h"
 
 #include <hip/hip_runtime.h>
 #include <cstdarg>

@@ -186,17 +186,6 @@ int64_t acx_ppm_grid_blocks(const acx_ppm_lds& lds, int64_t n_items_bound, uint3
 // state after a haystack = the state after its last longest_word bytes walked from the root
 hipError_t acx_launch_tail_state(const acx_walk_args& a, int32_t longest, hipStream_t s);
 int acx_num_cus();
-// iter_long from the records of a position-parallel scan over the dictionary of acx_long.cpp (acx_long.hip)
-struct acx_long_args {
-    uint2* rec;                    // the scan's records, per haystack; the reported ones are written over them from the front
-    const int64_t* off;            // their offsets [n_hay + 1]
-    int64_t n_hay;
-    const int32_t* index_base;     // nullable: the first index of haystack h (the records' end indices count from it)
-    uint32_t longest;              // longest dictionary entry
-    int32_t* counts;               // out: records reported per haystack
-};
-hipError_t acx_launch_long_sweep(const acx_long_args& a, hipStream_t s);
-hipError_t acx_launch_long_move(const uint2* rec, const int64_t* off, const int64_t* new_off, int64_t n_hay, const int32_t* real, uint2* dst, hipStream_t s);
 // dev_skip for the kernel families that do not know it (serial walks, k_ppm_scan): the records of the context — a prefix
 // of every haystack's records, they are sorted by end_index — are dropped and the rest rebased.  kept[h] and new offsets
 // come from k_skip_count + scan, then k_skip_move copies into `dst`.

@@ -14,6 +14,7 @@
 // written over the records from the front (never ahead of one still to be read); k_long_move puts them where the caller
 // finds them.
 #include "acx_kernels.h"
+#include "acx_long.h"
 
 #include <hip/hip_runtime.h>
 #include <stdint.h>
