@@ -73,10 +73,16 @@ def parse():
     ap.add_argument("--mode", choices=["iter", "iter_long"], default="iter")
     ap.add_argument("--scaling", choices=["weak", "strong"], default="weak")
     ap.add_argument("--variant", type=int, default=0)
-    ap.add_argument("--scan-streams", type=int, default=2,
-                    help="streams the scans of consecutive steps alternate over (default 2: the blocks of step k + 1 start on the CUs that "
-                         "step k's finished blocks leave — one block of the scan kernel fills a CU's LDS, so the kernels share the chip only "
-                         "at that seam; 1: one stream, every scan kernel starts when the one before has drained: 500 instead of 530 GB/s)")
+    ap.add_argument("--scan-streams", type=int, default=1,
+                    help="streams the scans of consecutive steps alternate over.  Default 1: `value` and `roofline` come from the regime in which "
+                         "HIP events, the pre-pass and rocprofv3 agree on the scan kernel's launch duration (0.2615 / 0.2618 ms / 254 us).  On 2 "
+                         "the blocks of step k + 1 start on the CUs step k's finished blocks leave (512 -> 546 GB/s), but a launch's span then "
+                         "overlaps its neighbour's: rocprofv3 says 339 us where the events say 0.2675 ms (tools/r4_clock_check.sh) — so the "
+                         "--two-stream-leg measures that mode in a timed region of its own (`two_scan_streams`) and reports no roofline for it")
+    ap.add_argument("--two-stream-leg", action="store_true",
+                    help="after the headline measurement, time the same K steps once more with the scans on two streams and report it as "
+                         "`two_scan_streams` (throughput only).  Not part of the default command: its launches would mix into the kernel "
+                         "averages of a rocprofv3 run of that command (146 launches averaging 296 us = half 254, half 339)")
     ap.add_argument("--pipeline", type=int, default=2,
                     help="result objects kept in flight per GPU (ACX_SCAN_ASYNC): the host queues step i+1 and reads "
                          "the counters of step i-1 while step i runs; on ONE stream the kernels of consecutive steps "
@@ -307,7 +313,7 @@ def make_batches(torch, dev, workload, keys, vocab, n_batches, reads, read_len, 
     return batches, host0, e2e0, corpus_bytes
 
 
-SCAN_STREAMS = 2
+SCAN_STREAMS = 1
 
 
 def measure(torch, dist, dev, image, batches, mode, steps, warmup, P, event_every, variant):
@@ -461,9 +467,9 @@ def roofline_entry(image, batches, m, mode_name, workload, variant, steps, event
         # HIP events around the kernel, on its stream, inside the timed region: in every N-th step (an event
         # pair costs the stream ~19 us of idle time in the step it is in)
         "kernel_events": {"every_nth_step": event_every, "samples": len(m["walk_ms"])},
-        # with two scan streams the launch of step k + 1 begins while the last blocks of step k still run: a launch's duration
-        # then covers CUs it shares at both seams (it can exceed ms_per_step); kernel_alone_ms is the same kernel in the
-        # pre-pass, where every step is waited for before the next is issued
+        # kernel_alone_ms: the same kernel in the pre-pass, where every step is waited for before the next is issued.  With
+        # --scan-streams 2 launches overlap and kernel_avg_ms (HIP events) is NOT what rocprofv3 reports as the launch's span
+        # (0.2675 ms against 339 us): achieved / frac of such a line are not comparable with the profile — the default is 1
         "launches_overlap": m["scan_streams"] > 1, "kernel_alone_ms": round(pre["walk"], 4),
         # HBM bytes of the dominant kernel per launch from the PMC passes (FETCH_SIZE + WRITE_SIZE): `traffic` is the figure
         # corrected as /opt/skills/guides/MI355X_MICROARCH.md prescribes for gfx950 (FETCH_SIZE x 2: it tallies 128-B requests
@@ -656,6 +662,19 @@ def main():
             out["end_to_end_GBps"] = hflat.size / best / 1e9
             out["end_to_end_ms"] = best * 1e3
             _lib.lib().acx_result_free(res_e2e)
+        if world == 1 and args.mode == "iter" and args.scan_streams == 1 and P > 1 and args.two_stream_leg:
+            # The same K steps with the scans of consecutive steps on TWO streams, in a timed region of its own (same barriers).
+            # Throughput only: with two streams a launch's span overlaps its neighbour's, and the instruments no longer agree on
+            # its duration (HIP events 0.2675 ms, rocprofv3 339 us; on one stream 0.2615 ms / 254 us: tools/r4_clock_check.sh,
+            # profiles/r4_clock_check.txt) — so no roofline is derived from this mode, and it is never `value`.
+            SCAN_STREAMS = 2
+            m2 = measure(torch, None, dev, image, batches, mode, args.steps, args.warmup, P, 0, args.variant)
+            SCAN_STREAMS = 1
+            out["two_scan_streams"] = {"value": m2["bytes_rank"] / m2["dt"] / 1e9, "unit": "GB/s", "ms_per_step": m2["dt"] / args.steps * 1e3,
+                                       "steps": args.steps, "step_ms_host_intervals": m2["step_ms"], "scan_streams": m2["scan_streams"],
+                                       "roofline": None,
+                                       "note": "scans of consecutive steps alternate over two streams (--scan-streams 2); launch durations overlap: no per-launch figure"}
+            del m2
         if world == 1 and args.cpu_sample_reads != 0 and host0:
             sample = host0 if not args.cpu_sample_reads else host0[: args.cpu_sample_reads]
             out["cpu_baseline"] = cpu_baseline(keys, sample, args.mode)
