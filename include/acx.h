@@ -331,6 +331,11 @@ void acx_result_free(acx_result_t* r);
 int  acx_scan_host(acx_image_t* img, int mode, const uint8_t* hay, const int64_t* off, int64_t n_hay,
                    const int32_t* init_state, const int32_t* index_base,
                    acx_result_t** result);
+/* The same for a caller that does not continue the walk (Automaton.iter_batch): no carried-in states, no final states.
+ * ACX_SCAN_LONG then takes its position-parallel form (acx_blob_long_trie above) where that applies, and an
+ * ACX_SCAN_ALL image never builds its dense table.  acx_result_fetch_host returns final_state = NULL. */
+int  acx_scan_host_nofinal(acx_image_t* img, int mode, const uint8_t* hay, const int64_t* off, int64_t n_hay,
+                           const int32_t* index_base, acx_result_t** result);
 /* acx_scan_host / acx_scan_host_ctx scan a batch larger than this many bytes in groups of haystacks, one launch each, and
  * assemble one result (default, and 0: 4 GiB — what one launch stages).  Process-wide. */
 void acx_set_host_group_bytes(int64_t bytes);

@@ -109,6 +109,7 @@ SIGNATURES = {
     "acx_result_timing": (C.c_int, [_P] + [C.POINTER(C.c_float)] * 4),
     "acx_result_free": (None, [_P]),
     "acx_scan_host": (C.c_int, [_P, C.c_int, _P, _P, C.c_int64, _P, _P, _PP]),
+    "acx_scan_host_nofinal": (C.c_int, [_P, C.c_int, _P, _P, C.c_int64, _P, _PP]),
     "acx_scan_host_ctx": (C.c_int, [_P, _P, _P, C.c_int64, _P, _P, _P, C.c_int32, _PP]),
     "acx_device_count": (C.c_int, [C.POINTER(C.c_int)]),
     "acx_device_set": (C.c_int, [C.c_int]),

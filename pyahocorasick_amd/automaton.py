@@ -465,8 +465,12 @@ class Automaton:
             f.write(self.flat_image_bytes())
 
     # ---- batch scan (NEW: the reference scans one haystack per iterator) ---------------
-    def scan_batch(self, data, offsets, mode=ACX_SCAN_ALL, init_state=None, index_base=None, context=None, skip_white_space=False):
+    def scan_batch(self, data, offsets, mode=ACX_SCAN_ALL, init_state=None, index_base=None, context=None, skip_white_space=False,
+                   final_states=True):
         """Scan haystacks data[offsets[k]:offsets[k+1]] on the GPU; returns a BatchResult.
+
+        final_states=False (no init_state): the result carries no final states (acx_scan_host_nofinal) — what a caller that
+        does not continue the walk asks for; ACX_SCAN_LONG then runs position-parallel.
 
         data: bytes-like; offsets: int64[n+1] with offsets[0] == 0.
         context (ACX_SCAN_ALL): (bytes-like, int64[n+1]) — the bytes a stream delivered in front of every haystack
@@ -504,11 +508,15 @@ class Automaton:
                 raise ValueError("bad context offsets")
             ctx = (cbuf, coff)
         with self._lock:
-            return self._scan_locked(buf, off, n, mode, init, base, ctx, ACX_SCAN_SKIP_WS if skip_white_space else 0)
+            return self._scan_locked(buf, off, n, mode, init, base, ctx, ACX_SCAN_SKIP_WS if skip_white_space else 0,
+                                     final_states=final_states or init is not None)
 
-    def _scan_locked(self, buf, off, n, mode, init, base, ctx=None, flags=0):
+    def _scan_locked(self, buf, off, n, mode, init, base, ctx=None, flags=0, final_states=True):
         img = self._ensure_image()
-        if ctx is not None:
+        if ctx is None and not final_states:
+            check(lib().acx_scan_host_nofinal(img.handle, mode, buf.ctypes.data if buf.size else None, off.ctypes.data, n,
+                                              base.ctypes.data if base is not None else None, C.byref(self._result)))
+        elif ctx is not None:
             check(lib().acx_scan_host_ctx(img.handle, buf.ctypes.data if buf.size else None, off.ctypes.data, n,
                                           ctx[0].ctypes.data if ctx[0].size else C.c_void_p(1), ctx[1].ctypes.data,
                                           base.ctypes.data if base is not None else None, flags, C.byref(self._result)))
@@ -538,7 +546,7 @@ class Automaton:
         for h in haystacks:
             if not isinstance(h, bytes):
                 raise TypeError("bytes required")
-        return self.scan_batch(b"".join(haystacks), off, ACX_SCAN_LONG if long else ACX_SCAN_ALL).tolists()
+        return self.scan_batch(b"".join(haystacks), off, ACX_SCAN_LONG if long else ACX_SCAN_ALL, final_states=False).tolists()
 
     # ---- dict-like enumeration (src/Automaton.c:722-873, src/AutomatonItemsIter.c) ---------------
     def _items_iter(self, args, what):

@@ -1554,6 +1554,10 @@ extern "C" int acx_scan_host(acx_image_t* img, int mode, const uint8_t* hay, con
                              const int32_t* init_state, const int32_t* index_base, acx_result_t** result) {
     return scan_host_impl(img, mode, hay, off, n_hay, init_state, index_base, result, 1, 0);
 }
+extern "C" int acx_scan_host_nofinal(acx_image_t* img, int mode, const uint8_t* hay, const int64_t* off, int64_t n_hay,
+                                     const int32_t* index_base, acx_result_t** result) {
+    return scan_host_impl(img, mode, hay, off, n_hay, nullptr, index_base, result, 0, 0);
+}
 
 // want_final = 0: no final states (an image with the position-parallel structures then never builds its dense table
 // for ACX_SCAN_ALL: acx_scan_host_ctx, what the iterators and find_all call)
