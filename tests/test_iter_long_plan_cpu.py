@@ -348,3 +348,16 @@ def test_dictionary_does_not_apply_to_keys_longer_than_63():
     from helpers import build_pair
     A, _ = build_pair([b"a" * 70, b"b"])
     assert long_dictionary(A) is None
+
+
+def test_dictionary_of_config5_has_the_size_the_design_counts_on():
+    """100 k ACGT keys of 8-32 letters (BASELINE config 2 / 5): D = 100 000 E + 59 612 FE + 20 921 U-only = 180 533 entries, none longer
+    than 32 — the numbers DESIGN.md §4.3b prices the position-parallel iter_long with (1.8 x the scan of the keys alone)."""
+    from helpers import build_pair
+    from pyahocorasick_amd.workloads import dna_keys
+    keys = dna_keys(100_000, seed=0)
+    A, _ = build_pair(keys)
+    dkeys, dvals, reals, longest = long_dictionary(A)
+    kinds = np.array([(v & 0xFFFFFFFF) >> 30 for v in dvals])
+    assert len(dkeys) == 180_533 and int((kinds == 1).sum()) == 100_000 and int((kinds == 2).sum()) == 59_612 and int((kinds == 0).sum()) == 20_921
+    assert longest == 32 and all(((v & 0xFFFFFFFF) >> 24) & 63 == len(k) for k, v in zip(dkeys[:2000], dvals[:2000]))
