@@ -4,10 +4,13 @@
 Default workload (BASELINE.json configs[1], the configuration the metric is quoted on):
 100,000 unique ACGT keys of length U[8,32] (seed 0) -> one flattened automaton;
 batches of 1,000,000 x 150 B DNA-style reads (every even read has a planted key), resident in HBM
-before the timed region.  A "step" is one pass of the hot path over ONE batch (scan kernel +
-prefix sum + gather -> match records and per-read offsets in HBM).  The timed loop ROTATES over
---batches distinct batches (default 4 x 150 MB = 600 MB, beyond the 256 MiB Infinity Cache), so the
-haystack bytes of a step come from HBM, not from a cache that the previous step filled.
+before the timed region.  A pass of the hot path scans ONE batch (scan kernel + gather -> match
+records and per-read offsets in HBM); `ms_per_step` is the time of one such pass.  A pass is a third
+of a millisecond, so each of the K driver steps is R passes (`inner_repeats`, chosen so that the
+timed region lasts >= --min-timed-ms: a 6 ms region would let one barrier's skew decide a multi-GPU
+line): the timed region is K x R passes, `value` = all bytes scanned / its duration.  The loop ROTATES
+over --batches distinct batches (default 4 x 150 MB = 600 MB, beyond the 256 MiB Infinity Cache), so the
+haystack bytes of a pass come from HBM, not from a cache that the previous pass filled.
 
     python bench.py [--gpus N --steps K --warmup W]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
@@ -20,10 +23,13 @@ haystack bytes of a step come from HBM, not from a cache that the previous step 
     --scaling strong           N > 1: ONE fixed corpus (c2: the read batches, c3: the text, c4: the packets) is cut
                                into N contiguous shards (reads by count, packets by BYTES, text with a
                                longest_word-1 halo); default "weak": every rank scans its own batches of the full size
+    --workload c2o | c2k       config 2 as the GENERAL stream kernel takes it: the reads as an offsets batch of ragged
+                               lengths U[100,150]; keys of 8-64 letters
     --configs all|none         N = 1, default workload only: after the headline measurement the other named
                                single-GPU configurations are measured in the same run and reported under
-                               "configs": c5 (iter_long, same automaton and batches), c3 and c4 (two batches each) —
-                               each with value, ms_per_step, roofline and a sample-limited cpu_baseline
+                               "configs": c5 (iter_long, same automaton and batches), c2_offsets, c2_long_keys, c3 and
+                               c4 (two batches each) — each with value, ms_per_step, roofline and a sample-limited
+                               cpu_baseline
 
 N > 1: one process per GPU; rank 0 builds + flattens the automaton and the flat image is replicated
 with ONE RCCL broadcast; no data-path collective; time = max over ranks, value = all ranks' bytes /
@@ -62,9 +68,10 @@ KERNEL_SOURCES = {
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=60)          # (a step is a third of a millisecond: 60 of them make the timed region 19 ms)
+    ap.add_argument("--steps", type=int, default=20)          # (K driver steps of R passes each: --inner-repeats)
     ap.add_argument("--warmup", type=int, default=4)
-    ap.add_argument("--workload", choices=["c2", "c3", "c4"], default="c2")
+    ap.add_argument("--workload", choices=["c2", "c2o", "c2k", "c3", "c4"], default="c2",
+                    help="c2o / c2k: config 2 as the general stream kernel takes it — the reads as an offsets batch of ragged lengths, keys of 8-64 letters")
     ap.add_argument("--keys", type=int, default=None, help="dictionary size (default: 100,000; c4: 1,000,000)")
     ap.add_argument("--reads", type=int, default=1_000_000)
     ap.add_argument("--read-len", type=int, default=150)
@@ -73,16 +80,25 @@ def parse():
     ap.add_argument("--mode", choices=["iter", "iter_long"], default="iter")
     ap.add_argument("--scaling", choices=["weak", "strong"], default="weak")
     ap.add_argument("--variant", type=int, default=0)
-    ap.add_argument("--scan-streams", type=int, default=1,
-                    help="streams the scans of consecutive steps alternate over.  Default 1: `value` and `roofline` come from the regime in which "
-                         "HIP events, the pre-pass and rocprofv3 agree on the scan kernel's launch duration (0.2615 / 0.2618 ms / 254 us).  On 2 "
-                         "the blocks of step k + 1 start on the CUs step k's finished blocks leave (512 -> 546 GB/s), but a launch's span then "
-                         "overlaps its neighbour's: rocprofv3 says 339 us where the events say 0.2675 ms (tools/r4_clock_check.sh) — so the "
-                         "--two-stream-leg measures that mode in a timed region of its own (`two_scan_streams`) and reports no roofline for it")
-    ap.add_argument("--two-stream-leg", action="store_true",
-                    help="after the headline measurement, time the same K steps once more with the scans on two streams and report it as "
-                         "`two_scan_streams` (throughput only).  Not part of the default command: its launches would mix into the kernel "
-                         "averages of a rocprofv3 run of that command (146 launches averaging 296 us = half 254, half 339)")
+    ap.add_argument("--scan-streams", type=int, default=2,
+                    help="streams the scans of consecutive steps alternate over (position-parallel scans; the batches of consecutive steps are "
+                         "independent).  Default 2: the blocks of step k + 1 start on the CUs step k's finished blocks leave, so the uneven end "
+                         "of one launch and the launch seam (step - kernel = 35-41 us on one stream) are hidden (512 -> 546 GB/s).  Launch spans "
+                         "then OVERLAP, and no per-launch duration describes the kernel any more (rocprofv3: 339 us per launch, HIP events: "
+                         "0.2675 ms, tools/r4_clock_check.sh): `roofline` is therefore computed from the UNION of the dominant kernel's spans per "
+                         "launch — the timed region / launches, an upper bound of it — which tools/roofline_check.py recomputes from a rocprofv3 "
+                         "kernel trace; `roofline.kernel_alone` holds the launch measured with the chip to itself.  1: one stream — every clock "
+                         "agrees on the launch duration (the regime of rounds 1-4 and of profiles/r5_c2_kernel_stats.md)")
+    ap.add_argument("--one-stream-leg", action="store_true",
+                    help="after the headline measurement, time the same steps once more with every scan on ONE stream and report it as "
+                         "`one_scan_stream` (value, step, the kernel's launch duration by HIP events inside that timed region).  Not part of the "
+                         "default command: its launches would mix into the averages of a rocprofv3 run of that command")
+    ap.add_argument("--inner-repeats", type=int, default=0,
+                    help="R: every one of the K driver steps is R passes of the hot path, each over one batch (the timed region is K x R batch "
+                         "scans; ms_per_step = region / (K x R) = one batch scan, `value` = bytes / region).  0 (default): R is chosen from a "
+                         "short calibration so that the region lasts --min-timed-ms whatever --steps says — a step is a third of a "
+                         "millisecond, and a region of 6 ms would let one barrier's skew decide an 8-GPU line")
+    ap.add_argument("--min-timed-ms", type=float, default=250.0, help="length of the timed region that the automatic --inner-repeats aims at")
     ap.add_argument("--pipeline", type=int, default=2,
                     help="result objects kept in flight per GPU (ACX_SCAN_ASYNC): the host queues step i+1 and reads "
                          "the counters of step i-1 while step i runs; on ONE stream the kernels of consecutive steps "
@@ -100,6 +116,9 @@ def parse():
     ap.add_argument("--configs", choices=["all", "none"], default=None,
                     help="the other named single-GPU configurations in the same run (default: all for the default command on one GPU)")
     ap.add_argument("--lib", default=None, help="another build of libacx.so (development A/B, tools/build_variant.sh) instead of the package's")
+    ap.add_argument("--dry-run", action="store_true",
+                    help="no GPU: the ranks come up over gloo, the blob is broadcast and validated, every rank stages its shard on the host as "
+                         "the real run does, byte and haystack counts are reduced and printed as one JSON line (tests/test_parallel_cpu.py)")
     ap.add_argument("--launch-check", action="store_true",
                     help="start the ranks (gloo, no GPU), agree on the world size, print {\"n_gpus\": N, \"launch_check\": true} and exit: "
                          "tests/test_parallel_cpu.py runs the self-launch path of --gpus N with it")
@@ -145,6 +164,65 @@ def launch_check(args):
         raise SystemExit("launch check: %d ranks answered, --gpus %d" % (seen, args.gpus))
     if rank == 0:
         print(json.dumps({"n_gpus": seen, "launch_check": True}), flush=True)
+
+
+def dry_run(args):
+    """--dry-run: everything of a multi-rank run that needs no GPU, over gloo — the ranks come up and agree on the world
+    size, rank 0 builds and flattens the dictionary, ONE broadcast replicates the blob (checksum verified on every rank),
+    every rank stages its shard of --batches batches on the host exactly as the real run does (weak or strong), and the byte
+    and haystack counts are reduced as the real line reduces them.  Nothing is scanned (the product has no CPU scan); rank 0
+    prints {"dry_run": true, "n_gpus", "bytes_total", "corpus_bytes_per_batch", "per_rank": [...]}.
+    tests/test_parallel_cpu.py runs it with small sizes and checks shard cover / disjointness against the oracle."""
+    import hashlib as hl
+    sys.stdout.flush()
+    json_fd = os.dup(1)                                      # (gloo reports its connections on fd 1: the JSON line gets a descriptor of its own)
+    os.dup2(2, 1)
+    import torch
+    import torch.distributed as dist
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    if world > 1:
+        dist.init_process_group("gloo")
+    import pyahocorasick_amd as acx
+    from pyahocorasick_amd import _lib
+    from pyahocorasick_amd.parallel import broadcast_blob
+    import ctypes as C
+    n_keys = args.keys or (1_000_000 if args.workload == "c4" else 100_000)
+    keys, vocab = build_keys(args.workload, n_keys)
+    strong = args.scaling == "strong" and world > 1
+    if strong and args.mode == "iter_long" and args.workload == "c3":
+        raise SystemExit("iter_long restarts depend on everything in front of a position: ONE haystack does not shard (config 3 is an iter workload)")
+    blob = None
+    if rank == 0:
+        A = acx.Automaton(acx.STORE_INTS)
+        A.add_words(keys, range(len(keys)))
+        A.make_automaton()
+        blob = A.flat_image_bytes()
+    t = broadcast_blob(blob, src=0)
+    got = t.numpy().tobytes()
+    _lib.check(_lib.lib().acx_blob_validate((C.c_char * len(got)).from_buffer_copy(got), len(got)))     # header + checksum, on every rank
+    batches, _, _, corpus_bytes = make_batches(torch, None, args.workload, keys, vocab, max(1, args.batches), args.reads, args.read_len,
+                                               args.batch_mb, rank, world, strong)
+    mine = [sum(b[1] for b in batches), sum(b[2] for b in batches), len(got)]
+    sha = hl.sha256()
+    for b in batches:
+        sha.update(np.ascontiguousarray(b[0]).tobytes())
+    rows = [mine + [int(sha.hexdigest()[:12], 16)]]
+    if world > 1:
+        tt = torch.zeros(world, 4, dtype=torch.int64)
+        tt[rank] = torch.tensor(rows[0], dtype=torch.int64)
+        dist.all_reduce(tt)
+        rows = tt.tolist()
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        os.write(json_fd, (json.dumps({"dry_run": True, "n_gpus": world, "scaling": "strong" if strong else "weak", "mode": args.mode, "workload": args.workload,
+                          "batches": len(batches), "bytes_total": sum(r[0] for r in rows), "haystacks_total": sum(r[1] for r in rows),
+                          "corpus_bytes_per_batch": int(np.mean(corpus_bytes)), "corpus_bytes_all_batches": int(np.sum(corpus_bytes)),
+                          "blob_bytes": rows[0][2], "blob_bytes_equal_on_all_ranks": len({r[2] for r in rows}) == 1,
+                          "per_rank": [{"rank": i, "bytes": r[0], "haystacks": r[1], "shard_sha48": "%012x" % r[3]} for i, r in enumerate(rows)]}) + "\n").encode())
 
 
 def kernel_source_hash(kernel):
@@ -229,6 +307,8 @@ def cpu_baseline(keys, hays, mode):
 
 WORKLOAD_NAMES = {
     "c2": "config2: %d ACGT keys 8-32 B, %d x %d B reads per batch",
+    "c2o": "config2 delivered as an offsets batch: %d ACGT keys 8-32 B, %d reads per batch cut to U[100,%d] B (the general stream kernel)",
+    "c2k": "config2 with longer keys: %d ACGT keys 8-64 B, %d x %d B reads per batch (the general stream kernel)",
     "c3": "config3 shape: %d multi-word text keys, %d MiB of text per batch scanned as ONE haystack",
     "c4": "config4 shape: %d Snort-style byte signatures 4-128 B, %d MiB of packets 64-1500 B per batch",
 }
@@ -237,8 +317,10 @@ WORKLOAD_NAMES = {
 def build_keys(workload, n_keys):
     from pyahocorasick_amd import workloads as W
     vocab = None
-    if workload == "c2":
+    if workload in ("c2", "c2o"):
         keys = W.dna_keys(n_keys, seed=0)
+    elif workload == "c2k":
+        keys = W.dna_keys(n_keys, seed=0, klo=8, khi=64)
     elif workload == "c3":
         vocab = W.text_vocab(1_000_000 if n_keys >= 100_000 else 10 * n_keys, seed=2)
         keys = W.text_keys(vocab, n_keys, seed=3)
@@ -266,13 +348,13 @@ def strong_shard(workload, data, off, rank, world, longest):
 def make_batches(torch, dev, workload, keys, vocab, n_batches, reads, read_len, batch_mb, rank, world, strong):
     """this rank's batches, resident in HBM: [(device bytes, capacity, n haystacks, device offsets or None, stride, shortest)],
     the haystacks of batch 0 for the CPU baseline, batch 0 as (bytes, offsets) for the host-to-host leg, bytes of the whole
-    corpus of one step over all ranks"""
+    corpus of one step over all ranks.  dev = None (--dry-run, no GPU): the batches stay numpy arrays on the host."""
     from pyahocorasick_amd import workloads as W
     longest = max(len(k) for k in keys)
     batches, host0, e2e0, corpus_bytes = [], None, None, []
     for b in range(n_batches):
         seed = 1 + b + (0 if strong else 16 * rank)          # strong: every rank generates the SAME corpus and keeps its shard
-        if workload == "c2":
+        if workload in ("c2", "c2k"):
             r = W.dna_reads(keys, reads, read_len, seed=seed)
             corpus_bytes.append(r.size)
             if strong:
@@ -282,6 +364,18 @@ def make_batches(torch, dev, workload, keys, vocab, n_batches, reads, read_len, 
             if b == 0:
                 host0 = [r[i].tobytes() for i in range(n)]
                 e2e0 = (np.ascontiguousarray(flat), np.arange(n + 1, dtype=np.int64) * L)
+        elif workload == "c2o":
+            # the reads of config 2 with ragged lengths U[100, read_len], back to back, delivered by offsets
+            r = W.dna_reads(keys, reads, read_len, seed=seed)
+            lens = np.random.default_rng(1000 + seed).integers(min(100, read_len), read_len + 1, size=len(r), dtype=np.int64)
+            keep = np.arange(read_len, dtype=np.int64)[None, :] < lens[:, None]
+            flat = np.ascontiguousarray(r[keep])
+            off = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+            corpus_bytes.append(len(flat))
+            n, L = len(lens), 0
+            if b == 0:
+                host0 = [flat[off[i]:off[i + 1]].tobytes() for i in range(min(n, 200_000))]
+                e2e0 = (flat, off)
         elif workload == "c3":
             nbytes = batch_mb << 20
             flat = np.concatenate([W.text_corpus(vocab, min(64 << 20, nbytes - o), seed=4 + 64 * seed + o // (64 << 20))
@@ -300,25 +394,31 @@ def make_batches(torch, dev, workload, keys, vocab, n_batches, reads, read_len, 
                 flat, off = strong_shard("c4", flat, off, rank, world, longest)
             n, L = len(off) - 1, 0
             if b == 0:
-                m = int(np.searchsorted(off, 32 << 20))
+                m = min(len(off) - 1, int(np.searchsorted(off, 32 << 20)))
                 host0 = [flat[off[i]:off[i + 1]].tobytes() for i in range(m)]
                 e2e0 = (np.ascontiguousarray(flat), off)
+        # offsets batches: the shortest haystack, which the caller of acx_scan_batch vouches for (min_hay_len)
+        shortest = int(np.diff(off).min()) if off is not None and len(off) > 1 else 0
+        if dev is None:
+            batches.append((np.ascontiguousarray(flat), len(flat), n, off, L, shortest))
+            continue
         d_hay = torch.empty(len(flat) + 64, dtype=torch.uint8, device=dev)
         d_hay[: len(flat)].copy_(torch.from_numpy(np.ascontiguousarray(flat)))
         d_off = torch.from_numpy(np.ascontiguousarray(off)).to(dev) if off is not None else None
-        # offsets batches: the shortest haystack, which the caller of acx_scan_batch vouches for (min_hay_len)
-        shortest = int(np.diff(off).min()) if off is not None and len(off) > 1 else 0
         batches.append((d_hay, len(flat), n, d_off, L, shortest))
-    torch.cuda.synchronize()
+    if dev is not None:
+        torch.cuda.synchronize()
     return batches, host0, e2e0, corpus_bytes
 
 
-SCAN_STREAMS = 1
+SCAN_STREAMS = 2
+MIN_TIMED_MS = 250.0
 
 
-def measure(torch, dist, dev, image, batches, mode, steps, warmup, P, event_every, variant):
-    """K timed steps rotating over the batches (barrier + synchronize on both sides, max over ranks by the caller).  Every
-    collected step's record count is compared with the count of the same batch in the untimed pre-pass."""
+def measure(torch, dist, dev, image, batches, mode, steps, warmup, P, event_every, variant, repeats=0):
+    """K x R timed passes rotating over the batches (barrier + synchronize on both sides, max over ranks by the caller; R =
+    `repeats`, or — 0 — chosen from a short calibration so that the region lasts MIN_TIMED_MS, the same R on every rank).
+    Every collected pass's record count is compared with the count of the same batch in the untimed pre-pass."""
     from pyahocorasick_amd.device import Scanner
     B = len(batches)
     scs = [Scanner(image) for _ in range(P)]
@@ -372,7 +472,26 @@ def measure(torch, dist, dev, image, batches, mode, steps, warmup, P, event_ever
             dist.barrier()
         torch.cuda.synchronize()
 
-    # ---- the timed region: K steps, rotating over the batches; the dominant kernel of every N-th step is bracketed
+    # ---- R: how many passes make one driver step (calibration: a few pipelined passes, untimed region) ----------------
+    R = int(repeats)
+    if R <= 0:
+        ncal = max(2 * P, 2 * B, 8)
+        torch.cuda.synchronize()
+        tc = time.perf_counter()
+        for k in range(ncal):
+            step(k)
+        for x in scs:
+            x.wait()
+        torch.cuda.synchronize()
+        t_pass = (time.perf_counter() - tc) / ncal
+        R = int(min(100000, max(1, -(-MIN_TIMED_MS * 1e-3 // max(1e-9, steps * t_pass)))))
+        if dist is not None:                                 # the same R on every rank: the largest any of them asks for
+            rr = torch.tensor([R], dtype=torch.int64, device=dev)
+            dist.all_reduce(rr, op=dist.ReduceOp.MAX)
+            R = int(rr.item())
+    passes = steps * R
+
+    # ---- the timed region: K x R passes, rotating over the batches; the dominant kernel of every N-th pass is bracketed
     #      by HIP events on the stream it runs on (timing = 2: an event between two kernels costs ~5 us of idle GPU)
     walk_ms, timed, owner = [], {}, {}
 
@@ -388,7 +507,7 @@ def measure(torch, dist, dev, image, batches, mode, steps, warmup, P, event_ever
     marks = []                                             # host clock after every collected step: a stall shows as ONE long interval
     barrier()
     t0 = time.perf_counter()
-    for k in range(steps):
+    for k in range(passes):
         if k >= P:
             collect(scs[k % P])
             marks.append(time.perf_counter())
@@ -396,8 +515,8 @@ def measure(torch, dist, dev, image, batches, mode, steps, warmup, P, event_ever
         timed[id(scs[k % P])] = ev
         owner[id(scs[k % P])] = k
         step(k, timing=2 if ev else False)
-    for k in range(max(0, steps - P), steps):
-        collect(scs[k % P])                                # every step complete: totals read and checked, records in HBM
+    for k in range(max(0, passes - P), passes):
+        collect(scs[k % P])                                # every pass complete: totals read and checked, records in HBM
         marks.append(time.perf_counter())
     torch.cuda.synchronize()
     dt_rank = time.perf_counter() - t0
@@ -406,21 +525,34 @@ def measure(torch, dist, dev, image, batches, mode, steps, warmup, P, event_ever
     gaps = np.diff(np.array([t0] + marks)) * 1e3
     step_ms = {"median": round(float(np.median(gaps)), 4), "max": round(float(gaps.max()), 4), "argmax": int(gaps.argmax())}
     return {"dt": dt, "dt_rank": dt_rank, "walk_ms": walk_ms, "pre": pre, "step_ms": step_ms, "matches_per_batch": matches_per_batch, "sync_ms": sync_ms,
-            "bytes_rank": sum(batches[k % B][1] for k in range(steps)), "matches_rank": sum(matches_per_batch[k % B] for k in range(steps)),
+            "repeats": R, "passes": passes,
+            "bytes_rank": sum(batches[k % B][1] for k in range(passes)), "matches_rank": sum(matches_per_batch[k % B] for k in range(passes)),
             "scanner": scs[0], "stream": stream, "keepalive": (ssc if P > 1 else None, extra), "scan_streams": len(streams)}
 
 
-def roofline_entry(image, batches, m, mode_name, workload, variant, steps, event_every):
-    """the dominant kernel against the HBM roofline: algorithmic bytes per launch / its average duration (HIP events inside the
-    timed region), PMC traffic from profiles/traffic.json when it was measured on these kernel sources"""
+def roofline_entry(image, batches, m, mode_name, workload, variant, event_every):
+    """the dominant kernel against the HBM roofline: algorithmic bytes per launch / its launch duration, PMC traffic from
+    profiles/traffic.json when it was measured on these kernel sources.
+
+    The launch duration: with ONE scan stream, HIP events around the kernel inside the timed region (rocprofv3's average
+    agrees: profiles/r4_clock_check.txt).  With TWO (the default) launch spans overlap — the blocks of launch k + 1 start on
+    the CUs launch k's finished blocks leave — and no per-launch clock describes the kernel (events 0.2675 ms, rocprofv3
+    339 us for the same launches): there the duration is the UNION of the kernel's spans per launch, bounded from above by
+    timed region / launches = ms_per_step, which is what is used (so `frac` of such a line can only understate the kernel).
+    tools/roofline_check.py recomputes it from a rocprofv3 --kernel-trace of the same command.  `step` is the
+    regime-independent figure: all algorithmic bytes of a batch scan / ms_per_step."""
     B = len(batches)
+    passes = m["passes"]
     d_hay, cap0, n0, d_off0, L0, shortest0 = batches[0]
-    H = m["bytes_rank"] / steps                              # haystack bytes per rank per step (mean over the rotation)
-    M = m["matches_rank"] / steps
-    Nh = float(np.mean([batches[k % B][2] for k in range(steps)]))
+    H = m["bytes_rank"] / passes                             # haystack bytes per rank per pass (mean over the rotation)
+    M = m["matches_rank"] / passes
+    Nh = float(np.mean([batches[k % B][2] for k in range(passes)]))
     A_bytes = H + 8 * M + 12 * Nh                            # SURVEY.md §8(d): H + 8*M + 12*N
     pre = m["pre"]
-    walk = float(np.mean(m["walk_ms"])) if m["walk_ms"] else pre["walk"]
+    ms_pass = m["dt_rank"] / passes * 1e3
+    overlap = m["scan_streams"] > 1
+    walk_ev = float(np.mean(m["walk_ms"])) if m["walk_ms"] else pre["walk"]
+    walk = ms_pass if overlap else walk_ev
     used_ppm = mode_name == "iter" and image.ppm_kernel(stride=L0, has_offsets=d_off0 is not None, variant=variant, min_hay_len=shortest0,
                                                           dev_hay=d_hay.data_ptr(), n_hay=n0)
     if mode_name != "iter":
@@ -439,7 +571,7 @@ def roofline_entry(image, batches, m, mode_name, workload, variant, steps, event
         walk_kernel, walk_bytes = "k_ppm_scan", H + 8 * M + 8 * (H / 256)
     else:
         walk_kernel, walk_bytes = ("k_walk_itop" if image.itop_depth > 0 and not (variant >> 16) & 1 else "k_walk_all"), H + 12 * Nh
-    traffic_raw = traffic_corr = None
+    traffic = traffic_raw = traffic_x2 = None
     traffic_note = "profiles/traffic.json absent"
     tpath = os.path.join(ROOT, "profiles", "traffic.json")
     src_hash = kernel_source_hash(walk_kernel)
@@ -454,32 +586,44 @@ def roofline_entry(image, batches, m, mode_name, workload, variant, steps, event
                 traffic_note = "PMC entry is for other sources of %s (%s, now %s): refused" % (walk_kernel, ent.get("kernel_source_sha"), src_hash)
             else:
                 traffic_raw = ent["fetch_bytes_raw"] + ent["write_bytes"]
-                traffic_corr = ent["fetch_bytes_x2_gfx950"] + ent["write_bytes"]
+                traffic_x2 = ent["fetch_bytes_x2_gfx950"] + ent["write_bytes"]
+                # one figure: FETCH_SIZE scaled by the factor tools/fetch_calib.hip measured for THIS access mix on this chip
+                # (profiles/r5_fetch_calibration.json; entries made before it existed carry none: the x2 bound stands in)
+                traffic = ent.get("traffic_calibrated", traffic_x2)
                 traffic_note = ent.get("note", "")
         except Exception as ex:                             # noqa: BLE001
             traffic_note = "unreadable: %s" % ex
-    gpu_ms = walk + pre["scan"] + pre["expand"]
+    gpu_ms = walk_ev + pre["scan"] + pre["expand"]
+
+    def fig(nbytes, ms):
+        return {"algorithmic_bytes": nbytes, "ms": round(ms, 4), "achieved": nbytes / (ms * 1e-3) / 1e9, "frac": nbytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS}
+
     return {
         "bound": "hbm", "kernel": walk_kernel,
         "achieved": walk_bytes / (walk * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
         "frac": walk_bytes / (walk * 1e-3) / 1e9 / HBM_PEAK_GBS,
         "algorithmic_bytes": walk_bytes, "kernel_avg_ms": round(walk, 4),
-        # HIP events around the kernel, on its stream, inside the timed region: in every N-th step (an event
-        # pair costs the stream ~19 us of idle time in the step it is in)
-        "kernel_events": {"every_nth_step": event_every, "samples": len(m["walk_ms"])},
-        # kernel_alone_ms: the same kernel in the pre-pass, where every step is waited for before the next is issued.  With
-        # --scan-streams 2 launches overlap and kernel_avg_ms (HIP events) is NOT what rocprofv3 reports as the launch's span
-        # (0.2675 ms against 339 us): achieved / frac of such a line are not comparable with the profile — the default is 1
-        "launches_overlap": m["scan_streams"] > 1, "kernel_alone_ms": round(pre["walk"], 4),
-        # HBM bytes of the dominant kernel per launch from the PMC passes (FETCH_SIZE + WRITE_SIZE): `traffic` is the figure
-        # corrected as /opt/skills/guides/MI355X_MICROARCH.md prescribes for gfx950 (FETCH_SIZE x 2: it tallies 128-B requests
-        # at 64 B; an upper bound where the requests are narrow gathers), `traffic_raw` the counters as they read
-        "traffic": traffic_corr, "traffic_raw": traffic_raw, "traffic_corrected": traffic_corr,
+        "kernel_ms_source": ("union of the kernel's overlapping launch spans per launch, bounded by timed region / launches (two scan streams)"
+                             if overlap else "HIP events around the kernel on its stream, inside the timed region"),
+        # HIP events around the kernel, on its stream, inside the timed region: in every N-th pass (an event
+        # pair costs the stream ~19 us of idle time in the pass it is in).  With overlapping launches they are reported, not used.
+        "kernel_events": {"every_nth_step": event_every, "samples": len(m["walk_ms"]), "avg_ms": round(walk_ev, 4)},
+        "launches_overlap": overlap,
+        # the same kernel in the pre-pass: one launch at a time, waited for (the chip to itself) — the per-launch figure that
+        # rocprofv3 --stats of a --scan-streams 1 run agrees with
+        "kernel_alone": dict(fig(walk_bytes, pre["walk"]), source="pre-pass: one launch at a time, HIP events"),
+        "kernel_alone_ms": round(pre["walk"], 4),
+        # regime-independent: ALL algorithmic bytes of a batch scan (A = H + 8 M + 12 N) over the whole step, as the driver's clock sees it
+        "step": fig(A_bytes, ms_pass),
+        # HBM bytes of the dominant kernel per launch from the PMC passes (FETCH_SIZE + WRITE_SIZE).  `traffic`: FETCH_SIZE scaled
+        # by the factor measured for this access mix (tools/fetch_calib.hip), or — entries older than the calibration — the
+        # bound /opt/skills/guides/MI355X_MICROARCH.md prescribes for gfx950 (FETCH_SIZE x 2); `traffic_raw`: the counters as read
+        "traffic": traffic, "traffic_raw": traffic_raw, "traffic_x2_bound": traffic_x2,
         "traffic_note": traffic_note, "kernel_source_sha": src_hash,
-        # the whole batch scan (scan kernel + prefix sum + gather), A = H + 8*M + 12*N
+        # the whole batch scan (scan kernel + prefix sum + gather) by the kernels' own durations, A = H + 8*M + 12*N
         "pipeline": {"algorithmic_bytes": A_bytes, "gpu_ms": round(gpu_ms, 4),
                      "achieved": A_bytes / (gpu_ms * 1e-3) / 1e9, "frac": A_bytes / (gpu_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                     "kernel_ms": {"walk": round(walk, 4), "scan": round(pre["scan"], 4), "expand": round(pre["expand"], 4)}},
+                     "kernel_ms": {"walk": round(walk_ev, 4), "scan": round(pre["scan"], 4), "expand": round(pre["expand"], 4)}},
     }
 
 
@@ -502,15 +646,16 @@ def other_config(torch, dev, acx, name, workload, mode_name, keys, vocab, image,
     t_stage = time.perf_counter() - t0
     mode = acx.ACX_SCAN_ALL if mode_name == "iter" else acx.ACX_SCAN_LONG
     steps = max(8, min(args.steps, 20))
-    m = measure(torch, None, dev, image, batches, mode, steps, 2, max(1, args.pipeline), args.event_every, 0)
+    m = measure(torch, None, dev, image, batches, mode, steps, 2, max(1, args.pipeline), args.event_every, 0, args.inner_repeats)
     out = {
-        "value": m["bytes_rank"] / m["dt"] / 1e9, "unit": "GB/s", "ms_per_step": m["dt"] / steps * 1e3, "steps": steps,
+        "value": m["bytes_rank"] / m["dt"] / 1e9, "unit": "GB/s", "ms_per_step": m["dt"] / m["passes"] * 1e3, "steps": steps,
+        "inner_repeats": m["repeats"], "timed_region_ms": round(m["dt"] * 1e3, 3),
         "ms_per_step_synchronous": m["sync_ms"], "step_ms_host_intervals": m["step_ms"], "scan_streams": m["scan_streams"],
-        "matches_per_step": m["matches_rank"] / steps,
-        "workload": (WORKLOAD_NAMES[workload] % ((n_keys, args.reads, args.read_len) if workload == "c2" else (n_keys, batch_mb)))
+        "matches_per_step": m["matches_rank"] / m["passes"],
+        "workload": (WORKLOAD_NAMES[workload] % ((n_keys, args.reads, args.read_len) if workload.startswith("c2") else (n_keys, batch_mb)))
                     + ", Automaton.%s; %d distinct batches rotated (%.0f MB resident)" % (mode_name, len(batches), sum(b[1] for b in batches) / 1e6),
         "states": int(image.num_states), "image_mb": round(image.nbytes / 1e6, 1),
-        "roofline": roofline_entry(image, batches, m, mode_name, workload, 0, steps, args.event_every),
+        "roofline": roofline_entry(image, batches, m, mode_name, workload, 0, args.event_every),
         "setup": {"build_flatten_upload_s": None if t_build is None else round(t_build, 3), "stage_batches_s": round(t_stage, 3)},
     }
     if cpu_sample and host0:
@@ -524,6 +669,8 @@ def main():
     self_launch(args)                                      # --gpus N > 1 outside torch.distributed.run: N ranks are started here
     if args.launch_check:
         return launch_check(args)
+    if args.dry_run:
+        return dry_run(args)
     # stdout must carry exactly ONE JSON line: RCCL prints a version banner on fd 1 when its
     # communicator comes up, so everything until the final print goes to stderr instead.
     sys.stdout.flush()
@@ -584,22 +731,31 @@ def main():
     t_stage = time.perf_counter() - t0
     mode = acx.ACX_SCAN_ALL if args.mode == "iter" else acx.ACX_SCAN_LONG
     P = max(1, args.pipeline)
-    global SCAN_STREAMS
+    global SCAN_STREAMS, MIN_TIMED_MS
     SCAN_STREAMS = max(1, args.scan_streams)
-    m = measure(torch, dist, dev, image, batches, mode, args.steps, args.warmup, P, args.event_every, args.variant)
+    MIN_TIMED_MS = max(0.0, args.min_timed_ms)
+    m = measure(torch, dist, dev, image, batches, mode, args.steps, args.warmup, P, args.event_every, args.variant, args.inner_repeats)
     dt, bytes_rank, matches_rank = m["dt"], m["bytes_rank"], m["matches_rank"]
-    per_rank = [bytes_rank / m["dt_rank"] / 1e9]
+    passes = m["passes"]
+    # what every rank saw for itself: throughput and step by its own clock (before the closing barrier), the dominant kernel by
+    # HIP events inside the timed region and alone in the pre-pass
+    mine = [bytes_rank / m["dt_rank"] / 1e9, m["dt_rank"] / passes * 1e3,
+            float(np.mean(m["walk_ms"])) if m["walk_ms"] else float("nan"), m["pre"]["walk"]]
+    per_rank = [mine]
+    ranks_seen = 1
     if dist is not None:
         tt = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
-        agg = torch.tensor([bytes_rank, matches_rank], dtype=torch.int64, device=dev)
+        agg = torch.tensor([bytes_rank, matches_rank, 1], dtype=torch.int64, device=dev)
         dist.all_reduce(agg, op=dist.ReduceOp.SUM)
-        bytes_all, matches_all = int(agg[0].item()), int(agg[1].item())
-        pr = torch.zeros(world, dtype=torch.float64, device=dev)
-        pr[rank] = per_rank[0]
+        bytes_all, matches_all, ranks_seen = int(agg[0].item()), int(agg[1].item()), int(agg[2].item())
+        pr = torch.zeros(world, len(mine), dtype=torch.float64, device=dev)
+        pr[rank] = torch.tensor(mine, dtype=torch.float64, device=dev)
         dist.all_reduce(pr, op=dist.ReduceOp.SUM)
         per_rank = pr.tolist()
+        if ranks_seen != dist.get_world_size() or ranks_seen != args.gpus:
+            raise SystemExit("--gpus %d, the process group has %d ranks, %d took part in the reduction" % (args.gpus, dist.get_world_size(), ranks_seen))
     else:
         bytes_all, matches_all = bytes_rank, matches_rank
 
@@ -619,8 +775,8 @@ def main():
         assert np.array_equal(off_g, mo) and np.array_equal(e, oe) and np.array_equal(v, ov), "GPU result differs from the oracle"
 
     if rank == 0:
-        ms_step = dt / args.steps * 1e3
-        wname = WORKLOAD_NAMES[args.workload] % ((n_keys, args.reads, args.read_len) if args.workload == "c2" else (n_keys, args.batch_mb))
+        ms_step = dt / passes * 1e3
+        wname = WORKLOAD_NAMES[args.workload] % ((n_keys, args.reads, args.read_len) if args.workload.startswith("c2") else (n_keys, args.batch_mb))
         # bytes of the corpus one step covers over all ranks: strong scaling cuts ONE corpus (bytes_total / step stays what one
         # GPU scans alone, plus the halos of a text shard), weak scaling gives every rank its own
         out = {
@@ -628,20 +784,28 @@ def main():
             "value": bytes_all / dt / 1e9,
             "unit": "GB/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            # a driver step = R passes of the hot path, each over ONE batch (so that the timed region lasts >= --min-timed-ms
+            # whatever --steps says); ms_per_step = timed region / (steps x R) = one batch scan; value = all bytes / timed region
+            "inner_repeats": m["repeats"], "passes": passes, "timed_region_ms": round(dt * 1e3, 3), "ms_per_driver_step": dt / args.steps * 1e3,
             "ms_per_step": ms_step, "higher_is_better": True, "scaling": "strong" if strong else "weak",
             "vs_baseline": None, "dtype": "u8", "data": "synthetic",
             "matches_per_s": matches_all / dt,
-            "matches_per_step": matches_all / args.steps / world,
-            "bytes_total": bytes_all, "bytes_per_step_all_ranks": bytes_all / args.steps,
+            "matches_per_step": matches_all / passes / world,
+            "bytes_total": bytes_all, "bytes_per_step_all_ranks": bytes_all / passes,
             "corpus_bytes_per_batch": int(np.mean(corpus_bytes)),
             "ms_per_step_synchronous": m["sync_ms"], "step_ms_host_intervals": m["step_ms"],
-            "per_rank_GBps": {"min": min(per_rank), "max": max(per_rank)},
+            "per_rank_GBps": {"min": min(r[0] for r in per_rank), "max": max(r[0] for r in per_rank)},
+            "ranks": {"reported_by_process_group": (dist.get_world_size() if dist is not None else 1), "took_part": ranks_seen,
+                      "backend": (dist.get_backend() if dist is not None else None),
+                      "per_rank": [{"rank": i, "GBps": round(r[0], 2), "ms_per_step": round(r[1], 5),
+                                    "kernel_ms_events": None if r[2] != r[2] else round(r[2], 5), "kernel_alone_ms": round(r[3], 5)}
+                                   for i, r in enumerate(per_rank)]},
             "config": {"workload": wname + ", Automaton.%s; %d distinct batches rotated (%.0f MB resident per GPU)"
                                    % (args.mode, B, sum(b[1] for b in batches) / 1e6),
                        "states": int(image.num_states), "classes": int(image.num_classes),
                        "image_mb": round(image.nbytes / 1e6, 1), "variant": args.variant, "pipeline_depth": P, "scan_streams": m["scan_streams"],
                        "parallelism": "replicated automaton (1 RCCL broadcast), haystacks sharded x%d (%s)" % (world, "strong" if strong else "weak")},
-            "roofline": roofline_entry(image, batches, m, args.mode, args.workload, args.variant, args.steps, args.event_every),
+            "roofline": roofline_entry(image, batches, m, args.mode, args.workload, args.variant, args.event_every),
             "setup": {"build_flatten_s": round(t_build, 3), "broadcast_upload_s": round(t_bcast, 3), "stage_batches_s": round(t_stage, 3)},
         }
         if world == 1 and e2e0 is not None and args.mode == "iter" and not args.no_e2e:
@@ -662,19 +826,18 @@ def main():
             out["end_to_end_GBps"] = hflat.size / best / 1e9
             out["end_to_end_ms"] = best * 1e3
             _lib.lib().acx_result_free(res_e2e)
-        if world == 1 and args.mode == "iter" and args.scan_streams == 1 and P > 1 and args.two_stream_leg:
-            # The same K steps with the scans of consecutive steps on TWO streams, in a timed region of its own (same barriers).
-            # Throughput only: with two streams a launch's span overlaps its neighbour's, and the instruments no longer agree on
-            # its duration (HIP events 0.2675 ms, rocprofv3 339 us; on one stream 0.2615 ms / 254 us: tools/r4_clock_check.sh,
-            # profiles/r4_clock_check.txt) — so no roofline is derived from this mode, and it is never `value`.
-            SCAN_STREAMS = 2
-            m2 = measure(torch, None, dev, image, batches, mode, args.steps, args.warmup, P, 0, args.variant)
+        if world == 1 and args.mode == "iter" and args.scan_streams > 1 and args.one_stream_leg:
+            # The same passes with every scan on ONE stream, in a timed region of its own (same barriers): the regime in which HIP
+            # events, the pre-pass and rocprofv3 agree on the kernel's launch duration (tools/r4_clock_check.sh,
+            # profiles/r4_clock_check.txt).  Never `value`.
             SCAN_STREAMS = 1
-            out["two_scan_streams"] = {"value": m2["bytes_rank"] / m2["dt"] / 1e9, "unit": "GB/s", "ms_per_step": m2["dt"] / args.steps * 1e3,
-                                       "steps": args.steps, "step_ms_host_intervals": m2["step_ms"], "scan_streams": m2["scan_streams"],
-                                       "roofline": None,
-                                       "note": "scans of consecutive steps alternate over two streams (--scan-streams 2); launch durations overlap: no per-launch figure"}
-            del m2
+            m1 = measure(torch, None, dev, image, batches, mode, args.steps, args.warmup, P, args.event_every, args.variant, m["repeats"])
+            SCAN_STREAMS = max(1, args.scan_streams)
+            out["one_scan_stream"] = {"value": m1["bytes_rank"] / m1["dt"] / 1e9, "unit": "GB/s", "ms_per_step": m1["dt"] / m1["passes"] * 1e3,
+                                      "steps": args.steps, "inner_repeats": m1["repeats"], "step_ms_host_intervals": m1["step_ms"],
+                                      "scan_streams": m1["scan_streams"],
+                                      "roofline": roofline_entry(image, batches, m1, args.mode, args.workload, args.variant, args.event_every)}
+            del m1
         if world == 1 and args.cpu_sample_reads != 0 and host0:
             sample = host0 if not args.cpu_sample_reads else host0[: args.cpu_sample_reads]
             out["cpu_baseline"] = cpu_baseline(keys, sample, args.mode)
@@ -689,10 +852,16 @@ def main():
             except SystemExit as ex:                          # (a failed sub-configuration must not take the headline line with it)
                 cfgs["c5_iter_long"] = {"error": str(ex)}
             del m, batches, host0, e2e0
+            # config 2 as the GENERAL stream kernel sees it: the same reads as an offsets batch of ragged lengths (same image)
+            try:
+                cfgs["c2_offsets"] = other_config(torch, dev, acx, "c2_offsets", "c2o", "iter", keys, None, image, None, None, args,
+                                                  n_keys, args.batch_mb, 100_000 if cpu_on else 0)
+            except (SystemExit, Exception) as ex:            # noqa: BLE001
+                cfgs["c2_offsets"] = {"error": "%s: %s" % (type(ex).__name__, ex)}
             image.free()
             del image, image_tensor
             torch.cuda.empty_cache()
-            for name, wl, nk in (("c3", "c3", 100_000), ("c4", "c4", 1_000_000)):
+            for name, wl, nk in (("c2_long_keys", "c2k", n_keys), ("c3", "c3", 100_000), ("c4", "c4", 1_000_000)):
                 try:
                     k2, v2 = build_keys(wl, nk)
                     cfgs[name] = other_config(torch, dev, acx, name, wl, "iter", k2, v2, None, None, None, args, nk, 512, 100_000 if cpu_on else 0)

@@ -29,6 +29,12 @@
 extern "C" {
 #endif
 
+/* libacx.so is built with -fvisibility=hidden: the entry points declared in this header — and nothing else, no kernel
+ * launcher, no C++ internals — are what the library exports (tests/test_capi_symbols.py reads `nm -D`). */
+#if defined(__GNUC__) || defined(__clang__)
+#pragma GCC visibility push(default)
+#endif
+
 #define ACX_ABI_VERSION 3          /* 3: acx_scan_params.dev_skip, acx_scan_host_ctx, acx_trie_add_words, ACX_SCAN_SKIP_WS */
 
 typedef enum acx_status {
@@ -356,6 +362,10 @@ void acx_dev_free(void* p);
 int  acx_memcpy_h2d(void* dst_dev, const void* src_host, size_t nbytes);
 int  acx_memcpy_d2h(void* dst_host, const void* src_dev, size_t nbytes);
 int  acx_device_sync(void);
+
+#if defined(__GNUC__) || defined(__clang__)
+#pragma GCC visibility pop
+#endif
 
 #ifdef __cplusplus
 }

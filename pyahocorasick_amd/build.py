@@ -50,7 +50,7 @@ def build_libacx(force=False, verbose=True):
     extra = os.environ.get("ACX_EXTRA_CFLAGS", "").split()
     objdir = os.path.join(ROOT, "build", "obj" + ("_" + "_".join(x.strip("-").replace("=", "_") for x in extra) if extra else ""))
     os.makedirs(objdir, exist_ok=True)
-    base = [_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function", *extra,
+    base = [_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fvisibility=hidden", "-fvisibility-inlines-hidden", "-Wall", "-Wno-unused-function", *extra,
             # code object v5 loads on every ROCm >= 5.x runtime, including the HIP runtime that
             # PyTorch wheels bundle (a process must only ever hold ONE HIP runtime: see _lib.py)
             "-mcode-object-version=5",
@@ -69,7 +69,7 @@ def build_libacx(force=False, verbose=True):
     for src, pr in procs:
         if pr.wait() != 0:
             raise subprocess.CalledProcessError(pr.returncode, "hipcc -c " + src)
-    cmd = [_hipcc(), "--offload-arch=gfx950", "-fPIC", "-shared", "-o", LIB] + objs
+    cmd = [_hipcc(), "--offload-arch=gfx950", "-fPIC", "-shared", "-Wl,--version-script=" + os.path.join(CSRC, "libacx.map"), "-o", LIB] + objs
     if verbose:
         print("[pyahocorasick_amd.build]", " ".join(cmd), flush=True)
     subprocess.check_call(cmd)

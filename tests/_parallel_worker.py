@@ -67,6 +67,26 @@ def main():
             assert np.array_equal(res[0], mo) and np.array_equal(res[1], e) and np.array_equal(res[2], v)
         else:
             assert res is None
+    # iter_long shards (bench.py --mode iter_long): WHOLE haystacks per rank, by count and by bytes, no halo — a restart
+    # depends on everything in front of a position inside its haystack and on nothing outside it.  Rank order = the
+    # sequential result (oracle: automaton_search_iter_long_next, src/AutomatonSearchIterLong.c:89-153)
+    for splitter in (lambda: shard_range(len(reads), rank, world), lambda: shard_range_by_bytes(off, rank, world)):
+        lo, hi = splitter()
+        loc_off, loc_e, loc_v = [0], [], []
+        for h in range(lo, hi):
+            pairs = orc.flat_iter_long(got, data[off[h]:off[h + 1]])
+            loc_e += [p[0] for p in pairs]
+            loc_v += [p[1] for p in pairs]
+            loc_off.append(len(loc_e))
+        res = gather_csr(np.array(loc_off, dtype=np.int64), np.array(loc_e, dtype=np.int32), np.array(loc_v, dtype=np.int32))
+        if rank == 0:
+            O = orc.Oracle()
+            for i, k in enumerate(keys):
+                O.add_word(k, i)
+            O.make_automaton()
+            mo, e, v = O.batch(data, off, 1)
+            assert len(e) > 100
+            assert np.array_equal(res[0], mo) and np.array_equal(res[1], e) and np.array_equal(res[2], v)
     # one long haystack (config-3 style), cut with a longest_word - 1 halo: every rank scans its own shard plus the
     # halo in front of it, keeps the matches that end in its own range; rank order = the sequential result
     from pyahocorasick_amd.workloads import text_corpus, text_keys, text_vocab

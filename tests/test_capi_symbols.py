@@ -26,6 +26,15 @@ def test_header_functions_all_exported_and_bound():
     assert sorted(_lib.SIGNATURES) == names, "ctypes binding table out of sync with include/acx.h"
 
 
+def test_library_exports_the_c_abi_and_nothing_else():
+    """-fvisibility=hidden + the visibility pragma of include/acx.h: no kernel launcher, no C++ internal is linkable"""
+    import subprocess
+    out = subprocess.check_output(["nm", "-D", "--defined-only", _lib.LIB_PATH]).decode().split("\n")
+    syms = [l.split()[-1] for l in out if l.strip()]
+    exported = sorted(s for s in syms if not s.startswith(("__hip_", "_init", "_fini", "__bss", "_edata", "_end")))
+    assert exported == declared_functions(), sorted(set(exported) ^ set(declared_functions()))
+
+
 def test_library_loads_and_reports_abi():
     l = _lib.lib()
     assert l.acx_abi_version() == 3

@@ -95,3 +95,39 @@ def test_bench_gpus_n_launches_its_own_ranks():
     env2 = dict(env, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
     p2 = subprocess.run([sys.executable, bench, "--gpus", "2", "--launch-check"], env=env2, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=120)
     assert p2.returncode != 0 and b"WORLD_SIZE=1" in p2.stderr
+
+
+def _dry_run(*extra, expect_fail=False):
+    import json
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["OMP_NUM_THREADS"] = "1"
+    bench = os.path.join(os.path.dirname(HERE), "bench.py")
+    p = subprocess.run([sys.executable, bench, "--gpus", "2", "--dry-run", "--keys", "1500", *extra], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
+    if expect_fail:
+        assert p.returncode != 0
+        return p.stderr.decode(errors="replace")
+    assert p.returncode == 0, p.stderr.decode(errors="replace")[-3000:]
+    return json.loads(p.stdout.decode(errors="replace").strip().splitlines()[-1])
+
+
+def test_bench_dry_run_strong_scaling_covers_one_corpus():
+    """`bench.py --gpus 2 --scaling strong --dry-run` (gloo, no GPU): the blob reaches every rank by one broadcast and validates,
+    the ranks' shards add up to ONE corpus — packets (config 4, iter_long: whole haystacks, no halo) and reads exactly, text
+    plus the longest_word - 1 bytes of halo of every rank but the first."""
+    d = _dry_run("--workload", "c4", "--batch-mb", "2", "--batches", "2", "--scaling", "strong", "--mode", "iter_long")
+    assert d["dry_run"] and d["n_gpus"] == 2 and d["scaling"] == "strong" and d["blob_bytes_equal_on_all_ranks"]
+    assert d["bytes_total"] == d["corpus_bytes_all_batches"] and len(d["per_rank"]) == 2
+    sizes = [r["bytes"] for r in d["per_rank"]]
+    assert abs(sizes[0] - sizes[1]) <= 2 * 2 * 1500                     # balanced by bytes, two batches
+    d = _dry_run("--reads", "4001", "--batches", "2", "--scaling", "strong", "--mode", "iter_long")
+    assert d["bytes_total"] == d["corpus_bytes_all_batches"] == 2 * 4001 * 150 and d["haystacks_total"] == 2 * 4001
+    assert d["per_rank"][0]["shard_sha48"] != d["per_rank"][1]["shard_sha48"]
+    d = _dry_run("--workload", "c3", "--batch-mb", "2", "--batches", "1", "--scaling", "strong")
+    halo = d["bytes_total"] - d["corpus_bytes_all_batches"]
+    assert 0 < halo < 256 and d["haystacks_total"] == 2                 # one rank's halo: longest_word - 1 bytes
+    # weak scaling: every rank its own batches of the full size
+    d = _dry_run("--reads", "3000", "--batches", "1")
+    assert d["scaling"] == "weak" and d["bytes_total"] == 2 * 3000 * 150 and d["per_rank"][0]["shard_sha48"] != d["per_rank"][1]["shard_sha48"]
+    # iter_long does not shard INSIDE a haystack
+    err = _dry_run("--workload", "c3", "--batch-mb", "2", "--batches", "1", "--scaling", "strong", "--mode", "iter_long", expect_fail=True)
+    assert "does not shard" in err

@@ -9,7 +9,7 @@ SRC=${SRC:-acx_ppm_stream4.hip}
 python -c "from pyahocorasick_amd.build import build_libacx; build_libacx(verbose=False)"
 mkdir -p build/variants
 for S in $SRC; do
-  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -w -mcode-object-version=5 -Iinclude -Ipyahocorasick_amd/csrc "$@" \
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -fvisibility=hidden -fvisibility-inlines-hidden -w -mcode-object-version=5 -Iinclude -Ipyahocorasick_amd/csrc "$@" \
       -c pyahocorasick_amd/csrc/$S -o build/variants/${NAME}_$S.o
 done
 OBJS=""
@@ -17,5 +17,5 @@ for o in build/obj/*.o; do
   b=$(basename $o .o)
   if [[ " $SRC " == *" $b "* ]]; then OBJS="$OBJS build/variants/${NAME}_$b.o"; else OBJS="$OBJS $o"; fi
 done
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -fPIC -shared -o build/variants/libacx_$NAME.so $OBJS
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -fPIC -shared -Wl,--version-script=pyahocorasick_amd/csrc/libacx.map -o build/variants/libacx_$NAME.so $OBJS
 echo build/variants/libacx_$NAME.so
