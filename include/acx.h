@@ -354,6 +354,37 @@ int  acx_scan_host_ctx(acx_image_t* img, const uint8_t* hay, const int64_t* off,
                        int32_t flags /* ACX_SCAN_SKIP_WS or 0: iter(..., ignore_white_space=True) */,
                        acx_result_t** result);
 
+/* ------------------------------------------------------------------------------------
+ * 4b. The walk over the HOST trie (acx_hostwalk.cpp) — BASELINE.json's config 1 ("iter() over a 1 KB haystack on CPU:
+ *     plumbing, no GPU"), a process without a device, and haystacks that do not pay a launch.  The reference walks its
+ *     pointer trie at 18-26 us per KB; a GPU scan of 1 KB is ~90 us of launch and copies.  Same semantics
+ *     as acx_scan_host_ctx (ACX_SCAN_ALL: ctx, ACX_SCAN_SKIP_WS) and acx_scan_host (ACX_SCAN_LONG: states), on the arena
+ *     trie itself: automaton_search_iter_next / automaton_build_output / ahocorasick_next
+ *     (src/AutomatonSearchIter.c:243-300, :157-197; src/trie.c:177-194), automaton_search_iter_long_next
+ *     (src/AutomatonSearchIterLong.c:89-153).  No image is needed.  At most ACX_HOSTWALK_MAX_BYTES of haystack per call:
+ *     batches belong to the GPU.
+ *       init_node / final states (ACX_SCAN_LONG): a state of the host walk is  -(arena node) - 1  (0 = root), so that it
+ *       is never mistaken for a state id of a device image (those are > 0); a stream that carries a negative state
+ *       continues on the host walk, one that carries a positive one on the device.
+ *     The result is read with acx_result_fetch_host / acx_result_num_matches (it has no device side).
+ *     Which scans come here is the HOST SIDE's decision, by acx_host_walk_applies(total bytes):
+ *       limit < 0   never (a process without a device then fails with ACX_E_NODEVICE as before)
+ *       limit >= 0  when the process has no device, or the scan is of at most `limit` bytes (default 2048: below the
+ *                   measured crossover of a GPU scan)
+ *     acx_host_walk_calls() counts the walks of this process: the GPU test-suite switches the walk off
+ *     (tests/conftest.py: limit -1; the drop-in module also reads ACX_HOST_WALK_BYTES at import) and asserts the counter
+ *     did not move — no GPU parity result can come from the host.
+ * ---------------------------------------------------------------------------------- */
+#define ACX_HOSTWALK_MAX_BYTES       (1ll << 20)
+#define ACX_HOST_WALK_DEFAULT_BYTES  2048
+int     acx_trie_scan_host(const acx_trie_t* t, int mode, const uint8_t* hay, const int64_t* off, int64_t n_hay,
+                           const uint8_t* ctx, const int64_t* ctx_off, const int32_t* init_node, const int32_t* index_base,
+                           int32_t flags, int want_final, acx_result_t** result);
+void    acx_set_host_walk_bytes(int64_t limit);
+int64_t acx_host_walk_bytes(void);
+int     acx_host_walk_applies(int64_t total_bytes);
+int64_t acx_host_walk_calls(void);
+
 /* device helpers used by bindings that have no HIP runtime of their own */
 int  acx_device_count(int* n);
 int  acx_device_set(int dev);

@@ -111,6 +111,11 @@ SIGNATURES = {
     "acx_scan_host": (C.c_int, [_P, C.c_int, _P, _P, C.c_int64, _P, _P, _PP]),
     "acx_scan_host_nofinal": (C.c_int, [_P, C.c_int, _P, _P, C.c_int64, _P, _PP]),
     "acx_scan_host_ctx": (C.c_int, [_P, _P, _P, C.c_int64, _P, _P, _P, C.c_int32, _PP]),
+    "acx_trie_scan_host": (C.c_int, [_P, C.c_int, _P, _P, C.c_int64, _P, _P, _P, _P, C.c_int32, C.c_int, _PP]),
+    "acx_set_host_walk_bytes": (None, [C.c_int64]),
+    "acx_host_walk_bytes": (C.c_int64, []),
+    "acx_host_walk_applies": (C.c_int, [C.c_int64]),
+    "acx_host_walk_calls": (C.c_int64, []),
     "acx_device_count": (C.c_int, [C.POINTER(C.c_int)]),
     "acx_device_set": (C.c_int, [C.c_int]),
     "acx_dev_malloc": (C.c_int, [_PP, C.c_size_t]),

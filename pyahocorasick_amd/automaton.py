@@ -511,7 +511,23 @@ class Automaton:
             return self._scan_locked(buf, off, n, mode, init, base, ctx, ACX_SCAN_SKIP_WS if skip_white_space else 0,
                                      final_states=final_states or init is not None)
 
+    def _host_walk(self, n, off, mode, init):
+        """Does this scan go to the walk over the host trie (acx_trie_scan_host: BASELINE config 1, no device, haystacks
+        that do not pay a launch)?  A carried state decides alone: negative = a node of the host trie, positive = a
+        state of the device image.  ACX_SCAN_ALL with carried states is a device-only form (contexts replace it)."""
+        if init is not None and init.size and (init != 0).any():
+            return mode == ACX_SCAN_LONG and bool((init <= 0).all())
+        return bool(lib().acx_host_walk_applies(int(off[n]) if n else 0))
+
     def _scan_locked(self, buf, off, n, mode, init, base, ctx=None, flags=0, final_states=True):
+        if self._host_walk(n, off, mode, init):
+            check(lib().acx_trie_scan_host(self._trie, mode, buf.ctypes.data if buf.size else None, off.ctypes.data, n,
+                                           (ctx[0].ctypes.data if ctx[0].size else C.c_void_p(1)) if ctx is not None else None,
+                                           ctx[1].ctypes.data if ctx is not None else None,
+                                           init.ctypes.data if (init is not None and mode == ACX_SCAN_LONG) else None,
+                                           base.ctypes.data if base is not None else None, flags,
+                                           1 if final_states else 0, C.byref(self._result)))
+            return self._fetch_result(n)
         img = self._ensure_image()
         if ctx is None and not final_states:
             check(lib().acx_scan_host_nofinal(img.handle, mode, buf.ctypes.data if buf.size else None, off.ctypes.data, n,
@@ -525,6 +541,9 @@ class Automaton:
                                       init.ctypes.data if init is not None else None,
                                       base.ctypes.data if base is not None else None,
                                       C.byref(self._result)))
+        return self._fetch_result(n)
+
+    def _fetch_result(self, n):
         p_off, p_m, p_f = C.c_void_p(), C.c_void_p(), C.c_void_p()
         check(lib().acx_result_fetch_host(self._result, C.byref(p_off), C.byref(p_m), C.byref(p_f)))
         total = lib().acx_result_num_matches(self._result)

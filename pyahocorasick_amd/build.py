@@ -13,7 +13,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
 CSRC = os.path.join(HERE, "csrc")
-SOURCES = ["acx_trie.cpp", "acx_ppm.cpp", "acx_persist.cpp", "acx_items.cpp", "acx_long.cpp", "acx_kernels.hip", "acx_ppm_kernels.hip", "acx_ppm_stream4.hip", "acx_build.hip", "acx_ws.hip", "acx_long.hip", "acx_capi.hip"]
+SOURCES = ["acx_trie.cpp", "acx_ppm.cpp", "acx_persist.cpp", "acx_items.cpp", "acx_long.cpp", "acx_hostwalk.cpp", "acx_kernels.hip", "acx_ppm_kernels.hip", "acx_ppm_stream4.hip", "acx_build.hip", "acx_ws.hip", "acx_long.hip", "acx_capi.hip"]
 HEADERS = [os.path.join(ROOT, "include", "acx.h"), os.path.join(ROOT, "include", "acx_blob.h"),
            os.path.join(CSRC, "acx_internal.h"), os.path.join(CSRC, "acx_kernels.h"), os.path.join(CSRC, "acx_trie_impl.h"),
            os.path.join(CSRC, "acx_ppm_layout.h"), os.path.join(CSRC, "acx_ppm_device.h"), os.path.join(CSRC, "acx_long.h")]

@@ -444,6 +444,10 @@ struct acx_result {
     int64_t total = 0;
     bool has_final = false;
     bool host_valid = false;
+    // acx_trie_scan_host (acx_hostwalk.cpp): the result of a walk over the host trie lives in ordinary memory (a process
+    // without a device cannot pin any); the device accessors return NULL for it
+    bool host_walk = false;
+    std::vector<int64_t> hw_off; std::vector<acx_match_t> hw_m; std::vector<int32_t> hw_fin;
     hipStream_t stream = nullptr;
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
     hipEvent_t done = nullptr;  // recorded after the last operation of a scan: completion of THIS result, not of the whole stream
@@ -1265,7 +1269,7 @@ extern "C" int acx_scan_batch(acx_image_t* img, const acx_scan_params* p, acx_re
     if (p->struct_bytes != sizeof(acx_scan_params))
         return acx_fail(ACX_E_INVAL, "acx_scan_batch: params.struct_bytes = %u, library expects %zu", p->struct_bytes, sizeof(acx_scan_params));
     if (*result && (*result)->pending) { int rcw = result_complete(*result); if (rcw) return rcw; }     // still in flight on its old stream
-    if (*result) (*result)->ws_active = false;
+    if (*result) { (*result)->ws_active = false; (*result)->host_walk = false; }
     if (!(p->flags & ACX_SCAN_SKIP_WS) || p->n_hay <= 0) return scan_batch_inner(img, p, result, stream_v);
     if (p->n_hay < 0 || p->hay_capacity < 0) return acx_fail(ACX_E_INVAL, "acx_scan_batch: negative size");
     if (p->hay_capacity > ACX_MAX_LAUNCH_BYTES)
@@ -1279,17 +1283,28 @@ extern "C" int acx_scan_batch(acx_image_t* img, const acx_scan_params* p, acx_re
     return scan_batch_ws(img, p, *result, (hipStream_t)stream_v);
 }
 
-extern "C" int64_t acx_result_num_matches(acx_result_t* r) { return (r && result_complete(r) == ACX_OK) ? r->total : 0; }
-extern "C" const int64_t* acx_result_offsets_dev(acx_result_t* r) { return (r && result_complete(r) == ACX_OK) ? r->match_off.p : nullptr; }
+extern "C" int64_t acx_result_num_matches(acx_result_t* r) {
+    if (r && r->host_walk) return (int64_t)r->hw_m.size();
+    return (r && result_complete(r) == ACX_OK) ? r->total : 0;
+}
+// (the result of a host walk has no device side: acx_result_fetch_host is its accessor)
+static bool no_dev_side(acx_result_t* r) { if (r && r->host_walk) { (void)acx_fail(ACX_E_STATE, "the result of acx_trie_scan_host has no device buffers: use acx_result_fetch_host"); return true; } return false; }
+extern "C" const int64_t* acx_result_offsets_dev(acx_result_t* r) { return (r && !no_dev_side(r) && result_complete(r) == ACX_OK) ? r->match_off.p : nullptr; }
 extern "C" const acx_match_t* acx_result_matches_dev(acx_result_t* r) {
-    return (r && result_complete(r) == ACX_OK) ? (const acx_match_t*)r->matches.p : nullptr;
+    return (r && !no_dev_side(r) && result_complete(r) == ACX_OK) ? (const acx_match_t*)r->matches.p : nullptr;
 }
 extern "C" const int32_t* acx_result_final_state_dev(acx_result_t* r) {
-    return (r && r->has_final && result_complete(r) == ACX_OK) ? r->final_state.p : nullptr;
+    return (r && !no_dev_side(r) && r->has_final && result_complete(r) == ACX_OK) ? r->final_state.p : nullptr;
 }
 
 extern "C" int acx_result_fetch_host(acx_result_t* r, const int64_t** off, const acx_match_t** matches, const int32_t** final_state) {
     if (!r) return acx_fail(ACX_E_INVAL, "acx_result_fetch_host: NULL result");
+    if (r->host_walk) {
+        if (off) *off = r->hw_off.data();
+        if (matches) *matches = r->hw_m.data();
+        if (final_state) *final_state = r->has_final ? r->hw_fin.data() : nullptr;
+        return ACX_OK;
+    }
     { int rcw = result_complete(r); if (rcw) return rcw; }
     if (!r->host_valid) {
         int rc;
@@ -1313,6 +1328,7 @@ extern "C" int acx_result_fetch_host(acx_result_t* r, const int64_t** off, const
 
 extern "C" int acx_result_timing(acx_result_t* r, float* walk_ms, float* scan_ms, float* expand_ms, float* total_ms) {
     if (!r) return acx_fail(ACX_E_INVAL, "acx_result_timing: NULL result");
+    if (r->host_walk) return acx_fail(ACX_E_STATE, "acx_result_timing: the result of a host walk has no kernel timing");
     { int rcw = result_complete(r); if (rcw) return rcw; }
     if (!r->timed) return acx_fail(ACX_E_STATE, "acx_result_timing: the last scan was not run with params.timing = 1");
     if (walk_ms) *walk_ms = r->t_walk;
@@ -1358,6 +1374,7 @@ static int scan_host_pipelined(acx_image_t* img, const uint8_t* hay, int64_t n_h
         if (ppm_plan(img, &q) != 2) return ACX_HOST_RETRY;
     }
     if (r->pending) { int rcw = result_complete(r); if (rcw) return rcw; }
+    r->host_walk = false;
     if ((rc = r->h_off.ensure((size_t)n_hay + 2))) return rc;
     {   // room for the records: what earlier calls needed, or one per eight bytes
         const size_t want = (size_t)(total_bytes / 8) + 1024;
@@ -1543,6 +1560,45 @@ extern "C" int acx_scan_host_ctx(acx_image_t* img, const uint8_t* hay, const int
     return acx_scan_batch(img, &p, result, nullptr);
 }
 
+// ---- the walk over the host trie (acx_hostwalk.cpp): BASELINE config 1, processes without a device, haystacks below the launch crossover ----
+int acxi_hostwalk_batch(const acx_trie_t* t, int mode, const uint8_t* hay, const int64_t* off, int64_t n_hay,
+                       const uint8_t* ctx, const int64_t* ctx_off, const int32_t* init_node, const int32_t* index_base,
+                       int32_t flags, std::vector<int64_t>* moff, std::vector<acx_match_t>* m, std::vector<int32_t>* fin);
+static std::atomic<int64_t> g_host_walk_bytes{ACX_HOST_WALK_DEFAULT_BYTES};
+static std::atomic<int64_t> g_host_walk_calls{0};
+extern "C" void acx_set_host_walk_bytes(int64_t bytes) { g_host_walk_bytes.store(bytes < 0 ? -1 : bytes); }
+extern "C" int64_t acx_host_walk_bytes(void) { return g_host_walk_bytes.load(); }
+extern "C" int64_t acx_host_walk_calls(void) { return g_host_walk_calls.load(); }
+extern "C" int acx_host_walk_applies(int64_t total_bytes) {
+    const int64_t lim = g_host_walk_bytes.load();
+    if (lim < 0 || total_bytes < 0 || total_bytes > ACX_HOSTWALK_MAX_BYTES) return 0;
+    static const int n_dev = [] { int c = 0; return hipGetDeviceCount(&c) == hipSuccess ? c : 0; }();
+    return (n_dev == 0 || total_bytes <= lim) ? 1 : 0;
+}
+extern "C" int acx_trie_scan_host(const acx_trie_t* t, int mode, const uint8_t* hay, const int64_t* off, int64_t n_hay,
+                                  const uint8_t* ctx, const int64_t* ctx_off, const int32_t* init_node, const int32_t* index_base,
+                                  int32_t flags, int want_final, acx_result_t** result) {
+    if (!t || !off || !result || n_hay < 0) return acx_fail(ACX_E_INVAL, "acx_trie_scan_host: bad argument");
+    if (off[0] != 0 || (ctx && (!ctx_off || ctx_off[0] != 0))) return acx_fail(ACX_E_INVAL, "acx_trie_scan_host: off[0] and ctx_off[0] must be 0");
+    if (off[n_hay] > ACX_HOSTWALK_MAX_BYTES)
+        return acx_fail(ACX_E_UNSUPPORTED, "acx_trie_scan_host: %lld bytes: the host walk is for what does not pay a launch (<= %lld bytes); batches go to acx_scan_host",
+                        (long long)off[n_hay], (long long)ACX_HOSTWALK_MAX_BYTES);
+    acx_result* r = *result;
+    if (!r) {
+        r = new (std::nothrow) acx_result();
+        if (!r) return acx_fail(ACX_E_NOMEM, "acx_trie_scan_host: out of memory");
+        *result = r;
+    }
+    if (r->pending) { int rcw = result_complete(r); if (rcw) return rcw; }
+    r->host_walk = false; r->host_valid = false;
+    const bool fin = mode == ACX_SCAN_LONG && want_final;
+    int rc = acxi_hostwalk_batch(t, mode, hay, off, n_hay, ctx, ctx_off, init_node, index_base, flags, &r->hw_off, &r->hw_m, fin ? &r->hw_fin : nullptr);
+    if (rc) return rc;
+    r->host_walk = true; r->n_hay = n_hay; r->total = (int64_t)r->hw_m.size(); r->has_final = fin && n_hay > 0;
+    g_host_walk_calls.fetch_add(1);
+    return ACX_OK;
+}
+
 static std::atomic<int64_t> g_host_group_bytes{0};
 extern "C" void acx_set_host_group_bytes(int64_t bytes) { g_host_group_bytes.store(bytes > 0 ? bytes : 0); }
 static int64_t max_launch_bytes() {
@@ -1600,6 +1656,7 @@ static int scan_host_impl(acx_image_t* img, int mode, const uint8_t* hay, const 
         if (!r) return acx_fail(ACX_E_NOMEM, "acx_scan_host: out of memory");
         *result = r;
     }
+    r->host_walk = false;
     int64_t limit = max_launch_bytes();
     if ((flags & ACX_SCAN_SKIP_WS) && limit > 0xFFFFFFFFll) limit = 0xFFFFFFFFll;     // (positions of the compacted batch's map are 32-bit)
     if (total_bytes <= limit) return scan_host_once(img, mode, hay, off, n_hay, init_state, index_base, result, want_final, flags);

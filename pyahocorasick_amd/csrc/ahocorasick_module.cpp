@@ -291,6 +291,24 @@ bool run_scan(AutomatonObject* a, int mode, const uint8_t* data, const int64_t* 
               const int32_t* init_state, const int32_t* index_base,
               const int64_t** moff, const acx_match_t** m, const int32_t** fin, ScanLease* lease,
               const uint8_t* ctx = nullptr, int64_t ctx_len = 0, int32_t flags = 0) {
+    // What does not pay a launch — BASELINE config 1, a process without a device, a haystack below the crossover — is a walk
+    // over the host trie (acx_trie_scan_host, include/acx.h §4b).  A carried iter_long state decides alone: a negative one is
+    // a node of the host trie, a positive one a state of the device image.
+    bool host;
+    if (init_state && n == 1 && init_state[0] != 0) host = mode == ACX_SCAN_LONG && init_state[0] < 0;
+    else host = !init_state && acx_host_walk_applies(off[n]) != 0;
+    if (host) {
+        lease->a = a;
+        if (a->results && !a->results->empty()) { lease->res = a->results->back(); a->results->pop_back(); }
+        const int64_t c_off[2] = {0, ctx_len};
+        // (the GIL stays held: microseconds, and the walk reads the trie that add_word of another thread would grow)
+        int rc = acx_trie_scan_host(a->trie, mode, data, off, n, (mode == ACX_SCAN_ALL && ctx && n == 1) ? ctx : nullptr,
+                                    (mode == ACX_SCAN_ALL && ctx && n == 1) ? c_off : nullptr,
+                                    mode == ACX_SCAN_LONG ? init_state : nullptr, index_base, flags, 1, &lease->res);
+        if (!rc) rc = acx_result_fetch_host(lease->res, moff, m, fin);
+        if (rc) { set_acx_error(rc); return false; }
+        return true;
+    }
     if (!gpu_sync(a)) return false;
     lease->a = a; lease->ref = a->image; lease->ref->users++;
     if (a->results && !a->results->empty()) { lease->res = a->results->back(); a->results->pop_back(); }
@@ -1248,8 +1266,23 @@ PyObject* module_load(PyObject*, PyObject* args) {
     return (PyObject*)a;
 }
 
+// NEW (not in the reference): which scans are walked over the host trie instead of launched (include/acx.h §4b)
+PyObject* module_set_host_walk_bytes(PyObject*, PyObject* args) {
+    long long n;
+    if (!PyArg_ParseTuple(args, "L", &n)) return nullptr;
+    acx_set_host_walk_bytes((int64_t)n);
+    Py_RETURN_NONE;
+}
+PyObject* module_host_walk_bytes(PyObject*, PyObject*) { return PyLong_FromLongLong((long long)acx_host_walk_bytes()); }
+PyObject* module_host_walk_calls(PyObject*, PyObject*) { return PyLong_FromLongLong((long long)acx_host_walk_calls()); }
+
 PyMethodDef module_methods[] = {
     {"load", (PyCFunction)module_load, METH_VARARGS, "load(path, deserializer) -> Automaton: read a file written by Automaton.save"},
+    {"set_host_walk_bytes", (PyCFunction)module_set_host_walk_bytes, METH_VARARGS,
+     "set_host_walk_bytes(n): searches of at most n bytes walk the host trie instead of launching a GPU scan (default 2048; "
+     "-1: never, a process without a GPU then raises; with no GPU every search of up to 1 MiB is walked on the host)"},
+    {"host_walk_bytes", (PyCFunction)module_host_walk_bytes, METH_NOARGS, "the limit set by set_host_walk_bytes"},
+    {"host_walk_calls", (PyCFunction)module_host_walk_calls, METH_NOARGS, "searches of this process that were walked on the host"},
     {nullptr, nullptr, 0, nullptr}};
 
 PyModuleDef module_def = {PyModuleDef_HEAD_INIT, "ahocorasick",
@@ -1288,6 +1321,9 @@ PyMODINIT_FUNC PyInit_ahocorasick(void) {
     if (PyType_Ready(&SearchIterType) < 0) return nullptr;
 
     PyObject* m = PyModule_Create(&module_def);
+    // ACX_HOST_WALK_BYTES: the limit of set_host_walk_bytes for processes that cannot call it first (the GPU test-suite runs the
+    // reference's own tests against this module with ACX_HOST_WALK_BYTES=-1: every search there is a GPU scan)
+    if (const char* e = getenv("ACX_HOST_WALK_BYTES")) { if (*e) acx_set_host_walk_bytes((int64_t)atoll(e)); }
     if (!m) return nullptr;
     Py_INCREF(&AutomatonType);
     if (PyModule_AddObject(m, "Automaton", (PyObject*)&AutomatonType) < 0) return nullptr;

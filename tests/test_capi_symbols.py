@@ -60,15 +60,41 @@ def test_struct_layout_matches_header(tmp_path):
 
 
 def test_scan_without_gpu_fails_loudly(have_gpu):
-    """the product path never falls back to a CPU implementation"""
+    """no GPU scan is ever answered by a CPU implementation behind the caller's back: with the walk over the host trie
+    switched off (limit -1) a process without a device raises; a batch beyond what that walk takes (1 MiB) raises whatever
+    the limit is — batches belong to the GPU"""
     if have_gpu:
         return
+    import numpy as np
     import pytest
     import pyahocorasick_amd as acx
     A = acx.Automaton(acx.STORE_INTS)
     A.add_word(b"he", 1)
     A.make_automaton()
+    l = _lib.lib()
+    l.acx_set_host_walk_bytes(-1)
+    try:
+        assert l.acx_host_walk_applies(3) == 0
+        with pytest.raises(acx.AcxError):
+            list(A.iter(b"she"))
+        with pytest.raises(acx.AcxError):
+            A.iter_batch([b"she"])
+    finally:
+        l.acx_set_host_walk_bytes(2048)
+    assert l.acx_host_walk_applies(3) == 1 and l.acx_host_walk_applies((1 << 20) + 1) == 0
+    big = np.full((1 << 20) + 64, ord("x"), dtype=np.uint8)
     with pytest.raises(acx.AcxError):
-        list(A.iter(b"she"))
-    with pytest.raises(acx.AcxError):
-        A.iter_batch([b"she"])
+        A.scan_batch(big, [0, big.size])
+    r = C_scan_host_too_large(A, big)
+    assert r == _lib.ACX_E_UNSUPPORTED
+
+
+def C_scan_host_too_large(A, big):
+    import ctypes as C
+    import numpy as np
+    off = np.array([0, big.size], dtype=np.int64)
+    res = C.c_void_p()
+    rc = _lib.lib().acx_trie_scan_host(A._trie, 0, big.ctypes.data, off.ctypes.data, 1, None, None, None, None, 0, 0, C.byref(res))
+    if res:
+        _lib.lib().acx_result_free(res)
+    return rc
