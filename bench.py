@@ -80,9 +80,9 @@ def parse():
     ap.add_argument("--mode", choices=["iter", "iter_long"], default="iter")
     ap.add_argument("--scaling", choices=["weak", "strong"], default="weak")
     ap.add_argument("--variant", type=int, default=0)
-    ap.add_argument("--scan-streams", type=int, default=2,
+    ap.add_argument("--scan-streams", type=int, default=3,
                     help="streams the scans of consecutive steps alternate over (position-parallel scans; the batches of consecutive steps are "
-                         "independent).  Default 2: the blocks of step k + 1 start on the CUs step k's finished blocks leave, so the uneven end "
+                         "independent).  Default 3 (with --pipeline 3; 2 in round 4's two-stream leg): the blocks of step k + 1 start on the CUs step k's finished blocks leave, so the uneven end "
                          "of one launch and the launch seam (step - kernel = 35-41 us on one stream) are hidden (512 -> 546 GB/s).  Launch spans "
                          "then OVERLAP, and no per-launch duration describes the kernel any more (rocprofv3: 339 us per launch, HIP events: "
                          "0.2675 ms, tools/r4_clock_check.sh): `roofline` is therefore computed from the UNION of the dominant kernel's spans per "
@@ -99,10 +99,13 @@ def parse():
                          "short calibration so that the region lasts --min-timed-ms whatever --steps says — a step is a third of a "
                          "millisecond, and a region of 6 ms would let one barrier's skew decide an 8-GPU line")
     ap.add_argument("--min-timed-ms", type=float, default=250.0, help="length of the timed region that the automatic --inner-repeats aims at")
-    ap.add_argument("--pipeline", type=int, default=2,
+    ap.add_argument("--pipeline", type=int, default=3,
                     help="result objects kept in flight per GPU (ACX_SCAN_ASYNC): the host queues step i+1 and reads "
                          "the counters of step i-1 while step i runs; on ONE stream the kernels of consecutive steps "
-                         "still run strictly one after the other.  1 = one synchronous call per step")
+                         "still run strictly one after the other.  1 = one synchronous call per step.  Default 3 (with 3 scan "
+                         "streams): with 2 x 2 the host queues scan k + 2 only when gather k has completed, and the union of the scan "
+                         "kernel's launch spans covered 90 %% of the timed region (profiles/r5b_c2_spans.json: 239.8 of 267.3 us per "
+                         "step); profiles/r5c_pipeline_sweep.txt: 2 x 2 565.7, 3 x 3 580.1, 4 x 2 536.3, 4 x 4 557.9, 6 x 2 567.4, 6 x 3 578.4 GB/s")
     ap.add_argument("--event-every", type=int, default=4,
                     help="bracket the dominant kernel by HIP events in every N-th timed step (0: in none).  Two event records cost "
                          "the stream about 19 us of idle time per step they are in (config 2: 442 GB/s with events in every step, "
@@ -411,7 +414,7 @@ def make_batches(torch, dev, workload, keys, vocab, n_batches, reads, read_len, 
     return batches, host0, e2e0, corpus_bytes
 
 
-SCAN_STREAMS = 2
+SCAN_STREAMS = 3
 MIN_TIMED_MS = 250.0
 
 
