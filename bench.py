@@ -429,7 +429,10 @@ def measure(torch, dist, dev, image, batches, mode, steps, warmup, P, event_ever
     # (iter_long's walk kernel is many small blocks: two of them share every CU for their whole length and each other's L2 —
     #  168 instead of 171 GB/s — so only the position-parallel scans alternate)
     from pyahocorasick_amd import ACX_SCAN_ALL
-    n_streams = min(SCAN_STREAMS, P) if mode == ACX_SCAN_ALL else 1
+    # (iter_long in its position-parallel form — a scan over the dictionary of acx_long.cpp + one sweep — honours ACX_SCAN_ASYNC since
+    #  round 5: scan kernel on the caller's stream, gather and sweep behind it on a side stream; the serial walk, many small blocks
+    #  that share every CU, lost 2 % on two streams)
+    n_streams = min(SCAN_STREAMS, P)
     extra = [torch.cuda.Stream() for _ in range(max(0, n_streams - 1))]
     streams = [stream] + [x.cuda_stream for x in extra]     # slot k % P scans on stream (k % P) % len(streams)
 

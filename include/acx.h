@@ -173,11 +173,15 @@ int  acx_blob_validate(const void* blob, size_t nbytes);             /* host blo
  * src/AutomatonSearchIterLong.c:89-153, a serial state machine — only ever reports nodes that end a key (E) or whose fail
  * node does while they do not (FE), and whether it stops at one depends on the next LONGER path of the trie that ends
  * with it (U: the nodes whose fail node is an E or FE node).  A trie of exactly these node strings, each with the value
- * index | length << 24 | kind << 30  (kind 0 U, 1 E, 2 FE; real_vals[index] = what iter_long reports for the node),
+ * index | length << 24 | kind << 30  (kind 0 U, 1 E, 2 FE, 3 an E node with no E / FE node below it in the trie: reported the
+ * moment it is reached; real_vals[index] = what iter_long reports for the node; when the dictionary has fewer than
+ * 2^ACX_LONG_SMALL_BITS entries the index takes that many bits and the six above it say how many letters below the node the deepest
+ * E / FE node of its subtree lies: how far the sweep looks ahead along a remembered node's path),
  * finalised.  ACX_SCAN_ALL over it gives, per haystack, the records a single sweep turns into iter_long's output; the
  * device side builds it from an image on the first ACX_SCAN_LONG scan.  *n = 0 (and no trie) when the form does not apply:
  * a node deeper than 63 letters, 2^24 nodes or more.  Host only; the trie is the caller's (acx_trie_free), real_vals is
  * malloc'd (acx_blob_free). */
+#define ACX_LONG_SMALL_BITS 18
 int  acx_blob_long_trie(const void* blob, size_t nbytes, acx_trie_t** out_trie, int32_t** real_vals, int64_t* n, int32_t* longest);
 
 typedef struct acx_image acx_image_t;

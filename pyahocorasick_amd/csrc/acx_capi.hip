@@ -110,7 +110,7 @@ struct acx_image {
     int long_state = 0;
     acx_image* long_img = nullptr;
     int32_t* long_real = nullptr;              // device: what iter_long reports for dictionary entry i
-    uint32_t long_longest = 0;
+    uint32_t long_longest = 0; int64_t long_n_real = 0;
 };
 
 // The steady-state step of the itop walk uses 32-bit offsets: table and cells from the lower of
@@ -421,6 +421,8 @@ struct acx_result {
     // straight into the result's pinned host buffers (device-mapped pointers) instead of r->matches / r->match_off
     uint2* ext_matches = nullptr; int64_t ext_capacity = 0; int64_t* ext_match_off = nullptr; int64_t ext_off_base = 0;
     acx_result* long_inner = nullptr;           // ACX_SCAN_LONG position-parallel: the result of the scan over the dictionary D
+    bool long_pending = false;                  // ... asynchronous: the sweep over the inner scan's records is queued behind its gather (long_complete)
+    acx_image* long_img = nullptr; uint32_t reruns = 0;   // reruns: scans of this result that were issued again at completion (pool too small, a broken promise)
     hipStream_t copy_stream = nullptr;
     bool ppm_self = false;      // the pending stream scan is a fixed-stride one: block sums, totals and clean-up in k_ppm_gather_pos
     int bs_parity = 0;          // which half of wave_aux the next such scan sums into
@@ -540,6 +542,7 @@ static int ppm_complete(acx_result* r) {
             acx_scan_params p = r->pend_params;
             p.min_hay_len = 0; p.flags &= ~(int32_t)ACX_SCAN_ASYNC;
             acx_result* self = r;
+            r->reruns++;
             return scan_batch_inner(r->pend_img, &p, &self, (void*)s);
         }
         r->total = r->h_total.p[0];
@@ -550,6 +553,7 @@ static int ppm_complete(acx_result* r) {
         if (ext && small && !overflow) return ACX_HOST_RETRY;          // (the caller's buffer: it falls back to the staged path)
         if (attempt >= 4) return acx_fail(ACX_E_NOMEM, "position-parallel scan: record pool still too small after %d attempts", attempt);
         int rc;
+        r->reruns++;
         if (small && !ext) {
             if ((rc = r->matches.ensure((size_t)r->total))) return rc;
             r->pend_ca.matches = r->matches.p; r->pend_ca.capacity = (int64_t)r->matches.cap;
@@ -580,9 +584,11 @@ static int ppm_complete(acx_result* r) {
 
 // Finish a scan whose kernels are queued: wait, read the total, and if the speculative expand did
 // not fit the match buffer grow it and run expand again (the events are intact).
+static int long_complete(acx_result* r);
 static int result_complete(acx_result* r) {
     if (!r || !r->pending) return ACX_OK;
     r->pending = false;
+    if (r->long_pending) { r->long_pending = false; return long_complete(r); }
     if (r->ppm) { r->ppm = false; return ppm_complete(r); }
     hipStream_t s = r->stream;
     // wait for this scan only: later scans queued on the same stream (other result objects) keep running
@@ -1007,61 +1013,78 @@ static int scan_ppm(acx_image_t* img, const acx_scan_params* p, acx_result* r, h
 static acx_image* image_long(acx_image* img) {
     std::lock_guard<std::mutex> g(img->long_mu);
     if (img->long_state) return img->long_state > 0 ? img->long_img : nullptr;
-    img->long_state = -1;
-    if (!img->ppm_g || !img->dev) return nullptr;
+    // long_state = -1 only where the form does not APPLY (no position-parallel section, a node deeper than 63 letters, 2^24 entries or
+    // more, a dictionary that gets no such section itself).  A failure for want of memory or of the device leaves it 0 — the next
+    // ACX_SCAN_LONG scan tries again — and says why through acx_last_error(); this scan takes the serial walk.
+    if (!img->ppm_g || !img->dev) { img->long_state = -1; return nullptr; }
     acx_trie_t* t = nullptr; int32_t* real = nullptr; int64_t n = 0; int32_t longest = 0;
     {
         std::vector<uint8_t> host;
-        try { host.resize(img->nbytes); } catch (const std::bad_alloc&) { return nullptr; }
-        if (hipMemcpy(host.data(), img->dev, img->nbytes, hipMemcpyDeviceToHost) != hipSuccess) return nullptr;
-        if (acx_blob_long_trie(host.data(), img->nbytes, &t, &real, &n, &longest) != ACX_OK || n == 0 || !t) return nullptr;
+        try { host.resize(img->nbytes); } catch (const std::bad_alloc&) { (void)acx_fail(ACX_E_NOMEM, "iter_long: no host memory for the image (%zu bytes): the serial walk takes this scan", img->nbytes); return nullptr; }
+        if (hipMemcpy(host.data(), img->dev, img->nbytes, hipMemcpyDeviceToHost) != hipSuccess) { (void)acx_fail(ACX_E_HIP, "iter_long: the image did not come back from the device: the serial walk takes this scan"); return nullptr; }
+        const int rcb = acx_blob_long_trie(host.data(), img->nbytes, &t, &real, &n, &longest);
+        if (rcb == ACX_E_NOMEM) return nullptr;                        // (the message is acx_blob_long_trie's)
+        if (rcb != ACX_OK || n == 0 || !t) { img->long_state = -1; return nullptr; }
     }
     void* blob2 = nullptr; size_t nb2 = 0;
     int rc = acx_flatten_ex(t, ACX_FLATTEN_NO_ITOP | ACX_FLATTEN_TABLE_DEVICE, &blob2, &nb2);
     acx_trie_free(t);
     acx_image* li = nullptr;
     if (!rc) { rc = acx_image_upload(blob2, nb2, &li); acx_blob_free(blob2); }
-    if (rc || !li || !li->ppm_g) { if (li) acx_image_free(li); free(real); return nullptr; }
+    if (rc || !li) { if (li) acx_image_free(li); free(real); if (rc != ACX_E_NOMEM && rc != ACX_E_HIP) img->long_state = -1; return nullptr; }
+    if (!li->ppm_g) { acx_image_free(li); free(real); img->long_state = -1; return nullptr; }
     li->long_state = -1;                                              // (no dictionary of the dictionary)
     int32_t* d_real = nullptr;
     if (hipMalloc((void**)&d_real, (size_t)n * 4) != hipSuccess || hipMemcpy(d_real, real, (size_t)n * 4, hipMemcpyHostToDevice) != hipSuccess) {
         if (d_real) (void)hipFree(d_real);
-        acx_image_free(li); free(real); return nullptr;
+        acx_image_free(li); free(real);
+        (void)acx_fail(ACX_E_NOMEM, "iter_long: no device memory for the dictionary's values: the serial walk takes this scan");
+        return nullptr;
     }
     free(real);
-    img->long_img = li; img->long_real = d_real; img->long_longest = (uint32_t)longest; img->long_state = 1;
+    img->long_img = li; img->long_real = d_real; img->long_n_real = n; img->long_longest = (uint32_t)longest; img->long_state = 1;
     return li;
 }
 
 enum { ACX_LONG_FALLBACK = 2 };         // internal: not this batch (the serial walk takes it)
-// the scan over D (any position-parallel plan), then one sweep per haystack over its records, a prefix sum, a move
-static int scan_long_ppm(acx_image* img, acx_image* li, const acx_scan_params* p, acx_result* r, hipStream_t s) {
-    acx_scan_params q = *p;
-    q.mode = ACX_SCAN_ALL; q.flags &= ~(int32_t)ACX_SCAN_ASYNC; q.want_final_state = 0; q.dev_skip = nullptr; q.dev_init_state = nullptr;
-    if (!ppm_plan(li, &q)) return ACX_LONG_FALLBACK;
-    if (!r->long_inner) { r->long_inner = new (std::nothrow) acx_result(); if (!r->long_inner) return acx_fail(ACX_E_NOMEM, "acx_scan_batch: out of memory"); }
+// the sweep over the records of the scan over D (in->matches / in->match_off, on the device), a prefix sum, the move, the total into
+// the result's pinned word: queued on `g`
+static int long_enqueue_sweep(acx_result* r, acx_image* img, hipStream_t g) {
     acx_result* in = r->long_inner;
-    int rc = scan_batch_inner(li, &q, &in, (void*)s);
-    if (rc) return rc;
-    if (in->pending && (rc = result_complete(in))) return rc;
-    const size_t n = (size_t)p->n_hay;
-    if ((rc = r->counts.ensure(n + 1))) return rc;
-    if ((rc = r->match_off.ensure(n + 1))) return rc;
-    if ((rc = r->partials.ensure((size_t)acx_scan_num_partials((int64_t)n) + 2))) return rc;
-    if (r->timed) for (auto& e : r->ev) if (!e) HIP_TRY(hipEventCreate(&e));
-    if (r->timed) HIP_TRY(hipEventRecord(r->ev[2], s));
+    const size_t n = (size_t)r->n_hay;
+    int rc;
+    if ((rc = r->matches.ensure(in->matches.cap + 1))) return rc;      // (no more records than the scan over D can hold)
+    if ((rc = r->h_total.ensure(4))) return rc;
     acx_long_args la;
-    la.rec = in->matches.p; la.off = in->match_off.p; la.n_hay = p->n_hay; la.index_base = p->dev_index_base;
+    la.rec = in->matches.p; la.off = in->match_off.p; la.n_hay = r->n_hay; la.index_base = r->pend_params.dev_index_base;
     la.longest = img->long_longest; la.counts = r->counts.p;
-    if ((rc = r->matches.ensure((size_t)in->total + 1))) return rc;     // (no more records than the scan over D found)
-    HIP_TRY(acx_launch_long_sweep(la, s));
-    HIP_TRY(acx_launch_scan(r->counts.p, (int64_t)n, r->match_off.p, r->partials.p, s));
-    HIP_TRY(acx_launch_long_move(in->matches.p, in->match_off.p, r->match_off.p, (int64_t)n, img->long_real, r->matches.p, s));
-    if (r->timed) HIP_TRY(hipEventRecord(r->ev[3], s));
-    int64_t total = 0;
-    HIP_TRY(hipMemcpyAsync(&total, r->match_off.p + n, sizeof total, hipMemcpyDeviceToHost, s));
-    HIP_TRY(hipStreamSynchronize(s));
-    r->total = total; r->has_final = false; r->pending = false; r->ppm = false;
+    // (queued behind a scan that may turn out incomplete — more records than its buffer holds: its offsets then point beyond the
+    //  buffer — the kernels look at the scan's total first and leave; entry indices are checked against the dictionary's size)
+    la.rec_capacity = (int64_t)in->matches.cap; la.n_real = img->long_n_real;
+    if (r->timed) HIP_TRY(hipEventRecord(r->ev[2], g));
+    HIP_TRY(acx_launch_long_sweep(la, g));
+    HIP_TRY(acx_launch_scan(r->counts.p, (int64_t)n, r->match_off.p, r->partials.p, g));
+    HIP_TRY(acx_launch_long_move(la, r->match_off.p, img->long_real, r->matches.p, g));
+    if (r->timed) HIP_TRY(hipEventRecord(r->ev[3], g));
+    HIP_TRY(hipMemcpyAsync(r->h_total.p, r->match_off.p + n, sizeof(int64_t), hipMemcpyDeviceToHost, g));
+    if (!r->done) HIP_TRY(hipEventCreateWithFlags(&r->done, hipEventDisableTiming));
+    HIP_TRY(hipEventRecord(r->done, g));
+    return ACX_OK;
+}
+// completion of an ACX_SCAN_LONG scan in its position-parallel form: the scan over D first (a pool that was too small is scanned
+// again there — the sweep then ran over nothing useful and is issued again), then the sweep's own event
+static int long_complete(acx_result* r) {
+    acx_result* in = r->long_inner;
+    acx_image* img = r->long_img;
+    const uint32_t before = in->reruns;
+    int rc = result_complete(in);
+    if (rc) return rc;
+    if (in->reruns != before) {                                       // (the sweep that was queued saw an incomplete scan and left at once, or swept stale records)
+        HIP_TRY(hipEventSynchronize(r->done));
+        if ((rc = long_enqueue_sweep(r, img, r->stream))) return rc;
+    }
+    HIP_TRY(hipEventSynchronize(r->done));
+    r->total = r->h_total.p[0]; r->has_final = false; r->ppm = false;
     if (r->timed) {
         float t_in_walk = 0, t_in_scan = 0, t_in_exp = 0, t_in_total = 0, t_sweep = 0;
         if (acx_result_timing(in, &t_in_walk, &t_in_scan, &t_in_exp, &t_in_total) != ACX_OK) { t_in_walk = t_in_total = 0; }
@@ -1070,6 +1093,30 @@ static int scan_long_ppm(acx_image* img, acx_image* li, const acx_scan_params* p
         r->t_total = (t_in_total > 0 ? t_in_total : t_in_walk) + t_sweep;
     }
     return finish_records(r);                                         // (ACX_SCAN_SKIP_WS: the indices go back to the batch the caller gave)
+}
+// the scan over D (any position-parallel plan), then one sweep per haystack over its records, a prefix sum, a move.  With
+// ACX_SCAN_ASYNC everything is queued — the scan kernel on the caller's stream, its gather and the sweep behind it on the inner
+// result's side stream, beside the caller's next scan kernel — and completes in acx_result_wait / the first accessor.
+static int scan_long_ppm(acx_image* img, acx_image* li, const acx_scan_params* p, acx_result* r, hipStream_t s) {
+    acx_scan_params q = *p;
+    q.mode = ACX_SCAN_ALL; q.want_final_state = 0; q.dev_skip = nullptr; q.dev_init_state = nullptr;
+    if (!ppm_plan(li, &q)) return ACX_LONG_FALLBACK;
+    if (!r->long_inner) { r->long_inner = new (std::nothrow) acx_result(); if (!r->long_inner) return acx_fail(ACX_E_NOMEM, "acx_scan_batch: out of memory"); }
+    acx_result* in = r->long_inner;
+    int rc = scan_batch_inner(li, &q, &in, (void*)s);
+    if (rc) return rc;
+    const size_t n = (size_t)p->n_hay;
+    if ((rc = r->counts.ensure(n + 1))) return rc;
+    if ((rc = r->match_off.ensure(n + 1))) return rc;
+    if ((rc = r->partials.ensure((size_t)acx_scan_num_partials((int64_t)n) + 2))) return rc;
+    if (r->timed) for (auto& e : r->ev) if (!e) HIP_TRY(hipEventCreate(&e));
+    r->pend_params = *p; r->long_img = img;
+    // where the inner scan's last kernel (its gather) was queued: the sweep goes behind it
+    hipStream_t g = (in->pending && in->ppm_stream && in->use_side && in->side) ? in->side : s;
+    if ((rc = long_enqueue_sweep(r, img, g))) return rc;
+    r->pending = true; r->long_pending = true; r->ppm = false;
+    if (p->flags & ACX_SCAN_ASYNC) return ACX_OK;
+    return result_complete(r);
 }
 
 static int scan_batch_inner(acx_image_t* img, const acx_scan_params* p, acx_result_t** result, void* stream_v) {

@@ -12,8 +12,10 @@
 // So iter_long = ACX_SCAN_ALL over the dictionary D = E + FE + U — the position-parallel kernels as they are: records
 // (end, value) per haystack, position ascending, longest first within a position, so that the record in front of one with
 // the same end IS its next longer path — followed by one sweep over the records of every haystack (k_long_sweep,
-// acx_kernels.hip).  The value of a D key packs what the sweep needs:  index | length << 24 | kind << 30  (kind 0 = U,
-// 1 = E, 2 = FE; index into `real`: what iter_long reports for the node, first_val of the blob).
+// acx_long.hip).  The value of a D key packs what the sweep needs:  index | length << 24 | kind << 30  (kind 0 = U,
+// 1 = E, 2 = FE, 3 = an E node with no E or FE node below it in the trie; index into `real`: what iter_long reports for the
+// node, first_val of the blob; a dictionary of fewer than 2^18 entries also carries, in bits 18-23, how far below the node the
+// deepest E / FE node of its subtree lies).
 #include "acx_internal.h"
 
 #include <cstdlib>
@@ -67,6 +69,18 @@ extern "C" int acx_blob_long_trie(const void* blob_v, size_t nbytes, acx_trie_t*
         if (f > 0 && (kind[f] & 3u)) kind[s] |= 4u;
         if (kind[s]) nd++;
     }
+    // below[s]: how far below node s the deepest E or FE node of its subtree lies (0: none).  The walk that remembers an E node
+    // (…IterLong.c:118-121) goes on down the trie; what it remembers can only be replaced within that many letters.  An E node with
+    // nothing below (kind 3 in the packed value) is certain to be reported the moment it is reached; for the others the sweep looks
+    // ahead along the path for `below` letters (6 bits of the value when the dictionary has fewer than 2^18 entries, else for
+    // longest - 1 letters).
+    std::vector<uint8_t> below(n, 0);
+    for (size_t s = n; s-- > 1;) {                                      // (BFS numbering: children behind their parents)
+        if (!(kind[s] & 3u) && !below[s]) continue;
+        const uint32_t c = 1u + below[s];
+        const uint32_t par = parent[s];
+        if (c > below[par]) below[par] = (uint8_t)(c > 63u ? 63u : c);
+    }
     for (size_t s = 1; s < n; s++) if (kind[s] && depth[s] > 63u) return ACX_OK;     // (deeper than the 6 bits of the length field: the serial walk stays)
     if (nd == 0 || nd >= ((size_t)1 << 24)) return ACX_OK;
     std::vector<uint8_t> keys;
@@ -87,8 +101,10 @@ extern "C" int acx_blob_long_trie(const void* blob_v, size_t nbytes, acx_trie_t*
             for (uint32_t i = len; i-- > 0;) { tmp[i] = pbyte[x]; x = parent[x]; }
             keys.insert(keys.end(), tmp, tmp + len);
             key_off.push_back((int64_t)keys.size());
-            const uint32_t k = kind[s] & 3u;
-            values.push_back((int64_t)(int32_t)((uint32_t)idx | (len << 24) | (k << 30)));
+            uint32_t k = kind[s] & 3u;
+            if (k == 1u && !below[s]) k = 3u;
+            const uint32_t hb = nd < ((size_t)1 << ACX_LONG_SMALL_BITS) ? (uint32_t)below[s] << ACX_LONG_SMALL_BITS : 0u;
+            values.push_back((int64_t)(int32_t)((uint32_t)idx | hb | (len << 24) | (k << 30)));
             real[idx] = first_val[s];                                   // (E: its own value; FE: its fail node's — the first output)
             if (len > longest) longest = len;
             idx++;

@@ -46,7 +46,7 @@ struct LdsRecs {
 // The record in front of the current one travels in registers (for "does a longer path end here?"); after a restart the
 // one in front ends before r, so it cannot end where the current one ends.
 template <typename R>
-__device__ __forceinline__ uint32_t sweep_one(R rec, uint32_t n, int32_t r, int32_t reach) {
+__device__ __forceinline__ uint32_t sweep_one(R rec, uint32_t n, int32_t r, int32_t reach, uint32_t imask) {
     // Straight-line: every condition a 0 / 1 word, combined with & and | (a short-circuit && is an exec-mask region and a
     // branch each — the first version of this loop was 80 basic blocks), one LDS read and one predicated write per trip.
     uint32_t k = 0, w = 0;                                             // the record to read, the next slot to write
@@ -59,7 +59,7 @@ __device__ __forceinline__ uint32_t sweep_one(R rec, uint32_t n, int32_t r, int3
         if (eor & (path ^ 1u)) break;
         const rec2_t x = rec.get(eor ? n - 1u : k);
         const int32_t e = (int32_t)x.x;
-        const uint32_t kind = x.y >> 30, len = (x.y >> 24) & 63u, idx = x.y & 0xFFFFFFu;
+        const uint32_t kind = x.y >> 30, len = (x.y >> 24) & 63u, idx = x.y & imask;
         const int32_t start = e - (int32_t)len + 1;
         const uint32_t is_fe = kind == 2u ? 1u : 0u, is_ev = kind != 0u ? 1u : 0u;
         // following a path: its end (the remembered record is reported, the records behind it are read again), a record of the path
@@ -100,36 +100,125 @@ __device__ __forceinline__ uint32_t wave_incl_scan_u32(uint32_t v, int lane) {
     return v;
 }
 
-// A wave per 64 consecutive haystacks: their records are one contiguous range, loaded into LDS with coalesced reads (as
-// many haystacks at a time as fit), swept there a lane per haystack, and the reported records of the 64 written back
-// packed from the range's first slot on (k_long_move then moves one contiguous piece per wave).  A haystack with more
-// records than the wave's LDS is swept in place in global memory by its lane alone.
-constexpr uint32_t LONG_CAP = 1200;                                   // records per wave in LDS (10 KiB with the skew; four waves per block, four blocks per CU)
-__global__ void __launch_bounds__(256) k_long_sweep(const acx_long_args a) {
-    __shared__ uint2 s_rec[4][LONG_CAP + LONG_CAP / 16 + 1];
-    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
-    uint2* const sw = s_rec[wid];
-    const int64_t n_groups = (a.n_hay + 63) / 64, n_waves = (int64_t)gridDim.x * 4;
+// ---- the sweep over COMPACT records (round 5) -----------------------------------------------------------------------------
+// What a trip of the loop above spends most of its instructions on does not depend on where the walk restarted: is the record
+// an event, where does its path start, does a longer path of the trie end with it.  The staging pass — lane per RECORD,
+// coalesced — answers that once per record and keeps only the E and FE records (a U record only ever says "a longer path ends
+// here" about the record behind it):
+//     {start, up_start, value}     start = end - length + 1;  up_start = the start of the record in front when it ends at the same
+//                                  index of the same haystack (the next LONGER path), else INT_MIN
+// and the rule of acx_long.cpp becomes  fires <=> up_start < r <= start.  kind 3 (an E node with no E / FE node below it in the
+// trie, acx_long.cpp) is reported the moment it fires — nothing the walk can still meet on that path replaces it — so only E
+// nodes with events below them make the lane look ahead along their path and read the records behind the report again.
+// k_long_sweep (round 4) spent 72 instructions per trip and ~70 trips per group of 64 haystacks (profiles/r4_iter_long_steps.txt);
+// tests/test_iter_long_plan_cpu.py holds this form in Python (sweep_records_compact), pinned against the oracle.
+#ifndef ACX_LONG_EXP
+#define ACX_LONG_EXP 0                    // development, timing only (results are wrong): 1 no sweep, 2 no copy-out, 4 no staging beyond the loads
+#endif
+#ifndef ACX_LC_CAP
+#define ACX_LC_CAP 1280
+#endif
+#ifndef ACX_LC_LOADS
+#define ACX_LC_LOADS 4
+#endif
+constexpr uint32_t LC_CAP = ACX_LC_CAP;                                     // compact records per wave in LDS: 12 bytes each, 15 KiB; one wave per block (the waves share nothing), ten blocks per CU
+constexpr uint32_t LC_CHUNKS = LC_CAP / 64;
+struct LongLds {
+    uint2 a[LC_CAP];                                                  // {start, up_start}; a lane's reports are written over its records from the front
+    uint32_t v[LC_CAP];                                               // index | length << 24 | kind << 30
+    uint32_t first_bits[LC_CAP / 32];                                 // raw record i of the batch is the first of its haystack
+    uint32_t cbase[LC_CHUNKS + 1];                                    // compact records in front of raw chunk c
+    unsigned long long kmask[LC_CHUNKS + 1];                          // which raw records of chunk c were kept
+};
+
+// one haystack over its compact records a[first .. first + n): reports written over them from the front; returns how many
+// small: the dictionary has fewer than 2^18 entries — the index is 18 bits, the six above it `below` (acx_long.cpp): a remembered node's
+// path is followed for that many letters, not for longest - 1
+__device__ __forceinline__ uint32_t sweep_compact(LongLds* L, uint32_t first, uint32_t n, int32_t r, int32_t reach, bool small) {
+    uint32_t k = 0, w = 0, path = 0, last_e = 0, last_i = 0, k_last = 0;
+    int32_t p = 0, limit = 0;
+    const uint32_t imask = small ? (1u << ACX_LONG_SMALL_BITS) - 1u : 0xFFFFFFu;
+    if (n == 0u) return 0u;
+    // The record of trip k + 1 is requested while trip k is worked off (a trip is a chain LDS read -> forty instructions -> the next
+    // address, and the wave's LDS — 15 KiB — leaves a SIMD three such chains to interleave); only the trip that ends a path reads
+    // somewhere else: behind the record it reports.
+    uint2 na = L->a[first]; uint32_t nv = L->v[first];
+    for (;;) {
+        const uint32_t eor = k >= n ? 1u : 0u;
+        if (eor & (path ^ 1u)) break;
+        const uint2 a = na;
+        const uint32_t val = nv;
+        { const uint32_t kp = first + (k + 1u < n ? k + 1u : n - 1u); na = L->a[kp]; nv = L->v[kp]; }
+        const int32_t start = (int32_t)a.x, up = (int32_t)a.y;
+        const uint32_t kind = val >> 30, idx = val & imask;
+        const int32_t e = start + (int32_t)((val >> 24) & 63u) - 1;
+#ifdef ACX_LONG_NOK3
+        const uint32_t now = kind == 2u ? 1u : 0u;
+#else
+        const uint32_t now = (kind >> 1);                              // kinds 2 (FE) and 3 (E, nothing below): reported at once
+#endif
+        const uint32_t p_end = path & (eor | (e > limit ? 1u : 0u));
+        const uint32_t p_hit = path & (p_end ^ 1u) & (start == p ? 1u : 0u);
+        const uint32_t fires = (path ^ 1u) & (eor ^ 1u) & (start >= r ? 1u : 0u) & (up < r ? 1u : 0u);
+        const uint32_t hit = p_hit | fires;
+        const uint32_t emit = p_end | (hit & now);
+        const uint32_t keep = hit & (now ^ 1u);                        // an E with events below: remembered, its path followed
+        uint2 out; out.x = p_end ? last_e : (uint32_t)e; out.y = p_end ? last_i : idx;
+        if (emit) L->a[first + w] = out;                               // (w <= the record being read or remembered)
+        w += emit;
+        r = emit ? (int32_t)out.x + 1 : r;
+        last_e = keep ? (uint32_t)e : last_e; last_i = keep ? idx : last_i;
+#ifdef ACX_LONG_NOBELOW
+        limit = keep ? start + reach : limit;
+#else
+        limit = keep ? (small ? e + (int32_t)((val >> ACX_LONG_SMALL_BITS) & 63u) : start + reach) : limit;
+#endif   // (below <= longest - length: never beyond p + reach)
+        const uint32_t k_next = p_end ? k_last + 1u : k + 1u;
+        if (p_end) { const uint32_t kr = first + (k_next < n ? k_next : n - 1u); na = L->a[kr]; nv = L->v[kr]; }    // (behind the report's own write: slot w - 1 <= k_last)
+        k_last = keep ? k : k_last;
+        p = (fires & keep) ? start : p;
+        path = (path & (emit ^ 1u)) | (fires & keep);
+        k = k_next;
+    }
+    return w;
+}
+
+// A wave per 64 consecutive haystacks: their records are one contiguous range.  As many haystacks at a time as fit (by their raw
+// counts) are staged — raw records read coalesced, turned into compact ones in LDS —, swept a lane per haystack, and the
+// reported records of the 64 written back packed from the range's first slot on (k_long_move then moves one contiguous piece
+// per wave).  A haystack with more records than the wave's LDS is swept in place in global memory by its lane alone, in the
+// raw form (sweep_one above).
+__global__ void __launch_bounds__(64) k_long_sweep(const acx_long_args a) {
+    __shared__ LongLds s_l;
+    const int lane = threadIdx.x & 63;
+    LongLds* const L = &s_l;
+    const int64_t n_groups = (a.n_hay + 63) / 64, n_waves = (int64_t)gridDim.x;
     const int32_t reach = (int32_t)a.longest - 1;
-    for (int64_t g = (int64_t)blockIdx.x * 4 + wid; g < n_groups; g += n_waves) {
+    const bool small = a.n_real < ((int64_t)1 << ACX_LONG_SMALL_BITS);
+    if (a.off[a.n_hay] > a.rec_capacity) return;                       // (the scan in front is incomplete: see acx_long_args)
+    for (int64_t g = (int64_t)blockIdx.x; g < n_groups; g += n_waves) {
         const int64_t h = g * 64 + lane;
         const bool valid = h < a.n_hay;
         const int64_t lo = a.off[valid ? h : a.n_hay], hi = valid ? a.off[h + 1] : lo;
         const int64_t base = a.off[g * 64];
         const uint32_t nrec = (uint32_t)(hi - lo);
-        const uint32_t lo_rel = (uint32_t)(lo - base);                  // (a group's records: fewer than 2^32)
+        const uint32_t lo_rel = (uint32_t)(lo - base);                  // (a group's records: fewer than 2^32 — the record pool is addressed with 32 bits)
         const int32_t r0 = (valid && a.index_base) ? a.index_base[h] : 0;
         const uint32_t incl = wave_incl_scan_u32(nrec, lane);
         uint32_t P = 0;                                                 // reported records of the group so far
         int done = 0;                                                   // lanes done
         while (done < 64) {
             const uint32_t start = done ? (uint32_t)__shfl((int)incl, done - 1, 64) : 0u;
-            const bool fits = lane >= done && incl - start <= LONG_CAP;
+#ifdef ACX_LONG_RAW                       // (development: every haystack by the raw in-place sweep)
+            const bool fits = false;
+#else
+            const bool fits = lane >= done && incl - start <= LC_CAP;
+#endif
             const int e = done + (int)__popcll(__ballot(fits));
             uint32_t c = 0;
             if (e == done) {
-                // the haystack of lane `done` alone has more records than LDS takes: in place, in global memory
-                if (lane == done) c = sweep_one(GlobalRecs{(rec2_t*)a.rec + lo}, nrec, r0, reach);
+                // the haystack of lane `done` alone has more records than LDS takes: in place, in global memory, raw records
+                if (lane == done) c = sweep_one(GlobalRecs{(rec2_t*)a.rec + lo}, nrec, r0, reach, small ? (1u << ACX_LONG_SMALL_BITS) - 1u : 0xFFFFFFu);
                 const uint32_t cc = (uint32_t)__shfl((int)c, done, 64), src_rel = (uint32_t)__shfl((int)lo_rel, done, 64);
                 long_wave_sync();
                 if (src_rel != P) {                                     // down to the group's packed place: 64 at a time, read before written
@@ -145,22 +234,62 @@ __global__ void __launch_bounds__(256) k_long_sweep(const acx_long_args a) {
                 P += cc; done++;
                 continue;
             }
-            const uint32_t sub_n = (uint32_t)__shfl((int)incl, e - 1, 64) - start;
-            // (eight loads in flight per lane: a load waited for before the next is issued is a round trip to memory per 64 records)
-            for (uint32_t i0 = 0; i0 < sub_n; i0 += 512u) {
-                uint2 v[8];
-#pragma unroll
-                for (int j = 0; j < 8; j++) { const uint32_t i = i0 + 64u * (uint32_t)j + (uint32_t)lane; v[j] = i < sub_n ? a.rec[base + start + i] : make_uint2(0u, 0u); }
-#pragma unroll
-                for (int j = 0; j < 8; j++) { const uint32_t i = i0 + 64u * (uint32_t)j + (uint32_t)lane; if (i < sub_n) sw[LdsRecs::slot(i)] = v[j]; }
-            }
-            long_wave_sync();
+            const uint32_t sub_n = (uint32_t)__shfl((int)incl, e - 1, 64) - start;      // raw records of this batch of haystacks
             const bool mine = lane >= done && lane < e;
-            if (mine) c = sweep_one(LdsRecs{(lds_rec2_t*)sw, lo_rel - start}, nrec, r0, reach);
+            // which raw records are the first of their haystack
+            if (lane < (int)(LC_CAP / 32)) L->first_bits[lane] = 0u;
+            long_wave_sync();
+            if (mine && nrec) atomicOr(&L->first_bits[(lo_rel - start) >> 5], 1u << ((lo_rel - start) & 31u));
+            long_wave_sync();
+            // raw -> compact, 64 records per trip; four loads in flight per lane
+            uint32_t cnt = 0;                                           // compact records so far
+            uint32_t carry_e = 0, carry_v = 0;                          // the raw record in front of this trip's first
+            for (uint32_t i0 = 0; i0 < sub_n; i0 += 64u * ACX_LC_LOADS) {
+                uint2 rv[ACX_LC_LOADS];
+#pragma unroll
+                for (int j = 0; j < ACX_LC_LOADS; j++) { const uint32_t i = i0 + 64u * (uint32_t)j + (uint32_t)lane; rv[j] = i < sub_n ? a.rec[base + start + i] : make_uint2(0u, 0u); }
+#pragma unroll
+                for (int j = 0; j < ACX_LC_LOADS; j++) {
+                    const uint32_t c0 = i0 + 64u * (uint32_t)j;
+                    if (c0 >= sub_n) break;                             // (wave-uniform)
+                    if (ACX_LONG_EXP & 4) { if (rv[j].x == 0x12345678u) L->v[lane] = rv[j].y; cnt += 61u; if (lane == 0) { L->cbase[c0 >> 6] = cnt - 61u; L->kmask[c0 >> 6] = 0x1FFFFFFFFFFFFFFFull; } continue; }
+                    const uint32_t i = c0 + (uint32_t)lane;
+                    // (the shuffles by ALL lanes, then the choice: inside a `lane ? shuffle : carry` lane 0 sits the shuffle out, and lane 1 reads an inactive lane)
+                    const uint32_t se = (uint32_t)__shfl_up((int)rv[j].x, 1, 64), sv = (uint32_t)__shfl_up((int)rv[j].y, 1, 64);
+                    const uint32_t pe = lane ? se : carry_e;
+                    const uint32_t pv = lane ? sv : carry_v;
+                    carry_e = (uint32_t)__shfl((int)rv[j].x, 63, 64); carry_v = (uint32_t)__shfl((int)rv[j].y, 63, 64);
+                    const bool in = i < sub_n;
+                    const uint32_t fb = in ? (L->first_bits[i >> 5] >> (i & 31u)) & 1u : 0u;
+                    const uint32_t val = rv[j].y;
+                    const int32_t st = (int32_t)rv[j].x - (int32_t)((val >> 24) & 63u) + 1;
+#ifdef ACX_LONG_NOFB
+                    const bool same = in && i > 0u && pe == rv[j].x; (void)fb;
+#else
+                    const bool same = in && !fb && i > 0u && pe == rv[j].x;
+#endif
+                    const int32_t up = same ? (int32_t)pe - (int32_t)((pv >> 24) & 63u) + 1 : INT32_MIN;
+                    const bool keep = in && (val >> 30) != 0u;
+                    const unsigned long long km = __ballot(keep);
+                    const uint32_t pos = cnt + (uint32_t)__popcll(km & ((1ull << lane) - 1ull));
+                    if (keep) { L->a[pos] = make_uint2((uint32_t)st, (uint32_t)up); L->v[pos] = val; }
+                    if (lane == 0) { L->cbase[c0 >> 6] = cnt; L->kmask[c0 >> 6] = km; }
+                    cnt += (uint32_t)__popcll(km);
+                }
+            }
+            if (lane == 0) { L->cbase[(sub_n + 63u) >> 6] = cnt; L->kmask[(sub_n + 63u) >> 6] = 0ull; }
+            long_wave_sync();
+            // where the compact records of this lane's haystack begin: the kept records in front of its first raw record
+            auto compact_at = [&](uint32_t raw) -> uint32_t { return L->cbase[raw >> 6] + (uint32_t)__popcll(L->kmask[raw >> 6] & ((1ull << (raw & 63u)) - 1ull)); };
+            const uint32_t cf = mine ? compact_at(lo_rel - start) : 0u;
+            const uint32_t cl = mine ? compact_at(lo_rel - start + nrec) : 0u;
+            if (mine && !(ACX_LONG_EXP & 1)) c = sweep_compact(L, cf, cl - cf, r0, reach, small);
+            if (ACX_LONG_EXP & 1) c = (cl - cf) / 2;
             const uint32_t ci = wave_incl_scan_u32(c, lane), tot = (uint32_t)__shfl((int)ci, 63, 64);
+            long_wave_sync();                                           // (every raw record of this batch has been read: the reports go over them)
             if (mine) {
                 uint2* dst = a.rec + base + P + (ci - c);
-                for (uint32_t i = 0; i < c; i++) dst[i] = sw[LdsRecs::slot(lo_rel - start + i)];
+                if (!(ACX_LONG_EXP & 2)) for (uint32_t i = 0; i < c; i++) dst[i] = L->a[cf + i];
                 if (valid) a.counts[h] = (int32_t)c;
             }
             P += tot; done = e;
@@ -171,34 +300,36 @@ __global__ void __launch_bounds__(256) k_long_sweep(const acx_long_args a) {
 
 // the reported records of every group of 64 haystacks — one contiguous piece at the front of the group's range — to
 // dst + new_off[first haystack of the group]; a wave per group
-__global__ void __launch_bounds__(256) k_long_move(const uint2* rec, const int64_t* off, const int64_t* new_off, int64_t n_hay, const int32_t* __restrict__ real, uint2* dst) {
+__global__ void __launch_bounds__(256) k_long_move(const acx_long_args a, const int64_t* new_off, const int32_t* __restrict__ real, uint2* dst) {
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
-    const int64_t n_groups = (n_hay + 63) / 64, n_waves = (int64_t)gridDim.x * 4;
+    const int64_t n_hay = a.n_hay, n_groups = (n_hay + 63) / 64, n_waves = (int64_t)gridDim.x * 4;
+    if (a.off[n_hay] > a.rec_capacity) return;                         // (the scan in front is incomplete: see acx_long_args)
+    const uint32_t n_real = (uint32_t)a.n_real;
     for (int64_t g = (int64_t)blockIdx.x * 4 + wid; g < n_groups; g += n_waves) {
         const int64_t h0 = g * 64, h1 = h0 + 64 < n_hay ? h0 + 64 : n_hay;
-        const uint2* src = rec + off[h0];
+        const uint2* src = a.rec + a.off[h0];
         uint2* d = dst + new_off[h0];
         const int64_t n = new_off[h1] - new_off[h0];
-        for (int64_t k = lane; k < n; k += 64) { uint2 v = src[k]; v.y = (uint32_t)real[v.y]; d[k] = v; }      // (entry index -> what iter_long reports for it)
+        for (int64_t k = lane; k < n; k += 64) { uint2 v = src[k]; v.y = v.y < n_real ? (uint32_t)real[v.y] : 0u; d[k] = v; }      // (entry index -> what iter_long reports for it)
     }
 }
 
 }  // namespace
 
 hipError_t acx_launch_long_sweep(const acx_long_args& a, hipStream_t s) {
-    int64_t blocks = ((a.n_hay + 63) / 64 + 3) / 4;
-    const int64_t cap = (int64_t)acx_num_cus() * 12;
+    int64_t blocks = (a.n_hay + 63) / 64;
+    const int64_t cap = (int64_t)acx_num_cus() * 40;
     if (blocks > cap) blocks = cap;
     if (blocks < 1) blocks = 1;
-    hipLaunchKernelGGL(k_long_sweep, dim3((unsigned)blocks), dim3(256), 0, s, a);
+    hipLaunchKernelGGL(k_long_sweep, dim3((unsigned)blocks), dim3(64), 0, s, a);
     return hipGetLastError();
 }
 
-hipError_t acx_launch_long_move(const uint2* rec, const int64_t* off, const int64_t* new_off, int64_t n_hay, const int32_t* real, uint2* dst, hipStream_t s) {
-    int64_t blocks = ((n_hay + 63) / 64 + 3) / 4;
+hipError_t acx_launch_long_move(const acx_long_args& a, const int64_t* new_off, const int32_t* real, uint2* dst, hipStream_t s) {
+    int64_t blocks = ((a.n_hay + 63) / 64 + 3) / 4;
     const int64_t cap = (int64_t)acx_num_cus() * 16;
     if (blocks > cap) blocks = cap;
     if (blocks < 1) blocks = 1;
-    hipLaunchKernelGGL(k_long_move, dim3((unsigned)blocks), dim3(256), 0, s, rec, off, new_off, n_hay, real, dst);
+    hipLaunchKernelGGL(k_long_move, dim3((unsigned)blocks), dim3(256), 0, s, a, new_off, real, dst);
     return hipGetLastError();
 }

@@ -1246,6 +1246,83 @@ __global__ void __launch_bounds__(PPM_GPOS_THREADS) k_ppm_gather_pos(const acx_p
     if (blockIdx.x == 0 && threadIdx.x == 0) c.match_off[c.n_hay] = c.off_base + total;
 }
 
+// k_ppm_gather_pos for the usual fixed-stride scan (no index base, no stream contexts, positions of a wave a 32-bit multiply-high
+// away from their haystack), written for REGISTERS: k_ppm_stream4 holds 4 x 120 of a SIMD's 512 registers per lane, and a wave
+// that needs more than 32 finds no room beside it — the gather of scan k then runs in the holes the scans k + 1, k + 2 leave
+// (profiles/r5e_c2_timeline_3x3.txt: it waits 200 us, and every third of a step no scan kernel runs at all).  One record per
+// lane and trip (8-byte accesses, a wave's 512 bytes contiguous), everything wave-uniform in scalar registers.
+__global__ void __launch_bounds__(PPM_GPOS_THREADS) k_ppm_gather_pos_lean(const acx_ppm_gather_args c) {
+    constexpr int GT = PPM_GPOS_THREADS;
+    const int n_blocks = (int)(c.n_waves / ACX_PPM_WAVES);
+    auto block_add = [&](uint32_t x) -> uint32_t {
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) x += __shfl_xor(x, d, 64);
+        return x;
+    };
+    uint32_t total32 = 0;
+#pragma unroll 1
+    for (int b = threadIdx.x; b < n_blocks; b += GT) total32 += c.block_sum[b];
+    const int64_t total = (int64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)block_add(total32));
+    if (blockIdx.x == 0) {
+        uint32_t f1 = 0, f2 = 0;
+        if (threadIdx.x == 0) { f1 = (uint32_t)((const int32_t*)(c.ctl + 8))[0]; f2 = (uint32_t)((const int32_t*)(c.ctl + 9))[0]; c.host_words[0] = total; c.host_words[1] = (int32_t)f1; c.host_words[2] = (int32_t)f2; }
+        const uint32_t seen = (uint32_t)__shfl((int)(f1 | f2 | 0x100u), 0, 64);
+        if (seen && threadIdx.x < 16) c.ctl[threadIdx.x] = 0ull;
+        for (int b = threadIdx.x; b < ACX_PPM_MAX_BLOCKS; b += GT) c.block_sum_next[b] = 0u;
+    }
+    const bool fits = total <= c.capacity;
+    const uint32_t stride = (uint32_t)c.stride;
+    const uint64_t H = (uint64_t)c.n_hay * stride;
+    const uint32_t m32 = (uint32_t)((((uint64_t)1 << 32) + stride - 1) / stride);
+    const uint32_t lane = threadIdx.x;
+#pragma unroll 1
+    for (int64_t w = blockIdx.x; w < c.n_waves; w += gridDim.x) {
+        const uint32_t* d = c.wave_desc + (size_t)w * PPM_DESC_WORDS;
+        const uint32_t ng = d[1], count = d[0];
+        const uint64_t blk_first = (uint64_t)(w / ACX_PPM_WAVES) * ACX_PPM_WAVES * (uint64_t)c.tpw;
+        const uint32_t slot = (uint32_t)(w % ACX_PPM_WAVES);
+        uint64_t A = (blk_first + acx_ppm_slot_first_tile(slot, (uint32_t)c.tpw, c.share_a, c.share_b)) * (uint64_t)c.tile_pos;
+        uint64_t B = (blk_first + acx_ppm_slot_first_tile(slot + 1u, (uint32_t)c.tpw, c.share_a, c.share_b)) * (uint64_t)c.tile_pos;
+        if (A > H) A = H;
+        if (B > H) B = H;
+        const int64_t hA = (int64_t)((A + stride - 1) / stride), hB = (int64_t)((B + stride - 1) / stride);
+        const int64_t h0 = (int64_t)(A / stride);
+        const uint32_t bias = (uint32_t)(A - (uint64_t)h0 * stride) - (uint32_t)A;         // offset in its haystack of a position g of this wave, were the haystack h0: g + bias
+        uint32_t part = 0;
+        const int wb = (int)(w / ACX_PPM_WAVES);
+#pragma unroll 1
+        for (int b = threadIdx.x; b < wb; b += GT) part += c.block_sum[b];
+        if (threadIdx.x < (int)(w % ACX_PPM_WAVES)) part += c.wave_desc[((size_t)wb * ACX_PPM_WAVES + threadIdx.x) * PPM_DESC_WORDS];
+        const uint32_t base = (uint32_t)__builtin_amdgcn_readfirstlane((int)block_add(part));      // (records of one scan: fewer than 2^32)
+        int64_t* const moff = c.match_off + h0;                           // match_off of the haystack of position A
+        const int64_t obase = c.off_base + (int64_t)base;
+        uint2* const dst = c.matches + base;
+        uint32_t li = 0;
+        uint32_t q_last = (uint32_t)(hA - 1 - h0);
+        for (uint32_t g = 0; g < ng && fits; g++) {
+            const uint2* src = c.scratch + d[2 + g];
+            const uint32_t n = d[18 + g];
+#pragma unroll 1
+            for (uint32_t k0 = 0; k0 < n; k0 += GT) {
+                const uint32_t k = k0 + lane;
+                if (k < n) {
+                    const uint2 rec = src[k];
+                    const uint32_t y = rec.x + bias, q = __umulhi(y, m32);
+                    uint32_t qp = q_last;
+                    if (k) { const uint32_t yp = src[k - 1].x + bias; qp = __umulhi(yp, m32); }
+                    for (uint32_t qq = qp + 1; (int32_t)(qq - q) <= 0; qq++) moff[(int32_t)qq] = obase + (int64_t)(li + k);     // haystacks that start between the two records
+                    dst[li + k] = make_uint2(y - q * stride, rec.y);
+                }
+            }
+            if (n) q_last = (uint32_t)__builtin_amdgcn_readfirstlane((int)__umulhi(src[n - 1].x + bias, m32));
+            li += n;
+        }
+        const int64_t h_last = fits ? h0 + (int64_t)(int32_t)q_last : hA - 1;
+        for (int64_t hh = h_last + 1 + threadIdx.x; hh < hB; hh += GT) c.match_off[hh] = c.off_base + (int64_t)base + (fits ? count : 0u);
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) c.match_off[c.n_hay] = c.off_base + total;
+}
+
 // records of every tile -> their final place; STRIDE scans: match_off[] from the tile offsets
 __global__ void __launch_bounds__(256) k_ppm_compact(const acx_ppm_compact_args c) {
     const int64_t n_items = c.n_items_dev ? *c.n_items_dev : c.n_items;
@@ -1410,7 +1487,20 @@ hipError_t acx_launch_ppm_gather(const uint32_t* wave_desc, int64_t n_waves, int
     const int64_t cap = (int64_t)num_cus() * 32;
     if (blocks > cap) blocks = cap;
     if (c.off) hipLaunchKernelGGL(k_ppm_gather, dim3((unsigned)blocks), dim3(256), 0, s, c);
-    else { const int64_t cap4 = 4 * cap; hipLaunchKernelGGL(k_ppm_gather_pos, dim3((unsigned)(n_waves < cap4 ? n_waves : cap4)), dim3(PPM_GPOS_THREADS), 0, s, c); }
+    else {
+        const int64_t cap4 = 4 * cap;
+        // the lean form (at most 32 registers per lane: it runs BESIDE k_ppm_stream4) where it applies: no index base, no contexts,
+        // the haystack of a position by a 32-bit multiply-high
+        const uint64_t span = ((uint64_t)c.tpw + c.share_a) * (uint64_t)c.tile_pos, st = (uint64_t)c.stride;
+#ifdef ACX_LEAN_GATHER                     // (A/B builds, tools/build_variant.sh.  Measured, profiles/r5_experiments.md: beside the scans it takes
+                                           //  245 us where the 56-register form takes 50 us in the holes the scans leave: 538.6 against 582.5 GB/s)
+        const bool lean = !c.index_base && !c.skip && st > 0 && (span + st) * st < ((uint64_t)1 << 32);
+#else
+        const bool lean = false; (void)span; (void)st;
+#endif
+        if (lean) hipLaunchKernelGGL(k_ppm_gather_pos_lean, dim3((unsigned)(n_waves < cap4 ? n_waves : cap4)), dim3(PPM_GPOS_THREADS), 0, s, c);
+        else hipLaunchKernelGGL(k_ppm_gather_pos, dim3((unsigned)(n_waves < cap4 ? n_waves : cap4)), dim3(PPM_GPOS_THREADS), 0, s, c);
+    }
     return hipGetLastError();
 }
 

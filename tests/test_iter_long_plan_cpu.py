@@ -233,18 +233,18 @@ def sweep_records(ends, vals, reals, longest, base=0):
             k += 1
             continue
         if kind == 2:
-            out.append((e, reals[v & 0xFFFFFF])); r = e + 1
+            out.append((e, reals[v & 0x3FFFF])); r = e + 1
         else:
-            p, last, done = e - ln + 1, (e, reals[v & 0xFFFFFF]), False
+            p, last, done = e - ln + 1, (e, reals[v & 0x3FFFF]), False
             j = k + 1
             while j < n and ends[j] <= p + longest - 1:
                 v2 = vals[j] & 0xFFFFFFFF
                 k2, l2 = v2 >> 30, (v2 >> 24) & 63
                 if k2 and ends[j] - l2 + 1 == p:
                     if k2 == 2:
-                        out.append((ends[j], reals[v2 & 0xFFFFFF])); r = ends[j] + 1; done = True
+                        out.append((ends[j], reals[v2 & 0x3FFFF])); r = ends[j] + 1; done = True
                         break
-                    last = (ends[j], reals[v2 & 0xFFFFFF])
+                    last = (ends[j], reals[v2 & 0x3FFFF])
                 j += 1
             if not done:
                 out.append(last); r = last[0] + 1
@@ -270,7 +270,7 @@ def sweep_records_lockstep(ends, vals, reals, longest, base=0):
             break
         kk = n - 1 if eor else k
         e, v = ends[kk], vals[kk] & 0xFFFFFFFF
-        kind, ln, idx = v >> 30, (v >> 24) & 63, v & 0xFFFFFF
+        kind, ln, idx = v >> 30, (v >> 24) & 63, v & 0x3FFFF                  # (dictionaries of fewer than 2^18 entries: bits 18-23 are `below`)
         start = e - ln + 1
         is_fe, is_ev = int(kind == 2), int(kind != 0)
         p_end = path & (eor | int(e > p + reach))
@@ -302,6 +302,65 @@ def sweep_records_lockstep(ends, vals, reals, longest, base=0):
     return out
 
 
+def sweep_records_compact(ends, vals, reals, longest, base=0, small=True):
+    """the sweep as k_long_sweep runs it since round 5 (acx_long.hip): the staging pass turns the raw records into compact ones —
+    U records dropped, {start, up_start, value} kept for the E / FE records — and sweep_compact, statement by statement: a record
+    fires iff up_start < r <= start; kinds 2 (FE) and 3 (an E node with nothing below it) are reported at once, kind 1 is
+    remembered and its path followed — for `below` letters (bits 18-23 of the value: how far below the node the deepest E / FE
+    node lies) when the dictionary is small (fewer than 2^18 entries), else for longest - 1 letters"""
+    INT_MIN = -(1 << 31)
+    imask = (1 << 18) - 1 if small else 0xFFFFFF
+    if not small:
+        vals = [v & ~(63 << 18) for v in vals]                  # (a large dictionary's values carry no `below`)
+    comp = []
+    for i, (e, v) in enumerate(zip(ends, vals)):
+        v &= 0xFFFFFFFF
+        if v >> 30 == 0:
+            continue
+        st = e - ((v >> 24) & 63) + 1
+        up = INT_MIN
+        if i > 0 and ends[i - 1] == e:
+            up = e - (((vals[i - 1] & 0xFFFFFFFF) >> 24) & 63) + 1
+        comp.append((st, up, v))
+    out, r, k, w, n = [], base, 0, 0, len(comp)
+    path, p, last_e, last_i, k_last, limit = 0, 0, 0, 0, 0, 0
+    reach = longest - 1
+    if n == 0:
+        return out
+    while True:
+        eor = 1 if k >= n else 0
+        if eor & (path ^ 1):
+            break
+        kk = n - 1 if eor else k
+        start, up, v = comp[kk]
+        kind, idx = v >> 30, v & imask
+        e = start + ((v >> 24) & 63) - 1
+        now = kind >> 1
+        p_end = path & (eor | int(e > limit))
+        p_hit = path & (p_end ^ 1) & int(start == p)
+        fires = (path ^ 1) & (eor ^ 1) & int(start >= r) & int(up < r)
+        hit = p_hit | fires
+        emit = p_end | (hit & now)
+        keep = hit & (now ^ 1)
+        ox, oy = (last_e, last_i) if p_end else (e, idx)
+        if emit:
+            out.append((ox, reals[oy])); assert w <= kk
+        w += emit
+        r = ox + 1 if emit else r
+        if keep:
+            last_e, last_i = e, idx
+            limit = e + ((v >> 18) & 63) if small else start + reach
+            assert limit <= (start if fires else p) + reach
+        k_next = k_last + 1 if p_end else k + 1
+        if keep:
+            k_last = k
+        if fires & keep:
+            p = start
+        path = (path & (emit ^ 1)) | (fires & keep)
+        k = k_next
+    return out
+
+
 def _check_product_dictionary(keys, hays, values=None):
     from helpers import build_pair
     keys = list(dict.fromkeys(keys))
@@ -311,6 +370,13 @@ def _check_product_dictionary(keys, hays, values=None):
     assert D is not None
     dkeys, dvals, reals, longest = D
     assert longest == max(len(k) for k in dkeys) and len(set(dkeys)) == len(dkeys)
+    # kind 3 = an E entry that is a proper prefix of no other E / FE entry (nothing below it in the trie can replace it), kind 1 = one that is
+    ev = [k for k, v in zip(dkeys, dvals) if ((v & 0xFFFFFFFF) >> 30) != 0]
+    for k, v in zip(dkeys, dvals):
+        kind = (v & 0xFFFFFFFF) >> 30
+        if kind in (1, 3):
+            below = any(len(x) > len(k) and x.startswith(k) for x in ev)
+            assert kind == (1 if below else 3), (k, kind)
     OD = orc.Oracle()
     for k, v in zip(dkeys, dvals):
         OD.add_word(k, v)
@@ -320,6 +386,9 @@ def _check_product_dictionary(keys, hays, values=None):
         got = sweep_records([e for e, _ in recs], [v for _, v in recs], reals, longest)
         assert got == O.iter_long(h), (keys, h)
         assert sweep_records_lockstep([e for e, _ in recs], [v for _, v in recs], reals, longest) == got, (keys, h)
+        assert sweep_records_compact([e for e, _ in recs], [v for _, v in recs], reals, longest) == got, (keys, h)
+        assert sweep_records_compact([e + 77 for e, _ in recs], [v for _, v in recs], reals, longest, base=77) == [(e + 77, v) for e, v in got], (keys, h)
+        assert sweep_records_compact([e for e, _ in recs], [v for _, v in recs], reals, longest, small=False) == got, (keys, h)
         got = sweep_records([e + 77 for e, _ in recs], [v for _, v in recs], reals, longest, base=77)      # index_base
         assert got == [(e + 77, v) for e, v in O.iter_long(h)], (keys, h)
 
@@ -359,5 +428,8 @@ def test_dictionary_of_config5_has_the_size_the_design_counts_on():
     A, _ = build_pair(keys)
     dkeys, dvals, reals, longest = long_dictionary(A)
     kinds = np.array([(v & 0xFFFFFFFF) >> 30 for v in dvals])
-    assert len(dkeys) == 180_533 and int((kinds == 1).sum()) == 100_000 and int((kinds == 2).sum()) == 59_612 and int((kinds == 0).sum()) == 20_921
+    assert len(dkeys) == 180_533 and int((kinds == 2).sum()) == 59_612 and int((kinds == 0).sum()) == 20_921
+    # the 100 000 E entries: 95 440 have no E / FE node below them (kind 3: reported the moment they fire), 4 560 do (kind 1: 2 984 of
+    # the 3 840 eight-letter keys among them — the keys most matches are of)
+    assert int((kinds == 3).sum()) == 95_440 and int((kinds == 1).sum()) == 4_560
     assert longest == 32 and all(((v & 0xFFFFFFFF) >> 24) & 63 == len(k) for k, v in zip(dkeys[:2000], dvals[:2000]))
