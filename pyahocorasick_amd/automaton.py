@@ -136,6 +136,14 @@ def _extension():
 
 
 class Automaton:
+    """The ctypes mirror of the drop-in's `ahocorasick.Automaton` (csrc/ahocorasick_module.cpp is the product's host side; tests and
+    bench.py drive this class for its numpy-level batch API: scan_batch, flat_image_bytes, flatten_flags, save_image).
+
+    KEY_SEQUENCE automata are the EXTENSION's: `Automaton(store, KEY_SEQUENCE)` returns an instance of the extension's type, not of this
+    class — isinstance(A, pyahocorasick_amd.Automaton) is False for it, a subclass of this class loses its type there, and the
+    batch methods named above do not exist on it (iter / iter_long / find_all / keys / pickling do, as in the reference).  It needs the
+    built extension (`python -m pyahocorasick_amd.build`; ImportError otherwise).  tests/test_key_sequence.py pins all of this."""
+
     def __new__(cls, *args):
         # KEY_SEQUENCE (src/utils.c:238-289: keys and haystacks are tuples of integers) lives in ONE place, the extension:
         # this class hands such automata to it (the numpy-level batch methods below are for byte automata)

@@ -761,8 +761,9 @@ static int ppm_plan(const acx_image* img, const acx_scan_params* p) {
 // the image and the parameters (keep the two in step)
 static bool ppm_plan_stream4(const acx_image* img, const acx_scan_params* p) {
     const acx_ppm_header& ph = img->ppm;
+    const uint32_t f2 = (img->ppm_g2 && !((p->variant >> 20) & 1)) ? ph.F2 : 0u;       // (as scan_ppm sets acx_ppm_args.F2: no second level without its bitmap)
     return img->ppm_hot4 && img->ppm_cid && !((p->variant >> 19) & 1) && !p->dev_off && !p->dev_skip && p->stride >= 8 && p->stride < 2048 &&
-           ph.sym_bits == 2 && ph.pow2 && ph.sym_arith != 0 && ph.K == 4 && !ph.g_global && (!ph.F2 || ((p->variant >> 20) & 1)) &&
+           ph.sym_bits == 2 && ph.pow2 && ph.sym_arith != 0 && ph.K == 4 && !ph.g_global && !f2 &&
            ph.C == 9 && ph.F == 10 && ppm_halo_pos(ph) == 32 && ph.longest <= 33 && ph.g_words * 4u == (128u << 10) &&
            ppm_stream_nsub(ph, 32, false) == 8;
 }
@@ -999,6 +1000,10 @@ static int scan_ppm(acx_image_t* img, const acx_scan_params* p, acx_result* r, h
         wa.final_state = r->final_state.p;
     }
     r->pend_img = img; r->pend_params = *p;
+    // acx_scan_plan (what bench.py names its roofline kernel by) and the launcher must agree on k_ppm_stream4: the plan asks the image
+    // and the parameters, the launcher the arguments filled above — a scan on which they differ is refused, not mislabelled
+    if (pa.fast && acx_ppm_stream4_eligible(pa) != ppm_plan_stream4(img, p))
+        return acx_fail(ACX_E_STATE, "internal: acx_scan_plan and the launcher disagree on k_ppm_stream4 for this scan (ppm_plan_stream4 / acx_ppm_stream4_eligible)");
     r->use_side = (p->flags & ACX_SCAN_ASYNC) != 0 && r->ppm_stream && !acx_tune_env("ACX_NO_SIDE_STREAM");
     if ((rc = ppm_enqueue(r, img, r->ppm_chunk ? &r->pend_cka : nullptr, r->has_final ? &r->pend_tail : nullptr, s))) return rc;
     r->pending = true; r->ppm = true;

@@ -15,9 +15,9 @@ int acx_blob_check_header(const acx_blob_header* h, size_t nbytes);
 }
 
 
-/* Tuning hooks (A/B switches, size caps of the builders, launch shapes) exist in builds made with -DACX_TUNING only:
- * the default library reads ACX_HOST_THREADS, ACX_FLATTEN_TABLE, ACX_FORCE_WIDE_LAYOUT, ACX_NO_ITOP, ACX_NO_PPM,
- * ACX_MAX_LAUNCH_BYTES (layouts and limits the tests exercise) and the two *_TIMING switches, nothing else. */
+/* Tuning hooks (A/B switches, size caps of the builders, launch shapes) exist in builds made with -DACX_TUNING only.  The release
+ * library reads ACX_HOST_THREADS (acx_trie_impl.h) and nothing else; the drop-in module reads ACX_HOST_WALK_BYTES at import
+ * (include/acx.h §4b).  Layout options are flags of acx_flatten_ex. */
 #include <stdlib.h>
 static inline const char* acx_tune_env(const char* name) {
 #ifdef ACX_TUNING

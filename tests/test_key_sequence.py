@@ -153,3 +153,26 @@ print(json.dumps(out))
     for case, res2 in zip(CASES[:9], json.loads(r.stdout)):
         for res in res2:
             assert res["keys"] == case["enum_keys"] and res["values"] == case["enum_values"] and res["iter"] == case["iter"]
+
+
+def test_the_ctypes_mirror_hands_sequence_automata_to_the_extension():
+    """pyahocorasick_amd.Automaton(store, KEY_SEQUENCE) IS the extension's automaton (one implementation of KEY_SEQUENCE): not an
+    instance of the mirror class — a subclass loses its type there too —, without the numpy-level batch methods, searchable and
+    picklable like any automaton of the extension (the class docstring says so)"""
+    import pyahocorasick_amd as acx
+    A = acx.Automaton(acx.STORE_INTS, acx.KEY_SEQUENCE)
+    assert not isinstance(A, acx.Automaton) and type(A).__module__ == "ahocorasick"
+
+    class Sub(acx.Automaton):
+        pass
+    S = Sub(acx.STORE_INTS, acx.KEY_SEQUENCE)
+    assert type(S) is type(A) and not isinstance(S, Sub)
+    assert isinstance(Sub(acx.STORE_INTS), Sub)                          # (byte automata keep the subclass)
+    for name in ("scan_batch", "flat_image_bytes", "flatten_flags"):      # (add_words and iter_batch exist on the extension too)
+        assert not hasattr(A, name), name
+    for i, k in enumerate([(1, 2, 3), (2, 3), (60000, 5)]):
+        A.add_word(k, i)
+    A.make_automaton()
+    assert list(A.iter((9, 1, 2, 3, 60000, 5))) == [(3, 0), (3, 1), (5, 2)]
+    B = pickle.loads(pickle.dumps(A))
+    assert type(B) is type(A) and list(B.iter((9, 1, 2, 3, 60000, 5))) == [(3, 0), (3, 1), (5, 2)] and sorted(B.keys()) == sorted(A.keys())
