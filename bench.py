@@ -724,7 +724,10 @@ def main():
         del A
     t_build = time.perf_counter() - t0
     t0 = time.perf_counter()
-    image, image_tensor = broadcast_image(blob, src=0, device=dev)
+    # iter_long workloads: the dictionary of its position-parallel form is built once on rank 0 and travels behind the blob in the SAME
+    # broadcast (parallel.broadcast_image(long_pack=True) / acx_image_set_long): no rank builds it from a device-to-host copy of its image
+    runs_long = args.mode == "iter_long" or (world == 1 and args.workload == "c2" and args.variant == 0 and not args.keys and (args.configs or "all") == "all")
+    image, image_tensor = broadcast_image(blob, src=0, device=dev, long_pack=runs_long)
     torch.cuda.synchronize()
     t_bcast = time.perf_counter() - t0
     del blob

@@ -184,6 +184,13 @@ int  acx_blob_validate(const void* blob, size_t nbytes);             /* host blo
 #define ACX_LONG_SMALL_BITS 18
 int  acx_blob_long_trie(const void* blob, size_t nbytes, acx_trie_t** out_trie, int32_t** real_vals, int64_t* n, int32_t* longest);
 
+/* The same dictionary as a relocatable PACK (a 256-byte header, the dictionary's flat image, the reported values), built once from the
+ * host blob: with N GPUs the pack travels behind the blob in the ONE broadcast of the set-up (pyahocorasick_amd/parallel.py
+ * broadcast_image(long_pack=True)) and acx_image_set_long installs it on every rank — without it every rank's first ACX_SCAN_LONG scan
+ * copies its whole image back to the host and builds the dictionary there.  A pack whose header says "does not apply" is valid: the
+ * image then keeps the serial walk.  malloc'd (acx_blob_free). */
+int  acx_blob_long_pack(const void* blob, size_t nbytes, void** pack, size_t* pack_bytes);
+
 typedef struct acx_image acx_image_t;
 /* copy a host blob to the current HIP device */
 int  acx_image_upload(const void* blob, size_t nbytes, acx_image_t** out);
@@ -202,6 +209,11 @@ int  acx_image_adopt(void* dev_blob, size_t nbytes, const void* host_header, acx
  * opened: libacx has no link-time dependency on it.  The image owns its device copy. */
 int  acx_image_broadcast(const void* host_blob, size_t nbytes, void* nccl_comm, int root, int rank, void* stream, acx_image_t** out);
 void acx_image_free(acx_image_t* img);
+/* install the pack of acx_blob_long_pack on an image that has not scanned in ACX_SCAN_LONG mode yet.  on_device = 0: `pack` is host
+ * memory (the dictionary is uploaded); 1: it is device memory — e.g. the tail of the broadcast's receive buffer — and is adopted IN
+ * PLACE: the caller keeps it alive as long as the image. */
+int  acx_image_set_long(acx_image_t* img, const void* pack, size_t pack_bytes, int on_device);
+int  acx_image_long_state(const acx_image_t* img);     /* 1: dictionary present, -1: the form does not apply (serial walk), 0: not built yet */
 int64_t acx_image_num_states(const acx_image_t* img);
 int64_t acx_image_num_classes(const acx_image_t* img);
 size_t  acx_image_nbytes(const acx_image_t* img);

@@ -111,6 +111,9 @@ SIGNATURES = {
     "acx_scan_host": (C.c_int, [_P, C.c_int, _P, _P, C.c_int64, _P, _P, _PP]),
     "acx_scan_host_nofinal": (C.c_int, [_P, C.c_int, _P, _P, C.c_int64, _P, _PP]),
     "acx_scan_host_ctx": (C.c_int, [_P, _P, _P, C.c_int64, _P, _P, _P, C.c_int32, _PP]),
+    "acx_blob_long_pack": (C.c_int, [_P, C.c_size_t, _PP, C.POINTER(C.c_size_t)]),
+    "acx_image_set_long": (C.c_int, [_P, _P, C.c_size_t, C.c_int]),
+    "acx_image_long_state": (C.c_int, [_P]),
     "acx_trie_scan_host": (C.c_int, [_P, C.c_int, _P, _P, C.c_int64, _P, _P, _P, _P, C.c_int32, C.c_int, _PP]),
     "acx_set_host_walk_bytes": (None, [C.c_int64]),
     "acx_host_walk_bytes": (C.c_int64, []),

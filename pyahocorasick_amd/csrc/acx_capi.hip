@@ -110,7 +110,7 @@ struct acx_image {
     int long_state = 0;
     acx_image* long_img = nullptr;
     int32_t* long_real = nullptr;              // device: what iter_long reports for dictionary entry i
-    uint32_t long_longest = 0; int64_t long_n_real = 0;
+    uint32_t long_longest = 0; int64_t long_n_real = 0; bool long_real_owned = true;
 };
 
 // The steady-state step of the itop walk uses 32-bit offsets: table and cells from the lower of
@@ -355,7 +355,7 @@ extern "C" void acx_image_free(acx_image_t* img) {
     if (img->owns && img->dev) (void)hipFree(img->dev);
     if (img->built_table) (void)hipFree(img->built_table);
     if (img->long_img) acx_image_free(img->long_img);
-    if (img->long_real) (void)hipFree(img->long_real);
+    if (img->long_real && img->long_real_owned) (void)hipFree(img->long_real);
     delete img;
 }
 extern "C" int64_t acx_image_num_states(const acx_image_t* img) { return img ? img->h.n_states : 0; }
@@ -1050,6 +1050,92 @@ static acx_image* image_long(acx_image* img) {
     img->long_img = li; img->long_real = d_real; img->long_n_real = n; img->long_longest = (uint32_t)longest; img->long_state = 1;
     return li;
 }
+
+// ---- the dictionary of iter_long as a travelling companion of the blob (multi-GPU: SURVEY §8e) ----------------------------------------
+// image_long above builds the dictionary per image, from the image itself: on N ranks that is N device-to-host copies of the whole
+// blob and N host builds.  acx_blob_long_pack builds it ONCE, from the host blob, into a relocatable pack that rides behind the blob
+// in the ONE broadcast (pyahocorasick_amd/parallel.py broadcast_image(long_pack=True)); acx_image_set_long installs it — a pack already
+// in device memory is adopted in place.
+struct acx_long_pack_header {       // 256 bytes, little-endian
+    uint64_t magic;                 // "ACXLONG1"
+    uint64_t total_bytes;           // of the pack
+    uint64_t d_off, d_bytes;        // the dictionary's flat image (0, 0: the position-parallel form does not apply to this automaton)
+    uint64_t real_off, n_real;      // int32[n_real]: what iter_long reports for dictionary entry i
+    uint32_t longest, reserved0;
+    uint64_t trie_version;          // of the blob the pack was made from
+    uint8_t pad[256 - 64];
+};
+static_assert(sizeof(acx_long_pack_header) == 256, "acx_long_pack_header is 256 bytes");
+static const uint64_t ACX_LONG_PACK_MAGIC = 0x31474E4F4C584341ull;     // "ACXLONG1"
+
+extern "C" int acx_blob_long_pack(const void* blob, size_t nbytes, void** pack_out, size_t* pack_bytes) {
+    if (!blob || !pack_out || !pack_bytes) return acx_fail(ACX_E_INVAL, "acx_blob_long_pack: NULL argument");
+    *pack_out = nullptr; *pack_bytes = 0;
+    acx_trie_t* t = nullptr; int32_t* real = nullptr; int64_t n = 0; int32_t longest = 0;
+    int rc = acx_blob_long_trie(blob, nbytes, &t, &real, &n, &longest);
+    if (rc) return rc;
+    void* d = nullptr; size_t dn = 0;
+    if (n > 0 && t) {
+        rc = acx_flatten_ex(t, ACX_FLATTEN_NO_ITOP | ACX_FLATTEN_TABLE_DEVICE, &d, &dn);
+        acx_trie_free(t);
+        if (rc) { free(real); return rc; }
+        acx_blob_header dh; memcpy(&dh, d, sizeof dh);
+        if (!dh.off_ppm) { acx_blob_free(d); d = nullptr; dn = 0; n = 0; }     // (a dictionary without a position-parallel section: the form does not apply)
+    } else if (t) acx_trie_free(t);
+    acx_long_pack_header h;
+    memset(&h, 0, sizeof h);
+    h.magic = ACX_LONG_PACK_MAGIC;
+    h.d_off = dn ? 256 : 0; h.d_bytes = dn;
+    h.real_off = dn ? 256 + ((dn + 255) & ~(size_t)255) : 0; h.n_real = dn ? (uint64_t)n : 0;
+    h.longest = (uint32_t)longest;
+    { acx_blob_header bh; memcpy(&bh, blob, sizeof bh); h.trie_version = bh.trie_version; }
+    h.total_bytes = dn ? h.real_off + (((size_t)n * 4 + 255) & ~(size_t)255) : 256;
+    uint8_t* out = (uint8_t*)calloc(1, (size_t)h.total_bytes);
+    if (!out) { if (d) acx_blob_free(d); free(real); return acx_fail(ACX_E_NOMEM, "acx_blob_long_pack: out of memory"); }
+    memcpy(out, &h, sizeof h);
+    if (dn) { memcpy(out + h.d_off, d, dn); memcpy(out + h.real_off, real, (size_t)n * 4); }
+    if (d) acx_blob_free(d);
+    free(real);
+    *pack_out = out; *pack_bytes = (size_t)h.total_bytes;
+    return ACX_OK;
+}
+
+extern "C" int acx_image_set_long(acx_image_t* img, const void* pack, size_t pack_bytes, int on_device) {
+    if (!img || !pack || pack_bytes < sizeof(acx_long_pack_header)) return acx_fail(ACX_E_INVAL, "acx_image_set_long: bad argument");
+    std::lock_guard<std::mutex> g(img->long_mu);
+    if (img->long_state) return acx_fail(ACX_E_STATE, "acx_image_set_long: the image already has its iter_long dictionary (or knows it gets none)");
+    acx_long_pack_header h;
+    if (on_device) HIP_TRY(hipMemcpy(&h, pack, sizeof h, hipMemcpyDeviceToHost)); else memcpy(&h, pack, sizeof h);
+    if (h.magic != ACX_LONG_PACK_MAGIC || h.total_bytes > pack_bytes || h.d_off + h.d_bytes > h.total_bytes || h.real_off + h.n_real * 4 > h.total_bytes)
+        return acx_fail(ACX_E_FORMAT, "acx_image_set_long: not a pack of acx_blob_long_pack");
+    if (h.trie_version != img->h.trie_version) return acx_fail(ACX_E_STATE, "acx_image_set_long: the pack was made from another version of the automaton");
+    if (!h.d_bytes || !img->ppm_g) { img->long_state = -1; return ACX_OK; }       // (does not apply: the serial walk stays)
+    const uint8_t* base = (const uint8_t*)pack;
+    acx_image* li = nullptr;
+    int32_t* d_real = nullptr;
+    int rc;
+    if (on_device) {
+        acx_blob_header dh;
+        HIP_TRY(hipMemcpy(&dh, base + h.d_off, sizeof dh, hipMemcpyDeviceToHost));
+        if ((rc = acx_image_adopt((void*)(base + h.d_off), (size_t)h.d_bytes, &dh, &li))) return rc;     // (in place: the caller keeps the pack alive, as it keeps the blob)
+        d_real = (int32_t*)(base + h.real_off);
+        img->long_real_owned = false;
+    } else {
+        if ((rc = acx_image_upload(base + h.d_off, (size_t)h.d_bytes, &li))) return rc;
+        if (hipMalloc((void**)&d_real, (size_t)h.n_real * 4 + 4) != hipSuccess || hipMemcpy(d_real, base + h.real_off, (size_t)h.n_real * 4, hipMemcpyHostToDevice) != hipSuccess) {
+            if (d_real) (void)hipFree(d_real);
+            acx_image_free(li);
+            return acx_fail(ACX_E_NOMEM, "acx_image_set_long: no device memory for the dictionary's values");
+        }
+        img->long_real_owned = true;
+    }
+    if (!li->ppm_g) { acx_image_free(li); if (img->long_real_owned && d_real) (void)hipFree(d_real); img->long_state = -1; return ACX_OK; }
+    li->long_state = -1;
+    img->long_img = li; img->long_real = d_real; img->long_n_real = (int64_t)h.n_real; img->long_longest = h.longest; img->long_state = 1;
+    return ACX_OK;
+}
+// 1: the image has its dictionary, -1: it gets none (the serial walk), 0: not built yet (the first ACX_SCAN_LONG scan builds it)
+extern "C" int acx_image_long_state(const acx_image_t* img) { return img ? img->long_state : 0; }
 
 enum { ACX_LONG_FALLBACK = 2 };         // internal: not this batch (the serial walk takes it)
 // the sweep over the records of the scan over D (in->matches / in->match_off, on the device), a prefix sum, the move, the total into

@@ -45,6 +45,18 @@ class DeviceBuffer:
             pass
 
 
+def long_pack(blob_bytes):
+    """the dictionary of the position-parallel iter_long for the automaton in `blob_bytes`, as one relocatable pack
+    (acx_blob_long_pack: host only) — what rides behind the blob in the set-up broadcast"""
+    buf = (C.c_char * len(blob_bytes)).from_buffer_copy(blob_bytes) if not isinstance(blob_bytes, C.Array) else blob_bytes
+    out, n = C.c_void_p(), C.c_size_t()
+    check(lib().acx_blob_long_pack(buf, len(blob_bytes), C.byref(out), C.byref(n)))
+    try:
+        return bytes((C.c_char * n.value).from_address(out.value))
+    finally:
+        lib().acx_blob_free(out)
+
+
 class Image:
     """A flat automaton resident in HBM.  Build from an Automaton (`Image.from_automaton`),
     from blob bytes, or adopt a device buffer that already holds the blob (the receive
@@ -90,6 +102,20 @@ class Image:
         hdr = (C.c_char * ACX_BLOB_HEADER_BYTES).from_buffer_copy(bytes(host_header[:ACX_BLOB_HEADER_BYTES]))
         check(lib().acx_image_adopt(C.c_void_p(dev_ptr), nbytes, hdr, C.byref(h)))
         return cls(h, keepalive)
+
+    def set_long(self, pack, pack_bytes=None, on_device=False):
+        """install the iter_long dictionary built once by long_pack() (acx_image_set_long): `pack` = host bytes, or — on_device — the
+        device address of a pack that the caller keeps alive (the tail of the broadcast's receive buffer)"""
+        if on_device:
+            check(lib().acx_image_set_long(self.handle, C.c_void_p(int(pack)), int(pack_bytes), 1))
+        else:
+            buf = (C.c_char * len(pack)).from_buffer_copy(pack)
+            check(lib().acx_image_set_long(self.handle, buf, len(pack), 0))
+
+    @property
+    def long_state(self):
+        """1: the iter_long dictionary is installed, -1: the position-parallel form does not apply, 0: not built yet"""
+        return lib().acx_image_long_state(self.handle)
 
     @property
     def num_states(self):

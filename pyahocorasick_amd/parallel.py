@@ -68,15 +68,44 @@ def broadcast_blob(blob, src=0, device=None):
     return t
 
 
-def broadcast_image(blob, src=0, device=None):
+def pack_with_long(blob):
+    """blob + the iter_long dictionary built from it (device.long_pack, host only), laid end to end for ONE broadcast: the pack starts
+    at the first 256-byte boundary behind the blob.  Returns (payload bytes, offset of the pack)."""
+    from .device import long_pack
+    pack = long_pack(blob)
+    off = (len(blob) + 255) & ~255
+    return bytes(blob) + b"\0" * (off - len(blob)) + pack, off
+
+
+def broadcast_image(blob, src=0, device=None, long_pack=False):
     """broadcast_blob + adopt the received device buffer as a libacx image (no extra copy).
-    Returns (Image, tensor); the Image keeps the tensor alive."""
+    Returns (Image, tensor); the Image keeps the tensor alive.
+
+    long_pack=True (ACX_SCAN_LONG workloads): the source rank builds the dictionary of the position-parallel iter_long ONCE from its
+    host blob and sends it behind the blob in the same broadcast; every rank adopts it in place (acx_image_set_long) — otherwise each
+    rank's first iter_long scan copies its whole image back to the host and builds the dictionary there."""
+    import torch
+    import torch.distributed as dist
     from .device import Image
-    t = broadcast_blob(blob, src, device)
+    distributed = dist.is_available() and dist.is_initialized()
+    rank = dist.get_rank() if distributed else src
+    payload, pack_off = blob, 0
+    if long_pack:
+        if rank == src:
+            payload, pack_off = pack_with_long(blob)
+        meta = torch.tensor([len(blob) if rank == src else 0, pack_off], dtype=torch.int64, device=device if device is not None else torch.device("cpu"))
+        if distributed:
+            dist.broadcast(meta, src=src)
+        blob_bytes, pack_off = int(meta[0].item()), int(meta[1].item())
+    t = broadcast_blob(payload if rank == src else b"", src, device)
     if t.device.type != "cuda":
         raise RuntimeError("broadcast_image needs a GPU tensor; the scan has no CPU path")
+    if not long_pack:
+        blob_bytes = t.numel()
     header = bytes(t[:ACX_BLOB_HEADER_BYTES].cpu().numpy().tobytes())
-    img = Image.adopt(t.data_ptr(), t.numel(), header, keepalive=t)
+    img = Image.adopt(t.data_ptr(), blob_bytes, header, keepalive=t)
+    if long_pack:
+        img.set_long(t.data_ptr() + pack_off, t.numel() - pack_off, on_device=True)
     return img, t
 
 

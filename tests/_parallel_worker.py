@@ -124,6 +124,25 @@ def main():
         no_halo, _ = orc.flat_iter(tgot, hay[lo1:hi1])
         straddle = [m for m in whole if lo1 <= m[0] < lo1 + longest - 1]
         assert len([1 for e, v in no_halo if e + lo1 < lo1 + longest - 1]) <= len(straddle)
+    # ---- iter_long: the dictionary of its position-parallel form rides behind the blob in ONE broadcast (parallel.pack_with_long):
+    #      every rank finds, at the offset rank 0 announces, a pack whose dictionary image validates and whose values are rank 0's
+    from pyahocorasick_amd.parallel import pack_with_long
+    import struct
+    import torch
+    payload, pack_off = (pack_with_long(blob) if rank == 0 else (b"", 0))
+    meta = torch.tensor([len(blob) if rank == 0 else 0, pack_off], dtype=torch.int64)
+    dist.broadcast(meta, src=0)
+    blob_bytes, pack_off = int(meta[0]), int(meta[1])
+    pgot = broadcast_blob(payload, src=0).numpy().tobytes()
+    assert pgot[:blob_bytes] == got and pack_off % 256 == 0 and pack_off >= blob_bytes
+    pack = pgot[pack_off:]
+    magic, total, d_off, d_bytes, real_off, n_real, longest_d = struct.unpack_from("<QQQQQQI", pack, 0)
+    assert magic == int.from_bytes(b"ACXLONG1", "little") and total == len(pack) and d_bytes > 0 and n_real > len(keys)
+    dbuf = C.create_string_buffer(pack[d_off:d_off + d_bytes], d_bytes)
+    _lib.check(_lib.lib().acx_blob_validate(dbuf, d_bytes))
+    digests = [None] * world
+    dist.all_gather_object(digests, hashlib.sha256(pack).hexdigest())
+    assert len(set(digests)) == 1
     dist.barrier()
     dist.destroy_process_group()
     if rank == 0:

@@ -102,3 +102,51 @@ def test_config5_shape_against_the_serial_walk():
     m = 3000
     mo, oe, ov = O.batch(flat[: m * L].tobytes(), np.arange(m + 1, dtype=np.int64) * L, 1)
     assert np.array_equal(got[0][0][: m + 1], mo) and np.array_equal(got[0][1][: mo[-1]], oe) and np.array_equal(got[0][2][: mo[-1]], ov)
+
+
+def test_dictionary_built_once_on_the_host_and_installed():
+    """multi-GPU set-up: the dictionary of the position-parallel iter_long is built ONCE from the host blob
+    (acx_blob_long_pack) and installed on an image — from host memory, and adopted in place from device memory where it sits
+    behind the blob as after parallel.broadcast_image(long_pack=True) — instead of every rank building it from a copy of its image;
+    both give the oracle's records, and a pack that says "does not apply" leaves the serial walk"""
+    from pyahocorasick_amd.device import long_pack
+    from pyahocorasick_amd.parallel import pack_with_long
+    from pyahocorasick_amd._lib import ACX_BLOB_HEADER_BYTES
+    keys, reads = dna_workload(3000, 2048, 150, seed=11)
+    A, O = build_pair(keys)
+    blob = A.flat_image_bytes()
+    flat = np.ascontiguousarray(reads.reshape(-1))
+    n, L = reads.shape
+    off = np.arange(n + 1, dtype=np.int64) * L
+    mo, oe, ov = O.batch(flat.tobytes(), off, 1)
+    d_hay = DeviceBuffer.from_numpy(flat, pad=64)
+
+    def check(img):
+        assert img.long_state == 1
+        assert img.ppm_kernel(stride=L, dev_hay=d_hay.ptr.value, n_hay=n, mode=acx.ACX_SCAN_LONG) is not None
+        sc = Scanner(img)
+        sc.scan(d_hay, len(flat), n, mode=acx.ACX_SCAN_LONG, stride=L)
+        moff, e, v, _ = sc.fetch()
+        assert np.array_equal(moff, mo) and np.array_equal(e, oe) and np.array_equal(v, ov)
+
+    img = Image.from_blob(blob)
+    assert img.long_state == 0
+    img.set_long(long_pack(blob))
+    check(img)
+    with pytest.raises(acx.AcxError):
+        img.set_long(long_pack(blob))                                   # (once)
+    payload, pack_off = pack_with_long(blob)
+    d_all = DeviceBuffer.from_numpy(np.frombuffer(payload, dtype=np.uint8), pad=64)
+    img2 = Image.adopt(d_all.ptr.value, len(blob), blob[:ACX_BLOB_HEADER_BYTES], keepalive=d_all)
+    img2.set_long(d_all.ptr.value + pack_off, len(payload) - pack_off, on_device=True)
+    check(img2)
+    B, OB = build_pair([b"a" * 70, b"ab"])
+    bb = B.flat_image_bytes()
+    img3 = Image.from_blob(bb)
+    img3.set_long(long_pack(bb))
+    assert img3.long_state == -1
+    hay = np.frombuffer(b"xxab" + b"a" * 80 + b"ab", dtype=np.uint8)
+    sc = Scanner(img3)
+    sc.scan(DeviceBuffer.from_numpy(hay, pad=64), len(hay), 1, mode=acx.ACX_SCAN_LONG, stride=len(hay))
+    moff, e, v, _ = sc.fetch()
+    assert list(zip(e.tolist(), v.tolist())) == OB.iter_long(hay.tobytes())
