@@ -164,7 +164,10 @@ enum { ACX_FLATTEN_NO_PPM       = 1,    /* no position-parallel section: ACX_SCA
        ACX_FLATTEN_WIDE         = 2,    /* the wide entry layout (27-bit states) although the narrow one would fit */
        ACX_FLATTEN_NO_ITOP      = 4,    /* no implicit top-of-trie structures */
        ACX_FLATTEN_TABLE_HOST   = 8,    /* the dense table is built on the host and travels in the blob */
-       ACX_FLATTEN_TABLE_DEVICE = 16 }; /* the blob carries the sparse form only: the table is built in HBM (default above 64 MiB) */
+       ACX_FLATTEN_TABLE_DEVICE = 16,   /* the blob carries the sparse form only: the table is built in HBM (default above 64 MiB) */
+       ACX_FLATTEN_HOT12        = 32 }; /* four-letter alphabets: k_ppm_stream4's hot cells as 12 bytes — the value of the shallowest key AND the id of
+                                           the depth-C node — instead of 8 + cid[] (include/acx_blob.h).  For dictionaries in which the cells that send
+                                           a walk deeper mostly end a key as well: the dictionaries of iter_long (acx_blob_long_pack uses it) */
 int  acx_flatten_ex(const acx_trie_t* t, uint32_t flags, void** blob, size_t* nbytes);
 void acx_blob_free(void* blob);
 int  acx_blob_validate(const void* blob, size_t nbytes);             /* host blob */

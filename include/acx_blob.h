@@ -194,6 +194,10 @@ typedef struct acx_blob_header {
  *       [1]  eowmask != 0: the value of its shallowest key; else the deep id of the depth-C node (0: none)
  *       cid[code_C] = the deep id of the depth-C node (0: absent or childless): read by the walks that go deeper from a
  *       cell whose second word holds a value.
+ *       off_hot4 != 0 with off_cid == 0 (ACX_FLATTEN_HOT12): the cells are 12 bytes and there is no cid section —
+ *       [0] as above, [1] the value of the shallowest key of eowmask (0: none), [2] the deep id of the depth-C node (0: none).
+ *       For dictionaries whose walks mostly start from cells that also end a key (the dictionaries of iter_long, acx_long.cpp):
+ *       with 8-byte cells every such walker waits for cid[] before its first record — one more round trip in every pass.
  *   gh (optional, g_global images): a hashed copy of G for LDS, see ACX_PPM_GH_* below.
  *   G2[code_F2] (global, L2 resident, at most 2^25 bits; optional): the same question as G asked with F2 > F symbols,
  *       put to the positions that passed G before they become candidates: set iff the depth-F2 node exists or a key
@@ -248,8 +252,8 @@ typedef struct acx_ppm_header {
     uint64_t off_hot;        /* uint32 [2 * K^C]: the 8-byte hot cells (stream kernel) */
     uint32_t top_base[ACX_PPM_MAX_C + 2];
     uint64_t off_chains;     /* singles */
-    uint64_t off_hot4;       /* uint32 [2 * K^C]: hot cells of k_ppm_stream4 (0: absent) */
-    uint64_t off_cid;        /* uint32 [K^C]: deep id of every depth-C node (with off_hot4) */
+    uint64_t off_hot4;       /* uint32 [2 * K^C]: hot cells of k_ppm_stream4 (0: absent); [3 * K^C] when off_cid == 0 */
+    uint64_t off_cid;        /* uint32 [K^C]: deep id of every depth-C node (with off_hot4; 0 with 12-byte cells) */
     uint64_t off_gh;         /* uint32 [ACX_PPM_GH_WORDS]: hashed copy of a global filter for LDS (g_global images; 0: absent) */
 } acx_ppm_header;
 

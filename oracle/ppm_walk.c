@@ -151,18 +151,20 @@ int64_t ppm_check_hot(const uint8_t* blob) {
     }
     /* hot4 / cid (k_ppm_stream4, include/acx_blob.h): the value where a key ends, else the id; "go deeper" for two symbols */
     if (h.sym_bits == 2) {
-        if (!h.off_hot4 || !h.off_cid) return -4;
+        if (!h.off_hot4) return -4;
         const uint32_t* hot4 = (const uint32_t*)(sec + h.off_hot4);
-        const uint32_t* cid = (const uint32_t*)(sec + h.off_cid);
+        const uint32_t* cid = h.off_cid ? (const uint32_t*)(sec + h.off_cid) : 0;      /* 0: 12-byte cells, the id in their third word (ACX_FLATTEN_HOT12) */
+        const uint32_t w = cid ? 2u : 3u;
         for (uint64_t c = 0; c <= nC; c++) {
-            if (c == nC) { if (hot4[2 * c] | hot4[2 * c + 1] | cid[c]) bad++; continue; }      /* the spare cell: all zero */
+            if (c == nC) { if (hot4[w * c] | hot4[w * c + 1] | (cid ? cid[c] : hot4[w * c + 2])) bad++; continue; }      /* the spare cell: all zero */
             const uint32_t* cell = cells + c * 8;
             uint32_t go = 0;
             for (uint32_t s1 = 0; s1 < 4; s1++)
                 for (uint32_t s2 = 0; s2 < 4; s2++)
                     if (cell[1] && (((cell[2] >> (4 + s1)) & 1u) || ((cell[2] >> (8 + 4 * s1 + s2)) & 1u))) go |= 1u << (4 * s1 + s2);
-            int ok = hot4[2 * c] == (cell[0] | go << 16) && (cell[0] >> 16) == 0 && cid[c] == cell[1];
-            ok = ok && hot4[2 * c + 1] == (cell[0] ? cell[3] : cell[1]);
+            int ok = hot4[w * c] == (cell[0] | go << 16) && (cell[0] >> 16) == 0 && (cid ? cid[c] : hot4[w * c + 2]) == cell[1];
+            if (cid) ok = ok && hot4[2 * c + 1] == (cell[0] ? cell[3] : cell[1]);
+            else ok = ok && hot4[3 * c + 1] == (cell[0] ? cell[3] : 0u);
             ok = ok && ((go != 0) == (cell[1] != 0));
             if (!ok) bad++;
         }

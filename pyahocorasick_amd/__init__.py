@@ -16,6 +16,6 @@ from .automaton import (  # noqa: F401
     unicode, load,
 )
 from ._lib import AcxError, AcxNoDevice, ACX_SCAN_ALL, ACX_SCAN_LONG, device_count  # noqa: F401
-from ._lib import ACX_FLATTEN_NO_PPM, ACX_FLATTEN_WIDE, ACX_FLATTEN_NO_ITOP, ACX_FLATTEN_TABLE_HOST, ACX_FLATTEN_TABLE_DEVICE  # noqa: F401
+from ._lib import ACX_FLATTEN_NO_PPM, ACX_FLATTEN_WIDE, ACX_FLATTEN_NO_ITOP, ACX_FLATTEN_TABLE_HOST, ACX_FLATTEN_TABLE_DEVICE, ACX_FLATTEN_HOT12  # noqa: F401
 
 __version__ = "0.1.0"

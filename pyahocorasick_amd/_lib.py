@@ -18,7 +18,7 @@ ACX_SCAN_ASYNC = 1
 ACX_SCAN_SKIP_WS = 2        # white space (0x09..0x0D, 0x20) never touches the automaton; indices stay those of the original bytes
 ACX_BLOB_HEADER_BYTES = 256
 # layout options of acx_flatten_ex (include/acx.h)
-ACX_FLATTEN_NO_PPM, ACX_FLATTEN_WIDE, ACX_FLATTEN_NO_ITOP, ACX_FLATTEN_TABLE_HOST, ACX_FLATTEN_TABLE_DEVICE = 1, 2, 4, 8, 16
+ACX_FLATTEN_NO_PPM, ACX_FLATTEN_WIDE, ACX_FLATTEN_NO_ITOP, ACX_FLATTEN_TABLE_HOST, ACX_FLATTEN_TABLE_DEVICE, ACX_FLATTEN_HOT12 = 1, 2, 4, 8, 16, 32
 
 
 class AcxError(RuntimeError):

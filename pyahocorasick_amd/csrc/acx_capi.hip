@@ -103,6 +103,7 @@ struct acx_image {
     const uint32_t* ppm_chains = nullptr;
     const uint32_t* ppm_hot4 = nullptr;        // hot cells and depth-C ids of k_ppm_stream4 (four-letter alphabets; nullptr: absent)
     const uint32_t* ppm_cid = nullptr;
+    bool ppm_hot12 = false;                    // hot4's cells are 12 bytes, the id inline (ACX_FLATTEN_HOT12)
     const uint32_t* ppm_gh = nullptr;          // hashed copy of a global filter for LDS (nullptr: absent)
     // ACX_SCAN_LONG position-parallel (acx_long.cpp): a second image, over the dictionary D = E + FE + U of this one, built on
     // the first such scan; long_state 0: not tried yet, 1: there, -1: does not apply (the serial walk stays)
@@ -160,7 +161,8 @@ static int image_resolve(acx_image* img, const uint32_t* lvl_host) {
                  inside(ph.off_top_val, (uint64_t)ph.n_top * 4) && inside(ph.off_kids, ((uint64_t)ph.n_deep + 1) * ph.K * 16) &&
                  inside(ph.off_chains, ((uint64_t)ph.n_chain + 1) * 16) &&
                  (ph.off_gh == 0 || (ph.g_global && inside(ph.off_gh, (uint64_t)ACX_PPM_GH_WORDS * 4))) &&
-                 ((ph.off_hot4 == 0 && ph.off_cid == 0) || (ph.sym_bits == 2 && inside(ph.off_hot4, (nC + 1) * 8) && inside(ph.off_cid, (nC + 1) * 4)));
+                 ((ph.off_hot4 == 0 && ph.off_cid == 0) || (ph.sym_bits == 2 && inside(ph.off_hot4, (nC + 1) * 8) && inside(ph.off_cid, (nC + 1) * 4)) ||
+                  (ph.sym_bits == 2 && ph.off_cid == 0 && inside(ph.off_hot4, (nC + 1) * 12)));      // (12-byte cells: no cid section)
             uint64_t tbase = 0;
             for (uint32_t d = 0; ok && d <= ph.C; d++) { ok = ph.top_base[d] == tbase; tbase += pw(ph.K, d); }
             ok = ok && ph.n_top == tbase && (ph.sym_arith == 0 || (ph.K == 4 && ph.sym_arith <= 7));
@@ -177,6 +179,7 @@ static int image_resolve(acx_image* img, const uint32_t* lvl_host) {
         img->ppm_chains = (const uint32_t*)(sec + ph.off_chains);
         img->ppm_hot4 = ph.off_hot4 ? (const uint32_t*)(sec + ph.off_hot4) : nullptr;
         img->ppm_cid = ph.off_cid ? (const uint32_t*)(sec + ph.off_cid) : nullptr;
+        img->ppm_hot12 = ph.off_hot4 != 0 && ph.off_cid == 0;
         img->ppm_gh = ph.off_gh ? (const uint32_t*)(sec + ph.off_gh) : nullptr;
         if (!ph.g_global && acx_ppm_lds_layout(ph.g_words, ph.sym_bits, ph.longest).total_words * 4 > ACX_PPM_LDS_BYTES) img->ppm_g = nullptr;
     }
@@ -762,7 +765,7 @@ static int ppm_plan(const acx_image* img, const acx_scan_params* p) {
 static bool ppm_plan_stream4(const acx_image* img, const acx_scan_params* p) {
     const acx_ppm_header& ph = img->ppm;
     const uint32_t f2 = (img->ppm_g2 && !((p->variant >> 20) & 1)) ? ph.F2 : 0u;       // (as scan_ppm sets acx_ppm_args.F2: no second level without its bitmap)
-    return img->ppm_hot4 && img->ppm_cid && !((p->variant >> 19) & 1) && !p->dev_off && !p->dev_skip && p->stride >= 8 && p->stride < 2048 &&
+    return img->ppm_hot4 && (img->ppm_cid || img->ppm_hot12) && !((p->variant >> 19) & 1) && !p->dev_off && !p->dev_skip && p->stride >= 8 && p->stride < 2048 &&
            ph.sym_bits == 2 && ph.pow2 && ph.sym_arith != 0 && ph.K == 4 && !ph.g_global && !f2 &&
            ph.C == 9 && ph.F == 10 && ppm_halo_pos(ph) == 32 && ph.longest <= 33 && ph.g_words * 4u == (128u << 10) &&
            ppm_stream_nsub(ph, 32, false) == 8;
@@ -826,7 +829,7 @@ static int scan_ppm(acx_image_t* img, const acx_scan_params* p, acx_result* r, h
     pa.n_items = n_items;
     pa.cls = img->cls; pa.g = img->ppm_g; pa.cells = img->ppm_cells; pa.top_val = img->ppm_top_val;
     pa.kids = img->ppm_kids; pa.chains = img->ppm_chains; pa.n_branch = ph.n_deep;
-    pa.hot4 = ((p->variant >> 19) & 1) ? nullptr : img->ppm_hot4; pa.cid = img->ppm_cid;        // (variant bit 19: the general stream kernel instead of k_ppm_stream4, A/B)
+    pa.hot4 = ((p->variant >> 19) & 1) ? nullptr : img->ppm_hot4; pa.cid = img->ppm_cid; pa.hot12 = img->ppm_hot12 ? 1u : 0u;        // (variant bit 19: the general stream kernel instead of k_ppm_stream4, A/B)
     pa.hot = img->ppm_hot; pa.symtab = img->ppm_symtab; pa.sym_arith = ph.sym_arith; pa.sym_lut = ph.sym_lut;
     pa.K = ph.K; pa.sym_bits = ph.sym_bits; pa.pow2 = ph.pow2; pa.C = ph.C; pa.F = ph.F; pa.g_words = ph.g_words;
     pa.g2 = ((p->variant >> 20) & 1) ? nullptr : img->ppm_g2; pa.F2 = pa.g2 ? ph.F2 : 0u;      // (variant bit 20: without the second-level filter, A/B)
@@ -1032,7 +1035,7 @@ static acx_image* image_long(acx_image* img) {
         if (rcb != ACX_OK || n == 0 || !t) { img->long_state = -1; return nullptr; }
     }
     void* blob2 = nullptr; size_t nb2 = 0;
-    int rc = acx_flatten_ex(t, ACX_FLATTEN_NO_ITOP | ACX_FLATTEN_TABLE_DEVICE, &blob2, &nb2);
+    int rc = acx_flatten_ex(t, ACX_FLATTEN_NO_ITOP | ACX_FLATTEN_TABLE_DEVICE | ACX_FLATTEN_HOT12, &blob2, &nb2);
     acx_trie_free(t);
     acx_image* li = nullptr;
     if (!rc) { rc = acx_image_upload(blob2, nb2, &li); acx_blob_free(blob2); }
@@ -1076,7 +1079,7 @@ extern "C" int acx_blob_long_pack(const void* blob, size_t nbytes, void** pack_o
     if (rc) return rc;
     void* d = nullptr; size_t dn = 0;
     if (n > 0 && t) {
-        rc = acx_flatten_ex(t, ACX_FLATTEN_NO_ITOP | ACX_FLATTEN_TABLE_DEVICE, &d, &dn);
+        rc = acx_flatten_ex(t, ACX_FLATTEN_NO_ITOP | ACX_FLATTEN_TABLE_DEVICE | ACX_FLATTEN_HOT12, &d, &dn);
         acx_trie_free(t);
         if (rc) { free(real); return rc; }
         acx_blob_header dh; memcpy(&dh, d, sizeof dh);

@@ -115,6 +115,7 @@ struct acx_ppm_args {
     const uint32_t* kids; const uint32_t* chains; uint32_t n_branch;
     const uint32_t* hot;     // k_ppm_stream: 8-byte hot cells
     const uint32_t* gh;      // k_ppm_stream, filter in global memory: its hashed copy for LDS (include/acx_blob.h ACX_PPM_GH_*; nullptr: ask G for every position)
+    uint32_t hot12;          // k_ppm_stream4: hot4's cells are 12 bytes, the id in the third word (no cid[])
     const uint32_t* hot4; const uint32_t* cid;   // k_ppm_stream4: its hot cells and the ids of the depth-C nodes (include/acx_blob.h; nullptr: absent or not wanted)
     const uint8_t* symtab;   // byte -> symbol, 0xFF = a byte of no key
     uint32_t sym_arith, sym_lut;   // K == 4: symbol = (byte >> (sym_arith - 1)) & 3, sym_lut = the four key bytes (0: table only)

@@ -260,7 +260,7 @@ int build_reversed(const acx_trie* t, acx_trie* rev, std::vector<int32_t>* depth
 
 // Returns ACX_OK with *out = nullptr when the automaton gets no ppm image (keys too long, deep rows
 // too large): the scan then uses the serial walk kernels.  *out is malloc'd.
-int acx_ppm_build(const acx_trie* t, const uint8_t* cls, uint32_t n_classes, bool has_other, uint8_t** out, size_t* nbytes) {
+int acx_ppm_build(const acx_trie* t, const uint8_t* cls, uint32_t n_classes, bool has_other, uint8_t** out, size_t* nbytes, bool hot12) {
     *out = nullptr; *nbytes = 0;
     if (t->count <= 0 || t->longest_word <= 0 || t->longest_word > (int64_t)ACX_PPM_MAX_LONGEST) return ACX_OK;
     try {
@@ -441,8 +441,9 @@ int acx_ppm_build(const acx_trie* t, const uint8_t* cls, uint32_t n_classes, boo
         h.off_cells = off;    off = align256(off + (size_t)nC * 32);
         h.off_hot = off;      off = align256(off + (size_t)nC * 8);
         if (h.sym_bits == 2) {                                          // four-letter alphabets: the cells k_ppm_stream4 reads (one spare cell behind them, all zero)
-            h.off_hot4 = off; off = align256(off + ((size_t)nC + 1) * 8);
-            h.off_cid = off;  off = align256(off + ((size_t)nC + 1) * 4);
+            // (hot12 — ACX_FLATTEN_HOT12, the dictionaries of iter_long —: 12-byte cells with the id in the third word, no cid section)
+            h.off_hot4 = off; off = align256(off + ((size_t)nC + 1) * (hot12 ? 12 : 8));
+            if (!hot12) { h.off_cid = off;  off = align256(off + ((size_t)nC + 1) * 4); }
         }
         if (h.g_global) { h.off_gh = off; off = align256(off + (size_t)ACX_PPM_GH_WORDS * 4); }       // (dropped again below when it rejects too little)
         h.off_top_val = off;  off = align256(off + (size_t)h.n_top * 4);
@@ -559,9 +560,15 @@ int acx_ppm_build(const acx_trie* t, const uint8_t* cls, uint32_t n_classes, boo
             if (hot4) {                                                  // include/acx_blob.h "hot4": the value where a key ends, the id elsewhere
                 uint32_t go = 0;
                 if (cell[1]) for (uint32_t t4 = 0; t4 < 16; t4++) if (((cell[2] >> (4 + (t4 >> 2))) | (cell[2] >> (8 + t4))) & 1u) go |= 1u << t4;
-                hot4[cc * 2] = mask | go << 16;
-                hot4[cc * 2 + 1] = mask ? cell[3] : cell[1];
-                cid[cc] = cell[1];
+                if (cid) {
+                    hot4[cc * 2] = mask | go << 16;
+                    hot4[cc * 2 + 1] = mask ? cell[3] : cell[1];
+                    cid[cc] = cell[1];
+                } else {                                                 // 12-byte cells: the value AND the id
+                    hot4[cc * 3] = mask | go << 16;
+                    hot4[cc * 3 + 1] = mask ? cell[3] : 0u;
+                    hot4[cc * 3 + 2] = cell[1];
+                }
             }
             if (F == C) { if (cell[0] | cell[1]) G[cc >> 5] |= 1u << (cc & 31); }
             else if (cell[0]) for (uint32_t s = 0; s < sigma; s++) { const uint64_t x = cc * sigma + s; G[x >> 5] |= 1u << (x & 31); }

@@ -80,7 +80,10 @@ __device__ __forceinline__ void lds_wr16(uint32_t byte_addr, uint32_t v) { *(lds
 
 __device__ __forceinline__ uint32_t top_base4(uint32_t d) { return 0x55555555u & ((1u << (2u * d)) - 1u); }   // (4^d - 1) / 3: top_base[d] of a four-symbol image
 
-template <bool DUMMY>
+// H12: the image's hot4 cells are 12 bytes — { eowmask | go << 16, value of the shallowest key (0: none), deep id of the depth-C node } —
+// (include/acx_blob.h; the dictionaries of iter_long, acx_long.cpp: there nearly every cell that sends a walk deeper also ends a key, so
+// with 8-byte cells nearly every walker waits for cid[] first — one more round trip to the L2 in the chain of every pass)
+template <bool H12>
 __global__ void __launch_bounds__(ACX_PPM_BLOCK) k_ppm_stream4(const acx_ppm_args a) {
     extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
     {
@@ -209,11 +212,12 @@ __global__ void __launch_bounds__(ACX_PPM_BLOCK) k_ppm_stream4(const acx_ppm_arg
     // ONE set of slot registers: step 1 is the last reader of a round's hot cells, step 3 loads the next round's into the
     // same registers (a second set would have to be copied into the first, and a copy of a loaded register is a wait)
     u32x2 hcO[S4_NE];
+    uint32_t hidO[H12 ? S4_NE : 1];                                    // H12: the ids of the depth-C nodes
     uint32_t ppO[S4_NE];                                               // entry (position + 33) | symbols that exist << 12 | (16 + the next two symbols) << 18
     uint32_t nO = 0, nN = 0, cgO = 0, cgN = 0, symO = wbase, symN = wbase;
     bool haveO = false;
 #pragma unroll
-    for (int e = 0; e < S4_NE; e++) { hcO[e].x = 0; hcO[e].y = 0; ppO[e] = 0; }
+    for (int e = 0; e < S4_NE; e++) { hcO[e].x = 0; hcO[e].y = 0; ppO[e] = 0; if (H12) hidO[e] = 0; }
 
     // bytes of the tile in wnext -> symbols (registers); the bytes of the tile at e_next are requested
     auto convert = [&](bool more, uint32_t e_next) {
@@ -354,7 +358,7 @@ __global__ void __launch_bounds__(ACX_PPM_BLOCK) k_ppm_stream4(const acx_ppm_arg
                     S4_SLOTS(e,
                         const uint32_t g = (gomask >> e) & 1u;
                         const uint32_t slot = (g != 0u && rnk < 64u) ? rnk : 64u;       // (slot 64: nobody reads it)
-                        u32x2 v; v.x = (ppO[e] & 0x7FFFFFu) | (hcO[e].x << 23); v.y = hcO[e].y;
+                        u32x2 v; v.x = (ppO[e] & 0x7FFFFFu) | (hcO[e].x << 23); v.y = H12 ? hidO[H12 ? e : 0] : hcO[e].y;
                         *(u32x2*)(dq + 2 * slot) = v;
                         rnk += g;
                     )
@@ -368,9 +372,9 @@ __global__ void __launch_bounds__(ACX_PPM_BLOCK) k_ppm_stream4(const acx_ppm_arg
                     // the cell's second word is a value (a key ends within the cell's levels as well: one walker in twelve): the id comes
                     // from cid[] — requested here, looked at when the others have taken their first step (their record gather is
                     // issued behind this load and waited for first: no round trip of its own)
-                    const bool pend = go && (pk >> 23) != 0u;
+                    const bool pend = !H12 && go && (pk >> 23) != 0u;         // (12-byte cells hand the id over whatever else they hold)
                     uint32_t cidv = 0;
-                    if (pend) cidv = a.cid[P.window(wpq) >> (32u - 2u * S4_C)];
+                    if (!H12 && pend) cidv = a.cid[P.window(wpq) >> (32u - 2u * S4_C)];
                     uint32_t dd = S4_C, wc = 0;
                     int32_t wa = 0, wb = 0;
                     uint32_t s1 = P.sym_at(wpq - S4_C);
@@ -591,6 +595,12 @@ __global__ void __launch_bounds__(ACX_PPM_BLOCK) k_ppm_stream4(const acx_ppm_arg
                     const uint32_t wa = ((ent >> 2) & 0x7FCu) + sbase;
                     const uint32_t X = __builtin_amdgcn_alignbit(lds_rd32(wa + 8u), lds_rd32(wa + 4u), ent << 1);
                     const uint32_t off = (X >> (32u - 2u * S4_C - 3u)) & ((8u << (2u * S4_C)) - 8u);
+                    if (H12) {
+                        const uint32_t o12 = qi < n ? off + (off >> 1) : (12u << (2u * S4_C));      // (cell x 12 bytes; the spare cell behind the last)
+                        const u32x2 c01 = *(const u32x2*)((const uint8_t*)a.hot4 + o12);
+                        hidO[H12 ? e : 0] = *(const uint32_t*)((const uint8_t*)a.hot4 + o12 + 8u);
+                        hcO[e] = c01;
+                    } else
                     hcO[e] = *(const u32x2*)((const uint8_t*)a.hot4 + ((ACX_S4_EXP & 1) ? ((qi < n ? off : 0u) & 56u) : (qi < n ? off : (8u << (2u * S4_C)))));
                     const uint32_t t5 = __builtin_amdgcn_ubfe(X, 32u - 2u * (S4_C + 2u), 4u) | 16u;     // 16 + the next two symbols: the cell's "go deeper" bit
                     ppO[e] = ent | (L << 12) | (t5 << 18);
@@ -643,14 +653,14 @@ __global__ void __launch_bounds__(ACX_PPM_BLOCK) k_ppm_stream4(const acx_ppm_arg
 
 // Does k_ppm_stream4 take this scan?  (acx_ppm_args as scan_ppm filled them for the stream kernels.)
 bool acx_ppm_stream4_eligible(const acx_ppm_args& a) {
-    return a.fast && a.hot4 && a.cid && !a.off && !a.skip && a.m24 && a.stride >= 8 && a.stride < 2048 &&
+    return a.fast && a.hot4 && (a.cid || a.hot12) && !a.off && !a.skip && a.m24 && a.stride >= 8 && a.stride < 2048 &&
            a.sym_bits == 2 && a.pow2 && a.sym_arith != 0 && a.K == 4 && !a.g_global && !a.F2 && a.nsub == 8 &&
            a.C == S4_C && a.F == S4_F && a.halo_pos == S4_HP && a.longest <= S4_HP + 1u && a.g_words * 4u == S4_G_BYTES;
 }
 
 hipError_t acx_launch_ppm_stream4(const acx_ppm_args& a, int64_t blocks, hipStream_t s) {
     const size_t lds_bytes = S4_G_BYTES + 16u * S4_WAVE_BYTES;
-    auto kernel = k_ppm_stream4<false>;
+    auto kernel = a.hot12 ? k_ppm_stream4<true> : k_ppm_stream4<false>;
     hipError_t e = hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(kernel, dim3((unsigned)blocks), dim3(ACX_PPM_BLOCK), lds_bytes, s, a);

@@ -439,7 +439,7 @@ int acx_flatten_ex(const acx_trie_t* t, uint32_t flags, void** blob_out, size_t*
     uint8_t* ppm = nullptr;
     size_t ppm_bytes = 0;
     {
-        const int rcp = (flags & ACX_FLATTEN_NO_PPM) ? ACX_OK : acx_ppm_build(t, cls, K, has_other, &ppm, &ppm_bytes);
+        const int rcp = (flags & ACX_FLATTEN_NO_PPM) ? ACX_OK : acx_ppm_build(t, cls, K, has_other, &ppm, &ppm_bytes, (flags & ACX_FLATTEN_HOT12) != 0);
         if (rcp) return rcp;
     }
     struct PpmFree { uint8_t* p; ~PpmFree() { free(p); } } ppm_guard{ppm};

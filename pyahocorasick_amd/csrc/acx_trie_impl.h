@@ -149,6 +149,6 @@ uint32_t acx_letter_value(const uint8_t* b, int len);     // decode one stored l
 
 // position-parallel scan image (acx_ppm.cpp; layout: include/acx_blob.h).  *out = nullptr (and ACX_OK)
 // when the automaton gets none.  malloc'd.
-int acx_ppm_build(const acx_trie* t, const uint8_t* cls, uint32_t n_classes, bool has_other, uint8_t** out, size_t* nbytes);
+int acx_ppm_build(const acx_trie* t, const uint8_t* cls, uint32_t n_classes, bool has_other, uint8_t** out, size_t* nbytes, bool hot12 = false);
 
 #endif

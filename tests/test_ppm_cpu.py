@@ -8,6 +8,7 @@ import pytest
 
 from helpers import build_pair, expected_pairs, load_json, dna_workload
 from oracle import orc
+import pyahocorasick_amd as acx
 
 RANDOM = load_json("ref_random.json")
 VECTORS = load_json("ref_vectors.json")
@@ -18,7 +19,9 @@ def _ppm_header(blob):
     if not off_ppm:
         return None
     names = ("magic", "K", "sym_bits", "pow2", "C", "F")
-    return dict(zip(names, struct.unpack_from("<6I", blob, off_ppm)))
+    d = dict(zip(names, struct.unpack_from("<6I", blob, off_ppm)))
+    d["off_hot4"], d["off_cid"] = struct.unpack_from("<2Q", blob, off_ppm + 232)      # (acx_ppm_header: 18 uint32, 8 uint64, top_base[22], off_chains, then these)
+    return d
 
 
 def _case_values(c):
@@ -53,6 +56,11 @@ def test_ppm_walk_randomised_vs_oracle():
         assert hdr is not None
         shapes.add((hdr["sym_bits"], hdr["pow2"], hdr["F"] > hdr["C"]))
         assert orc.ppm_check_hot(blob) == 0
+        if hdr["sym_bits"] == 2:                                         # ACX_FLATTEN_HOT12: 12-byte hot cells (value AND id), no cid section — pinned against the 32-byte cells too
+            b12 = A.flat_image_bytes(acx.ACX_FLATTEN_HOT12)
+            h12 = _ppm_header(b12)
+            assert h12["off_hot4"] != 0 and h12["off_cid"] == 0 and orc.ppm_check_hot(b12) == 0
+            assert orc.ppm_iter(b12, b"".join(keys)[:200]) == O.iter(b"".join(keys)[:200])
         text_alpha = alpha if rng.random() < 0.5 else alpha + b"#"       # a byte no key contains
         for _ in range(8):
             hay = bytes(rng.choice(text_alpha) for _ in range(rng.randint(0, 300)))
