@@ -530,7 +530,42 @@ def measure(torch, dist, dev, image, batches, mode, steps, warmup, P, event_ever
     dt = time.perf_counter() - t0
     gaps = np.diff(np.array([t0] + marks)) * 1e3
     step_ms = {"median": round(float(np.median(gaps)), 4), "max": round(float(gaps.max()), 4), "argmax": int(gaps.argmax())}
+    # ---- the union leg, BEHIND the timed region (it is in nothing that `value` is made of): with launches that overlap — several scan
+    #      streams — no per-launch span is a duration of the kernel (each includes the time it shares the chip), and timed region / launches
+    #      includes the time only gathers run.  What the algorithmic bytes of a launch can be divided by is the time the kernel occupies the
+    #      chip per launch: the UNION of its launch spans / launches.  Measured live: an event pair on the scan's stream around every launch
+    #      of 12 x P pipelined passes, the first and last P left out; tools/roofline_check.py recomputes the same from a rocprofv3 trace.
+    union_ms = None
+    if len(streams) > 1:
+        tstreams = [torch.cuda.current_stream()] + extra
+        U = 12 * P
+        evs = []
+        torch.cuda.synchronize()
+        for k in range(U):
+            if k >= P:
+                scs[k % P].wait()
+            so = tstreams[(k % P) % len(streams)]
+            ea, eb = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            ea.record(so)
+            step(k)
+            eb.record(so)
+            evs.append((ea, eb))
+        for x in scs:
+            x.wait()
+        torch.cuda.synchronize()
+        iv = sorted((evs[0][0].elapsed_time(ea), evs[0][0].elapsed_time(eb)) for ea, eb in evs[P:U - P])
+        tot, cs, ce = 0.0, None, None
+        for a_, b_ in iv:
+            if ce is None or a_ > ce:
+                if ce is not None:
+                    tot += ce - cs
+                cs, ce = a_, b_
+            else:
+                ce = max(ce, b_)
+        tot += (ce - cs) if ce is not None else 0.0
+        union_ms = tot / max(1, len(iv))
     return {"dt": dt, "dt_rank": dt_rank, "walk_ms": walk_ms, "pre": pre, "step_ms": step_ms, "matches_per_batch": matches_per_batch, "sync_ms": sync_ms,
+            "union_ms": union_ms,
             "repeats": R, "passes": passes,
             "bytes_rank": sum(batches[k % B][1] for k in range(passes)), "matches_rank": sum(matches_per_batch[k % B] for k in range(passes)),
             "scanner": scs[0], "stream": stream, "keepalive": (ssc if P > 1 else None, extra), "scan_streams": len(streams)}
@@ -541,11 +576,13 @@ def roofline_entry(image, batches, m, mode_name, workload, variant, event_every)
     profiles/traffic.json when it was measured on these kernel sources.
 
     The launch duration: with ONE scan stream, HIP events around the kernel inside the timed region (rocprofv3's average
-    agrees: profiles/r4_clock_check.txt).  With TWO (the default) launch spans overlap — the blocks of launch k + 1 start on
-    the CUs launch k's finished blocks leave — and no per-launch clock describes the kernel (events 0.2675 ms, rocprofv3
-    339 us for the same launches): there the duration is the UNION of the kernel's spans per launch, bounded from above by
-    timed region / launches = ms_per_step, which is what is used (so `frac` of such a line can only understate the kernel).
-    tools/roofline_check.py recomputes it from a rocprofv3 --kernel-trace of the same command.  `step` is the
+    agrees: profiles/r4_clock_check.txt).  With several (the default: three, three results in flight) launch spans overlap —
+    the blocks of launch k + 1 start on the CUs launch k's finished blocks leave — and no per-launch clock describes the
+    kernel (events 0.50 ms, rocprofv3 500 us for launches of which one completes every 0.26 ms): there the duration is the
+    UNION of the kernel's launch spans / launches — the time the kernel occupies the chip per launch —, measured by
+    measure()'s union leg with an event pair around every launch; tools/roofline_check.py recomputes it from a
+    rocprofv3 --kernel-trace of the same command (profiles/r5_*_spans.json).  Timed region / launches (`kernel_region_bound_ms`)
+    bounds it from above: the difference is the time in which only gathers run.  `step` is the
     regime-independent figure: all algorithmic bytes of a batch scan / ms_per_step."""
     B = len(batches)
     passes = m["passes"]
@@ -558,7 +595,7 @@ def roofline_entry(image, batches, m, mode_name, workload, variant, event_every)
     ms_pass = m["dt_rank"] / passes * 1e3
     overlap = m["scan_streams"] > 1
     walk_ev = float(np.mean(m["walk_ms"])) if m["walk_ms"] else pre["walk"]
-    walk = ms_pass if overlap else walk_ev
+    walk = (m.get("union_ms") or ms_pass) if overlap else walk_ev
     used_ppm = mode_name == "iter" and image.ppm_kernel(stride=L0, has_offsets=d_off0 is not None, variant=variant, min_hay_len=shortest0,
                                                           dev_hay=d_hay.data_ptr(), n_hay=n0)
     if mode_name != "iter":
@@ -609,8 +646,10 @@ def roofline_entry(image, batches, m, mode_name, workload, variant, event_every)
         "achieved": walk_bytes / (walk * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
         "frac": walk_bytes / (walk * 1e-3) / 1e9 / HBM_PEAK_GBS,
         "algorithmic_bytes": walk_bytes, "kernel_avg_ms": round(walk, 4),
-        "kernel_ms_source": ("union of the kernel's overlapping launch spans per launch, bounded by timed region / launches (two scan streams)"
+        "kernel_ms_source": ("union of the kernel's overlapping launch spans / launches: events around every launch of a pipelined leg behind the timed region "
+                             "(tools/roofline_check.py: the same from a rocprofv3 trace); timed region / launches bounds it from above"
                              if overlap else "HIP events around the kernel on its stream, inside the timed region"),
+        "kernel_region_bound_ms": round(ms_pass, 4),
         # HIP events around the kernel, on its stream, inside the timed region: in every N-th pass (an event
         # pair costs the stream ~19 us of idle time in the pass it is in).  With overlapping launches they are reported, not used.
         "kernel_events": {"every_nth_step": event_every, "samples": len(m["walk_ms"]), "avg_ms": round(walk_ev, 4)},

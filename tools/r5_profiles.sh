@@ -22,12 +22,12 @@ if [ -n "$CALIB" ]; then
 fi
 for CFG in $CFGS; do
   case $CFG in
-    c2)  BARGS="--configs none"; MARGS=""; NAME=headline;;
-    c5)  BARGS="--configs none --mode iter_long"; MARGS="--mode iter_long"; NAME=c5_iter_long;;
+    c2)  BARGS="--configs none"; MARGS=""; NAME=headline; KEY=c2_iter; KERNEL=k_ppm_stream4; HB=150000000;;
+    c5)  BARGS="--configs none --mode iter_long"; MARGS="--mode iter_long"; NAME=c5_iter_long; KEY=c2_iter_long; KERNEL=k_ppm_stream4; HB=150000000;;
     c2o) BARGS="--configs none --workload c2o"; MARGS=""; NAME=c2_offsets;;
     c2k) BARGS="--configs none --workload c2k"; MARGS=""; NAME=c2_long_keys;;
-    c3)  BARGS="--configs none --workload c3 --steps 12"; MARGS="--alphabet text --bytes 536870912"; NAME=c3;;
-    c4)  BARGS="--configs none --workload c4 --steps 12"; MARGS="--alphabet snort --keys 1000000 --bytes 536870912"; NAME=c4;;
+    c3)  BARGS="--configs none --workload c3 --steps 12"; MARGS="--alphabet text --bytes 536870912"; NAME=c3; KEY=c3_iter; KERNEL=k_ppm_stream; HB=536870912;;
+    c4)  BARGS="--configs none --workload c4 --steps 12"; MARGS="--alphabet snort --keys 1000000 --bytes 536870912"; NAME=c4; KEY=c4_iter; KERNEL=k_ppm_stream; HB=536870912;;
   esac
   T=${TAG}_${CFG}
   echo "== $CFG: rocprofv3 --kernel-trace --stats -- python bench.py $BARGS --cpu-sample-reads 0 --no-e2e"
@@ -43,7 +43,9 @@ for CFG in $CFGS; do
       (cd /tmp && timeout -k 5 240 rocprofv3 --pmc $C --output-format csv -d $OUT/${T}_pmc_s$i -o pmc -- python $R/tools/microbench.py --variants 0 --reps 3 $MARGS > $OUT/${T}_pmc_s$i.log 2>&1; echo "pmc [$C] rc=$?")
     done
     python tools/pmc_summary.py $OUT ${T} > $OUT/${T}_pmc_summary.json 2> $OUT/${T}_pmc_summary.err
+    python tools/make_traffic.py $OUT/${T}_pmc_summary.json $KEY $KERNEL "" $HB > $OUT/${T}_traffic_entry.json 2>&1; tail -4 $OUT/${T}_traffic_entry.json
     find $OUT -name "*.csv" -size +4M -delete
   fi
 done
+cp profiles/traffic.json $OUT/${TAG}_traffic.json
 echo "== done"
