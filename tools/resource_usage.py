@@ -14,10 +14,12 @@ FIELDS = [("TotalSGPRs", "SGPR"), ("VGPRs", "VGPR"), ("SGPRs Spill", "s-spill"),
 
 
 def demangle(n):
-    try:
-        return subprocess.check_output(["/opt/rocm/lib/llvm/bin/llvm-cxxfilt", n], text=True).strip()
-    except Exception:
-        return n
+    for tool in ("/opt/rocm/lib/llvm/bin/llvm-cxxfilt", "c++filt"):
+        try:
+            return subprocess.check_output([tool, n], text=True).strip()
+        except Exception:
+            continue
+    return n
 
 
 def main(files):
