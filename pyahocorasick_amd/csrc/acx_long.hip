@@ -124,7 +124,7 @@ __device__ __forceinline__ uint32_t wave_incl_scan_u32(uint32_t v, int lane) {
 constexpr uint32_t LC_CAP = ACX_LC_CAP;                                     // compact records per wave in LDS: 12 bytes each, 15 KiB; one wave per block (the waves share nothing), ten blocks per CU
 constexpr uint32_t LC_CHUNKS = LC_CAP / 64;
 struct LongLds {
-    uint2 a[LC_CAP];                                                  // {start, up_start}; a lane's reports are written over its records from the front
+    uint2 a[LC_CAP + 64];                                             // {start, up_start}; a lane's reports are written over its records from the front; [LC_CAP + lane]: where a lane with nothing to report writes
     uint32_t v[LC_CAP];                                               // index | length << 24 | kind << 30
     uint32_t first_bits[LC_CAP / 32];                                 // raw record i of the batch is the first of its haystack
     uint32_t cbase[LC_CHUNKS + 1];                                    // compact records in front of raw chunk c
@@ -134,29 +134,24 @@ struct LongLds {
 // one haystack over its compact records a[first .. first + n): reports written over them from the front; returns how many
 // small: the dictionary has fewer than 2^18 entries — the index is 18 bits, the six above it `below` (acx_long.cpp): a remembered node's
 // path is followed for that many letters, not for longest - 1
-__device__ __forceinline__ uint32_t sweep_compact(LongLds* L, uint32_t first, uint32_t n, int32_t r, int32_t reach, bool small) {
+__device__ __forceinline__ uint32_t sweep_compact(LongLds* L, uint32_t first, uint32_t n, int32_t r, int32_t reach, bool small, uint32_t dump) {
     uint32_t k = 0, w = 0, path = 0, last_e = 0, last_i = 0, k_last = 0;
     int32_t p = 0, limit = 0;
     const uint32_t imask = small ? (1u << ACX_LONG_SMALL_BITS) - 1u : 0xFFFFFFu;
     if (n == 0u) return 0u;
-    // The record of trip k + 1 is requested while trip k is worked off (a trip is a chain LDS read -> forty instructions -> the next
-    // address, and the wave's LDS — 15 KiB — leaves a SIMD three such chains to interleave); only the trip that ends a path reads
-    // somewhere else: behind the record it reports.
-    uint2 na = L->a[first]; uint32_t nv = L->v[first];
+    // Straight-line: one LDS read and one LDS write per trip whatever the walk is doing — a lane with nothing to report writes to its
+    // dump slot —, every condition a 0 / 1 word.  (The record of the next trip requested early and re-requested after a rewind, a
+    // predicated write, the two forms of `limit` as branches: five exec-mask regions per trip, 370 ns per trip and wave.)
     for (;;) {
         const uint32_t eor = k >= n ? 1u : 0u;
         if (eor & (path ^ 1u)) break;
-        const uint2 a = na;
-        const uint32_t val = nv;
-        { const uint32_t kp = first + (k + 1u < n ? k + 1u : n - 1u); na = L->a[kp]; nv = L->v[kp]; }
+        const uint32_t kk = first + (eor ? n - 1u : k);
+        const uint2 a = L->a[kk];
+        const uint32_t val = L->v[kk];
         const int32_t start = (int32_t)a.x, up = (int32_t)a.y;
         const uint32_t kind = val >> 30, idx = val & imask;
         const int32_t e = start + (int32_t)((val >> 24) & 63u) - 1;
-#ifdef ACX_LONG_NOK3
-        const uint32_t now = kind == 2u ? 1u : 0u;
-#else
         const uint32_t now = (kind >> 1);                              // kinds 2 (FE) and 3 (E, nothing below): reported at once
-#endif
         const uint32_t p_end = path & (eor | (e > limit ? 1u : 0u));
         const uint32_t p_hit = path & (p_end ^ 1u) & (start == p ? 1u : 0u);
         const uint32_t fires = (path ^ 1u) & (eor ^ 1u) & (start >= r ? 1u : 0u) & (up < r ? 1u : 0u);
@@ -164,17 +159,13 @@ __device__ __forceinline__ uint32_t sweep_compact(LongLds* L, uint32_t first, ui
         const uint32_t emit = p_end | (hit & now);
         const uint32_t keep = hit & (now ^ 1u);                        // an E with events below: remembered, its path followed
         uint2 out; out.x = p_end ? last_e : (uint32_t)e; out.y = p_end ? last_i : idx;
-        if (emit) L->a[first + w] = out;                               // (w <= the record being read or remembered)
+        L->a[emit ? first + w : dump] = out;                            // (w <= the record being read or remembered)
         w += emit;
         r = emit ? (int32_t)out.x + 1 : r;
         last_e = keep ? (uint32_t)e : last_e; last_i = keep ? idx : last_i;
-#ifdef ACX_LONG_NOBELOW
-        limit = keep ? start + reach : limit;
-#else
-        limit = keep ? (small ? e + (int32_t)((val >> ACX_LONG_SMALL_BITS) & 63u) : start + reach) : limit;
-#endif   // (below <= longest - length: never beyond p + reach)
+        const int32_t lim_new = small ? e + (int32_t)((val >> ACX_LONG_SMALL_BITS) & 63u) : start + reach;   // (below <= longest - length: never beyond p + reach)
+        limit = keep ? lim_new : limit;
         const uint32_t k_next = p_end ? k_last + 1u : k + 1u;
-        if (p_end) { const uint32_t kr = first + (k_next < n ? k_next : n - 1u); na = L->a[kr]; nv = L->v[kr]; }    // (behind the report's own write: slot w - 1 <= k_last)
         k_last = keep ? k : k_last;
         p = (fires & keep) ? start : p;
         path = (path & (emit ^ 1u)) | (fires & keep);
@@ -283,7 +274,7 @@ __global__ void __launch_bounds__(64) k_long_sweep(const acx_long_args a) {
             auto compact_at = [&](uint32_t raw) -> uint32_t { return L->cbase[raw >> 6] + (uint32_t)__popcll(L->kmask[raw >> 6] & ((1ull << (raw & 63u)) - 1ull)); };
             const uint32_t cf = mine ? compact_at(lo_rel - start) : 0u;
             const uint32_t cl = mine ? compact_at(lo_rel - start + nrec) : 0u;
-            if (mine && !(ACX_LONG_EXP & 1)) c = sweep_compact(L, cf, cl - cf, r0, reach, small);
+            if (mine && !(ACX_LONG_EXP & 1)) c = sweep_compact(L, cf, cl - cf, r0, reach, small, LC_CAP + (uint32_t)lane);
             if (ACX_LONG_EXP & 1) c = (cl - cf) / 2;
             const uint32_t ci = wave_incl_scan_u32(c, lane), tot = (uint32_t)__shfl((int)ci, 63, 64);
             long_wave_sync();                                           // (every raw record of this batch has been read: the reports go over them)
