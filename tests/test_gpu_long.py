@@ -150,3 +150,22 @@ def test_dictionary_built_once_on_the_host_and_installed():
     sc.scan(DeviceBuffer.from_numpy(hay, pad=64), len(hay), 1, mode=acx.ACX_SCAN_LONG, stride=len(hay))
     moff, e, v, _ = sc.fetch()
     assert list(zip(e.tolist(), v.tolist())) == OB.iter_long(hay.tobytes())
+
+
+def test_large_dictionary_takes_the_24_bit_form():
+    """a dictionary of 2^18 entries or more carries no `below` in its values (include/acx.h: the index then takes 24 bits and the
+    sweep follows a remembered node's path for longest - 1 letters): 250 000 DNA keys -> D of ~450 000 entries, three ways as above"""
+    from pyahocorasick_amd.workloads import dna_keys, dna_reads
+    import ctypes as C
+    from pyahocorasick_amd._lib import check, lib
+    keys = dna_keys(250_000, seed=5)
+    A, O = build_pair(keys)
+    blob = A.flat_image_bytes()
+    trie, real, n, longest = C.c_void_p(), C.c_void_p(), C.c_int64(), C.c_int32()
+    buf = (C.c_char * len(blob)).from_buffer_copy(blob)
+    check(lib().acx_blob_long_trie(buf, len(blob), C.byref(trie), C.byref(real), C.byref(n), C.byref(longest)))
+    lib().acx_trie_free(trie); lib().acx_blob_free(real)
+    assert n.value >= 1 << 18, n.value
+    reads = dna_reads(keys, 6000, 150, seed=6)
+    flat = np.ascontiguousarray(reads.reshape(-1))
+    assert _three_way(A, O, flat, n=reads.shape[0], L=reads.shape[1]) is not None
