@@ -169,3 +169,26 @@ def test_large_dictionary_takes_the_24_bit_form():
     reads = dna_reads(keys, 6000, 150, seed=6)
     flat = np.ascontiguousarray(reads.reshape(-1))
     assert _three_way(A, O, flat, n=reads.shape[0], L=reads.shape[1]) is not None
+
+
+def test_byte_signatures_at_scale():
+    """an 8-bit alphabet at scale (verdict r4, weak 1b): 60 000 Snort-style signatures of 4-60 bytes over packets — iter_long takes the
+    position-parallel form (k_ppm_stream over D) and agrees with the serial walk and the oracle; with signatures of up to 128 bytes D
+    holds nodes deeper than 63 letters, the form does not apply — the pack says so, long_state is -1 — and the serial walk answers"""
+    from pyahocorasick_amd.device import long_pack
+    from pyahocorasick_amd.workloads import packet_payloads, snort_signatures
+    sigs = snort_signatures(60_000, seed=9, lo=4, hi=60)
+    A, O = build_pair(sigs)
+    flat, off = packet_payloads(sigs, 4 << 20, seed=10, plant_frac=0.6)
+    flat = np.ascontiguousarray(np.frombuffer(flat, dtype=np.uint8) if not isinstance(flat, np.ndarray) else flat)
+    assert _three_way(A, O, flat, off=off) is not None
+    sigs2 = snort_signatures(20_000, seed=11, lo=4, hi=128)
+    assert max(len(s) for s in sigs2) > 64
+    B, OB = build_pair(sigs2)
+    blob = B.flat_image_bytes()
+    img = Image.from_blob(blob)
+    img.set_long(long_pack(blob))
+    assert img.long_state == -1
+    flat2, off2 = packet_payloads(sigs2, 1 << 20, seed=12, plant_frac=0.6)
+    flat2 = np.ascontiguousarray(np.frombuffer(flat2, dtype=np.uint8) if not isinstance(flat2, np.ndarray) else flat2)
+    assert _three_way(B, OB, flat2, off=off2, expect_plan=False) is None
