@@ -425,6 +425,10 @@ struct acx_result {
     uint2* ext_matches = nullptr; int64_t ext_capacity = 0; int64_t* ext_match_off = nullptr; int64_t ext_off_base = 0;
     acx_result* long_inner = nullptr;           // ACX_SCAN_LONG position-parallel: the result of the scan over the dictionary D
     bool long_pending = false;                  // ... asynchronous: the sweep over the inner scan's records is queued behind its gather (long_complete)
+    // the sweep straight from the record pool (acx_long.h acx_long_fuse_args): on the INNER result `fuse` points at the outer one's arguments — its
+    // stream scan then queues k_long_gather_sweep where it would queue k_ppm_gather_pos, into `long_out` —, `fused` says whether it did
+    const acx_long_fuse_args* fuse = nullptr; bool fused = false; DevBuf<uint2> long_out; acx_ppm_gather_args fused_ga;
+    acx_long_fuse_args fuse_args; DevBuf<uint32_t> long_aux; bool long_nofuse = false; uint32_t fail_seen = 0;
     acx_image* long_img = nullptr; uint32_t reruns = 0;   // reruns: scans of this result that were issued again at completion (pool too small, a broken promise)
     hipStream_t copy_stream = nullptr;
     bool ppm_self = false;      // the pending stream scan is a fixed-stride one: block sums, totals and clean-up in k_ppm_gather_pos
@@ -471,6 +475,7 @@ struct acx_result {
         scratch.release(); scr_off.release(); ppm_ctl.release(); hay_local.release(); wave_desc.release(); wave_aux.release();
         events.release(); matches.release(); h_off.release(); h_matches.release(); h_final.release(); h_total.release();
         in_hay.release(); in_off.release(); in_init.release(); in_base.release(); in_skip.release(); h_stage.release();
+        long_out.release(); long_aux.release();
         skip_kept.release(); skip_off.release(); matches2.release();
         ws_hay.release(); ws_map.release(); ws_cnt.release(); ws_skip.release(); ws_tile_off.release(); ws_off.release(); ws_partials.release();
         for (auto& e : ev) if (e) (void)hipEventDestroy(e);
@@ -534,6 +539,27 @@ static int finish_records(acx_result* r) {
 
 // position-parallel scan: the record pool ran out (grow it and scan again) or the match buffer
 // is too small (grow it and copy again: the pool is intact)
+// the second half of a stream scan: k_ppm_gather_pos / k_ppm_gather — or, for the scan over iter_long's dictionary (r->fuse), the sweep straight
+// from the record pool where it applies: a fixed-stride scan whose haystacks are no longer than a tile, positions a 32-bit multiply-high from
+// their haystack, no stream contexts
+static int launch_gather_or_fused(acx_result* r, hipStream_t g) {
+    r->fused = false;
+    const acx_ppm_gather_args& ga = r->pend_ga;
+    if (r->fuse && r->ppm_self && !ga.off && !ga.skip && ga.stride > 0 && ga.stride <= ga.tile_pos) {
+        const uint64_t span = ((uint64_t)ga.tpw + ga.share_a) * (uint64_t)ga.tile_pos, st = (uint64_t)ga.stride;
+        if ((span + 2 * st) * st < ((uint64_t)1 << 32) && (uint64_t)ga.n_hay * st + st < ((uint64_t)1 << 32)) {
+            int rc = r->long_out.ensure((size_t)ga.capacity + (size_t)ga.n_waves * ACX_LONG_WAVE_SLACK + 64);
+            if (rc) return rc;
+            r->fused_ga = ga; r->fused_ga.matches = r->long_out.p;
+            HIP_TRY(acx_launch_long_gather_sweep(r->fused_ga, *r->fuse, g));
+            r->fused = true;
+            return ACX_OK;
+        }
+    }
+    HIP_TRY(acx_launch_ppm_gather(r->pend_pa.wave_desc, r->pend_ga.n_waves, r->pend_item_off, r->pend_ga, g));
+    return ACX_OK;
+}
+
 static int ppm_complete(acx_result* r) {
     hipStream_t s = r->stream;
     for (int attempt = 0;; attempt++) {
@@ -568,7 +594,7 @@ static int ppm_complete(acx_result* r) {
             if ((rc = ppm_enqueue(r, r->pend_img, r->ppm_chunk ? &r->pend_cka : nullptr, r->ppm_tail ? &r->pend_tail : nullptr, s))) return rc;
         } else {
             hipStream_t g = (r->ppm_stream && r->use_side && r->side) ? r->side : s;
-            if (r->ppm_stream) HIP_TRY(acx_launch_ppm_gather(r->pend_pa.wave_desc, r->pend_ga.n_waves, r->pend_item_off, r->pend_ga, g));
+            if (r->ppm_stream) { if ((rc = launch_gather_or_fused(r, g))) return rc; }
             else HIP_TRY(acx_launch_ppm_compact(r->pend_ca, r->pend_items, g));
             HIP_TRY(hipEventRecord(r->done, g));
         }
@@ -683,7 +709,7 @@ static int ppm_enqueue(acx_result* r, acx_image* img, const acx_chunk_args* ca, 
             g = r->side;
         }
         if (r->timed_all) HIP_TRY(hipEventRecord(r->ev[2], g));
-        HIP_TRY(acx_launch_ppm_gather(r->pend_pa.wave_desc, r->pend_ga.n_waves, r->pend_item_off, r->pend_ga, g));
+        { int rcg = launch_gather_or_fused(r, g); if (rcg) return rcg; }
     } else {
         HIP_TRY(acx_launch_scan(r->pend_counts, ni, r->pend_item_off, r->partials.p, s));
         if (r->timed_all) HIP_TRY(hipEventRecord(r->ev[2], s));
@@ -1147,24 +1173,36 @@ static int long_enqueue_sweep(acx_result* r, acx_image* img, hipStream_t g) {
     acx_result* in = r->long_inner;
     const size_t n = (size_t)r->n_hay;
     int rc;
-    if ((rc = r->matches.ensure(in->matches.cap + 1))) return rc;      // (no more records than the scan over D can hold)
     if ((rc = r->h_total.ensure(4))) return rc;
-    acx_long_args la;
-    la.rec = in->matches.p; la.off = in->match_off.p; la.n_hay = r->n_hay; la.index_base = r->pend_params.dev_index_base;
-    la.longest = img->long_longest; la.counts = r->counts.p;
-    // (queued behind a scan that may turn out incomplete — more records than its buffer holds: its offsets then point beyond the
-    //  buffer — the kernels look at the scan's total first and leave; entry indices are checked against the dictionary's size)
-    la.rec_capacity = (int64_t)in->matches.cap; la.n_real = img->long_n_real;
-    if (r->timed) HIP_TRY(hipEventRecord(r->ev[2], g));
-    HIP_TRY(acx_launch_long_sweep(la, g));
-    HIP_TRY(acx_launch_scan(r->counts.p, (int64_t)n, r->match_off.p, r->partials.p, g));
-    HIP_TRY(acx_launch_long_move(la, r->match_off.p, img->long_real, r->matches.p, g));
-    if (r->timed) HIP_TRY(hipEventRecord(r->ev[3], g));
+    if (in->fused) {
+        // the inner scan's second half WAS the sweep (k_long_gather_sweep, straight from the record pool): counts per haystack and the packed
+        // reports of every scan wave are there — a prefix sum and the move remain
+        if ((rc = r->matches.ensure(in->matches.cap + 1))) return rc;
+        if (r->timed) HIP_TRY(hipEventRecord(r->ev[2], g));
+        HIP_TRY(acx_launch_scan(r->counts.p, (int64_t)n, r->match_off.p, r->partials.p, g));
+        HIP_TRY(acx_launch_long_move_waves(in->fused_ga, r->fuse_args, r->match_off.p, img->long_real, r->matches.p, g));
+        if (r->timed) HIP_TRY(hipEventRecord(r->ev[3], g));
+        HIP_TRY(hipMemcpyAsync(r->h_total.p + 3, r->fuse_args.fail, sizeof(uint32_t), hipMemcpyDeviceToHost, g));
+    } else {
+        if ((rc = r->matches.ensure(in->matches.cap + 1))) return rc;      // (no more records than the scan over D can hold)
+        acx_long_args la;
+        la.rec = in->matches.p; la.off = in->match_off.p; la.n_hay = r->n_hay; la.index_base = r->pend_params.dev_index_base;
+        la.longest = img->long_longest; la.counts = r->counts.p;
+        // (queued behind a scan that may turn out incomplete — more records than its buffer holds: its offsets then point beyond the
+        //  buffer — the kernels look at the scan's total first and leave; entry indices are checked against the dictionary's size)
+        la.rec_capacity = (int64_t)in->matches.cap; la.n_real = img->long_n_real;
+        if (r->timed) HIP_TRY(hipEventRecord(r->ev[2], g));
+        HIP_TRY(acx_launch_long_sweep(la, g));
+        HIP_TRY(acx_launch_scan(r->counts.p, (int64_t)n, r->match_off.p, r->partials.p, g));
+        HIP_TRY(acx_launch_long_move(la, r->match_off.p, img->long_real, r->matches.p, g));
+        if (r->timed) HIP_TRY(hipEventRecord(r->ev[3], g));
+    }
     HIP_TRY(hipMemcpyAsync(r->h_total.p, r->match_off.p + n, sizeof(int64_t), hipMemcpyDeviceToHost, g));
     if (!r->done) HIP_TRY(hipEventCreateWithFlags(&r->done, hipEventDisableTiming));
     HIP_TRY(hipEventRecord(r->done, g));
     return ACX_OK;
 }
+static int scan_long_ppm(acx_image* img, acx_image* li, const acx_scan_params* p, acx_result* r, hipStream_t s);
 // completion of an ACX_SCAN_LONG scan in its position-parallel form: the scan over D first (a pool that was too small is scanned
 // again there — the sweep then ran over nothing useful and is issued again), then the sweep's own event
 static int long_complete(acx_result* r) {
@@ -1178,6 +1216,15 @@ static int long_complete(acx_result* r) {
         if ((rc = long_enqueue_sweep(r, img, r->stream))) return rc;
     }
     HIP_TRY(hipEventSynchronize(r->done));
+    if (in->fused && (uint32_t)r->h_total.p[3] != r->fail_seen) {
+        // a batch of 64 haystacks held more records than a wave's LDS (or a wave's reports outgrew its region): this result sweeps the
+        // GATHERED records from now on (k_ppm_gather_pos + k_long_sweep, which takes haystacks of any size), starting with this scan
+        r->fail_seen = (uint32_t)r->h_total.p[3];
+        r->long_nofuse = true;
+        acx_scan_params p = r->pend_params;
+        p.flags &= ~(int32_t)ACX_SCAN_ASYNC;
+        return scan_long_ppm(img, img->long_img, &p, r, r->stream);
+    }
     r->total = r->h_total.p[0]; r->has_final = false; r->ppm = false;
     if (r->timed) {
         float t_in_walk = 0, t_in_scan = 0, t_in_exp = 0, t_in_total = 0, t_sweep = 0;
@@ -1197,12 +1244,25 @@ static int scan_long_ppm(acx_image* img, acx_image* li, const acx_scan_params* p
     if (!ppm_plan(li, &q)) return ACX_LONG_FALLBACK;
     if (!r->long_inner) { r->long_inner = new (std::nothrow) acx_result(); if (!r->long_inner) return acx_fail(ACX_E_NOMEM, "acx_scan_batch: out of memory"); }
     acx_result* in = r->long_inner;
-    int rc = scan_batch_inner(li, &q, &in, (void*)s);
-    if (rc) return rc;
     const size_t n = (size_t)p->n_hay;
+    int rc;
     if ((rc = r->counts.ensure(n + 1))) return rc;
     if ((rc = r->match_off.ensure(n + 1))) return rc;
     if ((rc = r->partials.ensure((size_t)acx_scan_num_partials((int64_t)n) + 2))) return rc;
+    // the sweep straight from the record pool — the inner scan launches it in place of its gather — is OPT-IN (variant bit 26: A/B and the four-way
+    // tests): measured, it loses (profiles/r5_experiments.md §7: k_long_gather_sweep 239 us where k_ppm_gather_pos + k_long_sweep take 65 + 168 —
+    // reading the pool's grants costs what the gather cost, and the staging that finds haystack boundaries in a stream of positions is dearer)
+    in->fuse = nullptr;
+    if (!r->long_nofuse && ((p->variant >> 26) & 1)) {
+        const size_t need = 64 + (size_t)ACX_PPM_MAX_BLOCKS * 16;
+        if (r->long_aux.cap < need) { if ((rc = r->long_aux.ensure(need))) return rc; HIP_TRY(hipMemset(r->long_aux.p, 0, 64 * sizeof(uint32_t))); r->fail_seen = 0; }
+        r->fuse_args.counts = r->counts.p; r->fuse_args.fail = r->long_aux.p; r->fuse_args.wave_base = r->long_aux.p + 64;
+        r->fuse_args.longest = img->long_longest; r->fuse_args.n_real = img->long_n_real;
+        in->fuse = &r->fuse_args;
+    }
+    in->fused = false;
+    rc = scan_batch_inner(li, &q, &in, (void*)s);
+    if (rc) return rc;
     if (r->timed) for (auto& e : r->ev) if (!e) HIP_TRY(hipEventCreate(&e));
     r->pend_params = *p; r->long_img = img;
     // where the inner scan's last kernel (its gather) was queued: the sweep goes behind it

@@ -20,6 +20,23 @@ struct acx_long_args {
     int64_t n_real;                // entries of the dictionary (an index beyond them — stale records — reports 0); fewer than 2^18: the values carry `below` (acx.h)
 };
 hipError_t acx_launch_long_sweep(const acx_long_args& a, hipStream_t s);
+
+// The sweep straight from the scan's record POOL (fixed-stride stream scans whose haystacks are no longer than a tile): what
+// k_ppm_gather_pos would move to its final place first — 8 bytes per record written and read again — is read from the grants of the
+// scan's waves, swept, and only the reported records are written.  One wave per wave of the scan kernel, k_ppm_gather_pos's
+// bookkeeping (total and flags to the host's pinned words, control words and the next scan's block sums back to zero) included.
+struct acx_ppm_gather_args;
+#define ACX_LONG_WAVE_SLACK 256u     /* slots of the output region of a scan wave beyond its own record count */
+struct acx_long_fuse_args {
+    int32_t* counts;               // out: records reported per haystack [n_hay]
+    uint32_t* wave_base;           // out: where the packed reports of the scan's wave w start in gather_args.matches [n_waves]
+    uint32_t* fail;                // out: counts the batches of 64 haystacks that held more records than a wave's LDS (the host then sweeps the gathered records instead)
+    uint32_t longest;              // longest dictionary entry
+    int64_t n_real;                // entries of the dictionary
+};
+hipError_t acx_launch_long_gather_sweep(const acx_ppm_gather_args& c, const acx_long_fuse_args& f, hipStream_t s);
+// the packed reports of every wave of the scan -> dst + new_off[first haystack that starts in the wave's run]
+hipError_t acx_launch_long_move_waves(const acx_ppm_gather_args& c, const acx_long_fuse_args& f, const int64_t* new_off, const int32_t* real, uint2* dst, hipStream_t s);
 hipError_t acx_launch_long_move(const acx_long_args& a, const int64_t* new_off, const int32_t* real, uint2* dst, hipStream_t s);
 
 #endif

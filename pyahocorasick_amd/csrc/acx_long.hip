@@ -12,9 +12,13 @@
 //         :131-132, :148-150: report what is remembered, restart behind it
 // tests/test_iter_long_plan_cpu.py holds the same sweep in Python, pinned against the oracle.  The reported records are
 // written over the records from the front (never ahead of one still to be read); k_long_move puts them where the caller
-// finds them.
+// finds them.  Round 5: the haystacks whose records fit a wave's LDS — all but pathological ones — are swept in the COMPACT form
+// (sweep_compact below); the raw form (sweep_one) remains for a haystack whose records do not fit.
 #include "acx_kernels.h"
 #include "acx_long.h"
+#include "acx_ppm_layout.h"
+
+#define PPM_DESC_WORDS_L ACX_PPM_DESC_WORDS       // per wave of the scan kernel: total, n_grants, 16 x base, 16 x count (acx_ppm_kernels.hip)
 
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -22,17 +26,8 @@
 namespace {
 
 typedef uint32_t rec2_t __attribute__((ext_vector_type(2)));          // (a record as a plain vector: pointers to it may carry an address space)
-typedef __attribute__((address_space(3))) rec2_t lds_rec2_t;
-// where record k of a haystack lives: in global memory, or in the wave's LDS.  There record i of the group sits at slot
-// i + i / 16: the lanes of a wave stand about sixteen records apart — 128 bytes, the same bank for all of them — and
-// the skew spreads them over the banks.
+// where record k of a haystack lives for the raw in-place sweep below: in global memory (the haystack whose records outgrow a wave's LDS)
 struct GlobalRecs { rec2_t* p; __device__ rec2_t get(uint32_t k) const { return p[k]; } __device__ void put(uint32_t k, rec2_t v) const { p[k] = v; } };
-struct LdsRecs {
-    lds_rec2_t* p; uint32_t first;                                      // the haystack's first record, counted from the group's first in LDS
-    __device__ static uint32_t slot(uint32_t i) { return i + (i >> 4); }
-    __device__ rec2_t get(uint32_t k) const { return p[slot(first + k)]; }
-    __device__ void put(uint32_t k, rec2_t v) const { p[slot(first + k)] = v; }
-};
 
 // The sweep of ONE haystack over its records rec[0 .. n) (R: where they live, below), reported records written over them
 // from the front; returns how many.  r: the haystack's first index.  ONE record is read per trip of the loop whatever the
@@ -305,6 +300,190 @@ __global__ void __launch_bounds__(256) k_long_move(const acx_long_args a, const 
     }
 }
 
+
+// ---- the sweep straight from the record pool (acx_long.h: acx_long_fuse_args) ------------------------------------------------------
+// A wave per wave w of the scan kernel.  Its run of tiles covers the positions [A, B); it sweeps the haystacks that START in there,
+// 64 at a time: their records are the part of w's record stream (its grants, in order) with positions in [h_lo * stride,
+// h_hi * stride) — and, for the last haystack, the head of wave w + 1's stream (a haystack is no longer than a tile: it ends in the
+// next wave's run at the latest).  Staging turns (global position, value) into the compact records of sweep_compact — the haystack of
+// a position by a 32-bit multiply-high as k_ppm_gather_pos finds it —; the reports go, packed, to matches[base ..), base = the
+// records of the waves in front (what k_ppm_gather_pos calls base: at least as many slots as reports).
+struct StreamCursor {                                                // where a wave stands in a record stream: a scan wave's grants in order
+    const uint32_t* d; uint32_t g, i;                                 // descriptor, grant, record within it
+};
+__global__ void __launch_bounds__(64) k_long_gather_sweep(const acx_ppm_gather_args c, const acx_long_fuse_args f) {
+    __shared__ LongLds s_l;
+    __shared__ uint32_t s_first[64];
+    LongLds* const L = &s_l;
+    constexpr int GT = 64;
+    const int lane = threadIdx.x;
+    const int n_blocks = (int)(c.n_waves / ACX_PPM_WAVES);
+    auto wave_add = [&](uint32_t x) -> uint32_t {
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) x += __shfl_xor(x, d, 64);
+        return x;
+    };
+    uint32_t total32 = 0;
+#pragma unroll 1
+    for (int b = lane; b < n_blocks; b += GT) total32 += c.block_sum[b];
+    const int64_t total = (int64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)wave_add(total32));
+    if (blockIdx.x == 0) {                                             // (k_ppm_gather_pos's bookkeeping)
+        uint32_t f1 = 0, f2 = 0;
+        if (lane == 0) { f1 = (uint32_t)((const int32_t*)(c.ctl + 8))[0]; f2 = (uint32_t)((const int32_t*)(c.ctl + 9))[0]; c.host_words[0] = total; c.host_words[1] = (int32_t)f1; c.host_words[2] = (int32_t)f2; }
+        const uint32_t seen = (uint32_t)__shfl((int)(f1 | f2 | 0x100u), 0, 64);
+        if (seen && lane < 16) c.ctl[lane] = 0ull;
+        for (int b = lane; b < ACX_PPM_MAX_BLOCKS; b += GT) c.block_sum_next[b] = 0u;
+    }
+    const bool fits = total <= c.capacity;
+    const uint32_t stride = (uint32_t)c.stride;
+    const uint64_t H = (uint64_t)c.n_hay * stride;
+    const uint32_t m32 = (uint32_t)((((uint64_t)1 << 32) + stride - 1) / stride);
+    const int32_t reach = (int32_t)f.longest - 1;
+    const bool small = f.n_real < ((int64_t)1 << ACX_LONG_SMALL_BITS);
+#pragma unroll 1
+    for (int64_t w = blockIdx.x; w < c.n_waves; w += gridDim.x) {
+        const uint32_t* const d_own = c.wave_desc + (size_t)w * PPM_DESC_WORDS_L;
+        const uint64_t blk_first = (uint64_t)(w / ACX_PPM_WAVES) * ACX_PPM_WAVES * (uint64_t)c.tpw;
+        const uint32_t slot = (uint32_t)(w % ACX_PPM_WAVES);
+        uint64_t A = (blk_first + acx_ppm_slot_first_tile(slot, (uint32_t)c.tpw, c.share_a, c.share_b)) * (uint64_t)c.tile_pos;
+        uint64_t B = (blk_first + acx_ppm_slot_first_tile(slot + 1u, (uint32_t)c.tpw, c.share_a, c.share_b)) * (uint64_t)c.tile_pos;
+        if (A > H) A = H;
+        if (B > H) B = H;
+        const int64_t hA = (int64_t)((A + stride - 1) / stride), hB = (int64_t)((B + stride - 1) / stride);   // haystacks that start in [A, B)
+        const int64_t h0 = (int64_t)(A / stride);
+        const uint32_t bias = (uint32_t)(A - (uint64_t)h0 * stride) - (uint32_t)A;         // position g of this wave or the next: offset g + bias from the start of haystack h0
+        uint32_t part = 0;
+        const int wb = (int)(w / ACX_PPM_WAVES);
+#pragma unroll 1
+        for (int b = lane; b < wb; b += GT) part += c.block_sum[b];
+        if (lane < (int)(w % ACX_PPM_WAVES)) part += c.wave_desc[((size_t)wb * ACX_PPM_WAVES + lane) * PPM_DESC_WORDS_L];
+        const uint32_t base = (uint32_t)__builtin_amdgcn_readfirstlane((int)wave_add(part));
+        // (its reports may outnumber its own records by those of the last haystack's tail in wave w + 1's stream: ACX_LONG_WAVE_SLACK slots of slack per wave)
+        const uint32_t obase = base + (uint32_t)w * ACX_LONG_WAVE_SLACK, oroom = d_own[0] + ACX_LONG_WAVE_SLACK;
+        if (lane == 0) f.wave_base[w] = obase;
+        if (!fits) {                                                    // (the host grows the buffer and issues the scan's second half again)
+            for (int64_t hh = hA + lane; hh < hB; hh += GT) f.counts[hh] = 0;
+            continue;
+        }
+        StreamCursor cur{d_own, 0u, 0u};
+        bool in_next = false;                                           // reading the head of wave w + 1's stream
+        uint32_t P = 0;                                                 // reports of this wave so far
+#pragma unroll 1
+        for (int64_t hs = hA; hs < hB; hs += 64) {
+            const int64_t he = hs + 64 < hB ? hs + 64 : hB;
+            const uint32_t p_lo = (uint32_t)((uint64_t)hs * stride), p_hi = (uint32_t)((uint64_t)he * stride - 1u) ;   // positions of these haystacks: [p_lo, p_hi]  (below 2^32: the launcher checks)
+            const uint32_t q_lo = (uint32_t)(hs - h0);                  // haystack numbers relative to h0
+            s_first[lane] = 0xFFFFFFFFu;
+            long_wave_sync();
+            uint32_t cnt = 0;                                           // compact records of this batch
+            uint32_t carry_pos = 0xFFFFFFFFu, carry_v = 0, last_kept_q = 0xFFFFFFFFu;
+            bool overflow = false;
+            bool done = false;
+            while (!done && !overflow) {                                // up to 64 x ACX_LC_LOADS records of the stream per trip, all their loads in flight at once
+                uint32_t ng = cur.d[1];
+                while (cur.g < ng && cur.i >= cur.d[18 + cur.g]) { cur.g++; cur.i = 0; }       // (wave-uniform: d[] are scalar loads)
+                if (cur.g >= ng) {
+                    if (in_next || w + 1 >= c.n_waves) break;
+                    in_next = true; cur.d = c.wave_desc + (size_t)(w + 1) * PPM_DESC_WORDS_L; cur.g = 0; cur.i = 0;
+                    continue;
+                }
+                const uint32_t n_g = cur.d[18 + cur.g];
+                const uint2* src = c.scratch + cur.d[2 + cur.g];
+                const uint32_t i_first = cur.i;
+                uint2 rvv[ACX_LC_LOADS];
+#pragma unroll
+                for (int j = 0; j < ACX_LC_LOADS; j++) { const uint32_t ii = i_first + 64u * (uint32_t)j + (uint32_t)lane; rvv[j] = ii < n_g ? src[ii] : make_uint2(0xFFFFFFFFu, 0u); }
+#pragma unroll
+                for (int j = 0; j < ACX_LC_LOADS; j++) {
+                    const uint32_t i0j = i_first + 64u * (uint32_t)j;
+                    if (i0j >= n_g) break;                              // (wave-uniform)
+                    const uint32_t left = n_g - i0j, nv = left < 64u ? left : 64u;
+                    const uint2 rv = rvv[j];
+                    const bool valid = (uint32_t)lane < nv;
+                    const bool inr = valid && rv.x <= p_hi;
+                    const uint32_t n_in = (uint32_t)__popcll(__ballot(inr));          // (positions ascend: a prefix of the lanes)
+                    const uint32_t y = rv.x + bias, q = __umulhi(y, m32);
+                    const uint32_t val = rv.y;
+                    const int32_t e = (int32_t)(y - q * stride) + ((inr && c.index_base) ? c.index_base[h0 + (int64_t)(int32_t)q] : 0);
+                    const uint32_t spos = (uint32_t)__shfl_up((int)rv.x, 1, 64), sval = (uint32_t)__shfl_up((int)val, 1, 64);
+                    const uint32_t ppos = lane ? spos : carry_pos, pval = lane ? sval : carry_v;
+                    const bool same = inr && ppos == rv.x;               // the record in front ends at the same position: the next LONGER path
+                    const int32_t st = e - (int32_t)((val >> 24) & 63u) + 1;
+                    const int32_t up = same ? e - (int32_t)((pval >> 24) & 63u) + 1 : INT32_MIN;
+                    const bool keep = inr && rv.x >= p_lo && (val >> 30) != 0u;
+                    const unsigned long long km = __ballot(keep);
+                    const uint32_t pos = cnt + (uint32_t)__popcll(km & ((1ull << lane) - 1ull));
+                    const uint32_t nk = (uint32_t)__popcll(km);
+                    if (cnt + nk > LC_CAP) { overflow = true; break; }
+                    if (keep) { L->a[pos] = make_uint2((uint32_t)st, (uint32_t)up); L->v[pos] = val; }
+                    // the first compact record of every haystack: the kept record in front belongs to another one
+                    {
+                        const unsigned long long below_me = km & ((1ull << lane) - 1ull);
+                        const int prev_lane = below_me ? 63 - (int)__clzll(below_me) : -1;
+                        const uint32_t sq = (uint32_t)__shfl((int)q, prev_lane < 0 ? 0 : prev_lane, 64);
+                        const uint32_t pq = prev_lane < 0 ? last_kept_q : sq;
+                        if (keep && pq != q) s_first[q - q_lo] = pos;
+                        if (nk) last_kept_q = (uint32_t)__shfl((int)q, 63 - (int)__clzll(km), 64);
+                    }
+                    cnt += nk;
+                    carry_pos = (uint32_t)__shfl((int)rv.x, (int)nv - 1, 64); carry_v = (uint32_t)__shfl((int)val, (int)nv - 1, 64);
+                    cur.i += n_in;
+                    if (n_in < nv) { done = true; break; }               // the rest of the stream belongs to later haystacks
+                }
+            }
+            if (overflow) { if (lane == 0) atomicAdd(f.fail, 1u); for (int64_t hh = hs + lane; hh < hB; hh += GT) f.counts[hh] = 0; break; }
+            long_wave_sync();
+            // compact records of haystack hs + lane: [first, next haystack's first)
+            const bool mine = hs + lane < he;
+            const uint32_t my_first = s_first[lane];
+            uint32_t nxt = my_first;                                     // the first of the next haystack that has records (suffix minimum over the lanes behind), else cnt
+            {
+                uint32_t v = (uint32_t)__shfl_down((int)my_first, 1, 64);
+                if (lane == 63) v = 0xFFFFFFFFu;
+#pragma unroll
+                for (int dd = 1; dd < 64; dd <<= 1) { const uint32_t t = (uint32_t)__shfl_down((int)v, dd, 64); if (lane + dd < 64) v = t < v ? t : v; }
+                nxt = v == 0xFFFFFFFFu ? cnt : v;
+            }
+            const bool has = mine && my_first != 0xFFFFFFFFu;
+            const int32_t r0 = (mine && c.index_base) ? c.index_base[hs + lane] : 0;
+            uint32_t cc = 0;
+            if (has) cc = sweep_compact(L, my_first, nxt - my_first, r0, reach, small, LC_CAP + (uint32_t)lane);
+            const uint32_t ci = wave_incl_scan_u32(cc, lane), tot = (uint32_t)__shfl((int)ci, 63, 64);
+            long_wave_sync();
+            if (P + tot > oroom) { if (lane == 0) atomicAdd(f.fail, 1u); for (int64_t hh = hs + lane; hh < hB; hh += GT) f.counts[hh] = 0; break; }
+            if (mine) {
+                uint2* dst = c.matches + obase + P + (ci - cc);
+                for (uint32_t i = 0; i < cc; i++) dst[i] = L->a[my_first + i];
+                f.counts[hs + lane] = (int32_t)cc;
+            }
+            P += tot;
+            long_wave_sync();
+        }
+    }
+}
+
+// the packed reports of the scan's wave w -> dst + new_off[hA]; a wave per wave of the scan
+__global__ void __launch_bounds__(256) k_long_move_waves(const acx_ppm_gather_args c, const acx_long_fuse_args f, const int64_t* new_off, const int32_t* __restrict__ real, uint2* dst) {
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    const uint32_t stride = (uint32_t)c.stride;
+    const uint64_t H = (uint64_t)c.n_hay * stride;
+    const uint32_t n_real = (uint32_t)f.n_real;
+    for (int64_t w = (int64_t)blockIdx.x * 4 + wid; w < c.n_waves; w += (int64_t)gridDim.x * 4) {
+        const uint64_t blk_first = (uint64_t)(w / ACX_PPM_WAVES) * ACX_PPM_WAVES * (uint64_t)c.tpw;
+        const uint32_t slot = (uint32_t)(w % ACX_PPM_WAVES);
+        uint64_t A = (blk_first + acx_ppm_slot_first_tile(slot, (uint32_t)c.tpw, c.share_a, c.share_b)) * (uint64_t)c.tile_pos;
+        uint64_t B = (blk_first + acx_ppm_slot_first_tile(slot + 1u, (uint32_t)c.tpw, c.share_a, c.share_b)) * (uint64_t)c.tile_pos;
+        if (A > H) A = H;
+        if (B > H) B = H;
+        const int64_t hA = (int64_t)((A + stride - 1) / stride), hB = (int64_t)((B + stride - 1) / stride);
+        if (hA >= hB) continue;
+        const uint2* src = c.matches + f.wave_base[w];
+        uint2* d = dst + new_off[hA];
+        const int64_t n = new_off[hB] - new_off[hA];
+        for (int64_t k = lane; k < n; k += 64) { uint2 v = src[k]; v.y = v.y < n_real ? (uint32_t)real[v.y] : 0u; d[k] = v; }
+    }
+}
+
 }  // namespace
 
 hipError_t acx_launch_long_sweep(const acx_long_args& a, hipStream_t s) {
@@ -322,5 +501,23 @@ hipError_t acx_launch_long_move(const acx_long_args& a, const int64_t* new_off, 
     if (blocks > cap) blocks = cap;
     if (blocks < 1) blocks = 1;
     hipLaunchKernelGGL(k_long_move, dim3((unsigned)blocks), dim3(256), 0, s, a, new_off, real, dst);
+    return hipGetLastError();
+}
+
+hipError_t acx_launch_long_gather_sweep(const acx_ppm_gather_args& c, const acx_long_fuse_args& f, hipStream_t s) {
+    int64_t blocks = c.n_waves;
+    const int64_t cap = (int64_t)acx_num_cus() * 40;
+    if (blocks > cap) blocks = cap;
+    if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(k_long_gather_sweep, dim3((unsigned)blocks), dim3(64), 0, s, c, f);
+    return hipGetLastError();
+}
+
+hipError_t acx_launch_long_move_waves(const acx_ppm_gather_args& c, const acx_long_fuse_args& f, const int64_t* new_off, const int32_t* real, uint2* dst, hipStream_t s) {
+    int64_t blocks = (c.n_waves + 3) / 4;
+    const int64_t cap = (int64_t)acx_num_cus() * 16;
+    if (blocks > cap) blocks = cap;
+    if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(k_long_move_waves, dim3((unsigned)blocks), dim3(256), 0, s, c, f, new_off, real, dst);
     return hipGetLastError();
 }

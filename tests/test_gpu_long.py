@@ -1,6 +1,8 @@
 """GPU: ACX_SCAN_LONG as a position-parallel scan over the dictionary D = E + FE + U (acx_long.cpp) + one sweep per haystack
 (acx_long.hip), three ways: the new path (the scan plan says so: the test refuses to pass on the serial walk), the serial
-walk k_walk_long_sel (variant bit 25) and the oracle (oracle/ac_oracle.c orc_iter_long).  Bit-exact records and offsets."""
+walk k_walk_long_sel (variant bit 25) and the oracle (oracle/ac_oracle.c orc_iter_long) — and, fourth, the sweep straight from the
+scan's record pool (variant bit 26; it applies to fixed strides no longer than a tile, elsewhere the bit changes nothing).  Bit-exact records
+and offsets."""
 import numpy as np
 import pytest
 
@@ -11,6 +13,7 @@ from helpers import build_pair, dna_workload
 pytestmark = pytest.mark.gpu
 
 SERIAL = 1 << 25
+FUSED = 1 << 26           # the sweep straight from the scan's record pool (k_long_gather_sweep) instead of k_ppm_gather_pos + k_long_sweep: opt-in, slower (A/B)
 
 
 def _three_way(A, O, flat, off=None, n=None, L=None, base=None, expect_plan=True):
@@ -32,7 +35,7 @@ def _three_way(A, O, flat, off=None, n=None, L=None, base=None, expect_plan=True
     mo, oe, ov = O.batch(flat.tobytes(), host_off, 1)
     if base is not None:
         oe = oe + np.repeat(base, np.diff(mo)).astype(np.int32)
-    for variant in (0, SERIAL):
+    for variant in (0, FUSED, SERIAL):
         sc = Scanner(img)
         sc.scan(d_hay, len(flat), n, mode=acx.ACX_SCAN_LONG, dev_index_base=d_base, variant=variant, **kw)
         moff, e, v, _ = sc.fetch()
@@ -94,7 +97,7 @@ def test_config5_shape_against_the_serial_walk():
     d_hay = DeviceBuffer.from_numpy(flat, pad=64)
     assert img.ppm_kernel(stride=L, dev_hay=d_hay.ptr.value, n_hay=n, mode=acx.ACX_SCAN_LONG) == "stream4"
     got = []
-    for variant in (0, SERIAL):
+    for variant in (0, FUSED, SERIAL):
         sc = Scanner(img)
         sc.scan(d_hay, n * L, n, stride=L, mode=acx.ACX_SCAN_LONG, variant=variant)
         got.append(sc.fetch()[:3])
