@@ -77,11 +77,14 @@ def one_case(rng, trial):
                     fins_equal.append(fin)
     from pyahocorasick_amd import ACX_SCAN_LONG
     lo, le, lv = O.batch(flat.tobytes(), off, 1)                    # iter_long
-    sc = Scanner(img)
-    sc.scan(d_hay, n * L, n, stride=L, mode=ACX_SCAN_LONG)
-    moff, e, v, _ = sc.fetch()
-    if not (np.array_equal(moff, lo) and np.array_equal(e, le) and np.array_equal(v, lv)):
-        raise SystemExit("ITER_LONG MISMATCH trial %d sigma %d keys %d" % (trial, sigma, len(keys)))
+    # the position-parallel form (where it applies: else the serial walk answers) synchronous and asynchronous, the sweep straight from the
+    # record pool (variant bit 26), the serial walk (bit 25)
+    for variant, asyn in ((0, False), (0, True), (1 << 26, False), (1 << 26, True), (1 << 25, False)):
+        sc = Scanner(img)
+        sc.scan(d_hay, n * L, n, stride=L, mode=ACX_SCAN_LONG, variant=variant, asynchronous=asyn)
+        moff, e, v, _ = sc.fetch()
+        if not (np.array_equal(moff, lo) and np.array_equal(e, le) and np.array_equal(v, lv)):
+            raise SystemExit("ITER_LONG MISMATCH trial %d variant %#x async %s sigma %d keys %d kmax %d n %d L %d" % (trial, variant, asyn, sigma, len(keys), kmax, n, L))
     for fin in fins_equal[1:]:
         if not np.array_equal(fin, fins_equal[0]):
             raise SystemExit("FINAL STATE MISMATCH trial %d" % trial)
