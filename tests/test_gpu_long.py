@@ -195,3 +195,45 @@ def test_byte_signatures_at_scale():
     flat2, off2 = packet_payloads(sigs2, 1 << 20, seed=12, plant_frac=0.6)
     flat2 = np.ascontiguousarray(np.frombuffer(flat2, dtype=np.uint8) if not isinstance(flat2, np.ndarray) else flat2)
     assert _three_way(B, OB, flat2, off=off2, expect_plan=False) is None
+
+
+_BCAST_SCRIPT = r"""
+import sys
+import numpy as np
+import torch                                        # (first: ONE HIP runtime per process, pyahocorasick_amd/_lib.py)
+sys.path.insert(0, sys.argv[1]); sys.path.insert(0, sys.argv[1] + "/tests")
+import pyahocorasick_amd as acx
+from pyahocorasick_amd import _lib
+from pyahocorasick_amd.device import DeviceBuffer, Scanner
+from pyahocorasick_amd.parallel import broadcast_image
+from helpers import build_pair, dna_workload
+_lib.lib().acx_set_host_walk_bytes(-1)
+keys, reads = dna_workload(2000, 1024, 150, seed=21)
+A, O = build_pair(keys)
+img, t = broadcast_image(A.flat_image_bytes(), src=0, device=torch.device("cuda:0"), long_pack=True)
+assert img.long_state == 1
+flat = np.ascontiguousarray(reads.reshape(-1))
+n, L = reads.shape
+sc = Scanner(img)
+sc.scan(DeviceBuffer.from_numpy(flat, pad=64), len(flat), n, mode=acx.ACX_SCAN_LONG, stride=L)
+moff, e, v, _ = sc.fetch()
+mo, oe, ov = O.batch(flat.tobytes(), np.arange(n + 1, dtype=np.int64) * L, 1)
+assert np.array_equal(moff, mo) and np.array_equal(e, oe) and np.array_equal(v, ov)
+assert _lib.lib().acx_host_walk_calls() == 0
+print("BCAST_LONG_OK", int(moff[-1]))
+"""
+
+
+def test_broadcast_image_with_the_long_pack_single_process(tmp_path):
+    """parallel.broadcast_image(long_pack=True) — what bench.py --mode iter_long calls on every rank — in a process of its own (torch
+    first: one HIP runtime per process) without a process group: the payload goes to the device as it would arrive from the broadcast,
+    blob and pack are adopted in place, iter_long == oracle"""
+    import os
+    import subprocess
+    import sys
+    pytest.importorskip("torch")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = tmp_path / "bcast_long.py"
+    script.write_text(_BCAST_SCRIPT)
+    p = subprocess.run([sys.executable, str(script), root], capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0 and "BCAST_LONG_OK" in p.stdout, (p.stdout[-2000:], p.stderr[-3000:])
