@@ -356,8 +356,10 @@ __global__ void __launch_bounds__(ACX_PPM_BLOCK) k_ppm_stream(const acx_ppm_args
     uint32_t* const obits_tile = obits + HP / 32;                      // (the halo is a whole number of words)
     uint16_t* const queue = (uint16_t*)(wbase + a.lds.sym_words + a.lds.oth_words);
     uint32_t* const sbits = wbase + a.lds.sym_words + a.lds.oth_words + a.lds.queue_words;   // OFFS: haystack starts of the tile, one bit per position
-    uint16_t* const slast = (uint16_t*)(sbits + BW);                   //       last start (+1) at or before the end of each bitmap word
-    uint16_t* const scnt = slast + BW;                                 //       starts before each bitmap word
+    // (byte tables since round 5 — a tile of 2048 positions with its two uint16 tables did not fit beside a 128 KiB filter, and the offsets
+    //  batches of a four-letter dictionary ran on tiles of 1024: 0.334 against 0.287 ms per 150 MB on fixed strides, profiles/r5_experiments.md §8)
+    uint8_t* const sback = (uint8_t*)(sbits + BW);                     //       bitmap words back from word w to the last word with a start at or before it (255: none)
+    uint8_t* const scnt = sback + BW;                                  //       starts before each bitmap word (at most 255 per tile: more raise short_hay)
     uint8_t* const sym_tile_bytes = (uint8_t*)(sym + 2 + HW);
     for (uint32_t i = lane; i < 2 + HW + TW + 1; i += 64) sym[i] = 0;
     for (uint32_t i = lane; i < (HP + TPOS) / 32 + 1; i += 64) obits[i] = 0;
@@ -546,8 +548,9 @@ __global__ void __launch_bounds__(ACX_PPM_BLOCK) k_ppm_stream(const acx_ppm_args
             fh_next = a.first_h[tile + 1];
             int64_t fe = fh_next < a.n_hay ? fh_next : a.n_hay;
             uint32_t m = fe > fh ? (uint32_t)(fe - fh) : 0u;
-            if (m > TPOS / 8) {                                         // the contract is broken (a haystack shorter than 8 bytes):
-                m = TPOS / 8;                                           // say so; the host scans again on the general kernel
+            constexpr uint32_t MAX_STARTS = TPOS / 8 < 255u ? TPOS / 8 : 255u;   // (the count table is bytes)
+            if (m > MAX_STARTS) {                                       // the contract is broken (a haystack shorter than 8 bytes; or a tile of 2048 positions that is all 8-byte haystacks):
+                m = MAX_STARTS;                                         // say so; the host scans again on the general kernel
                 if (lane == 0) *a.short_hay = 1;
             }
             if ((uint32_t)lane < BW) sbits[lane] = 0;
@@ -564,10 +567,10 @@ __global__ void __launch_bounds__(ACX_PPM_BLOCK) k_ppm_stream(const acx_ppm_args
                 // two starts at one position — an empty haystack, which the contract excludes as well — would count as
                 // one: the ranks of everything behind it would be off by one.  Same answer: say so, the host scans again.
                 if (tot != m && lane == 0) *a.short_hay = 1;
-                uint32_t last = wv ? 32u * lane + (31 - __clz(wv)) + 1 : 0u;
+                uint32_t lastw = wv ? (uint32_t)lane + 1u : 0u;         // 1 + the last word at or before this one that holds a start (0: none)
 #pragma unroll
-                for (int d = 1; d < 64; d <<= 1) { const uint32_t t = __shfl_up(last, d, 64); if (lane >= d && t > last) last = t; }
-                if ((uint32_t)lane < BW) { slast[lane] = (uint16_t)last; scnt[lane] = (uint16_t)before; }
+                for (int d = 1; d < 64; d <<= 1) { const uint32_t t = __shfl_up(lastw, d, 64); if (lane >= d && t > lastw) lastw = t; }
+                if ((uint32_t)lane < BW) { sback[lane] = lastw ? (uint8_t)((uint32_t)lane + 1u - lastw) : (uint8_t)255; scnt[lane] = (uint8_t)before; }
             }
             hbase = (uint32_t)(fh - 1);                                 // (fh = 0: wraps; off[0] = 0, so every position of that tile has rank >= 1)
             base_r = fh > 0 ? (uint32_t)((int64_t)e0 - a.off[fh - 1]) : 0u;
@@ -583,10 +586,10 @@ __global__ void __launch_bounds__(ACX_PPM_BLOCK) k_ppm_stream(const acx_ppm_args
             if (!OFFS) { rank = divmod(r_tile + p, r); return; }
             const uint32_t w = p >> 5;
             const uint32_t prev = sbits[w] & (0xFFFFFFFFu >> (31u - (p & 31u)));      // starts of this word at or before p
-            const uint32_t lw = w ? slast[w - 1] : 0u;
+            const uint32_t back = w ? sback[w - 1] : 255u;
             rank = scnt[w] + (uint32_t)__popc(prev);
             if (prev) r = p - (32u * w + (31 - __clz(prev)));
-            else if (lw) r = p - (lw - 1u);
+            else if (back != 255u) { const uint32_t wb = w - 1u - back; r = p - (32u * wb + (31 - __clz(sbits[wb]))); }
             else r = base_r + p;
         };
 

@@ -86,7 +86,7 @@ static inline acx_ppm_lds acx_ppm_stream_layout(uint32_t g_words, uint32_t sym_b
     L.sym_words = (2 + halo_pos / spw + tpos / spw + 1 + 3u) & ~3u;
     L.oth_words = ((halo_pos + tpos) / 32 + 1 + 3u) & ~3u;
     L.queue_words = 384 / 2 + 2;                                       // PPM_QCAP uint16 entries + a spare slot
-    L.cnt32 = 0; L.cnt_words = offs ? (tpos / 32) * 2 + 2 : 0;          // offsets batches: start bitmap, last-start and count tables
+    L.cnt32 = 0; L.cnt_words = offs ? (tpos / 32) + (tpos / 32) / 2 + 2 : 0;   // offsets batches: start bitmap (a word per 32 positions), two byte tables (a byte per word each)
     L.wave_words = (L.sym_words + L.oth_words + L.queue_words + L.cnt_words + 3u) & ~3u;
     L.g_off = 0;
     L.map_off = (g_words + 3u) & ~3u;
