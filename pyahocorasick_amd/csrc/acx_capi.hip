@@ -672,9 +672,13 @@ static int ppm_enqueue(acx_result* r, acx_image* img, const acx_chunk_args* ca, 
     const acx_ppm_args& pa = r->pend_pa;
     const int64_t ni = r->pend_items;
     // (a stream scan leaves the control words zeroed behind it: only the first one, and one after another kernel family, clears them)
+    // (the flags of the host's pinned words are cleared BEFORE anything is queued: the kernels of a small batch write them — through the
+    //  device-mapped pointer — sooner than this function returns)
+    r->h_total.p[1] = 0; r->h_total.p[2] = 0;
     const bool self = r->ppm_stream && r->ppm_self;
-    if (!(self && r->ctl_zero)) HIP_TRY(hipMemsetAsync(r->ppm_ctl.p, 0, 16 * sizeof(unsigned long long), s));
-    r->ctl_zero = self;
+    const bool words = r->ppm_stream && r->pend_ga.host_words && r->pend_ga.ctl;      // the scan's second half writes total and flags to the host and zeroes the control words
+    if (!(words && r->ctl_zero)) HIP_TRY(hipMemsetAsync(r->ppm_ctl.p, 0, 16 * sizeof(unsigned long long), s));
+    r->ctl_zero = words;
     if (self) {                                         // this scan's block sums (zeroed by the gather of the scan before), the next scan's
         r->pend_pa.block_sum = r->wave_aux.p + (size_t)r->bs_parity * ACX_PPM_MAX_BLOCKS;
         r->pend_ga.block_sum = r->pend_pa.block_sum;
@@ -717,8 +721,7 @@ static int ppm_enqueue(acx_result* r, acx_image* img, const acx_chunk_args* ca, 
         if (ca) HIP_TRY(acx_launch_hay_offsets(r->ck_first.p, r->ck_match_off.p, ca->n_hay, r->match_off.p, s));
     }
     if (r->timed_all) HIP_TRY(hipEventRecord(r->ev[3], g));
-    r->h_total.p[1] = 0; r->h_total.p[2] = 0;
-    if (!self) {                                        // (k_ppm_gather_pos writes total and flags into h_total itself)
+    if (!words) {                                       // (k_ppm_gather_pos / k_ppm_wave_scan write total and flags into h_total themselves)
         HIP_TRY(hipMemcpyAsync(r->h_total.p, r->pend_item_off + (r->ppm_stream ? r->pend_ga.n_waves : ni), sizeof(int64_t), hipMemcpyDeviceToHost, g));
         HIP_TRY(hipMemcpyAsync(r->h_total.p + 1, r->ppm_ctl.p + 8, sizeof(int32_t), hipMemcpyDeviceToHost, g));
         HIP_TRY(hipMemcpyAsync(r->h_total.p + 2, r->ppm_ctl.p + 9, sizeof(int32_t), hipMemcpyDeviceToHost, g));
@@ -995,7 +998,8 @@ static int scan_ppm(acx_image_t* img, const acx_scan_params* p, acx_result* r, h
         }
         ga.share_a = pa.share_a; ga.share_b = pa.share_b;
         ga.stride_magic = pa.stride_magic; ga.index_base = chunked ? nullptr : p->dev_index_base; ga.skip = chunked ? nullptr : p->dev_skip;
-        if (!chunked) {
+        {   // (both gathers of the stream scans report through the host's pinned words and clean the control words up: k_ppm_gather_pos, and —
+            //  offsets batches — k_ppm_wave_scan in front of k_ppm_gather)
             void* dp = nullptr;
             HIP_TRY(hipHostGetDevicePointer(&dp, r->h_total.p, 0));
             ga.host_words = (long long*)dp; ga.ctl = r->ppm_ctl.p;

@@ -1078,7 +1078,9 @@ __global__ void __launch_bounds__(256) k_ppm_first_h(const int64_t* off, int64_t
 }
 
 // exclusive prefix sum of the waves' record counts: wave_off[w], wave_off[n_waves] = total
-__global__ void __launch_bounds__(1024) k_ppm_wave_scan(const uint32_t* wave_desc, int64_t n_waves, int64_t* wave_off) {
+// ctl / host_words (nullable): as k_ppm_gather_pos does for fixed-stride scans — the total and the two flags into the host's pinned words,
+// the control words back to zero for the result's next scan: no copies behind the gather, no memset in front of the next scan kernel
+__global__ void __launch_bounds__(1024) k_ppm_wave_scan(const uint32_t* wave_desc, int64_t n_waves, int64_t* wave_off, unsigned long long* ctl, long long* host_words) {
     __shared__ int64_t s_part[16];
     __shared__ int64_t s_carry;
     if (threadIdx.x == 0) s_carry = 0;
@@ -1100,6 +1102,12 @@ __global__ void __launch_bounds__(1024) k_ppm_wave_scan(const uint32_t* wave_des
         __syncthreads();
     }
     if (threadIdx.x == 0) wave_off[n_waves] = s_carry;
+    if (ctl && host_words) {
+        uint32_t f1 = 0, f2 = 0;
+        if (threadIdx.x == 0) { f1 = (uint32_t)((const int32_t*)(ctl + 8))[0]; f2 = (uint32_t)((const int32_t*)(ctl + 9))[0]; host_words[0] = s_carry; host_words[1] = (int32_t)f1; host_words[2] = (int32_t)f2; }
+        const uint32_t seen = (uint32_t)__shfl((int)(f1 | f2 | 0x100u), 0, 64);       // (a value that depends on the flags lane 0 read: the stores below wait for its loads)
+        if (seen && threadIdx.x < 16) ctl[threadIdx.x] = 0ull;
+    }
 }
 
 // one block per wave of k_ppm_stream: its grants, in order, to matches + wave_off[w]; then match_off[]
@@ -1483,7 +1491,7 @@ hipError_t acx_launch_ppm_first_h(const int64_t* off, int64_t n_hay, int64_t n_t
 }
 
 hipError_t acx_launch_ppm_gather(const uint32_t* wave_desc, int64_t n_waves, int64_t* wave_off, const acx_ppm_gather_args& c, hipStream_t s) {
-    if (c.off) hipLaunchKernelGGL(k_ppm_wave_scan, dim3(1), dim3(1024), 0, s, wave_desc, n_waves, wave_off);
+    if (c.off) hipLaunchKernelGGL(k_ppm_wave_scan, dim3(1), dim3(1024), 0, s, wave_desc, n_waves, wave_off, c.ctl, c.host_words);
     int64_t blocks = n_waves;
     const int64_t hb = (c.n_hay + 256) / 256;
     if (blocks < hb) blocks = hb;
