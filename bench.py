@@ -25,7 +25,7 @@ haystack bytes of a pass come from HBM, not from a cache that the previous pass 
                                longest_word-1 halo); default "weak": every rank scans its own batches of the full size
     --workload c2o | c2k       config 2 as the GENERAL stream kernel takes it: the reads as an offsets batch of ragged
                                lengths U[100,150]; keys of 8-64 letters
-    --configs all|none         N = 1, default workload only: after the headline measurement the other named
+    --configs all|none|LIST    N = 1, default workload only (LIST: a comma list of their names): after the headline measurement the other named
                                single-GPU configurations are measured in the same run and reported under
                                "configs": c5 (iter_long, same automaton and batches), c2_offsets, c2_long_keys, c3 and
                                c4 (two batches each) — each with value, ms_per_step, roofline and a sample-limited
@@ -63,6 +63,9 @@ KERNEL_SOURCES = {
     "k_walk_itop": ("acx_kernels.hip", "acx_kernels.h"),
     "k_walk_all": ("acx_kernels.hip", "acx_kernels.h"),
 }
+
+
+ALL_CONFIGS = ("c5_iter_long", "c2_offsets", "c2_long_keys", "c3", "c4")
 
 
 def parse():
@@ -116,8 +119,9 @@ def parse():
     ap.add_argument("--cpu-sample-reads", type=int, default=None,
                     help="haystacks timed on the CPU baseline legs (default: the whole first batch; 0 disables)")
     ap.add_argument("--verify", action="store_true", help="check the first batch's GPU output against the oracle (all records)")
-    ap.add_argument("--configs", choices=["all", "none"], default=None,
-                    help="the other named single-GPU configurations in the same run (default: all for the default command on one GPU)")
+    ap.add_argument("--configs", default=None,
+                    help="the other named single-GPU configurations in the same run: all | none | a comma list of their names "
+                         "(c5_iter_long,c2_offsets,c2_long_keys,c3,c4); default: all for the default command on one GPU")
     ap.add_argument("--lib", default=None, help="another build of libacx.so (development A/B, tools/build_variant.sh) instead of the package's")
     ap.add_argument("--dry-run", action="store_true",
                     help="no GPU: the ranks come up over gloo, the blob is broadcast and validated, every rank stages its shard on the host as "
@@ -535,7 +539,7 @@ def measure(torch, dist, dev, image, batches, mode, steps, warmup, P, event_ever
     #      includes the time only gathers run.  What the algorithmic bytes of a launch can be divided by is the time the kernel occupies the
     #      chip per launch: the UNION of its launch spans / launches.  Measured live: an event pair on the scan's stream around every launch
     #      of 12 x P pipelined passes, the first and last P left out; tools/roofline_check.py recomputes the same from a rocprofv3 trace.
-    union_ms = None
+    union_ms = union_share = None
     if len(streams) > 1:
         tstreams = [torch.cuda.current_stream()] + extra
         U = 12 * P
@@ -564,8 +568,12 @@ def measure(torch, dist, dev, image, batches, mode, steps, warmup, P, event_ever
                 ce = max(ce, b_)
         tot += (ce - cs) if ce is not None else 0.0
         union_ms = tot / max(1, len(iv))
+        # ... and as a share of the leg's own region (first counted launch's start to the last one's end): the leg is not the timed region —
+        # an event pair per launch, no totals read — and where its step differs from the timed region's, the share is what carries over
+        leg_region = (max(b_ for _, b_ in iv) - min(a_ for a_, _ in iv)) if iv else 0.0
+        union_share = min(1.0, tot / leg_region) if leg_region > 0 else None
     return {"dt": dt, "dt_rank": dt_rank, "walk_ms": walk_ms, "pre": pre, "step_ms": step_ms, "matches_per_batch": matches_per_batch, "sync_ms": sync_ms,
-            "union_ms": union_ms,
+            "union_ms": union_ms, "union_share": union_share,
             "repeats": R, "passes": passes,
             "bytes_rank": sum(batches[k % B][1] for k in range(passes)), "matches_rank": sum(matches_per_batch[k % B] for k in range(passes)),
             "scanner": scs[0], "stream": stream, "keepalive": (ssc if P > 1 else None, extra), "scan_streams": len(streams)}
@@ -595,8 +603,12 @@ def roofline_entry(image, batches, m, mode_name, workload, variant, event_every)
     ms_pass = m["dt_rank"] / passes * 1e3
     overlap = m["scan_streams"] > 1
     walk_ev = float(np.mean(m["walk_ms"])) if m["walk_ms"] else pre["walk"]
-    # (the union leg runs behind the timed region, with an event pair around every launch: where it comes out ABOVE timed region / launches —
-    #  the bound that holds in the timed region itself — the bound is the better figure)
+    # (the union leg runs behind the timed region with an event pair around every launch, which costs its stream 5–20 us of idle time: the
+    #  leg's step is longer than the timed region's by about that, and the SHARE of its region that the spans cover — reported as
+    #  kernel_union_share — is 4–8 % below what a rocprofv3 trace of the timed region shows on steps of 0.2–0.3 ms (0.958 against 0.995 on
+    #  config 2).  The union per launch itself carries over — the idle time is not inside the spans —, and where it comes out ABOVE timed
+    #  region / launches, the bound that holds in the timed region itself, the bound is the better figure)
+    share = m.get("union_share")
     walk = min(m.get("union_ms") or ms_pass, ms_pass) if overlap else walk_ev
     used_ppm = mode_name == "iter" and image.ppm_kernel(stride=L0, has_offsets=d_off0 is not None, variant=variant, min_hay_len=shortest0,
                                                           dev_hay=d_hay.data_ptr(), n_hay=n0)
@@ -651,7 +663,8 @@ def roofline_entry(image, batches, m, mode_name, workload, variant, event_every)
         "kernel_ms_source": ("union of the kernel's overlapping launch spans / launches: events around every launch of a pipelined leg behind the timed region "
                              "(tools/roofline_check.py: the same from a rocprofv3 trace); timed region / launches bounds it from above"
                              if overlap else "HIP events around the kernel on its stream, inside the timed region"),
-        "kernel_region_bound_ms": round(ms_pass, 4),
+        "kernel_region_bound_ms": round(ms_pass, 4), "kernel_union_share": None if not (overlap and share) else round(share, 4),
+        "kernel_union_leg_ms": None if not (overlap and m.get("union_ms")) else round(m["union_ms"], 4),
         # HIP events around the kernel, on its stream, inside the timed region: in every N-th pass (an event
         # pair costs the stream ~19 us of idle time in the pass it is in).  With overlapping launches they are reported, not used.
         "kernel_events": {"every_nth_step": event_every, "samples": len(m["walk_ms"]), "avg_ms": round(walk_ev, 4)},
@@ -767,7 +780,10 @@ def main():
     t0 = time.perf_counter()
     # iter_long workloads: the dictionary of its position-parallel form is built once on rank 0 and travels behind the blob in the SAME
     # broadcast (parallel.broadcast_image(long_pack=True) / acx_image_set_long): no rank builds it from a device-to-host copy of its image
-    runs_long = args.mode == "iter_long" or (world == 1 and args.workload == "c2" and args.variant == 0 and not args.keys and (args.configs or "all") == "all")
+    if args.configs not in (None, "all", "none") and set(args.configs.split(",")) - set(ALL_CONFIGS):
+        raise SystemExit("--configs: all, none or a comma list of %s" % ", ".join(ALL_CONFIGS))
+    runs_long = args.mode == "iter_long" or (world == 1 and args.workload == "c2" and args.variant == 0 and not args.keys
+                                             and ((args.configs or "all") == "all" or "c5_iter_long" in (args.configs or "").split(",")))
     image, image_tensor = broadcast_image(blob, src=0, device=dev, long_pack=runs_long)
     torch.cuda.synchronize()
     t_bcast = time.perf_counter() - t0
@@ -893,25 +909,32 @@ def main():
             out["cpu_baseline"] = cpu_baseline(keys, sample, args.mode)
         # ---- the other named single-GPU configurations, in the same run (driver-timed: BENCH_rNN.json carries them) ----
         want = args.configs or ("all" if (world == 1 and args.workload == "c2" and args.mode == "iter" and args.variant == 0 and not args.keys) else "none")
-        if want == "all" and world == 1:
+        if want != "none" and world == 1:
             cfgs = {}
             cpu_on = args.cpu_sample_reads != 0
+            names = set(ALL_CONFIGS if want == "all" else want.split(","))
+            if not os.environ.get("ACX_BENCH_KEEP_HEADLINE"):
+                m = None                                      # the headline's scanners go first: their results, side streams and events
             try:
-                cfgs["c5_iter_long"] = other_config(torch, dev, acx, "c5_iter_long", "c2", "iter_long", keys, None, image, batches, host0, args,
-                                                    n_keys, args.batch_mb, 200_000 if cpu_on else 0)
+                if "c5_iter_long" in names:
+                    cfgs["c5_iter_long"] = other_config(torch, dev, acx, "c5_iter_long", "c2", "iter_long", keys, None, image, batches, host0, args,
+                                                        n_keys, args.batch_mb, 200_000 if cpu_on else 0)
             except SystemExit as ex:                          # (a failed sub-configuration must not take the headline line with it)
                 cfgs["c5_iter_long"] = {"error": str(ex)}
-            del m, batches, host0, e2e0
+            del m, batches, host0, e2e0                  # (m: the name; the scanners went above)
             # config 2 as the GENERAL stream kernel sees it: the same reads as an offsets batch of ragged lengths (same image)
             try:
-                cfgs["c2_offsets"] = other_config(torch, dev, acx, "c2_offsets", "c2o", "iter", keys, None, image, None, None, args,
-                                                  n_keys, args.batch_mb, 100_000 if cpu_on else 0)
+                if "c2_offsets" in names:
+                    cfgs["c2_offsets"] = other_config(torch, dev, acx, "c2_offsets", "c2o", "iter", keys, None, image, None, None, args,
+                                                      n_keys, args.batch_mb, 100_000 if cpu_on else 0)
             except (SystemExit, Exception) as ex:            # noqa: BLE001
                 cfgs["c2_offsets"] = {"error": "%s: %s" % (type(ex).__name__, ex)}
             image.free()
             del image, image_tensor
             torch.cuda.empty_cache()
             for name, wl, nk in (("c2_long_keys", "c2k", n_keys), ("c3", "c3", 100_000), ("c4", "c4", 1_000_000)):
+                if name not in names:
+                    continue
                 try:
                     k2, v2 = build_keys(wl, nk)
                     cfgs[name] = other_config(torch, dev, acx, name, wl, "iter", k2, v2, None, None, None, args, nk, 512, 100_000 if cpu_on else 0)

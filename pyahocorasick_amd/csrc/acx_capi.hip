@@ -418,12 +418,13 @@ struct acx_result {
     bool ppm_stream = false; acx_ppm_gather_args pend_ga; DevBuf<uint32_t> wave_desc, wave_aux;
     // ACX_SCAN_ASYNC scans: the gather (memory bound) runs on a stream of the result's own, so that the next
     // scan kernel (instruction bound) of another result on the caller's stream overlaps it
-    bool use_side = false; hipStream_t side = nullptr; hipEvent_t ev_scan = nullptr;
+    bool use_side = false; hipStream_t side = nullptr; hipEvent_t ev_scan = nullptr;      // (side: one of the device's pool, not owned)
     bool ctl_zero = false;      // ppm_ctl is known to be all zero (the gather of the last fixed-stride stream scan cleaned up)
     // acx_scan_host, pipelined (scan_host_pipelined): the gather of a fixed-stride stream scan writes records and offsets
     // straight into the result's pinned host buffers (device-mapped pointers) instead of r->matches / r->match_off
     uint2* ext_matches = nullptr; int64_t ext_capacity = 0; int64_t* ext_match_off = nullptr; int64_t ext_off_base = 0;
     acx_result* long_inner = nullptr;           // ACX_SCAN_LONG position-parallel: the result of the scan over the dictionary D
+    bool is_long_inner = false;                 // ... and this IS such a result (which side stream it takes: side_stream_from_pool)
     bool long_pending = false;                  // ... asynchronous: the sweep over the inner scan's records is queued behind its gather (long_complete)
     // the sweep straight from the record pool (acx_long.h acx_long_fuse_args): on the INNER result `fuse` points at the outer one's arguments — its
     // stream scan then queues k_long_gather_sweep where it would queue k_ppm_gather_pos, into `long_out` —, `fused` says whether it did
@@ -481,11 +482,46 @@ struct acx_result {
         for (auto& e : ev) if (e) (void)hipEventDestroy(e);
         if (done) (void)hipEventDestroy(done);
         if (ev_scan) (void)hipEventDestroy(ev_scan);
-        if (side) (void)hipStreamDestroy(side);
         if (copy_stream) (void)hipStreamDestroy(copy_stream);
         delete long_inner;
     }
 };
+
+// The side streams of asynchronous scans belong to the device, not to the results: ACX_SIDE_STREAMS of them, made on first use and kept
+// for the life of the library.  (A stream per result — rounds 3 and 4 — makes the number of HIP streams, and of the hardware queues under
+// them, grow with the number of Scanner objects a process keeps around, and WHICH queues a scan's work sits on is worth 5–10 % of its
+// throughput: profiles/r5_experiments.md §10.)
+//   * `iter` results (what follows their scan kernel is ONE gather of ~45 us) all take stream 0: with the caller's three scan streams that
+//     is four busy queues, and the gathers of consecutive results follow one another on the chip anyway (a gather does not run beside a
+//     scan kernel — registers — so it runs in the seams between them).  Config 2: 605–607 GB/s against 572–577 with a stream per result;
+//   * the inner results of `iter_long` (gather + sweep + prefix sum + move: 40 % of a step) take the streams round robin, so that the tail
+//     of one haystack batch overlaps the tail of the next: 227 GB/s on three streams, 216–218 on two, 201 on one.
+// The lowest priority: this work fills the CUs that the scan kernels of the caller's streams leave idle, it must not take a CU before them
+// (a scan block needs a whole CU: LDS and registers).
+#ifndef ACX_SIDE_STREAMS
+#define ACX_SIDE_STREAMS 3
+#endif
+#define ACX_MAX_DEVICES 64
+static hipError_t side_stream_from_pool(bool round_robin, hipStream_t* out) {
+    static std::mutex mu;
+    static hipStream_t pool[ACX_MAX_DEVICES][ACX_SIDE_STREAMS];
+    static unsigned next[ACX_MAX_DEVICES];
+    int device = -1;                                          // (streams belong to the device that is current when they are made)
+    { hipError_t e = hipGetDevice(&device); if (e != hipSuccess) return e; }
+    if (device < 0 || device >= ACX_MAX_DEVICES) return hipErrorInvalidDevice;
+    std::lock_guard<std::mutex> g(mu);
+    const unsigned k = round_robin ? next[device]++ % ACX_SIDE_STREAMS : 0u;
+    if (!pool[device][k]) {
+        int lo_pri = 0, hi_pri = 0;
+        hipError_t e;
+        if (acx_tune_env("ACX_SIDE_DEFAULT_PRIORITY") || hipDeviceGetStreamPriorityRange(&lo_pri, &hi_pri) != hipSuccess || lo_pri == hi_pri)
+            e = hipStreamCreateWithFlags(&pool[device][k], hipStreamNonBlocking);
+        else e = hipStreamCreateWithPriority(&pool[device][k], hipStreamNonBlocking, acx_tune_env("ACX_SIDE_HIGH_PRIORITY") ? hi_pri : lo_pri);
+        if (e != hipSuccess) { pool[device][k] = nullptr; return e; }
+    }
+    *out = pool[device][k];
+    return hipSuccess;
+}
 
 static int ppm_enqueue(acx_result* r, acx_image* img, const acx_chunk_args* ca, const acx_walk_args* tail, hipStream_t s);
 static int ppm_size_pool(acx_result* r, size_t records);
@@ -699,14 +735,7 @@ static int ppm_enqueue(acx_result* r, acx_image* img, const acx_chunk_args* ca, 
     hipStream_t g = s;                                 // where the rest of this scan is queued
     if (r->ppm_stream) {
         if (r->use_side) {
-            if (!r->side) {
-                // the lowest priority: the copy fills the CUs that the scan kernels of the caller's stream leave idle, it
-                // must not take a CU before them (a scan block needs a whole CU: LDS and registers)
-                int lo_pri = 0, hi_pri = 0;
-                if (acx_tune_env("ACX_SIDE_DEFAULT_PRIORITY") || hipDeviceGetStreamPriorityRange(&lo_pri, &hi_pri) != hipSuccess || lo_pri == hi_pri)
-                    HIP_TRY(hipStreamCreateWithFlags(&r->side, hipStreamNonBlocking));
-                else HIP_TRY(hipStreamCreateWithPriority(&r->side, hipStreamNonBlocking, acx_tune_env("ACX_SIDE_HIGH_PRIORITY") ? hi_pri : lo_pri));
-            }
+            if (!r->side) HIP_TRY(side_stream_from_pool(r->is_long_inner, &r->side));
             if (!r->ev_scan) HIP_TRY(hipEventCreateWithFlags(&r->ev_scan, hipEventDisableTiming));
             HIP_TRY(hipEventRecord(r->ev_scan, s));
             HIP_TRY(hipStreamWaitEvent(r->side, r->ev_scan, 0));
@@ -1246,7 +1275,11 @@ static int scan_long_ppm(acx_image* img, acx_image* li, const acx_scan_params* p
     acx_scan_params q = *p;
     q.mode = ACX_SCAN_ALL; q.want_final_state = 0; q.dev_skip = nullptr; q.dev_init_state = nullptr;
     if (!ppm_plan(li, &q)) return ACX_LONG_FALLBACK;
-    if (!r->long_inner) { r->long_inner = new (std::nothrow) acx_result(); if (!r->long_inner) return acx_fail(ACX_E_NOMEM, "acx_scan_batch: out of memory"); }
+    if (!r->long_inner) {
+        r->long_inner = new (std::nothrow) acx_result();
+        if (!r->long_inner) return acx_fail(ACX_E_NOMEM, "acx_scan_batch: out of memory");
+        r->long_inner->is_long_inner = true;
+    }
     acx_result* in = r->long_inner;
     const size_t n = (size_t)p->n_hay;
     int rc;
