@@ -487,8 +487,8 @@ struct acx_result {
     }
 };
 
-// The side streams of asynchronous scans belong to the device, not to the results: ACX_SIDE_STREAMS of them, made on first use and kept
-// for the life of the library.  (A stream per result — rounds 3 and 4 — makes the number of HIP streams, and of the hardware queues under
+// The side streams of asynchronous scans belong to the device, not to the results: ACX_SIDE_STREAMS of them, made at the first asynchronous
+// scan on the device and kept for the life of the library.  (A stream per result — rounds 3 and 4 — makes the number of HIP streams, and of the hardware queues under
 // them, grow with the number of Scanner objects a process keeps around, and WHICH queues a scan's work sits on is worth 5–10 % of its
 // throughput: profiles/r5_experiments.md §10.)
 //   * `iter` results (what follows their scan kernel is ONE gather of ~45 us) all take stream 0: with the caller's three scan streams that
@@ -510,16 +510,23 @@ static hipError_t side_stream_from_pool(bool round_robin, hipStream_t* out) {
     { hipError_t e = hipGetDevice(&device); if (e != hipSuccess) return e; }
     if (device < 0 || device >= ACX_MAX_DEVICES) return hipErrorInvalidDevice;
     std::lock_guard<std::mutex> g(mu);
-    const unsigned k = round_robin ? next[device]++ % ACX_SIDE_STREAMS : 0u;
-    if (!pool[device][k]) {
+    if (!pool[device][0]) {
+        // ALL streams of the pool are made, and used once, at the first request: which queues they get then does not depend on what the
+        // process scans first (made on first use, `iter_long` after an `iter` measurement in the same process ran at 211.5–213.5 GB/s where
+        // it runs at 224.4–224.7 with the pool made at once; the `iter` scans in front: 590–594 either way — tools/r5_eager.sh)
         int lo_pri = 0, hi_pri = 0;
-        hipError_t e;
-        if (acx_tune_env("ACX_SIDE_DEFAULT_PRIORITY") || hipDeviceGetStreamPriorityRange(&lo_pri, &hi_pri) != hipSuccess || lo_pri == hi_pri)
-            e = hipStreamCreateWithFlags(&pool[device][k], hipStreamNonBlocking);
-        else e = hipStreamCreateWithPriority(&pool[device][k], hipStreamNonBlocking, acx_tune_env("ACX_SIDE_HIGH_PRIORITY") ? hi_pri : lo_pri);
-        if (e != hipSuccess) { pool[device][k] = nullptr; return e; }
+        const bool plain = acx_tune_env("ACX_SIDE_DEFAULT_PRIORITY") || hipDeviceGetStreamPriorityRange(&lo_pri, &hi_pri) != hipSuccess || lo_pri == hi_pri;
+        hipStream_t made[ACX_SIDE_STREAMS];
+        for (unsigned j = 0; j < ACX_SIDE_STREAMS; j++) {
+            hipError_t e = plain ? hipStreamCreateWithFlags(&made[j], hipStreamNonBlocking)
+                                 : hipStreamCreateWithPriority(&made[j], hipStreamNonBlocking, acx_tune_env("ACX_SIDE_HIGH_PRIORITY") ? hi_pri : lo_pri);
+            if (e != hipSuccess) { for (unsigned i = 0; i < j; i++) (void)hipStreamDestroy(made[i]); return e; }
+            hipEvent_t ev;                                    // (one packet through it: the stream has its queue now)
+            if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) == hipSuccess) { (void)hipEventRecord(ev, made[j]); (void)hipEventSynchronize(ev); (void)hipEventDestroy(ev); }
+        }
+        for (unsigned j = 0; j < ACX_SIDE_STREAMS; j++) pool[device][j] = made[j];
     }
-    *out = pool[device][k];
+    *out = pool[device][round_robin ? next[device]++ % ACX_SIDE_STREAMS : 0u];
     return hipSuccess;
 }
 
