@@ -418,7 +418,7 @@ struct acx_result {
     bool ppm_stream = false; acx_ppm_gather_args pend_ga; DevBuf<uint32_t> wave_desc, wave_aux;
     // ACX_SCAN_ASYNC scans: the gather (memory bound) runs on a stream of the result's own, so that the next
     // scan kernel (instruction bound) of another result on the caller's stream overlaps it
-    bool use_side = false; hipStream_t side = nullptr; hipEvent_t ev_scan = nullptr;      // (side: one of the device's pool, not owned)
+    bool use_side = false; hipStream_t side = nullptr; int side_device = -1; hipEvent_t ev_scan = nullptr;      // (side: one of side_device's pool, not owned)
     bool ctl_zero = false;      // ppm_ctl is known to be all zero (the gather of the last fixed-stride stream scan cleaned up)
     // acx_scan_host, pipelined (scan_host_pipelined): the gather of a fixed-stride stream scan writes records and offsets
     // straight into the result's pinned host buffers (device-mapped pointers) instead of r->matches / r->match_off
@@ -742,7 +742,10 @@ static int ppm_enqueue(acx_result* r, acx_image* img, const acx_chunk_args* ca, 
     hipStream_t g = s;                                 // where the rest of this scan is queued
     if (r->ppm_stream) {
         if (r->use_side) {
-            if (!r->side) HIP_TRY(side_stream_from_pool(r->is_long_inner, &r->side));
+            if (!r->side || r->side_device != img->device) {              // (a result that moves to an image of another device takes that device's)
+                HIP_TRY(side_stream_from_pool(r->is_long_inner, &r->side));
+                r->side_device = img->device;
+            }
             if (!r->ev_scan) HIP_TRY(hipEventCreateWithFlags(&r->ev_scan, hipEventDisableTiming));
             HIP_TRY(hipEventRecord(r->ev_scan, s));
             HIP_TRY(hipStreamWaitEvent(r->side, r->ev_scan, 0));
