@@ -129,7 +129,10 @@ def parse():
     ap.add_argument("--launch-check", action="store_true",
                     help="start the ranks (gloo, no GPU), agree on the world size, print {\"n_gpus\": N, \"launch_check\": true} and exit: "
                          "tests/test_parallel_cpu.py runs the self-launch path of --gpus N with it")
-    return ap.parse_args()
+    args = ap.parse_args()
+    if args.configs not in (None, "all", "none") and set(args.configs.split(",")) - set(ALL_CONFIGS):
+        ap.error("--configs: all, none or a comma list of %s" % ", ".join(ALL_CONFIGS))
+    return args
 
 
 def self_launch(args):
@@ -780,8 +783,6 @@ def main():
     t0 = time.perf_counter()
     # iter_long workloads: the dictionary of its position-parallel form is built once on rank 0 and travels behind the blob in the SAME
     # broadcast (parallel.broadcast_image(long_pack=True) / acx_image_set_long): no rank builds it from a device-to-host copy of its image
-    if args.configs not in (None, "all", "none") and set(args.configs.split(",")) - set(ALL_CONFIGS):
-        raise SystemExit("--configs: all, none or a comma list of %s" % ", ".join(ALL_CONFIGS))
     runs_long = args.mode == "iter_long" or (world == 1 and args.workload == "c2" and args.variant == 0 and not args.keys
                                              and ((args.configs or "all") == "all" or "c5_iter_long" in (args.configs or "").split(",")))
     image, image_tensor = broadcast_image(blob, src=0, device=dev, long_pack=runs_long)

@@ -131,3 +131,13 @@ def test_bench_dry_run_strong_scaling_covers_one_corpus():
     # iter_long does not shard INSIDE a haystack
     err = _dry_run("--workload", "c3", "--batch-mb", "2", "--batches", "1", "--scaling", "strong", "--mode", "iter_long", expect_fail=True)
     assert "does not shard" in err
+
+
+def test_bench_configs_takes_all_none_or_a_list_of_names():
+    """`--configs` names which of the other single-GPU configurations the default line measures: all, none or a comma list; a name that
+    is none of them is refused when the arguments are parsed (before any rank starts)."""
+    bench = os.path.join(os.path.dirname(HERE), "bench.py")
+    p = subprocess.run([sys.executable, bench, "--configs", "c5_iter_long,c9", "--dry-run"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=120)
+    assert p.returncode == 2 and b"--configs" in p.stderr and b"c2_long_keys" in p.stderr
+    p = subprocess.run([sys.executable, bench, "--configs", "c5_iter_long,c3", "--launch-check"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
+    assert p.returncode == 0, p.stderr.decode(errors="replace")[-2000:]
