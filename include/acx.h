@@ -303,8 +303,9 @@ typedef struct acx_scan_params {
  * overlaps the next batch) or on several (the expand of batch i then overlaps the walk of
  * batch i+1): bench.py --pipeline / --streams.
  * An asynchronous scan is complete when acx_result_wait (or an accessor) returns — NOT when `stream` has
- * drained: the library queues the final copy of the records on a stream of the result's own, so that it
- * overlaps the next scan kernel that the caller queues on `stream`. */
+ * drained: the library queues the final copy of the records on a low-priority side stream of its own (a pool of three per
+ * device, made at the device's first asynchronous scan: `iter` results share one, `iter_long` results take them in turn), so
+ * that it overlaps the next scan kernel that the caller queues on `stream`. */
 enum { ACX_SCAN_ASYNC = 1,
 /* White space never touches the automaton: AutomatonSearchIter with ignore_white_space=True steps over every letter
  * that iswspace() accepts without changing its state, and reports end indices of the original string
