@@ -39,6 +39,16 @@
 #else
 #define S4_PH(i) do { } while (0)
 #endif
+// -DACX_S4_TSEG=<16 a + b>: every wave adds up the clock ticks (s_memtime, 100 MHz) between points a and b of a trip of the loop —
+// ONE pair of clock reads per trip, waited for at the trip's end, so that the kernel runs at (nearly) its own speed; a build per segment
+// (tools/r6_phase_profile.sh).  phase_out[0]: ticks, [1]: trips that passed both points, [7]: waves.
+#ifdef ACX_S4_TSEG
+// (the clock value goes straight into a VGPR: the kernel has no scalar registers to spare — a live SGPR pair more and it spills to scratch)
+#define S4_TP(k) do { if ((ACX_S4_TSEG >> 4) == (k)) { unsigned long long t_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)); tp_v = (uint32_t)t_; tp_have = 1u; } \
+                      if ((ACX_S4_TSEG & 15) == (k) && tp_have == 1u) { unsigned long long t_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)); tp_sum_v += (uint32_t)t_ - tp_v; tp_n_v += 1u; tp_have = 0u; } } while (0)
+#else
+#define S4_TP(k) do { } while (0)
+#endif
 #ifdef ACX_S4_MARK
 #define S4_MARK(x) asm volatile("; MARK " #x)
 #else
@@ -83,6 +93,14 @@ __device__ __forceinline__ uint32_t top_base4(uint32_t d) { return 0x55555555u &
 // H12: the image's hot4 cells are 12 bytes — { eowmask | go << 16, value of the shallowest key (0: none), deep id of the depth-C node } —
 // (include/acx_blob.h; the dictionaries of iter_long, acx_long.cpp: there nearly every cell that sends a walk deeper also ends a key, so
 // with 8-byte cells nearly every walker waits for cid[] first — one more round trip to the L2 in the chain of every pass)
+// a slot's hot cell in registers AS ITS LOAD FILLS THEM: two words, or — 12-byte cells — three (a third word kept in a register of its own
+// is a copy of a loaded register, i.e. a wait for the gather in the trip that issues it: tools/s4_waits.sh)
+typedef uint32_t u32x3a __attribute__((ext_vector_type(3), aligned(4)));
+template <bool H12> struct S4Cell { typedef u32x2 type; };
+template <> struct S4Cell<true> { typedef u32x3a type; };
+__device__ __forceinline__ uint32_t s4_cell_id(const u32x2& c) { return c.y; }      // (8-byte cells: the second word is the id where it is no value)
+__device__ __forceinline__ uint32_t s4_cell_id(const u32x3a& c) { return c.z; }
+
 template <bool H12>
 __global__ void __launch_bounds__(ACX_PPM_BLOCK) k_ppm_stream4(const acx_ppm_args a) {
     extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
@@ -161,17 +179,20 @@ __global__ void __launch_bounds__(ACX_PPM_BLOCK) k_ppm_stream4(const acx_ppm_arg
     const uint32_t step_r = S4_TPOS % stride;
 
     // a lane's 32 bytes of a tile (read once: they need not stay in the caches)
-    uint32_t wnext[8];
+    u32x4 wn0 = {0, 0, 0, 0}, wn1 = {0, 0, 0, 0};                      // (two register quadruples, as the two loads fill them: tools/s4_waits.sh — eight scalars made the compiler copy a loaded register, i.e. wait for the load it had just issued)
     auto load_lane_full = [&](uint32_t b) {
         const u32x4a v0 = __builtin_nontemporal_load((const u32x4a*)(a.hay + b));
         const u32x4a v1 = __builtin_nontemporal_load((const u32x4a*)(a.hay + b + 16u));
-        wnext[0] = v0.x; wnext[1] = v0.y; wnext[2] = v0.z; wnext[3] = v0.w; wnext[4] = v1.x; wnext[5] = v1.y; wnext[6] = v1.z; wnext[7] = v1.w;
+        wn0 = v0; wn1 = v1;
     };
     auto load_lane = [&](uint32_t b) {                                 // the tile may end inside the buffer's last bytes
         if ((int64_t)b + 32 <= a.hay_cap) load_lane_full(b);
         else {
 #pragma unroll
-            for (int j = 0; j < 8; j++) wnext[j] = (int64_t)b + 4 * j + 4 <= a.hay_cap ? *(const uint32_t*)(a.hay + b + 4u * j) : load_dw_tail(a.hay, a.hay_cap, b + 4u * j);
+            for (int j = 0; j < 8; j++) {
+                const uint32_t w = (int64_t)b + 4 * j + 4 <= a.hay_cap ? *(const uint32_t*)(a.hay + b + 4u * j) : load_dw_tail(a.hay, a.hay_cap, b + 4u * j);
+                if (j < 4) wn0[j] = w; else wn1[j - 4] = w;
+            }
         }
     };
     // (a tile whose 2048 bytes lie inside the buffer: no checks)
@@ -206,27 +227,30 @@ __global__ void __launch_bounds__(ACX_PPM_BLOCK) k_ppm_stream4(const acx_ppm_arg
     // a value requested early and looked at late, an id that rides behind another gather — made the kernel faster,
     // instructions taken out did not.
     uint32_t cur = 0;                                                  // symbol buffer of the tile whose candidates are being fetched
+#ifdef ACX_S4_TSEG
+    uint32_t tp_v = 0, tp_sum_v = 0, tp_n_v = 0, tp_have = 0;
+#endif
     bool tile_ok = true;
     uint32_t pw = 0, x_ex = 0, x_tot = 0, seg_lo = 0, use_other = 0, any_cur = 0;
     uint32_t Wc1 = 0, Wc2 = 0, anyo_c = 0;                             // the symbols of the tile that is being staged, which of its bytes occur in no key
     // ONE set of slot registers: step 1 is the last reader of a round's hot cells, step 3 loads the next round's into the
     // same registers (a second set would have to be copied into the first, and a copy of a loaded register is a wait)
-    u32x2 hcO[S4_NE];
-    uint32_t hidO[H12 ? S4_NE : 1];                                    // H12: the ids of the depth-C nodes
+    typedef typename S4Cell<H12>::type cell_t;
+    cell_t hcO[S4_NE];                                                 // (H12: .z = the id of the depth-C node)
     uint32_t ppO[S4_NE];                                               // entry (position + 33) | symbols that exist << 12 | (16 + the next two symbols) << 18
     uint32_t nO = 0, nN = 0, cgO = 0, cgN = 0, symO = wbase, symN = wbase;
     bool haveO = false;
 #pragma unroll
-    for (int e = 0; e < S4_NE; e++) { hcO[e].x = 0; hcO[e].y = 0; ppO[e] = 0; if (H12) hidO[e] = 0; }
+    for (int e = 0; e < S4_NE; e++) { hcO[e] = (cell_t)(0u); ppO[e] = 0; }
 
-    // bytes of the tile in wnext -> symbols (registers); the bytes of the tile at e_next are requested
+    // bytes of the tile in wn0, wn1 -> symbols (registers); the bytes of the tile at e_next are requested
     auto convert = [&](bool more, uint32_t e_next) {
         S4_MARK(M_STAGE);
         uint32_t diff = 0, pr[8];
         anyo_c = 0;
 #pragma unroll
         for (int j = 0; j < 8; j++) {
-            const uint32_t w = wnext[j];
+            const uint32_t w = j < 4 ? wn0[j] : wn1[j - 4];
             const uint32_t x = (w >> ar_shift) & 0x03030303u;
             diff |= __builtin_amdgcn_perm(0u, ar_lut, x) ^ w;            // the letters permuted by the symbols give the bytes back iff all four are letters
             pr[j] = x * 0x01041040u;                                      // one multiply gathers the four 2-bit fields into the top byte
@@ -235,7 +259,7 @@ __global__ void __launch_bounds__(ACX_PPM_BLOCK) k_ppm_stream4(const acx_ppm_arg
         Wc2 = __builtin_amdgcn_perm(pr[5], pr[4], 0x0c0c0703u) | __builtin_amdgcn_perm(pr[7], pr[6], 0x07030c0cu);
         if (__any(diff != 0u)) {                                        // some byte of the tile is none of the four letters
 #pragma unroll
-            for (int j = 0; j < 8; j++) anyo_c |= nib_of(wnext[j]) << (4 * j);
+            for (int j = 0; j < 8; j++) anyo_c |= nib_of(j < 4 ? wn0[j] : wn1[j - 4]) << (4 * j);
         }
         if (more) load_tile(e_next);
     };
@@ -254,6 +278,7 @@ __global__ void __launch_bounds__(ACX_PPM_BLOCK) k_ppm_stream4(const acx_ppm_arg
         }
         wave_sync();
         const uint32_t W0 = sym_tile[(int)(2u * lane) - 1];
+        S4_TP(8);
         S4_MARK(M_FILTER);
         // the filter: every lane asks the bitmap about its own 32 positions, windows in registers (as k_ppm_stream)
         {
@@ -286,6 +311,7 @@ __global__ void __launch_bounds__(ACX_PPM_BLOCK) k_ppm_stream4(const acx_ppm_arg
             const uint32_t nv = npos > lp ? (npos - lp < 32u ? npos - lp : 32u) : 0u;
             pw &= (nv >= 32u ? 0xFFFFFFFFu : (1u << nv) - 1u) & ~anyo;      // (a byte of no key ends no key)
         }
+        S4_TP(9);
         S4_MARK(M_PREFIX);
         x_ex = wave_excl_scan((uint32_t)__popc(pw), x_tot);
         if (ACX_S4_EXP & 16) x_tot = 0;
@@ -297,9 +323,20 @@ __global__ void __launch_bounds__(ACX_PPM_BLOCK) k_ppm_stream4(const acx_ppm_arg
 #ifdef ACX_S4_PHASES
     unsigned long long ph[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tph = __builtin_amdgcn_s_memtime();
 #endif
+#ifdef ACX_S4_TSEG
+    tp_have = 0;
+#endif
 #define S4_SLOTS(e, ...) _Pragma("unroll") for (int g_ = 0; g_ < S4_NE; g_ += 2) { if (g_ == 0 || (uint32_t)g_ < k) { _Pragma("unroll") for (int e = g_; e < g_ + 2; e++) { __VA_ARGS__ } } }
     for (;;) {
         S4_PH(7);
+        S4_TP(0);
+        // Every load of the trip before is waited for HERE — the hot cells of the round that step 1 looks at next (the youngest of them:
+        // nothing is lost) and the bytes of the next tile.  Left to the compiler, which cannot know that a fetched round is always worked
+        // off in the next trip, the waits land where those registers are next WRITTEN — behind the record stores of step 2 and the
+        // loads of step 3, as waits for the stores' completion and for the loads just issued (tools/s4_waits.sh lists them).
+        asm volatile("" : "+v"(wn0), "+v"(wn1));
+#pragma unroll
+        for (int e = 0; e < S4_NE; e++) asm volatile("" : "+v"(hcO[e]));
         // ---- 1. the round fetched one trip earlier: top levels, deeper walks -----------------------------------------------
         const uint32_t k = (nO + 63u) >> 6;                              // slots of set O that hold entries
         uint32_t cn[S4_NE];
@@ -325,6 +362,7 @@ __global__ void __launch_bounds__(ACX_PPM_BLOCK) k_ppm_stream4(const acx_ppm_arg
                 va[e] = (int32_t)hcO[e].y;
                 cmax = cn[e] > cmax ? cn[e] : cmax;
             )
+            S4_TP(1);
             S4_MARK(M_SECOND);
             // a second key within the cell's levels (0.6 % of the matching positions of config 2): the value of the first such
             // slot of the lane is REQUESTED here and looked at behind the deeper walks — a wait here would be one more
@@ -358,7 +396,7 @@ __global__ void __launch_bounds__(ACX_PPM_BLOCK) k_ppm_stream4(const acx_ppm_arg
                     S4_SLOTS(e,
                         const uint32_t g = (gomask >> e) & 1u;
                         const uint32_t slot = (g != 0u && rnk < 64u) ? rnk : 64u;       // (slot 64: nobody reads it)
-                        u32x2 v; v.x = (ppO[e] & 0x7FFFFFu) | (hcO[e].x << 23); v.y = H12 ? hidO[H12 ? e : 0] : hcO[e].y;
+                        u32x2 v; v.x = (ppO[e] & 0x7FFFFFu) | (hcO[e].x << 23); v.y = s4_cell_id(hcO[e]);
                         *(u32x2*)(dq + 2 * slot) = v;
                         rnk += g;
                     )
@@ -432,10 +470,14 @@ __global__ void __launch_bounds__(ACX_PPM_BLOCK) k_ppm_stream4(const acx_ppm_arg
                 }
                 wave_sync();
             }
+            // (the requested value is waited for HERE, behind the walks' own waits: left to the compiler, the wait lands behind the
+            //  record stores of step 2 — `s_waitcnt vmcnt(2)`, i.e. a wait for the STORES' completion, a quarter of a wave's time)
+            asm volatile("" : "+v"(vbt));
             if (vbte < (uint32_t)S4_NE) set_vb(vbte, vbt);
         }
 
         S4_PH(0);
+        S4_TP(2);
         // ---- 2. set O: placement, records ------------------------------------------------------------------------------------
         if (haveO) {
             const uint32_t cg = cgO;
@@ -525,6 +567,7 @@ __global__ void __launch_bounds__(ACX_PPM_BLOCK) k_ppm_stream4(const acx_ppm_arg
                         E.X = P.window(S4_HP + E.p);
                         const u32x4* cell = (const u32x4*)((const uint8_t*)a.cells + ((E.X >> (32u - 2u * S4_C)) << 5));
                         E.c0 = cell[0]; E.c1 = cell[1];
+                        asm volatile("" : "+v"(E.c0), "+v"(E.c1));       // (waited for here, on the rare path: a load that may still be pending where the paths join costs the COMMON path a wait for everything)
                         const uint32_t idx = E.idx;
                         P.matches(E, from, 0xFFFFFFFFu, [&](uint32_t kk2, int32_t v) { out[oe - kk2] = make_uint2(idx, (uint32_t)v); });
                     }
@@ -536,6 +579,7 @@ __global__ void __launch_bounds__(ACX_PPM_BLOCK) k_ppm_stream4(const acx_ppm_arg
 
         }
 
+        S4_TP(3);
         // ---- 3. this trip hands over the last candidates of the current tile: the next tile's bytes -> symbols ------------------
         const uint32_t ex_lo = (tile_ok && seg_lo) ? (uint32_t)__builtin_amdgcn_readlane((int)x_ex, (int)seg_lo) : 0u;
         const uint32_t qcap = use_other ? S4_QCAP_OTHER : S4_QCAP;
@@ -544,6 +588,7 @@ __global__ void __launch_bounds__(ACX_PPM_BLOCK) k_ppm_stream4(const acx_ppm_arg
         if (st) convert(tiles_left > 2u, e0 + 2u * S4_TPOS);
 
         S4_PH(1);
+        S4_TP(4);
         // ---- 4. the next round of this tile: its candidates -> the queue, in position order; fetch -------------------------------
         bool haveN = false;
         if (tile_ok && x_tot != 0u) {
@@ -563,6 +608,7 @@ __global__ void __launch_bounds__(ACX_PPM_BLOCK) k_ppm_stream4(const acx_ppm_arg
             }
             seg_lo = seg_hi;
             wave_sync();
+            S4_TP(5);
             if (n && !(ACX_S4_EXP & 8)) {
                 S4_MARK(M_FETCH);
                 // where the entries sit, their windows, the requests for their hot cells.  Straight-line over the slots (lane l
@@ -595,11 +641,9 @@ __global__ void __launch_bounds__(ACX_PPM_BLOCK) k_ppm_stream4(const acx_ppm_arg
                     const uint32_t wa = ((ent >> 2) & 0x7FCu) + sbase;
                     const uint32_t X = __builtin_amdgcn_alignbit(lds_rd32(wa + 8u), lds_rd32(wa + 4u), ent << 1);
                     const uint32_t off = (X >> (32u - 2u * S4_C - 3u)) & ((8u << (2u * S4_C)) - 8u);
-                    if (H12) {
+                    if constexpr (H12) {
                         const uint32_t o12 = qi < n ? off + (off >> 1) : (12u << (2u * S4_C));      // (cell x 12 bytes; the spare cell behind the last)
-                        const u32x2 c01 = *(const u32x2*)((const uint8_t*)a.hot4 + o12);
-                        hidO[H12 ? e : 0] = *(const uint32_t*)((const uint8_t*)a.hot4 + o12 + 8u);
-                        hcO[e] = c01;
+                        hcO[e] = *(const u32x3a*)((const uint8_t*)a.hot4 + o12);
                     } else
                     hcO[e] = *(const u32x2*)((const uint8_t*)a.hot4 + ((ACX_S4_EXP & 1) ? ((qi < n ? off : 0u) & 56u) : (qi < n ? off : (8u << (2u * S4_C)))));
                     const uint32_t t5 = __builtin_amdgcn_ubfe(X, 32u - 2u * (S4_C + 2u), 4u) | 16u;     // 16 + the next two symbols: the cell's "go deeper" bit
@@ -611,6 +655,7 @@ __global__ void __launch_bounds__(ACX_PPM_BLOCK) k_ppm_stream4(const acx_ppm_arg
         }
 
         S4_PH(3);
+        S4_TP(6);
         // ---- the round that was fetched is the next trip's set O; a tile that has handed over all its candidates makes room for the next ---------------------
         S4_MARK(M_TAIL);
         nO = nN; cgO = cgN; symO = symN; haveO = haveN;
@@ -628,15 +673,23 @@ __global__ void __launch_bounds__(ACX_PPM_BLOCK) k_ppm_stream4(const acx_ppm_arg
             tiles_left--;
             tile_ok = st;
             wave_sync();
+            S4_TP(7);
             // ---- 5. stage the next tile ------------------------------------------------------------------------------------
             if (st) stage_rest();
         }
         S4_PH(4);
+        S4_TP(10);
+#ifdef ACX_S4_TSEG
+        tp_have = 0;
+#endif
         if (!tile_ok && !haveO) break;
     }
 #undef S4_SLOTS
 #ifdef ACX_S4_PHASES
     if (lane == 0 && a.phase_out) for (int i = 0; i < 8; i++) atomicAdd(a.phase_out + i, ph[i]);
+#endif
+#ifdef ACX_S4_TSEG
+    if (lane == 0 && a.phase_out) { atomicAdd(a.phase_out + 0, (unsigned long long)tp_sum_v); atomicAdd(a.phase_out + 1, (unsigned long long)tp_n_v); atomicAdd(a.phase_out + 7, 1ull); }
 #endif
 #ifdef ACX_S4_WAVETIME
     if (lane == 0 && a.phase_out && wave_id < 4096u) { a.phase_out[8 + 2 * wave_id] = wt0; a.phase_out[8 + 2 * wave_id + 1] = __builtin_amdgcn_s_memrealtime(); }

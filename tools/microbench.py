@@ -39,6 +39,7 @@ def main():
     ap.add_argument("--layout", default="stride", choices=["stride", "offsets", "one"],
                     help="stride: fixed-length reads (direct path); offsets: same reads through a device "
                          "offsets array (chunked path); one: the whole buffer as ONE haystack (chunk+halo)")
+    ap.add_argument("--flatten-flags", type=int, default=0, help="layout options of the flat image (acx_flatten_ex, ACX_FLATTEN_*; 32: 12-byte hot cells)")
     ap.add_argument("--lib", default=None, help="another build of libacx.so (development variants): loaded instead of the one in the package")
     args = ap.parse_args()
     if args.lib:
@@ -68,6 +69,7 @@ def main():
     t_gen = time.time() - t0
     t1 = time.time()
     A = acx.Automaton(acx.STORE_INTS)
+    A.flatten_flags = args.flatten_flags
     A.add_words(keys, range(len(keys)))
     t_add = time.time() - t1; t1 = time.time()
     A.make_automaton()
