@@ -263,6 +263,8 @@ __global__ void __launch_bounds__(ACX_PPM_BLOCK) k_ppm_stream4(const acx_ppm_arg
         }
         if (more) load_tile(e_next);
     };
+    wave_sync();
+    uint32_t halo_w = (uint32_t)__builtin_amdgcn_readfirstlane((int)lds_rd32(wbase + 3u * 4u));     // (the prologue wrote the halo words of buffer 0 in front of a wave_sync)
     // the tile at e0 (its symbols in Wc1, Wc2): symbols -> buffer `cur`, the filter, the prefix sum
     auto stage_rest = [&]() {
         uint32_t* const sym_tile = (uint32_t*)(lds + wbase + cur * S4_SYMB) + 4;
@@ -276,8 +278,10 @@ __global__ void __launch_bounds__(ACX_PPM_BLOCK) k_ppm_stream4(const acx_ppm_arg
             obits_tile[lane] = anyo;
             if (!any_prev && lane == 0) obits[0] = 0;                    // (the tile before left no such bits, and a queue may have been there)
         }
-        wave_sync();
-        const uint32_t W0 = sym_tile[(int)(2u * lane) - 1];
+        // the 16 symbols in front of the lane's own: the second word of the lane before it, over the DPP network (wave_shr:1; lane 0: the
+        // last word of the tile before, kept in a scalar) — no LDS round trip in front of the filter
+        const uint32_t W0 = (uint32_t)__builtin_amdgcn_update_dpp((int)halo_w, (int)W2, 0x138, 0xF, 0xF, false);
+        halo_w = (uint32_t)__builtin_amdgcn_readlane((int)W2, 63);
         S4_TP(8);
         S4_MARK(M_FILTER);
         // the filter: every lane asks the bitmap about its own 32 positions, windows in registers (as k_ppm_stream)
@@ -412,7 +416,7 @@ __global__ void __launch_bounds__(ACX_PPM_BLOCK) k_ppm_stream4(const acx_ppm_arg
                     // issued behind this load and waited for first: no round trip of its own)
                     const bool pend = !H12 && go && (pk >> 23) != 0u;         // (12-byte cells hand the id over whatever else they hold)
                     uint32_t cidv = 0;
-                    if (!H12 && pend) cidv = a.cid[P.window(wpq) >> (32u - 2u * S4_C)];
+                    if (!H12 && pend) cidv = a.cid[(ACX_S4_EXP & 256) ? ((P.window(wpq) >> (32u - 2u * S4_C)) & 15u) : (P.window(wpq) >> (32u - 2u * S4_C))];   // (256, timing only: cid[] from one line)
                     uint32_t dd = S4_C, wc = 0;
                     int32_t wa = 0, wb = 0;
                     uint32_t s1 = P.sym_at(wpq - S4_C);
@@ -422,6 +426,8 @@ __global__ void __launch_bounds__(ACX_PPM_BLOCK) k_ppm_stream4(const acx_ppm_arg
                         const uint32_t single = did >> 31, first = single ^ 1u;
                         uint32_t off = single ? a.single_off + (did << 4) : a.row_off + ((did + s1) << 4);   // (bit 31 shifts out; a row's id is a record index)
                         off = go ? off : a.row_off;
+                        if ((ACX_S4_EXP & 512) && !first_step) off = a.row_off + (off & 112u);   // (timing only: the records behind the first from one line)
+                        if ((ACX_S4_EXP & 64) && first_step) off = a.row_off + (off & 112u);     // (timing only: the first record gather from one line)
                         const u32x4 rec = *(const u32x4*)(a.deep_base + off);
                         const uint32_t g = go ? 1u : 0u;
                         const uint32_t len = rec.y & 0xFFu;
@@ -442,6 +448,7 @@ __global__ void __launch_bounds__(ACX_PPM_BLOCK) k_ppm_stream4(const acx_ppm_arg
                             if (pend) { dd = S4_C; did = cidv; go = cidv != 0u; }
                         }
                         if (!__any(go)) break;
+                        if (ACX_S4_EXP & 32) break;                      // (timing only: one step per walker)
                         s1 = go ? P.sym_at(wpq - dd) : 0u;
                     }
                     dq[2 * lane] = (uint32_t)wa; dq[2 * lane + 1] = (uint32_t)wb; dcnt[lane] = (uint16_t)wc;
@@ -541,7 +548,11 @@ __global__ void __launch_bounds__(ACX_PPM_BLOCK) k_ppm_stream4(const acx_ppm_arg
 #ifdef ACX_S4_PRED_STORES
                     if (c) *(uint2*)(out8 + (oe << 3)) = make_uint2(rr[e], (uint32_t)va[e]);
 #else
+#ifdef ACX_S4_NT_STORES
+                    { u32x2 rv_; rv_.x = rr[e]; rv_.y = (uint32_t)va[e]; __builtin_nontemporal_store(rv_, (u32x2*)(out8 + ((c ? oe : rt) << 3))); }
+#else
                     *(uint2*)(out8 + ((c ? oe : rt) << 3)) = make_uint2(rr[e], (uint32_t)va[e]);
+#endif
 #endif
                     two |= (c > 1u ? 1u : 0u) << e;
                     slow |= (c > 2u ? 1u : 0u) << e;
