@@ -464,19 +464,17 @@ __global__ void __launch_bounds__(ACX_PPM_BLOCK) k_ppm_stream(const acx_ppm_args
         h_tile = (uint32_t)__builtin_amdgcn_readfirstlane((int)h_tile); r_tile = (uint32_t)__builtin_amdgcn_readfirstlane((int)r_tile);
     }
     // a lane's PPL bytes of a tile (contiguous: 16-byte loads; read once: they need not stay in the caches)
-    auto load_lane = [&](uint32_t b, uint32_t (&w)[DPL]) {
+    // (register quadruples, as the loads fill them: scalars made the compiler copy loaded registers — a wait for a load just issued, tools/isa_waits.py)
+    auto load_lane = [&](uint32_t b, u32x4 (&w)[DPL / 4]) {
         if ((int64_t)b + PPL <= a.hay_cap) {
 #pragma unroll
-            for (int j = 0; j < (int)DPL / 4; j++) {
-                const u32x4a v = __builtin_nontemporal_load((const u32x4a*)(a.hay + b + 16u * j));
-                w[4 * j] = v.x; w[4 * j + 1] = v.y; w[4 * j + 2] = v.z; w[4 * j + 3] = v.w;
-            }
+            for (int j = 0; j < (int)DPL / 4; j++) { const u32x4a v = __builtin_nontemporal_load((const u32x4a*)(a.hay + b + 16u * j)); w[j] = v; }
         } else {
 #pragma unroll
-            for (int j = 0; j < (int)DPL; j++) w[j] = load_dw(b + 4u * j);
+            for (int j = 0; j < (int)DPL; j++) w[j / 4][j % 4] = load_dw(b + 4u * j);
         }
     };
-    uint32_t wnext[DPL];
+    u32x4 wnext[DPL / 4];
     load_lane(e0 + PPL * (uint32_t)lane, wnext);
     int64_t fh_next = OFFS ? a.first_h[t_begin] : 0;
 
@@ -518,7 +516,7 @@ __global__ void __launch_bounds__(ACX_PPM_BLOCK) k_ppm_stream(const acx_ppm_args
                 uint32_t pr[4];
 #pragma unroll
                 for (int j = 0; j < 4; j++) {
-                    const uint32_t w = wnext[4 * g + j];
+                    const uint32_t w = wnext[g][j];
                     const uint32_t x = (w >> ar_shift) & 0x03030303u;
                     diff |= __builtin_amdgcn_perm(0u, ar_lut, x) ^ w;
                     pr[j] = x * 0x01041040u;
@@ -527,13 +525,13 @@ __global__ void __launch_bounds__(ACX_PPM_BLOCK) k_ppm_stream(const acx_ppm_args
             }
             if (__any(diff != 0u)) {                                   // some byte of the tile is none of the four letters
 #pragma unroll
-                for (int j = 0; j < (int)DPL; j++) { uint32_t nb; (void)convert(wnext[j], nb); anyo |= nb << (4 * j); }
+                for (int j = 0; j < (int)DPL; j++) { uint32_t nb; (void)convert(wnext[j / 4][j % 4], nb); anyo |= nb << (4 * j); }
             }
         } else {
 #pragma unroll
             for (int j = 0; j < (int)DPL; j++) {
                 uint32_t nb;
-                const uint32_t packed = convert(wnext[j], nb);
+                const uint32_t packed = convert(wnext[j / 4][j % 4], nb);
                 W[1 + (4 * SB * j) / 32] |= packed << ((4 * SB * j) & 31);
                 anyo |= nb << (4 * j);
             }
@@ -785,6 +783,13 @@ __global__ void __launch_bounds__(ACX_PPM_BLOCK) k_ppm_stream(const acx_ppm_args
             )
             wave_sync();                                                 // (the queue's memory is free from here on)
             PH(2);
+            // (the hot cells are waited for here; loads return in order, so the bytes of the next tile — requested a tile earlier — have
+            //  arrived as well, and the compiler is told so: left alone it waits for them where they are used, behind the record stores of
+            //  the tile's last round, i.e. for the stores' completion)
+#pragma unroll
+            for (int e = 0; e < NE; e++) asm volatile("" : "+v"(hc[e]));
+#pragma unroll
+            for (int j = 0; j < (int)DPL / 4; j++) asm volatile("" : "+v"(wnext[j]));
             // 2. top levels: how many keys end here, the value of the shallowest, whether the walk goes deeper
             uint32_t n_go = 0, gomask = 0, tvany = 0;
             uint32_t tvm[NE];
@@ -987,6 +992,7 @@ __global__ void __launch_bounds__(ACX_PPM_BLOCK) k_ppm_stream(const acx_ppm_args
                         E.X = P.window(HP + E.p);                        // (read again: the windows of the round need not stay in registers for this)
                         const u32x4* cell = (const u32x4*)((const uint8_t*)a.cells + (code_n(E.X, Cn) << 5));
                         E.c0 = cell[0]; E.c1 = cell[1];
+                        asm volatile("" : "+v"(E.c0), "+v"(E.c1));       // (waited for on the rare path, not where the paths join)
                         const uint32_t idx = E.idx;
                         P.matches(E, from, 0xFFFFFFFFu, [&](uint32_t kk2, int32_t v) { out[oe - kk2] = make_uint2(idx, (uint32_t)v); });
                     }
