@@ -122,6 +122,14 @@ def parse():
     ap.add_argument("--configs", default=None,
                     help="the other named single-GPU configurations in the same run: all | none | a comma list of their names "
                          "(c5_iter_long,c2_offsets,c2_long_keys,c3,c4); default: all for the default command on one GPU")
+    ap.add_argument("--dummy-streams", type=int, default=0,
+                    help="make (and use once) this many HIP streams before anything else — what RCCL's and a caller's own streams do to the order in "
+                         "which the scan and side streams get their hardware queues (include/acx.h, ACX_SCAN_ASYNC; tools/r6_queues.sh)")
+    ap.add_argument("--verbose", action="store_true",
+                    help="print the FULL line (every field, the prose ones included: > 15 KB for the default command).  Default: the compact "
+                         "line (< 7 KB: the driver keeps an 8 KB tail of the output) — the contract's fields, `roofline` and `cpu_baseline` of "
+                         "every configuration, and {name: [GB/s, roofline.frac]} of all of them in `config.all`")
+    ap.add_argument("--full-json", default=None, help="also write the full line to this file (profiles/r6_bench_full.json is one)")
     ap.add_argument("--lib", default=None, help="another build of libacx.so (development A/B, tools/build_variant.sh) instead of the package's")
     ap.add_argument("--dry-run", action="store_true",
                     help="no GPU: the ranks come up over gloo, the blob is broadcast and validated, every rank stages its shard on the host as "
@@ -727,6 +735,70 @@ def other_config(torch, dev, acx, name, workload, mode_name, keys, vocab, image,
     return out
 
 
+def _rnd(x, n=4):
+    return round(x, n) if isinstance(x, float) else x
+
+
+def compact_roofline(r):
+    """what the contract asks of `roofline` (bound, achieved, peak, unit, frac, traffic) + what tools/roofline_check.py recomputes it from"""
+    if not r:
+        return r
+    return {"bound": r["bound"], "kernel": r["kernel"], "achieved": _rnd(r["achieved"], 1), "peak": r["peak"], "unit": r["unit"], "frac": _rnd(r["frac"], 5),
+            "traffic": r.get("traffic"), "algorithmic_bytes": int(r["algorithmic_bytes"]), "kernel_avg_ms": r["kernel_avg_ms"],
+            "kernel_alone_ms": r.get("kernel_alone_ms"), "launches_overlap": r.get("launches_overlap"),
+            "step": {"algorithmic_bytes": int(r["step"]["algorithmic_bytes"]), "ms": r["step"]["ms"], "frac": _rnd(r["step"]["frac"], 5)}}
+
+
+def compact_cpu(c):
+    if not c:
+        return c
+    out = {"value": _rnd(c["value"], 5), "unit": c["unit"], "cores": c["cores"], "kind": c["kind"], "host_cpus": c.get("host_cpus"),
+           "sample": c["sample"].split(",")[0] + ", %.1f s on 1 core" % c.get("seconds", 0.0)}
+    if c.get("all_cores"):
+        out["all_cores"] = {"value": _rnd(c["all_cores"]["value"], 4), "cores": c["all_cores"]["cores"]}
+    return out
+
+
+def compact_line(out):
+    """The driver's line: the full object minus prose and per-step lists — short enough for the 8 KB tail the driver keeps of the
+    output (two of six configurations were cut off).  `--verbose` prints, `--full-json` writes, the whole object."""
+    keep = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "inner_repeats", "passes", "timed_region_ms", "ms_per_step", "higher_is_better",
+            "scaling", "vs_baseline", "dtype", "data", "matches_per_s", "matches_per_step", "bytes_total", "ms_per_step_synchronous", "per_rank_GBps",
+            "end_to_end_GBps", "setup")
+    o = {k: _rnd(out[k], 5) for k in keep if k in out}
+    o["per_rank_GBps"] = {k: _rnd(v, 2) for k, v in out["per_rank_GBps"].items()}
+    if out["n_gpus"] > 1:
+        o["ranks"] = {"reported_by_process_group": out["ranks"]["reported_by_process_group"], "took_part": out["ranks"]["took_part"],
+                      "GBps": [r["GBps"] for r in out["ranks"]["per_rank"]], "kernel_alone_ms": [r["kernel_alone_ms"] for r in out["ranks"]["per_rank"]]}
+    cfg = dict(out["config"])
+    cfg["workload"] = cfg["workload"].split(";")[0]
+    frac = lambda e: _rnd(e["roofline"]["frac"], 4) if e.get("roofline") else None
+    allc = {"headline": [_rnd(out["value"], 1), frac(out)]}
+    for name, e in (out.get("configs") or {}).items():
+        allc[name] = [_rnd(e["value"], 1), frac(e)] if "value" in e else [None, None]
+    cfg["all"] = allc                                          # {configuration: [GB/s, roofline.frac]} — `parsed` of the driver keeps `config`
+    o["config"] = cfg
+    o["roofline"] = compact_roofline(out.get("roofline"))
+    if "cpu_baseline" in out:
+        o["cpu_baseline"] = compact_cpu(out["cpu_baseline"])
+    if "one_scan_stream" in out:
+        o["one_scan_stream"] = {"value": _rnd(out["one_scan_stream"]["value"], 1), "ms_per_step": _rnd(out["one_scan_stream"]["ms_per_step"], 5),
+                                "roofline": compact_roofline(out["one_scan_stream"]["roofline"])}
+    if "configs" in out:
+        cc = {}
+        for name, e in out["configs"].items():
+            if "value" not in e:
+                cc[name] = {"error": str(e.get("error"))[:160]}
+                continue
+            cc[name] = {"value": _rnd(e["value"], 2), "unit": e["unit"], "ms_per_step": _rnd(e["ms_per_step"], 5), "steps": e["steps"], "inner_repeats": e["inner_repeats"],
+                        "scan_streams": e["scan_streams"], "workload": e["workload"].split(":")[0].split(";")[0], "roofline": compact_roofline(e["roofline"]),
+                        "setup_s": (e.get("setup") or {}).get("build_flatten_upload_s")}
+            if "cpu_baseline" in e:
+                cc[name]["cpu_baseline"] = compact_cpu(e["cpu_baseline"])
+        o["configs"] = cc
+    return o
+
+
 def main():
     args = parse()
     self_launch(args)                                      # --gpus N > 1 outside torch.distributed.run: N ranks are started here
@@ -767,6 +839,15 @@ def main():
         _lib.LIB_PATH = os.path.abspath(args.lib)
     from pyahocorasick_amd.parallel import broadcast_image
     _lib.check(_lib.lib().acx_device_set(local_rank))
+    dummy_streams = []
+    if args.dummy_streams > 0:
+        os.environ["ACX_BENCH_DUMMY_STREAMS"] = str(args.dummy_streams)
+        for _ in range(args.dummy_streams):
+            st = torch.cuda.Stream(device=dev)
+            with torch.cuda.stream(st):
+                torch.zeros(1, device=dev).add_(1)
+            dummy_streams.append(st)                            # (kept alive: their queues stay taken)
+        torch.cuda.synchronize()
 
     # ---- dictionary: built on rank 0 (CPU), replicated by one RCCL broadcast ---------------------
     n_keys = args.keys or (1_000_000 if args.workload == "c4" else 100_000)
@@ -871,7 +952,11 @@ def main():
                                    % (args.mode, B, sum(b[1] for b in batches) / 1e6),
                        "states": int(image.num_states), "classes": int(image.num_classes),
                        "image_mb": round(image.nbytes / 1e6, 1), "variant": args.variant, "pipeline_depth": P, "scan_streams": m["scan_streams"],
-                       "parallelism": "replicated automaton (1 RCCL broadcast), haystacks sharded x%d (%s)" % (world, "strong" if strong else "weak")},
+                       "parallelism": "replicated automaton (1 RCCL broadcast), haystacks sharded x%d (%s)" % (world, "strong" if strong else "weak"),
+                       # what the overlap of scans and their follow-up work rests on (include/acx.h, ACX_SCAN_ASYNC): hardware queues of the
+                       # process, results in flight, the library's side streams per device
+                       "queues": {"GPU_MAX_HW_QUEUES": os.environ.get("GPU_MAX_HW_QUEUES"), "results_in_flight": P, "scan_streams": m["scan_streams"],
+                                  "side_streams": int(_lib.lib().acx_async_streams()), "streams_made_first": int(os.environ.get("ACX_BENCH_DUMMY_STREAMS", "0"))}},
             "roofline": roofline_entry(image, batches, m, args.mode, args.workload, args.variant, args.event_every),
             "setup": {"build_flatten_s": round(t_build, 3), "broadcast_upload_s": round(t_bcast, 3), "stage_batches_s": round(t_stage, 3)},
         }
@@ -944,7 +1029,10 @@ def main():
                     cfgs[name] = {"error": "%s: %s" % (type(ex).__name__, ex)}
                 torch.cuda.empty_cache()
             out["configs"] = cfgs
-        os.write(json_fd, (json.dumps(out) + "\n").encode())
+        if args.full_json:
+            with open(args.full_json, "w") as f:
+                f.write(json.dumps(out) + "\n")
+        os.write(json_fd, (json.dumps(out if args.verbose else compact_line(out), separators=(",", ":")) + "\n").encode())
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

@@ -35,7 +35,10 @@ extern "C" {
 #pragma GCC visibility push(default)
 #endif
 
-#define ACX_ABI_VERSION 3          /* 3: acx_scan_params.dev_skip, acx_scan_host_ctx, acx_trie_add_words, ACX_SCAN_SKIP_WS */
+#define ACX_ABI_VERSION 4          /* 3: acx_scan_params.dev_skip, acx_scan_host_ctx, acx_trie_add_words, ACX_SCAN_SKIP_WS
+                                    * 4: acx_trie_scan_host, acx_set_host_walk_bytes / acx_host_walk_applies / acx_host_walk_calls, acx_blob_long_pack,
+                                    *    acx_image_set_long / acx_image_long_state, ACX_FLATTEN_HOT12, acx_async_streams; the values that acx_blob_long_trie
+                                    *    returns carry kind 3 and, for dictionaries below 2^18 entries, `below` in bits 18-23 (section 3b) */
 
 typedef enum acx_status {
     ACX_OK            =  0,
@@ -305,7 +308,15 @@ typedef struct acx_scan_params {
  * An asynchronous scan is complete when acx_result_wait (or an accessor) returns — NOT when `stream` has
  * drained: the library queues the final copy of the records on a low-priority side stream of its own (a pool of three per
  * device, made at the device's first asynchronous scan: `iter` results share one, `iter_long` results take them in turn), so
- * that it overlaps the next scan kernel that the caller queues on `stream`. */
+ * that it overlaps the next scan kernel that the caller queues on `stream`.
+ * Queues.  How much of that overlap a process gets depends on how the HIP runtime maps its streams onto hardware queues: by default
+ * it has FOUR per process, and a stream gets one at its first use.  Three scan streams + the library's side stream are four busy
+ * queues; a process that also holds RCCL's streams or streams of its own shares queues between them, and a gather that shares a queue
+ * with a scan stream runs behind that stream's kernels instead of in the seams between them (config 2 of bench.py: 590-607 GB/s with
+ * the side stream on a queue of its own, 565-577 without; profiles/r5_experiments.md section 10).  The environment variable
+ * GPU_MAX_HW_QUEUES (read by the HIP runtime when it starts, i.e. it must be set before the first HIP call of the process; bench.py
+ * sets 8) raises the number; the library cannot set it for a process whose runtime is already up.  acx_async_streams() says what
+ * the library itself holds. */
 enum { ACX_SCAN_ASYNC = 1,
 /* White space never touches the automaton: AutomatonSearchIter with ignore_white_space=True steps over every letter
  * that iswspace() accepts without changing its state, and reports end indices of the original string
@@ -330,6 +341,9 @@ int  acx_scan_batch(acx_image_t* img, const acx_scan_params* p, acx_result_t** r
  * names the dominant kernel of its roofline entry with it. */
 int  acx_scan_plan(const acx_image_t* img, const acx_scan_params* p);
 int  acx_result_wait(acx_result_t* r);
+/* the side streams the library makes per device for the follow-up work of asynchronous scans (the pool's size; 0: none made, asynchronous
+ * scans finish on the caller's stream) */
+int  acx_async_streams(void);
 
 /* All accessors below complete the scan (acx_result_wait) as needed. */
 int64_t            acx_result_num_matches(acx_result_t* r);

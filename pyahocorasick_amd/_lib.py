@@ -56,6 +56,7 @@ _u8p = C.c_char_p
 SIGNATURES = {
     "acx_last_error": (C.c_char_p, []),
     "acx_abi_version": (C.c_int, []),
+    "acx_async_streams": (C.c_int, []),
     "acx_trie_new": (C.c_int, [_PP]),
     "acx_trie_free": (None, [_P]),
     "acx_trie_add_word": (C.c_int, [_P, _u8p, C.c_size_t, C.c_int64, C.POINTER(C.c_int)]),
@@ -162,8 +163,8 @@ def lib():
                               "`python -m pyahocorasick_amd.build --force`)" % (LIB_PATH, name))
         fn.restype = res
         fn.argtypes = args
-    if l.acx_abi_version() != 3:
-        raise ImportError("pyahocorasick_amd: libacx ABI version %d, binding expects 3" % l.acx_abi_version())
+    if l.acx_abi_version() != 4:
+        raise ImportError("pyahocorasick_amd: libacx ABI version %d, binding expects 4" % l.acx_abi_version())
     _lib = l
     return l
 

@@ -502,14 +502,26 @@ struct acx_result {
 #define ACX_SIDE_STREAMS 3
 #endif
 #define ACX_MAX_DEVICES 64
-static hipError_t side_stream_from_pool(bool round_robin, hipStream_t* out) {
+extern "C" int acx_async_streams(void) { return (int)ACX_SIDE_STREAMS; }
+// `device`: the IMAGE's device — the streams are made on it (the caller's current device is restored) and kept under its number: a
+// caller whose current device is another one gets streams of the device its scan runs on.
+static hipError_t side_stream_from_pool(int device, bool round_robin, hipStream_t* out) {
     static std::mutex mu;
     static hipStream_t pool[ACX_MAX_DEVICES][ACX_SIDE_STREAMS];
     static unsigned next[ACX_MAX_DEVICES];
-    int device = -1;                                          // (streams belong to the device that is current when they are made)
-    { hipError_t e = hipGetDevice(&device); if (e != hipSuccess) return e; }
     if (device < 0 || device >= ACX_MAX_DEVICES) return hipErrorInvalidDevice;
     std::lock_guard<std::mutex> g(mu);
+    int cur_dev = -1;
+    { hipError_t e = hipGetDevice(&cur_dev); if (e != hipSuccess) return e; }
+    struct DeviceGuard {                                       // makes `device` current while the pool's streams are made, then the caller's again
+        int back = -1;
+        ~DeviceGuard() { if (back >= 0) (void)hipSetDevice(back); }
+    } guard;
+    if (!pool[device][0] && cur_dev != device) {
+        hipError_t e = hipSetDevice(device);
+        if (e != hipSuccess) return e;
+        guard.back = cur_dev;
+    }
     if (!pool[device][0]) {
         // ALL streams of the pool are made, and used once, at the first request: which queues they get then does not depend on what the
         // process scans first (made on first use, `iter_long` after an `iter` measurement in the same process ran at 211.5–213.5 GB/s where
@@ -743,7 +755,7 @@ static int ppm_enqueue(acx_result* r, acx_image* img, const acx_chunk_args* ca, 
     if (r->ppm_stream) {
         if (r->use_side) {
             if (!r->side || r->side_device != img->device) {              // (a result that moves to an image of another device takes that device's)
-                HIP_TRY(side_stream_from_pool(r->is_long_inner, &r->side));
+                HIP_TRY(side_stream_from_pool(img->device, r->is_long_inner, &r->side));
                 r->side_device = img->device;
             }
             if (!r->ev_scan) HIP_TRY(hipEventCreateWithFlags(&r->ev_scan, hipEventDisableTiming));
@@ -1178,7 +1190,12 @@ extern "C" int acx_image_set_long(acx_image_t* img, const void* pack, size_t pac
     if (img->long_state) return acx_fail(ACX_E_STATE, "acx_image_set_long: the image already has its iter_long dictionary (or knows it gets none)");
     acx_long_pack_header h;
     if (on_device) HIP_TRY(hipMemcpy(&h, pack, sizeof h, hipMemcpyDeviceToHost)); else memcpy(&h, pack, sizeof h);
-    if (h.magic != ACX_LONG_PACK_MAGIC || h.total_bytes > pack_bytes || h.d_off + h.d_bytes > h.total_bytes || h.real_off + h.n_real * 4 > h.total_bytes)
+    // (every bound by subtraction — a sum of two fields of a malformed header may wrap — and the alignments the device reads rely on:
+    //  the dictionary's image is adopted IN PLACE when the pack is in device memory, its values are read as 32-bit words)
+    const bool empty = h.d_bytes == 0;
+    if (h.magic != ACX_LONG_PACK_MAGIC || h.total_bytes > pack_bytes || h.total_bytes < sizeof(acx_long_pack_header) ||
+        (!empty && (h.d_off < 256 || h.d_off % 256 != 0 || h.d_off > h.total_bytes || h.d_bytes > h.total_bytes - h.d_off || h.d_bytes < sizeof(acx_blob_header) ||
+                    h.real_off % 4 != 0 || h.real_off > h.total_bytes || h.real_off < h.d_off + h.d_bytes || h.n_real > (h.total_bytes - h.real_off) / 4)))
         return acx_fail(ACX_E_FORMAT, "acx_image_set_long: not a pack of acx_blob_long_pack");
     if (h.trie_version != img->h.trie_version) return acx_fail(ACX_E_STATE, "acx_image_set_long: the pack was made from another version of the automaton");
     if (!h.d_bytes || !img->ppm_g) { img->long_state = -1; return ACX_OK; }       // (does not apply: the serial walk stays)
@@ -1828,7 +1845,11 @@ extern "C" int acx_trie_scan_host(const acx_trie_t* t, int mode, const uint8_t* 
                                   int32_t flags, int want_final, acx_result_t** result) {
     if (!t || !off || !result || n_hay < 0) return acx_fail(ACX_E_INVAL, "acx_trie_scan_host: bad argument");
     if (off[0] != 0 || (ctx && (!ctx_off || ctx_off[0] != 0))) return acx_fail(ACX_E_INVAL, "acx_trie_scan_host: off[0] and ctx_off[0] must be 0");
-    if (off[n_hay] > ACX_HOSTWALK_MAX_BYTES)
+    // (a stream that carries a node of the HOST trie — iter_long().set() behind a chunk that the walk took — goes on here whatever the
+    //  chunk's size: the state means nothing to the device image, and refusing the chunk would break a stream that has begun)
+    bool carried = false;
+    if (init_node && mode == ACX_SCAN_LONG) for (int64_t i = 0; i < n_hay; i++) if (init_node[i] < 0) { carried = true; break; }
+    if (off[n_hay] > ACX_HOSTWALK_MAX_BYTES && !carried)
         return acx_fail(ACX_E_UNSUPPORTED, "acx_trie_scan_host: %lld bytes: the host walk is for what does not pay a launch (<= %lld bytes); batches go to acx_scan_host",
                         (long long)off[n_hay], (long long)ACX_HOSTWALK_MAX_BYTES);
     acx_result* r = *result;

@@ -37,7 +37,7 @@ def test_library_exports_the_c_abi_and_nothing_else():
 
 def test_library_loads_and_reports_abi():
     l = _lib.lib()
-    assert l.acx_abi_version() == 3
+    assert l.acx_abi_version() == 4
 
 
 def test_struct_layout_matches_header(tmp_path):

@@ -315,6 +315,41 @@ def test_a_carried_host_state_never_reaches_the_device():
     assert list(zip(r3.end_index.tolist(), r3.value.tolist())) == O.iter_long(b"cd")
 
 
+def test_a_carried_host_state_takes_a_chunk_beyond_the_walks_cap(tmp_path):
+    """iter_long(small chunk) leaves a NEGATIVE state when the chunk ends inside a key; set() with a chunk beyond ACX_HOSTWALK_MAX_BYTES
+    then has to go on on the host walk (the state means nothing to a device image) instead of being refused — through the ctypes
+    mirror's scan_batch and through the extension's iter_long().set()"""
+    keys = [b"abcd", b"bc", b"cdeab", b"dea"]
+    A, O = build_pair(keys)
+    rnd = random.Random(7)
+    big = bytes(rnd.choice(b"abcde") for _ in range((1 << 20) + 4097))
+    r1 = A.scan_batch(b"xxab", [0, 4], acx.ACX_SCAN_LONG)
+    assert int(r1.final_state[0]) < 0                          # "ab": inside "abcd"
+    _lib.lib().acx_set_host_walk_bytes(2048)                    # (the default limit of a process with a device)
+    r2 = A.scan_batch(big, [0, len(big)], acx.ACX_SCAN_LONG, init_state=r1.final_state, index_base=[4])
+    want = O.iter_long(b"xxab" + big)
+    got = list(zip(r1.end_index.tolist(), r1.value.tolist())) + list(zip(r2.end_index.tolist(), r2.value.tolist()))
+    assert got == want and len(want) > 1000
+    _lib.lib().acx_set_host_walk_bytes(1 << 20)
+    body = """
+import random
+rnd = random.Random(7)
+big = bytes(rnd.choice(b"abcde") for _ in range((1 << 20) + 4097))
+D = ahocorasick.Automaton()
+for i, w in enumerate((b"abcd", b"bc", b"cdeab", b"dea")):
+    D.add_word(w, i)
+D.make_automaton()
+ahocorasick.set_host_walk_bytes(2048)
+it = D.iter_long(b"xxab")
+got = list(it)
+it.set(big)
+got += list(it)
+print(json.dumps({"got": got, "walks": ahocorasick.host_walk_calls()}))
+"""
+    r = _dropin_script(tmp_path, body)
+    assert [tuple(x) for x in r["got"]] == want and r["walks"] >= 2
+
+
 # ------------------------------------------------------------------ the reference's own test-suite, on the CPU
 @pytest.mark.parametrize("flavour", ["bytes", "unicode"])
 def test_reference_suite_against_dropin_on_the_host_walk(flavour):
