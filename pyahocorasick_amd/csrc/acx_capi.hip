@@ -1251,8 +1251,11 @@ static int long_enqueue_sweep(acx_result* r, acx_image* img, hipStream_t g) {
         // (queued behind a scan that may turn out incomplete — more records than its buffer holds: its offsets then point beyond the
         //  buffer — the kernels look at the scan's total first and leave; entry indices are checked against the dictionary's size)
         la.rec_capacity = (int64_t)in->matches.cap; la.n_real = img->long_n_real;
+        la.compact = (r->pend_params.variant >> 27) & 1;                  // (A/B and the multi-way tests: the compact form of round 5)
         if (r->timed) HIP_TRY(hipEventRecord(r->ev[2], g));
         HIP_TRY(acx_launch_long_sweep(la, g));
+        // (round 6 tried a prefix sum over the 15 625 GROUPS in one block + a move that finds its haystacks' offsets itself instead of the
+        //  three-launch prefix sum over every haystack: 0.185 against 0.177 ms for sweep + prefix sum + move — the one block is the slower)
         HIP_TRY(acx_launch_scan(r->counts.p, (int64_t)n, r->match_off.p, r->partials.p, g));
         HIP_TRY(acx_launch_long_move(la, r->match_off.p, img->long_real, r->matches.p, g));
         if (r->timed) HIP_TRY(hipEventRecord(r->ev[3], g));

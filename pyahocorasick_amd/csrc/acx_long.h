@@ -17,6 +17,7 @@ struct acx_long_args {
     // The sweep may be queued behind a scan that turns out incomplete (asynchronous scans: more records than its buffer holds —
     // the host issues it again at completion): off[n_hay] > rec_capacity says so, and the kernels leave at once.
     int64_t rec_capacity;
+    int32_t compact;               // 1: the sweep over compact records (round 5: a staging pass drops the U records; `variant` bit 27), 0: over the raw records in LDS
     int64_t n_real;                // entries of the dictionary (an index beyond them — stale records — reports 0); fewer than 2^18: the values carry `below` (acx.h)
 };
 hipError_t acx_launch_long_sweep(const acx_long_args& a, hipStream_t s);

@@ -41,13 +41,17 @@ struct GlobalRecs { rec2_t* p; __device__ rec2_t get(uint32_t k) const { return 
 // The record in front of the current one travels in registers (for "does a longer path end here?"); after a restart the
 // one in front ends before r, so it cannot end where the current one ends.
 template <typename R>
-__device__ __forceinline__ uint32_t sweep_one(R rec, uint32_t n, int32_t r, int32_t reach, uint32_t imask) {
+__device__ __forceinline__ uint32_t sweep_one(R rec, uint32_t n, int32_t r, int32_t reach, bool small) {
     // Straight-line: every condition a 0 / 1 word, combined with & and | (a short-circuit && is an exec-mask region and a
     // branch each — the first version of this loop was 80 basic blocks), one LDS read and one predicated write per trip.
+    // Round 6: kinds 2 (FE) and 3 (an E node with no E / FE node below it) are reported the moment they fire (`now`), a
+    // remembered E's path is followed for `below` letters where the values carry it (small dictionaries) — what round 5 found for
+    // the compact form, without its staging pass (tests/test_iter_long_plan_cpu.py: sweep_records_lockstep_now).
     uint32_t k = 0, w = 0;                                             // the record to read, the next slot to write
     int32_t prev_e = INT32_MIN; uint32_t prev_len = 0;
     uint32_t path = 0;                                                 // 1: following a path
-    int32_t p = 0; uint32_t last_e = 0, last_i = 0, k_last = 0;
+    int32_t p = 0, limit = 0; uint32_t last_e = 0, last_i = 0, k_last = 0;
+    const uint32_t imask = small ? (1u << ACX_LONG_SMALL_BITS) - 1u : 0xFFFFFFu;
     if (n == 0u) return 0u;
     for (;;) {
         const uint32_t eor = k >= n ? 1u : 0u;                         // behind the last record
@@ -56,29 +60,31 @@ __device__ __forceinline__ uint32_t sweep_one(R rec, uint32_t n, int32_t r, int3
         const int32_t e = (int32_t)x.x;
         const uint32_t kind = x.y >> 30, len = (x.y >> 24) & 63u, idx = x.y & imask;
         const int32_t start = e - (int32_t)len + 1;
-        const uint32_t is_fe = kind == 2u ? 1u : 0u, is_ev = kind != 0u ? 1u : 0u;
+        const uint32_t now = kind >> 1, is_ev = kind != 0u ? 1u : 0u;
         // following a path: its end (the remembered record is reported, the records behind it are read again), a record of the path
-        const uint32_t p_end = path & (eor | (e > p + reach ? 1u : 0u));
+        const uint32_t p_end = path & (eor | (e > limit ? 1u : 0u));
         const uint32_t p_hit = path & (p_end ^ 1u) & is_ev & (start == p ? 1u : 0u);
-        const uint32_t p_fe = p_hit & is_fe, p_e = p_hit & (is_fe ^ 1u);
+        const uint32_t p_now = p_hit & now, p_e = p_hit & (now ^ 1u);
         // looking for a stop
         const uint32_t s_act = (path ^ 1u) & (eor ^ 1u);
         const uint32_t longer_in = (prev_e == e ? 1u : 0u) & (e - (int32_t)prev_len + 1 >= r ? 1u : 0u);    // a longer path ends here and starts at or behind r
         const uint32_t fires = s_act & is_ev & (start >= r ? 1u : 0u) & (longer_in ^ 1u);                     // (start >= r implies e >= r)
-        const uint32_t s_fe = fires & is_fe, s_e = fires & (is_fe ^ 1u);
-        const uint32_t emit = p_end | p_fe | s_fe;
+        const uint32_t s_now = fires & now, s_e = fires & (now ^ 1u);
+        const uint32_t emit = p_end | p_now | s_now;
         rec2_t out; out.x = p_end ? last_e : (uint32_t)e; out.y = p_end ? last_i : idx;
         if (emit) rec.put(w, out);                                      // (w <= the record being read or remembered: never ahead of one still to be read)
         w += emit;
         r = emit ? (int32_t)out.x + 1 : r;
         const uint32_t keep = p_e | s_e;                                // remember this record
         last_e = keep ? (uint32_t)e : last_e; last_i = keep ? idx : last_i;
+        const int32_t lim_new = small ? e + (int32_t)((x.y >> ACX_LONG_SMALL_BITS) & 63u) : start + reach;   // (below <= longest - length: never beyond p + reach)
+        limit = keep ? lim_new : limit;
         const uint32_t k_next = p_end ? k_last + 1u : k + 1u;
         k_last = keep ? k : k_last;
         p = s_e ? start : p;
-        const uint32_t seen = s_act | p_fe;                             // this record is the one "in front" of the next
+        const uint32_t seen = s_act | p_now;                            // this record is the one "in front" of the next
         prev_e = p_end ? INT32_MIN : (seen ? e : prev_e); prev_len = seen ? len : prev_len;
-        path = (path & (p_end ^ 1u) & (p_fe ^ 1u)) | s_e;
+        path = (path & (p_end ^ 1u) & (p_now ^ 1u)) | s_e;
         k = k_next;
     }
     return w;
@@ -204,7 +210,7 @@ __global__ void __launch_bounds__(64) k_long_sweep(const acx_long_args a) {
             uint32_t c = 0;
             if (e == done) {
                 // the haystack of lane `done` alone has more records than LDS takes: in place, in global memory, raw records
-                if (lane == done) c = sweep_one(GlobalRecs{(rec2_t*)a.rec + lo}, nrec, r0, reach, small ? (1u << ACX_LONG_SMALL_BITS) - 1u : 0xFFFFFFu);
+                if (lane == done) c = sweep_one(GlobalRecs{(rec2_t*)a.rec + lo}, nrec, r0, reach, small);
                 const uint32_t cc = (uint32_t)__shfl((int)c, done, 64), src_rel = (uint32_t)__shfl((int)lo_rel, done, 64);
                 long_wave_sync();
                 if (src_rel != P) {                                     // down to the group's packed place: 64 at a time, read before written
@@ -276,6 +282,87 @@ __global__ void __launch_bounds__(64) k_long_sweep(const acx_long_args a) {
             if (mine) {
                 uint2* dst = a.rec + base + P + (ci - c);
                 if (!(ACX_LONG_EXP & 2)) for (uint32_t i = 0; i < c; i++) dst[i] = L->a[cf + i];
+                if (valid) a.counts[h] = (int32_t)c;
+            }
+            P += tot; done = e;
+            long_wave_sync();
+        }
+    }
+}
+
+// ---- the sweep over RAW records in LDS (round 4's kernel, round 6: with `now` and `below` in sweep_one) ------------------------------------
+// Staging is a copy — eight loads in flight per lane, record i of the batch at slot i + i / 16: the lanes of a wave stand about sixteen
+// records apart (128 bytes: one bank for all of them), the skew spreads them over the banks —, four waves per block, 10 KiB each.
+// Against the compact form: a trip per U record more (a few per haystack), no ballots, prefix counts and bit tables in the staging pass.
+typedef __attribute__((address_space(3))) rec2_t lds_rec2_t;
+struct LdsRecs {
+    lds_rec2_t* p; uint32_t first;                                      // the haystack's first record, counted from the batch's first in LDS
+    __device__ static uint32_t slot(uint32_t i) { return i + (i >> 4); }
+    __device__ rec2_t get(uint32_t k) const { return p[slot(first + k)]; }
+    __device__ void put(uint32_t k, rec2_t v) const { p[slot(first + k)] = v; }
+};
+#ifndef ACX_LONG_CAP
+#define ACX_LONG_CAP 1200
+#endif
+constexpr uint32_t LONG_CAP = ACX_LONG_CAP;                                   // records per wave in LDS (10 KiB with the skew; four waves per block, four blocks per CU)
+__global__ void __launch_bounds__(256) k_long_sweep_raw(const acx_long_args a) {
+    __shared__ uint2 s_rec[4][LONG_CAP + LONG_CAP / 16 + 1];
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    uint2* const sw = s_rec[wid];
+    const int64_t n_groups = (a.n_hay + 63) / 64, n_waves = (int64_t)gridDim.x * 4;
+    const int32_t reach = (int32_t)a.longest - 1;
+    const bool small = a.n_real < ((int64_t)1 << ACX_LONG_SMALL_BITS);
+    if (a.off[a.n_hay] > a.rec_capacity) return;                       // (the scan in front is incomplete: see acx_long_args)
+    for (int64_t g = (int64_t)blockIdx.x * 4 + wid; g < n_groups; g += n_waves) {
+        const int64_t h = g * 64 + lane;
+        const bool valid = h < a.n_hay;
+        const int64_t lo = a.off[valid ? h : a.n_hay], hi = valid ? a.off[h + 1] : lo;
+        const int64_t base = a.off[g * 64];
+        const uint32_t nrec = (uint32_t)(hi - lo);
+        const uint32_t lo_rel = (uint32_t)(lo - base);                  // (a group's records: fewer than 2^32)
+        const int32_t r0 = (valid && a.index_base) ? a.index_base[h] : 0;
+        const uint32_t incl = wave_incl_scan_u32(nrec, lane);
+        uint32_t P = 0;                                                 // reported records of the group so far
+        int done = 0;                                                   // lanes done
+        while (done < 64) {
+            const uint32_t start = done ? (uint32_t)__shfl((int)incl, done - 1, 64) : 0u;
+            const bool fits = lane >= done && incl - start <= LONG_CAP;
+            const int e = done + (int)__popcll(__ballot(fits));
+            uint32_t c = 0;
+            if (e == done) {
+                // the haystack of lane `done` alone has more records than LDS takes: in place, in global memory
+                if (lane == done) c = sweep_one(GlobalRecs{(rec2_t*)a.rec + lo}, nrec, r0, reach, small);
+                const uint32_t cc = (uint32_t)__shfl((int)c, done, 64), src_rel = (uint32_t)__shfl((int)lo_rel, done, 64);
+                long_wave_sync();
+                if (src_rel != P) {                                     // down to the group's packed place: 64 at a time, read before written
+                    for (uint32_t i0 = 0; i0 < cc; i0 += 64) {
+                        uint2 v = make_uint2(0, 0);
+                        if (i0 + lane < cc) v = a.rec[base + src_rel + i0 + lane];
+                        long_wave_sync();
+                        if (i0 + lane < cc) a.rec[base + P + i0 + lane] = v;
+                        long_wave_sync();
+                    }
+                }
+                if (lane == done && valid) a.counts[h] = (int32_t)c;
+                P += cc; done++;
+                continue;
+            }
+            const uint32_t sub_n = (uint32_t)__shfl((int)incl, e - 1, 64) - start;
+            // (eight loads in flight per lane: a load waited for before the next is issued is a round trip to memory per 64 records)
+            for (uint32_t i0 = 0; i0 < sub_n; i0 += 512u) {
+                uint2 v[8];
+#pragma unroll
+                for (int j = 0; j < 8; j++) { const uint32_t i = i0 + 64u * (uint32_t)j + (uint32_t)lane; v[j] = i < sub_n ? a.rec[base + start + i] : make_uint2(0u, 0u); }
+#pragma unroll
+                for (int j = 0; j < 8; j++) { const uint32_t i = i0 + 64u * (uint32_t)j + (uint32_t)lane; if (i < sub_n) sw[LdsRecs::slot(i)] = v[j]; }
+            }
+            long_wave_sync();
+            const bool mine = lane >= done && lane < e;
+            if (mine) c = sweep_one(LdsRecs{(lds_rec2_t*)sw, lo_rel - start}, nrec, r0, reach, small);
+            const uint32_t ci = wave_incl_scan_u32(c, lane), tot = (uint32_t)__shfl((int)ci, 63, 64);
+            if (mine) {
+                uint2* dst = a.rec + base + P + (ci - c);
+                for (uint32_t i = 0; i < c; i++) dst[i] = sw[LdsRecs::slot(lo_rel - start + i)];
                 if (valid) a.counts[h] = (int32_t)c;
             }
             P += tot; done = e;
@@ -487,6 +574,14 @@ __global__ void __launch_bounds__(256) k_long_move_waves(const acx_ppm_gather_ar
 }  // namespace
 
 hipError_t acx_launch_long_sweep(const acx_long_args& a, hipStream_t s) {
+    if (!a.compact) {
+        int64_t blocks = ((a.n_hay + 63) / 64 + 3) / 4;
+        const int64_t cap = (int64_t)acx_num_cus() * 12;
+        if (blocks > cap) blocks = cap;
+        if (blocks < 1) blocks = 1;
+        hipLaunchKernelGGL(k_long_sweep_raw, dim3((unsigned)blocks), dim3(256), 0, s, a);
+        return hipGetLastError();
+    }
     int64_t blocks = (a.n_hay + 63) / 64;
     const int64_t cap = (int64_t)acx_num_cus() * 40;
     if (blocks > cap) blocks = cap;
@@ -521,3 +616,4 @@ hipError_t acx_launch_long_move_waves(const acx_ppm_gather_args& c, const acx_lo
     hipLaunchKernelGGL(k_long_move_waves, dim3((unsigned)blocks), dim3(256), 0, s, c, f, new_off, real, dst);
     return hipGetLastError();
 }
+

@@ -302,6 +302,60 @@ def sweep_records_lockstep(ends, vals, reals, longest, base=0):
     return out
 
 
+def sweep_records_lockstep_now(ends, vals, reals, longest, base=0, small=True):
+    """round 6: the RAW lock-step sweep (sweep_one of acx_long.hip, statement by statement) with what round 5 found for the compact
+    form: kinds 2 (FE) and 3 (an E node with nothing below it) are reported the moment they fire (`now`), a remembered E's path is
+    followed for `below` letters (bits 18-23 of the value) when the dictionary is small, else for longest - 1.  No staging pass beyond a
+    copy: the record in front travels in registers, U records cost a trip each"""
+    INT_MIN = -(1 << 31)
+    imask = (1 << 18) - 1 if small else 0xFFFFFF
+    if not small:
+        vals = [v & ~(63 << 18) for v in vals]
+    out, r, k, w, n = [], base, 0, 0, len(ends)
+    prev_e, prev_len = INT_MIN, 0
+    path, p, last_e, last_i, k_last, limit = 0, 0, 0, 0, 0, 0
+    reach = longest - 1
+    if n == 0:
+        return out
+    while True:
+        eor = 1 if k >= n else 0
+        if eor & (path ^ 1):
+            break
+        kk = n - 1 if eor else k
+        e, v = ends[kk], vals[kk] & 0xFFFFFFFF
+        kind, ln, idx = v >> 30, (v >> 24) & 63, v & imask
+        start = e - ln + 1
+        now, is_ev = kind >> 1, int(kind != 0)
+        p_end = path & (eor | int(e > limit))
+        p_hit = path & (p_end ^ 1) & is_ev & int(start == p)
+        p_now, p_e = p_hit & now, p_hit & (now ^ 1)
+        s_act = (path ^ 1) & (eor ^ 1)
+        longer_in = int(prev_e == e) & int(e - prev_len + 1 >= r)
+        fires = s_act & is_ev & int(start >= r) & (longer_in ^ 1)
+        s_now, s_e = fires & now, fires & (now ^ 1)
+        emit = p_end | p_now | s_now
+        ox, oy = (last_e, last_i) if p_end else (e, idx)
+        if emit:
+            out.append((ox, reals[oy])); assert w <= kk
+        w += emit
+        r = ox + 1 if emit else r
+        keep = p_e | s_e
+        if keep:
+            last_e, last_i = e, idx
+            limit = e + ((v >> 18) & 63) if small else start + reach
+        k_next = k_last + 1 if p_end else k + 1
+        if keep:
+            k_last = k
+        if s_e:
+            p = start
+        seen = s_act | p_now
+        prev_e = INT_MIN if p_end else (e if seen else prev_e)
+        prev_len = ln if seen else prev_len
+        path = (path & (p_end ^ 1) & (p_now ^ 1)) | s_e
+        k = k_next
+    return out
+
+
 def sweep_records_compact(ends, vals, reals, longest, base=0, small=True):
     """the sweep as k_long_sweep runs it since round 5 (acx_long.hip): the staging pass turns the raw records into compact ones —
     U records dropped, {start, up_start, value} kept for the E / FE records — and sweep_compact, statement by statement: a record
@@ -389,6 +443,9 @@ def _check_product_dictionary(keys, hays, values=None):
         assert sweep_records_compact([e for e, _ in recs], [v for _, v in recs], reals, longest) == got, (keys, h)
         assert sweep_records_compact([e + 77 for e, _ in recs], [v for _, v in recs], reals, longest, base=77) == [(e + 77, v) for e, v in got], (keys, h)
         assert sweep_records_compact([e for e, _ in recs], [v for _, v in recs], reals, longest, small=False) == got, (keys, h)
+        assert sweep_records_lockstep_now([e for e, _ in recs], [v for _, v in recs], reals, longest) == got, (keys, h)
+        assert sweep_records_lockstep_now([e for e, _ in recs], [v for _, v in recs], reals, longest, small=False) == got, (keys, h)
+        assert sweep_records_lockstep_now([e + 77 for e, _ in recs], [v for _, v in recs], reals, longest, base=77) == [(e + 77, v) for e, v in got], (keys, h)
         got = sweep_records([e + 77 for e, _ in recs], [v for _, v in recs], reals, longest, base=77)      # index_base
         assert got == [(e + 77, v) for e, v in O.iter_long(h)], (keys, h)
 

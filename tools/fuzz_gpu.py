@@ -79,7 +79,7 @@ def one_case(rng, trial):
     lo, le, lv = O.batch(flat.tobytes(), off, 1)                    # iter_long
     # the position-parallel form (where it applies: else the serial walk answers) synchronous and asynchronous, the sweep straight from the
     # record pool (variant bit 26), the serial walk (bit 25)
-    for variant, asyn in ((0, False), (0, True), (1 << 26, False), (1 << 26, True), (1 << 25, False)):
+    for variant, asyn in ((0, False), (0, True), (1 << 27, False), (1 << 27, True), (1 << 26, False), (1 << 26, True), (1 << 25, False)):
         sc = Scanner(img)
         sc.scan(d_hay, n * L, n, stride=L, mode=ACX_SCAN_LONG, variant=variant, asynchronous=asyn)
         moff, e, v, _ = sc.fetch()
