@@ -361,6 +361,62 @@ def test_config5_iter_long_full_size(config2):
             assert got == list(R.iter_long(reads[h].tobytes())), h
 
 
+@pytest.mark.slow
+def test_c2_offsets_full_size_every_record(config2):
+    """bench.py's `c2_offsets` workload — config 2's reads cut to ragged lengths U[100, 150], back to back, delivered by offsets: the
+    GENERAL stream kernel's offsets form (k_ppm_stream<2,8,..,OFFS>, haystack starts through the queue, k_ppm_wave_scan + k_ppm_gather) —
+    at full size, every offset and every record against the oracle (VERDICT r5 missing 6: it was only count-checked against its own
+    pre-pass)"""
+    keys, reads, A, img, d_hay = config2
+    n, L = reads.shape
+    lens = np.random.default_rng(1001).integers(100, L + 1, size=n, dtype=np.int64)       # (bench.make_batches, batch 0: seed 1000 + 1)
+    keep = np.arange(L, dtype=np.int64)[None, :] < lens[:, None]
+    flat = np.ascontiguousarray(reads[keep])
+    off = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+    d_flat = DeviceBuffer.from_numpy(flat, pad=64)
+    d_off = DeviceBuffer.from_numpy(off)
+    plan = img.ppm_kernel(stride=0, has_offsets=True, dev_hay=d_flat.ptr.value, n_hay=n, min_hay_len=100)
+    assert plan == "stream", plan
+    sc = Scanner(img)
+    total = sc.scan(d_flat, len(flat), n, dev_off=d_off, min_hay_len=100)
+    moff, e, v, _ = sc.fetch()
+    O = orc.Oracle()
+    for i, k in enumerate(keys):
+        O.add_word(k, i)
+    O.make_automaton()
+    mo, oe, ov = O.batch_records(flat, off, 0)
+    assert total == mo[-1] and total > 7_000_000
+    assert np.array_equal(moff, mo) and np.array_equal(e, oe) and np.array_equal(v, ov)
+
+
+@pytest.mark.slow
+def test_c2_long_keys_full_size_every_record():
+    """bench.py's `c2_long_keys` workload — 100 k ACGT keys of 8-64 letters (beyond k_ppm_stream4's 33), 1 M x 150 B reads: the general
+    stream kernel's fixed-stride form with 24-bit positions (k_ppm_stream<2,8,true,false,false,true,true,6>) — every offset and every
+    record against the oracle"""
+    from pyahocorasick_amd.workloads import dna_keys, dna_reads
+    keys = dna_keys(100_000, seed=0, klo=8, khi=64)
+    reads = dna_reads(keys, 1_000_000, 150, seed=1)
+    A = acx.Automaton(acx.STORE_INTS)
+    A.add_words(keys, range(len(keys)))
+    A.make_automaton()
+    img = Image.from_automaton(A)
+    n, L = reads.shape
+    d_hay = DeviceBuffer.from_numpy(reads.reshape(-1), pad=64)
+    plan = img.ppm_kernel(stride=L, has_offsets=False, dev_hay=d_hay.ptr.value, n_hay=n)
+    assert plan == "stream", plan                                   # (keys beyond 33 letters: not k_ppm_stream4's)
+    sc = Scanner(img)
+    total = sc.scan(d_hay, n * L, n, stride=L)
+    moff, e, v, _ = sc.fetch()
+    O = orc.Oracle()
+    for i, k in enumerate(keys):
+        O.add_word(k, i)
+    O.make_automaton()
+    mo, oe, ov = O.batch_records(reads.reshape(-1), np.arange(n + 1, dtype=np.int64) * L, 0)
+    assert total == mo[-1] and total > 3_000_000
+    assert np.array_equal(moff, mo) and np.array_equal(e, oe) and np.array_equal(v, ov)
+
+
 def test_iter_long_rows_in_lds_vs_plain_vs_oracle():
     """iter_long on a batch that fills the chip keeps the rows of the shallowest states in LDS (k_walk_long<.., true>);
     variant bit 21 takes the plain kernel.  Both against the oracle, record for record: fixed stride with carried-in
