@@ -430,6 +430,7 @@ def make_batches(torch, dev, workload, keys, vocab, n_batches, reads, read_len, 
 
 
 SCAN_STREAMS = 3
+_SCAN_STREAMS = []                      # the process's extra scan streams (measure())
 MIN_TIMED_MS = 250.0
 
 
@@ -448,7 +449,14 @@ def measure(torch, dist, dev, image, batches, mode, steps, warmup, P, event_ever
     #  round 5: scan kernel on the caller's stream, gather and sweep behind it on a side stream; the serial walk, many small blocks
     #  that share every CU, lost 2 % on two streams)
     n_streams = min(SCAN_STREAMS, P)
-    extra = [torch.cuda.Stream() for _ in range(max(0, n_streams - 1))]
+    # The scan streams are made ONCE per process and shared by every configuration it measures: which hardware queue a stream gets depends on
+    # the order in which the process made its streams, and a configuration whose gather overlaps its scans for most of a step is sensitive to
+    # WHICH queues its streams share — `c2_long_keys` ran at 607 / 646 / 703 GB/s behind the headline alone / in a process of its own / behind
+    # `c2_offsets` while every measure() made two streams of its own (round 6).  Shared streams: the line's entries are what a process of their
+    # own gives (tools/roofline_check.py compares them with traces of exactly that).
+    while len(_SCAN_STREAMS) < max(0, n_streams - 1):
+        _SCAN_STREAMS.append(torch.cuda.Stream())
+    extra = _SCAN_STREAMS[:max(0, n_streams - 1)]
     streams = [stream] + [x.cuda_stream for x in extra]     # slot k % P scans on stream (k % P) % len(streams)
 
     def step(k, timing=False):
@@ -713,7 +721,9 @@ def other_config(torch, dev, acx, name, workload, mode_name, keys, vocab, image,
         del A
     t0 = time.perf_counter()
     if batches is None:
-        batches, host0, _, _ = make_batches(torch, dev, workload, keys, vocab, 2, args.reads, args.read_len, batch_mb, 0, 1, False)
+        # (config 2's shapes rotate over FOUR batches as the headline does: two offsets batches are 250 MB — what the 256 MiB Infinity Cache
+        #  holds — and `c2_offsets` ran 5 % faster in the line than in a process of its own, which stages four; 512 MiB batches: two)
+        batches, host0, _, _ = make_batches(torch, dev, workload, keys, vocab, 4 if workload.startswith("c2") else 2, args.reads, args.read_len, batch_mb, 0, 1, False)
     t_stage = time.perf_counter() - t0
     mode = acx.ACX_SCAN_ALL if mode_name == "iter" else acx.ACX_SCAN_LONG
     steps = max(8, min(args.steps, 20))

@@ -829,6 +829,10 @@ __global__ void __launch_bounds__(ACX_PPM_BLOCK) k_ppm_stream(const acx_ppm_args
             // (one that is done re-reads record 0).
             uint32_t n_deep;
             const uint32_t d_base = wave_excl_scan(n_go, n_deep);
+#ifdef ACX_PPM_DEV
+            if (a.dbg & 32u) n_deep = 0;                                  // timing / traffic only: no deeper walks
+            if (a.dbg & 64u) { _Pragma("unroll") for (int e = 0; e < NE; e++) hc[e] = *(const u32x2*)((const uint8_t*)a.hot + ((code_n(XX[e], Cn) & 7u) << 3)); }   // (traffic only: the hot cells once more, from one line)
+#endif
             uint32_t* const dq = (uint32_t*)queue;                       // [0..127]: {staged position | L << 12, id} -> {first, second value}; then 64 counts
             uint16_t* const dcnt = (uint16_t*)(dq + 130);              // (dq[128..129]: the dump slot)
             for (uint32_t d0 = 0; d0 < n_deep; d0 += 64u) {
@@ -1442,6 +1446,9 @@ hipError_t acx_launch_ppm_scan(const acx_ppm_args& a, int64_t n_items_bound, hip
         if (a.nsub != 8 && a.nsub != 4) return hipErrorInvalidValue;
 #ifdef ACX_PPM_DEV      /* development builds: the config-2 kernel only (compile time) */
         if (a.sym_bits == 2 && a.nsub == 8 && ar && !offs && a.m24) return launch(k_ppm_stream<2, 8, true, false, false, true, true, ACX_PPM_NE>);
+#ifdef ACX_PPM_DEV_C4   /* ... and config 4's (a million signatures, offsets batch, global filter + its hashed copy) */
+        if (a.sym_bits == 8 && a.g_global && a.nsub == 4 && offs && p2) return launch(k_ppm_stream<8, 4, true, true, true, false, false, 4>);
+#endif
         return hipErrorInvalidValue;
 #else
         if (a.sym_bits == 8) {

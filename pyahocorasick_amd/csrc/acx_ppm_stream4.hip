@@ -8,7 +8,8 @@
 // k_ppm_stream).  What is different, and why (profiles/r4_*): the kernel is bound by instruction issue — every
 // instruction of every kind costs its SIMD an issue slot — so
 //   * the geometry is constant: C, F, the halo, the LDS layout (2 KiB per wave, so that an LDS address is an OR) and
-//     the tile size are compile-time numbers, the kernel reads a dozen arguments instead of fifty (no SGPR spills);
+//     the tile size are compile-time numbers, the kernel reads a dozen arguments instead of fifty (16-18 SGPRs still spill to lanes
+//     of a VGPR: derived scalars, read back mostly on rare paths — tools/resource_usage.py);
 //   * the hot cell is `hot4` (include/acx_blob.h): its second word is the VALUE of the shallowest key that ends here —
 //     what nearly every candidate that is no false alarm needs — and the id of the depth-C node only where no key
 //     ends; one 16-bit field says "go deeper" for the next two symbols.  The top level of a slot is a dozen
@@ -17,6 +18,8 @@
 //     are all one add away from;
 //   * the haystack of a tile is staged by straight-line code (whole tiles: two 16-byte loads per lane, no bounds
 //     checks; the last tile of a batch: a copy of the loop body that checks).
+//   * round 6: the waits for loads are where the loads are needed (profiles/r6_s4_issue_budget.md §3: the compiler's placement had put them
+//     behind the record stores and in front of the filter), the filter's neighbour word comes over the DPP network.
 // Integer only, no MFMA: there is no contraction on this path.
 #include "acx_kernels.h"
 #include "acx_ppm_layout.h"

@@ -12,7 +12,7 @@ sys.path.insert(0, os.path.join(ROOT, "tools"))
 
 
 def _line():
-    return json.loads(open(os.path.join(ROOT, "profiles", "r5_bench.json")).read().strip().splitlines()[-1])
+    return json.loads(open(os.path.join(ROOT, "profiles", "r6_bench.json")).read().strip().splitlines()[-1])
 
 
 def test_union_of_spans():
@@ -23,9 +23,9 @@ def test_union_of_spans():
 
 
 def test_committed_line_is_inside_what_the_committed_traces_support():
-    spans = sorted(glob.glob(os.path.join(ROOT, "profiles", "r5_c*_spans.json")))
+    spans = sorted(glob.glob(os.path.join(ROOT, "profiles", "r6_c*_spans.json")))
     assert len(spans) == 6
-    p = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "roofline_check.py"), "check", os.path.join(ROOT, "profiles", "r5_bench.json"), *spans],
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "roofline_check.py"), "check", os.path.join(ROOT, "profiles", "r6_bench.json"), *spans],
                        stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=120)
     out = p.stdout.decode()
     assert p.returncode == 0, out
@@ -49,6 +49,27 @@ def test_committed_line_keeps_the_bench_contract():
     assert set(d["configs"]) == {"c5_iter_long", "c2_offsets", "c2_long_keys", "c3", "c4"}
     for name, v in d["configs"].items():
         assert v["value"] > 100 and 0 < v["roofline"]["frac"] < 1 and "cpu_baseline" in v, name
+
+
+def test_the_drivers_line_fits_the_tail_the_driver_keeps():
+    """the driver keeps an 8 KB tail of the output and, in `parsed`, the headline's `config` / `roofline` / `cpu_baseline`:
+    the committed line (the default command's, as the driver runs it) is below 7000 characters, `config.all` names all six configurations
+    with [GB/s, roofline.frac], and compacting the FULL object of the same run gives a line of the same shape"""
+    raw = open(os.path.join(ROOT, "profiles", "r6_bench.json")).read().strip().splitlines()[-1]
+    assert len(raw) < 7000, len(raw)
+    d = json.loads(raw)
+    assert set(d["config"]["all"]) == {"headline", "c5_iter_long", "c2_offsets", "c2_long_keys", "c3", "c4"}
+    for name, (gbps, frac) in d["config"]["all"].items():
+        ent = d if name == "headline" else d["configs"][name]
+        assert abs(gbps - ent["value"]) < 0.06 and abs(frac - ent["roofline"]["frac"]) < 6e-5, name
+    q = d["config"]["queues"]
+    assert q["scan_streams"] == 3 and q["results_in_flight"] == 3 and q["side_streams"] == 3 and q["GPU_MAX_HW_QUEUES"] == "8"
+    sys.path.insert(0, ROOT)
+    import bench
+    full = json.loads(open(os.path.join(ROOT, "profiles", "r6_bench_full.json")).read().strip().splitlines()[-1])
+    again = json.dumps(bench.compact_line(full), separators=(",", ":"))
+    assert len(again) < 7000 and json.loads(again)["config"]["all"] == d["config"]["all"]
+    assert len(json.dumps(full)) > 12000                      # (what the line was before: beyond the driver's tail)
 
 
 def test_traffic_entries_belong_to_the_kernel_sources_in_the_tree():

@@ -5,7 +5,7 @@
 #     the dominant kernel's launch spans per launch over the timed region: with two scan streams launches overlap);
 #   * optionally (PMC=1) four counter passes per configuration on tools/microbench.py (counters only, separate runs) ->
 #     <TAG>_<cfg>_pmc_summary.json; CALIB=1: the same counters on tools/fetch_calib.bin (known byte counts).
-# usage: [PMC=1] [CALIB=1] tools/r5_profiles.sh TAG [cfg ...]     cfg in: c2 c5 c2o c2k c3 c4
+# usage: [PMC=1] [CALIB=1] [NOSTATS=1] tools/r5_profiles.sh TAG [cfg ...]     cfg in: c2 c5 c2o c2k c3 c4   (NOSTATS: the counter passes only)
 cd "${GRAFT_REPO_ROOT:-/root/repo}"; export TMPDIR=/tmp; R=$(pwd); OUT=$R/gpurun_out; mkdir -p $OUT
 TAG=${1:-r5}; shift
 CFGS=${@:-c2 c5 c2o c2k c3 c4}
@@ -30,12 +30,14 @@ for CFG in $CFGS; do
     c4)  BARGS="--configs none --workload c4 --steps 12"; MARGS="--alphabet snort --keys 1000000 --bytes 536870912"; NAME=c4; KEY=c4_iter; KERNEL=k_ppm_stream; HB=536870912;;
   esac
   T=${TAG}_${CFG}
+  if [ -z "$NOSTATS" ]; then
   echo "== $CFG: rocprofv3 --kernel-trace --stats -- python bench.py $BARGS --cpu-sample-reads 0 --no-e2e"
   (cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats -d $OUT/${T}_prof -o stats -- python $R/bench.py $BARGS --cpu-sample-reads 0 --no-e2e > $OUT/${T}_prof_bench.json 2> $OUT/${T}_prof.err; echo "rocprof rc=$?")
   DB=$(find $OUT/${T}_prof -name "*.db" | head -1)
   python tools/rocpd_summary.py $DB $OUT/${T}_kernel_stats "rocprofv3 --kernel-trace --stats -- python bench.py $BARGS --cpu-sample-reads 0 --no-e2e" > /dev/null 2>&1 && head -9 $OUT/${T}_kernel_stats.md | tail -4
   python tools/roofline_check.py export $DB $OUT/${T}_prof_bench.json $OUT/${T}_spans.json $NAME
   rm -rf $OUT/${T}_prof
+  fi
   if [ -n "$PMC" ] && [ "$CFG" != "c2o" ] && [ "$CFG" != "c2k" ]; then
     i=0
     for C in "${CTRS[@]}"; do

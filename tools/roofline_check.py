@@ -53,7 +53,9 @@ def union_us(spans):
 
 def export(db, bench_path, out_path, config=None):
     line = _last_json_line(bench_path)
-    ent = line                                                # (the profiled command runs this configuration alone: its line's top level)
+    # (the profiled command runs this configuration alone — its line's top level — or, round 6, behind the headline in ONE process as the
+    #  driver's command does: `--configs <name>`, its entry of `configs`; its launches are the trace's last then)
+    ent = line["configs"][config] if (config and config in (line.get("configs") or {})) else line
     kernel = ent["roofline"]["kernel"]
     passes = int(ent.get("passes") or ent["steps"] * ent.get("inner_repeats", 1))
     c = sqlite3.connect(db)
@@ -87,6 +89,50 @@ def export(db, bench_path, out_path, config=None):
     }
     json.dump(out, open(out_path, "w"), indent=1)
     print(json.dumps({k: out[k] for k in ("config", "kernel", "timed_launches", "avg_span_us_timed", "union_per_launch_us", "overlapping")}))
+
+
+# round 6: ONE trace of the driver's own command holds every configuration — their dominant kernels are different instantiations
+SIGNATURES = {
+    "headline": "k_ppm_stream4<false>", "c5_iter_long": "k_ppm_stream4<true>",
+    "c2_offsets": "k_ppm_stream<2, 8, true, true, false, true, false, 6>", "c2_long_keys": "k_ppm_stream<2, 8, true, false, false, true, true, 6>",
+    "c3": "k_ppm_stream<8, 8, false, true, false, false, false, 4>", "c4": "k_ppm_stream<8, 4, true, true, true, false, false, 4>",
+}
+UNION_LEG_LAUNCHES = 36          # bench.py measure(): 12 x P launches with event pairs BEHIND every timed region (P = 3 results in flight)
+
+
+def export_all(db, bench_path, out_prefix):
+    """spans of every configuration of the line from a rocprofv3 --kernel-trace of `python bench.py --no-e2e --cpu-sample-reads 0` (the
+    driver's command without its CPU and host-to-host legs): the timed launches of a configuration are the last `passes` launches of ITS
+    instantiation in front of the union leg's."""
+    line = _last_json_line(bench_path)
+    c = sqlite3.connect(db)
+    names = [r[0] for r in c.execute("select name from sqlite_master where type in ('table','view')")]
+    src = "kernels" if "kernels" in names else next(n for n in names if "kernel_dispatch" in n)
+    cols = [r[1] for r in c.execute("pragma table_info(%s)" % src)]
+    name_col = "name" if "name" in cols else next(x for x in cols if "name" in x)
+    rows = c.execute("select %s, start, end from %s order by start" % (name_col, src)).fetchall()
+    for config, sig in SIGNATURES.items():
+        ent = line if config == "headline" else (line.get("configs") or {}).get(config)
+        if not ent or "roofline" not in ent:
+            continue
+        mine = [(s, e) for n, s, e in rows if sig in n]
+        if not mine:
+            print("%s: no launches of %s" % (config, sig)); continue
+        passes = int(ent.get("passes") or ent["steps"] * ent.get("inner_repeats", 1))
+        tail = UNION_LEG_LAUNCHES if len(mine) >= passes + UNION_LEG_LAUNCHES else 0
+        timed = mine[-(passes + tail):len(mine) - tail] if len(mine) >= passes + tail else mine
+        out = {
+            "config": config, "kernel": ent["roofline"]["kernel"], "instantiation": sig, "launches_in_trace": len(mine), "timed_launches": len(timed),
+            "avg_span_us_timed": sum(e - s for s, e in timed) / len(timed) / 1e3,
+            "union_us_timed": union_us(timed), "union_per_launch_us": union_us(timed) / len(timed),
+            "timed_region_us": (max(e for _, e in timed) - min(s for s, _ in timed)) / 1e3,
+            "overlapping": any(timed[k + 1][0] < timed[k][1] for k in range(len(timed) - 1)),
+            "bench_line_of_the_profiled_run": {"value": ent["value"], "ms_per_step": ent["ms_per_step"], "frac": ent["roofline"]["frac"],
+                                               "algorithmic_bytes": ent["roofline"]["algorithmic_bytes"]},
+            "source": "rocprofv3 --kernel-trace --stats of `python bench.py --no-e2e --cpu-sample-reads 0`: ALL configurations in one process, as the driver runs them (tools/r6_trace_all.sh)",
+        }
+        json.dump(out, open("%s_%s_spans.json" % (out_prefix, {"headline": "c2", "c5_iter_long": "c5", "c2_offsets": "c2o", "c2_long_keys": "c2k"}.get(config, config)), "w"), indent=1)
+        print(json.dumps({k: out[k] for k in ("config", "timed_launches", "avg_span_us_timed", "union_per_launch_us", "timed_region_us")}))
 
 
 def check(bench_path, span_paths, tol=0.05):
@@ -126,6 +172,8 @@ def check(bench_path, span_paths, tol=0.05):
 if __name__ == "__main__":
     if len(sys.argv) >= 5 and sys.argv[1] == "export":
         export(sys.argv[2], sys.argv[3], sys.argv[4], sys.argv[5] if len(sys.argv) > 5 else None)
+    elif len(sys.argv) >= 5 and sys.argv[1] == "export_all":
+        export_all(sys.argv[2], sys.argv[3], sys.argv[4])
     elif len(sys.argv) >= 4 and sys.argv[1] == "check":
         args = [a for a in sys.argv[2:] if not a.startswith("--tol")]
         tol = next((float(a.split("=")[1]) for a in sys.argv[2:] if a.startswith("--tol=")), 0.05)
