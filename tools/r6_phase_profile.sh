@@ -4,7 +4,7 @@
 #   tools/r6_phase_profile.sh build            (here: build/variants/libacx_tseg_<a>_<b>.so)
 #   tools/r6_phase_profile.sh run [TAG]        (GPU box: gpurun_out/<TAG>_phase_profile.txt)
 cd "${GRAFT_REPO_ROOT:-$(dirname "$0")/..}"
-SEGS="6_9 9_11 11_12 12_7 6_7 7_8"
+SEGS=${SEGS:-"0_1 1_2 2_3 3_4 4_5 5_6 6_7 7_8 8_9 9_10 0_10"}
 FL="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -fvisibility=hidden -fvisibility-inlines-hidden -w -mcode-object-version=5 -Iinclude -Ipyahocorasick_amd/csrc"
 if [ "$1" == "build" ]; then
   set -e
