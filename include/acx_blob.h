@@ -76,7 +76,7 @@
 #define ACX_ITOP_FLAG_TFLAGS_ID 2u
 
 #define ACX_BLOB_MAGIC        0x31424F4C42584341ull   /* "ACXBLOB1" */
-#define ACX_BLOB_VERSION      3u          /* 3: the "PPM4" section (PPM3 + hot4 / cid for four-letter alphabets); 2: the checksum below, "PPM3" */
+#define ACX_BLOB_VERSION      4u          /* 4: "PPM5" (deep records of up to 48 / sym_bits symbols); 3: the "PPM4" section (PPM3 + hot4 / cid for four-letter alphabets); 2: the checksum below, "PPM3" */
 #define ACX_BLOB_HEADER_BYTES 256u
 #define ACX_BLOB_ALIGN        256u
 
@@ -205,16 +205,17 @@ typedef struct acx_blob_header {
  *       window holds four 8-bit symbols, F2 = 5 takes one more from the symbol array).
  *   top_val[top_base[d] + code_d] (global): value of the key that is node (d, code_d), d <= C (the sixth key on).
  * Deeper: the walk stands on a node that has children and takes one 16-byte record per step
- *       { label, len | is_key << 8 | exists << 9, value, next id }
+ *       { label, len | is_key << 8 | exists << 9 | more label << 16, value, next id }
  *   a node with two or more children owns a ROW of K records (section `kids`; its id is the index of the row's first
  *   record, row number x K, so that the device adds the symbol and never multiplies), indexed by the next
  *   symbol; a node with exactly one child owns a SINGLE record (section `chains`; its id carries bit 31).  A record
  *   consumes 1 + len symbols (row) or len symbols (single): it follows the unbranched, key-free path below its first
- *   edge for up to 32 / sym_bits symbols (label: their symbols, first one in the top bits); `next` is the id of the
- *   node it ends on if that node has children.
+ *   edge for up to 48 / sym_bits symbols (label: the first 32 / sym_bits of them, first one in the top bits; the top half
+ *   of the second word: the 16 / sym_bits behind those, the same way); `next` is the id of the node it ends on if that
+ *   node has children.
  * All section offsets are relative to the start of the acx_ppm_header.
  */
-#define ACX_PPM_MAGIC 0x344D5050u   /* "PPM4" */
+#define ACX_PPM_MAGIC 0x354D5050u   /* "PPM5" */
 #define ACX_PPM_MAX_C 20
 /* gh: a filter that lives in global memory (g_global: 2^24 bits for three 8-bit symbols) costs one L2 request per position.
  * gh is a hashed copy of it that LDS can hold: bit acx_ppm_gh_index(code_F) is set for every code whose bit of G is set, so a

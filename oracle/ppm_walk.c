@@ -100,9 +100,15 @@ int64_t ppm_iter_fill(const uint8_t* blob, const uint8_t* hay, int64_t len, int3
                 if (!(rec[1] & 0x200u)) break;          /* no child on this symbol */
                 const uint32_t len = rec[1] & 0xFFu;
                 if (L < d + (int64_t)first + len) break;
-                uint32_t label = 0;
-                for (uint32_t i = 0; i < len; i++) label |= (uint32_t)symtab[hay[e - d - first - i]] << (32 - SB * (i + 1));
-                if (label != rec[0]) break;
+                /* the label: 32 / SB symbols in the first word, the next 16 / SB in the top half of the second (include/acx_blob.h) */
+                uint32_t label = 0, more = 0;
+                const uint32_t ms = 32u / SB;
+                for (uint32_t i = 0; i < len; i++) {
+                    const uint32_t sy = (uint32_t)symtab[hay[e - d - first - i]];
+                    if (i < ms) label |= sy << (32 - SB * (i + 1));
+                    else more |= sy << (32 - SB * (i - ms + 1));
+                }
+                if (label != rec[0] || more != (rec[1] & 0xFFFF0000u)) break;
                 d += first + len;
                 if (rec[1] & 0x100u) { if (nm < PPM_MAX_MATCH) mv[nm++] = (int32_t)rec[2]; }
                 id = rec[3];

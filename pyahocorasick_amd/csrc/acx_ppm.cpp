@@ -383,20 +383,29 @@ int acx_ppm_build(const acx_trie* t, const uint8_t* cls, uint32_t n_classes, boo
         // that consumes 1 + len symbols (rows) or len symbols (singles):
         //   a node with two or more children owns a ROW of K records, indexed by the next symbol;
         //   a node with exactly one child owns a SINGLE record (its id carries bit 31).
-        // A record follows the unbranched path below its first edge for up to 32 / sym_bits symbols,
+        // A record follows the unbranched path below its first edge for up to 48 / sym_bits symbols,
         // stopping at the first node that is a key, branches or is a leaf; `next` is the id of that
         // node if it has children.  Random text leaves the trie within a level or two of the cells;
         // the long walks are occurrences of long keys, whose tails are unbranched.
         std::vector<uint32_t> deep(n, 0);           // id of a node the walk can stand on (0: none)
         std::vector<int32_t> row_nodes, single_nodes;
-        auto path_end = [&](int32_t c, uint32_t& len, uint32_t& label, uint32_t first) -> int32_t {
-            // follow the unbranched, key-free path below node c (which was reached by `first` counted symbols)
+        // (a record's label: max_syms symbols in its first word, 16 / sym_bits more in the top half of its second — 24 symbols of a
+        //  four-letter alphabet: with the C = 9 of the cells and a row's own symbol every key of up to 34 letters that shares no
+        //  tail with another ends ONE gather below its cell.  A walk's steps are dependent round trips to the L2, and a wave
+        //  takes a step when any of its walkers does.)
+        const uint32_t more_syms = 16u / h.sym_bits, rec_syms = max_syms + more_syms;
+        auto put_sym = [&](uint64_t& label, uint32_t len, int32_t v) {   // symbol number len (from 1) of a label: bits 63..32 the first word, 31..16 the second's top half
+            const uint64_t sy = (uint64_t)symof[rev.nodes[v].letter];
+            if (len <= max_syms) label |= sy << (64 - h.sym_bits * len);
+            else label |= sy << (32 - h.sym_bits * (len - max_syms));
+        };
+        auto path_end = [&](int32_t c, uint32_t& len, uint64_t& label) -> int32_t {
+            // follow the unbranched, key-free path below node c
             int32_t v = c;
-            while (len < max_syms && !rev.nodes[v].eow && nkids[v] == 1) {
+            while (len < rec_syms && !rev.nodes[v].eow && nkids[v] == 1) {
                 v = rev.nodes[v].first_child; len++;
-                label |= (uint32_t)symof[rev.nodes[v].letter] << (32 - h.sym_bits * len);
+                put_sym(label, len, v);
             }
-            (void)first;
             return v;
         };
         {
@@ -412,14 +421,15 @@ int acx_ppm_build(const acx_trie* t, const uint8_t* cls, uint32_t n_classes, boo
                 const int32_t u = work.back(); work.pop_back();
                 if (nkids[u] >= 2) {
                     for (int32_t c = rev.nodes[u].first_child; c >= 0; c = rev.nodes[c].next_sibling) {
-                        uint32_t len = 0, label = 0;
-                        const int32_t v = path_end(c, len, label, 1);
+                        uint32_t len = 0; uint64_t label = 0;
+                        const int32_t v = path_end(c, len, label);
                         if (nkids[v]) want(v);
                     }
                 } else {
                     const int32_t c = rev.nodes[u].first_child;
-                    uint32_t len = 1, label = (uint32_t)symof[rev.nodes[c].letter] << (32 - h.sym_bits);
-                    const int32_t v = path_end(c, len, label, 0);
+                    uint32_t len = 1; uint64_t label = 0;
+                    put_sym(label, 1, c);
+                    const int32_t v = path_end(c, len, label);
                     if (nkids[v]) want(v);
                 }
             }
@@ -489,9 +499,9 @@ int acx_ppm_build(const acx_trie* t, const uint8_t* cls, uint32_t n_classes, boo
         // ids as the kernels read them: a row's id is its first record's index (row number x K: no multiply on the
         // device), a single's id is its number with bit 31 set
         auto stored_id = [&](int32_t v) -> uint32_t { const uint32_t d = deep[v]; return (d >> 31) ? d : d * sigma; };
-        auto fill = [&](uint32_t* rec, int32_t v, uint32_t len, uint32_t label) {
-            rec[0] = label;
-            rec[1] = len | (rev.nodes[v].eow ? 0x100u : 0u) | 0x200u;   // 0x200: the record exists
+        auto fill = [&](uint32_t* rec, int32_t v, uint32_t len, uint64_t label) {
+            rec[0] = (uint32_t)(label >> 32);
+            rec[1] = len | (rev.nodes[v].eow ? 0x100u : 0u) | 0x200u | ((uint32_t)label & 0xFFFF0000u);   // 0x200: the record exists; top half: the symbols beyond the first word's
             rec[2] = rev.nodes[v].eow ? (uint32_t)val32(rev.nodes[v]) : 0u;
             rec[3] = stored_id(v);
         };
@@ -500,8 +510,8 @@ int acx_ppm_build(const acx_trie* t, const uint8_t* cls, uint32_t n_classes, boo
                 const int32_t u = row_nodes[b];
                 for (int32_t c = rev.nodes[u].first_child; c >= 0; c = rev.nodes[c].next_sibling) {
                     const uint32_t s1 = (uint32_t)symof[rev.nodes[c].letter];
-                    uint32_t len = 0, label = 0;
-                    const int32_t v = path_end(c, len, label, 1);
+                    uint32_t len = 0; uint64_t label = 0;
+                    const int32_t v = path_end(c, len, label);
                     fill(rows + ((size_t)(b + 1) * sigma + s1) * 4, v, len, label);
                 }
             }
@@ -510,8 +520,9 @@ int acx_ppm_build(const acx_trie* t, const uint8_t* cls, uint32_t n_classes, boo
             for (size_t k = lo; k < hi; k++) {
                 const int32_t u = single_nodes[k];
                 const int32_t c = rev.nodes[u].first_child;
-                uint32_t len = 1, label = (uint32_t)symof[rev.nodes[c].letter] << (32 - h.sym_bits);
-                const int32_t v = path_end(c, len, label, 0);
+                uint32_t len = 1; uint64_t label = 0;
+                put_sym(label, 1, c);
+                const int32_t v = path_end(c, len, label);
                 fill(singles + (size_t)(k + 1) * 4, v, len, label);
             }
         });

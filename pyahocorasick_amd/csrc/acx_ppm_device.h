@@ -85,6 +85,16 @@ struct Ppm {
         const uint32_t w = endbit >> 5;
         return __builtin_amdgcn_alignbit(s_sym[w], s_sym[w - 1], endbit & 31u);
     }
+    // A deep record's label against the symbols that end at position q (include/acx_blob.h: the first 32 / SB symbols in x, the next
+    // 16 / SB in the top half of y): 0 iff the len newest agree.  len >= 1 (a caller lets a record without symbols pass by itself);
+    // the second window is read at q when the label has no second part, so that no walker reads in front of the staged symbols.
+    __device__ __forceinline__ uint32_t label_diff(uint32_t q, uint32_t len, uint32_t x, uint32_t y) const {
+        constexpr uint32_t MS = 32u / SB;
+        const uint32_t l1 = len < MS ? len : MS, l2 = len - l1;
+        const uint32_t d1 = (window(q) ^ x) >> ((0u - SB * l1) & 31u);
+        const uint32_t d2 = ((window(l2 ? q - MS : q) ^ y) >> 16) >> ((16u - SB * l2) & 15u);
+        return d1 | (l2 ? d2 : 0u);
+    }
     __device__ __forceinline__ uint32_t sym_at(uint32_t q) const {
         const uint32_t bit = SB * q + 32;
         return (s_sym[bit >> 5] >> (bit & 31u)) & ((1u << SB) - 1u);
@@ -195,7 +205,7 @@ struct Ppm {
                 if (!(rec.y & 0x200u)) break;
                 const uint32_t len = rec.y & 0xFFu;
                 if (E.L < d + first + len) break;
-                if (len && ((window(q - d - first) ^ rec.x) >> (32 - SB * len))) break;
+                if (len && label_diff(q - d - first, len, rec.x, rec.y)) break;
                 d += first + len;
                 if (rec.y & 0x100u) { if (n >= from && n < upto) f(n, (int32_t)rec.z); n++; }
                 id = rec.w;

@@ -864,7 +864,7 @@ __global__ void __launch_bounds__(ACX_PPM_BLOCK) k_ppm_stream(const acx_ppm_args
                         const uint32_t len = rec.y & 0xFFu;
                         const uint32_t dn = dd + first + len;
                         const uint32_t wq = go ? wpq - dd - first : HP;      // (a walker that is done reads a harmless window)
-                        const uint32_t diff = (P.window(wq) ^ rec.x) >> ((0u - SB * len) & 31u);
+                        const uint32_t diff = P.label_diff(wq, len, rec.x, rec.y);
                         const uint32_t ok = g & (rec.y >> 9) & (wL >= dn ? 1u : 0u) & ((len == 0u ? 1u : 0u) | (diff == 0u ? 1u : 0u));
                         const uint32_t hit = ok & (rec.y >> 8) & 1u;
                         wa = (hit & (wc == 0u ? 1u : 0u)) ? (int32_t)rec.z : wa;
