@@ -430,6 +430,7 @@ struct acx_result {
     // stream scan then queues k_long_gather_sweep where it would queue k_ppm_gather_pos, into `long_out` —, `fused` says whether it did
     const acx_long_fuse_args* fuse = nullptr; bool fused = false; DevBuf<uint2> long_out; acx_ppm_gather_args fused_ga;
     acx_long_fuse_args fuse_args; DevBuf<uint32_t> long_aux; bool long_nofuse = false; uint32_t fail_seen = 0;
+    DevBuf<uint32_t> long_gtot;                                        // reports per group (k_long_sweep_raw -> k_long_place)
     acx_image* long_img = nullptr; uint32_t reruns = 0;   // reruns: scans of this result that were issued again at completion (pool too small, a broken promise)
     hipStream_t copy_stream = nullptr;
     bool ppm_self = false;      // the pending stream scan is a fixed-stride one: block sums, totals and clean-up in k_ppm_gather_pos
@@ -476,7 +477,7 @@ struct acx_result {
         scratch.release(); scr_off.release(); ppm_ctl.release(); hay_local.release(); wave_desc.release(); wave_aux.release();
         events.release(); matches.release(); h_off.release(); h_matches.release(); h_final.release(); h_total.release();
         in_hay.release(); in_off.release(); in_init.release(); in_base.release(); in_skip.release(); h_stage.release();
-        long_out.release(); long_aux.release();
+        long_out.release(); long_aux.release(); long_gtot.release();
         skip_kept.release(); skip_off.release(); matches2.release();
         ws_hay.release(); ws_map.release(); ws_cnt.release(); ws_skip.release(); ws_tile_off.release(); ws_off.release(); ws_partials.release();
         for (auto& e : ev) if (e) (void)hipEventDestroy(e);
@@ -1251,13 +1252,22 @@ static int long_enqueue_sweep(acx_result* r, acx_image* img, hipStream_t g) {
         // (queued behind a scan that may turn out incomplete — more records than its buffer holds: its offsets then point beyond the
         //  buffer — the kernels look at the scan's total first and leave; entry indices are checked against the dictionary's size)
         la.rec_capacity = (int64_t)in->matches.cap; la.n_real = img->long_n_real;
+        la.gtot = nullptr;
         la.compact = (r->pend_params.variant >> 27) & 1;                  // (A/B and the multi-way tests: the compact form of round 5)
         if (r->timed) HIP_TRY(hipEventRecord(r->ev[2], g));
-        HIP_TRY(acx_launch_long_sweep(la, g));
-        // (round 6 tried a prefix sum over the 15 625 GROUPS in one block + a move that finds its haystacks' offsets itself instead of the
-        //  three-launch prefix sum over every haystack: 0.185 against 0.177 ms for sweep + prefix sum + move — the one block is the slower)
-        HIP_TRY(acx_launch_scan(r->counts.p, (int64_t)n, r->match_off.p, r->partials.p, g));
-        HIP_TRY(acx_launch_long_move(la, r->match_off.p, img->long_real, r->matches.p, g));
+        if (!la.compact && !((r->pend_params.variant >> 28) & 1)) {
+            // the prefix sum and the move in one launch (acx_long.hip: k_long_place)
+            const size_t groups = (n + 63) / 64;
+            if ((rc = r->long_gtot.ensure(groups + 1))) return rc;
+            la.gtot = r->long_gtot.p;
+            HIP_TRY(acx_launch_long_sweep(la, g));
+            HIP_TRY(acx_launch_long_place(la, r->match_off.p, img->long_real, r->matches.p, g));
+        } else {
+            // (variant bit 28, and the compact form: sweep in place, a three-launch prefix sum over the counts, a move; A/B and the multi-way tests)
+            HIP_TRY(acx_launch_long_sweep(la, g));
+            HIP_TRY(acx_launch_scan(r->counts.p, (int64_t)n, r->match_off.p, r->partials.p, g));
+            HIP_TRY(acx_launch_long_move(la, r->match_off.p, img->long_real, r->matches.p, g));
+        }
         if (r->timed) HIP_TRY(hipEventRecord(r->ev[3], g));
     }
     HIP_TRY(hipMemcpyAsync(r->h_total.p, r->match_off.p + n, sizeof(int64_t), hipMemcpyDeviceToHost, g));

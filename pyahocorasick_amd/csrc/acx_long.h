@@ -18,9 +18,13 @@ struct acx_long_args {
     // the host issues it again at completion): off[n_hay] > rec_capacity says so, and the kernels leave at once.
     int64_t rec_capacity;
     int32_t compact;               // 1: the sweep over compact records (round 5: a staging pass drops the U records; `variant` bit 27), 0: over the raw records in LDS
+    uint32_t* gtot;                // nullable, out (the raw sweep): records reported per group of 64 haystacks
     int64_t n_real;                // entries of the dictionary (an index beyond them — stale records — reports 0); fewer than 2^18: the values carry `below` (acx.h)
 };
 hipError_t acx_launch_long_sweep(const acx_long_args& a, hipStream_t s);
+// prefix sum over the counts and move in one launch (acx_long.hip: k_long_place; needs gtot from the raw sweep): reports to dst, their offsets per
+// haystack to new_off[n_hay + 1]
+hipError_t acx_launch_long_place(const acx_long_args& a, int64_t* new_off, const int32_t* real, uint2* dst, hipStream_t s);
 
 // The sweep straight from the scan's record POOL (fixed-stride stream scans whose haystacks are no longer than a tile): what
 // k_ppm_gather_pos would move to its final place first — 8 bytes per record written and read again — is read from the grants of the
@@ -33,6 +37,7 @@ struct acx_long_fuse_args {
     uint32_t* wave_base;           // out: where the packed reports of the scan's wave w start in gather_args.matches [n_waves]
     uint32_t* fail;                // out: counts the batches of 64 haystacks that held more records than a wave's LDS (the host then sweeps the gathered records instead)
     uint32_t longest;              // longest dictionary entry
+    uint32_t* gtot;                // nullable, out (the raw sweep): records reported per group of 64 haystacks
     int64_t n_real;                // entries of the dictionary
 };
 hipError_t acx_launch_long_gather_sweep(const acx_ppm_gather_args& c, const acx_long_fuse_args& f, hipStream_t s);

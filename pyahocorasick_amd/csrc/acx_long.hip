@@ -368,6 +368,63 @@ __global__ void __launch_bounds__(256) k_long_sweep_raw(const acx_long_args a) {
             P += tot; done = e;
             long_wave_sync();
         }
+        if (a.gtot && lane == 0) a.gtot[g] = P;
+    }
+}
+
+// ---- prefix sum and move in ONE launch ---------------------------------------------------------------------------------------------
+// k_long_sweep_raw leaves the reports of a group of 64 haystacks packed at the front of the group's records, a count per haystack and
+// the group's total (gtot).  What followed was a prefix sum over the counts (three launches) and k_long_move: five kernels behind the
+// gather, each of which has to find CUs beside the next batch's scan kernel.  k_long_place does both in one: a block takes a CHUNK of
+// 16 groups and adds up the totals of all the groups in front of it ITSELF — 15 625 words for a million haystacks, in the L2 since the
+// sweep wrote them; every block reads its own prefix of them, 30 KB on average —, then every wave places four groups: offsets per
+// haystack from the counts, the records moved.  No look-back and no tickets: two versions with a look-back over published totals were
+// built first and were slower (sweeping in the same launch: a wave waited for the slowest sweep of the 64 groups in front, 0.31 ms
+// against 0.18 for sweep + prefix sum + move; publishing totals only: 8 192 waves start at once and the last walk back over 8 000
+// unfinished words, a round trip to memory per 64 — 0.30 ms for the placement alone).
+constexpr int LONG_PLACE_GROUPS = 16;                                  // groups per block
+__global__ void __launch_bounds__(256) k_long_place(const acx_long_args a, int64_t* new_off, const int32_t* __restrict__ real, uint2* dst) {
+    __shared__ uint32_t s_part[4];
+    __shared__ uint32_t s_excl[LONG_PLACE_GROUPS + 1];
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    const int64_t n_hay = a.n_hay, n_groups = (n_hay + 63) / 64;
+    if (a.off[n_hay] > a.rec_capacity) return;                         // (the scan in front is incomplete: see acx_long_args)
+    const uint32_t n_real = (uint32_t)a.n_real;
+    const int64_t g0 = (int64_t)blockIdx.x * LONG_PLACE_GROUPS;
+    // the reports in front of the chunk
+    uint32_t sum = 0;
+    {
+        int64_t i = threadIdx.x;
+        for (; i + 768 < g0; i += 1024) {                               // (four loads in flight per thread)
+            const uint32_t v0 = a.gtot[i], v1 = a.gtot[i + 256], v2 = a.gtot[i + 512], v3 = a.gtot[i + 768];
+            sum += (v0 + v1) + (v2 + v3);
+        }
+        for (; i < g0; i += 256) sum += a.gtot[i];
+    }
+    sum = wave_incl_scan_u32(sum, lane);
+    if (lane == 63) s_part[wid] = sum;
+    __syncthreads();
+    if (threadIdx.x < 64) {
+        const uint32_t before = s_part[0] + s_part[1] + s_part[2] + s_part[3];
+        const uint32_t t = (lane < LONG_PLACE_GROUPS && g0 + lane < n_groups) ? a.gtot[g0 + lane] : 0u;
+        const uint32_t inc = wave_incl_scan_u32(t, lane);
+        if (lane < LONG_PLACE_GROUPS) s_excl[lane] = before + inc - t;
+        if (lane == LONG_PLACE_GROUPS - 1) s_excl[LONG_PLACE_GROUPS] = before + inc;
+    }
+    __syncthreads();
+    for (int k = wid; k < LONG_PLACE_GROUPS; k += 4) {
+        const int64_t g = g0 + k;
+        if (g >= n_groups) break;
+        const int64_t h = g * 64 + lane;
+        const bool valid = h < n_hay;
+        const uint32_t excl = s_excl[k], total = s_excl[k + 1] - excl;
+        const uint32_t c = valid ? (uint32_t)a.counts[h] : 0u;
+        const uint2* src = a.rec + a.off[g * 64];
+        const uint32_t ci = wave_incl_scan_u32(c, lane);
+        if (valid) new_off[h] = (int64_t)excl + (ci - c);
+        if (g == n_groups - 1 && lane == 0) new_off[n_hay] = (int64_t)excl + total;
+        uint2* const d = dst + excl;
+        for (uint32_t i = (uint32_t)lane; i < total; i += 64u) { uint2 v = src[i]; v.y = v.y < n_real ? (uint32_t)real[v.y] : 0u; d[i] = v; }   // (entry index -> what iter_long reports for it)
     }
 }
 
@@ -587,6 +644,14 @@ hipError_t acx_launch_long_sweep(const acx_long_args& a, hipStream_t s) {
     if (blocks > cap) blocks = cap;
     if (blocks < 1) blocks = 1;
     hipLaunchKernelGGL(k_long_sweep, dim3((unsigned)blocks), dim3(64), 0, s, a);
+    return hipGetLastError();
+}
+
+hipError_t acx_launch_long_place(const acx_long_args& a, int64_t* new_off, const int32_t* real, uint2* dst, hipStream_t s) {
+    const int64_t n_groups = (a.n_hay + 63) / 64;
+    int64_t blocks = (n_groups + LONG_PLACE_GROUPS - 1) / LONG_PLACE_GROUPS;
+    if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(k_long_place, dim3((unsigned)blocks), dim3(256), 0, s, a, new_off, real, dst);
     return hipGetLastError();
 }
 

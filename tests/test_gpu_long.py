@@ -14,6 +14,7 @@ pytestmark = pytest.mark.gpu
 
 SERIAL = 1 << 25
 COMPACT = 1 << 27         # the sweep over compact records (round 5's form; round 6's default sweeps the raw records in LDS): A/B
+THREE_STEPS = 1 << 28    # sweep, prefix sum, move as three steps (round 6's default does them in one launch: k_long_sweep_place): A/B
 FUSED = 1 << 26           # the sweep straight from the scan's record pool (k_long_gather_sweep) instead of k_ppm_gather_pos + k_long_sweep: opt-in, slower (A/B)
 
 
@@ -36,7 +37,7 @@ def _three_way(A, O, flat, off=None, n=None, L=None, base=None, expect_plan=True
     mo, oe, ov = O.batch(flat.tobytes(), host_off, 1)
     if base is not None:
         oe = oe + np.repeat(base, np.diff(mo)).astype(np.int32)
-    for variant in (0, COMPACT, FUSED, SERIAL):
+    for variant in (0, THREE_STEPS, COMPACT, FUSED, SERIAL):
         sc = Scanner(img)
         sc.scan(d_hay, len(flat), n, mode=acx.ACX_SCAN_LONG, dev_index_base=d_base, variant=variant, **kw)
         moff, e, v, _ = sc.fetch()
@@ -98,7 +99,7 @@ def test_config5_shape_against_the_serial_walk():
     d_hay = DeviceBuffer.from_numpy(flat, pad=64)
     assert img.ppm_kernel(stride=L, dev_hay=d_hay.ptr.value, n_hay=n, mode=acx.ACX_SCAN_LONG) == "stream4"
     got = []
-    for variant in (0, COMPACT, FUSED, SERIAL):
+    for variant in (0, THREE_STEPS, COMPACT, FUSED, SERIAL):
         sc = Scanner(img)
         sc.scan(d_hay, n * L, n, stride=L, mode=acx.ACX_SCAN_LONG, variant=variant)
         got.append(sc.fetch()[:3])
