@@ -430,6 +430,7 @@ struct acx_result {
     // stream scan then queues k_long_gather_sweep where it would queue k_ppm_gather_pos, into `long_out` —, `fused` says whether it did
     const acx_long_fuse_args* fuse = nullptr; bool fused = false; DevBuf<uint2> long_out; acx_ppm_gather_args fused_ga;
     acx_long_fuse_args fuse_args; DevBuf<uint32_t> long_aux; bool long_nofuse = false; uint32_t fail_seen = 0;
+    DevBuf<uint32_t> start_bits; size_t start_bits_words = 0; bool start_bits_clean = false;         // k_ppm_stream4 on an offsets batch: bit p = a haystack starts at byte p
     DevBuf<uint32_t> long_gtot;                                        // reports per group (k_long_sweep_raw -> k_long_place)
     acx_image* long_img = nullptr; uint32_t reruns = 0;   // reruns: scans of this result that were issued again at completion (pool too small, a broken promise)
     hipStream_t copy_stream = nullptr;
@@ -477,7 +478,7 @@ struct acx_result {
         scratch.release(); scr_off.release(); ppm_ctl.release(); hay_local.release(); wave_desc.release(); wave_aux.release();
         events.release(); matches.release(); h_off.release(); h_matches.release(); h_final.release(); h_total.release();
         in_hay.release(); in_off.release(); in_init.release(); in_base.release(); in_skip.release(); h_stage.release();
-        long_out.release(); long_aux.release(); long_gtot.release();
+        long_out.release(); long_aux.release(); long_gtot.release(); start_bits.release();
         skip_kept.release(); skip_off.release(); matches2.release();
         ws_hay.release(); ws_map.release(); ws_cnt.release(); ws_skip.release(); ws_tile_off.release(); ws_off.release(); ws_partials.release();
         for (auto& e : ev) if (e) (void)hipEventDestroy(e);
@@ -613,6 +614,7 @@ static int launch_gather_or_fused(acx_result* r, hipStream_t g) {
         }
     }
     HIP_TRY(acx_launch_ppm_gather(r->pend_pa.wave_desc, r->pend_ga.n_waves, r->pend_item_off, r->pend_ga, g));
+    if (r->pend_ga.pos_records && r->pend_ga.used_bits) r->start_bits_clean = true;       // (k_ppm_gather_pos<true> zeroes the start bitmap its scan used)
     return ACX_OK;
 }
 
@@ -747,7 +749,11 @@ static int ppm_enqueue(acx_result* r, acx_image* img, const acx_chunk_args* ca, 
         HIP_TRY(acx_launch_scan(r->nck.p, ca->n_hay, r->ck_first.p, r->partials.p, s));
         HIP_TRY(acx_launch_chunk_fill(*ca, ni, s));
     }
-    if (r->ppm_stream && pa.off) HIP_TRY(acx_launch_ppm_first_h(pa.off, pa.n_hay, ni, (int64_t)pa.nsub * 256, (int64_t*)pa.first_h, s));
+    if (r->ppm_stream && pa.off && !pa.start_bits) HIP_TRY(acx_launch_ppm_first_h(pa.off, pa.n_hay, ni, (int64_t)pa.nsub * 256, (int64_t*)pa.first_h, s));
+    if (r->ppm_stream && pa.off && pa.start_bits) {
+        HIP_TRY(acx_launch_ppm_start_bits(pa.off, pa.n_hay, (uint32_t*)pa.start_bits, r->start_bits_words, !r->start_bits_clean, s));
+        r->start_bits_clean = false;                                    // (until this scan's gather is queued)
+    }
     if (r->timed) HIP_TRY(hipEventRecord(r->ev[0], s));
     HIP_TRY(acx_launch_ppm_scan(pa, ni, s));
     if (r->timed) HIP_TRY(hipEventRecord(r->ev[1], s));
@@ -846,10 +852,12 @@ static int ppm_plan(const acx_image* img, const acx_scan_params* p) {
 static bool ppm_plan_stream4(const acx_image* img, const acx_scan_params* p) {
     const acx_ppm_header& ph = img->ppm;
     const uint32_t f2 = (img->ppm_g2 && !((p->variant >> 20) & 1)) ? ph.F2 : 0u;       // (as scan_ppm sets acx_ppm_args.F2: no second level without its bitmap)
-    return img->ppm_hot4 && (img->ppm_cid || img->ppm_hot12) && !((p->variant >> 19) & 1) && !p->dev_off && !p->dev_skip && p->stride >= 8 && p->stride < 2048 &&
+    const bool image_ok = img->ppm_hot4 && (img->ppm_cid || img->ppm_hot12) && !((p->variant >> 19) & 1) && !p->dev_skip &&
            ph.sym_bits == 2 && ph.pow2 && ph.sym_arith != 0 && ph.K == 4 && !ph.g_global && !f2 &&
-           ph.C == 9 && ph.F == 10 && ppm_halo_pos(ph) == 32 && ph.longest <= 33 && ph.g_words * 4u == (128u << 10) &&
-           ppm_stream_nsub(ph, 32, false) == 8;
+           ph.C == 9 && ph.F == 10 && ppm_halo_pos(ph) == 32 && ph.longest <= 33 && ph.g_words * 4u == (128u << 10);
+    if (!image_ok) return false;
+    if (p->dev_off) return p->hay_capacity < ((int64_t)1 << 32) - 4096 && ppm_stream_nsub(ph, 32, true) == 8;      // (an offsets batch: the starts as a bitmap, scan_ppm)
+    return p->stride >= 8 && p->stride < 2048 && ppm_stream_nsub(ph, 32, false) == 8;
 }
 
 static acx_image* image_long(acx_image* img);
@@ -1013,7 +1021,19 @@ static int scan_ppm(acx_image_t* img, const acx_scan_params* p, acx_result* r, h
         if ((rc = r->hay_local.ensure(n + 1))) return rc;
         pa.wave_desc = r->wave_desc.p;
         pa.block_sum = nullptr;
-        if (!chunked) {
+        // an offsets batch that k_ppm_stream4 takes (variant bit 19: the general stream kernel, A/B): the haystacks' starts as a bitmap for the
+        // scan, records with global positions, k_ppm_gather_pos<true> behind it — everything below as for a fixed stride
+        pa.off = chunked ? p->dev_off : nullptr;
+        const bool s4o = chunked && acx_ppm_stream4_offs_ok(pa) && p->hay_capacity < ((int64_t)1 << 32) - 4096;
+        pa.off = nullptr;
+        if (s4o) {
+            const size_t words = ((size_t)stream_tiles + 3) * 64 + 64;
+            if (r->start_bits.cap < words) r->start_bits_clean = false;   // (a new buffer; the one in use is cleaned by every scan's gather)
+            if ((rc = r->start_bits.ensure(words))) return rc;
+            r->start_bits_words = words;
+            pa.start_bits = r->start_bits.p;
+        }
+        if (!chunked || s4o) {
             // fixed stride: block sums instead of a prefix-sum launch, totals and clean-up by k_ppm_gather_pos (acx_kernels.h);
             // two sets of sums: the gather of one scan zeroes the set of the result's next scan
             if (blocks > ACX_PPM_MAX_BLOCKS) return acx_fail(ACX_E_UNSUPPORTED, "position-parallel scan: %lld blocks", (long long)blocks);
@@ -1040,6 +1060,7 @@ static int scan_ppm(acx_image_t* img, const acx_scan_params* p, acx_result* r, h
         if (!chunked && r->ext_matches) { ga.matches = r->ext_matches; ga.capacity = r->ext_capacity; ga.match_off = r->ext_match_off; ga.off_base = r->ext_off_base; }
         ga.n_hay = p->n_hay; ga.stride = p->stride;
         ga.off = chunked ? p->dev_off : nullptr;
+        ga.pos_records = s4o ? 1 : 0; ga.used_bits = s4o ? r->start_bits.p : nullptr; ga.used_words = s4o ? (uint64_t)(r->start_bits_words & ~(size_t)3) : 0;
         ga.tile_pos = tpos; ga.tpw = (stream_tiles + n_waves - 1) / n_waves;
         // unequal runs for the waves of a block (acx_ppm_layout.h; variant bit 17: equal runs, A/B)
         pa.share_a = pa.share_b = 0;
@@ -1049,14 +1070,14 @@ static int scan_ppm(acx_image_t* img, const acx_scan_params* p, acx_result* r, h
             pa.share_a = (uint32_t)((ga.tpw * pa_ + 500) / 1000); pa.share_b = (uint32_t)((ga.tpw * pb_ + 500) / 1000);
         }
         ga.share_a = pa.share_a; ga.share_b = pa.share_b;
-        ga.stride_magic = pa.stride_magic; ga.index_base = chunked ? nullptr : p->dev_index_base; ga.skip = chunked ? nullptr : p->dev_skip;
+        ga.stride_magic = pa.stride_magic; ga.index_base = (chunked && !s4o) ? nullptr : p->dev_index_base; ga.skip = chunked ? nullptr : p->dev_skip;
         {   // (both gathers of the stream scans report through the host's pinned words and clean the control words up: k_ppm_gather_pos, and —
             //  offsets batches — k_ppm_wave_scan in front of k_ppm_gather)
             void* dp = nullptr;
             HIP_TRY(hipHostGetDevicePointer(&dp, r->h_total.p, 0));
             ga.host_words = (long long*)dp; ga.ctl = r->ppm_ctl.p;
         }
-        r->ppm_self = !chunked;
+        r->ppm_self = !chunked || s4o;
     }
 
     acx_ppm_compact_args& ca = r->pend_ca;            // (the general kernel: per-tile counts, scan, compact)

@@ -130,6 +130,7 @@ struct acx_ppm_args {
     uint32_t share_a, share_b;   // k_ppm_stream4: the unequal runs of a block's waves (acx_ppm_slot_first_tile; 0, 0: equal)
     uint32_t m24;            // k_ppm_stream: ceil(2^23 / stride) for strides below 2048 (a 24-bit multiply divides), else 0
     const int64_t* off; const int64_t* first_h;    // k_ppm_stream on an offsets batch: offsets, first haystack at or after every tile
+    const uint32_t* start_bits;                    // k_ppm_stream4 on an offsets batch: bit p = a haystack starts at byte p (two tiles of zero words behind the last)
     uint32_t g_global;       // the filter bitmap is read from global memory (not copied to LDS)
     const uint8_t* deep_base; uint32_t row_off, single_off;   // k_ppm_stream: rows and singles as 32-bit offsets from one base
     uint32_t* wave_desc;     // k_ppm_stream: per wave {records, grants, 16 x base, 16 x count}
@@ -167,6 +168,9 @@ struct acx_ppm_gather_args {       // k_ppm_stream results -> final place
     const uint2* scratch; uint2* matches; int64_t capacity;
     const int32_t* hay_local; int64_t* match_off; int64_t n_hay; int64_t stride;
     const int64_t* off;            // offsets batch (else nullptr: fixed stride — records carry global positions)
+    uint64_t used_words;           // (their number: a multiple of 4)
+    uint32_t* used_bits;           // that case: the scan's start bitmap — every wave's block here zeroes the words of its run of tiles (the result's next scan finds it clean: no memset in front of its scan kernel)
+    int32_t pos_records;           // 1: an offsets batch scanned by k_ppm_stream4 (records carry global positions all the same) — k_ppm_gather_pos<true> instead of k_ppm_wave_scan + k_ppm_gather
     int64_t tile_pos, tpw;         // positions per tile, tiles per wave
     uint64_t stride_magic;         // fixed stride: ceil(2^64 / stride) (0 for stride 1)
     const int32_t* index_base;     // fixed stride: added to every index of haystack h (nullable)
@@ -180,6 +184,10 @@ hipError_t acx_launch_ppm_gather(const uint32_t* wave_desc, int64_t n_waves, int
 hipError_t acx_launch_ppm_scan(const acx_ppm_args& a, int64_t n_items_bound, hipStream_t s);
 // k_ppm_stream4 (acx_ppm_stream4.hip): fixed-stride batches over four-letter alphabets; eligible() says whether it takes the scan
 bool acx_ppm_stream4_eligible(const acx_ppm_args& a);
+bool acx_ppm_stream4_offs_ok(const acx_ppm_args& a);      // an offsets batch it would take once start_bits exists
+// start_bits for k_ppm_stream4's offsets form: bit p of the bitmap = a haystack starts at byte p (n_words words; zero_first: zeroed here first —
+// otherwise they ARE zero: k_ppm_gather_pos<true> clears what its scan used, acx_ppm_gather_args.used_bits)
+hipError_t acx_launch_ppm_start_bits(const int64_t* off, int64_t n_hay, uint32_t* bits, size_t n_words, bool zero_first, hipStream_t s);
 hipError_t acx_launch_ppm_stream4(const acx_ppm_args& a, int64_t blocks, hipStream_t s);
 hipError_t acx_launch_ppm_compact(const acx_ppm_compact_args& c, int64_t n_items_bound, hipStream_t s);
 int64_t acx_ppm_grid_blocks(const acx_ppm_lds& lds, int64_t n_items_bound, uint32_t reserve_cus = 0);   // blocks of a k_ppm_scan launch

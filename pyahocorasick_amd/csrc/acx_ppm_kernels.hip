@@ -1075,6 +1075,17 @@ __global__ void __launch_bounds__(ACX_PPM_BLOCK) k_ppm_stream(const acx_ppm_args
 #endif
 }
 
+// bit p of `bits` = a haystack starts at byte p (k_ppm_stream4 on an offsets batch; the words were zeroed in front of this launch).  The batch's end is
+// no start: off[n_hay] is left out, and so is every offset at or beyond it (empty haystacks at the end)
+__global__ void __launch_bounds__(256) k_ppm_start_bits(const int64_t* off, int64_t n_hay, uint32_t* bits, uint64_t n_bits) {
+    const int64_t n_threads = (int64_t)gridDim.x * 256;
+    const uint64_t end = (uint64_t)off[n_hay];
+    for (int64_t h = (int64_t)blockIdx.x * 256 + threadIdx.x; h < n_hay; h += n_threads) {
+        const uint64_t p = (uint64_t)off[h];
+        if (p < end && p < n_bits) atomicOr(bits + (p >> 5), 1u << (p & 31u));
+    }
+}
+
 // first_h[t] = the first haystack that starts at or after byte t * tile_pos (n_hay + 1 entries of `off`; the last
 // one, the end of the batch, counts): one binary search per tile
 __global__ void __launch_bounds__(256) k_ppm_first_h(const int64_t* off, int64_t n_hay, int64_t n_tiles, int64_t tile_pos, int64_t* first_h) {
@@ -1161,6 +1172,8 @@ __global__ void __launch_bounds__(256) k_ppm_gather(const acx_ppm_gather_args c)
 // records in front of position h * stride.  A wave of k_ppm_stream covers the positions [A, B) = its run of tiles, so its
 // block here knows every haystack that starts in there: those in front of its first record, those between two records
 // of different haystacks (the thread of the later record fills the gap), those behind its last record.
+// OFFS: an offsets batch that k_ppm_stream4 scanned — the same records; the haystack of a position is the last one whose offset is at or below it.
+template <bool OFFS>
 __global__ void __launch_bounds__(PPM_GPOS_THREADS) k_ppm_gather_pos(const acx_ppm_gather_args c) {
     // One WAVE per block and no LDS: the scan kernel of the NEXT batch, beside which this kernel runs, may hold every byte of
     // a CU's LDS (k_ppm_stream4 does), and a block that asks for any — 16 bytes for a reduction — then finds no CU to start on.
@@ -1187,13 +1200,13 @@ __global__ void __launch_bounds__(PPM_GPOS_THREADS) k_ppm_gather_pos(const acx_p
         for (int b = threadIdx.x; b < ACX_PPM_MAX_BLOCKS; b += GT) c.block_sum_next[b] = 0u;
     }
     const bool fits = total <= c.capacity;
-    const uint32_t stride = (uint32_t)c.stride;
-    const uint64_t H = (uint64_t)c.n_hay * stride;
+    const uint32_t stride = OFFS ? 1u : (uint32_t)c.stride;
+    const uint64_t H = OFFS ? (uint64_t)c.off[c.n_hay] : (uint64_t)c.n_hay * stride;
     const int lane = threadIdx.x & 63;
     // positions of one wave lie within tpw * tile_pos of its first: the haystack of a position is a 32-bit multiply-high
     // away (exact while (offset in its haystack + distance) * stride < 2^32), else the 64-bit magic
     const uint64_t span = ((uint64_t)c.tpw + c.share_a) * (uint64_t)c.tile_pos;       // (the longest run of a wave)
-    const bool small = (span + stride) * (uint64_t)stride < ((uint64_t)1 << 32);
+    const bool small = !OFFS && (span + stride) * (uint64_t)stride < ((uint64_t)1 << 32);
     const uint32_t m32 = small ? (uint32_t)((((uint64_t)1 << 32) + stride - 1) / stride) : 0u;
     for (int64_t w = blockIdx.x; w < c.n_waves; w += gridDim.x) {
         const uint32_t* d = c.wave_desc + (size_t)w * PPM_DESC_WORDS;
@@ -1205,11 +1218,37 @@ __global__ void __launch_bounds__(PPM_GPOS_THREADS) k_ppm_gather_pos(const acx_p
         uint64_t B = (blk_first + acx_ppm_slot_first_tile(slot + 1u, (uint32_t)c.tpw, c.share_a, c.share_b)) * (uint64_t)c.tile_pos;
         if (A > H) A = H;
         if (B > H) B = H;
-        const int64_t hA = (int64_t)((A + stride - 1) / stride), hB = (int64_t)((B + stride - 1) / stride);   // haystacks that start in [A, B): hA .. hB - 1
-        const int64_t h0 = (int64_t)(A / stride);                      // haystack of position A
-        const uint32_t rA = (uint32_t)(A - (uint64_t)h0 * stride), A32 = (uint32_t)A;
+        int64_t hA, hB, h0;                                            // haystacks that start in [A, B): hA .. hB - 1; the haystack of position A
+        if (OFFS && c.used_bits) {
+            // the scan is over: its start bitmap back to zero, every block the words of its wave's run (16 bytes per lane and store)
+            const uint64_t w0 = (blk_first + acx_ppm_slot_first_tile(slot, (uint32_t)c.tpw, c.share_a, c.share_b)) * (uint64_t)(c.tile_pos >> 5);
+            uint64_t w1 = (blk_first + acx_ppm_slot_first_tile(slot + 1u, (uint32_t)c.tpw, c.share_a, c.share_b)) * (uint64_t)(c.tile_pos >> 5);
+            if (w1 > c.used_words) w1 = c.used_words;
+            u32x4 z; z.x = 0; z.y = 0; z.z = 0; z.w = 0;
+            for (uint64_t i = w0 + 4u * (uint32_t)lane; i < w1; i += 4u * GT) *(u32x4*)(c.used_bits + i) = z;
+        }
+        if (OFFS) {
+            // (a haystack that starts at the batch's end — an empty one — belongs to the wave whose run reaches the end)
+            // (the first haystack that starts at or behind a position: a binary search over the offsets, twice per wave)
+            auto first_at = [&](uint64_t x) -> int64_t { int64_t lo = 0, hi = c.n_hay; while (lo < hi) { const int64_t mid = (lo + hi) >> 1; if ((uint64_t)c.off[mid] >= x) hi = mid; else lo = mid + 1; } return lo; };
+            hA = A >= H ? c.n_hay : first_at(A);
+            hB = B >= H ? c.n_hay : first_at(B);
+            h0 = (hA < c.n_hay && (uint64_t)c.off[hA] == A) ? hA : hA - 1;
+            if (A >= H) h0 = c.n_hay - 1;
+        } else {
+            hA = (int64_t)((A + stride - 1) / stride); hB = (int64_t)((B + stride - 1) / stride);
+            h0 = (int64_t)(A / stride);
+        }
+        const uint32_t rA = OFFS ? 0u : (uint32_t)(A - (uint64_t)h0 * stride), A32 = (uint32_t)A;
         // haystack (relative to h0) and index of a position of this wave
         auto locate = [&](uint32_t gpos, uint32_t& idx) -> uint32_t {
+            if (OFFS) {
+                int64_t lo = 0, hi = c.n_hay;                           // the smallest h with off[h] > gpos
+                while (lo < hi) { const int64_t mid = (lo + hi) >> 1; if ((uint64_t)c.off[mid] > (uint64_t)gpos) hi = mid; else lo = mid + 1; }
+                const int64_t h = lo - 1;
+                idx = gpos - (uint32_t)c.off[h];
+                return (uint32_t)(h - h0);
+            }
             if (small) { const uint32_t y = rA + (gpos - A32), q = __umulhi(y, m32); idx = y - q * stride; return q; }
             uint32_t rem; const uint32_t hh = div_magic(gpos, c.stride_magic, stride, rem); idx = rem; return (uint32_t)((int64_t)hh - h0);
         };
@@ -1222,6 +1261,62 @@ __global__ void __launch_bounds__(PPM_GPOS_THREADS) k_ppm_gather_pos(const acx_p
         u32x2* dst = (u32x2*)(c.matches + base);
         uint32_t li = 0;                                               // records of this wave in front of the current grant
         uint32_t q_last = (uint32_t)(hA - 1 - h0);                     // haystack (relative) of the last record so far; none: the one in front of the first start
+        if (OFFS) {
+            // One record per lane and trip.  The records of a wave are in position order, so the haystack of a record is at or behind that
+            // of the record before it: the trip loads the 64 offsets from the haystack of the LAST trip's last record on (one coalesced load),
+            // and a lane finds its record's haystack among them by six lane exchanges (positions and offsets fit 32 bits: the scan kernel
+            // asked for that).  A record beyond those 64 haystacks (sparse matches) searches the offsets behind them.  The haystack of the record before: the lane below (lane 0: the last trip's last record).
+            // (the 64 offsets are kept while the records stay within their first half — some ten trips for config 2's density —, and a trip's
+            //  records are requested one trip ahead: most trips wait for no load that depends on the trip before)
+            int64_t hw = -1;                                             // the haystack of W's lane 0; -1: none loaded
+            uint32_t W = 0;
+            for (uint32_t g = 0; g < ng && fits; g++) {
+                const u32x2* src = (const u32x2*)(c.scratch + d[2 + g]);
+                const uint32_t n = d[18 + g];
+                u32x2 nxt; nxt.x = 0xFFFFFFFFu; nxt.y = 0u;
+                if ((uint32_t)lane < n) nxt = __builtin_nontemporal_load(src + lane);
+#pragma unroll 1
+                for (uint32_t k0 = 0; k0 < n; k0 += GT) {
+                    const uint32_t k = k0 + (uint32_t)lane;
+                    const bool valid = k < n;
+                    const u32x2 rec = nxt;
+                    nxt.x = 0xFFFFFFFFu; nxt.y = 0u;
+                    if (k + GT < n) nxt = __builtin_nontemporal_load(src + k + GT);
+                    int64_t hq = h0 + (int64_t)(int32_t)q_last;           // (wave-uniform) the haystack of the record in front
+                    if (hq < 0) hq = 0;
+                    if (hw < 0 || hq - hw >= 32) {
+                        hw = hq;
+                        const int64_t wi = hw + lane;
+                        W = (uint32_t)c.off[wi < c.n_hay ? wi : c.n_hay];
+                    }
+                    uint32_t j = 0;                                      // the largest j with W[j] <= position (W[0] is: positions only grow)
+#pragma unroll
+                    for (uint32_t step = 32; step >= 1; step >>= 1) { const uint32_t t = j + step; const uint32_t wv = (uint32_t)__shfl((int)W, (int)t, 64); if (wv <= rec.x) j = t; }
+                    int64_t h = hw + j;
+                    uint32_t oh = (uint32_t)__shfl((int)W, (int)j, 64);
+                    if (__any(valid && j == 63u)) {                      // maybe beyond the 64 haystacks: the offsets behind them
+                        if (valid && j == 63u) {
+                            int64_t lo = h + 1, hi = c.n_hay;
+                            while (lo < hi) { const int64_t mid = (lo + hi) >> 1; if ((uint64_t)c.off[mid] > (uint64_t)rec.x) hi = mid; else lo = mid + 1; }
+                            h = lo - 1; oh = (uint32_t)c.off[h];
+                        }
+                    }
+                    if (h > c.n_hay - 1) h = c.n_hay - 1;                 // (lanes beyond the grant's end)
+                    const uint32_t q = (uint32_t)(h - h0);
+                    uint32_t qp = (uint32_t)__shfl_up((int)q, 1, 64);
+                    if (lane == 0) qp = q_last;
+                    if (valid) {
+                        for (uint32_t qq = qp + 1; (int32_t)(qq - q) <= 0; qq++) c.match_off[h0 + (int64_t)(int32_t)qq] = c.off_base + base + li + k;   // haystacks that start between the two records
+                        u32x2 o; o.y = rec.y;
+                        o.x = rec.x - oh + (c.index_base ? (uint32_t)c.index_base[h] : 0u);
+                        __builtin_nontemporal_store(o, dst + li + k);
+                    }
+                    const uint32_t nv = n - k0 < (uint32_t)GT ? n - k0 : (uint32_t)GT;
+                    q_last = (uint32_t)__shfl((int)q, (int)(nv - 1u), 64);
+                }
+                li += n;
+            }
+        } else
         for (uint32_t g = 0; g < ng && fits; g++) {
             const u32x2* src = (const u32x2*)(c.scratch + d[2 + g]);
             const uint32_t n = d[18 + g];
@@ -1503,14 +1598,30 @@ hipError_t acx_launch_ppm_first_h(const int64_t* off, int64_t n_hay, int64_t n_t
     return hipGetLastError();
 }
 
+hipError_t acx_launch_ppm_start_bits(const int64_t* off, int64_t n_hay, uint32_t* bits, size_t n_words, bool zero_first, hipStream_t s) {
+    if (zero_first) {
+        hipError_t e = hipMemsetAsync(bits, 0, n_words * sizeof(uint32_t), s);
+        if (e != hipSuccess) return e;
+    }
+    int64_t blocks = (n_hay + 255) / 256;
+    const int64_t cap = (int64_t)num_cus() * 16;
+    if (blocks > cap) blocks = cap;
+    if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(k_ppm_start_bits, dim3((unsigned)blocks), dim3(256), 0, s, off, n_hay, bits, (uint64_t)n_words * 32u);
+    return hipGetLastError();
+}
+
 hipError_t acx_launch_ppm_gather(const uint32_t* wave_desc, int64_t n_waves, int64_t* wave_off, const acx_ppm_gather_args& c, hipStream_t s) {
-    if (c.off) hipLaunchKernelGGL(k_ppm_wave_scan, dim3(1), dim3(1024), 0, s, wave_desc, n_waves, wave_off, c.ctl, c.host_words);
+    if (c.off && !c.pos_records) hipLaunchKernelGGL(k_ppm_wave_scan, dim3(1), dim3(1024), 0, s, wave_desc, n_waves, wave_off, c.ctl, c.host_words);
     int64_t blocks = n_waves;
     const int64_t hb = (c.n_hay + 256) / 256;
     if (blocks < hb) blocks = hb;
     const int64_t cap = (int64_t)num_cus() * 32;
     if (blocks > cap) blocks = cap;
-    if (c.off) hipLaunchKernelGGL(k_ppm_gather, dim3((unsigned)blocks), dim3(256), 0, s, c);
+    if (c.off && c.pos_records) {
+        const int64_t cap4 = 4 * cap;
+        hipLaunchKernelGGL(k_ppm_gather_pos<true>, dim3((unsigned)(n_waves < cap4 ? n_waves : cap4)), dim3(PPM_GPOS_THREADS), 0, s, c);
+    } else if (c.off) hipLaunchKernelGGL(k_ppm_gather, dim3((unsigned)blocks), dim3(256), 0, s, c);
     else {
         const int64_t cap4 = 4 * cap;
         // the lean form (at most 32 registers per lane: it runs BESIDE k_ppm_stream4) where it applies: no index base, no contexts,
@@ -1523,7 +1634,7 @@ hipError_t acx_launch_ppm_gather(const uint32_t* wave_desc, int64_t n_waves, int
         const bool lean = false; (void)span; (void)st;
 #endif
         if (lean) hipLaunchKernelGGL(k_ppm_gather_pos_lean, dim3((unsigned)(n_waves < cap4 ? n_waves : cap4)), dim3(PPM_GPOS_THREADS), 0, s, c);
-        else hipLaunchKernelGGL(k_ppm_gather_pos, dim3((unsigned)(n_waves < cap4 ? n_waves : cap4)), dim3(PPM_GPOS_THREADS), 0, s, c);
+        else hipLaunchKernelGGL(k_ppm_gather_pos<false>, dim3((unsigned)(n_waves < cap4 ? n_waves : cap4)), dim3(PPM_GPOS_THREADS), 0, s, c);
     }
     return hipGetLastError();
 }

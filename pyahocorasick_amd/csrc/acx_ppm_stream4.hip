@@ -104,7 +104,13 @@ template <> struct S4Cell<true> { typedef u32x3a type; };
 __device__ __forceinline__ uint32_t s4_cell_id(const u32x2& c) { return c.y; }      // (8-byte cells: the second word is the id where it is no value)
 __device__ __forceinline__ uint32_t s4_cell_id(const u32x3a& c) { return c.z; }
 
-template <bool H12>
+// OFFS: the batch is an offsets batch (acx_ppm_args.off) instead of a fixed stride.  Then the symbols a key may use end at the START of the
+// position's haystack, and the starts arrive as a bitmap (start_bits: bit p = a haystack starts at byte p; one word per lane and tile, loaded
+// with the tile's bytes) that shares a word array with the bytes of no key: a bit at position x of `obits` says "what a key that ends at or
+// behind x may use begins at x" — a start at x, or a byte of no key at x - 1 — and the limit of an entry is its distance to the last such bit
+// (other_limit; fixed strides keep the cheaper form: a multiply for the offset in the haystack, the bits only where bytes of no key are
+// around).  The records carry global positions as ever; k_ppm_gather_pos<true> finds their haystacks in the offsets.
+template <bool H12, bool OFFS>
 __global__ void __launch_bounds__(ACX_PPM_BLOCK) k_ppm_stream4(const acx_ppm_args a) {
     extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
     {
@@ -129,8 +135,10 @@ __global__ void __launch_bounds__(ACX_PPM_BLOCK) k_ppm_stream4(const acx_ppm_arg
 
     // the batch: H bytes, cut into tiles; a wave takes a contiguous run of them (k_ppm_gather_pos counts on exactly this cut)
     const uint32_t stride = (uint32_t)a.stride, m24 = a.m24;
-    const uint32_t H = (uint32_t)(a.n_hay * a.stride - 1) + 1u;       // (the launcher checks the size)
-    const uint32_t n_tiles = (uint32_t)(((int64_t)H + S4_TPOS - 1) / S4_TPOS);
+    uint32_t H;                                                        // (the launcher checks the size)
+    if (OFFS) { const int64_t hb = a.off[a.n_hay]; H = (uint32_t)(hb < a.hay_cap ? hb : a.hay_cap); } else H = (uint32_t)(a.n_hay * a.stride - 1) + 1u;
+    const uint32_t lo_pos = OFFS ? (uint32_t)a.off[0] : 0u;            // (bytes in front of the first haystack belong to none)
+    const uint32_t n_tiles = OFFS ? (uint32_t)a.n_items : (uint32_t)(((int64_t)H + S4_TPOS - 1) / S4_TPOS);      // (offsets: the host's count — it sized the grid and the gather's runs by the buffer)
     const uint32_t n_waves = gridDim.x * ACX_PPM_WAVES;
     const uint32_t tpw = (n_tiles + n_waves - 1) / n_waves;
     const uint32_t wave_id = blockIdx.x * ACX_PPM_WAVES + wid;
@@ -154,13 +162,18 @@ __global__ void __launch_bounds__(ACX_PPM_BLOCK) k_ppm_stream4(const acx_ppm_arg
         const uint32_t d = __builtin_amdgcn_perm(0u, ar_lut, x) ^ w;
         return ((d & 0xFFu) ? 1u : 0u) | ((d & 0xFF00u) ? 2u : 0u) | ((d & 0xFF0000u) ? 4u : 0u) | ((d >> 24) ? 8u : 0u);
     };
-    // symbols that exist going back from staged position q when bytes of no key are around (as k_ppm_stream)
+    // symbols that exist going back from staged position q when bytes of no key (OFFS: or haystack starts) are around.  A key has at most
+    // 33 letters (acx_ppm_stream4_eligible): the word of q and the one in front of it hold every bit that can matter — no loop over words
+    // (an offsets batch asks this of EVERY entry, and its last start lies a haystack's length back: the loop was a fifth of the kernel).
+    // q >= 32 (a tile's positions start behind the halo word), so the word in front exists.
     auto other_limit = [&](uint32_t q) -> uint32_t {
-        uint32_t w = q >> 5;
-        uint32_t m = obits[w] & (0xFFFFFFFFu >> (31u - (q & 31u)));
-        while (m == 0u && w > 0u) m = obits[--w];
-        const uint32_t last = m ? 32u * w + (31u - (uint32_t)__clz(m)) + 1u : 0u;
-        return q + 1 - last;
+        const uint32_t w = q >> 5;
+        const uint32_t m1 = obits[w - 1u];
+        const uint32_t m0 = obits[w] & (0xFFFFFFFFu >> (31u - (q & 31u)));
+        const unsigned long long v = ((unsigned long long)m0 << 32) | m1;
+        // the last bit at or in front of q: position 32 (w - 1) + 63 - clz; OFFS: that position is the first usable one, else the one behind it
+        const uint32_t last = 32u * (w - 1u) + 63u - (uint32_t)__builtin_clzll(v | 1ull) + (OFFS ? 0u : 1u);
+        return v ? q + 1u - last : 64u;
     };
 
     // ---- prologue: the halo of the run's first tile ---------------------------------------------------
@@ -177,9 +190,19 @@ __global__ void __launch_bounds__(ACX_PPM_BLOCK) k_ppm_stream4(const acx_ppm_arg
         }
         if (__any(nib != 0)) any_prev = 1;
     }
-    uint32_t r_tile;
-    { uint32_t rr0; (void)div_magic(e0, a.stride_magic, stride, rr0); r_tile = (uint32_t)__builtin_amdgcn_readfirstlane((int)rr0); }
-    const uint32_t step_r = S4_TPOS % stride;
+    uint32_t o_carry = 0;                                              // OFFS: which bytes of the 32 in front of the tile occur in no key (bit 31: the byte in front of the tile's first)
+    if (OFFS) {
+        wave_sync();
+        if (e0 > 0) {
+            o_carry = (uint32_t)__builtin_amdgcn_readfirstlane((int)obits[0]);
+            wave_sync();
+            if (lane == 0) obits[0] = (o_carry << 1) | a.start_bits[(e0 >> 5) - 1u];
+        }
+        any_prev = 1;
+    }
+    uint32_t r_tile = 0;
+    if (!OFFS) { uint32_t rr0; (void)div_magic(e0, a.stride_magic, stride, rr0); r_tile = (uint32_t)__builtin_amdgcn_readfirstlane((int)rr0); }
+    const uint32_t step_r = OFFS ? 0u : S4_TPOS % stride;
 
     // a lane's 32 bytes of a tile (read once: they need not stay in the caches)
     u32x4 wn0 = {0, 0, 0, 0}, wn1 = {0, 0, 0, 0};                      // (two register quadruples, as the two loads fill them: tools/s4_waits.sh — eight scalars made the compiler copy a loaded register, i.e. wait for the load it had just issued)
@@ -201,7 +224,11 @@ __global__ void __launch_bounds__(ACX_PPM_BLOCK) k_ppm_stream4(const acx_ppm_arg
     // (a tile whose 2048 bytes lie inside the buffer: no checks)
     const uint32_t full_end = a.hay_cap >= (int64_t)S4_TPOS ? (uint32_t)((a.hay_cap < 0xFFFFFFFFll ? a.hay_cap : 0xFFFFFFFFll) - S4_TPOS) : 0u;
     const bool any_full = a.hay_cap >= (int64_t)S4_TPOS;
-    auto load_tile = [&](uint32_t e) { if (any_full && e <= full_end) load_lane_full(e + 32u * lane); else load_lane(e + 32u * lane); };
+    uint32_t wsb = 0;                                                  // OFFS: the lane's word of the start bitmap, requested with the tile's bytes
+    auto load_tile = [&](uint32_t e) {
+        if (any_full && e <= full_end) load_lane_full(e + 32u * lane); else load_lane(e + 32u * lane);
+        if (OFFS) wsb = a.start_bits[(e >> 5) + lane];
+    };
     load_tile(e0);
 
     // the wave's record stream
@@ -236,6 +263,7 @@ __global__ void __launch_bounds__(ACX_PPM_BLOCK) k_ppm_stream4(const acx_ppm_arg
     bool tile_ok = true;
     uint32_t pw = 0, x_ex = 0, x_tot = 0, seg_lo = 0, use_other = 0, any_cur = 0;
     uint32_t Wc1 = 0, Wc2 = 0, anyo_c = 0;                             // the symbols of the tile that is being staged, which of its bytes occur in no key
+    uint32_t Bc = 0;                                                   // OFFS: its word of `obits` (starts | bytes of no key, one position on)
     // ONE set of slot registers: step 1 is the last reader of a round's hot cells, step 3 loads the next round's into the
     // same registers (a second set would have to be copied into the first, and a copy of a loaded register is a wait)
     typedef typename S4Cell<H12>::type cell_t;
@@ -264,6 +292,12 @@ __global__ void __launch_bounds__(ACX_PPM_BLOCK) k_ppm_stream4(const acx_ppm_arg
 #pragma unroll
             for (int j = 0; j < 8; j++) anyo_c |= nib_of(j < 4 ? wn0[j] : wn1[j - 4]) << (4 * j);
         }
+        if (OFFS) {
+            // the byte of no key in front of a lane's first position: the last bit of the lane before it (lane 0: of the tile before)
+            const uint32_t before = (uint32_t)__builtin_amdgcn_update_dpp((int)o_carry, (int)anyo_c, 0x138, 0xF, 0xF, false);
+            o_carry = (uint32_t)__builtin_amdgcn_readlane((int)anyo_c, 63);
+            Bc = (anyo_c << 1) | (before >> 31) | wsb;
+        }
         if (more) load_tile(e_next);
     };
     wave_sync();
@@ -275,9 +309,10 @@ __global__ void __launch_bounds__(ACX_PPM_BLOCK) k_ppm_stream4(const acx_ppm_arg
         const uint32_t npos = left < S4_TPOS ? left : S4_TPOS;
         const uint32_t W1 = Wc1, W2 = Wc2, anyo = anyo_c;
         { u32x2 v; v.x = W1; v.y = W2; *(u32x2*)(sym_tile + 2u * lane) = v; }
-        any_cur = __any(anyo != 0) ? 1u : 0u;
+        any_cur = OFFS ? 1u : (__any(anyo != 0) ? 1u : 0u);
         use_other = any_cur | any_prev;
-        if (use_other) {
+        if (OFFS) obits_tile[lane] = Bc;
+        else if (use_other) {
             obits_tile[lane] = anyo;
             if (!any_prev && lane == 0) obits[0] = 0;                    // (the tile before left no such bits, and a queue may have been there)
         }
@@ -317,6 +352,10 @@ __global__ void __launch_bounds__(ACX_PPM_BLOCK) k_ppm_stream4(const acx_ppm_arg
             const uint32_t lp = 32u * lane;
             const uint32_t nv = npos > lp ? (npos - lp < 32u ? npos - lp : 32u) : 0u;
             pw &= (nv >= 32u ? 0xFFFFFFFFu : (1u << nv) - 1u) & ~anyo;      // (a byte of no key ends no key)
+            if (OFFS && e0 < lo_pos) {                                   // (bytes in front of the first haystack)
+                const uint32_t cut = lo_pos - e0;
+                pw &= cut >= lp + 32u ? 0u : (cut > lp ? ~((1u << (cut - lp)) - 1u) : 0xFFFFFFFFu);
+            }
         }
         S4_TP(9);
         S4_MARK(M_PREFIX);
@@ -342,6 +381,7 @@ __global__ void __launch_bounds__(ACX_PPM_BLOCK) k_ppm_stream4(const acx_ppm_arg
         // off in the next trip, the waits land where those registers are next WRITTEN — behind the record stores of step 2 and the
         // loads of step 3, as waits for the stores' completion and for the loads just issued (tools/s4_waits.sh lists them).
         asm volatile("" : "+v"(wn0), "+v"(wn1));
+        if (OFFS) asm volatile("" : "+v"(wsb));
 #pragma unroll
         for (int e = 0; e < S4_NE; e++) asm volatile("" : "+v"(hcO[e]));
         // ---- 1. the round fetched one trip earlier: top levels, deeper walks -----------------------------------------------
@@ -647,10 +687,13 @@ __global__ void __launch_bounds__(ACX_PPM_BLOCK) k_ppm_stream4(const acx_ppm_arg
                     const uint32_t ent = lds_rd16(qaddr + 128u * (uint32_t)e);      // position + 33
                     // 1 + the offset in its haystack = x1 - stride * floor((x1 - 1) / stride), the quotient by a 24-bit multiply
                     // (exact while x1 - 1 < stride + 2048)
-                    const uint32_t x1 = ent + cx1;
-                    const uint32_t q = ((uint32_t)__umul24(x1, m24) + nm24) >> 23;
-                    const uint32_t L0 = x1 - (uint32_t)__umul24(q, stride);
-                    const uint32_t L = L0 < LL[e] ? L0 : LL[e];
+                    uint32_t L = LL[e];
+                    if (!OFFS) {
+                        const uint32_t x1 = ent + cx1;
+                        const uint32_t q = ((uint32_t)__umul24(x1, m24) + nm24) >> 23;
+                        const uint32_t L0 = x1 - (uint32_t)__umul24(q, stride);
+                        L = L0 < LL[e] ? L0 : LL[e];
+                    }
                     // the 32 bits of symbols that end with the entry's position: words (ent >> 4) + 1 and + 2 of the symbol buffer
                     const uint32_t wa = ((ent >> 2) & 0x7FCu) + sbase;
                     const uint32_t X = __builtin_amdgcn_alignbit(lds_rd32(wa + 8u), lds_rd32(wa + 4u), ent << 1);
@@ -719,15 +762,21 @@ __global__ void __launch_bounds__(ACX_PPM_BLOCK) k_ppm_stream4(const acx_ppm_arg
 }  // namespace
 
 // Does k_ppm_stream4 take this scan?  (acx_ppm_args as scan_ppm filled them for the stream kernels.)
-bool acx_ppm_stream4_eligible(const acx_ppm_args& a) {
-    return a.fast && a.hot4 && (a.cid || a.hot12) && !a.off && !a.skip && a.m24 && a.stride >= 8 && a.stride < 2048 &&
+static bool s4_image_ok(const acx_ppm_args& a) {
+    return a.fast && a.hot4 && (a.cid || a.hot12) && !a.skip &&
            a.sym_bits == 2 && a.pow2 && a.sym_arith != 0 && a.K == 4 && !a.g_global && !a.F2 && a.nsub == 8 &&
            a.C == S4_C && a.F == S4_F && a.halo_pos == S4_HP && a.longest <= S4_HP + 1u && a.g_words * 4u == S4_G_BYTES;
 }
+bool acx_ppm_stream4_eligible(const acx_ppm_args& a) {
+    if (a.off) return a.start_bits != nullptr && s4_image_ok(a);      // (an offsets batch: scan_ppm made the start bitmap because acx_ppm_stream4_offs_ok said yes)
+    return s4_image_ok(a) && a.m24 && a.stride >= 8 && a.stride < 2048;
+}
+// ... an offsets batch (before its start bitmap exists)?
+bool acx_ppm_stream4_offs_ok(const acx_ppm_args& a) { return a.off != nullptr && s4_image_ok(a); }
 
 hipError_t acx_launch_ppm_stream4(const acx_ppm_args& a, int64_t blocks, hipStream_t s) {
     const size_t lds_bytes = S4_G_BYTES + 16u * S4_WAVE_BYTES;
-    auto kernel = a.hot12 ? k_ppm_stream4<true> : k_ppm_stream4<false>;
+    auto kernel = a.off ? (a.hot12 ? k_ppm_stream4<true, true> : k_ppm_stream4<false, true>) : (a.hot12 ? k_ppm_stream4<true, false> : k_ppm_stream4<false, false>);
     hipError_t e = hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(kernel, dim3((unsigned)blocks), dim3(ACX_PPM_BLOCK), lds_bytes, s, a);

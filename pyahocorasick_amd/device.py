@@ -135,7 +135,7 @@ class Image:
 
     def ppm_kernel(self, stride=0, has_offsets=False, variant=0, dev_hay=0x1000, n_hay=1, min_hay_len=0, mode=ACX_SCAN_ALL):
         """which kernel family a scan of such a batch takes (acx_scan_plan): None = the serial walks, "scan" = k_ppm_scan,
-        "stream" = k_ppm_stream, "stream4" = k_ppm_stream4 (four letters, fixed stride); mode ACX_SCAN_LONG: the family that
+        "stream" = k_ppm_stream, "stream4" = k_ppm_stream4 (four letters; fixed stride or offsets); mode ACX_SCAN_LONG: the family that
         scans the dictionary of the position-parallel iter_long (acx_long.cpp), None = the serial walk"""
         p = ScanParams()
         p.struct_bytes = C.sizeof(ScanParams)

@@ -59,18 +59,24 @@ def test_min_hay_len_promise_broken_is_detected_and_rescanned():
     lens = [200] * 50 + [3] + [200] * 50
     off = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
     flat = np.ascontiguousarray(alpha[rng.integers(0, 4, size=int(off[-1]))])
-    img = _check(A, O, flat, off, min_hay_len=8)
-    assert img.ppm_kernel(stride=0, has_offsets=True, variant=0, min_hay_len=8, dev_hay=0, n_hay=len(lens)) == "stream"
+    GENERAL = 1 << 19         # the general stream kernel (k_ppm_stream's offsets form: starts through the queue, the promise checked) instead of k_ppm_stream4's
+    img = _check(A, O, flat, off, min_hay_len=8, variant=GENERAL)
+    assert img.ppm_kernel(stride=0, has_offsets=True, variant=GENERAL, min_hay_len=8, dev_hay=0, n_hay=len(lens)) == "stream"
+    # (four letters, keys of up to 33: k_ppm_stream4's offsets form — the starts are a bitmap there, any lengths, no promise to break)
+    assert img.ppm_kernel(stride=0, has_offsets=True, variant=0, min_hay_len=8, dev_hay=0, n_hay=len(lens)) == "stream4"
+    _check(A, O, flat, off, min_hay_len=8)
     # (a') a few EMPTY haystacks: two starts at one position, nowhere near too many per tile — noticed as well
     lens = [200] * 20 + [0] + [200] * 20 + [0, 0] + [5] + [200] * 20 + [0]
     off = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
     flat = np.ascontiguousarray(alpha[rng.integers(0, 4, size=int(off[-1]))])
+    _check(A, O, flat, off, min_hay_len=8, variant=GENERAL)
     _check(A, O, flat, off, min_hay_len=8)
     # (b) thousands of 3-byte haystacks, still promising 8: more starts in a tile than the kernel has room for;
     # it raises its flag and the result comes from a second scan on the general kernels
     lens = [3] * 5000 + [300] * 20 + [1] * 3000 + [0] * 10 + [2] * 999
     off = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
     flat = np.ascontiguousarray(alpha[rng.integers(0, 4, size=int(off[-1]))])
+    _check(A, O, flat, off, min_hay_len=8, variant=GENERAL)
     _check(A, O, flat, off, min_hay_len=8)
     _check(A, O, flat, off, min_hay_len=0)
     # the same through the asynchronous entry
@@ -119,3 +125,34 @@ def test_one_scanner_through_batches_of_every_shape():
         moff, e, v, _ = sc.fetch()
         mo, oe, ov = O.batch(flat.tobytes(), off, 0)
         assert np.array_equal(moff, mo) and np.array_equal(e, oe) and np.array_equal(v, ov), (i, kind, n, L)
+
+
+def test_stream4_offsets_batches_one_scanner_many_batches():
+    """k_ppm_stream4's offsets form keeps a bitmap of the haystacks' starts per result; the gather of a scan zeroes the words its scan used, so that the
+    next scan of the same result scatters into a clean bitmap without a memset.  One Scanner, batches of different sizes and shapes one after the
+    other (a larger one in between makes the buffer grow), empty haystacks, bytes of no key — every offset and record against the oracle every time"""
+    rng = np.random.default_rng(77)
+    alpha = np.frombuffer(b"ACGT", dtype=np.uint8)
+    keys = list({bytes(alpha[rng.integers(0, 4, size=int(k))]) for k in rng.integers(3, 30, size=3000)})
+    A, O = build_pair(keys)
+    img = Image.from_automaton(A)
+    sc = Scanner(img)
+    shapes = [(3000, 100, 150, 0.0), (500, 0, 40, 0.02), (20000, 60, 300, 0.0), (3000, 100, 150, 0.0), (40, 2000, 9000, 0.001), (7000, 1, 90, 0.0)]
+    for n, lo, hi, p_other in shapes:
+        lens = rng.integers(lo, hi + 1, size=n, dtype=np.int64)
+        off = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+        flat = np.ascontiguousarray(alpha[rng.integers(0, 4, size=int(off[-1]))])
+        for h in rng.integers(0, n, size=n // 3):                        # plant keys
+            k = np.frombuffer(keys[int(rng.integers(0, len(keys)))], dtype=np.uint8)
+            if lens[h] >= len(k):
+                p = int(off[h] + rng.integers(0, lens[h] - len(k) + 1))
+                flat[p:p + len(k)] = k
+        if p_other:
+            flat[rng.random(len(flat)) < p_other] = ord("N")
+        assert img.ppm_kernel(stride=0, has_offsets=True, min_hay_len=8, dev_hay=0, n_hay=n) == "stream4"
+        d_hay = DeviceBuffer.from_numpy(flat, pad=64)
+        d_off = DeviceBuffer.from_numpy(off)
+        sc.scan(d_hay, len(flat), n, dev_off=d_off, min_hay_len=8)
+        moff, e, v, _ = sc.fetch()
+        mo, oe, ov = O.batch(flat.tobytes(), off, 0)
+        assert mo[-1] > 0 and np.array_equal(moff, mo) and np.array_equal(e, oe) and np.array_equal(v, ov), (n, lo, hi)

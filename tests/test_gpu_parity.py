@@ -363,10 +363,11 @@ def test_config5_iter_long_full_size(config2):
 
 @pytest.mark.slow
 def test_c2_offsets_full_size_every_record(config2):
-    """bench.py's `c2_offsets` workload — config 2's reads cut to ragged lengths U[100, 150], back to back, delivered by offsets: the
-    GENERAL stream kernel's offsets form (k_ppm_stream<2,8,..,OFFS>, haystack starts through the queue, k_ppm_wave_scan + k_ppm_gather) —
-    at full size, every offset and every record against the oracle (VERDICT r5 missing 6: it was only count-checked against its own
-    pre-pass)"""
+    """bench.py's `c2_offsets` workload — config 2's reads cut to ragged lengths U[100, 150], back to back, delivered by offsets:
+    k_ppm_stream4's offsets form (the haystacks' starts as a bitmap, k_ppm_gather_pos<true> finds the haystack of every record in the
+    offsets), and the GENERAL stream kernel's (variant bit 19: k_ppm_stream<2,8,..,OFFS>, starts through the queue, k_ppm_wave_scan +
+    k_ppm_gather) — at full size, every offset and every record against the oracle (VERDICT r5 missing 6: it was only count-checked
+    against its own pre-pass)"""
     keys, reads, A, img, d_hay = config2
     n, L = reads.shape
     lens = np.random.default_rng(1001).integers(100, L + 1, size=n, dtype=np.int64)       # (bench.make_batches, batch 0: seed 1000 + 1)
@@ -375,18 +376,19 @@ def test_c2_offsets_full_size_every_record(config2):
     off = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
     d_flat = DeviceBuffer.from_numpy(flat, pad=64)
     d_off = DeviceBuffer.from_numpy(off)
-    plan = img.ppm_kernel(stride=0, has_offsets=True, dev_hay=d_flat.ptr.value, n_hay=n, min_hay_len=100)
-    assert plan == "stream", plan
-    sc = Scanner(img)
-    total = sc.scan(d_flat, len(flat), n, dev_off=d_off, min_hay_len=100)
-    moff, e, v, _ = sc.fetch()
     O = orc.Oracle()
     for i, k in enumerate(keys):
         O.add_word(k, i)
     O.make_automaton()
     mo, oe, ov = O.batch_records(flat, off, 0)
-    assert total == mo[-1] and total > 7_000_000
-    assert np.array_equal(moff, mo) and np.array_equal(e, oe) and np.array_equal(v, ov)
+    for variant, want in ((0, "stream4"), (1 << 19, "stream")):
+        plan = img.ppm_kernel(stride=0, has_offsets=True, dev_hay=d_flat.ptr.value, n_hay=n, min_hay_len=100, variant=variant)
+        assert plan == want, plan
+        sc = Scanner(img)
+        total = sc.scan(d_flat, len(flat), n, dev_off=d_off, min_hay_len=100, variant=variant)
+        moff, e, v, _ = sc.fetch()
+        assert total == mo[-1] and total > 7_000_000
+        assert np.array_equal(moff, mo) and np.array_equal(e, oe) and np.array_equal(v, ov), variant
 
 
 @pytest.mark.slow
