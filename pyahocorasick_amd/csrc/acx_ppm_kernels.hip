@@ -1080,9 +1080,13 @@ __global__ void __launch_bounds__(ACX_PPM_BLOCK) k_ppm_stream(const acx_ppm_args
 __global__ void __launch_bounds__(256) k_ppm_start_bits(const int64_t* off, int64_t n_hay, uint32_t* bits, uint64_t n_bits) {
     const int64_t n_threads = (int64_t)gridDim.x * 256;
     const uint64_t end = (uint64_t)off[n_hay];
-    for (int64_t h = (int64_t)blockIdx.x * 256 + threadIdx.x; h < n_hay; h += n_threads) {
-        const uint64_t p = (uint64_t)off[h];
-        if (p < end && p < n_bits) atomicOr(bits + (p >> 5), 1u << (p & 31u));
+    // (four offsets in flight per thread: the kernel stands in front of the scan kernel, and its time is the latency of its loads and atomics)
+    for (int64_t h = (int64_t)blockIdx.x * 256 + threadIdx.x; h < n_hay; h += 4 * n_threads) {
+        uint64_t p[4];
+#pragma unroll
+        for (int j = 0; j < 4; j++) p[j] = h + j * n_threads < n_hay ? (uint64_t)off[h + j * n_threads] : ~0ull;
+#pragma unroll
+        for (int j = 0; j < 4; j++) if (p[j] < end && p[j] < n_bits) atomicOr(bits + (p[j] >> 5), 1u << (p[j] & 31u));
     }
 }
 
@@ -1603,8 +1607,8 @@ hipError_t acx_launch_ppm_start_bits(const int64_t* off, int64_t n_hay, uint32_t
         hipError_t e = hipMemsetAsync(bits, 0, n_words * sizeof(uint32_t), s);
         if (e != hipSuccess) return e;
     }
-    int64_t blocks = (n_hay + 255) / 256;
-    const int64_t cap = (int64_t)num_cus() * 16;
+    int64_t blocks = (n_hay + 1023) / 1024;
+    const int64_t cap = (int64_t)num_cus() * 8;
     if (blocks > cap) blocks = cap;
     if (blocks < 1) blocks = 1;
     hipLaunchKernelGGL(k_ppm_start_bits, dim3((unsigned)blocks), dim3(256), 0, s, off, n_hay, bits, (uint64_t)n_words * 32u);

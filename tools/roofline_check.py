@@ -93,8 +93,8 @@ def export(db, bench_path, out_path, config=None):
 
 # round 6: ONE trace of the driver's own command holds every configuration — their dominant kernels are different instantiations
 SIGNATURES = {
-    "headline": "k_ppm_stream4<false>", "c5_iter_long": "k_ppm_stream4<true>",
-    "c2_offsets": "k_ppm_stream<2, 8, true, true, false, true, false, 6>", "c2_long_keys": "k_ppm_stream<2, 8, true, false, false, true, true, 6>",
+    "headline": "k_ppm_stream4<false, false>", "c5_iter_long": "k_ppm_stream4<true, false>",
+    "c2_offsets": "k_ppm_stream4<false, true>", "c2_long_keys": "k_ppm_stream<2, 8, true, false, false, true, true, 6>",
     "c3": "k_ppm_stream<8, 8, false, true, false, false, false, 4>", "c4": "k_ppm_stream<8, 4, true, true, true, false, false, 4>",
 }
 UNION_LEG_LAUNCHES = 36          # bench.py measure(): 12 x P launches with event pairs BEHIND every timed region (P = 3 results in flight)

@@ -3,7 +3,7 @@
    inside the <false> kernel; the FIRST vmcnt wait behind that mark is dropped) or "M_REC:1:-1" (the LAST vmcnt wait of that region)"""
 import os, re, sys
 src = open(sys.argv[1]).read().split("\n")
-start = next(i for i, l in enumerate(src) if l.startswith("_ZN12_GLOBAL__N_113k_ppm_stream4ILb0EEEv12acx_ppm_args:"))
+start = next(i for i, l in enumerate(src) if l.startswith("_ZN12_GLOBAL__N_113k_ppm_stream4ILb0ELb0EEEv12acx_ppm_args:"))
 end = next(i for i in range(start, len(src)) if "s_endpgm" in src[i])
 marks = []   # (line, name)
 for i in range(start, end):

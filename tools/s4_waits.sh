@@ -9,7 +9,7 @@ python3 - <<'PY'
 import os, re
 src = open("build/isa/s4_mark.s").read().split("\n")
 # the kernel <false>: from its label to its s_endpgm
-start = next(i for i, l in enumerate(src) if l.startswith("_ZN12_GLOBAL__N_113k_ppm_stream4ILb" + os.environ.get("KERN", "0") + "EEEv12acx_ppm_args:"))
+start = next(i for i, l in enumerate(src) if l.startswith("_ZN12_GLOBAL__N_113k_ppm_stream4ILb" + os.environ.get("KERN", "0") + "ELb" + os.environ.get("OFFS", "0") + "EEEv12acx_ppm_args:"))
 end = next(i for i in range(start, len(src)) if "s_endpgm" in src[i])
 body = src[start:end + 1]
 open("build/isa/loop0.s", "w").write("\n".join(body))
@@ -24,4 +24,4 @@ for i, l in enumerate(body):
 for l in body:
     if re.search(r"\.(vgpr_count|sgpr_count|vgpr_spill_count|sgpr_spill_count)", l): print(l.strip())
 PY
-grep -A30 "k_ppm_stream4ILb${KERN:-0}EEEv12acx_ppm_args$" build/isa/s4_mark.s | grep -E "NumVgprs|NumSgprs|ScratchSize|Occupancy|spill" | head
+grep -A30 "k_ppm_stream4ILb${KERN:-0}ELb${OFFS:-0}EEEv12acx_ppm_args$" build/isa/s4_mark.s | grep -E "NumVgprs|NumSgprs|ScratchSize|Occupancy|spill" | head
