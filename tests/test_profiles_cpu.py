@@ -39,7 +39,7 @@ def test_committed_line_keeps_the_bench_contract():
         assert k in d, k
     assert d["n_gpus"] == 1 and d["higher_is_better"] is True and d["unit"] == "GB/s" and d["vs_baseline"] is None and "workload" in d["config"]
     r = d["roofline"]
-    assert r["bound"] == "hbm" and r["peak"] == 8000.0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9
+    assert r["bound"] == "hbm" and r["peak"] == 8000.0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 2e-5      # (the compact line rounds `achieved` to 0.1 GB/s and `frac` to five digits)
     assert r["traffic"] and r["traffic"] > r["algorithmic_bytes"]           # calibrated HBM bytes per launch: above the algorithmic ones
     assert abs(r["step"]["frac"] - r["step"]["algorithmic_bytes"] / (d["ms_per_step"] * 1e-3) / 1e9 / 8000.0) < 2e-3
     # value = bytes of one step / its time: config 2's 150 MB batches
