@@ -1276,7 +1276,7 @@ static int long_enqueue_sweep(acx_result* r, acx_image* img, hipStream_t g) {
         la.gtot = nullptr;
         la.compact = (r->pend_params.variant >> 27) & 1;                  // (A/B and the multi-way tests: the compact form of round 5)
         if (r->timed) HIP_TRY(hipEventRecord(r->ev[2], g));
-        if (!la.compact && !((r->pend_params.variant >> 28) & 1)) {
+        if (!la.compact && !((r->pend_params.variant >> 29) & 1)) {
             // the prefix sum and the move in one launch (acx_long.hip: k_long_place)
             const size_t groups = (n + 63) / 64;
             if ((rc = r->long_gtot.ensure(groups + 1))) return rc;
@@ -1284,7 +1284,7 @@ static int long_enqueue_sweep(acx_result* r, acx_image* img, hipStream_t g) {
             HIP_TRY(acx_launch_long_sweep(la, g));
             HIP_TRY(acx_launch_long_place(la, r->match_off.p, img->long_real, r->matches.p, g));
         } else {
-            // (variant bit 28, and the compact form: sweep in place, a three-launch prefix sum over the counts, a move; A/B and the multi-way tests)
+            // (variant bit 29, and the compact form: sweep in place, a three-launch prefix sum over the counts, a move; A/B and the multi-way tests)
             HIP_TRY(acx_launch_long_sweep(la, g));
             HIP_TRY(acx_launch_scan(r->counts.p, (int64_t)n, r->match_off.p, r->partials.p, g));
             HIP_TRY(acx_launch_long_move(la, r->match_off.p, img->long_real, r->matches.p, g));

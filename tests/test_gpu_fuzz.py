@@ -27,9 +27,10 @@ def test_fuzz_slice_fixed_seed():
 
 
 def test_fuzz_stream4_slice_fixed_seed():
-    """tools/fuzz_stream4.py: the batches k_ppm_stream4 takes (four-letter alphabets, fixed strides, keys of up to 33 letters;
-    bytes of no key, nested keys, dense dictionaries, runs of tiles per wave, index_base) against the oracle and k_ppm_stream;
-    every case checks that the plan names k_ppm_stream4"""
+    """tools/fuzz_stream4.py: the batches k_ppm_stream4 takes (four-letter alphabets, fixed strides and — every other case — the same reads
+    cut to ragged lengths as an offsets batch, empty haystacks included; keys of up to 33 letters; bytes of no key, nested keys, dense
+    dictionaries, runs of tiles per wave, index_base) against the oracle, k_ppm_stream and k_ppm_scan; every case checks that the plan
+    names k_ppm_stream4"""
     import fuzz_stream4
     rng = np.random.default_rng(424242)
     matches = 0

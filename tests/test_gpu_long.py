@@ -14,7 +14,7 @@ pytestmark = pytest.mark.gpu
 
 SERIAL = 1 << 25
 COMPACT = 1 << 27         # the sweep over compact records (round 5's form; round 6's default sweeps the raw records in LDS): A/B
-THREE_STEPS = 1 << 28    # sweep, prefix sum, move as three steps (round 6's default does them in one launch: k_long_sweep_place): A/B
+THREE_STEPS = 1 << 29    # sweep, three-launch prefix sum, move (round 6's default: prefix sum and move in one launch, k_long_place): A/B
 FUSED = 1 << 26           # the sweep straight from the scan's record pool (k_long_gather_sweep) instead of k_ppm_gather_pos + k_long_sweep: opt-in, slower (A/B)
 
 

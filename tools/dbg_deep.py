@@ -1,4 +1,4 @@
-"""stand-alone repro for k_ppm_stream4's deep stream: a small four-letter dictionary with keys beyond ten letters, fixed stride; the first
+"""stand-alone repro for k_ppm_stream4's deeper walks: a small four-letter dictionary with keys beyond ten letters, fixed stride; the first
 haystack whose records differ from the oracle's is printed.    python tools/dbg_deep.py [n_reads] [stride] [n_keys] [seed]"""
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))

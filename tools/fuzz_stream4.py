@@ -1,6 +1,7 @@
 """Randomised differential run of k_ppm_stream4 (acx_ppm_stream4.hip) on the GPU: four-letter alphabets that a shift tells
-apart, dictionaries whose image has C = 9 / F = 10, keys of at most 33 letters, fixed strides 8 .. 2047 — the batches the
-kernel takes — against the oracle and against k_ppm_stream (variant bit 19), with what the kernel has special paths for:
+apart, dictionaries whose image has C = 9 / F = 10, keys of at most 33 letters, fixed strides 8 .. 2047 and — every other case —
+the same reads cut to ragged lengths (empty ones too) as an OFFSETS batch — the batches the
+kernel takes — against the oracle and against k_ppm_stream (variant bit 19) / k_ppm_scan, with what the kernel has special paths for:
 bytes of no key, haystacks shorter than the longest key, many keys ending at one position (nested keys: the general
 enumeration), dense dictionaries (a tile holds more candidates than a round), batches large enough that every wave takes
 a run of tiles, index_base.  Every case asserts that the scan plan really names k_ppm_stream4.
@@ -65,7 +66,34 @@ def one_case(rng, trial):
         if not (np.array_equal(moff, mo) and np.array_equal(e, oe) and np.array_equal(v, ov)):
             raise SystemExit("MISMATCH trial %d variant %#x alphabet %r keys %d (%d..%d) n %d L %d foreign %s"
                              % (trial, variant, bytes(alpha), len(keys), kmin, kmax, n, L, foreign))
-    return len(oe)
+    total = len(oe)
+    if rng.random() < 0.5:
+        # the offsets form: the same reads cut to ragged lengths, back to back (k_ppm_start_bits, the limits from the start bitmap, k_ppm_gather_pos<true>)
+        lo = int(rng.choice([0, 1, 8, max(1, L // 2)]))
+        lens = rng.integers(lo, L + 1, size=n, dtype=np.int64)
+        if rng.random() < 0.3:
+            lens[rng.integers(0, n, size=max(1, n // 7))] = 0         # runs of empty haystacks
+        keep = np.arange(L, dtype=np.int64)[None, :] < lens[:, None]
+        flat2 = np.ascontiguousarray(reads[keep])
+        off2 = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+        if len(flat2) == 0:
+            return total
+        d_hay2 = DeviceBuffer.from_numpy(flat2, pad=64)
+        d_off2 = DeviceBuffer.from_numpy(off2)
+        if img.ppm_kernel(stride=0, has_offsets=True, min_hay_len=8, dev_hay=d_hay2.ptr.value, n_hay=n) != "stream4":
+            raise SystemExit("trial %d: the plan of the offsets batch is not stream4" % trial)
+        mo2, oe2, ov2 = O.batch(flat2.tobytes(), off2, 0)
+        if base is not None:
+            oe2 = oe2 + np.repeat(base, np.diff(mo2)).astype(np.int32)
+        for variant in (0, (1 << 24) | (1 << 28)):                   # k_ppm_stream4's offsets form; k_ppm_scan (any lengths)
+            sc = Scanner(img)
+            sc.scan(d_hay2, len(flat2), n, dev_off=d_off2, dev_index_base=d_base, min_hay_len=8 if variant == 0 else 0, variant=variant)
+            moff, e, v, _ = sc.fetch()
+            if not (np.array_equal(moff, mo2) and np.array_equal(e, oe2) and np.array_equal(v, ov2)):
+                raise SystemExit("MISMATCH (offsets) trial %d variant %#x alphabet %r keys %d (%d..%d) n %d L %d lo %d foreign %s"
+                                 % (trial, variant, bytes(alpha), len(keys), kmin, kmax, n, L, lo, foreign))
+        total += len(oe2)
+    return total
 
 
 def main():
