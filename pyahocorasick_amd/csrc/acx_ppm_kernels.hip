@@ -1548,6 +1548,9 @@ hipError_t acx_launch_ppm_scan(const acx_ppm_args& a, int64_t n_items_bound, hip
 #ifdef ACX_PPM_DEV_C4   /* ... and config 4's (a million signatures, offsets batch, global filter + its hashed copy) */
         if (a.sym_bits == 8 && a.g_global && a.nsub == 4 && offs && p2) return launch(k_ppm_stream<8, 4, true, true, true, false, false, 4>);
 #endif
+#ifdef ACX_PPM_DEV_C3   /* ... and config 3's (100 k text keys, one long haystack as an offsets batch of one, the filter in LDS) */
+        if (a.sym_bits == 8 && !a.g_global && a.nsub == 8 && offs && !p2) return launch(k_ppm_stream<8, 8, false, true, false, false, false, 4>);
+#endif
         return hipErrorInvalidValue;
 #else
         if (a.sym_bits == 8) {
