@@ -76,7 +76,7 @@
 #define ACX_ITOP_FLAG_TFLAGS_ID 2u
 
 #define ACX_BLOB_MAGIC        0x31424F4C42584341ull   /* "ACXBLOB1" */
-#define ACX_BLOB_VERSION      4u          /* 4: "PPM5" (deep records of up to 48 / sym_bits symbols); 3: the "PPM4" section (PPM3 + hot4 / cid for four-letter alphabets); 2: the checksum below, "PPM3" */
+#define ACX_BLOB_VERSION      5u          /* 5: "PPM6" (hot4: the path below a one-child cell); 4: "PPM5" (deep records of up to 48 / sym_bits symbols); 3: the "PPM4" section (PPM3 + hot4 / cid for four-letter alphabets); 2: the checksum below, "PPM3" */
 #define ACX_BLOB_HEADER_BYTES 256u
 #define ACX_BLOB_ALIGN        256u
 
@@ -215,7 +215,7 @@ typedef struct acx_blob_header {
  *   node has children.
  * All section offsets are relative to the start of the acx_ppm_header.
  */
-#define ACX_PPM_MAGIC 0x354D5050u   /* "PPM5" */
+#define ACX_PPM_MAGIC 0x364D5050u   /* "PPM6" */
 #define ACX_PPM_MAX_C 20
 /* gh: a filter that lives in global memory (g_global: 2^24 bits for three 8-bit symbols) costs one L2 request per position.
  * gh is a hashed copy of it that LDS can hold: bit acx_ppm_gh_index(code_F) is set for every code whose bit of G is set, so a

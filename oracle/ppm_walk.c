@@ -168,7 +168,14 @@ int64_t ppm_check_hot(const uint8_t* blob) {
             for (uint32_t s1 = 0; s1 < 4; s1++)
                 for (uint32_t s2 = 0; s2 < 4; s2++)
                     if (cell[1] && (((cell[2] >> (4 + s1)) & 1u) || ((cell[2] >> (8 + 4 * s1 + s2)) & 1u))) go |= 1u << (4 * s1 + s2);
-            int ok = hot4[w * c] == (cell[0] | go << 16) && (cell[0] >> 16) == 0 && (cid ? cid[c] : hot4[w * c + 2]) == cell[1];
+            uint32_t xw = cell[0] | go << 16;
+            if ((cell[1] >> 31) && h.C <= 9) {                          /* one child: the path of its single record (bit 13; its symbols; the shift that keeps as many as it has, up to 7) instead of the 16 bits */
+                const uint32_t* rec = (const uint32_t*)(sec + h.off_chains) + (size_t)(cell[1] & 0x7FFFFFFFu) * 4;
+                const uint32_t len = rec[1] & 0xFFu, np = len < 7u ? len : 7u;
+                xw = cell[0] | (14u - 2u * np) << 9 | 1u << 13 | (rec[0] >> 18) << 16;
+                if (np == 0 || !(rec[1] & 0x200u)) bad++;
+            }
+            int ok = hot4[w * c] == xw && (cell[0] >> 16) == 0 && (cid ? cid[c] : hot4[w * c + 2]) == cell[1];
             if (cid) ok = ok && hot4[2 * c + 1] == (cell[0] ? cell[3] : cell[1]);
             else ok = ok && hot4[3 * c + 1] == (cell[0] ? cell[3] : 0u);
             ok = ok && ((go != 0) == (cell[1] != 0));

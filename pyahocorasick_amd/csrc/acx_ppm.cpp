@@ -571,12 +571,22 @@ int acx_ppm_build(const acx_trie* t, const uint8_t* cls, uint32_t n_classes, boo
             if (hot4) {                                                  // include/acx_blob.h "hot4": the value where a key ends, the id elsewhere
                 uint32_t go = 0;
                 if (cell[1]) for (uint32_t t4 = 0; t4 < 16; t4++) if (((cell[2] >> (4 + (t4 >> 2))) | (cell[2] >> (8 + t4))) & 1u) go |= 1u << t4;
+                uint32_t xw = mask | go << 16;
+                if ((cell[1] >> 31) && C <= 9) {                         // (bits 9 .. 12 are free of the mask: what k_ppm_stream4 reads has C = 9)
+                    // the depth-C node has ONE child (its id is a single's): everything below it begins with the unbranched, key-free path of its
+                    // record — bit 13, the path's symbols (at most seven: what the entry's window still holds; bits 16 .. 29, the first on top) instead of the
+                    // 16 bits, and in bits 9 .. 12 how far to shift the 14 bits right to keep the path's own; the walk goes deeper iff the text agrees with
+                    // all of them (include/acx_blob.h "hot4")
+                    const uint32_t* rec = singles + (size_t)(cell[1] & 0x7FFFFFFFu) * 4;
+                    const uint32_t len = rec[1] & 0xFFu, np = len < 7u ? len : 7u;
+                    xw = mask | (14u - 2u * np) << 9 | 1u << 13 | (rec[0] >> 18) << 16;
+                }
                 if (cid) {
-                    hot4[cc * 2] = mask | go << 16;
+                    hot4[cc * 2] = xw;
                     hot4[cc * 2 + 1] = mask ? cell[3] : cell[1];
                     cid[cc] = cell[1];
                 } else {                                                 // 12-byte cells: the value AND the id
-                    hot4[cc * 3] = mask | go << 16;
+                    hot4[cc * 3] = xw;
                     hot4[cc * 3 + 1] = mask ? cell[3] : 0u;
                     hot4[cc * 3 + 2] = cell[1];
                 }

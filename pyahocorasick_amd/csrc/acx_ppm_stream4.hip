@@ -268,7 +268,7 @@ __global__ void __launch_bounds__(ACX_PPM_BLOCK) k_ppm_stream4(const acx_ppm_arg
     // same registers (a second set would have to be copied into the first, and a copy of a loaded register is a wait)
     typedef typename S4Cell<H12>::type cell_t;
     cell_t hcO[S4_NE];                                                 // (H12: .z = the id of the depth-C node)
-    uint32_t ppO[S4_NE];                                               // entry (position + 33) | symbols that exist << 12 | (16 + the next two symbols) << 18
+    uint32_t ppO[S4_NE];                                               // entry (position + 33) | symbols that exist << 12 | the seven symbols below the cell's << 18
     uint32_t nO = 0, nN = 0, cgO = 0, cgN = 0, symO = wbase, symN = wbase;
     bool haveO = false;
 #pragma unroll
@@ -404,7 +404,13 @@ __global__ void __launch_bounds__(ACX_PPM_BLOCK) k_ppm_stream4(const acx_ppm_arg
                 const uint32_t m = hw & ((1u << Lc) - 1u);
                 cn[e] = (uint32_t)__popc(m);
                 // the walk below the cell: bit 16 + (next two symbols) — asked whatever L is: a walk that runs out of symbols ends at once
-                const uint32_t g = __builtin_amdgcn_ubfe(hw, pk >> 18, 1u);
+                // (a cell whose node has one child holds that child's unbranched path — up to seven symbols — instead of the 16 bits: the walk goes deeper
+                //  iff the text agrees with all of them; three futile walkers in four came from such cells, the text agreeing with two symbols by chance)
+                const uint32_t t14 = pk >> 18;
+                const uint32_t g_many = __builtin_amdgcn_ubfe(hw, 16u + (t14 >> 10), 1u);
+                const uint32_t g_one = ((t14 ^ (hw >> 16)) >> __builtin_amdgcn_ubfe(hw, 9u, 4u)) == 0u ? 1u : 0u;      // (bits 30, 31 of the cell's word are zero there)
+                uint32_t g = (hw & 0x2000u) ? g_one : g_many;
+                if (ACX_S4_EXP & 8192) g &= (((pk & 0xFFFu) * 2654435761u) >> 30) == 0u ? 1u : 0u;      // (timing only: three walkers in four dropped — what a go field over three symbols could give)
                 gomask |= g << e; n_go += g;
                 va[e] = (int32_t)hcO[e].y;
                 cmax = cn[e] > cmax ? cn[e] : cmax;
@@ -703,8 +709,8 @@ __global__ void __launch_bounds__(ACX_PPM_BLOCK) k_ppm_stream4(const acx_ppm_arg
                         hcO[e] = *(const u32x3a*)((const uint8_t*)a.hot4 + o12);
                     } else
                     hcO[e] = *(const u32x2*)((const uint8_t*)a.hot4 + ((ACX_S4_EXP & 1) ? ((qi < n ? off : 0u) & 56u) : (qi < n ? off : (8u << (2u * S4_C)))));
-                    const uint32_t t5 = __builtin_amdgcn_ubfe(X, 32u - 2u * (S4_C + 2u), 4u) | 16u;     // 16 + the next two symbols: the cell's "go deeper" bit
-                    ppO[e] = ent | (L << 12) | (t5 << 18);
+                    const uint32_t t14 = __builtin_amdgcn_ubfe(X, 32u - 2u * (S4_C + 7u), 14u);         // the seven symbols below the cell's (the first in the top bits): what the cell's "go deeper" field is asked about
+                    ppO[e] = ent | (L << 12) | (t14 << 18);
                 )
                 wave_sync();                                         // (the queue's memory is free from here on)
                 nN = n; cgN = e0 - 33u; symN = sbase; haveN = true;
