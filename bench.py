@@ -109,6 +109,14 @@ def parse():
                          "streams): with 2 x 2 the host queues scan k + 2 only when gather k has completed, and the union of the scan "
                          "kernel's launch spans covered 90 %% of the timed region (profiles/r5b_c2_spans.json: 239.8 of 267.3 us per "
                          "step); profiles/r5c_pipeline_sweep.txt: 2 x 2 565.7, 3 x 3 580.1, 4 x 2 536.3, 4 x 4 557.9, 6 x 2 567.4, 6 x 3 578.4 GB/s")
+    ap.add_argument("--long-depth", type=int, default=0,
+                    help="iter_long: result objects in flight AND scan streams (instead of --pipeline / --scan-streams).  A step of iter_long is a scan kernel and "
+                         "four smaller ones behind it (gather, sweep, placement) that find CUs only in the tails of the scan kernels: with more batches in "
+                         "flight the tails are fuller.  tools/r6_depth.sh (alone in its process): 3 -> 248.9, 4 -> 255.5, 5 -> 257.4, 6 -> 258.4 GB/s; the "
+                         "headline and c2_offsets are best at 3 (629.8 / 529.7 against 529-564 / 491-500 at 4-6).  Behind the headline and the host-path legs "
+                         "of the default command config 5 moves by +-4 %% from run to run at ANY depth (profiles/r6_line_runs.txt: 238-257; which hardware "
+                         "queues its streams share).  Default 0 = as --pipeline / --scan-streams: with 5 or 6 results in flight behind the headline TWO of "
+                         "fourteen default-command runs died of a GPU memory fault inside this configuration (none in dozens at 3; not found: DESIGN.md 8)")
     ap.add_argument("--event-every", type=int, default=4,
                     help="bracket the dominant kernel by HIP events in every N-th timed step (0: in none).  Two event records cost "
                          "the stream about 19 us of idle time per step they are in (config 2: 442 GB/s with events in every step, "
@@ -430,6 +438,8 @@ def make_batches(torch, dev, workload, keys, vocab, n_batches, reads, read_len, 
 
 
 SCAN_STREAMS = 3
+LONG_DEPTH = 0                          # --long-depth: results in flight and scan streams of an iter_long measurement (0: as the others)
+ACX_LONG_MODE = None                    # acx.ACX_SCAN_LONG once the package is imported (main)
 _SCAN_STREAMS = []                      # the process's extra scan streams (measure())
 MIN_TIMED_MS = 250.0
 
@@ -448,12 +458,14 @@ def measure(torch, dist, dev, image, batches, mode, steps, warmup, P, event_ever
     # (iter_long in its position-parallel form — a scan over the dictionary of acx_long.cpp + one sweep — honours ACX_SCAN_ASYNC since
     #  round 5: scan kernel on the caller's stream, gather and sweep behind it on a side stream; the serial walk, many small blocks
     #  that share every CU, lost 2 % on two streams)
-    n_streams = min(SCAN_STREAMS, P)
+    n_streams = P if (LONG_DEPTH and mode == ACX_LONG_MODE) else min(SCAN_STREAMS, P)
     # The scan streams are made ONCE per process and shared by every configuration it measures: which hardware queue a stream gets depends on
     # the order in which the process made its streams, and a configuration whose gather overlaps its scans for most of a step is sensitive to
     # WHICH queues its streams share — `c2_long_keys` ran at 607 / 646 / 703 GB/s behind the headline alone / in a process of its own / behind
     # `c2_offsets` while every measure() made two streams of its own (round 6).  Shared streams: the line's entries are what a process of their
     # own gives (tools/roofline_check.py compares them with traces of exactly that).
+    # (iter_long's further streams (--long-depth) are made when it is measured: made at the process's first measurement they cost config 5 more —
+    #  237.9 / 249.3 / 243.8 GB/s in three lines against 251.9 / 254.9 / 248.6, profiles/r6_line_runs.txt)
     while len(_SCAN_STREAMS) < max(0, n_streams - 1):
         _SCAN_STREAMS.append(torch.cuda.Stream())
     extra = _SCAN_STREAMS[:max(0, n_streams - 1)]
@@ -706,9 +718,16 @@ def roofline_entry(image, batches, m, mode_name, workload, variant, event_every)
     }
 
 
+def _progress(what):
+    """ACX_BENCH_PROGRESS=1: which leg the process is in, to stderr (a leg that dies says nothing else)"""
+    if os.environ.get("ACX_BENCH_PROGRESS"):
+        print("[bench] " + what, file=sys.stderr, flush=True)
+
+
 def other_config(torch, dev, acx, name, workload, mode_name, keys, vocab, image, batches, host0, args, n_keys, batch_mb, cpu_sample):
     """one of the other named single-GPU configurations, measured like the headline (fewer batches and steps)"""
     from pyahocorasick_amd.device import Image
+    _progress("config " + name)
     t0 = time.perf_counter()
     t_build = None
     if image is None:
@@ -727,11 +746,12 @@ def other_config(torch, dev, acx, name, workload, mode_name, keys, vocab, image,
     t_stage = time.perf_counter() - t0
     mode = acx.ACX_SCAN_ALL if mode_name == "iter" else acx.ACX_SCAN_LONG
     steps = max(8, min(args.steps, 20))
-    m = measure(torch, None, dev, image, batches, mode, steps, 2, max(1, args.pipeline), args.event_every, 0, args.inner_repeats)
+    depth = args.long_depth if (mode_name == "iter_long" and args.long_depth > 0) else max(1, args.pipeline)
+    m = measure(torch, None, dev, image, batches, mode, steps, 2, depth, args.event_every, 0, args.inner_repeats)
     out = {
         "value": m["bytes_rank"] / m["dt"] / 1e9, "unit": "GB/s", "ms_per_step": m["dt"] / m["passes"] * 1e3, "steps": steps,
         "inner_repeats": m["repeats"], "timed_region_ms": round(m["dt"] * 1e3, 3),
-        "ms_per_step_synchronous": m["sync_ms"], "step_ms_host_intervals": m["step_ms"], "scan_streams": m["scan_streams"],
+        "ms_per_step_synchronous": m["sync_ms"], "step_ms_host_intervals": m["step_ms"], "scan_streams": m["scan_streams"], "results_in_flight": depth,
         "matches_per_step": m["matches_rank"] / m["passes"],
         "workload": (WORKLOAD_NAMES[workload] % ((n_keys, args.reads, args.read_len) if workload.startswith("c2") else (n_keys, batch_mb)))
                     + ", Automaton.%s; %d distinct batches rotated (%.0f MB resident)" % (mode_name, len(batches), sum(b[1] for b in batches) / 1e6),
@@ -801,7 +821,7 @@ def compact_line(out):
                 cc[name] = {"error": str(e.get("error"))[:160]}
                 continue
             cc[name] = {"value": _rnd(e["value"], 2), "unit": e["unit"], "ms_per_step": _rnd(e["ms_per_step"], 5), "steps": e["steps"], "inner_repeats": e["inner_repeats"],
-                        "scan_streams": e["scan_streams"], "workload": e["workload"].split(":")[0].split(";")[0], "roofline": compact_roofline(e["roofline"]),
+                        "scan_streams": e["scan_streams"], "results_in_flight": e.get("results_in_flight"), "workload": e["workload"].split(":")[0].split(";")[0], "roofline": compact_roofline(e["roofline"]),
                         "setup_s": (e.get("setup") or {}).get("build_flatten_upload_s")}
             if "cpu_baseline" in e:
                 cc[name]["cpu_baseline"] = compact_cpu(e["cpu_baseline"])
@@ -888,11 +908,16 @@ def main():
                                                       rank, world, strong)
     t_stage = time.perf_counter() - t0
     mode = acx.ACX_SCAN_ALL if args.mode == "iter" else acx.ACX_SCAN_LONG
-    P = max(1, args.pipeline)
-    global SCAN_STREAMS, MIN_TIMED_MS
+    global SCAN_STREAMS, MIN_TIMED_MS, LONG_DEPTH, ACX_LONG_MODE
+    # (iter_long: --long-depth results in flight on as many scan streams, unless --pipeline / --scan-streams say otherwise)
+    P = args.long_depth if (args.mode == "iter_long" and args.long_depth > 0 and "--pipeline" not in sys.argv) else max(1, args.pipeline)
+    LONG_DEPTH = args.long_depth if "--scan-streams" not in sys.argv else 0
+    ACX_LONG_MODE = acx.ACX_SCAN_LONG
     SCAN_STREAMS = max(1, args.scan_streams)
     MIN_TIMED_MS = max(0.0, args.min_timed_ms)
+    _progress("headline")
     m = measure(torch, dist, dev, image, batches, mode, args.steps, args.warmup, P, args.event_every, args.variant, args.inner_repeats)
+    _progress("headline measured")
     dt, bytes_rank, matches_rank = m["dt"], m["bytes_rank"], m["matches_rank"]
     passes = m["passes"]
     # what every rank saw for itself: throughput and step by its own clock (before the closing barrier), the dominant kernel by
@@ -975,6 +1000,7 @@ def main():
             # memory — acx_scan_host_ctx + acx_result_fetch_host, what Automaton.iter / find_all / iter_batch call.
             # Never `value`.  (On this box H2D and D2H do not overlap: profiles/r3_pcie_probe.txt.)
             import ctypes as C
+            _progress("host-to-host leg")
             res_e2e = C.c_void_p()
             hflat, hoff = e2e0
             best = None

@@ -119,7 +119,8 @@ def export_all(db, bench_path, out_prefix):
         if not mine:
             print("%s: no launches of %s" % (config, sig)); continue
         passes = int(ent.get("passes") or ent["steps"] * ent.get("inner_repeats", 1))
-        tail = UNION_LEG_LAUNCHES if len(mine) >= passes + UNION_LEG_LAUNCHES else 0
+        leg = 12 * int(ent.get("results_in_flight") or (ent.get("config") or {}).get("queues", {}).get("results_in_flight") or 3)      # (iter_long: --long-depth results in flight)
+        tail = leg if len(mine) >= passes + leg else 0
         timed = mine[-(passes + tail):len(mine) - tail] if len(mine) >= passes + tail else mine
         out = {
             "config": config, "kernel": ent["roofline"]["kernel"], "instantiation": sig, "launches_in_trace": len(mine), "timed_launches": len(timed),
