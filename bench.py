@@ -109,14 +109,15 @@ def parse():
                          "streams): with 2 x 2 the host queues scan k + 2 only when gather k has completed, and the union of the scan "
                          "kernel's launch spans covered 90 %% of the timed region (profiles/r5b_c2_spans.json: 239.8 of 267.3 us per "
                          "step); profiles/r5c_pipeline_sweep.txt: 2 x 2 565.7, 3 x 3 580.1, 4 x 2 536.3, 4 x 4 557.9, 6 x 2 567.4, 6 x 3 578.4 GB/s")
-    ap.add_argument("--long-depth", type=int, default=0,
+    ap.add_argument("--long-depth", type=int, default=6,
                     help="iter_long: result objects in flight AND scan streams (instead of --pipeline / --scan-streams).  A step of iter_long is a scan kernel and "
                          "four smaller ones behind it (gather, sweep, placement) that find CUs only in the tails of the scan kernels: with more batches in "
                          "flight the tails are fuller.  tools/r6_depth.sh (alone in its process): 3 -> 248.9, 4 -> 255.5, 5 -> 257.4, 6 -> 258.4 GB/s; the "
                          "headline and c2_offsets are best at 3 (629.8 / 529.7 against 529-564 / 491-500 at 4-6).  Behind the headline and the host-path legs "
                          "of the default command config 5 moves by +-4 %% from run to run at ANY depth (profiles/r6_line_runs.txt: 238-257; which hardware "
-                         "queues its streams share).  Default 0 = as --pipeline / --scan-streams: with 5 or 6 results in flight behind the headline TWO of "
-                         "fourteen default-command runs died of a GPU memory fault inside this configuration (none in dozens at 3; not found: DESIGN.md 8)")
+                         "queues its streams share); 6 has the best mean there as well (252 against 250 at 3).  0: as --pipeline / --scan-streams.  (With 5 "
+                         "or 6 results in flight two of fourteen default-command runs died of a GPU memory fault in this configuration before the gathers "
+                         "and the sweep were made safe against the records of a scan whose pool ran out: DESIGN.md 7, tools/r6_crash.sh — 0 of 40 since.)")
     ap.add_argument("--event-every", type=int, default=4,
                     help="bracket the dominant kernel by HIP events in every N-th timed step (0: in none).  Two event records cost "
                          "the stream about 19 us of idle time per step they are in (config 2: 442 GB/s with events in every step, "

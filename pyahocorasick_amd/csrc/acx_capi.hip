@@ -1274,6 +1274,7 @@ static int long_enqueue_sweep(acx_result* r, acx_image* img, hipStream_t g) {
         //  buffer — the kernels look at the scan's total first and leave; entry indices are checked against the dictionary's size)
         la.rec_capacity = (int64_t)in->matches.cap; la.n_real = img->long_n_real;
         la.gtot = nullptr;
+        la.scan_words = (in->ppm_stream && in->pend_ga.host_words && in->pend_ga.ctl) ? in->pend_ga.host_words : nullptr;   // (what the inner scan's gather reports: see acx_long_args)
         la.compact = (r->pend_params.variant >> 27) & 1;                  // (A/B and the multi-way tests: the compact form of round 5)
         if (r->timed) HIP_TRY(hipEventRecord(r->ev[2], g));
         if (!la.compact && !((r->pend_params.variant >> 29) & 1)) {

@@ -18,6 +18,8 @@ struct acx_long_args {
     // the host issues it again at completion): off[n_hay] > rec_capacity says so, and the kernels leave at once.
     int64_t rec_capacity;
     int32_t compact;               // 1: the sweep over compact records (round 5: a staging pass drops the U records; `variant` bit 27), 0: over the raw records in LDS
+    const long long* scan_words;   // nullable: the pinned words the scan's gather wrote (k_ppm_gather_pos: total, pool ran out, short haystack) — the kernels leave when
+                                   // a flag is set: the records of such a scan are whatever the pool's memory held, and the host scans again
     uint32_t* gtot;                // nullable, out (the raw sweep): records reported per group of 64 haystacks
     int64_t n_real;                // entries of the dictionary (an index beyond them — stale records — reports 0); fewer than 2^18: the values carry `below` (acx.h)
 };
@@ -37,6 +39,8 @@ struct acx_long_fuse_args {
     uint32_t* wave_base;           // out: where the packed reports of the scan's wave w start in gather_args.matches [n_waves]
     uint32_t* fail;                // out: counts the batches of 64 haystacks that held more records than a wave's LDS (the host then sweeps the gathered records instead)
     uint32_t longest;              // longest dictionary entry
+    const long long* scan_words;   // nullable: the pinned words the scan's gather wrote (k_ppm_gather_pos: total, pool ran out, short haystack) — the kernels leave when
+                                   // a flag is set: the records of such a scan are whatever the pool's memory held, and the host scans again
     uint32_t* gtot;                // nullable, out (the raw sweep): records reported per group of 64 haystacks
     int64_t n_real;                // entries of the dictionary
 };

@@ -188,6 +188,7 @@ __global__ void __launch_bounds__(64) k_long_sweep(const acx_long_args a) {
     const int32_t reach = (int32_t)a.longest - 1;
     const bool small = a.n_real < ((int64_t)1 << ACX_LONG_SMALL_BITS);
     if (a.off[a.n_hay] > a.rec_capacity) return;                       // (the scan in front is incomplete: see acx_long_args)
+    if (a.scan_words && (a.scan_words[1] | a.scan_words[2])) return;   // (... or its record pool ran out: its records are no records)
     for (int64_t g = (int64_t)blockIdx.x; g < n_groups; g += n_waves) {
         const int64_t h = g * 64 + lane;
         const bool valid = h < a.n_hay;
@@ -313,6 +314,7 @@ __global__ void __launch_bounds__(256) k_long_sweep_raw(const acx_long_args a) {
     const int32_t reach = (int32_t)a.longest - 1;
     const bool small = a.n_real < ((int64_t)1 << ACX_LONG_SMALL_BITS);
     if (a.off[a.n_hay] > a.rec_capacity) return;                       // (the scan in front is incomplete: see acx_long_args)
+    if (a.scan_words && (a.scan_words[1] | a.scan_words[2])) return;   // (... or its record pool ran out: its records are no records)
     for (int64_t g = (int64_t)blockIdx.x * 4 + wid; g < n_groups; g += n_waves) {
         const int64_t h = g * 64 + lane;
         const bool valid = h < a.n_hay;
@@ -389,6 +391,7 @@ __global__ void __launch_bounds__(256) k_long_place(const acx_long_args a, int64
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
     const int64_t n_hay = a.n_hay, n_groups = (n_hay + 63) / 64;
     if (a.off[n_hay] > a.rec_capacity) return;                         // (the scan in front is incomplete: see acx_long_args)
+    if (a.scan_words && (a.scan_words[1] | a.scan_words[2])) return;   // (... or its record pool ran out: its records are no records)
     const uint32_t n_real = (uint32_t)a.n_real;
     const int64_t g0 = (int64_t)blockIdx.x * LONG_PLACE_GROUPS;
     // the reports in front of the chunk
@@ -434,6 +437,7 @@ __global__ void __launch_bounds__(256) k_long_move(const acx_long_args a, const 
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
     const int64_t n_hay = a.n_hay, n_groups = (n_hay + 63) / 64, n_waves = (int64_t)gridDim.x * 4;
     if (a.off[n_hay] > a.rec_capacity) return;                         // (the scan in front is incomplete: see acx_long_args)
+    if (a.scan_words && (a.scan_words[1] | a.scan_words[2])) return;   // (... or its record pool ran out: its records are no records)
     const uint32_t n_real = (uint32_t)a.n_real;
     for (int64_t g = (int64_t)blockIdx.x * 4 + wid; g < n_groups; g += n_waves) {
         const int64_t h0 = g * 64, h1 = h0 + 64 < n_hay ? h0 + 64 : n_hay;

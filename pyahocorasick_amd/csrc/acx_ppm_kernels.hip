@@ -1265,6 +1265,7 @@ __global__ void __launch_bounds__(PPM_GPOS_THREADS) k_ppm_gather_pos(const acx_p
         u32x2* dst = (u32x2*)(c.matches + base);
         uint32_t li = 0;                                               // records of this wave in front of the current grant
         uint32_t q_last = (uint32_t)(hA - 1 - h0);                     // haystack (relative) of the last record so far; none: the one in front of the first start
+        const uint32_t q_max = (uint32_t)((hB > hA ? hB - 1 : hA - 1) - h0);     // the last haystack a record of this wave can belong to
         if (OFFS) {
             // One record per lane and trip.  The records of a wave are in position order, so the haystack of a record is at or behind that
             // of the record before it: the trip loads the 64 offsets from the haystack of the LAST trip's last record on (one coalesced load),
@@ -1306,6 +1307,7 @@ __global__ void __launch_bounds__(PPM_GPOS_THREADS) k_ppm_gather_pos(const acx_p
                         }
                     }
                     if (h > c.n_hay - 1) h = c.n_hay - 1;                 // (lanes beyond the grant's end)
+                    if (h > h0 + (int64_t)(int32_t)q_max) h = h0 + (int64_t)(int32_t)q_max;   // (records of a scan whose pool ran out: see emit)
                     const uint32_t q = (uint32_t)(h - h0);
                     uint32_t qp = (uint32_t)__shfl_up((int)q, 1, 64);
                     if (lane == 0) qp = q_last;
@@ -1331,13 +1333,16 @@ __global__ void __launch_bounds__(PPM_GPOS_THREADS) k_ppm_gather_pos(const acx_p
             u32x4* dst2 = (u32x4*)(dst + li + head);
             auto emit = [&](uint32_t k, u32x2 rec, uint32_t q_prev) -> u32x2 {      // record k of the grant; q_prev: haystack of the record before it
                 uint32_t idx;
-                const uint32_t q = locate(rec.x, idx);
+                uint32_t q = locate(rec.x, idx);
+                // (a wave's records belong to the haystacks up to the last one that starts in its run.  Records of a scan whose pool ran out are
+                //  whatever the pool's memory held — the host scans again, but this kernel has run by then: no record may send it outside match_off)
+                if ((int32_t)q > (int32_t)q_max) q = q_max;
                 for (uint32_t qq = q_prev + 1; (int32_t)(qq - q) <= 0; qq++) c.match_off[h0 + (int64_t)(int32_t)qq] = c.off_base + base + li + k;   // haystacks that start between the two records
                 u32x2 o; o.y = rec.y;
                 o.x = idx + (c.index_base ? (uint32_t)c.index_base[h0 + (int64_t)(int32_t)q] : 0u) - (c.skip ? (uint32_t)c.skip[h0 + (int64_t)(int32_t)q] : 0u);
                 return o;
             };
-            auto q_of = [&](uint32_t k) -> uint32_t { uint32_t t; return locate(src[k].x, t); };
+            auto q_of = [&](uint32_t k) -> uint32_t { uint32_t t; const uint32_t qv = locate(src[k].x, t); return (int32_t)qv > (int32_t)q_max ? q_max : qv; };
             if (head && threadIdx.x == 0) __builtin_nontemporal_store(emit(0, __builtin_nontemporal_load(src), q_last), dst + li);
             for (uint32_t k0 = 0; k0 < pairs; k0 += GT) {
                 const uint32_t k = k0 + threadIdx.x;
@@ -1348,7 +1353,8 @@ __global__ void __launch_bounds__(PPM_GPOS_THREADS) k_ppm_gather_pos(const acx_p
                     u32x2 r1; r1.x = v.z; r1.y = v.w;
                     const uint32_t qp = r ? q_of(r - 1) : q_last;      // (the neighbour's second record: an L2 hit)
                     uint32_t t0;
-                    const uint32_t q0 = locate(r0.x, t0);
+                    uint32_t q0 = locate(r0.x, t0);
+                    if ((int32_t)q0 > (int32_t)q_max) q0 = q_max;
                     const u32x2 o0 = emit(r, r0, qp), o1 = emit(r + 1, r1, q0);
                     u32x4 o; o.x = o0.x; o.y = o0.y; o.z = o1.x; o.w = o1.y;
                     __builtin_nontemporal_store(o, dst2 + k);
@@ -1419,6 +1425,7 @@ __global__ void __launch_bounds__(PPM_GPOS_THREADS) k_ppm_gather_pos_lean(const 
         uint2* const dst = c.matches + base;
         uint32_t li = 0;
         uint32_t q_last = (uint32_t)(hA - 1 - h0);
+        const uint32_t q_max = (uint32_t)((hB > hA ? hB - 1 : hA - 1) - h0);     // (no record may send the kernel outside match_off: see k_ppm_gather_pos)
         for (uint32_t g = 0; g < ng && fits; g++) {
             const uint2* src = c.scratch + d[2 + g];
             const uint32_t n = d[18 + g];
@@ -1427,9 +1434,11 @@ __global__ void __launch_bounds__(PPM_GPOS_THREADS) k_ppm_gather_pos_lean(const 
                 const uint32_t k = k0 + lane;
                 if (k < n) {
                     const uint2 rec = src[k];
-                    const uint32_t y = rec.x + bias, q = __umulhi(y, m32);
+                    const uint32_t y = rec.x + bias;
+                    uint32_t q = __umulhi(y, m32);
+                    if ((int32_t)q > (int32_t)q_max) q = q_max;
                     uint32_t qp = q_last;
-                    if (k) { const uint32_t yp = src[k - 1].x + bias; qp = __umulhi(yp, m32); }
+                    if (k) { const uint32_t yp = src[k - 1].x + bias; qp = __umulhi(yp, m32); if ((int32_t)qp > (int32_t)q_max) qp = q_max; }
                     for (uint32_t qq = qp + 1; (int32_t)(qq - q) <= 0; qq++) moff[(int32_t)qq] = obase + (int64_t)(li + k);     // haystacks that start between the two records
                     dst[li + k] = make_uint2(y - q * stride, rec.y);
                 }

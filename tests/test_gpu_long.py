@@ -241,3 +241,31 @@ def test_broadcast_image_with_the_long_pack_single_process(tmp_path):
     script.write_text(_BCAST_SCRIPT)
     p = subprocess.run([sys.executable, str(script), root], capture_output=True, text=True, timeout=600)
     assert p.returncode == 0 and "BCAST_LONG_OK" in p.stdout, (p.stdout[-2000:], p.stderr[-3000:])
+
+
+def test_a_scan_whose_pool_runs_out_leaves_nothing_for_the_sweep_to_trip_over():
+    """The first scan of a fresh result over a dense batch outgrows its record pool: the host notices at completion and scans again, but the
+    gather and the sweep of the first attempt have run by then — over whatever the pool's memory held.  In recycled device memory that is no
+    zeros (round 6: a process that had run the host path and freed other results died of a GPU memory fault here, one run in ten with five or
+    six results in flight).  The gathers keep every record's haystack inside the wave's range, the sweep leaves when the scan's flags say so
+    (acx_long_args.scan_words).  Here: device memory dirtied and freed, six fresh results in flight, twice; records against the oracle."""
+    keys, reads = dna_workload(100_000, 60_000, 150, seed=5)
+    A, O = build_pair(keys)
+    img = Image.from_automaton(A)
+    n, L = reads.shape
+    flat = np.ascontiguousarray(reads.reshape(-1))
+    d_hay = DeviceBuffer.from_numpy(flat, pad=64)
+    m = 2000
+    mo, oe, ov = O.batch(flat[: m * L].tobytes(), np.arange(m + 1, dtype=np.int64) * L, 1)
+    for attempt in range(2):
+        noise = np.random.default_rng(attempt).integers(0, 2**32, size=48 << 20, dtype=np.uint32)
+        junk = [DeviceBuffer.from_numpy(noise) for _ in range(6)]       # 1.2 GB of anything ...
+        for j in junk:
+            j.free()                                                   # ... back to the allocator: the results below get these pages
+        scs = [Scanner(img) for _ in range(6)]
+        for sc in scs:
+            sc.scan(d_hay, n * L, n, stride=L, mode=acx.ACX_SCAN_LONG, asynchronous=True)
+        for sc in scs:
+            moff, e, v, _ = sc.fetch()
+            assert np.array_equal(moff[: m + 1], mo) and np.array_equal(e[: mo[-1]], oe) and np.array_equal(v[: mo[-1]], ov)
+        del scs
