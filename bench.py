@@ -113,11 +113,10 @@ def parse():
                     help="iter_long: result objects in flight AND scan streams (instead of --pipeline / --scan-streams).  A step of iter_long is a scan kernel and "
                          "four smaller ones behind it (gather, sweep, placement) that find CUs only in the tails of the scan kernels: with more batches in "
                          "flight the tails are fuller.  tools/r6_depth.sh (alone in its process): 3 -> 248.9, 4 -> 255.5, 5 -> 257.4, 6 -> 258.4 GB/s; the "
-                         "headline and c2_offsets are best at 3 (629.8 / 529.7 against 529-564 / 491-500 at 4-6).  Behind the headline and the host-path legs "
-                         "of the default command config 5 moves by +-4 %% from run to run at ANY depth (profiles/r6_line_runs.txt: 238-257; which hardware "
-                         "queues its streams share); 6 has the best mean there as well (252 against 250 at 3).  0: as --pipeline / --scan-streams.  (With 5 "
-                         "or 6 results in flight two of fourteen default-command runs died of a GPU memory fault in this configuration before the gathers "
-                         "and the sweep were made safe against the records of a scan whose pool ran out: DESIGN.md 7, tools/r6_crash.sh — 0 of 40 since.)")
+                         "headline and c2_offsets are best at 3 (629.8 / 529.7 against 529-564 / 491-500 at 4-6).  Behind the headline: ten lines of the default "
+                         "command within 257.6-259.9 (profiles/r6_line_runs.txt).  0: as --pipeline / --scan-streams.  (Before the gathers and the sweep were "
+                         "made safe against the records of a scan whose pool ran out — DESIGN.md 7, tools/r6_crash.sh — config 5 moved by +-4 %% from run to "
+                         "run behind the headline, and with 5 or 6 results in flight one run in ten died of a GPU memory fault there.)")
     ap.add_argument("--event-every", type=int, default=4,
                     help="bracket the dominant kernel by HIP events in every N-th timed step (0: in none).  Two event records cost "
                          "the stream about 19 us of idle time per step they are in (config 2: 442 GB/s with events in every step, "
