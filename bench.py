@@ -116,7 +116,7 @@ def parse():
                          "headline and c2_offsets are best at 3 (629.8 / 529.7 against 529-564 / 491-500 at 4-6).  Behind the headline: ten lines of the default "
                          "command within 257.6-259.9 (profiles/r6_line_runs.txt).  0: as --pipeline / --scan-streams.  (Before the gathers and the sweep were "
                          "made safe against the records of a scan whose pool ran out — DESIGN.md 7, tools/r6_crash.sh — config 5 moved by +-4 %% from run to "
-                         "run behind the headline, and with 5 or 6 results in flight one run in ten died of a GPU memory fault there.)")
+                         "run behind the headline, and with 5 or 6 results in flight four runs of about a hundred died of a GPU memory fault there.)")
     ap.add_argument("--event-every", type=int, default=4,
                     help="bracket the dominant kernel by HIP events in every N-th timed step (0: in none).  Two event records cost "
                          "the stream about 19 us of idle time per step they are in (config 2: 442 GB/s with events in every step, "

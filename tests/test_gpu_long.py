@@ -246,7 +246,7 @@ def test_broadcast_image_with_the_long_pack_single_process(tmp_path):
 def test_a_scan_whose_pool_runs_out_leaves_nothing_for_the_sweep_to_trip_over():
     """The first scan of a fresh result over a dense batch outgrows its record pool: the host notices at completion and scans again, but the
     gather and the sweep of the first attempt have run by then — over whatever the pool's memory held.  In recycled device memory that is no
-    zeros (round 6: a process that had run the host path and freed other results died of a GPU memory fault here, one run in ten with five or
+    zeros (round 6: a process that had run the host path and freed other results died of a GPU memory fault here, four runs of about a hundred with five or
     six results in flight).  The gathers keep every record's haystack inside the wave's range, the sweep leaves when the scan's flags say so
     (acx_long_args.scan_words).  Here: every 4- and 5-letter word is a key (several records per position: the first scan of every result
     outgrows its pool by far), device memory dirtied and freed first, six fresh results in flight, twice; records against the oracle.
